@@ -1,0 +1,134 @@
+/*
+ * oracle_sampling.c -- CPU restatement of tf_ops/sampling (FPS, gather, scatter-add).
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: the reference has no CPU
+ * implementation and no test of these ops; this follows the CUDA kernel line by line.
+ */
+#include "oracle.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define FPS_BLOCK 512 /* tf_sampling_g.cu:108 BlockSize; launcher :204 uses 512 threads */
+
+/*
+ * Literal simulation of farthestpointsamplingKernel (tf_sampling_g.cu:105-170):
+ * 512 "threads", thread t scans k = t, t+512, ... with a strict '>' (:146), then the
+ * 9-level shared-memory tree keeps the LEFT slot on ties (:153-163).
+ *   - temp[] (running min distance) starts at 1e38 (:117-119)
+ *   - idxs[0] = 0 (:114-116); centre coordinates are read from the original cloud (:127-129)
+ *   - d = (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 in fp32, no FMA (:142); d2 = min(d,td) (:143)
+ *   - m <= 0: nothing written (:106-107)
+ */
+void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int *idxs)
+{
+    if (m <= 0) return;
+    float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    float dists[FPS_BLOCK];
+    int dists_i[FPS_BLOCK];
+    for (int i = 0; i < b; i++) {
+        const float *pts = dataset + (size_t)i * n * 3;
+        int old = 0;
+        idxs[(size_t)i * m + 0] = old;
+        for (int j = 0; j < n; j++) temp[j] = 1e38f;
+        for (int j = 1; j < m; j++) {
+            float x1 = pts[old * 3 + 0];
+            float y1 = pts[old * 3 + 1];
+            float z1 = pts[old * 3 + 2];
+            for (int t = 0; t < FPS_BLOCK; t++) {
+                int besti = 0;
+                float best = -1;
+                for (int k = t; k < n; k += FPS_BLOCK) {
+                    float td = temp[k];
+                    float x2 = pts[k * 3 + 0];
+                    float y2 = pts[k * 3 + 1];
+                    float z2 = pts[k * 3 + 2];
+                    float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+                    float d2 = (d < td) ? d : td; /* CUDA min(float,float) == fminf */
+                    if (d2 != td) temp[k] = d2;
+                    if (d2 > best) {
+                        best = d2;
+                        besti = k;
+                    }
+                }
+                dists[t] = best;
+                dists_i[t] = besti;
+            }
+            for (int u = 0; (1 << u) < FPS_BLOCK; u++) {
+                for (int t = 0; t < (FPS_BLOCK >> (u + 1)); t++) {
+                    int i1 = (t * 2) << u;
+                    int i2 = (t * 2 + 1) << u;
+                    if (dists[i1] < dists[i2]) {
+                        dists[i1] = dists[i2];
+                        dists_i[i1] = dists_i[i2];
+                    }
+                }
+            }
+            old = dists_i[0];
+            idxs[(size_t)i * m + j] = old;
+        }
+    }
+    free(temp);
+}
+
+/*
+ * Closed form of the same selection rule: winner = max d2; ties -> smallest (k mod 512),
+ * then smallest k.  Lanes with no point (t >= n) hold (best=-1, besti=0) and can only
+ * win when every real d2 is < -1, i.e. never for finite input.
+ */
+void oracle_farthest_point_sample_closed(int b, int n, int m, const float *dataset, int *idxs)
+{
+    if (m <= 0) return;
+    float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+    for (int i = 0; i < b; i++) {
+        const float *pts = dataset + (size_t)i * n * 3;
+        int old = 0;
+        idxs[(size_t)i * m + 0] = old;
+        for (int j = 0; j < n; j++) temp[j] = 1e38f;
+        for (int j = 1; j < m; j++) {
+            float x1 = pts[old * 3 + 0], y1 = pts[old * 3 + 1], z1 = pts[old * 3 + 2];
+            float best = -1;
+            int besti = 0;
+            int bestlane = 0;
+            for (int k = 0; k < n; k++) {
+                float x2 = pts[k * 3 + 0], y2 = pts[k * 3 + 1], z2 = pts[k * 3 + 2];
+                float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1);
+                float td = temp[k];
+                float d2 = (d < td) ? d : td;
+                temp[k] = d2;
+                int lane = k % FPS_BLOCK;
+                if (d2 > best || (d2 == best && lane < bestlane)) {
+                    best = d2;
+                    besti = k;
+                    bestlane = lane;
+                }
+            }
+            old = besti;
+            idxs[(size_t)i * m + j] = old;
+        }
+    }
+    free(temp);
+}
+
+/* gatherpointKernel, tf_sampling_g.cu:172-181 */
+void oracle_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out)
+{
+    for (int i = 0; i < b; i++)
+        for (int j = 0; j < m; j++) {
+            int a = idx[(size_t)i * m + j];
+            out[((size_t)i * m + j) * 3 + 0] = inp[((size_t)i * n + a) * 3 + 0];
+            out[((size_t)i * m + j) * 3 + 1] = inp[((size_t)i * n + a) * 3 + 1];
+            out[((size_t)i * m + j) * 3 + 2] = inp[((size_t)i * n + a) * 3 + 2];
+        }
+}
+
+/* scatteraddpointKernel, tf_sampling_g.cu:183-192.  The reference adds with atomics
+ * (order unspecified); the oracle adds in ascending j. */
+void oracle_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g)
+{
+    for (int i = 0; i < b; i++)
+        for (int j = 0; j < m; j++) {
+            int a = idx[(size_t)i * m + j];
+            inp_g[((size_t)i * n + a) * 3 + 0] += out_g[((size_t)i * m + j) * 3 + 0];
+            inp_g[((size_t)i * n + a) * 3 + 1] += out_g[((size_t)i * m + j) * 3 + 1];
+            inp_g[((size_t)i * n + a) * 3 + 2] += out_g[((size_t)i * m + j) * 3 + 2];
+        }
+}
