@@ -1,0 +1,181 @@
+/*
+ * votenet_hip.h -- C ABI of libvotenet_hip.so: the MI355X (gfx950) implementation of the
+ * VoteNet / PointNet++ point-cloud hot path.
+ *
+ * Boundary.  The reference (qq456cvb/VoteNet) puts this path behind a "launcher seam": free
+ * functions declared in tf_ops/<op>/tf_<op>.cpp and defined in tf_<op>_g.cu (GPU ops) or in
+ * the same .cpp (CPU ops).  Each entry point below replaces one of them; the citation says
+ * which.  Differences from the reference seam, all deliberate:
+ *   - extern "C", plain pointers and sizes, no TensorFlow / torch types;
+ *   - every pointer is DEVICE memory (the reference's interpolate / NMS ops take host
+ *     memory and force a device<->host round trip every step);
+ *   - an explicit stream (a hipStream_t passed as void*; NULL = the null stream) -- the
+ *     reference launches on the legacy default stream (tf_sampling_g.cu:204);
+ *   - an int status (0 = ok, VOTENET_E_* otherwise; text via votenet_last_error()) -- the
+ *     reference launchers return void and never check an error.  Argument validation
+ *     mirrors the OP_REQUIRES checks of the TF wrappers (cited per function).
+ * Ownership is the reference's: the caller owns every buffer, launchers never allocate,
+ * gradient buffers must be zeroed by the caller (tf_sampling.cpp:174, tf_grouping.cpp:204,
+ * tf_interpolate.cpp:258).  All tensors are dense, row-major, fp32 / int32.
+ * Calls are asynchronous with respect to the host and stateless (re-entrant).
+ *
+ * libvotenet_hip.so additionally exports the reference's launcher names with their exact
+ * C++ signatures (farthestpointsamplingLauncher, gatherpointLauncher, scatteraddpointLauncher,
+ * queryBallPointLauncher, groupPointLauncher, groupPointGradLauncher), so tf_sampling.cpp /
+ * tf_grouping.cpp link against it unchanged in place of tf_*_g.cu.o -- see INTEGRATION.md.
+ */
+#ifndef VOTENET_HIP_H
+#define VOTENET_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VOTENET_OK 0
+#define VOTENET_E_INVALID_ARGUMENT 1 /* the reference's errors::InvalidArgument */
+#define VOTENET_E_HIP 2              /* a HIP runtime / launch error (hipGetLastError) */
+#define VOTENET_E_WORKSPACE 3        /* caller-provided workspace too small */
+
+/* Text of the last error raised on the calling thread ("" if none). */
+const char *votenet_last_error(void);
+/* Library / build identification, e.g. "votenet_hip 0.1 gfx950". */
+const char *votenet_version(void);
+
+/* ---------------------------------------------------------------- tf_ops/sampling */
+
+/* Replaces farthestpointsamplingLauncher (decl tf_sampling.cpp:94, def tf_sampling_g.cu:203-205,
+ * kernel :105-170).  inp (b,n,3) -> out (b,m) int32.  temp: scratch of at least
+ * votenet_fps_temp_floats(b,n) floats (the reference allocates 32*n, tf_sampling.cpp:115);
+ * may be NULL when that function returns 0.  Requires m > 0 (tf_sampling.cpp:99).
+ * Bit-exact with the reference rule: start at 0, running distance 1e38, arg-max of
+ * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
+int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
+size_t votenet_fps_temp_floats(int b, int n);
+
+/* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:172-181,206-208).
+ * inp (b,n,3), idx (b,m) -> out (b,m,3). */
+int votenet_gather_point(int b, int n, int m, const float *inp, const int *idx, float *out, void *stream);
+
+/* Replaces scatteraddpointLauncher (tf_sampling.cpp:150, tf_sampling_g.cu:183-192,209-211).
+ * out_g (b,m,3), idx (b,m) -> inp_g (b,n,3) += ; inp_g pre-zeroed by the caller. */
+int votenet_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g, void *stream);
+
+/* ---------------------------------------------------------------- tf_ops/grouping */
+
+/* Replaces queryBallPointLauncher (tf_grouping.cpp:66, tf_grouping_g.cu:3-36,125-128).
+ * xyz1 (b,n,3) candidates, xyz2 (b,m,3) queries -> idx (b,m,nsample), pts_cnt (b,m).
+ * First nsample candidates in ascending index with max(sqrtf(d2),1e-20f) < radius, remaining
+ * slots = first hit; a query with no hit gets idx row 0 and pts_cnt 0 (the reference leaves
+ * the row uninitialised).  Requires radius > 0, nsample > 0 (tf_grouping.cpp:71,74). */
+int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                             const float *xyz2, int *idx, int *pts_cnt, void *stream);
+
+/* Host helper (no GPU work): the squared-distance threshold the ball-query kernel compares
+ * against, T(r) = smallest fp32 with sqrtf(T) >= r, so that  s < T(r)  <=>  sqrtf(s) < r
+ * (tf_grouping_g.cu:24-25).  Not equal to r*r in general. */
+float votenet_ball_threshold(float radius);
+
+/* Replaces groupPointLauncher (tf_grouping.cpp:142, tf_grouping_g.cu:40-57,133-136).
+ * points (b,n,c), idx (b,m,nsample) -> out (b,m,nsample,c). */
+int votenet_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                        float *out, void *stream);
+
+/* Replaces groupPointGradLauncher (tf_grouping.cpp:173, tf_grouping_g.cu:61-78,137-141).
+ * grad_out (b,m,nsample,c), idx -> grad_points (b,n,c) += ; pre-zeroed by the caller. */
+int votenet_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                             float *grad_points, void *stream);
+
+/* ---------------------------------------------------------------- tf_ops/3d_interpolation */
+
+/* Replaces threenn_cpu (tf_interpolate.cpp:60-103).  xyz1 (b,n,3) unknown, xyz2 (b,m,3) known
+ * -> dist (b,n,3) SQUARED distances, idx (b,n,3); ties keep the lower index first; fewer
+ * than three known points -> (inf, 0). */
+int votenet_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                     void *stream);
+
+/* Replaces the four TF elementwise ops of utils.py:279-282: d=max(d,1e-10),
+ * w_i=(1/d_i)/((1/d_1+1/d_2)+1/d_3).  dist (b,n,3) -> weight (b,n,3). */
+int votenet_three_nn_weights(int b, int n, const float *dist, float *weight, void *stream);
+
+/* Replaces threeinterpolate_cpu (tf_interpolate.cpp:107-127).  points (b,m,c), idx/weight
+ * (b,n,3) -> out (b,n,c) = (p1*w1 + p2*w2) + p3*w3. */
+int votenet_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                              const float *weight, float *out, void *stream);
+
+/* Replaces threeinterpolate_grad_cpu (tf_interpolate.cpp:131-153).  grad_out (b,n,c) ->
+ * grad_points (b,m,c) += ; pre-zeroed by the caller. */
+int votenet_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                   const float *weight, float *grad_points, void *stream);
+
+/* ---------------------------------------------------------------- tf_ops/3d_nms */
+
+/* 3D IoU of every ordered pair of boxes of a scene (tf_nms3d.cpp:43-192, evaluated lazily
+ * pair by pair there).  bboxes (b,n,8,3) corner boxes in the order of model.py:108-110 ->
+ * iou (b,n,n), iou[s,i,j] = IoU(box i, box j) with box i as the reference's first argument. */
+int votenet_iou3d_matrix(int b, int n, const float *bboxes, float *iou, void *stream);
+
+/* Replaces NonMaxSuppression3DOp::Compute / DoNonMaxSuppressionOp (tf_nms3d.cpp:202-308).
+ * bboxes (b,n,8,3), scores (b,n), objectiveness (b,n,2), 0 <= iou_threshold <= 1
+ * (tf_nms3d.cpp:300) -> out (capacity b*n rows of [batch, box], int32) in descending-score
+ * visit order over the whole batch, *out_count (device int) = rows written.  The output
+ * length is data dependent, hence caller-provided capacity + device-side count.
+ * workspace: votenet_nms3d_workspace_bytes(b,n) bytes of device scratch.
+ * Equal scores are visited in ascending flat index (the reference's heap order for ties is
+ * unspecified). */
+int votenet_nms3d(int b, int n, const float *bboxes, const float *scores, const float *objectiveness,
+                  float iou_threshold, int *out, int *out_count, void *workspace, size_t workspace_bytes,
+                  void *stream);
+size_t votenet_nms3d_workspace_bytes(int b, int n);
+
+/* ---------------------------------------------------------------- grouped-point MLP
+ * (utils.py:50-57,125-132,149-155,286-293; the reference runs it as Tensorpack Conv2D 1x1 +
+ * BNReLU graph nodes on a materialised (B,m,K,3+C) tensor).  fp32 in / fp32 accumulate on
+ * v_mfma_f32_32x32x2_f32.  Row r of the implicit input matrix is either
+ *   GATHER : [xyz[idx[r]] - new_xyz[r / nsample] (3), feat[idx[r]] (c)]      (sample_and_group)
+ *   DENSE  : x[r, :] optionally passed through y = max(0, x*scale + shift)    (BNReLU of the
+ *            previous layer folded into the load)
+ * and the output is z = row * W + bias, plus per-channel sum / sum of squares of z
+ * (the BatchNorm batch statistics of this layer) accumulated into stats[2*cout].
+ */
+typedef struct votenet_mlp_input {
+    /* DENSE source (rows x cin); NULL for GATHER */
+    const float *x;
+    const float *in_scale; /* cin, or NULL: no affine+relu on load */
+    const float *in_shift; /* cin */
+    int in_relu;           /* apply max(0,.) after the affine */
+    /* GATHER source */
+    const float *xyz;     /* (b,n,3) */
+    const float *new_xyz; /* (b,m,3) */
+    const float *feat;    /* (b,n,c) or NULL */
+    const int *idx;       /* (b,m,nsample) */
+    int b, n, m, nsample, c;
+} votenet_mlp_input;
+
+/* z (rows x cout) = input(rows x cin) * w (cin x cout, row-major) + bias (cout, may be NULL).
+ * stats: 2*cout floats, [0,cout) += column sums of z, [cout,2cout) += column sums of z*z;
+ * pre-zeroed by the caller; may be NULL.  rows = b*m*nsample for GATHER. */
+int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
+                       const float *bias, float *z, float *stats, void *stream);
+
+/* BatchNorm scale/shift from accumulated statistics: mean = sum/rows, var = sumsq/rows - mean^2
+ * (biased), scale = gamma*rsqrt(var+eps), shift = beta - mean*scale.  Also writes mean and
+ * var (each may be NULL). */
+int votenet_bn_finalize(long rows, int c, const float *stats, const float *gamma, const float *beta, float eps,
+                        float *scale, float *shift, float *mean, float *var, void *stream);
+
+/* out (groups x c) = max over the k rows of each group of max(0?, z*scale+shift);
+ * argmax (groups x c, int32 row offset inside the group, may be NULL) for the backward pass. */
+int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *scale, const float *shift,
+                        int relu, float *out, int *argmax, void *stream);
+
+/* y = max(0?, z*scale+shift) materialised (rows x c); used where the next consumer is not a
+ * votenet_mlp_linear (e.g. the FP-layer output that feeds the voting head). */
+int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,
+                    void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VOTENET_HIP_H */

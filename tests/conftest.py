@@ -1,0 +1,47 @@
+"""pytest configuration: the `gpu` marker, import paths, and the shared oracle / library fixtures."""
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    """The CPU oracle (checker).  Built on demand."""
+    from oracle import oracle as orc
+    orc.lib()
+    return orc
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import numpy as np
+
+    def load(name):
+        return np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+    return load
+
+
+@pytest.fixture(scope="session")
+def hiplib():
+    """The product library; built on demand (hipcc cross-compiles without a GPU)."""
+    import votenet_amd
+    from votenet_amd import _lib
+    if not os.path.exists(_lib.lib_path()):
+        votenet_amd.build()
+    return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "gpu-marked test run without a GPU"
+    return torch.device("cuda:0")

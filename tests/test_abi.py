@@ -1,0 +1,96 @@
+"""CPU: the C-ABI library loads, exports every symbol include/votenet_hip.h declares (and the
+reference's own launcher names), and validates arguments like the reference's OP_REQUIRES checks.
+No compute is launched here (no GPU)."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "votenet_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(votenet_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_path():
+    syms = declared_symbols()
+    for must in ["votenet_farthest_point_sample", "votenet_gather_point", "votenet_gather_point_grad",
+                 "votenet_query_ball_point", "votenet_group_point", "votenet_group_point_grad", "votenet_three_nn",
+                 "votenet_three_interpolate", "votenet_three_interpolate_grad", "votenet_nms3d", "votenet_mlp_linear"]:
+        assert must in syms
+
+
+def test_library_exports_every_declared_symbol(hiplib):
+    for name in declared_symbols():
+        assert hasattr(hiplib, name), "libvotenet_hip.so does not export %s" % name
+
+
+def test_library_exports_reference_launcher_names(hiplib):
+    """tf_sampling.cpp:94,125,150 and tf_grouping.cpp:66,142,173 declare these (C++ linkage)."""
+    from votenet_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.lib_path()], capture_output=True, text=True).stdout
+    for sig in ["farthestpointsamplingLauncher(int, int, int, float const*, float*, int*)",
+                "gatherpointLauncher(int, int, int, float const*, int const*, float*)",
+                "scatteraddpointLauncher(int, int, int, float const*, int const*, float*)",
+                "queryBallPointLauncher(int, int, int, float, int, float const*, float const*, int*, int*)",
+                "groupPointLauncher(int, int, int, int, int, float const*, int const*, float*)",
+                "groupPointGradLauncher(int, int, int, int, int, float const*, int const*, float*)"]:
+        assert sig in out, sig
+
+
+def test_version_and_error_text(hiplib):
+    assert b"gfx950" in hiplib.votenet_version()
+    rc = hiplib.votenet_farthest_point_sample(1, 10, 0, None, None, None, None)
+    assert rc == 1  # VOTENET_E_INVALID_ARGUMENT
+    assert b"positive npoint" in hiplib.votenet_last_error()  # tf_sampling.cpp:99
+
+
+def test_argument_validation_mirrors_op_requires(hiplib):
+    f = ctypes.c_float
+    assert hiplib.votenet_query_ball_point(1, 8, 4, f(0.0), 4, None, None, None, None, None) == 1
+    assert b"positive radius" in hiplib.votenet_last_error()  # tf_grouping.cpp:71
+    assert hiplib.votenet_query_ball_point(1, 8, 4, f(0.1), 0, None, None, None, None, None) == 1
+    assert b"positive nsample" in hiplib.votenet_last_error()  # tf_grouping.cpp:74
+    assert hiplib.votenet_nms3d(1, 4, None, None, None, f(1.5), None, ctypes.c_void_p(8), None, 0, None) == 1
+    assert b"iou_threshold must be in [0, 1]" in hiplib.votenet_last_error()  # tf_nms3d.cpp:300
+    # empty problems are accepted without touching the device
+    assert hiplib.votenet_gather_point(0, 8, 4, None, None, None, None) == 0
+    assert hiplib.votenet_group_point(2, 8, 3, 0, 4, None, None, None, None) == 0
+    assert hiplib.votenet_three_nn(0, 0, 0, None, None, None, None, None) == 0
+
+
+def test_ball_threshold_table(hiplib):
+    """T(r) = smallest fp32 with sqrtf(T) >= r; differs from r*r for most radii."""
+    table = {0.2: 0.03999999910593033, 0.4: 0.1599999964237213, 0.8: 0.6399999856948853, 1.2: 1.440000057220459,
+             0.3: 0.09000000357627869, 0.1: 0.009999999776482582}
+    for r, t in table.items():
+        got = hiplib.votenet_ball_threshold(ctypes.c_float(np.float32(r)))
+        assert np.float32(got) == np.float32(t), (r, got, t)
+        r32 = np.float32(r)
+        assert np.sqrt(np.float32(got), dtype=np.float32) >= r32
+        assert np.sqrt(np.nextafter(np.float32(got), np.float32(0)), dtype=np.float32) < r32
+
+
+def test_workspace_queries(hiplib):
+    assert hiplib.votenet_fps_temp_floats(8, 20480) == 0          # register-resident
+    assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * 80000  # streaming fallback
+    assert hiplib.votenet_fps_temp_floats(64, 80000) == 32 * 80000
+    assert hiplib.votenet_nms3d_workspace_bytes(8, 256) >= 8 * 256 * 256 * 4
+
+
+def test_no_cpu_fallback_in_python_ops(hiplib):
+    import torch
+    from votenet_amd import VotenetError, tf_grouping, tf_interpolate, tf_sampling
+    x = torch.zeros(1, 16, 3)
+    with pytest.raises(VotenetError):
+        tf_sampling.farthest_point_sample(4, x)
+    with pytest.raises(VotenetError):
+        tf_grouping.query_ball_point(0.1, 4, x, x)
+    with pytest.raises(VotenetError):
+        tf_interpolate.three_nn(x, x)

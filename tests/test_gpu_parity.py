@@ -1,0 +1,294 @@
+"""GPU: the HIP path, called through the C ABI (votenet_amd.tf_* -> libvotenet_hip.so), against
+the CPU oracle on the same seeded inputs and against the committed golden vectors.
+Bar: bit-exact for indices / counts / pure copies; 1e-5 for floating-point sums."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+
+pytestmark = pytest.mark.gpu
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def ops(hiplib):
+    from votenet_amd import tf_grouping, tf_interpolate, tf_nms3d, tf_sampling
+
+    class Ops:
+        pass
+    o = Ops()
+    o.s, o.g, o.i, o.n = tf_sampling, tf_grouping, tf_interpolate, tf_nms3d
+    return o
+
+
+# ------------------------------------------------------------------ FPS
+def test_fps_golden_cases(ops, dev, golden):
+    g = golden("fps_cases")
+    for name, (xyz, m) in cases.fps_cases().items():
+        got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
+        assert got.dtype == np.int32 and (got == g[name]).all(), name
+
+
+@pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 64, 64), (3, 511, 77), (2, 512, 128), (2, 513, 128), (1, 1024, 256),
+                                   (2, 2048, 1024), (1, 2049, 100), (1, 4096, 512), (1, 8192, 300), (1, 12288, 200),
+                                   (1, 16384, 200), (2, 20480, 300), (1, 24576, 150), (1, 24577, 60), (1, 40000, 40)])
+def test_fps_vs_oracle(ops, dev, O, b, n, m):
+    xyz = np.random.default_rng(n * 7 + m).random((b, n, 3), dtype=np.float32) * 5
+    got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
+    assert (got == O.farthest_point_sample(m, xyz)).all()
+
+
+def test_fps_exact_ties_vs_oracle(ops, dev, O):
+    rng = np.random.default_rng(5)
+    for n, m in [(700, 300), (3000, 500), (20000, 200)]:
+        xyz = np.round(rng.random((2, n, 3), dtype=np.float32) * 6) / 2  # coarse lattice: many equal distances, duplicates
+        got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
+        assert (got == O.farthest_point_sample(m, xyz)).all(), (n, m)
+
+
+def test_fps_full_size_properties(ops, dev):
+    """BASELINE config 2 size (8 x 20480 -> 2048): size-independent properties, checked on the device."""
+    xyz = T(np.random.default_rng(0).random((8, 20480, 3), dtype=np.float32) * 5, dev)
+    idx = ops.s.farthest_point_sample(2048, xyz).long()
+    assert (idx[:, 0] == 0).all()
+    assert all(len(torch.unique(idx[s])) == 2048 for s in range(8))
+    # idempotence of the prefix: FPS(512) is the first 512 picks of FPS(2048)
+    assert (ops.s.farthest_point_sample(512, xyz).long() == idx[:, :512]).all()
+    # each pick attains the maximum of the running min distance (fp64 recomputation, relative slack)
+    s = 3
+    p = xyz[s].double()
+    td = torch.full((20480,), float("inf"), dtype=torch.float64, device=dev)
+    for j in range(1, 300):
+        td = torch.minimum(td, ((p - p[idx[s, j - 1]]) ** 2).sum(1))
+        assert td[idx[s, j]] >= td.max() * (1 - 1e-5)
+
+
+# ------------------------------------------------------------------ gather
+def test_gather_point_and_grad(ops, dev, O):
+    rng = np.random.default_rng(3)
+    xyz = rng.random((3, 500, 3), dtype=np.float32)
+    idx = rng.integers(0, 500, (3, 120)).astype(np.int32)
+    idx[0, :10] = 7  # repeated index: the gradient sums
+    x = T(xyz, dev).requires_grad_(True)
+    out = ops.s.gather_point(x, T(idx, dev))
+    assert (N(out) == O.gather_point(xyz, idx)).all()
+    go = rng.random((3, 120, 3), dtype=np.float32)
+    out.backward(T(go, dev))
+    assert np.allclose(N(x.grad), O.gather_point_grad(xyz, idx, go), rtol=1e-5, atol=1e-6)
+
+
+# ------------------------------------------------------------------ ball query / group
+def test_cfg1_golden(ops, dev, golden):
+    g = golden("cfg1")
+    xyz = cases.cfg1_cloud()
+    x = T(xyz, dev)
+    fidx = ops.s.farthest_point_sample(512, x)
+    assert (N(fidx) == g["fps_idx"]).all()
+    new_xyz = ops.s.gather_point(x, fidx)
+    idx, cnt = ops.g.query_ball_point(0.2, 32, x, new_xyz)
+    assert (N(idx) == g["idx"]).all() and (N(cnt) == g["pts_cnt"]).all()
+    assert sha(N(ops.g.group_point(x, idx))) == str(g["grouped_xyz_sha"])
+
+
+def test_grouping_reference_test_shape_golden(ops, dev, golden):
+    c, g = cases.grouping_optest(), golden("grouping_optest")
+    idx, cnt = ops.g.query_ball_point(c["radius"], c["nsample"], T(c["xyz1"], dev), T(c["xyz2"], dev))
+    assert (N(idx) == g["idx"]).all() and (N(cnt) == g["pts_cnt"]).all()
+    pts = T(c["points"], dev).requires_grad_(True)
+    out = ops.g.group_point(pts, idx)
+    assert (N(out) == g["out"]).all()
+    out.backward(T(c["grad_out"], dev))
+    assert np.allclose(N(pts.grad), g["grad"], rtol=1e-5, atol=1e-6)
+
+
+def test_grouping_demo_golden(ops, dev, golden):
+    c, g = cases.grouping_demo(), golden("grouping_demo")
+    idx, cnt = ops.g.query_ball_point(c["radius"], c["nsample"], T(c["xyz1"], dev), T(c["xyz2"], dev))
+    assert sha(N(idx)) == str(g["idx_sha"]) and (N(cnt) == g["pts_cnt"]).all()
+    assert sha(N(ops.g.group_point(T(c["points"], dev), idx))) == str(g["out_sha"])
+
+
+@pytest.mark.parametrize("b,n,m,r,k", [(1, 1, 1, 0.5, 4), (2, 63, 5, 0.3, 8), (2, 700, 90, 0.2, 16), (1, 2048, 512, 0.2, 32),
+                                       (3, 513, 64, 0.4, 64), (1, 100, 7, 0.05, 8), (2, 64, 64, 2.0, 5), (1, 2049, 65, 0.1, 100),
+                                       (1, 4097, 130, 0.25, 64), (2, 20480, 256, 0.04, 64), (1, 9000, 64, 0.3, 64)])
+def test_ball_query_vs_oracle(ops, dev, O, b, n, m, r, k):
+    rng = np.random.default_rng(n + m)
+    xyz1 = rng.random((b, n, 3), dtype=np.float32)
+    xyz2 = rng.random((b, m, 3), dtype=np.float32)
+    idx, cnt = ops.g.query_ball_point(r, k, T(xyz1, dev), T(xyz2, dev))
+    oi, oc = O.query_ball_point(r, k, xyz1, xyz2)
+    assert (N(cnt) == oc).all()
+    assert (N(idx) == oi).all()  # includes all-zero rows for queries with no neighbour
+
+
+def test_ball_query_boundary_radius(ops, dev, O):
+    """Pairs at distance exactly r, one ulp below, one ulp above: sqrtf(s) < r must be decided as the reference does."""
+    for r in [0.2, 0.4, 0.8, 1.2, 0.3, 0.1]:
+        r32 = np.float32(r)
+        q = np.zeros((1, 1, 3), np.float32)
+        xs = [r32, np.nextafter(r32, np.float32(0)), np.nextafter(r32, np.float32(9)), r32 * np.float32(0.5)]
+        xyz1 = np.zeros((1, 64, 3), np.float32)
+        for t, x in enumerate(xs):
+            xyz1[0, t * 3, 0] = x
+            xyz1[0, t * 3 + 1, 1] = x
+            xyz1[0, t * 3 + 2, :] = x / np.sqrt(np.float32(3))
+        xyz1[0, 12:] = 9.0
+        idx, cnt = ops.g.query_ball_point(r, 16, T(xyz1, dev), T(q, dev))
+        oi, oc = O.query_ball_point(r, 16, xyz1, q)
+        assert (N(idx) == oi).all() and (N(cnt) == oc).all(), r
+
+
+def test_sa1_full_size_ball_query_properties(ops, dev):
+    """sa1 size (8 x 20480 candidates, 2048 queries, r=0.2, K=64) checked through properties on the device."""
+    xyz = T(np.random.default_rng(1).random((8, 20480, 3), dtype=np.float32) * 5, dev)
+    fidx = ops.s.farthest_point_sample(2048, xyz)
+    new_xyz = ops.s.gather_point(xyz, fidx)
+    idx, cnt = ops.g.query_ball_point(0.2, 64, xyz, new_xyz)
+    assert (cnt >= 1).all() and (cnt <= 64).all()
+    li = idx.long()
+    g = torch.gather(xyz.unsqueeze(1).expand(-1, 2048, -1, -1), 2, li.unsqueeze(-1).expand(-1, -1, -1, 3))
+    d = (g - new_xyz.unsqueeze(2)).norm(dim=-1)
+    assert (d < 0.2 + 1e-5).all()  # every listed neighbour is inside the ball
+    valid = torch.arange(64, device=dev)[None, None, :] < cnt.unsqueeze(-1)
+    inc = (li[..., 1:] > li[..., :-1]) | ~valid[..., 1:]
+    assert inc.all()  # ascending candidate order within the valid prefix
+    assert ((li == li[..., :1]) | valid).all()  # padding repeats the first hit
+    # count == min(K, true neighbour count) on a sample of queries (fp64 recount with a safety band)
+    for s, j in [(0, 0), (3, 100), (7, 2047)]:
+        dd = (xyz[s].double() - new_xyz[s, j].double()).norm(dim=-1)
+        lo, hi = int((dd < 0.2 - 1e-5).sum()), int((dd < 0.2 + 1e-5).sum())
+        assert min(lo, 64) <= int(cnt[s, j]) <= min(hi, 64)
+
+
+@pytest.mark.parametrize("c", [1, 3, 4, 16, 67, 128])
+def test_group_point_and_grad(ops, dev, O, c):
+    rng = np.random.default_rng(c)
+    pts = rng.random((2, 300, c), dtype=np.float32)
+    idx = rng.integers(0, 300, (2, 40, 16)).astype(np.int32)
+    p = T(pts, dev).requires_grad_(True)
+    out = ops.g.group_point(p, T(idx, dev))
+    assert (N(out) == O.group_point(pts, idx)).all()
+    go = rng.random((2, 40, 16, c), dtype=np.float32)
+    out.backward(T(go, dev))
+    assert np.allclose(N(p.grad), O.group_point_grad(pts, idx, go), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ three_nn / interpolate
+def test_interpolate_reference_test_shape_golden(ops, dev, golden):
+    c, g = cases.interpolate_optest(), golden("interpolate_optest")
+    dist, idx = ops.i.three_nn(T(c["xyz1"], dev), T(c["xyz2"], dev))
+    assert (N(dist) == g["dist"]).all() and (N(idx) == g["idx"]).all()
+    w = torch.ones_like(dist) / 3.0
+    pts = T(c["points"], dev).requires_grad_(True)
+    out = ops.i.three_interpolate(pts, idx, w)
+    assert np.allclose(N(out), g["out"], rtol=1e-6, atol=1e-7)
+    assert (N(out) == g["out"]).all()  # same un-fused evaluation order -> bit-exact
+    out.backward(T(c["grad_out"], dev))
+    assert np.allclose(N(pts.grad), g["grad"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(N(ops.i.three_nn_weights(dist)), g["weights_idw"], rtol=1e-6, atol=0)
+
+
+def test_interpolate_demo_golden(ops, dev, golden):
+    c, g = cases.interpolate_demo(), golden("interpolate_demo")
+    dist, idx = ops.i.three_nn(T(c["xyz1"], dev), T(c["xyz2"], dev))
+    assert sha(N(dist)) == str(g["dist_sha"]) and sha(N(idx)) == str(g["idx_sha"])
+    out = ops.i.three_interpolate(T(c["points"], dev), idx, torch.ones_like(dist) / 3.0)
+    assert sha(N(out)) == str(g["out_sha"])
+
+
+@pytest.mark.parametrize("b,n,m,c", [(2, 300, 40, 8), (1, 1024, 512, 256), (1, 50, 2, 4), (1, 50, 1, 5), (8, 512, 256, 256)])
+def test_three_nn_interpolate_vs_oracle(ops, dev, O, b, n, m, c):
+    rng = np.random.default_rng(n + m)
+    xyz1 = rng.random((b, n, 3), dtype=np.float32)
+    xyz2 = rng.random((b, m, 3), dtype=np.float32)
+    if m > 10:
+        xyz2[:, 5] = xyz2[:, 9]  # equal distances: lower index ranks first
+    dist, idx = ops.i.three_nn(T(xyz1, dev), T(xyz2, dev))
+    od, oi = O.three_nn(xyz1, xyz2)
+    assert (N(idx) == oi).all() and (N(dist) == od).all()  # inf fill when m < 3
+    dsafe = np.where(np.isfinite(od), od, 1.0).astype(np.float32)
+    w = ops.i.three_nn_weights(T(dsafe, dev))
+    ow = O.three_nn_weights(dsafe)
+    assert np.allclose(N(w), ow, rtol=1e-6, atol=0)
+    pts = rng.random((b, m, c), dtype=np.float32)
+    p = T(pts, dev).requires_grad_(True)
+    out = ops.i.three_interpolate(p, idx, T(ow, dev))
+    assert (N(out) == O.three_interpolate(pts, oi, ow)).all()
+    go = rng.random((b, n, c), dtype=np.float32)
+    out.backward(T(go, dev))
+    assert np.allclose(N(p.grad), O.three_interpolate_grad(pts, oi, ow, go), rtol=1e-5, atol=1e-5)
+
+
+# ------------------------------------------------------------------ 3D IoU / NMS
+def test_nms_smoke_known_answer(ops, dev, golden):
+    c, g = cases.nms_smoke(), golden("nms_smoke")
+    bb, sc, ob = T(c["bboxes"], dev), T(c["scores"], dev), T(c["objectiveness"], dev)
+    assert (N(ops.n.NMS3D(bb, sc, ob, 0.5)) == g["keep_050"]).all()
+    assert (N(ops.n.NMS3D(bb, sc, ob, torch.tensor(0.25))) == g["keep_025"]).all()
+    iou = N(ops.n.iou3d_matrix(bb))
+    i3 = 0.8 * float(g["bev_intersection"])
+    assert abs(iou[0, 0, 1] - i3 / (1.512 - i3)) < 1e-5
+
+
+def test_nms_random_golden(ops, dev, golden):
+    c, g = cases.nms_random(), golden("nms_random")
+    bb, sc, ob = T(c["bboxes"], dev), T(c["scores"], dev), T(c["objectiveness"], dev)
+    iou = N(ops.n.iou3d_matrix(bb))
+    assert np.allclose(iou, g["iou"], rtol=0, atol=1e-5, equal_nan=True)
+    # keep lists are exact when no pair sits within 1e-5 of the threshold (checked, not assumed)
+    for thr, key in [(0.25, "keep_025"), (0.5, "keep_050")]:
+        assert not (np.abs(g["iou"] - thr) < 1e-5).any()
+        assert (N(ops.n.NMS3D(bb, sc, ob, thr)) == g[key]).all()
+
+
+def test_nms_full_size_vs_oracle(ops, dev, O):
+    """Config-3 size: 8 scenes x 256 proposals."""
+    c = cases.nms_random(b=8, n=256, seed=33, room=6.0)
+    bb, sc, ob = T(c["bboxes"], dev), T(c["scores"], dev), T(c["objectiveness"], dev)
+    keep = N(ops.n.NMS3D(bb, sc, ob, 0.25))
+    exp = O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.25)
+    iou = np.stack([O.iou3d_matrix(c["bboxes"][s]) for s in range(8)])
+    if not (np.abs(iou - 0.25) < 1e-5).any():
+        assert (keep == exp).all()
+    assert np.allclose(N(ops.n.iou3d_matrix(bb)), iou, rtol=0, atol=1e-5, equal_nan=True)
+
+
+def test_nms_edge_cases(ops, dev):
+    c = cases.nms_random(b=2, n=16, seed=2)
+    bb, sc = T(c["bboxes"], dev), T(c["scores"], dev)
+    none = torch.zeros(2, 16, 2, device=dev)
+    assert tuple(ops.n.NMS3D(bb, sc, none, 0.25).shape) == (0, 2)  # no candidate
+    allobj = torch.tensor([0.0, 1.0], device=dev).expand(2, 16, 2).contiguous()
+    assert len(ops.n.NMS3D(bb, sc, allobj, 1.0)) == 32  # nothing can exceed IoU 1
+    from votenet_amd import InvalidArgumentError
+    with pytest.raises(InvalidArgumentError):
+        ops.n.NMS3D(bb, sc, allobj, 1.5)  # tf_nms3d.cpp:300
+    with pytest.raises(InvalidArgumentError):
+        ops.n.NMS3D(bb[:, :, :4], sc, allobj, 0.5)  # tf_nms3d.cpp:287
+
+
+def test_argument_errors(ops, dev):
+    from votenet_amd import InvalidArgumentError
+    x = torch.zeros(1, 16, 3, device=dev)
+    with pytest.raises(InvalidArgumentError):
+        ops.s.farthest_point_sample(0, x)  # tf_sampling.cpp:99
+    with pytest.raises(InvalidArgumentError):
+        ops.g.query_ball_point(-1.0, 4, x, x)  # tf_grouping.cpp:71
+    with pytest.raises(InvalidArgumentError):
+        ops.g.query_ball_point(0.1, 0, x, x)  # tf_grouping.cpp:74
+    with pytest.raises(InvalidArgumentError):
+        ops.s.farthest_point_sample(4, torch.zeros(1, 16, 4, device=dev))  # tf_sampling.cpp:105

@@ -1,0 +1,123 @@
+"""ctypes binding of libvotenet_hip.so (the C ABI declared in include/votenet_hip.h).
+
+torch is used for device memory and streams only: every call passes raw device pointers,
+sizes and the current HIP stream across the C ABI.  No fallback path exists -- if the library
+is missing or a call fails, an exception is raised.
+"""
+import ctypes
+import os
+import subprocess
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libvotenet_hip.so")
+_lib = None
+
+
+class VotenetError(RuntimeError):
+    """A HIP runtime / launch / workspace error reported by libvotenet_hip.so."""
+
+
+class InvalidArgumentError(ValueError):
+    """Mirror of tf.errors.InvalidArgumentError raised by the reference's OP_REQUIRES checks."""
+
+
+def lib_path():
+    return _LIB_PATH
+
+
+def build(force=False):
+    """Compile libvotenet_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    if force and os.path.exists(_LIB_PATH):
+        os.remove(_LIB_PATH)
+    out = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
+    if out.returncode != 0:
+        raise VotenetError("libvotenet_hip.so build failed:\n" + out.stdout + out.stderr)
+    return _LIB_PATH
+
+
+_c_f = ctypes.c_void_p  # all device pointers cross the ABI as void*
+_SIGS = {
+    "votenet_farthest_point_sample": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_gather_point": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_gather_point_grad": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_query_ball_point": [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_group_point": [ctypes.c_int] * 5 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_group_point_grad": [ctypes.c_int] * 5 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_three_nn": [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_three_nn_weights": [ctypes.c_int] * 2 + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_three_interpolate": [ctypes.c_int] * 4 + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_three_interpolate_grad": [ctypes.c_int] * 4 + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_iou3d_matrix": [ctypes.c_int] * 2 + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_nms3d": [ctypes.c_int] * 2 + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 3 + [ctypes.c_size_t, ctypes.c_void_p],
+}
+
+
+def lib():
+    """Load the library once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise VotenetError(
+                "libvotenet_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback)" % _LIB_PATH)
+        L = ctypes.CDLL(_LIB_PATH)
+        L.votenet_last_error.restype = ctypes.c_char_p
+        L.votenet_version.restype = ctypes.c_char_p
+        L.votenet_fps_temp_floats.restype = ctypes.c_size_t
+        L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_nms3d_workspace_bytes.restype = ctypes.c_size_t
+        L.votenet_nms3d_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_ball_threshold.restype = ctypes.c_float
+        L.votenet_ball_threshold.argtypes = [ctypes.c_float]
+        for name, sig in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = ctypes.c_int
+            fn.argtypes = sig
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc == 0:
+        return
+    msg = lib().votenet_last_error().decode()
+    if rc == 1:
+        raise InvalidArgumentError(msg)
+    raise VotenetError("libvotenet_hip error %d: %s" % (rc, msg))
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def dev_f32(t, name, rank=None, last=None):
+    """Validate a float32 device tensor the way the TF wrappers validate shapes; return contiguous."""
+    if not isinstance(t, torch.Tensor):
+        raise InvalidArgumentError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise VotenetError("%s must live on the GPU (no CPU fallback in votenet_amd)" % name)
+    if t.dtype != torch.float32:
+        raise InvalidArgumentError("%s must be float32" % name)
+    if rank is not None and t.dim() != rank:
+        raise InvalidArgumentError("%s expects rank %d, got shape %s" % (name, rank, tuple(t.shape)))
+    if last is not None and t.shape[-1] != last:
+        raise InvalidArgumentError("%s expects last dimension %d, got shape %s" % (name, last, tuple(t.shape)))
+    return t.contiguous()
+
+
+def dev_i32(t, name, rank=None):
+    if not isinstance(t, torch.Tensor):
+        raise InvalidArgumentError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise VotenetError("%s must live on the GPU (no CPU fallback in votenet_amd)" % name)
+    if t.dtype != torch.int32:
+        raise InvalidArgumentError("%s must be int32" % name)
+    if rank is not None and t.dim() != rank:
+        raise InvalidArgumentError("%s expects rank %d, got shape %s" % (name, rank, tuple(t.shape)))
+    return t.contiguous()

@@ -1,0 +1,69 @@
+// common.h -- shared host/device helpers of libvotenet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/votenet_hip.h"
+
+namespace votenet {
+
+// ---- error plumbing (thread-local text behind votenet_last_error()) ----
+int set_error(int code, const char *fmt, ...);
+int check_launch(const char *what);
+inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+#define VN_REQUIRE(cond, ...)                                                   \
+    do {                                                                        \
+        if (!(cond)) return ::votenet::set_error(VOTENET_E_INVALID_ARGUMENT, __VA_ARGS__); \
+    } while (0)
+
+// ---- wave64 cross-lane helpers (DPP; no LDS traffic) ----
+// dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_mirror 0x140,
+// row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp_f32(float v)
+{
+    return __uint_as_float(dpp_u32<CTRL, ROW_MASK>(__float_as_uint(v)));
+}
+
+// max over the 16 lanes of each DPP row; every lane of the row ends with the row result
+__device__ __forceinline__ float row16_max_f32(float v)
+{
+    v = fmaxf(v, dpp_f32<0xB1>(v));  // quad_perm [1,0,3,2]
+    v = fmaxf(v, dpp_f32<0x4E>(v));  // quad_perm [2,3,0,1]
+    v = fmaxf(v, dpp_f32<0x141>(v)); // row_half_mirror
+    v = fmaxf(v, dpp_f32<0x140>(v)); // row_mirror
+    return v;
+}
+__device__ __forceinline__ unsigned row16_min_u32(unsigned v)
+{
+    v = min(v, dpp_u32<0xB1>(v));
+    v = min(v, dpp_u32<0x4E>(v));
+    v = min(v, dpp_u32<0x141>(v));
+    v = min(v, dpp_u32<0x140>(v));
+    return v;
+}
+// full wave64 reductions; the result is returned wave-uniform (SGPR)
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = row16_max_f32(v);
+    v = fmaxf(v, dpp_f32<0x142, 0xA>(v)); // row_bcast:15 into rows 1,3
+    v = fmaxf(v, dpp_f32<0x143, 0xC>(v)); // row_bcast:31 into rows 2,3
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+    v = row16_min_u32(v);
+    v = min(v, dpp_u32<0x142, 0xA>(v));
+    v = min(v, dpp_u32<0x143, 0xC>(v));
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+} // namespace votenet

@@ -1,0 +1,287 @@
+// grouping.hip -- ball query, group_point and its gradient for gfx950.
+//
+// Replaces tf_ops/grouping/tf_grouping_g.cu:3-78,125-141 of the reference.
+//
+// Ball query.  The reference runs one 256-thread block per scene, each thread scanning all
+// n candidates serially for its queries (tf_grouping_g.cu:13-35).  The result is order
+// dependent (first nsample hits in ascending candidate index), so a parallel scan has to emit
+// hits in candidate order.  Here a workgroup owns 64 queries (one per lane) and NW waves split
+// each candidate "super-chunk" between them; every wave computes, for its slice, a hit
+// BITMASK per query (32 candidates -> one dword, candidates broadcast from scalar loads, no
+// divergence, no early-exit bookkeeping in the hot loop) into LDS.  After one barrier the
+// waves switch roles: each takes 64/NW queries, pops the mask words in candidate order with
+// a wave prefix sum of popcounts and writes the first nsample indices.  The scan stops as soon
+// as all 64 queries of the workgroup are full (the reference's early exit, per workgroup).
+//
+// The hit test max(sqrtf(s),1e-20f) < r is evaluated as s < T(r), where T(r) is the smallest
+// fp32 with sqrtf(T) >= r, computed on the host with correctly rounded sqrtf.  This is
+// exactly equivalent for r > 1e-20 (sqrtf is monotone) and is NOT the same as s < r*r
+// (SURVEY.md appendix A.3).
+#include "common.h"
+#include <cmath>
+
+namespace votenet {
+
+constexpr int BQ_G = 8; // 32-candidate groups per wave per super-chunk
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void ball_query_kernel(int n, int m, float thr, int nsample,
+                                                              const float *__restrict__ xyz1,
+                                                              const float *__restrict__ xyz2, int *__restrict__ idx,
+                                                              int *__restrict__ pts_cnt)
+{
+    constexpr int WPQ = NW * BQ_G;       // mask words per query per super-chunk
+    constexpr int CHUNK = WPQ * 32;      // candidates per super-chunk
+    constexpr int QPW = 64 / NW;         // queries finalised by each wave
+    constexpr int LPQ = WPQ / 64 > 0 ? WPQ / 64 : 1; // mask words per lane in the pop phase (NW=16: 2, NW=4: 1 with half the lanes idle)
+    __shared__ unsigned masks[64][WPQ + 1];
+
+    const int scene = blockIdx.y;
+    const float *__restrict__ cand = xyz1 + (size_t)scene * n * 3;
+    const float *__restrict__ qry = xyz2 + (size_t)scene * m * 3;
+    int *__restrict__ oidx = idx + (size_t)scene * m * nsample;
+    int *__restrict__ ocnt = pts_cnt + (size_t)scene * m;
+
+    const int lane = lane_id();
+    const int w = wave_id_uniform();
+    const int q0 = blockIdx.x * 64;
+    const int q = q0 + lane;
+    const bool qvalid = q < m;
+    const int qq = qvalid ? q : (m - 1);
+    const float qx = qry[(size_t)qq * 3 + 0], qy = qry[(size_t)qq * 3 + 1], qz = qry[(size_t)qq * 3 + 2];
+
+    int cnt[QPW];   // hits found so far for the queries this wave finalises (uniform)
+    int first[QPW]; // first hit (uniform)
+#pragma unroll
+    for (int i = 0; i < QPW; i++) {
+        cnt[i] = 0;
+        first[i] = 0;
+    }
+
+    for (int base = 0; base < n; base += CHUNK) {
+        // ---- phase 1: hit masks, lane = query, candidates uniform across the wave
+#pragma unroll 1
+        for (int g = 0; g < BQ_G; g++) {
+            const int wbase = __builtin_amdgcn_readfirstlane(base + (w * BQ_G + g) * 32);
+            unsigned mask = 0;
+            if (wbase < n) {
+                const int valid = (n - wbase) < 32 ? (n - wbase) : 32;
+                if (valid == 32) {
+#pragma unroll
+                    for (int t = 0; t < 32; t++) {
+                        const float cx = cand[(size_t)(wbase + t) * 3 + 0];
+                        const float cy = cand[(size_t)(wbase + t) * 3 + 1];
+                        const float cz = cand[(size_t)(wbase + t) * 3 + 2];
+                        const float dx = qx - cx, dy = qy - cy, dz = qz - cz;
+                        const float s = dx * dx + dy * dy + dz * dz; // tf_grouping_g.cu:24, un-fused
+                        mask |= (s < thr ? 1u : 0u) << t;
+                    }
+                } else {
+                    for (int t = 0; t < valid; t++) {
+                        const float cx = cand[(size_t)(wbase + t) * 3 + 0];
+                        const float cy = cand[(size_t)(wbase + t) * 3 + 1];
+                        const float cz = cand[(size_t)(wbase + t) * 3 + 2];
+                        const float dx = qx - cx, dy = qy - cy, dz = qz - cz;
+                        const float s = dx * dx + dy * dy + dz * dz;
+                        mask |= (s < thr ? 1u : 0u) << t;
+                    }
+                }
+            }
+            masks[lane][w * BQ_G + g] = mask;
+        }
+        __syncthreads();
+        // ---- phase 2: pop masks in candidate order, wave w finalises queries w*QPW .. +QPW-1
+        bool wave_full = true;
+#pragma unroll
+        for (int i = 0; i < QPW; i++) {
+            const int ql = w * QPW + i;
+            if (cnt[i] < nsample && q0 + ql < m) {
+                unsigned long long bits = 0;
+                int cbase = 0;
+                if (WPQ >= 64) {
+                    bits = (unsigned long long)masks[ql][lane * LPQ] |
+                           ((unsigned long long)masks[ql][lane * LPQ + (LPQ > 1 ? 1 : 0)] << 32);
+                    if (LPQ == 1) bits &= 0xFFFFFFFFull;
+                    cbase = base + lane * LPQ * 32;
+                } else {
+                    bits = lane < WPQ ? (unsigned long long)masks[ql][lane] : 0ull;
+                    cbase = base + lane * 32;
+                }
+                const int pc = __popcll(bits);
+                int incl = pc; // inclusive prefix sum over lanes
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int t = __shfl_up(incl, d);
+                    if (lane >= d) incl += t;
+                }
+                const int total = __builtin_amdgcn_readlane(incl, 63);
+                if (total > 0) {
+                    if (cnt[i] == 0) {
+                        const unsigned long long have = __ballot(pc > 0);
+                        const int fl = __ffsll((long long)have) - 1;
+                        const int mine = cbase + (bits ? __ffsll((long long)bits) - 1 : 0);
+                        first[i] = __builtin_amdgcn_readlane(mine, fl);
+                    }
+                    int pos = cnt[i] + incl - pc;
+                    int *__restrict__ row = oidx + (size_t)(q0 + ql) * nsample;
+                    while (bits && pos < nsample) {
+                        const int t = __ffsll((long long)bits) - 1;
+                        row[pos] = cbase + t;
+                        pos++;
+                        bits &= bits - 1;
+                    }
+                    cnt[i] += total;
+                }
+            }
+            if (cnt[i] < nsample && q0 + ql < m) wave_full = false;
+        }
+        // barrier: masks are rewritten by the next super-chunk; also the block-wide early exit
+        if (__syncthreads_and(wave_full ? 1 : 0)) break;
+    }
+    // ---- epilogue: pad with the first hit (tf_grouping_g.cu:26-29), write pts_cnt (:34)
+#pragma unroll
+    for (int i = 0; i < QPW; i++) {
+        const int ql = w * QPW + i;
+        if (q0 + ql < m) {
+            const int c = cnt[i] < nsample ? cnt[i] : nsample;
+            int *__restrict__ row = oidx + (size_t)(q0 + ql) * nsample;
+            for (int l = c + lane; l < nsample; l += 64) row[l] = first[i];
+            if (lane == 0) ocnt[q0 + ql] = c;
+        }
+    }
+}
+
+// group_point, vectorised: c % 4 == 0.  One float4 per thread, rows = b*m*nsample.
+__global__ void group_point_vec4_kernel(long rows, int n, int c4, long rows_per_scene, const float4 *__restrict__ points,
+                                        const int *__restrict__ idx, float4 *__restrict__ out)
+{
+    const long total = rows * c4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / c4;
+        const int v = (int)(e - row * c4);
+        const long s = row / rows_per_scene;
+        const int ii = idx[row];
+        out[e] = points[((size_t)s * n + ii) * c4 + v];
+    }
+}
+
+__global__ void group_point_kernel(long rows, int n, int c, long rows_per_scene, const float *__restrict__ points,
+                                   const int *__restrict__ idx, float *__restrict__ out)
+{
+    const long total = rows * c;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / c;
+        const int l = (int)(e - row * c);
+        const long s = row / rows_per_scene;
+        const int ii = idx[row];
+        out[e] = points[((size_t)s * n + ii) * c + l];
+    }
+}
+
+// group_point_grad: grad_points[s, idx[row], :] += grad_out[row, :]  (tf_grouping_g.cu:61-78).
+// fp32 hardware atomics (global_atomic_add_f32); summation order is unspecified, as in the
+// reference.
+__global__ void group_point_grad_kernel(long rows, int n, int c, long rows_per_scene, const float *__restrict__ grad_out,
+                                        const int *__restrict__ idx, float *__restrict__ grad_points)
+{
+    const long total = rows * c;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / c;
+        const int l = (int)(e - row * c);
+        const long s = row / rows_per_scene;
+        const int ii = idx[row];
+        unsafeAtomicAdd(&grad_points[((size_t)s * n + ii) * c + l], grad_out[e]);
+    }
+}
+
+// smallest fp32 T with sqrtf(T) >= r (host, correctly rounded sqrtf)
+float ball_threshold(float r)
+{
+    float t = r * r;
+    while (t > 0.0f && sqrtf(t) >= r) t = nextafterf(t, 0.0f);
+    while (sqrtf(t) < r) t = nextafterf(t, INFINITY);
+    return t;
+}
+
+static inline int grid_for(long total, int block)
+{
+    long g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" float votenet_ball_threshold(float radius) { return ball_threshold(radius); }
+
+extern "C" int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                        const float *xyz2, int *idx, int *pts_cnt, void *stream)
+{
+    VN_REQUIRE(radius > 0, "QueryBallPoint expects positive radius");   // tf_grouping.cpp:71
+    VN_REQUIRE(nsample > 0, "QueryBallPoint expects positive nsample"); // tf_grouping.cpp:74
+    VN_REQUIRE(b >= 0 && n > 0, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape."); // :79
+    VN_REQUIRE(m >= 0, "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.");            // :84
+    if (b == 0 || m == 0) return VOTENET_OK;
+    VN_REQUIRE(xyz1 && xyz2 && idx && pts_cnt, "QueryBallPoint: null buffer");
+    // d = max(sqrtf(s),1e-20f) >= 1e-20 : nothing can be closer than a radius <= 1e-20
+    const float thr = (radius <= 1e-20f) ? -1.0f : ball_threshold(radius);
+    hipStream_t st = as_stream(stream);
+    dim3 grid((m + 63) / 64, b);
+    if (n > 2048)
+        hipLaunchKernelGGL((ball_query_kernel<16>), grid, dim3(1024), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
+    else
+        hipLaunchKernelGGL((ball_query_kernel<4>), grid, dim3(256), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
+    return check_launch("query_ball_point");
+}
+
+extern "C" int votenet_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
+                                   float *out, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0 && c > 0, "GroupPoint expects (batch_size, num_points, channel) points shape"); // tf_grouping.cpp:149
+    VN_REQUIRE(m >= 0 && nsample >= 0, "GroupPoint expects (batch_size, npoints, nsample) idx shape");        // :155
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(points && idx && out, "GroupPoint: null buffer");
+    hipStream_t st = as_stream(stream);
+    const long rps = (long)m * nsample;
+    if (c % 4 == 0 && ((uintptr_t)points % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+        const long total = rows * (c / 4);
+        hipLaunchKernelGGL(group_point_vec4_kernel, dim3(grid_for(total, 256)), dim3(256), 0, st, rows, n, c / 4, rps,
+                           (const float4 *)points, idx, (float4 *)out);
+    } else {
+        hipLaunchKernelGGL(group_point_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, st, rows, n, c, rps, points, idx,
+                           out);
+    }
+    return check_launch("group_point");
+}
+
+extern "C" int votenet_group_point_grad(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx,
+                                        float *grad_points, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0 && c > 0, "GroupPointGrad expects (batch_size, num_points, channel) points shape"); // :180
+    VN_REQUIRE(m >= 0 && nsample >= 0, "GroupPointGrad expects (batch_size, npoints, nsample) idx shape");        // :186
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(grad_out && idx && grad_points, "GroupPointGrad: null buffer");
+    hipLaunchKernelGGL(group_point_grad_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, n, c,
+                       (long)m * nsample, grad_out, idx, grad_points);
+    return check_launch("group_point_grad");
+}
+
+// ---- reference launcher names, C++ linkage, exact signatures (tf_grouping.cpp:66,142,173)
+void queryBallPointLauncher(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int *idx,
+                            int *pts_cnt)
+{
+    votenet_query_ball_point(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, nullptr);
+}
+void groupPointLauncher(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out)
+{
+    votenet_group_point(b, n, c, m, nsample, points, idx, out, nullptr);
+}
+void groupPointGradLauncher(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points)
+{
+    votenet_group_point_grad(b, n, c, m, nsample, grad_out, idx, grad_points, nullptr);
+}

@@ -1,0 +1,183 @@
+// interpolate.hip -- three_nn, inverse-distance weights, three_interpolate (+grad) for gfx950.
+//
+// Replaces the CPU-only ops of tf_ops/3d_interpolation/tf_interpolate.cpp:60-153 (which cost
+// the reference a device->host->device round trip around fp1/fp2 every step) and the four TF
+// elementwise ops of utils.py:279-282.
+//   three_nn : lane = unknown point, the m known points are broadcast through scalar loads;
+//              the reference's strict '<' insert cascade is kept literally so equal distances
+//              rank the lower index first.  Distances are SQUARED, fp32, un-fused.
+//   three_interpolate : one output row per wave-slice, lanes over channels (float4 when c%4==0),
+//              (p1*w1 + p2*w2) + p3*w3 un-fused, as tf_interpolate.cpp:119.
+#include "common.h"
+
+namespace votenet {
+
+__global__ __launch_bounds__(256) void three_nn_kernel(int n, int m, const float *__restrict__ xyz1,
+                                                       const float *__restrict__ xyz2, float *__restrict__ dist,
+                                                       int *__restrict__ idx)
+{
+    const int scene = blockIdx.y;
+    const float *__restrict__ unk = xyz1 + (size_t)scene * n * 3;
+    const float *__restrict__ known = xyz2 + (size_t)scene * m * 3;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int jj = j < n ? j : n - 1;
+    const float x1 = unk[(size_t)jj * 3 + 0], y1 = unk[(size_t)jj * 3 + 1], z1 = unk[(size_t)jj * 3 + 2];
+    // tf_interpolate.cpp:66: best* = 1e40 (double) -> +inf once stored as float
+    float best1 = INFINITY, best2 = INFINITY, best3 = INFINITY;
+    int besti1 = 0, besti2 = 0, besti3 = 0;
+    for (int k = 0; k < m; ++k) {
+        const float x2 = known[(size_t)k * 3 + 0], y2 = known[(size_t)k * 3 + 1], z2 = known[(size_t)k * 3 + 2];
+        const float d = (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1) + (z2 - z1) * (z2 - z1); // :73
+        if (d < best1) { // :74-89
+            best3 = best2; besti3 = besti2;
+            best2 = best1; besti2 = besti1;
+            best1 = d; besti1 = k;
+        } else if (d < best2) {
+            best3 = best2; besti3 = besti2;
+            best2 = d; besti2 = k;
+        } else if (d < best3) {
+            best3 = d; besti3 = k;
+        }
+    }
+    if (j < n) {
+        float *__restrict__ od = dist + ((size_t)scene * n + j) * 3;
+        int *__restrict__ oi = idx + ((size_t)scene * n + j) * 3;
+        od[0] = best1; od[1] = best2; od[2] = best3;
+        oi[0] = besti1; oi[1] = besti2; oi[2] = besti3;
+    }
+}
+
+__global__ void three_nn_weights_kernel(long rows, const float *__restrict__ dist, float *__restrict__ weight)
+{
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (long)gridDim.x * blockDim.x) {
+        float d0 = dist[r * 3 + 0], d1 = dist[r * 3 + 1], d2 = dist[r * 3 + 2];
+        d0 = d0 > 1e-10f ? d0 : 1e-10f; // utils.py:279
+        d1 = d1 > 1e-10f ? d1 : 1e-10f;
+        d2 = d2 > 1e-10f ? d2 : 1e-10f;
+        const float r0 = 1.0f / d0, r1 = 1.0f / d1, r2 = 1.0f / d2;
+        const float norm = (r0 + r1) + r2; // utils.py:280
+        weight[r * 3 + 0] = r0 / norm;     // utils.py:282
+        weight[r * 3 + 1] = r1 / norm;
+        weight[r * 3 + 2] = r2 / norm;
+    }
+}
+
+template <typename V>
+__device__ __forceinline__ V lerp3(const V &a, const V &b, const V &c, float w1, float w2, float w3);
+template <>
+__device__ __forceinline__ float lerp3<float>(const float &a, const float &b, const float &c, float w1, float w2, float w3)
+{
+    return a * w1 + b * w2 + c * w3;
+}
+template <>
+__device__ __forceinline__ float4 lerp3<float4>(const float4 &a, const float4 &b, const float4 &c, float w1, float w2,
+                                                float w3)
+{
+    float4 r;
+    r.x = a.x * w1 + b.x * w2 + c.x * w3;
+    r.y = a.y * w1 + b.y * w2 + c.y * w3;
+    r.z = a.z * w1 + b.z * w2 + c.z * w3;
+    r.w = a.w * w1 + b.w * w2 + c.w * w3;
+    return r;
+}
+
+// rows = b*n output rows, cv = channels per row in units of V
+template <typename V>
+__global__ void three_interpolate_kernel(long rows, int n, int m, int cv, const V *__restrict__ points,
+                                         const int *__restrict__ idx, const float *__restrict__ weight, V *__restrict__ out)
+{
+    const long total = rows * cv;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / cv;
+        const int l = (int)(e - row * cv);
+        const long s = row / n;
+        const int i1 = idx[row * 3], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+        const float w1 = weight[row * 3], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
+        const V *__restrict__ p = points + (size_t)s * m * cv;
+        out[e] = lerp3<V>(p[(size_t)i1 * cv + l], p[(size_t)i2 * cv + l], p[(size_t)i3 * cv + l], w1, w2, w3);
+    }
+}
+
+__global__ void three_interpolate_grad_kernel(long rows, int n, int m, int c, const float *__restrict__ grad_out,
+                                              const int *__restrict__ idx, const float *__restrict__ weight,
+                                              float *__restrict__ grad_points)
+{
+    const long total = rows * c;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / c;
+        const int l = (int)(e - row * c);
+        const long s = row / n;
+        const float g = grad_out[e];
+        float *__restrict__ gp = grad_points + (size_t)s * m * c;
+        unsafeAtomicAdd(&gp[(size_t)idx[row * 3 + 0] * c + l], g * weight[row * 3 + 0]); // tf_interpolate.cpp:144-146
+        unsafeAtomicAdd(&gp[(size_t)idx[row * 3 + 1] * c + l], g * weight[row * 3 + 1]);
+        unsafeAtomicAdd(&gp[(size_t)idx[row * 3 + 2] * c + l], g * weight[row * 3 + 2]);
+    }
+}
+
+static inline int grid_for(long total, int block)
+{
+    long g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2, float *dist, int *idx,
+                                void *stream)
+{
+    VN_REQUIRE(b >= 0 && n >= 0, "ThreeNN expects (b,n,3) xyz1 shape."); // tf_interpolate.cpp:163
+    VN_REQUIRE(m >= 0, "ThreeNN expects (b,m,3) xyz2 shape.");           // :168
+    if (b == 0 || n == 0) return VOTENET_OK;
+    VN_REQUIRE(xyz1 && (xyz2 || m == 0) && dist && idx, "ThreeNN: null buffer");
+    hipLaunchKernelGGL(three_nn_kernel, dim3((n + 255) / 256, b), dim3(256), 0, as_stream(stream), n, m, xyz1, xyz2, dist,
+                       idx);
+    return check_launch("three_nn");
+}
+
+extern "C" int votenet_three_nn_weights(int b, int n, const float *dist, float *weight, void *stream)
+{
+    const long rows = (long)b * n;
+    VN_REQUIRE(b >= 0 && n >= 0, "three_nn_weights expects (b,n,3) dist shape");
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(dist && weight, "three_nn_weights: null buffer");
+    hipLaunchKernelGGL(three_nn_weights_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, as_stream(stream), rows, dist,
+                       weight);
+    return check_launch("three_nn_weights");
+}
+
+extern "C" int votenet_three_interpolate(int b, int m, int c, int n, const float *points, const int *idx,
+                                         const float *weight, float *out, void *stream)
+{
+    VN_REQUIRE(b >= 0 && m > 0 && c > 0, "ThreeInterpolate expects (b,m,c) points shape"); // tf_interpolate.cpp:197
+    VN_REQUIRE(n >= 0, "ThreeInterpolate expects (b,n,3) idx shape");                     // :203
+    const long rows = (long)b * n;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(points && idx && weight && out, "ThreeInterpolate: null buffer");
+    hipStream_t st = as_stream(stream);
+    if (c % 4 == 0 && ((uintptr_t)points % 16 == 0) && ((uintptr_t)out % 16 == 0)) {
+        hipLaunchKernelGGL((three_interpolate_kernel<float4>), dim3(grid_for(rows * (c / 4), 256)), dim3(256), 0, st, rows, n,
+                           m, c / 4, (const float4 *)points, idx, weight, (float4 *)out);
+    } else {
+        hipLaunchKernelGGL((three_interpolate_kernel<float>), dim3(grid_for(rows * c, 256)), dim3(256), 0, st, rows, n, m, c,
+                           points, idx, weight, out);
+    }
+    return check_launch("three_interpolate");
+}
+
+extern "C" int votenet_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
+                                              const float *weight, float *grad_points, void *stream)
+{
+    VN_REQUIRE(b >= 0 && m > 0 && c > 0, "ThreeInterpolateGrad expects (b,m,c) points shape"); // tf_interpolate.cpp:231
+    VN_REQUIRE(n >= 0, "ThreeInterpolateGrad expects (b,n,3) idx shape");                     // :237
+    const long rows = (long)b * n;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(grad_out && idx && weight && grad_points, "ThreeInterpolateGrad: null buffer");
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, n,
+                       m, c, grad_out, idx, weight, grad_points);
+    return check_launch("three_interpolate_grad");
+}

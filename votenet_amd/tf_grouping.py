@@ -1,0 +1,61 @@
+"""Mirror of the reference's tf_ops/grouping/tf_grouping.py on torch (ROCm) tensors.
+
+query_ball_point has no gradient (tf_grouping.py:21); group_point's gradient w.r.t. points is
+GroupPointGrad (tf_grouping.py:42-46).  select_top_k / knn_point are reachable only with
+knn=True (utils.py:46-47), never set by model.py: out of scope.
+"""
+import torch
+
+from . import _lib as L
+
+
+def query_ball_point(radius, nsample, xyz1, xyz2):
+    """tf_grouping.py:8-20.  float, int, (B,n,3), (B,m,3) -> (idx (B,m,nsample) i32, pts_cnt (B,m) i32)."""
+    xyz1 = L.dev_f32(xyz1.detach(), "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.", 3, 3)
+    xyz2 = L.dev_f32(xyz2.detach(), "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.", 3, 3)
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    nsample = int(nsample)
+    idx = torch.empty((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
+    cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
+    with torch.cuda.device(xyz1.device):
+        L.check(L.lib().votenet_query_ball_point(b, n, m, float(radius), nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx),
+                                                 L.ptr(cnt), L.stream_ptr()))
+    return idx, cnt
+
+
+class _GroupPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, idx):
+        points = L.dev_f32(points, "GroupPoint expects (batch_size, num_points, channel) points shape", 3)
+        idx = L.dev_i32(idx, "GroupPoint expects (batch_size, npoints, nsample) idx shape", 3)
+        if idx.shape[0] != points.shape[0]:
+            raise L.InvalidArgumentError("GroupPoint expects (batch_size, npoints, nsample) idx shape")
+        b, n, c = points.shape
+        _, m, k = idx.shape
+        out = torch.empty((b, m, k, c), dtype=torch.float32, device=points.device)
+        with torch.cuda.device(points.device):
+            L.check(L.lib().votenet_group_point(b, n, c, m, k, L.ptr(points), L.ptr(idx), L.ptr(out), L.stream_ptr()))
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (idx,) = ctx.saved_tensors
+        return group_point_grad_raw(ctx.n, idx, grad_out), None
+
+
+def group_point_grad_raw(n, idx, grad_out):
+    """GroupPointGrad (tf_grouping.cpp:173-208): zero-filled (B,n,c) buffer + scatter-add."""
+    grad_out = L.dev_f32(grad_out, "GroupPointGrad expects (batch_size, npoints, nsample, channel) grad_out shape", 4)
+    b, m, k, c = grad_out.shape
+    g = torch.zeros((b, n, c), dtype=torch.float32, device=grad_out.device)  # tf_grouping.cpp:204
+    with torch.cuda.device(grad_out.device):
+        L.check(L.lib().votenet_group_point_grad(b, n, c, m, k, L.ptr(grad_out), L.ptr(idx), L.ptr(g), L.stream_ptr()))
+    return g
+
+
+def group_point(points, idx):
+    """tf_grouping.py:33-41.  (B,n,c) f32, (B,m,nsample) i32 -> (B,m,nsample,c) f32."""
+    return _GroupPoint.apply(points, idx)

@@ -1,0 +1,60 @@
+"""Mirror of the reference's tf_ops/sampling/tf_sampling.py on torch (ROCm) tensors.
+
+Same function names, positional order and return arity; autograd wiring mirrors
+RegisterGradient('GatherPoint') / ops.NoGradient('FarthestPointSample')
+(tf_sampling.py:43-47,57).  prob_sample (tf_sampling.py:13-22) is not used by VoteNet
+(utils.py:17) and is out of scope.
+"""
+import torch
+
+from . import _lib as L
+
+
+def farthest_point_sample(npoint, inp):
+    """tf_sampling.py:48-56.  int, (B,n,3) f32 -> (B,npoint) int32.  No gradient."""
+    inp = L.dev_f32(inp.detach(), "FarthestPointSample expects (batch_size,num_points,3) inp shape", 3, 3)
+    b, n, _ = inp.shape
+    npoint = int(npoint)
+    out = torch.empty((b, max(npoint, 0)), dtype=torch.int32, device=inp.device)
+    nt = L.lib().votenet_fps_temp_floats(b, n)
+    temp = torch.empty(nt, dtype=torch.float32, device=inp.device) if nt else None
+    with torch.cuda.device(inp.device):
+        L.check(L.lib().votenet_farthest_point_sample(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream_ptr()))
+    return out
+
+
+class _GatherPoint(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, idx):
+        inp = L.dev_f32(inp, "GatherPoint expects (batch_size,num_points,3) inp shape", 3, 3)
+        idx = L.dev_i32(idx, "GatherPoint expects (batch_size,num_result) idx shape", 2)
+        if idx.shape[0] != inp.shape[0]:
+            raise L.InvalidArgumentError("GatherPoint expects (batch_size,num_result) idx shape")
+        b, n, _ = inp.shape
+        m = idx.shape[1]
+        out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
+        with torch.cuda.device(inp.device):
+            L.check(L.lib().votenet_gather_point(b, n, m, L.ptr(inp), L.ptr(idx), L.ptr(out), L.stream_ptr()))
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return out
+
+    @staticmethod
+    def backward(ctx, out_g):
+        (idx,) = ctx.saved_tensors
+        return gather_point_grad_raw(ctx.n, idx, out_g), None
+
+
+def gather_point_grad_raw(n, idx, out_g):
+    """GatherPointGrad (tf_sampling.cpp:150-178): zero-filled (B,n,3) buffer + scatter-add."""
+    out_g = L.dev_f32(out_g, "GatherPointGradGpuOp expects (batch_size,num_result,3) out_g shape", 3, 3)
+    b, m = idx.shape
+    inp_g = torch.zeros((b, n, 3), dtype=torch.float32, device=out_g.device)  # tf_sampling.cpp:174
+    with torch.cuda.device(out_g.device):
+        L.check(L.lib().votenet_gather_point_grad(b, n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream_ptr()))
+    return inp_g
+
+
+def gather_point(inp, idx):
+    """tf_sampling.py:29-36.  (B,n,3) f32, (B,m) int32 -> (B,m,3) f32; d/d inp registered."""
+    return _GatherPoint.apply(inp, idx)
