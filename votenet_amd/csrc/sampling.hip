@@ -46,13 +46,27 @@ __device__ __forceinline__ unsigned fps_block_argmax(float best, unsigned key, f
     return fps_key_to_index((unsigned)__builtin_amdgcn_readfirstlane((int)bkey));
 }
 
-// Register-resident FPS: one workgroup (NW waves) per scene, P points per lane,
-// point k = tid + i * (64*NW) lives in slot i of lane tid.
+// Slot -> point index.  The per-lane arg-max keeps the LOWEST slot on ties, so slots must be
+// ordered by the reference tie key (k mod 512, then k).  With T = 64*NW threads:
+//   T >= 512 : k = tid + i*T              (k mod 512 is the same for every slot of a lane)
+//   T <  512 : a lane owns R = 512/T residues; slot i = a*Q + b  ->  k = b*512 + a*T + tid
+//              (all points of residue a*T+tid first, in ascending k, then the next residue)
+template <int NW, int P>
+__device__ __forceinline__ int fps_slot_to_k(int tid, int i)
+{
+    constexpr int T = NW * 64;
+    if (T >= 512) return tid + i * T;
+    constexpr int R = 512 / (T < 512 ? T : 512);
+    constexpr int Q = (P / R) > 0 ? (P / R) : 1;
+    static_assert(T >= 512 || P % R == 0, "P must be a multiple of 512/T");
+    return (i % Q) * 512 + (i / Q) * T + tid;
+}
+
+// Register-resident FPS: one workgroup (NW waves) per scene, P points per lane.
 template <int NW, int P>
 __global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const float *__restrict__ xyz,
                                                            int *__restrict__ out)
 {
-    constexpr int T = NW * 64;
     __shared__ float s_best[32];
     __shared__ unsigned s_key[32];
     const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
@@ -62,7 +76,7 @@ __global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const fl
     float x[P], y[P], z[P], td[P];
 #pragma unroll
     for (int i = 0; i < P; i++) {
-        const int k = tid + i * T;
+        const int k = fps_slot_to_k<NW, P>(tid, i);
         if (k < n) {
             x[i] = pts[(size_t)k * 3 + 0];
             y[i] = pts[(size_t)k * 3 + 1];
@@ -88,12 +102,12 @@ __global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const fl
             const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
             const float d2 = (d < td[i]) ? d : td[i];    // :143
             td[i] = d2;
-            if (d2 > best) { // :146 strict: the lowest slot (lowest k of this lane) wins ties
+            if (d2 > best) { // :146 strict: the lowest slot (smallest tie key of this lane) wins ties
                 best = d2;
                 bi = i;
             }
         }
-        const unsigned k = (unsigned)(tid + bi * T);
+        const unsigned k = (unsigned)fps_slot_to_k<NW, P>(tid, bi);
         old = (int)fps_block_argmax<NW>(best, fps_tiekey(k), s_best, s_key, j);
         if (tid == 0) o[j] = old;
     }
