@@ -154,15 +154,16 @@ typedef struct votenet_mlp_input {
 } votenet_mlp_input;
 
 /* z (rows x cout) = input(rows x cin) * w (cin x cout, row-major) + bias (cout, may be NULL).
- * stats: 2*cout floats, [0,cout) += column sums of z, [cout,2cout) += column sums of z*z;
- * pre-zeroed by the caller; may be NULL.  rows = b*m*nsample for GATHER. */
+ * stats: 2*cout DOUBLES, [0,cout) += column sums of z, [cout,2cout) += column sums of z*z
+ * (fp32 partial sums per workgroup, fp64 accumulation across workgroups); pre-zeroed by the
+ * caller; may be NULL.  rows = b*m*nsample for GATHER. */
 int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
-                       const float *bias, float *z, float *stats, void *stream);
+                       const float *bias, float *z, double *stats, void *stream);
 
 /* BatchNorm scale/shift from accumulated statistics: mean = sum/rows, var = sumsq/rows - mean^2
  * (biased), scale = gamma*rsqrt(var+eps), shift = beta - mean*scale.  Also writes mean and
  * var (each may be NULL). */
-int votenet_bn_finalize(long rows, int c, const float *stats, const float *gamma, const float *beta, float eps,
+int votenet_bn_finalize(long rows, int c, const double *stats, const float *gamma, const float *beta, float eps,
                         float *scale, float *shift, float *mean, float *var, void *stream);
 
 /* out (groups x c) = max over the k rows of each group of max(0?, z*scale+shift);

@@ -1,0 +1,117 @@
+"""GPU: grouped-point MLP kernels (fused gather + fp32 MFMA GEMM + BN statistics, BN/ReLU folded
+into the next load, max over K) against the CPU oracle (oracle/oracle_mlp.c).
+Tolerance: 1e-5 relative to the magnitude of the accumulated products (fp32 round-off class)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def close(got, exp, scale=None, tol=1e-5):
+    s = np.abs(exp).max() if scale is None else scale
+    return np.abs(got - exp).max() <= tol * max(s, 1.0)
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(128, 16, 64), (1000, 64, 64), (4096, 64, 128), (777, 128, 256), (300, 259, 256),
+                                           (512, 256, 259), (130, 128, 79), (64, 6, 64), (5, 3, 7), (2048, 512, 256)])
+def test_linear_dense_vs_oracle(hiplib, dev, O, rows, cin, cout):
+    from votenet_amd import mlp
+    rng = np.random.default_rng(rows + cin)
+    x = rng.normal(size=(rows, cin)).astype(np.float32)
+    w = (rng.normal(size=(cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    z, stats = mlp.linear_dense(T(x, dev), T(w, dev), T(b, dev))
+    oz = O.linear(x, w, b)
+    bound = (np.abs(x) @ np.abs(w)).max()
+    assert close(N(z), oz, bound)
+    st = N(stats)
+    assert np.allclose(st[:cout], oz.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    assert np.allclose(st[cout:], (oz.astype(np.float64) ** 2).sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_linear_dense_with_folded_bn_relu(hiplib, dev, O):
+    from votenet_amd import mlp
+    rng = np.random.default_rng(3)
+    rows, cin, cout = 1500, 64, 128
+    zprev = rng.normal(size=(rows, cin)).astype(np.float32) * 3 + 1
+    gamma, beta = rng.normal(size=cin).astype(np.float32), rng.normal(size=cin).astype(np.float32)
+    w = (rng.normal(size=(cin, cout)) * 0.2).astype(np.float32)
+    mean, var = O.bn_stats(zprev)
+    a = O.bn_relu(zprev, mean, var, gamma, beta)
+    oz = O.linear(a, w, None)
+    # device: statistics of zprev come from a first linear with identity weights
+    zp, st = mlp.linear_dense(T(zprev, dev), torch.eye(cin, device=dev))
+    scale, shift, dmean, dvar = mlp.bn_finalize(rows, st, T(gamma, dev), T(beta, dev))
+    assert np.allclose(N(dmean), mean, rtol=1e-5, atol=1e-6) and np.allclose(N(dvar), var, rtol=1e-5, atol=1e-6)
+    z, _ = mlp.linear_dense(T(zprev, dev), T(w, dev), None, scale, shift, True)
+    assert close(N(z), oz, (np.abs(a) @ np.abs(w)).max())
+    assert close(N(mlp.bn_relu(T(zprev, dev), scale, shift)), a)
+
+
+@pytest.mark.parametrize("b,n,m,k,c,cout", [(2, 300, 20, 16, 0, 64), (2, 300, 20, 16, 3, 64), (1, 500, 33, 64, 128, 128),
+                                            (2, 256, 16, 64, 256, 128), (1, 100, 7, 8, 5, 79)])
+def test_linear_gather_vs_oracle(hiplib, dev, O, b, n, m, k, c, cout):
+    """First SA layer: sample_and_group concat [dxyz, feat] (utils.py:50-57) folded into the GEMM load."""
+    from votenet_amd import mlp
+    rng = np.random.default_rng(n + c)
+    xyz = rng.random((b, n, 3), dtype=np.float32)
+    new_xyz = rng.random((b, m, 3), dtype=np.float32)
+    feat = rng.normal(size=(b, n, c)).astype(np.float32) if c else None
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    w = (rng.normal(size=(3 + c, cout)) * 0.3).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    x = O.group_concat(xyz, new_xyz, feat, idx).reshape(b * m * k, 3 + c)
+    oz = O.linear(x, w, bias)
+    z, st = mlp.linear_gather(T(xyz, dev), T(new_xyz, dev), T(feat, dev) if c else None, T(idx, dev), T(w, dev), T(bias, dev))
+    assert close(N(z), oz, (np.abs(x) @ np.abs(w)).max())
+    assert np.allclose(N(st)[:cout], oz.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+
+
+def test_sa_mlp_stack_cfg1(hiplib, dev, O):
+    """BASELINE config 1 end to end: 2048 pts -> FPS 512 -> ball r=0.2 K=32 -> MLP 64,64,128 (BNReLU) -> max over K."""
+    import cases
+    from votenet_amd import mlp, tf_grouping, tf_sampling
+    xyz = cases.cfg1_cloud()
+    rng = np.random.default_rng(1)
+    dims = [6, 64, 64, 128]
+    ws = [(rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(3)]
+    bs = [rng.normal(size=dims[i + 1]).astype(np.float32) * 0.1 for i in range(3)]
+    gs = [1 + 0.1 * rng.normal(size=dims[i + 1]).astype(np.float32) for i in range(3)]
+    be = [0.1 * rng.normal(size=dims[i + 1]).astype(np.float32) for i in range(3)]
+    # oracle
+    fidx = O.farthest_point_sample(512, xyz)
+    new_xyz = O.gather_point(xyz, fidx)
+    idx, _ = O.query_ball_point(0.2, 32, xyz, new_xyz)
+    a = O.group_concat(xyz, new_xyz, xyz, idx).reshape(-1, 6)
+    for i in range(3):
+        zz = O.linear(a, ws[i], bs[i])
+        mean, var = O.bn_stats(zz)
+        a = O.bn_relu(zz, mean, var, gs[i], be[i])
+    exp = O.max_over_k(a, 32)
+    # device
+    x = T(xyz, dev)
+    dfidx = tf_sampling.farthest_point_sample(512, x)
+    dnew = tf_sampling.gather_point(x, dfidx)
+    didx, _ = tf_grouping.query_ball_point(0.2, 32, x, dnew)
+    rows = 512 * 32
+    z, st = mlp.linear_gather(x, dnew, x, didx, T(ws[0], dev), T(bs[0], dev))
+    sc, sh, _, _ = mlp.bn_finalize(rows, st, T(gs[0], dev), T(be[0], dev))
+    for i in (1, 2):
+        z, st = mlp.linear_dense(z, T(ws[i], dev), T(bs[i], dev), sc, sh, True)
+        sc, sh, _, _ = mlp.bn_finalize(rows, st, T(gs[i], dev), T(be[i], dev))
+    out, arg = mlp.bn_relu_max(z, 32, sc, sh, True, want_argmax=True)
+    got = N(out)
+    assert got.shape == (512, 128)
+    assert np.abs(got - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max())
+    # argmax points at a row attaining the max
+    full = N(mlp.bn_relu(z, sc, sh)).reshape(512, 32, 128)
+    assert (np.take_along_axis(full, N(arg)[:, None, :].astype(np.int64), 1)[:, 0, :] == got).all()

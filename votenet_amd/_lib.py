@@ -54,6 +54,22 @@ _SIGS = {
 }
 
 
+class MlpInput(ctypes.Structure):
+    """struct votenet_mlp_input (include/votenet_hip.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p),
+                ("in_relu", ctypes.c_int),
+                ("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("feat", ctypes.c_void_p), ("idx", ctypes.c_void_p),
+                ("b", ctypes.c_int), ("n", ctypes.c_int), ("m", ctypes.c_int), ("nsample", ctypes.c_int), ("c", ctypes.c_int)]
+
+
+_SIGS.update({
+    "votenet_mlp_linear": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_bn_relu": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+})
+
+
 def lib():
     """Load the library once; raise loudly if it has not been built."""
     global _lib

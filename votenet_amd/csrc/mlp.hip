@@ -1,0 +1,415 @@
+// mlp.hip -- grouped-point MLP for gfx950: fp32 MFMA GEMM with a fused gather prologue and a
+// BatchNorm-statistics epilogue, plus the small BN / max-pool kernels around it.
+//
+// Replaces the SA/FP-layer MLP path of the reference (utils.py:50-57 sample_and_group concat,
+// :125-127 Conv2D 1x1 + BNReLU loop, :132 max-pool, :149-155 mlp2, :286-293 FP MLP), which the
+// reference runs as cuDNN 1x1 convolutions over a MATERIALISED (B,m,K,3+C) tensor with
+// BN / ReLU / max as separate graph nodes.  Here:
+//   * the (B*m*K, 3+C) input matrix never exists: the GEMM's A-operand loader gathers
+//     feat[idx[r]] rows and forms xyz[idx[r]] - new_xyz[r/K] on the fly (GATHER mode);
+//   * BNReLU of layer l is folded into the A-operand load of layer l+1 (DENSE mode with
+//     per-channel scale/shift + relu), so activations are written once, raw, and read once;
+//   * the epilogue accumulates the per-channel sum / sum of squares that BatchNorm needs
+//     (fp32 partials per workgroup, fp64 atomics across workgroups);
+//   * math runs on v_mfma_f32_32x32x2_f32 (fp32 in, fp32 accumulate, exact fp32 products --
+//     the reference computes this path in fp32); 128-row x 64/128-column workgroup tiles,
+//     4 waves, operands staged through LDS in [k][row] order so both MFMA operand reads are
+//     conflict-free ds_read_b32, global loads of the next k-slab in flight during the MFMAs.
+//
+// Internal K order of GATHER mode is [feat(c), dxyz(3)] (features first, so feature rows load
+// as aligned float4); row k of the caller's W (whose order is the reference's [dxyz, feat],
+// utils.py:55) is fetched through the same permutation, so the result is the reference's.
+#include "common.h"
+
+namespace votenet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_BM = 128; // rows per workgroup tile
+constexpr int MLP_BK = 16;  // k-slab
+constexpr int MLP_LDA = MLP_BM + 2; // [k][row] image; +2 -> conflict-free 4-lane-strided writes
+
+struct MlpIn {
+    // DENSE
+    const float *x;
+    const float *in_scale;
+    const float *in_shift;
+    int in_relu;
+    // GATHER
+    const float *xyz;
+    const float *new_xyz;
+    const float *feat;
+    const int *idx;
+    int n, m, nsample, c;
+};
+
+// One element of the implicit A matrix, internal k order.  Bounds are the caller's job.
+template <int MODE>
+__device__ __forceinline__ float a_elem(const MlpIn &in, long r, int k, int cin, int src /*gather: idx[r]*/, long scene)
+{
+    if (MODE == 0) {
+        float v = in.x[(size_t)r * cin + k];
+        if (in.in_scale) {
+            v = v * in.in_scale[k] + in.in_shift[k];
+            if (in.in_relu) v = v > 0.0f ? v : 0.0f;
+        }
+        return v;
+    } else {
+        if (k < in.c) return in.feat[((size_t)scene * in.n + src) * in.c + k];
+        const int d = k - in.c;
+        return in.xyz[((size_t)scene * in.n + src) * 3 + d] - in.new_xyz[(size_t)(r / in.nsample) * 3 + d]; // utils.py:51
+    }
+}
+
+// caller's W row for internal k (GATHER: features first internally, dxyz first in W)
+template <int MODE>
+__device__ __forceinline__ int w_row(int k, int c)
+{
+    if (MODE == 0) return k;
+    return k < c ? k + 3 : k - c;
+}
+
+// z = A(rows x cin) * W(cin x cout) + bias, stats += column sums of z and z^2.
+// WM x WN waves, each wave MT x NT tiles of 32x32.  BM = WM*MT*32 = 128, BN = WN*NT*32.
+template <int MODE, int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void mlp_linear_kernel(MlpIn in, long rows, int cin, int cout,
+                                                         const float *__restrict__ w, const float *__restrict__ bias,
+                                                         float *__restrict__ z, double *__restrict__ stats)
+{
+    static_assert(WM * WN == 4 && WM * MT * 32 == MLP_BM, "tile shape");
+    constexpr int BN = WN * NT * 32;
+    constexpr int LDB = BN + 4;
+    __shared__ float As[2][MLP_BK][MLP_LDA];
+    __shared__ float Bs[2][MLP_BK][LDB];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wv / WN, wn = wv % WN;
+    const int n0 = blockIdx.y * BN;
+    const int nk = (cin + MLP_BK - 1) / MLP_BK;
+    const long ntiles = (rows + MLP_BM - 1) / MLP_BM;
+    const bool a_vec4 = (MODE == 0) ? ((cin & 3) == 0) : ((in.c & 3) == 0 && in.c > 0);
+    const bool b_vec4 = ((cout & 3) == 0);
+
+    // A staging: thread t loads rows (t>>2) and (t>>2)+64 of the tile, k-quad (t&3) of the slab
+    const int a_row = tid >> 2, a_kq = tid & 3;
+    // B staging: BK x BN floats = 4*BN float4; thread t loads float4 #t and #t+256 (if BN=128)
+    constexpr int B_F4 = MLP_BK * BN / 4;       // 256 (BN=64) or 512 (BN=128)
+    constexpr int B_PER_T = B_F4 / 256;         // 1 or 2
+
+    float s1[NT], s2[NT]; // per-lane partial column sums over all tiles of this workgroup
+#pragma unroll
+    for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
+
+    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long m0 = tile * MLP_BM;
+        long ar[2];
+        int asrc[2];
+        long ascene[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            ar[h] = m0 + a_row + h * 64;
+            asrc[h] = 0;
+            ascene[h] = 0;
+            if (MODE == 1 && ar[h] < rows) {
+                asrc[h] = in.idx[ar[h]];
+                ascene[h] = ar[h] / ((long)in.m * in.nsample);
+            }
+        }
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+
+        float4 ra[2];
+        float4 rb[B_PER_T];
+        auto load_slab = [&](int kt) {
+            const int k0 = kt * MLP_BK + a_kq * 4;
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ar[h] < rows) {
+                    bool done = false;
+                    if (a_vec4) {
+                        if (MODE == 0 && k0 + 3 < cin) {
+                            v = *reinterpret_cast<const float4 *>(in.x + (size_t)ar[h] * cin + k0);
+                            if (in.in_scale) {
+                                const float4 sc = *reinterpret_cast<const float4 *>(in.in_scale + k0);
+                                const float4 sh = *reinterpret_cast<const float4 *>(in.in_shift + k0);
+                                v.x = v.x * sc.x + sh.x;
+                                v.y = v.y * sc.y + sh.y;
+                                v.z = v.z * sc.z + sh.z;
+                                v.w = v.w * sc.w + sh.w;
+                                if (in.in_relu) {
+                                    v.x = v.x > 0.f ? v.x : 0.f;
+                                    v.y = v.y > 0.f ? v.y : 0.f;
+                                    v.z = v.z > 0.f ? v.z : 0.f;
+                                    v.w = v.w > 0.f ? v.w : 0.f;
+                                }
+                            }
+                            done = true;
+                        } else if (MODE == 1 && k0 + 3 < in.c) {
+                            v = *reinterpret_cast<const float4 *>(in.feat + ((size_t)ascene[h] * in.n + asrc[h]) * in.c + k0);
+                            done = true;
+                        }
+                    }
+                    if (!done) {
+                        float t[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++)
+                            t[q] = (k0 + q < cin) ? a_elem<MODE>(in, ar[h], k0 + q, cin, asrc[h], ascene[h]) : 0.0f;
+                        v = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                ra[h] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < B_PER_T; u++) {
+                const int f = tid + u * 256;
+                const int kk = f / (BN / 4), nq = f % (BN / 4);
+                const int k = kt * MLP_BK + kk;
+                const int nn = n0 + nq * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < cin) {
+                    const float *wr = w + (size_t)w_row<MODE>(k, in.c) * cout;
+                    if (b_vec4 && nn + 3 < cout) {
+                        v = *reinterpret_cast<const float4 *>(wr + nn);
+                    } else {
+                        if (nn + 0 < cout) v.x = wr[nn + 0];
+                        if (nn + 1 < cout) v.y = wr[nn + 1];
+                        if (nn + 2 < cout) v.z = wr[nn + 2];
+                        if (nn + 3 < cout) v.w = wr[nn + 3];
+                    }
+                }
+                rb[u] = v;
+            }
+        };
+        auto store_slab = [&](int buf) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int r = a_row + h * 64;
+                As[buf][a_kq * 4 + 0][r] = ra[h].x;
+                As[buf][a_kq * 4 + 1][r] = ra[h].y;
+                As[buf][a_kq * 4 + 2][r] = ra[h].z;
+                As[buf][a_kq * 4 + 3][r] = ra[h].w;
+            }
+#pragma unroll
+            for (int u = 0; u < B_PER_T; u++) {
+                const int f = tid + u * 256;
+                const int kk = f / (BN / 4), nq = f % (BN / 4);
+                *reinterpret_cast<float4 *>(&Bs[buf][kk][nq * 4]) = rb[u];
+            }
+        };
+
+        load_slab(0);
+        int buf = 0;
+        for (int kt = 0; kt < nk; kt++) {
+            store_slab(buf);
+            __syncthreads();
+            if (kt + 1 < nk) load_slab(kt + 1); // global loads in flight during the MFMAs
+            const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+            for (int k2 = 0; k2 < MLP_BK / 2; k2++) {
+                float a[MT], b[NT];
+#pragma unroll
+                for (int i = 0; i < MT; i++) a[i] = As[buf][k2 * 2 + kh][(wm * MT + i) * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < NT; j++) b[j] = Bs[buf][k2 * 2 + kh][(wn * NT + j) * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+            }
+            buf ^= 1;
+        }
+        __syncthreads(); // the next tile's first store_slab reuses buffer 0/1
+
+        // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = n0 + (wn * NT + j) * 32 + (lane & 31);
+            const bool cok = col < cout;
+            const float bv = (bias && cok) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < MT; i++) {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const long row = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                    if (cok && row < rows) {
+                        const float v = acc[i][j][e] + bv;
+                        z[(size_t)row * cout + col] = v;
+                        s1[j] += v;
+                        s2[j] += v * v;
+                    }
+                }
+            }
+        }
+    }
+    if (stats) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
+            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
+            const int col = n0 + (wn * NT + j) * 32 + (lane & 31);
+            if (lane < 32 && col < cout) {
+                unsafeAtomicAdd(&stats[col], (double)t1);
+                unsafeAtomicAdd(&stats[cout + col], (double)t2);
+            }
+        }
+    }
+}
+
+// scale/shift from accumulated sums (biased variance, utils.py BNReLU training mode)
+__global__ void bn_finalize_kernel(long rows, int c, const double *__restrict__ stats, const float *__restrict__ gamma,
+                                   const float *__restrict__ beta, float eps, float *__restrict__ scale,
+                                   float *__restrict__ shift, float *__restrict__ mean, float *__restrict__ var)
+{
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= c) return;
+    const double mu = stats[o] / (double)rows;
+    double v = stats[c + o] / (double)rows - mu * mu;
+    if (v < 0) v = 0;
+    const float muf = (float)mu, vf = (float)v;
+    const float sc = gamma[o] / sqrtf(vf + eps);
+    scale[o] = sc;
+    shift[o] = beta[o] - muf * sc;
+    if (mean) mean[o] = muf;
+    if (var) var[o] = vf;
+}
+
+// out[g,c] = max_k act(z[g*k..,c]*scale+shift); argmax optional.  One thread per (group, channel quad).
+__global__ void bn_relu_max_kernel(long groups, int k, int c, const float *__restrict__ z, const float *__restrict__ scale,
+                                   const float *__restrict__ shift, int relu, float *__restrict__ out,
+                                   int *__restrict__ argmax)
+{
+    const long total = groups * c;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / c;
+        const int ch = (int)(e - g * c);
+        const float sc = scale[ch], sh = shift[ch];
+        const float *__restrict__ p = z + (size_t)g * k * c + ch;
+        float best = 0;
+        int bi = 0;
+        for (int j = 0; j < k; j++) {
+            float v = p[(size_t)j * c] * sc + sh;
+            if (relu && !(v > 0.0f)) v = 0.0f;
+            if (j == 0 || v > best) {
+                best = v;
+                bi = j;
+            }
+        }
+        out[e] = best;
+        if (argmax) argmax[e] = bi;
+    }
+}
+
+__global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, const float *__restrict__ scale,
+                               const float *__restrict__ shift, int relu, float *__restrict__ y)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(e % c);
+        float v = z[e] * scale[ch] + shift[ch];
+        if (relu && !(v > 0.0f)) v = 0.0f;
+        y[e] = v;
+    }
+}
+
+static inline int grid_for(long total, int block)
+{
+    long g = (total + block - 1) / block;
+    if (g > 256 * 16) g = 256 * 16;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+template <int MODE>
+static int launch_linear(const MlpIn &in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
+                         double *stats, hipStream_t st)
+{
+    const long ntiles = (rows + MLP_BM - 1) / MLP_BM;
+    if (cout > 64) {
+        const int ny = (cout + 127) / 128;
+        long gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
+        if (gx < 1) gx = 1;
+        hipLaunchKernelGGL((mlp_linear_kernel<MODE, 2, 2, 2, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, in, rows, cin, cout,
+                           w, bias, z, stats);
+    } else {
+        long gx = ntiles < 2048 ? ntiles : 2048;
+        hipLaunchKernelGGL((mlp_linear_kernel<MODE, 4, 1, 1, 2>), dim3((unsigned)gx, 1), dim3(256), 0, st, in, rows, cin, cout,
+                           w, bias, z, stats);
+    }
+    return check_launch("mlp_linear");
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
+                                  const float *bias, float *z, double *stats, void *stream)
+{
+    VN_REQUIRE(in != nullptr, "mlp_linear: null input descriptor");
+    VN_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "mlp_linear expects rows >= 0, cin > 0, cout > 0");
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(w && z, "mlp_linear: null buffer");
+    MlpIn d;
+    d.x = in->x;
+    d.in_scale = in->in_scale;
+    d.in_shift = in->in_shift;
+    d.in_relu = in->in_relu;
+    d.xyz = in->xyz;
+    d.new_xyz = in->new_xyz;
+    d.feat = in->feat;
+    d.idx = in->idx;
+    d.n = in->n;
+    d.m = in->m;
+    d.nsample = in->nsample;
+    d.c = in->feat ? in->c : 0;
+    hipStream_t st = as_stream(stream);
+    if (in->x) {
+        VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_linear: in_scale and in_shift go together");
+        return launch_linear<0>(d, rows, cin, cout, w, bias, z, stats, st);
+    }
+    VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_linear: GATHER input needs xyz, new_xyz and idx");
+    VN_REQUIRE(in->b > 0 && in->n > 0 && in->m > 0 && in->nsample > 0, "mlp_linear: GATHER input needs b, n, m, nsample > 0");
+    VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_linear: rows must equal b*m*nsample for a GATHER input");
+    VN_REQUIRE(cin == 3 + d.c, "mlp_linear: cin must equal 3 + c for a GATHER input (utils.py:55)");
+    return launch_linear<1>(d, rows, cin, cout, w, bias, z, stats, st);
+}
+
+extern "C" int votenet_bn_finalize(long rows, int c, const double *stats, const float *gamma, const float *beta, float eps,
+                                   float *scale, float *shift, float *mean, float *var, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0, "bn_finalize expects rows > 0, c > 0");
+    VN_REQUIRE(stats && gamma && beta && scale && shift, "bn_finalize: null buffer");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), rows, c, stats, gamma, beta,
+                       eps, scale, shift, mean, var);
+    return check_launch("bn_finalize");
+}
+
+extern "C" int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *scale, const float *shift,
+                                   int relu, float *out, int *argmax, void *stream)
+{
+    VN_REQUIRE(groups >= 0 && k > 0 && c > 0, "bn_relu_max expects groups >= 0, k > 0, c > 0");
+    if (groups == 0) return VOTENET_OK;
+    VN_REQUIRE(z && scale && shift && out, "bn_relu_max: null buffer");
+    hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups, k, c, z,
+                       scale, shift, relu, out, argmax);
+    return check_launch("bn_relu_max");
+}
+
+extern "C" int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,
+                               void *stream)
+{
+    VN_REQUIRE(rows >= 0 && c > 0, "bn_relu expects rows >= 0, c > 0");
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(z && scale && shift && y, "bn_relu: null buffer");
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows * c, c, z, scale,
+                       shift, relu, y);
+    return check_launch("bn_relu");
+}

@@ -1,0 +1,107 @@
+"""Thin torch-tensor front-end of the grouped-MLP entry points of the C ABI
+(votenet_mlp_linear / votenet_bn_finalize / votenet_bn_relu_max / votenet_bn_relu).
+
+These are the building blocks pointnet2.py composes into the reference's SA / FP layer MLPs
+(utils.py:125-132,149-155,286-293).  No torch math happens here: tensors are device buffers.
+"""
+import ctypes
+
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
+
+
+def _desc_dense(x, scale=None, shift=None, relu=True):
+    d = L.MlpInput()
+    d.x = x.data_ptr()
+    d.in_scale = scale.data_ptr() if scale is not None else None
+    d.in_shift = shift.data_ptr() if shift is not None else None
+    d.in_relu = 1 if (relu and scale is not None) else 0
+    return d
+
+
+def _desc_gather(xyz, new_xyz, feat, idx):
+    d = L.MlpInput()
+    d.x = None
+    d.xyz = xyz.data_ptr()
+    d.new_xyz = new_xyz.data_ptr()
+    d.feat = feat.data_ptr() if feat is not None else None
+    d.idx = idx.data_ptr()
+    d.b, d.n = xyz.shape[0], xyz.shape[1]
+    d.m, d.nsample = idx.shape[1], idx.shape[2]
+    d.c = feat.shape[2] if feat is not None else 0
+    return d
+
+
+def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, want_stats=True):
+    """z = act(x) @ w + bias with act = relu(x*in_scale+in_shift) folded into the load (or identity).
+    x (rows, cin) f32 -> z (rows, cout), stats (2*cout) f64 [column sums of z, of z*z] or None."""
+    x = L.dev_f32(x, "mlp_linear x", 2)
+    w = L.dev_f32(w, "mlp_linear w", 2)
+    rows, cin = x.shape
+    if w.shape[0] != cin:
+        raise L.InvalidArgumentError("mlp_linear: w has %d rows, input has %d channels" % (w.shape[0], cin))
+    cout = w.shape[1]
+    z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=x.device) if want_stats else None
+    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
+                                           L.stream_ptr()))
+    return z, stats
+
+
+def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
+    """First SA-layer linear with the sample_and_group concat (utils.py:50-57) folded into the load:
+    row (b,j,k) = [xyz[b,idx]-new_xyz[b,j] (3), feat[b,idx] (c)].  -> z (b*m*nsample, cout), stats."""
+    xyz = L.dev_f32(xyz, "mlp_linear xyz", 3, 3)
+    new_xyz = L.dev_f32(new_xyz, "mlp_linear new_xyz", 3, 3)
+    idx = L.dev_i32(idx, "mlp_linear idx", 3)
+    feat = L.dev_f32(feat, "mlp_linear feat", 3) if feat is not None else None
+    w = L.dev_f32(w, "mlp_linear w", 2)
+    b, m, k = idx.shape
+    c = feat.shape[2] if feat is not None else 0
+    cin, cout = 3 + c, w.shape[1]
+    if w.shape[0] != cin:
+        raise L.InvalidArgumentError("mlp_linear: w has %d rows, grouped input has %d channels" % (w.shape[0], cin))
+    rows = b * m * k
+    z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
+    stats = torch.zeros(2 * cout, dtype=torch.float64, device=xyz.device) if want_stats else None
+    d = _desc_gather(xyz, new_xyz, feat, idx)
+    with torch.cuda.device(xyz.device):
+        L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
+                                           L.stream_ptr()))
+    return z, stats
+
+
+def bn_finalize(rows, stats, gamma, beta, eps=BN_EPS):
+    """-> scale, shift, mean, var (each (c,) f32): scale=gamma*rsqrt(var+eps), shift=beta-mean*scale."""
+    c = gamma.shape[0]
+    out = torch.empty((4, c), dtype=torch.float32, device=gamma.device)
+    with torch.cuda.device(gamma.device):
+        L.check(L.lib().votenet_bn_finalize(rows, c, L.ptr(stats), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(out[0]),
+                                            L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.stream_ptr()))
+    return out[0], out[1], out[2], out[3]
+
+
+def bn_relu_max(z, k, scale, shift, relu=True, want_argmax=False):
+    """(groups*k, c) raw z -> (groups, c) max over each group's k rows of act(z*scale+shift)."""
+    rows, c = z.shape
+    groups = rows // k
+    out = torch.empty((groups, c), dtype=torch.float32, device=z.device)
+    arg = torch.empty((groups, c), dtype=torch.int32, device=z.device) if want_argmax else None
+    with torch.cuda.device(z.device):
+        L.check(L.lib().votenet_bn_relu_max(groups, k, c, L.ptr(z), L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(out),
+                                            L.ptr(arg), L.stream_ptr()))
+    return out, arg
+
+
+def bn_relu(z, scale, shift, relu=True):
+    rows, c = z.shape
+    y = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        L.check(L.lib().votenet_bn_relu(rows, c, L.ptr(z), L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(y),
+                                        L.stream_ptr()))
+    return y
