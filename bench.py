@@ -1,0 +1,185 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path's headline benchmark (contract: see the task statement / DESIGN.md).
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one pass of the hot path over one batch of 8 synthetic 20480-point scenes per GPU
+(BASELINE.json configs[2]/[3]: VoteNet layer stack sa1..sa4, fp1, fp2, voting, proposal).
+Workloads:
+    train : forward + backward + (N>1: one RCCL all-reduce of the flat gradient bucket) + Adam
+    fwd   : forward only (BASELINE.json configs[1] plus voting + proposal)
+Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
+    ap.add_argument("--points", type=int, default=20480, help="points per scene (config.py:1)")
+    ap.add_argument("--workload", default=None, choices=["train", "fwd"])
+    ap.add_argument("--scene", default="room", choices=["room", "uniform"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(points, scene_kind):
+    """The CPU oracle (the restatement of the reference's CPU path, oracle/) timed on ONE scene of the
+    same workload, forward only, single thread.  Bounded: ~10-30 s."""
+    import numpy as np
+    from oracle import oracle as O
+    from votenet_amd import synth
+    xyz = (synth.room_batch(1, points, 1000) if scene_kind == "room" else synth.uniform_batch(1, points, 1000))
+    rng = np.random.default_rng(0)
+
+    def mlp(x, dims, k=None, last_plain=False):
+        for i in range(len(dims) - 1):
+            w = (rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i])).astype(np.float32)
+            z = O.linear(x, w, np.zeros(dims[i + 1], np.float32))
+            if last_plain and i == len(dims) - 2:
+                x = z
+            else:
+                mean, var = O.bn_stats(z)
+                x = O.bn_relu(z, mean, var, np.ones(dims[i + 1], np.float32), np.zeros(dims[i + 1], np.float32))
+        return O.max_over_k(x, k) if k else x
+
+    def sa(xyz_, pts, m, r, k, widths, sample_xyz=None):
+        fidx = O.farthest_point_sample(m, sample_xyz if sample_xyz is not None else xyz_)
+        new_xyz = O.gather_point(xyz_, fidx)
+        idx, _ = O.query_ball_point(r, k, xyz_, new_xyz)
+        g = O.group_concat(xyz_, new_xyz, pts, idx).reshape(-1, 3 + pts.shape[2])
+        return new_xyz, mlp(g, [g.shape[1]] + widths, k).reshape(1, m, -1)
+
+    def fp(x1, x2, p1, p2, widths):
+        dist, idx = O.three_nn(x1, x2)
+        itp = O.three_interpolate(p2, idx, O.three_nn_weights(dist))
+        x = np.concatenate([itp, p1], 2).reshape(-1, itp.shape[2] + p1.shape[2])
+        return mlp(x, [x.shape[1]] + widths).reshape(1, x1.shape[1], -1)
+
+    t0 = time.perf_counter()
+    l1x, l1p = sa(xyz, xyz, 2048, 0.2, 64, [64, 64, 128])
+    l2x, l2p = sa(l1x, l1p, 1024, 0.4, 64, [128, 128, 256])
+    l3x, l3p = sa(l2x, l2p, 512, 0.8, 64, [128, 128, 256])
+    l4x, l4p = sa(l3x, l3p, 256, 1.2, 64, [128, 128, 256])
+    l3p2 = fp(l3x, l4x, l3p, l4p, [256, 256])
+    seeds = fp(l2x, l3x, l2p, l3p2, [256, 256])
+    x = np.concatenate([l2x, seeds], 2).reshape(-1, 259)
+    votes = (x + mlp(x, [259, 256, 256, 259], last_plain=True)).reshape(1, 1024, 259)
+    vx, vp = np.ascontiguousarray(votes[..., :3]), np.ascontiguousarray(votes[..., 3:])
+    px, pp = sa(vx, vp, 256, 0.3, 64, [128, 128, 128], sample_xyz=l2x)
+    mlp(pp.reshape(-1, 128), [128, 128, 128, 79], last_plain=True)
+    dt = time.perf_counter() - t0
+    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": 1, "kind": "port",
+            "sample": "forward pass of 1 synthetic %d-pt scene through the same layer stack on the CPU oracle "
+                      "(single thread, %.1f s; the oracle has no backward)" % (points, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from votenet_amd import model as VM
+    from votenet_amd import synth, tf_sampling
+    have_train = hasattr(VM.VoteNetHotPath, "train_step")
+    workload = args.workload or ("train" if have_train else "fwd")
+
+    B, n = args.batch, args.points
+    gen = synth.room_batch if args.scene == "room" else synth.uniform_batch
+    x = torch.from_numpy(gen(B, n, 1000 + rank * B)).to(dev)  # disjoint seeds per rank, resident in HBM
+    net = VM.VoteNetHotPath(dev, seed=0)
+    cot = None
+    if workload == "train":
+        cot = net.make_cotangents(B, seed=rank)
+        if world > 1:
+            dist.broadcast(net.store.flat, 0)
+
+    def step():
+        if workload == "train":
+            net.train_step(x, cot, world)
+        else:
+            net.forward(x)
+
+    tf_sampling.PROFILE_EVENTS = None
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    tf_sampling.PROFILE_EVENTS = []  # HIP events around every FPS launch, on the launch stream
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    events = tf_sampling.PROFILE_EVENTS
+    tf_sampling.PROFILE_EVENTS = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        # dominant kernel: the sa1 farthest-point-sampling launch (n=20480 -> 2048)
+        m1 = net.sa1.npoint
+        durs = [e0.elapsed_time(e1) for (e0, e1, b_, n_, m_) in events if n_ == n and m_ == m1]
+        roof = None
+        if durs:
+            avg_ms = sum(durs) / len(durs)
+            alg = B * (m1 - 1) * n * 16 + B * n * 12 + B * m1 * 4  # B*(m-1)*n*16 + B*n*12 + B*m*4
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+            if os.path.exists(pmc):
+                try:
+                    traffic = json.load(open(pmc)).get("fps_reg_kernel", {}).get("hbm_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            ach = alg / (avg_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "kernel": "fps_reg_kernel<16,20> (sa1 FPS %d->%d, on-chip resident)" % (n, m1),
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(n, args.scene)
+        out = {
+            "metric": "SUN RGB-D 20k-pt scenes/sec (%s)" % ("fwd+bwd" if workload == "train" else "fwd"),
+            "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("VoteNet hot path %s: sa1-4 + fp1-2 + voting + proposal, %d scenes x %d pts per GPU, "
+                                    "%s scenes" % ("train step (fwd+bwd+Adam, synthetic cotangents in place of the loss graph)"
+                                                   if workload == "train" else "forward", B, n, args.scene)),
+                       "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,73 @@
+"""Minimal driver of the hot path in VoteNet's layer configuration (the caller side of the path).
+
+This is NOT a reimplementation of the reference's model.py (losses, GT assignment and box decode
+are out of scope): it wires the SA / FP / voting / proposal layers with the
+exact shapes and hyper-parameters of model.py:39-49,53-61,89-93 so that the hot path can be
+driven, checked and timed end to end:
+
+    sa1 20480->2048 r0.2 K64 [64,64,128]     sa2 ->1024 r0.4 [128,128,256]
+    sa3 ->512 r0.8 [128,128,256]             sa4 ->256 r1.2 [128,128,256]
+    fp1 (l3<-l4) [256,256]                   fp2 (l2<-l3) [256,256]         seeds = l2_xyz
+    voting FC 259->256->256->259 (BNReLU,BNReLU,none); votes = [seed_xyz, seed_feat] + offset
+    proposal SA on votes, FPS on seeds (utils.py:42-43), 256 x r0.3 K64 [128,128,128] + [128,128,79]
+"""
+import torch
+
+from . import mlp as M
+from . import pointnet2 as P
+
+NH, NS, NC = 12, 10, 10  # config.py:2-3
+PROPOSAL_NUM = 256       # config.py:6
+PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
+
+
+class VoteNetHotPath:
+    def __init__(self, device, seed=0, npoints=(2048, 1024, 512, 256)):
+        self.device = device
+        s = P.ParamStore(device)
+        self.store = s
+        n1, n2, n3, n4 = npoints
+        self.sa1 = P.SAModule(s, "sa1", n1, 0.2, 64, 3, [64, 64, 128])      # model.py:39 (l0_points = xyz, C=3)
+        self.sa2 = P.SAModule(s, "sa2", n2, 0.4, 64, 128, [128, 128, 256])  # model.py:41
+        self.sa3 = P.SAModule(s, "sa3", n3, 0.8, 64, 256, [128, 128, 256])  # model.py:43
+        self.sa4 = P.SAModule(s, "sa4", n4, 1.2, 64, 256, [128, 128, 256])  # model.py:45
+        self.fp1 = P.FPModule(s, "fp1", 256, 256, [256, 256])               # model.py:48
+        self.fp2 = P.FPModule(s, "fp2", 256, 256, [256, 256])               # model.py:49
+        self.voting = P.make_mlp(s, "voting", 259, [256, 256, 259], "fc", last_plain=True)  # model.py:53-57
+        self.proposal = P.SAModule(s, "proposal", PROPOSAL_NUM, 0.3, 64, 256, [128, 128, 128],
+                                   mlp2=[128, 128, PROPOSAL_OUT])           # model.py:89-93
+        s.materialize(seed)
+
+    # ---- forward pieces -------------------------------------------------------------
+    def backbone(self, x, tape=None):
+        """model.py:35-50.  x (B,n,3) -> seeds_xyz (B,1024,3), seeds_points (B,1024,256)."""
+        l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape)
+        l2_xyz, l2_p, _ = self.sa2.forward(l1_xyz, l1_p, tape=tape)
+        l3_xyz, l3_p, _ = self.sa3.forward(l2_xyz, l2_p, tape=tape)
+        l4_xyz, l4_p, _ = self.sa4.forward(l3_xyz, l3_p, tape=tape)
+        l3_p2 = self.fp1.forward(l3_xyz, l4_xyz, l3_p, l4_p, tape=tape)
+        seeds_p = self.fp2.forward(l2_xyz, l3_xyz, l2_p, l3_p2, tape=tape)
+        return l2_xyz, seeds_p
+
+    def vote(self, seeds_xyz, seeds_points, tape=None):
+        """model.py:53-61: votes = [seeds_xyz, seeds_points] + FC(...)."""
+        b, n = seeds_xyz.shape[:2]
+        x = torch.cat([seeds_xyz, seeds_points], dim=2).view(b * n, 259)
+        recs = []
+        off, _, _ = P.mlp_chain_forward(self.voting, b * n, ("dense", x), recs)
+        votes = (x + off).view(b, n, 259)
+        if tape is not None:
+            tape.append(dict(op="vote", recs=recs, b=b, n=n))
+        return votes[..., :3].contiguous(), votes[..., 3:].contiguous()
+
+    def propose(self, votes_xyz, votes_points, seeds_xyz, tape=None):
+        """model.py:89-93: SA on votes with FPS on the seeds -> proposals_xyz (B,256,3), output (B,256,79)."""
+        p_xyz, p_out, _ = self.proposal.forward(votes_xyz, votes_points, sample_xyz=seeds_xyz, tape=tape)
+        return p_xyz, p_out
+
+    def forward(self, x, tape=None):
+        seeds_xyz, seeds_p = self.backbone(x, tape)
+        v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape)
+        p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
+        return dict(seeds_xyz=seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
+                    proposals_xyz=p_xyz, proposals_output=p_out)

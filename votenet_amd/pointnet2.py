@@ -1,0 +1,182 @@
+"""PointNet++ SA / FP layers of VoteNet on the HIP hot path -- mirror of the reference's utils.py.
+
+    sample_and_group     utils.py:25-61
+    pointnet_sa_module   utils.py:93-158   (group_all=False, pooling='max', knn=False: the only
+                                            configuration model.py uses)
+    pointnet_fp_module   utils.py:266-294
+
+The reference builds these from ~6 TF graph nodes per MLP layer on a materialised
+(B,m,K,3+C) tensor.  Here a layer is ONE fused launch (votenet_mlp_linear): the grouped
+tensor is never written, BN+ReLU of layer l is applied while layer l+1 loads its input, and
+BatchNorm batch statistics come out of the GEMM epilogue.  torch is used for buffers only;
+the backward pass is explicit (tape + hand-written backward kernels), not torch.autograd.
+
+Parameters live in one flat fp32 bucket (ParamStore) so that data-parallel training needs a
+single RCCL all-reduce over one contiguous gradient buffer per step.
+"""
+import math
+
+import torch
+
+from . import mlp as M
+from . import tf_grouping, tf_interpolate, tf_sampling
+
+
+# --------------------------------------------------------------------------- parameters
+class ParamStore:
+    """All trainable tensors as views into one flat fp32 buffer (and one flat gradient buffer)."""
+
+    def __init__(self, device):
+        self.device = device
+        self._specs = []  # (name, shape, init)
+        self.flat = None
+        self.grad = None
+        self.views = {}
+        self.gviews = {}
+
+    def declare(self, name, shape, init):
+        self._specs.append((name, tuple(shape), init))
+
+    def materialize(self, seed=0):
+        # every view starts on a 16-byte boundary (float4 loads of scale/shift/W rows)
+        offs, total = [], 0
+        for _, shape, _ in self._specs:
+            offs.append(total)
+            total += (math.prod(shape) + 3) // 4 * 4
+        self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        gen = torch.Generator(device="cpu").manual_seed(seed)
+        for (name, shape, init), off in zip(self._specs, offs):
+            n = math.prod(shape)
+            v = self.flat[off:off + n].view(shape)
+            if init == "he":
+                v.copy_((torch.randn(shape, generator=gen) * math.sqrt(2.0 / shape[0])).to(self.device))
+            elif init == "ones":
+                v.fill_(1.0)
+            self.views[name] = v
+            self.gviews[name] = self.grad[off:off + n].view(shape)
+        return self
+
+    def __getitem__(self, name):
+        return self.views[name]
+
+    def g(self, name):
+        return self.gviews[name]
+
+    def numel(self):
+        return sum(math.prod(s) for _, s, _ in self._specs)
+
+
+class Layer:
+    """One 1x1 Conv2D / FullyConnected (+ BatchNorm + ReLU): utils.py:126-127, model.py:56."""
+
+    def __init__(self, store, name, cin, cout, bn=True, relu=True):
+        self.store, self.name, self.cin, self.cout, self.bn, self.relu = store, name, cin, cout, bn, relu
+        store.declare(name + "/W", (cin, cout), "he")
+        store.declare(name + "/b", (cout,), "zeros")
+        if bn:
+            store.declare(name + "/gamma", (cout,), "ones")
+            store.declare(name + "/beta", (cout,), "zeros")
+
+    def p(self, k):
+        return self.store[self.name + "/" + k]
+
+    def gp(self, k):
+        return self.store.g(self.name + "/" + k)
+
+
+def make_mlp(store, scope, cin, widths, prefix="conv", last_plain=False):
+    layers = []
+    for i, co in enumerate(widths):
+        plain = last_plain and i == len(widths) - 1
+        layers.append(Layer(store, "%s/%s%d" % (scope, prefix, i), cin, co, bn=not plain, relu=not plain))
+        cin = co
+    return layers
+
+
+# --------------------------------------------------------------------------- MLP chains
+def mlp_chain_forward(layers, rows, first, tape):
+    """Run a chain of layers over `rows` rows.  first = ('gather', xyz, new_xyz, feat, idx) or ('dense', x).
+    Returns (z_last, scale_last, shift_last): the last layer's RAW output and its folded BN
+    (None, None for a plain last layer).  Appends one record per layer to `tape`."""
+    z = sc = sh = None
+    prev_relu = False
+    for i, L in enumerate(layers):
+        w, b = L.p("W"), L.p("b")
+        if i == 0 and first[0] == "gather":
+            _, xyz, new_xyz, feat, idx = first
+            zn, st = M.linear_gather(xyz, new_xyz, feat, idx, w, b, want_stats=L.bn)
+            rec = dict(layer=L, kind="gather", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx)
+        elif i == 0:
+            zn, st = M.linear_dense(first[1], w, b, want_stats=L.bn)
+            rec = dict(layer=L, kind="dense", x=first[1], in_scale=None, in_shift=None, in_relu=False)
+        else:
+            zn, st = M.linear_dense(z, w, b, sc, sh, prev_relu, want_stats=L.bn)
+            rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
+        if L.bn:
+            sc, sh, mean, var = M.bn_finalize(rows, st, L.p("gamma"), L.p("beta"))
+            rec.update(scale=sc, shift=sh, mean=mean, var=var)
+        else:
+            sc = sh = None
+        rec.update(z=zn, rows=rows)
+        tape.append(rec)
+        z, prev_relu = zn, L.relu
+    return z, sc, sh
+
+
+# --------------------------------------------------------------------------- SA / FP modules
+def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None):
+    """utils.py:42-49 (geometry part): FPS on sample_xyz if given, centres gathered from xyz."""
+    fps_idx = tf_sampling.farthest_point_sample(npoint, sample_xyz if sample_xyz is not None else xyz)
+    new_xyz = tf_sampling.gather_point(xyz, fps_idx)
+    idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    return fps_idx, new_xyz, idx, pts_cnt
+
+
+class SAModule:
+    """pointnet_sa_module (utils.py:93-158) with group_all=False, pooling='max', knn=False, use_xyz=True."""
+
+    def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None):
+        self.npoint, self.radius, self.nsample = npoint, radius, nsample
+        self.mlp = make_mlp(store, scope, 3 + cin, mlp, "conv")
+        self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
+
+    def forward(self, xyz, points, sample_xyz=None, tape=None):
+        """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,C'), idx (B,m,K)."""
+        b = xyz.shape[0]
+        fps_idx, new_xyz, idx, _ = sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
+        recs = []
+        rows = b * self.npoint * self.nsample
+        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs)
+        pooled, argmax = M.bn_relu_max(z, self.nsample, sc, sh, True, want_argmax=tape is not None)  # utils.py:132
+        recs2 = []
+        out = pooled
+        if self.mlp2:
+            z2, sc2, sh2 = mlp_chain_forward(self.mlp2, b * self.npoint, ("dense", pooled), recs2)
+            out = z2  # last conv_post layer has no activation (utils.py:153)
+        if tape is not None:
+            tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, fps_idx=fps_idx, idx=idx,
+                             xyz=xyz, points=points, new_xyz=new_xyz, b=b))
+        return new_xyz, out.view(b, self.npoint, -1), idx
+
+
+class FPModule:
+    """pointnet_fp_module (utils.py:266-294): 3-NN inverse-distance interpolation + MLP."""
+
+    def __init__(self, store, scope, cin1, cin2, mlp):
+        self.mlp = make_mlp(store, scope, cin1 + cin2, mlp, "conv_")
+
+    def forward(self, xyz1, xyz2, points1, points2, tape=None):
+        b, n1 = xyz1.shape[:2]
+        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)          # utils.py:278
+        weight = tf_interpolate.three_nn_weights(dist)           # utils.py:279-282
+        interp = tf_interpolate.three_interpolate(points2, idx, weight)  # utils.py:283
+        x = torch.cat([interp, points1], dim=2) if points1 is not None else interp  # utils.py:286
+        rows = b * n1
+        recs = []
+        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("dense", x.view(rows, -1)), recs)
+        y = M.bn_relu(z, sc, sh, True)
+        if tape is not None:
+            tape.append(dict(op="fp", module=self, recs=recs, idx=idx, weight=weight, m=xyz2.shape[1],
+                             c2=points2.shape[2], c1=0 if points1 is None else points1.shape[2], b=b, n1=n1))
+        return y.view(b, n1, -1)

@@ -9,6 +9,10 @@ import torch
 
 from . import _lib as L
 
+# bench.py sets this to a list to bracket every FPS launch with HIP events recorded on the
+# launch stream (torch's current stream): entries are (start, end, b, n, npoint).
+PROFILE_EVENTS = None
+
 
 def farthest_point_sample(npoint, inp):
     """tf_sampling.py:48-56.  int, (B,n,3) f32 -> (B,npoint) int32.  No gradient."""
@@ -19,7 +23,13 @@ def farthest_point_sample(npoint, inp):
     nt = L.lib().votenet_fps_temp_floats(b, n)
     temp = torch.empty(nt, dtype=torch.float32, device=inp.device) if nt else None
     with torch.cuda.device(inp.device):
+        if PROFILE_EVENTS is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(L.lib().votenet_farthest_point_sample(b, n, npoint, L.ptr(inp), L.ptr(temp), L.ptr(out), L.stream_ptr()))
+        if PROFILE_EVENTS is not None:
+            e1.record()
+            PROFILE_EVENTS.append((e0, e1, b, n, npoint))
     return out
 
 
