@@ -176,6 +176,50 @@ int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *
 int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,
                     void *stream);
 
+
+/* ---------------------------------------------------------------- grouped-point MLP, backward
+ * (the reference obtains these from TensorFlow autodiff over Conv2D / BatchNorm / ReLU /
+ * reduce_max nodes plus GroupPointGrad, tf_grouping.py:42-46).  Training-mode BatchNorm:
+ *   da' = da * [z*scale+shift > 0]        (ReLU mask; skipped when relu == 0)
+ *   s1 = sum_r da', s2 = sum_r da' * zhat, zhat = (z-mean)*rsqrt(var+eps)
+ *   dz = gamma*rsqrt(var+eps) * (da' - s1/N - zhat*s2/N),  dgamma += s2,  dbeta += s1
+ * da is dense (rows x c) when k == 0; when k > 0 it is the max-pool scatter of gout (rows/k x c)
+ * through argmax (rows/k x c): da[g*k+argmax[g,ch], ch] = gout[g,ch], zero elsewhere (utils.py:132). */
+int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
+                               const float *scale, const float *shift, const float *mean, const float *var, float eps,
+                               int relu, double *sums /* 2*c, pre-zeroed */, void *stream);
+int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
+                              const float *scale, const float *shift, const float *mean, const float *var, float eps,
+                              int relu, const float *gamma, const double *sums, float *dz /* rows x c */,
+                              float *dgamma /* += , may be NULL */, float *dbeta /* += , may be NULL */, void *stream);
+
+/* dbias[c] += column sums of dz (rows x c); scratch: c doubles. */
+int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float *dbias, void *stream);
+
+/* dw (cin x cout, the caller's row order) += input(rows x cin)^T * dz (rows x cout), the input
+ * described exactly as for votenet_mlp_linear (same fused GATHER / DENSE+BNReLU loaders).
+ * The contraction over rows is split across workgroups; partial tiles are added with fp32 atomics
+ * (summation order unspecified, like the reference's cuDNN / atomics-based gradients). */
+int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
+                      void *stream);
+
+/* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78)
+ * on the feature columns + the gradients of grouped_xyz - tile(new_xyz) on the first three:
+ *   d_in (b*m*nsample x (3+c)), columns [dxyz, feat]:
+ *   d_feat[b,idx,:] += d_in[:,3:] ; d_xyz[b,idx,:] += d_in[:,:3] ; d_new_xyz[b,j,:] -= sum_k d_in[:,:3]
+ * Each output may be NULL (not needed); outputs are accumulated into (pre-zeroed by the caller). */
+int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_in, const int *idx,
+                              float *d_feat, float *d_xyz, float *d_new_xyz, void *stream);
+
+/* Optimizer of model.py:240-250 over one flat parameter bucket: per-tensor
+ * tf.clip_by_average_norm(g, clip) = g*clip/max(||g||_2/numel, clip) (skipped when clip <= 0), then
+ * Adam(lr, beta1, beta2, eps) with bias correction for `step` (1-based).  seg: 2*ntensors element
+ * offsets (device, int64), [start, end) of each tensor inside the bucket; g is pre-multiplied by grad_scale
+ * (1/world_size after a summing all-reduce).  sumsq_scratch: ntensors floats. */
+int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scratch, float *p, const float *g, float *m, float *v,
+                      float lr, float beta1, float beta2, float eps, int step, float grad_scale, float clip_avg_norm,
+                      void *stream);
+
 #ifdef __cplusplus
 }
 #endif

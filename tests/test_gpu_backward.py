@@ -1,0 +1,165 @@
+"""GPU: the explicit backward pass (hand-written HIP kernels) against torch autograd in float64 over the
+same composition -- the analogue of the reference's own gradient tests
+(tf_grouping_op_test.py:23-25, tf_interpolate_op_test.py:19-21: compute_gradient_error < 1e-4)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+EPS = 1e-5
+
+
+def ref_chain(x, layers, params, recs):
+    """float64 autograd reference of mlp_chain_forward (BN in training mode, biased variance).
+    ReLU uses the ACTIVE SET of the device forward pass (recs), so both sides differentiate the same
+    piece of the piecewise-linear function; a fp32-vs-fp64 sign flip of a near-zero pre-activation
+    would otherwise reroute gradients and say nothing about the backward kernels."""
+    for L, r in zip(layers, recs):
+        z = x @ params[L.name + "/W"] + params[L.name + "/b"]
+        if L.bn:
+            mu = z.mean(0)
+            var = z.var(0, unbiased=False)
+            z = params[L.name + "/gamma"] * (z - mu) / torch.sqrt(var + EPS) + params[L.name + "/beta"]
+        if L.relu:
+            mask = (r["z"] * r["scale"] + r["shift"] > 0).double()
+            z = z * mask
+        x = z
+    return x
+
+
+def ref_sa(mod, params, xyz, pts, rec):
+    b, m, k = rec["idx"].shape
+    idx = rec["idx"].long()
+    bi = torch.arange(b, device=xyz.device)[:, None, None]
+    new_xyz = xyz[torch.arange(b, device=xyz.device)[:, None], rec["fps_idx"].long()]
+    g = xyz[bi, idx] - new_xyz[:, :, None, :]
+    if pts is not None:
+        g = torch.cat([g, pts[bi, idx]], -1)
+    y = ref_chain(g.reshape(b * m * k, -1), mod.mlp, params, rec["recs"]).view(b * m, k, -1)
+    y = y.gather(1, rec["argmax"].long()[:, None, :])[:, 0, :]  # max over k through the device argmax
+    if mod.mlp2:
+        y = ref_chain(y, mod.mlp2, params, rec["recs2"])
+    return new_xyz, y.view(b, m, -1)
+
+
+def ref_fp(mod, params, p1, p2, rec):
+    b, n1 = rec["b"], rec["n1"]
+    idx, w = rec["idx"].long(), rec["weight"].double()
+    bi = torch.arange(b, device=p2.device)[:, None, None]
+    interp = (p2[bi, idx] * w[..., None]).sum(2)
+    x = torch.cat([interp, p1], 2)
+    return ref_chain(x.view(b * n1, -1), mod.mlp, params, rec["recs"]).view(b, n1, -1)
+
+
+def relerr(a, b):
+    return float((a - b).abs().max() / max(1e-12, float(b.abs().max())))
+
+
+def perturb(net, dev):
+    g = torch.Generator().manual_seed(1)
+    for name, v in net.store.views.items():
+        if name.endswith("gamma"):
+            v.copy_((1 + 0.2 * torch.randn(v.shape, generator=g)).to(dev))
+        if name.endswith("beta") or name.endswith("/b"):
+            v.copy_((0.1 * torch.randn(v.shape, generator=g)).to(dev))
+
+
+def test_full_backward_vs_autograd(hiplib, dev):
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    x = torch.from_numpy(synth.room_batch(2, 2048, 5)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=2, npoints=(512, 256, 128, 64))
+    perturb(net, dev)
+    cot = net.make_cotangents(2, seed=0)
+    cot = {k: v * 100 for k, v in cot.items()}
+    net.store.grad.zero_()
+    tape = []
+    out = net.forward(x, tape)
+    net.backward(tape, cot)
+
+    # float64 autograd reference over the same indices (the geometry ops have no gradient)
+    params = {k: v.detach().double().clone().requires_grad_(True) for k, v in net.store.views.items()}
+    xd = x.double()
+    sa1, sa2, sa3, sa4, fp1, fp2, vote, prop = tape
+    l1x, l1p = ref_sa(net.sa1, params, xd, xd, sa1)
+    l2x, l2p = ref_sa(net.sa2, params, l1x, l1p, sa2)
+    l3x, l3p = ref_sa(net.sa3, params, l2x, l2p, sa3)
+    l4x, l4p = ref_sa(net.sa4, params, l3x, l3p, sa4)
+    l3p2 = ref_fp(net.fp1, params, l3p, l4p, fp1)
+    seeds = ref_fp(net.fp2, params, l2p, l3p2, fp2)
+    xx = torch.cat([l2x, seeds], 2).view(-1, 259)
+    votes = (xx + ref_chain(xx, net.voting, params, vote["recs"])).view(2, -1, 259)
+    vx, vp = votes[..., :3], votes[..., 3:]
+    _, pout = ref_sa(net.proposal, params, vx, vp, prop)
+    assert relerr(out["proposals_output"].double(), pout.detach()) < 2e-4
+    loss = (pout * cot["proposals_output"].double()).sum() + (vx * cot["votes_xyz"].double()).sum()
+    loss.backward()
+    worst = {}
+    for name in net.store.views:
+        ref = params[name].grad
+        got = net.store.g(name).double()
+        if name.endswith("/b") and not (name.endswith("fc2/b") or name.endswith("conv_post_2/b")):
+            # bias of a BatchNorm'ed layer: exactly zero here, round-off in autograd
+            assert float(got.abs().max()) == 0.0
+            continue
+        scale = max(float(ref.abs().max()), 1e-8)
+        worst[name] = float((got - ref).abs().max()) / scale
+    bad = {k: round(v, 5) for k, v in worst.items() if v > 2e-3}
+    print("WORST", sorted(((round(v, 6), k) for k, v in worst.items()), reverse=True)[:30])
+    assert not bad, bad
+    assert np.median(list(worst.values())) < 2e-4
+
+
+def test_wgrad_and_input_grad_unit(hiplib, dev):
+    """One gather layer + pool, checked element-wise including the xyz gradients (proposal-layer path)."""
+    from votenet_amd import pointnet2 as P
+    store = P.ParamStore(dev)
+    mod = P.SAModule(store, "t", 32, 0.4, 16, 8, [32, 16])
+    store.materialize(4)
+    g = torch.Generator().manual_seed(3)
+    xyz = torch.rand(2, 200, 3, generator=g).to(dev)
+    pts = torch.randn(2, 200, 8, generator=g).to(dev)
+    tape = []
+    _, out, _ = mod.forward(xyz, pts, tape=tape)
+    gout = torch.randn(out.shape, generator=g).to(dev)
+    d_feat, d_xyz = mod.backward(tape[0], gout, need_feat_grad=True, need_xyz_grad=True)
+    params = {k: v.detach().double().clone().requires_grad_(True) for k, v in store.views.items()}
+    xd, pd = xyz.double().requires_grad_(True), pts.double().requires_grad_(True)
+    _, y = ref_sa(mod, params, xd, pd, tape[0])
+    (y * gout.double()).sum().backward()
+    assert relerr(out.double(), y.detach()) < 1e-5
+    assert relerr(d_feat.double(), pd.grad) < 1e-4
+    assert relerr(d_xyz.double(), xd.grad) < 1e-4
+    for name in store.views:
+        if name.endswith("/b"):
+            continue
+        assert relerr(store.g(name).double(), params[name].grad) < 1e-4, name
+
+
+def test_clip_adam_vs_reference(hiplib, dev):
+    """model.py:240-250: per-tensor tf.clip_by_average_norm(g, 0.5) then Adam(1e-3)."""
+    from votenet_amd import model as VM
+    net = VM.VoteNetHotPath(dev, seed=1, npoints=(64, 32, 16, 8))
+    net.init_optimizer(lr=1e-3)
+    gen = torch.Generator().manual_seed(0)
+    p0 = {k: v.clone() for k, v in net.store.views.items()}
+    m = {k: torch.zeros_like(v) for k, v in p0.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in p0.items()}
+    from votenet_amd import mlp as M
+    for step in (1, 2, 3):
+        grads = {}
+        for i, (k, v) in enumerate(net.store.views.items()):
+            gsc = 1000.0 if i % 3 == 0 else 0.01  # some tensors above the clip threshold, some below
+            gt = (torch.randn(v.shape, generator=gen) * gsc).to(dev)
+            net.store.g(k).copy_(gt)
+            grads[k] = gt
+        M.clip_adam(net._seg, net._sumsq, net.store.flat, net.store.grad, net._m, net._v, 1e-3, step, grad_scale=0.5)
+        for k in p0:
+            gk = grads[k] * 0.5
+            avg = gk.norm() / gk.numel()
+            gk = gk * 0.5 / torch.maximum(avg, torch.tensor(0.5, device=dev))
+            m[k] = 0.9 * m[k] + 0.1 * gk
+            v2[k] = 0.999 * v2[k] + 0.001 * gk * gk
+            p0[k] = p0[k] - 1e-3 * (m[k] / (1 - 0.9 ** step)) / (torch.sqrt(v2[k] / (1 - 0.999 ** step)) + 1e-8)
+    for k in p0:
+        assert torch.allclose(net.store[k], p0[k], rtol=1e-4, atol=1e-6), k

@@ -1,0 +1,509 @@
+// mlp_bwd.hip -- backward pass of the grouped-point MLP for gfx950.
+//
+// The reference gets these gradients from TensorFlow autodiff over Conv2D / BatchNorm / ReLU /
+// reduce_max graph nodes plus its registered GroupPointGrad (tf_grouping.py:42-46).  Here:
+//   votenet_bn_backward_reduce : s1 = sum(da'), s2 = sum(da' * zhat) per channel, da' = da * [act > 0];
+//                                da is either dense or the max-pool scatter of (gout, argmax)
+//   votenet_bn_backward_apply  : dz = gamma*invstd * (da' - s1/N - zhat*s2/N)   (training-mode BN)
+//   votenet_mlp_wgrad          : dW += A^T dz on v_mfma_f32_32x32x2_f32 with the SAME fused A loaders
+//                                as the forward pass (gather / dense + folded BN+ReLU); the
+//                                contraction runs over rows, split across workgroups
+//   (input gradients da = dz W^T reuse votenet_mlp_linear with W^T)
+//   votenet_group_concat_grad  : scatter of the first layer's input gradient back to the feature
+//                                and xyz tables (GroupPointGrad + the tile/subtract of utils.py:51)
+//   votenet_clip_adam          : per-tensor clip_by_average_norm + Adam over the flat bucket (model.py:240-250)
+#include "common.h"
+
+namespace votenet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpIn {
+    const float *x;
+    const float *in_scale;
+    const float *in_shift;
+    int in_relu;
+    const float *xyz;
+    const float *new_xyz;
+    const float *feat;
+    const int *idx;
+    int n, m, nsample, c;
+};
+
+// ---------------------------------------------------------------- BN backward: reductions
+// block = 64 columns x 4 row-lanes; grid.x strides over rows, grid.y over column tiles of 64
+__global__ __launch_bounds__(256) void bn_bwd_reduce_dense_kernel(long rows, int c, const float *__restrict__ da,
+                                                                  const float *__restrict__ z, const float *__restrict__ scale,
+                                                                  const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                  const float *__restrict__ var, float eps, int relu,
+                                                                  double *__restrict__ sums)
+{
+    __shared__ float sh1[4][64], sh2[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cx;
+    float s1 = 0, s2 = 0;
+    if (col < c) {
+        const float sc = scale[col], sf = shift[col], mu = mean[col], inv = 1.0f / sqrtf(var[col] + eps);
+        for (long r = (long)blockIdx.x * 4 + ry; r < rows; r += (long)gridDim.x * 4) {
+            const float zz = z[(size_t)r * c + col];
+            float g = da[(size_t)r * c + col];
+            if (relu && !(zz * sc + sf > 0.0f)) g = 0.0f;
+            s1 += g;
+            s2 += g * ((zz - mu) * inv);
+        }
+    }
+    sh1[ry][cx] = s1;
+    sh2[ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        const float t1 = (sh1[0][cx] + sh1[1][cx]) + (sh1[2][cx] + sh1[3][cx]);
+        const float t2 = (sh2[0][cx] + sh2[1][cx]) + (sh2[2][cx] + sh2[3][cx]);
+        unsafeAtomicAdd(&sums[col], (double)t1);
+        unsafeAtomicAdd(&sums[c + col], (double)t2);
+    }
+}
+
+// max-pool mode: da'[g*k+argmax[g,col], col] = gout[g,col] * [act > 0], zero elsewhere
+__global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(long groups, int k, int c, const float *__restrict__ gout,
+                                                                 const int *__restrict__ argmax, const float *__restrict__ z,
+                                                                 const float *__restrict__ scale, const float *__restrict__ shift,
+                                                                 const float *__restrict__ mean, const float *__restrict__ var,
+                                                                 float eps, int relu, double *__restrict__ sums)
+{
+    __shared__ float sh1[4][64], sh2[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cx;
+    float s1 = 0, s2 = 0;
+    if (col < c) {
+        const float sc = scale[col], sf = shift[col], mu = mean[col], inv = 1.0f / sqrtf(var[col] + eps);
+        for (long g = (long)blockIdx.x * 4 + ry; g < groups; g += (long)gridDim.x * 4) {
+            const int a = argmax[(size_t)g * c + col];
+            const float zz = z[((size_t)g * k + a) * c + col];
+            float gg = gout[(size_t)g * c + col];
+            if (relu && !(zz * sc + sf > 0.0f)) gg = 0.0f;
+            s1 += gg;
+            s2 += gg * ((zz - mu) * inv);
+        }
+    }
+    sh1[ry][cx] = s1;
+    sh2[ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        const float t1 = (sh1[0][cx] + sh1[1][cx]) + (sh1[2][cx] + sh1[3][cx]);
+        const float t2 = (sh2[0][cx] + sh2[1][cx]) + (sh2[2][cx] + sh2[3][cx]);
+        unsafeAtomicAdd(&sums[col], (double)t1);
+        unsafeAtomicAdd(&sums[c + col], (double)t2);
+    }
+}
+
+// plain column sums (bias gradient of a layer without BatchNorm)
+__global__ __launch_bounds__(256) void colsum_kernel(long rows, int c, const float *__restrict__ x, double *__restrict__ sums)
+{
+    __shared__ float sh1[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cx;
+    float s1 = 0;
+    if (col < c)
+        for (long r = (long)blockIdx.x * 4 + ry; r < rows; r += (long)gridDim.x * 4) s1 += x[(size_t)r * c + col];
+    sh1[ry][cx] = s1;
+    __syncthreads();
+    if (ry == 0 && col < c) unsafeAtomicAdd(&sums[col], (double)((sh1[0][cx] + sh1[1][cx]) + (sh1[2][cx] + sh1[3][cx])));
+}
+
+// ---------------------------------------------------------------- BN backward: apply
+// dz = gamma*invstd*(da' - s1/N - zhat*s2/N);  also dgamma += s2, dbeta += s1 (block 0 only)
+__global__ void bn_bwd_apply_kernel(long rows, int c, int k /*0: dense*/, const float *__restrict__ da,
+                                    const int *__restrict__ argmax, const float *__restrict__ z,
+                                    const float *__restrict__ scale, const float *__restrict__ shift,
+                                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu,
+                                    const float *__restrict__ gamma, const double *__restrict__ sums, float *__restrict__ dz,
+                                    float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const long total = rows * c;
+    const double invn = 1.0 / (double)rows;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / c;
+        const int col = (int)(e - r * c);
+        const float inv = 1.0f / sqrtf(var[col] + eps);
+        const float zz = z[e];
+        float g;
+        if (k > 0) {
+            const long grp = r / k;
+            g = ((int)(r - grp * k) == argmax[(size_t)grp * c + col]) ? da[(size_t)grp * c + col] : 0.0f;
+        } else {
+            g = da[e];
+        }
+        if (relu && !(zz * scale[col] + shift[col] > 0.0f)) g = 0.0f;
+        const float m1 = (float)(sums[col] * invn), m2 = (float)(sums[c + col] * invn);
+        const float zh = (zz - mean[col]) * inv;
+        dz[e] = gamma[col] * inv * (g - m1 - zh * m2);
+    }
+    if (blockIdx.x == 0)
+        for (int col = threadIdx.x; col < c; col += blockDim.x) {
+            if (dgamma) dgamma[col] += (float)sums[c + col];
+            if (dbeta) dbeta[col] += (float)sums[col];
+        }
+}
+
+// dst[i] += (float)src[i]  (bias gradient from colsum)
+__global__ void add_f64_to_f32_kernel(int n, const double *__restrict__ src, float *__restrict__ dst)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] += (float)src[i];
+}
+
+// ---------------------------------------------------------------- weight gradient
+constexpr int WG_BR = 16;  // rows per slab (the MFMA contraction index)
+constexpr int WG_BI = 128; // dW rows (input channels) per workgroup tile
+constexpr int WG_BJ = 128; // dW cols (output channels) per workgroup tile
+
+template <int MODE>
+__device__ __forceinline__ int w_row(int k, int c)
+{
+    if (MODE == 0) return k;
+    return k < c ? k + 3 : k - c;
+}
+
+// dW[w_row(i), j] += sum_r A[r,i] * dz[r,j] over this workgroup's row range.
+// 4 waves as 2x2, each 64x64 (2x2 MFMA tiles).  LDS images are the natural [row][channel] slabs:
+// the A^T operand of lane l is As[k2*2 + (l>>5)][i0 + (l&31)], conflict-free.
+template <int MODE>
+__global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz,
+                                                        float *__restrict__ dw, long rows_per_block)
+{
+    __shared__ float As[2][WG_BR][WG_BI + 4];
+    __shared__ float Bs[2][WG_BR][WG_BJ + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int i0 = blockIdx.y * WG_BI, j0 = blockIdx.z * WG_BJ;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    if (r_begin >= r_end) return;
+    const bool a_vec4 = (MODE == 0) ? ((cin & 3) == 0) : ((in.c & 3) == 0 && in.c > 0);
+    const bool b_vec4 = (cout & 3) == 0;
+    // staging: slab = 16 rows x 128 channels = 512 float4; thread t: row (t>>5) + 8h, quad (t&31)
+    const int s_row = tid >> 5, s_q = tid & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
+
+    float4 ra[2], rb[2];
+    auto load_slab = [&](long r0) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const long r = r0 + s_row + h * 8;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < r_end) {
+                const int k0 = i0 + s_q * 4;
+                if (MODE == 0) {
+                    if (a_vec4 && k0 + 3 < cin) {
+                        va = *reinterpret_cast<const float4 *>(in.x + (size_t)r * cin + k0);
+                        if (in.in_scale) {
+                            const float4 sc = *reinterpret_cast<const float4 *>(in.in_scale + k0);
+                            const float4 sh = *reinterpret_cast<const float4 *>(in.in_shift + k0);
+                            va.x = va.x * sc.x + sh.x;
+                            va.y = va.y * sc.y + sh.y;
+                            va.z = va.z * sc.z + sh.z;
+                            va.w = va.w * sc.w + sh.w;
+                            if (in.in_relu) {
+                                va.x = va.x > 0.f ? va.x : 0.f;
+                                va.y = va.y > 0.f ? va.y : 0.f;
+                                va.z = va.z > 0.f ? va.z : 0.f;
+                                va.w = va.w > 0.f ? va.w : 0.f;
+                            }
+                        }
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            float v = 0.0f;
+                            if (k0 + q < cin) {
+                                v = in.x[(size_t)r * cin + k0 + q];
+                                if (in.in_scale) {
+                                    v = v * in.in_scale[k0 + q] + in.in_shift[k0 + q];
+                                    if (in.in_relu) v = v > 0.f ? v : 0.f;
+                                }
+                            }
+                            t[q] = v;
+                        }
+                        va = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                } else {
+                    const int src = in.idx[r];
+                    const long scene = r / ((long)in.m * in.nsample);
+                    if (a_vec4 && k0 + 3 < in.c) {
+                        va = *reinterpret_cast<const float4 *>(in.feat + ((size_t)scene * in.n + src) * in.c + k0);
+                    } else {
+                        float t[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const int k = k0 + q;
+                            float v = 0.0f;
+                            if (k < in.c)
+                                v = in.feat[((size_t)scene * in.n + src) * in.c + k];
+                            else if (k < cin)
+                                v = in.xyz[((size_t)scene * in.n + src) * 3 + (k - in.c)] -
+                                    in.new_xyz[(size_t)(r / in.nsample) * 3 + (k - in.c)];
+                            t[q] = v;
+                        }
+                        va = make_float4(t[0], t[1], t[2], t[3]);
+                    }
+                }
+                const int n0 = j0 + s_q * 4;
+                const float *zr = dz + (size_t)r * cout;
+                if (b_vec4 && n0 + 3 < cout) {
+                    vb = *reinterpret_cast<const float4 *>(zr + n0);
+                } else {
+                    if (n0 + 0 < cout) vb.x = zr[n0 + 0];
+                    if (n0 + 1 < cout) vb.y = zr[n0 + 1];
+                    if (n0 + 2 < cout) vb.z = zr[n0 + 2];
+                    if (n0 + 3 < cout) vb.w = zr[n0 + 3];
+                }
+            }
+            ra[h] = va;
+            rb[h] = vb;
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            *reinterpret_cast<float4 *>(&As[buf][s_row + h * 8][s_q * 4]) = ra[h];
+            *reinterpret_cast<float4 *>(&Bs[buf][s_row + h * 8][s_q * 4]) = rb[h];
+        }
+    };
+
+    load_slab(r_begin);
+    int buf = 0;
+    for (long r0 = r_begin; r0 < r_end; r0 += WG_BR) {
+        store_slab(buf);
+        __syncthreads();
+        if (r0 + WG_BR < r_end) load_slab(r0 + WG_BR);
+        const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+        for (int k2 = 0; k2 < WG_BR / 2; k2++) {
+            float a[2], b[2];
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                a[t] = As[buf][k2 * 2 + kh][(wi * 2 + t) * 32 + l31];
+                b[t] = Bs[buf][k2 * 2 + kh][(wj * 2 + t) * 32 + l31];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; s++)
+#pragma unroll
+                for (int t = 0; t < 2; t++) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[s][t], 0, 0, 0);
+        }
+        buf ^= 1;
+    }
+    // epilogue: atomically add the partial tile.  C/D: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            const int j = j0 + (wj * 2 + t) * 32 + (lane & 31);
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = i0 + (wi * 2 + s) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                if (i < cin && j < cout) unsafeAtomicAdd(&dw[(size_t)w_row<MODE>(i, in.c) * cout + j], acc[s][t][e]);
+            }
+        }
+}
+
+// ---------------------------------------------------------------- first-layer input gradient scatter
+// d_in (rows x (3+c)), columns [dxyz(3), feat(c)] (the reference's concat order, utils.py:55)
+//   d_feat[s, idx[r], :]  += d_in[r, 3:]
+//   d_xyz [s, idx[r], :]  += d_in[r, :3]          (only when d_xyz != NULL)
+//   d_new_xyz[s, j, :]    -= sum_k d_in[r, :3]    (only when d_new_xyz != NULL)
+__global__ void group_concat_grad_kernel(long rows, int n, int c, long rows_per_scene, int nsample,
+                                         const float *__restrict__ d_in, const int *__restrict__ idx,
+                                         float *__restrict__ d_feat, float *__restrict__ d_xyz, float *__restrict__ d_new_xyz)
+{
+    const int cc = 3 + c;
+    const long total = rows * cc;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long r = e / cc;
+        const int l = (int)(e - r * cc);
+        const long s = r / rows_per_scene;
+        const int ii = idx[r];
+        const float g = d_in[e];
+        if (l >= 3) {
+            if (d_feat) unsafeAtomicAdd(&d_feat[((size_t)s * n + ii) * c + (l - 3)], g);
+        } else {
+            if (d_xyz) unsafeAtomicAdd(&d_xyz[((size_t)s * n + ii) * 3 + l], g);
+            if (d_new_xyz) unsafeAtomicAdd(&d_new_xyz[(size_t)(r / nsample) * 3 + l], -g);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- optimizer
+// one workgroup per tensor: sum of squares of its gradient segment
+__global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict__ g, const long *__restrict__ seg,
+                                                        float *__restrict__ out)
+{
+    __shared__ float sh[256];
+    const long a = seg[2 * blockIdx.x], b = seg[2 * blockIdx.x + 1];
+    float s = 0;
+    for (long i = a + threadIdx.x; i < b; i += 256) s += g[i] * g[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+
+// tf.clip_by_average_norm(g, clip): g * clip / max(||g||/numel, clip)   (model.py:249), then Adam
+__global__ void clip_adam_kernel(const long *__restrict__ seg, const float *__restrict__ sumsq, float *__restrict__ p,
+                                 const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float lr, float b1,
+                                 float b2, float eps, float bc1, float bc2, float gscale, float clip)
+{
+    const long a = seg[2 * blockIdx.y], b = seg[2 * blockIdx.y + 1];
+    float factor = gscale;
+    if (clip > 0.0f) {
+        const float avg = sqrtf(sumsq[blockIdx.y]) * gscale / (float)(b - a);
+        factor = gscale * clip / (avg > clip ? avg : clip);
+    }
+    for (long i = a + (long)blockIdx.x * blockDim.x + threadIdx.x; i < b; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * factor;
+        const float mm = b1 * m[i] + (1.0f - b1) * gg;
+        const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
+        m[i] = mm;
+        v[i] = vv;
+        p[i] -= lr * (mm / bc1) / (sqrtf(vv / bc2) + eps);
+    }
+}
+
+static inline int grid_for(long total, int block, int cap = 256 * 16)
+{
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+static MlpIn to_dev(const votenet_mlp_input *in)
+{
+    MlpIn d;
+    d.x = in->x;
+    d.in_scale = in->in_scale;
+    d.in_shift = in->in_shift;
+    d.in_relu = in->in_relu;
+    d.xyz = in->xyz;
+    d.new_xyz = in->new_xyz;
+    d.feat = in->feat;
+    d.idx = in->idx;
+    d.n = in->n;
+    d.m = in->m;
+    d.nsample = in->nsample;
+    d.c = in->feat ? in->c : 0;
+    return d;
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
+                                          const float *scale, const float *shift, const float *mean, const float *var,
+                                          float eps, int relu, double *sums, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && k >= 0, "bn_backward_reduce expects rows > 0, c > 0, k >= 0");
+    VN_REQUIRE(da && z && scale && shift && mean && var && sums, "bn_backward_reduce: null buffer");
+    hipStream_t st = as_stream(stream);
+    const int ny = (c + 63) / 64;
+    if (k > 0) {
+        VN_REQUIRE(argmax != nullptr && rows % k == 0, "bn_backward_reduce: pooled mode needs argmax and rows % k == 0");
+        const long groups = rows / k;
+        hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(grid_for(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, st, groups, k, c,
+                           da, argmax, z, scale, shift, mean, var, eps, relu, sums);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_reduce_dense_kernel, dim3(grid_for(rows, 4, 2048 / ny + 1), ny), dim3(256), 0, st, rows, c, da,
+                           z, scale, shift, mean, var, eps, relu, sums);
+    }
+    return check_launch("bn_backward_reduce");
+}
+
+extern "C" int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
+                                         const float *scale, const float *shift, const float *mean, const float *var,
+                                         float eps, int relu, const float *gamma, const double *sums, float *dz,
+                                         float *dgamma, float *dbeta, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && k >= 0, "bn_backward_apply expects rows > 0, c > 0, k >= 0");
+    VN_REQUIRE(da && z && scale && shift && mean && var && gamma && sums && dz, "bn_backward_apply: null buffer");
+    VN_REQUIRE(k == 0 || argmax != nullptr, "bn_backward_apply: pooled mode needs argmax");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, c, k, da, argmax,
+                       z, scale, shift, mean, var, eps, relu, gamma, sums, dz, dgamma, dbeta);
+    return check_launch("bn_backward_apply");
+}
+
+extern "C" int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float *dbias, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0, "bias_grad expects rows > 0, c > 0");
+    VN_REQUIRE(dz && scratch && dbias, "bias_grad: null buffer");
+    hipStream_t st = as_stream(stream);
+    (void)hipMemsetAsync(scratch, 0, sizeof(double) * c, st);
+    const int ny = (c + 63) / 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid_for(rows, 4, 1024 / ny + 1), ny), dim3(256), 0, st, rows, c, dz, scratch);
+    hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3((c + 255) / 256), dim3(256), 0, st, c, scratch, dbias);
+    return check_launch("bias_grad");
+}
+
+extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
+                                 void *stream)
+{
+    VN_REQUIRE(in != nullptr, "mlp_wgrad: null input descriptor");
+    VN_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "mlp_wgrad expects rows >= 0, cin > 0, cout > 0");
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(dz && dw, "mlp_wgrad: null buffer");
+    MlpIn d = to_dev(in);
+    const int ti = (cin + WG_BI - 1) / WG_BI, tj = (cout + WG_BJ - 1) / WG_BJ;
+    long splits = 768 / (ti * tj);
+    if (splits < 1) splits = 1;
+    long rpb = (rows + splits - 1) / splits;
+    rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
+    if (rpb < 4 * WG_BR) rpb = 4 * WG_BR;
+    const long gx = (rows + rpb - 1) / rpb;
+    hipStream_t st = as_stream(stream);
+    if (in->x) {
+        hipLaunchKernelGGL((mlp_wgrad_kernel<0>), dim3((unsigned)gx, ti, tj), dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+    } else {
+        VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_wgrad: GATHER input needs xyz, new_xyz and idx");
+        VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_wgrad: rows must equal b*m*nsample for a GATHER input");
+        VN_REQUIRE(cin == 3 + d.c, "mlp_wgrad: cin must equal 3 + c for a GATHER input");
+        hipLaunchKernelGGL((mlp_wgrad_kernel<1>), dim3((unsigned)gx, ti, tj), dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+    }
+    return check_launch("mlp_wgrad");
+}
+
+extern "C" int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_in, const int *idx,
+                                         float *d_feat, float *d_xyz, float *d_new_xyz, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0 && c >= 0 && m >= 0 && nsample >= 0, "group_concat_grad: bad shape");
+    const long rows = (long)b * m * nsample;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(d_in && idx, "group_concat_grad: null buffer");
+    hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(rows * (3 + c), 256)), dim3(256), 0, as_stream(stream), rows, n, c,
+                       (long)m * nsample, nsample, d_in, idx, d_feat, d_xyz, d_new_xyz);
+    return check_launch("group_concat_grad");
+}
+
+extern "C" int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scratch, float *p, const float *g, float *m,
+                                 float *v, float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                                 float clip_avg_norm, void *stream)
+{
+    VN_REQUIRE(ntensors > 0 && step > 0, "clip_adam expects ntensors > 0 and step >= 1");
+    VN_REQUIRE(seg && sumsq_scratch && p && g && m && v, "clip_adam: null buffer");
+    hipStream_t st = as_stream(stream);
+    if (clip_avg_norm > 0.0f) hipLaunchKernelGGL(seg_sumsq_kernel, dim3(ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(16, ntensors), dim3(256), 0, st, seg, sumsq_scratch, p, g, m, v, lr, beta1, beta2, eps,
+                       bc1, bc2, grad_scale, clip_avg_norm);
+    return check_launch("clip_adam");
+}

@@ -105,3 +105,65 @@ def bn_relu(z, scale, shift, relu=True):
         L.check(L.lib().votenet_bn_relu(rows, c, L.ptr(z), L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(y),
                                         L.stream_ptr()))
     return y
+
+
+# --------------------------------------------------------------------------- backward
+def bn_backward(z, scale, shift, mean, var, gamma, relu, da, dgamma, dbeta, argmax=None, k=0, eps=BN_EPS):
+    """Training-mode BatchNorm (+ReLU) backward.  da: dense (rows,c), or pooled gout (rows/k,c) with argmax.
+    Returns dz (rows,c); accumulates dgamma / dbeta (views into the gradient bucket)."""
+    rows, c = z.shape
+    sums = torch.zeros(2 * c, dtype=torch.float64, device=z.device)
+    dz = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
+                                                   L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
+                                                   L.stream_ptr()))
+        L.check(L.lib().votenet_bn_backward_apply(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
+                                                  L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(gamma),
+                                                  L.ptr(sums), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr()))
+    return dz
+
+
+def bias_grad(dz, dbias):
+    rows, c = dz.shape
+    scratch = torch.empty(c, dtype=torch.float64, device=dz.device)
+    with torch.cuda.device(dz.device):
+        L.check(L.lib().votenet_bias_grad(rows, c, L.ptr(dz), L.ptr(scratch), L.ptr(dbias), L.stream_ptr()))
+
+
+def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
+    """dw += act(x)^T dz with the forward pass's folded BN+ReLU on x."""
+    rows, cin = x.shape
+    cout = dz.shape[1]
+    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.stream_ptr()))
+
+
+def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
+    b, m, k = idx.shape
+    c = feat.shape[2] if feat is not None else 0
+    d = _desc_gather(xyz, new_xyz, feat, idx)
+    with torch.cuda.device(xyz.device):
+        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.stream_ptr()))
+
+
+def group_concat_grad(d_in, idx, n, c, want_feat=True, want_xyz=False):
+    """-> d_feat (b,n,c) or None, d_xyz (b,n,3) or None, d_new_xyz (b,m,3) or None."""
+    b, m, k = idx.shape
+    dev = d_in.device
+    d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if (want_feat and c) else None
+    d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if want_xyz else None
+    d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if want_xyz else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().votenet_group_concat_grad(b, n, c, m, k, L.ptr(d_in), L.ptr(idx), L.ptr(d_feat), L.ptr(d_xyz),
+                                                  L.ptr(d_new), L.stream_ptr()))
+    return d_feat, d_xyz, d_new
+
+
+def clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5, beta1=0.9, beta2=0.999, eps=1e-8):
+    """model.py:240-250: per-tensor clip_by_average_norm(g, 0.5) then Adam(lr) on the flat bucket."""
+    with torch.cuda.device(p.device):
+        L.check(L.lib().votenet_clip_adam(seg.numel() // 2, L.ptr(seg), L.ptr(sumsq), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v),
+                                          float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
+                                          float(clip), L.stream_ptr()))

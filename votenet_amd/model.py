@@ -71,3 +71,67 @@ class VoteNetHotPath:
         p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
         return dict(seeds_xyz=seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
                     proposals_xyz=p_xyz, proposals_output=p_out)
+
+    # ---- backward / training --------------------------------------------------------
+    def make_cotangents(self, b, seed=0):
+        """Synthetic upstream gradients standing in for the reference's loss graph (model.py:141-231,
+        out of scope): d loss / d proposals_output (B,256,79) and d loss / d votes_xyz (B,1024,3)."""
+        g = torch.Generator(device="cpu").manual_seed(1234 + seed)
+        n_seed = self.sa2.npoint
+        return dict(proposals_output=(torch.randn(b, PROPOSAL_NUM, PROPOSAL_OUT, generator=g) / (b * PROPOSAL_NUM)).to(self.device),
+                    votes_xyz=(torch.randn(b, n_seed, 3, generator=g) / (b * n_seed)).to(self.device))
+
+    def backward(self, tape, cot):
+        """Reverse sweep over the tape of forward(); parameter gradients accumulate into store.grad."""
+        recs = {i: r for i, r in enumerate(tape)}
+        sa1, sa2, sa3, sa4, fp1, fp2, vote, prop = [recs[i] for i in range(8)]
+        # proposal layer: gradients reach the vote features AND the vote xyz (grouped xyz, gathered centres)
+        d_vp, d_vx = self.proposal.backward(prop, cot["proposals_output"], need_feat_grad=True, need_xyz_grad=True)
+        if cot.get("votes_xyz") is not None:
+            d_vx = d_vx + cot["votes_xyz"]
+        # voting: votes = x + FC(x), x = [seeds_xyz, seeds_points]
+        b, n = vote["b"], vote["n"]
+        d_votes = torch.cat([d_vx, d_vp], dim=2).view(b * n, 259)
+        d_x = d_votes + P.mlp_chain_backward(vote["recs"], d_votes, "plain", need_input_grad=True)
+        d_seeds_p = d_x[:, 3:].contiguous().view(b, n, 256)
+        # feature propagation
+        d_l2p, d_l3p2 = self.fp2.backward(fp2, d_seeds_p)
+        d_l3p, d_l4p = self.fp1.backward(fp1, d_l3p2)
+        # set abstraction (xyz carries no gradient in the backbone: the cloud is the input)
+        g3, _ = self.sa4.backward(sa4, d_l4p)
+        d_l3p = d_l3p + g3
+        g2, _ = self.sa3.backward(sa3, d_l3p)
+        d_l2p = d_l2p + g2
+        g1, _ = self.sa2.backward(sa2, d_l2p)
+        self.sa1.backward(sa1, g1, need_feat_grad=False)
+
+    def init_optimizer(self, lr=1e-3):
+        s = self.store
+        import math
+        base = s.flat.data_ptr()
+        seg = []
+        for name, shape, _ in s._specs:  # [start, end) of every tensor inside the flat bucket
+            a = (s.views[name].data_ptr() - base) // 4
+            seg += [a, a + math.prod(shape)]
+        self._seg = torch.tensor(seg, dtype=torch.int64, device=self.device)
+        self._sumsq = torch.zeros(len(seg) // 2, dtype=torch.float32, device=self.device)
+        self._m = torch.zeros_like(s.flat)
+        self._v = torch.zeros_like(s.flat)
+        self._step = 0
+        self._lr = lr
+
+    def train_step(self, x, cot, world=1):
+        """forward + backward + (world>1: ONE RCCL all-reduce of the flat gradient bucket) + clip/Adam."""
+        if not hasattr(self, "_seg"):
+            self.init_optimizer()
+        self.store.grad.zero_()
+        tape = []
+        out = self.forward(x, tape)
+        self.backward(tape, cot)
+        if world > 1:
+            import torch.distributed as dist
+            dist.all_reduce(self.store.grad)  # sum over ranks; 1/world folded into the optimizer's grad_scale
+        self._step += 1
+        M.clip_adam(self._seg, self._sumsq, self.store.flat, self.store.grad, self._m, self._v, self._lr, self._step,
+                    grad_scale=1.0 / world)
+        return out

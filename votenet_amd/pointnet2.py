@@ -124,6 +124,37 @@ def mlp_chain_forward(layers, rows, first, tape):
     return z, sc, sh
 
 
+def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
+    """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
+         'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
+         'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
+         'plain' : g = dz (rows, c) of a last layer without BN / activation    (mlp2, voting)
+    Accumulates parameter gradients into the store's gradient bucket.  Returns the gradient with respect
+    to the chain's input: (rows, cin) in the caller's column order ([dxyz, feat] for a gather input)."""
+    da = g
+    for i in range(len(recs) - 1, -1, -1):
+        r = recs[i]
+        L = r["layer"]
+        z = r["z"]
+        if L.bn:
+            pooled = (mode == "pool" and i == len(recs) - 1)
+            dz = M.bn_backward(z, r["scale"], r["shift"], r["mean"], r["var"], L.p("gamma"), L.relu, da, L.gp("gamma"),
+                               L.gp("beta"), argmax=argmax if pooled else None, k=k if pooled else 0)
+            # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
+        else:
+            dz = da
+            M.bias_grad(dz, L.gp("b"))
+        if r["kind"] == "gather":
+            M.wgrad_gather(r["xyz"], r["new_xyz"], r["feat"], r["idx"], dz, L.gp("W"))
+        else:
+            M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
+        if i > 0 or need_input_grad:
+            da, _ = M.linear_dense(dz, L.p("W").t().contiguous(), want_stats=False)  # da_prev = dz W^T
+        else:
+            da = None
+    return da
+
+
 # --------------------------------------------------------------------------- SA / FP modules
 def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None):
     """utils.py:42-49 (geometry part): FPS on sample_xyz if given, centres gathered from xyz."""
@@ -160,6 +191,24 @@ class SAModule:
         return new_xyz, out.view(b, self.npoint, -1), idx
 
 
+    def backward(self, rec, g_out, need_feat_grad=True, need_xyz_grad=False):
+        """g_out (B,m,C') -> d_points (B,n,C) or None, d_xyz (B,n,3) or None."""
+        b = rec["b"]
+        g = g_out.reshape(b * self.npoint, -1).contiguous()
+        if self.mlp2:
+            g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
+        need_in = (need_feat_grad and rec["points"] is not None) or need_xyz_grad
+        d_in = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_in)
+        if not need_in:
+            return None, None
+        n = rec["xyz"].shape[1]
+        c = 0 if rec["points"] is None else rec["points"].shape[2]
+        d_feat, d_xyz, d_new = M.group_concat_grad(d_in, rec["idx"], n, c, want_feat=need_feat_grad, want_xyz=need_xyz_grad)
+        if need_xyz_grad:
+            d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
+        return d_feat, d_xyz
+
+
 class FPModule:
     """pointnet_fp_module (utils.py:266-294): 3-NN inverse-distance interpolation + MLP."""
 
@@ -180,3 +229,12 @@ class FPModule:
             tape.append(dict(op="fp", module=self, recs=recs, idx=idx, weight=weight, m=xyz2.shape[1],
                              c2=points2.shape[2], c1=0 if points1 is None else points1.shape[2], b=b, n1=n1))
         return y.view(b, n1, -1)
+
+    def backward(self, rec, dy):
+        """dy (B,n1,C) -> d_points1 (B,n1,c1) or None, d_points2 (B,m,c2)."""
+        b, n1, c1, c2 = rec["b"], rec["n1"], rec["c1"], rec["c2"]
+        d_x = mlp_chain_backward(rec["recs"], dy.reshape(b * n1, -1).contiguous(), "act", need_input_grad=True)
+        d_interp = d_x[:, :c2].contiguous().view(b, n1, c2)
+        d_p1 = d_x[:, c2:].contiguous().view(b, n1, c1) if c1 else None
+        d_p2 = tf_interpolate.three_interpolate_grad_raw(rec["m"], rec["idx"], rec["weight"], d_interp)
+        return d_p1, d_p2
