@@ -106,13 +106,13 @@ def main():
 
     B, n = args.batch, args.points
     gen = synth.room_batch if args.scene == "room" else synth.uniform_batch
-    x = torch.from_numpy(gen(B, n, 1000 + rank * B)).to(dev)  # disjoint seeds per rank, resident in HBM
+    from votenet_amd import dp
+    x = torch.from_numpy(gen(B, n, dp.scene_seeds(rank, B)[0])).to(dev)  # disjoint seeds per rank, resident in HBM
     net = VM.VoteNetHotPath(dev, seed=0)
     cot = None
     if workload == "train":
         cot = net.make_cotangents(B, seed=rank)
-        if world > 1:
-            dist.broadcast(net.store.flat, 0)
+        dp.broadcast_params(net.store)
 
     def step():
         if workload == "train":

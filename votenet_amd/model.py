@@ -13,6 +13,7 @@ driven, checked and timed end to end:
 """
 import torch
 
+from . import dp
 from . import mlp as M
 from . import pointnet2 as P
 
@@ -128,10 +129,8 @@ class VoteNetHotPath:
         tape = []
         out = self.forward(x, tape)
         self.backward(tape, cot)
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(self.store.grad)  # sum over ranks; 1/world folded into the optimizer's grad_scale
+        gscale = dp.sync_gradients(self.store)  # ONE all-reduce (sum) of the flat bucket; 1/world goes to the optimizer
         self._step += 1
         M.clip_adam(self._seg, self._sumsq, self.store.flat, self.store.grad, self._m, self._v, self._lr, self._step,
-                    grad_scale=1.0 / world)
+                    grad_scale=gscale)
         return out
