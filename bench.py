@@ -159,7 +159,8 @@ def main():
                 except Exception:
                     traffic = None
             ach = alg / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "fps_reg_kernel<16,20> (sa1 FPS %d->%d, on-chip resident)" % (n, m1),
+            roof = {"bound": "hbm", "kernel": "fps_bucket_sort_kernel + fps_bucket_kernel<12,32> (sa1 FPS %d->%d, register resident, "
+                                             "exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg}
         cpu = None

@@ -63,6 +63,20 @@ __device__ __forceinline__ unsigned wave_min_u32(unsigned v)
     v = min(v, dpp_u32<0x143, 0xC>(v));
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
+__device__ __forceinline__ float wave_min_f32(float v)
+{
+    v = fminf(v, dpp_f32<0xB1>(v));
+    v = fminf(v, dpp_f32<0x4E>(v));
+    v = fminf(v, dpp_f32<0x141>(v));
+    v = fminf(v, dpp_f32<0x140>(v));
+    v = fminf(v, dpp_f32<0x142, 0xA>(v));
+    v = fminf(v, dpp_f32<0x143, 0xC>(v));
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), 63));
+}
+__device__ __forceinline__ float readlane_f32(float v, int lane)
+{
+    return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
+}
 __device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

@@ -1,0 +1,591 @@
+// fps.hip -- farthest point sampling for gfx950.
+//
+// Replaces farthestpointsamplingKernel / Launcher (tf_ops/sampling/tf_sampling_g.cu:105-170,203-205).
+//
+// FPS is a chain of m-1 dependent arg-max rounds per scene; with B = 8 scenes only 8 chains exist,
+// so the kernel is bound by the latency of ONE round on ONE compute unit, not by HBM.  The reference
+// keeps the running distances in global memory, re-reads every point past the first 3072 each round
+// and spends 10 barriers per round (tf_sampling_g.cu:111-165).  Three kernels here:
+//
+//   fps_reg_kernel     n <= 4096.  The scene (xyz + running distance, 4 VGPRs per point) lives in the
+//                      register file of one workgroup (16 waves x 1, 2 or 4 points per lane); a round is
+//                      a few un-fused distance updates per lane, a DPP wave arg-max and ONE barrier.
+//   fps_bucket_kernel  4096 < n <= 24576.  Same residency, plus EXACT spatial pruning: points are
+//                      pre-sorted into buckets of 64 (one register slot of one wave) by a Morton cell
+//                      sort (fps_bucket_sort_kernel); every bucket keeps its bounding box and the max of
+//                      its running distances.  A new sample can only lower distances of points closer
+//                      than their current running distance, so a bucket whose box is farther than its
+//                      max running distance is skipped -- nothing in it can change.  The skip test is
+//                      conservative (box distance shrunk by 1e-5 relative), skipped buckets keep their
+//                      cached arg-max, and ties are still resolved with the reference's key on ORIGINAL
+//                      indices: the sampled indices are bit-identical to the brute-force scan while the
+//                      VALU work per round drops from n points to a handful of buckets.  Spatially
+//                      adjacent buckets are dealt round-robin to the waves so the few active buckets of a
+//                      round are updated in parallel.
+//   fps_stream_kernel  n > 24576: running distances in the caller's temp buffer (reference layout).
+//
+// In all of them the winner's coordinates travel through the reduction (registers -> readlane -> one
+// LDS exchange), so a round touches no global memory on its critical path; register arrays are
+// 16-wide vector chunks so a wave-uniform slot index is one s_set_gpr_idx access, not a select chain.
+//
+// Tie rule (part of the result): winner = max d2, then smallest (k mod 512), then smallest k --
+// the reference's 512-thread stride + left-biased tree.  Encoded as a 32-bit key
+// ((k & 511) << 23 | k >> 9) minimised among the candidates that hold the max.
+// Distances are evaluated un-fused, left to right (-ffp-contract=off), matching the oracle.  They are
+// non-negative, so min / max / compare run on their bit patterns as unsigned integers (same order, no
+// NaN canonicalisation code); lanes or slots without a point carry distance +0 and key 0xFFFFFFFF, which
+// loses every tie against a real point exactly as the reference's (best = -1) idle threads do.
+#include "common.h"
+
+namespace votenet {
+
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ unsigned fps_tiekey(unsigned k) { return ((k & 511u) << 23) | (k >> 9); }
+__device__ __forceinline__ unsigned fps_key_to_index(unsigned key) { return ((key & 0x7FFFFFu) << 9) | (key >> 23); }
+__device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }
+
+// ---- wave64 reductions on unsigned keys: six dependent VOP2-DPP steps, result uniform
+#define FPS_DPP_REDUCE(OP)                                                                                   \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                 OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"              \
+                 OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                  \
+                 OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                       \
+                 OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"                     \
+                 OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 1"                         \
+                 : "+v"(v))
+#define FPS_DPP_REDUCE16(OP)                                                                                 \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
+                 OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"              \
+                 OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                  \
+                 OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\ts_nop 1"                           \
+                 : "+v"(v))
+__device__ __forceinline__ unsigned wmax_u32(unsigned v)
+{
+    FPS_DPP_REDUCE("v_max_u32_dpp");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned wmin_u32(unsigned v)
+{
+    FPS_DPP_REDUCE("v_min_u32_dpp");
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ unsigned r16max_u32(unsigned v) // every lane of a 16-lane row gets the row result
+{
+    FPS_DPP_REDUCE16("v_max_u32_dpp");
+    return v;
+}
+__device__ __forceinline__ unsigned r16min_u32(unsigned v)
+{
+    FPS_DPP_REDUCE16("v_min_u32_dpp");
+    return v;
+}
+
+// ---- register arrays are ONE 16- or 32-wide vector each (v16f32 / v32f32 register tuples), so that a
+// wave-uniform dynamic slot index is a single s_set_gpr_idx access: no select chain, no scratch
+typedef float f32v __attribute__((ext_vector_type(32)));
+template <int VW>
+struct SlotVec;
+template <>
+struct SlotVec<16> {
+    typedef f16v type;
+};
+template <>
+struct SlotVec<32> {
+    typedef f32v type;
+};
+
+// Wave arg-max under (value descending, key ascending).  Exact ties are rare, so the key reduction only
+// runs when more than one lane holds the maximum.  Returns the winning lane; vmax / kmin uniform.
+__device__ __forceinline__ int wave_argmax(unsigned val, unsigned key, unsigned &vmax, unsigned &kmin)
+{
+    vmax = wmax_u32(val);
+    unsigned long long hit = __ballot(val == vmax);
+    if (hit & (hit - 1)) { // several lanes hold the max
+        kmin = wmin_u32(val == vmax ? key : 0xFFFFFFFFu);
+        hit = __ballot(val == vmax && key == kmin);
+        return __ffsll((long long)hit) - 1;
+    }
+    const int l = __ffsll((long long)hit) - 1;
+    kmin = (unsigned)__builtin_amdgcn_readlane((int)key, l);
+    return l;
+}
+
+// Sampled indices are collected in the registers of wave 0 (lane j & 63 holds round j) and written
+// 64 at a time, so no global store sits between two rounds.
+struct FpsOut {
+    int *__restrict__ o;
+    int m;
+    int val;
+    __device__ __forceinline__ void put(int j, int k, int tid)
+    {
+        if (tid < 64) {
+            if ((j & 63) == tid) val = k;
+            if ((j & 63) == 63 || j == m - 1) {
+                const int base = j & ~63;
+                if (base + tid <= j) o[base + tid] = val;
+            }
+        }
+    }
+};
+
+struct FpsWinner {
+    unsigned k;    // original point index
+    float x, y, z; // its coordinates (uniform)
+};
+
+// Cross-wave stage: every wave contributes (wmax, wkey, wx, wy, wz); returns the block winner, uniform.
+// One barrier; the exchange buffer is double-buffered by round parity.
+template <int NW>
+__device__ __forceinline__ FpsWinner fps_cross_wave(unsigned wmax, unsigned wkey, float wx, float wy, float wz, unsigned *s_ex,
+                                                    int round)
+{
+    FpsWinner r;
+    if (NW == 1) {
+        r.k = fps_key_to_index(wkey);
+        r.x = wx;
+        r.y = wy;
+        r.z = wz;
+        return r;
+    }
+    unsigned *buf = s_ex + (round & 1) * 16 * 5;
+    const int w = wave_id_uniform();
+    const int lane = lane_id();
+    if (lane == 0) {
+        buf[w * 5 + 0] = wmax;
+        buf[w * 5 + 1] = wkey;
+        buf[w * 5 + 2] = fbits(wx);
+        buf[w * 5 + 3] = fbits(wy);
+        buf[w * 5 + 4] = fbits(wz);
+    }
+    // LDS-only barrier: __syncthreads() would also wait for vmcnt(0), i.e. for the global store of the
+    // previous round's index to complete -- hundreds of cycles on the critical path of every round
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int e = lane & 15;
+    const bool ev = e < NW;
+    const unsigned b2 = ev ? buf[e * 5 + 0] : 0u;
+    const unsigned k2 = ev ? buf[e * 5 + 1] : 0xFFFFFFFFu;
+    const unsigned ex = buf[(ev ? e : 0) * 5 + 2], ey = buf[(ev ? e : 0) * 5 + 3], ez = buf[(ev ? e : 0) * 5 + 4];
+    const unsigned bmax = r16max_u32(b2);
+    unsigned long long hit = __ballot(ev && b2 == bmax) & 0xFFFFull; // row 0 holds every entry once
+    unsigned key;
+    int fl;
+    if (hit & (hit - 1)) { // several waves hold the max: smallest key wins
+        const unsigned bkey = r16min_u32((ev && b2 == bmax) ? k2 : 0xFFFFFFFFu);
+        key = (unsigned)__builtin_amdgcn_readfirstlane((int)bkey);
+        hit = __ballot(ev && k2 == key && b2 == bmax);
+        fl = __ffsll((long long)hit) - 1;
+    } else {
+        fl = __ffsll((long long)hit) - 1;
+        key = (unsigned)__builtin_amdgcn_readlane((int)k2, fl);
+    }
+    r.k = fps_key_to_index(key);
+    r.x = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ex, fl));
+    r.y = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ey, fl));
+    r.z = __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)ez, fl));
+    return r;
+}
+
+// ------------------------------------------------------------------ brute force, register resident
+// NW waves x P points per lane: n <= 64 * NW * P.  Slots must be ordered by the tie key (k mod 512, k) so
+// that the strict '>' below keeps the smallest key of the lane.  With T = 64*NW threads:
+//   T >= 512 : k = tid + i*T              (k mod 512 is the same for every slot of a lane)
+//   T <  512 : a lane owns R = 512/T residues; slot i = a*Q + b  ->  k = b*512 + a*T + tid
+template <int NW, int P>
+__device__ __forceinline__ int fps_slot_to_k(int tid, int i)
+{
+    constexpr int T = NW * 64;
+    if (T >= 512) return tid + i * T;
+    constexpr int R = 512 / (T < 512 ? T : 512);
+    constexpr int Q = (P / R) > 0 ? (P / R) : 1;
+    static_assert(T >= 512 || P % R == 0, "P must be a multiple of 512/T");
+    return (i % Q) * 512 + (i / Q) * T + tid;
+}
+
+template <int NW, int P>
+__global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const float *__restrict__ xyz, int *__restrict__ out)
+{
+    __shared__ unsigned s_ex[2 * 16 * 5];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    int *__restrict__ o = out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x;
+
+    float x[P], y[P], z[P];
+    unsigned td[P];
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int k = fps_slot_to_k<NW, P>(tid, i);
+        const bool valid = k < n;
+        x[i] = valid ? pts[(size_t)k * 3 + 0] : 0.0f;
+        y[i] = valid ? pts[(size_t)k * 3 + 1] : 0.0f;
+        z[i] = valid ? pts[(size_t)k * 3 + 2] : 0.0f;
+        td[i] = valid ? fbits(1e38f) : 0u; // tf_sampling_g.cu:118
+    }
+    FpsOut fo = {o, m, 0};
+    fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
+    float cx = pts[0], cy = pts[1], cz = pts[2];
+    for (int j = 1; j < m; j++) {
+        unsigned best = 0u;
+        int bi = 0;
+        float bx = x[0], by = y[0], bz = z[0];
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const float dx = x[i] - cx, dy = y[i] - cy, dz = z[i] - cz;
+            const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
+            const unsigned d2 = min(fbits(d), td[i]);    // :143
+            td[i] = d2;
+            if (d2 > best) { // :146 strict: the lowest slot (smallest tie key of this lane) wins ties
+                best = d2;
+                bi = i;
+                bx = x[i];
+                by = y[i];
+                bz = z[i];
+            }
+        }
+        const int bk = fps_slot_to_k<NW, P>(tid, bi);
+        const unsigned key = bk < n ? fps_tiekey((unsigned)bk) : 0xFFFFFFFFu;
+        unsigned wmax, wkey;
+        const int fl = wave_argmax(best, key, wmax, wkey);
+        const FpsWinner win = fps_cross_wave<NW>(wmax, wkey, readlane_f32(bx, fl), readlane_f32(by, fl), readlane_f32(bz, fl), s_ex, j);
+        cx = win.x;
+        cy = win.y;
+        cz = win.z;
+        fo.put(j, (int)win.k, tid);
+    }
+}
+
+// ------------------------------------------------------------------ spatial bucketing (Morton cell counting sort)
+__device__ __forceinline__ unsigned part1by2_4(unsigned v) // spread 4 bits: abcd -> a00b00c00d
+{
+    v &= 0xF;
+    v = (v | (v << 4)) & 0xC3;  // ab0000cd
+    v = (v | (v << 2)) & 0x249; // a00b00c00d
+    return v;
+}
+
+// perm[scene, p] = original index of the p-th point in Morton-cell order (order inside a cell is arbitrary:
+// FPS results do not depend on it, ties are resolved on original indices).
+// Also writes the bounding box of every bucket of 64 consecutive sorted points: bbox[scene, g, 0..5] =
+// (xmin, ymin, zmin, xmax, ymax, zmax).
+__global__ __launch_bounds__(1024) void fps_bucket_sort_kernel(int n, const float *__restrict__ xyz, int *__restrict__ perm,
+                                                               float *__restrict__ bbox)
+{
+    __shared__ unsigned cnt[4096];
+    __shared__ float sred[6][16];
+    __shared__ unsigned wsum[16];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int k = tid; k < n; k += 1024)
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            const float v = pts[(size_t)k * 3 + a];
+            mn[a] = fminf(mn[a], v);
+            mx[a] = fmaxf(mx[a], v);
+        }
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        const float lo = wave_min_f32(mn[a]), hi = wave_max_f32(mx[a]);
+        if (lane == 0) {
+            sred[a][w] = lo;
+            sred[3 + a][w] = hi;
+        }
+    }
+    for (int c = tid; c < 4096; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    float lo[3], inv[3];
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        float l = sred[a][0], h = sred[3 + a][0];
+        for (int i = 1; i < 16; i++) {
+            l = fminf(l, sred[a][i]);
+            h = fmaxf(h, sred[3 + a][i]);
+        }
+        lo[a] = l;
+        inv[a] = (h > l) ? 16.0f / (h - l) : 0.0f;
+    }
+    auto cell_of = [&](int k) -> unsigned {
+        unsigned c = 0;
+#pragma unroll
+        for (int a = 0; a < 3; a++) {
+            int q = (int)((pts[(size_t)k * 3 + a] - lo[a]) * inv[a]);
+            q = q < 0 ? 0 : (q > 15 ? 15 : q);
+            c |= part1by2_4((unsigned)q) << a;
+        }
+        return c;
+    };
+    for (int k = tid; k < n; k += 1024) atomicAdd(&cnt[cell_of(k)], 1u);
+    __syncthreads();
+    // exclusive scan of 4096 counters: 4 per thread
+    unsigned c0 = cnt[tid * 4 + 0], c1 = cnt[tid * 4 + 1], c2 = cnt[tid * 4 + 2], c3 = cnt[tid * 4 + 3];
+    const unsigned tsum = c0 + c1 + c2 + c3;
+    unsigned incl = tsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const unsigned t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    unsigned woff = 0;
+    for (int i = 0; i < w; i++) woff += wsum[i];
+    const unsigned base = woff + incl - tsum;
+    cnt[tid * 4 + 0] = base;
+    cnt[tid * 4 + 1] = base + c0;
+    cnt[tid * 4 + 2] = base + c0 + c1;
+    cnt[tid * 4 + 3] = base + c0 + c1 + c2;
+    __syncthreads();
+    for (int k = tid; k < n; k += 1024) {
+        const unsigned pos = atomicAdd(&cnt[cell_of(k)], 1u);
+        pm[pos] = k;
+    }
+    __syncthreads(); // workgroup-scope release/acquire: the permutation written above is visible to the block
+    const int nb = (n + 63) / 64;
+    float *__restrict__ bb = bbox + (size_t)blockIdx.x * nb * 6;
+    for (int g = w; g < nb; g += 16) {
+        const int p = g * 64 + lane;
+        const bool valid = p < n;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) {
+            const int k = pm[p];
+            px = pts[(size_t)k * 3 + 0];
+            py = pts[(size_t)k * 3 + 1];
+            pz = pts[(size_t)k * 3 + 2];
+        }
+        const float xl = wave_min_f32(valid ? px : INFINITY), xh = wave_max_f32(valid ? px : -INFINITY);
+        const float yl = wave_min_f32(valid ? py : INFINITY), yh = wave_max_f32(valid ? py : -INFINITY);
+        const float zl = wave_min_f32(valid ? pz : INFINITY), zh = wave_max_f32(valid ? pz : -INFINITY);
+        if (lane == 0) {
+            bb[g * 6 + 0] = xl; bb[g * 6 + 1] = yl; bb[g * 6 + 2] = zl;
+            bb[g * 6 + 3] = xh; bb[g * 6 + 4] = yh; bb[g * 6 + 5] = zh;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ exact bucket-pruned FPS
+// NW waves per scene, P = VW (16 or 32) slots per lane.  Bucket g (64 consecutive Morton-sorted points) is slot
+// g / NW of wave g % NW, so spatial neighbours sit in different waves.  Lane i (< P) of a wave additionally
+// holds the metadata of that wave's bucket i: bounding box, max running distance, arg-max key and lane.
+template <int NW, int VW>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
+                                                             const int *__restrict__ perm, const float *__restrict__ bbox,
+                                                             int *__restrict__ out)
+{
+    constexpr int P = VW;
+    typedef typename SlotVec<VW>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *s_key = reinterpret_cast<unsigned *>(smem);                          // NW*P*64 tie keys by (slot, wave, lane)
+    unsigned *s_ex = reinterpret_cast<unsigned *>(smem + (size_t)NW * P * 64 * 4); // 2 x 16 x 5 exchange
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    int *__restrict__ o = out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id_uniform();
+    const int nb = (n + 63) / 64;
+
+    vec_t X, Y, Z, TD;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int g = i * NW + w;
+        const int p = g * 64 + lane;
+        const bool valid = p < n;
+        unsigned key = 0xFFFFFFFFu;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) {
+            const int k = pm[p];
+            px = pts[(size_t)k * 3 + 0];
+            py = pts[(size_t)k * 3 + 1];
+            pz = pts[(size_t)k * 3 + 2];
+            key = fps_tiekey((unsigned)k);
+        }
+        X[i] = px;
+        Y[i] = py;
+        Z[i] = pz;
+        TD[i] = valid ? 1e38f : 0.0f; // tf_sampling_g.cu:118; an empty slot never wins
+        s_key[(size_t)(i * NW + w) * 64 + lane] = key;
+    }
+    // metadata of bucket (slot = lane) in lanes < P
+    const int myg = lane * NW + w;
+    const bool hasb = lane < P && myg < nb;
+    const float *__restrict__ bb = bbox + ((size_t)blockIdx.x * nb + (hasb ? myg : 0)) * 6;
+    const float bxl = hasb ? bb[0] : INFINITY, byl = hasb ? bb[1] : INFINITY, bzl = hasb ? bb[2] : INFINITY;
+    const float bxh = hasb ? bb[3] : -INFINITY, byh = hasb ? bb[4] : -INFINITY, bzh = hasb ? bb[5] : -INFINITY;
+    unsigned bmax = hasb ? fbits(1e38f) : 0u;
+    unsigned bkey = 0xFFFFFFFFu;
+    int blane = 0;
+    __syncthreads();
+    FpsOut fo = {o, m, 0};
+    fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
+    float cx = pts[0], cy = pts[1], cz = pts[2];
+    for (int j = 1; j < m; j++) {
+        // (1) which of this wave's buckets can change?  lower bound of the distance to the bucket box,
+        //     shrunk by 1e-5 so that it is below every fp32-evaluated point distance of the bucket.
+        const float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
+        const float ey = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
+        const float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
+        const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+        unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+        // (2) update the active buckets, refresh their cached arg-max
+        while (act) {
+            const int i = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            const float dx = X[i] - cx, dy = Y[i] - cy, dz = Z[i] - cz; // uniform i: s_set_gpr_idx reads
+            const float d = dx * dx + dy * dy + dz * dz;                // tf_sampling_g.cu:142, un-fused
+            const unsigned d2 = min(fbits(d), fbits(TD[i]));            // :143
+            TD[i] = __uint_as_float(d2);
+            // running distances only decrease: if the cached arg-max lane kept its value, the bucket's
+            // (max, key, lane) entry is still exact and no reduction is needed
+            const int ol = __builtin_amdgcn_readlane(blane, i);
+            const unsigned omax = (unsigned)__builtin_amdgcn_readlane((int)bmax, i);
+            if ((unsigned)__builtin_amdgcn_readlane((int)d2, ol) != omax) {
+                const unsigned key = s_key[(size_t)(i * NW + w) * 64 + lane];
+                unsigned nmax, nkey;
+                const int nl = wave_argmax(d2, key, nmax, nkey);
+                if (lane == i) {
+                    bmax = nmax;
+                    bkey = nkey;
+                    blane = nl;
+                }
+            }
+        }
+        // (3) wave winner over the cached bucket entries (lanes < P)
+        unsigned wmax, wkey;
+        const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, wmax, wkey); // winning bucket = slot
+        const int fl = __builtin_amdgcn_readlane(blane, ws); // winning lane inside the bucket
+        const FpsWinner win = fps_cross_wave<NW>(wmax, wkey, readlane_f32(X[ws], fl), readlane_f32(Y[ws], fl), readlane_f32(Z[ws], fl),
+                                                 s_ex, j);
+        cx = win.x;
+        cy = win.y;
+        cz = win.z;
+        fo.put(j, (int)win.k, tid);
+    }
+}
+
+// ------------------------------------------------------------------ streaming fallback (n > 24576)
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m, const float *__restrict__ xyz,
+                                                              float *__restrict__ temp, int *__restrict__ out)
+{
+    constexpr int T = NW * 64;
+    static_assert(T % 512 == 0, "k mod 512 must be constant per lane");
+    __shared__ unsigned s_ex[2 * 16 * 5];
+    const int tid = threadIdx.x;
+    unsigned *__restrict__ td = reinterpret_cast<unsigned *>(temp) + (size_t)blockIdx.x * n;
+    for (int scene = blockIdx.x; scene < b; scene += gridDim.x) {
+        const float *__restrict__ pts = xyz + (size_t)scene * n * 3;
+        int *__restrict__ o = out + (size_t)scene * m;
+        for (int k = tid; k < n; k += T) td[k] = fbits(1e38f);
+        FpsOut fo = {o, m, 0};
+        fo.put(0, 0, tid);
+        float cx = pts[0], cy = pts[1], cz = pts[2];
+        for (int j = 1; j < m; j++) {
+            unsigned best = 0u, bk = (unsigned)tid;
+            float bx = 0.f, by = 0.f, bz = 0.f;
+            bool any = false;
+            for (int k = tid; k < n; k += T) { // ascending k, k mod 512 constant per lane
+                const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+                const float dx = px - cx, dy = py - cy, dz = pz - cz;
+                const float d = dx * dx + dy * dy + dz * dz;
+                const unsigned t0 = td[k];
+                const unsigned d2 = min(fbits(d), t0);
+                if (d2 != t0) td[k] = d2;
+                if (!any || d2 > best) {
+                    best = d2;
+                    bk = (unsigned)k;
+                    bx = px;
+                    by = py;
+                    bz = pz;
+                    any = true;
+                }
+            }
+            const unsigned key = any ? fps_tiekey(bk) : 0xFFFFFFFFu;
+            unsigned wmax, wkey;
+            const int fl = wave_argmax(best, key, wmax, wkey);
+            const FpsWinner win = fps_cross_wave<NW>(wmax, wkey, readlane_f32(bx, fl), readlane_f32(by, fl), readlane_f32(bz, fl),
+                                                     s_ex, j);
+            cx = win.x;
+            cy = win.y;
+            cz = win.z;
+            fo.put(j, (int)win.k, tid);
+        }
+        __syncthreads(); // td[] is re-initialised by other lanes for the next scene
+    }
+}
+
+static const int kFpsRegMax = 4096;         // brute-force register kernel
+static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" size_t votenet_fps_temp_floats(int b, int n)
+{
+    if (n <= kFpsRegMax) return 0;
+    if (n <= kFpsBucketMax) return (size_t)b * ((size_t)n + 6 * (size_t)((n + 63) / 64)); // Morton permutation + bucket boxes
+    return (size_t)(b < 32 ? b : 32) * (size_t)n;                                          // running distances, tf_sampling.cpp:115
+}
+
+#define FPS_LAUNCH(NW, P) hipLaunchKernelGGL((fps_reg_kernel<NW, P>), dim3(b), dim3(NW * 64), 0, st, n, m, inp, out)
+static int g_fps_dbg_nw = 0, g_fps_dbg_p = 0;
+extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a brute-force configuration (0,0 = automatic)
+{
+    g_fps_dbg_nw = nw;
+    g_fps_dbg_p = p;
+}
+#define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
+    do {                                                                                                           \
+        constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;                                          \
+        static bool attr_set = false;                                                                              \
+        if (!attr_set) {                                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<NW, VW>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            attr_set = true;                                                                                       \
+        }                                                                                                          \
+        hipLaunchKernelGGL((fps_bucket_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
+                           (const float *)(temp + (size_t)b * n), out);                                            \
+    } while (0)
+
+extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
+{
+    VN_REQUIRE(m > 0, "FarthestPointSample expects positive npoint");                               // tf_sampling.cpp:99
+    VN_REQUIRE(b >= 0 && n > 0, "FarthestPointSample expects (batch_size,num_points,3) inp shape"); // :105
+    VN_REQUIRE(inp && out, "FarthestPointSample: null buffer");
+    if (b == 0) return VOTENET_OK;
+    hipStream_t st = as_stream(stream);
+    if (n > kFpsRegMax)
+        VN_REQUIRE(temp != nullptr, "FarthestPointSample: temp scratch of %zu floats required for n=%d",
+                   votenet_fps_temp_floats(b, n), n);
+    if (g_fps_dbg_nw && n <= 64 * g_fps_dbg_nw * g_fps_dbg_p) {
+#define FPS_DBG(NW, P) if (g_fps_dbg_nw == NW && g_fps_dbg_p == P) { FPS_LAUNCH(NW, P); return check_launch("farthest_point_sample"); }
+        FPS_DBG(1, 8) FPS_DBG(1, 16) FPS_DBG(2, 4) FPS_DBG(2, 8) FPS_DBG(2, 16) FPS_DBG(4, 2) FPS_DBG(4, 4) FPS_DBG(4, 8) FPS_DBG(4, 16)
+        FPS_DBG(8, 1) FPS_DBG(8, 2) FPS_DBG(8, 4) FPS_DBG(8, 8) FPS_DBG(16, 1) FPS_DBG(16, 2) FPS_DBG(16, 4)
+    }
+    if (n <= 1024) {
+        FPS_LAUNCH(4, 4);
+    } else if (n <= 2048) {
+        FPS_LAUNCH(4, 8);
+    } else if (n <= 4096) {
+        FPS_LAUNCH(8, 8);
+    } else if (n <= kFpsBucketMax) {
+        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(b), dim3(1024), 0, st, n, inp, (int *)temp, temp + (size_t)b * n);
+        if (n <= 16 * 16 * 64) {
+            FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
+        } else {
+            FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
+        }
+    } else {
+        const int grid = b < 32 ? b : 32; // tf_sampling_g.cu:204
+        hipLaunchKernelGGL((fps_stream_kernel<16>), dim3(grid), dim3(1024), 0, st, b, n, m, inp, temp, out);
+    }
+    return check_launch("farthest_point_sample");
+}
+
+// the reference's own launcher name, C++ linkage, exact signature (tf_sampling.cpp:94)
+void farthestpointsamplingLauncher(int b, int n, int m, const float *inp, float *temp, int *out)
+{
+    votenet_farthest_point_sample(b, n, m, inp, temp, out, nullptr);
+}
