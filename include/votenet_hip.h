@@ -191,7 +191,8 @@ int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const i
 int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                               const float *scale, const float *shift, const float *mean, const float *var, float eps,
                               int relu, const float *gamma, const double *sums, float *dz /* rows x c */,
-                              float *dgamma /* += , may be NULL */, float *dbeta /* += , may be NULL */, void *stream);
+                              float *dgamma /* += , may be NULL */, float *dbeta /* += , may be NULL */,
+                              float *coef_scratch /* 5*c floats */, void *stream);
 
 /* dbias[c] += column sums of dz (rows x c); scratch: c doubles. */
 int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float *dbias, void *stream);

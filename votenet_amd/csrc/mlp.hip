@@ -25,9 +25,13 @@ namespace votenet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifndef MLP_MIN_WAVES
+#define MLP_MIN_WAVES 3
+#endif
 constexpr int MLP_BM = 128; // rows per workgroup tile
 constexpr int MLP_BK = 16;  // k-slab
 constexpr int MLP_LDA = MLP_BM + 2; // [k][row] image; +2 -> conflict-free 4-lane-strided writes
+constexpr int MLP_MAXC = 512;       // input channels whose folded BN scale/shift are staged in LDS
 
 struct MlpIn {
     // DENSE
@@ -72,7 +76,7 @@ __device__ __forceinline__ int w_row(int k, int c)
 // z = A(rows x cin) * W(cin x cout) + bias, stats += column sums of z and z^2.
 // WM x WN waves, each wave MT x NT tiles of 32x32.  BM = WM*MT*32 = 128, BN = WN*NT*32.
 template <int MODE, int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) void mlp_linear_kernel(MlpIn in, long rows, int cin, int cout,
+__global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel(MlpIn in, long rows, int cin, int cout,
                                                          const float *__restrict__ w, const float *__restrict__ bias,
                                                          float *__restrict__ z, double *__restrict__ stats)
 {
@@ -81,9 +85,17 @@ __global__ __launch_bounds__(256) void mlp_linear_kernel(MlpIn in, long rows, in
     constexpr int LDB = BN + 4;
     __shared__ float As[2][MLP_BK][MLP_LDA];
     __shared__ float Bs[2][MLP_BK][LDB];
+    __shared__ __attribute__((aligned(16))) float Ssc[MLP_MAXC], Ssh[MLP_MAXC]; // folded BN of the previous layer
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
+    const bool affine = (MODE == 0) && in.in_scale != nullptr;
+    const bool affine_lds = affine && cin <= MLP_MAXC;
+    if (affine_lds)
+        for (int k = tid; k < cin; k += 256) {
+            Ssc[k] = in.in_scale[k];
+            Ssh[k] = in.in_shift[k];
+        }
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WN, wn = wv % WN;
     const int n0 = blockIdx.y * BN;
@@ -102,14 +114,18 @@ __global__ __launch_bounds__(256) void mlp_linear_kernel(MlpIn in, long rows, in
 #pragma unroll
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
 
-    for (long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long m0 = tile * MLP_BM;
-        long ar[2];
-        int asrc[2];
-        long ascene[2];
+    // The (tile, k-slab) iteration space is flattened into one sequence of steps so that the software
+    // pipeline never drains between row tiles: while step s runs its MFMAs, the operands of step s+1
+    // (possibly the first slab of the NEXT tile) are loaded to registers, and they are written to the
+    // other LDS buffer half way through the MFMAs -- one barrier per step, no exposed global latency.
+    long ar[2];     // rows this thread stages for the step being PREFETCHED
+    int asrc[2];
+    long ascene[2];
+    auto set_rows = [&](long tile) {
+        const long m0p = tile * MLP_BM;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
-            ar[h] = m0 + a_row + h * 64;
+            ar[h] = m0p + a_row + h * 64;
             asrc[h] = 0;
             ascene[h] = 0;
             if (MODE == 1 && ar[h] < rows) {
@@ -117,138 +133,159 @@ __global__ __launch_bounds__(256) void mlp_linear_kernel(MlpIn in, long rows, in
                 ascene[h] = ar[h] / ((long)in.m * in.nsample);
             }
         }
-        f32x16 acc[MT][NT];
+    };
+    float4 ra[2];
+    float4 rb[B_PER_T];
+    auto load_slab = [&](int kt) {
+        const int k0 = kt * MLP_BK + a_kq * 4;
 #pragma unroll
-        for (int i = 0; i < MT; i++)
-#pragma unroll
-            for (int j = 0; j < NT; j++)
-#pragma unroll
-                for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-
-        float4 ra[2];
-        float4 rb[B_PER_T];
-        auto load_slab = [&](int kt) {
-            const int k0 = kt * MLP_BK + a_kq * 4;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ar[h] < rows) {
-                    bool done = false;
-                    if (a_vec4) {
-                        if (MODE == 0 && k0 + 3 < cin) {
-                            v = *reinterpret_cast<const float4 *>(in.x + (size_t)ar[h] * cin + k0);
-                            if (in.in_scale) {
-                                const float4 sc = *reinterpret_cast<const float4 *>(in.in_scale + k0);
-                                const float4 sh = *reinterpret_cast<const float4 *>(in.in_shift + k0);
-                                v.x = v.x * sc.x + sh.x;
-                                v.y = v.y * sc.y + sh.y;
-                                v.z = v.z * sc.z + sh.z;
-                                v.w = v.w * sc.w + sh.w;
-                                if (in.in_relu) {
-                                    v.x = v.x > 0.f ? v.x : 0.f;
-                                    v.y = v.y > 0.f ? v.y : 0.f;
-                                    v.z = v.z > 0.f ? v.z : 0.f;
-                                    v.w = v.w > 0.f ? v.w : 0.f;
-                                }
+        for (int h = 0; h < 2; h++) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ar[h] < rows) {
+                bool done = false;
+                if (a_vec4) {
+                    if (MODE == 0 && k0 + 3 < cin) {
+                        v = *reinterpret_cast<const float4 *>(in.x + (size_t)ar[h] * cin + k0);
+                        if (affine) {
+                            const float4 sc = affine_lds ? *reinterpret_cast<const float4 *>(&Ssc[k0])
+                                                         : *reinterpret_cast<const float4 *>(in.in_scale + k0);
+                            const float4 sh = affine_lds ? *reinterpret_cast<const float4 *>(&Ssh[k0])
+                                                         : *reinterpret_cast<const float4 *>(in.in_shift + k0);
+                            v.x = v.x * sc.x + sh.x;
+                            v.y = v.y * sc.y + sh.y;
+                            v.z = v.z * sc.z + sh.z;
+                            v.w = v.w * sc.w + sh.w;
+                            if (in.in_relu) {
+                                v.x = v.x > 0.f ? v.x : 0.f;
+                                v.y = v.y > 0.f ? v.y : 0.f;
+                                v.z = v.z > 0.f ? v.z : 0.f;
+                                v.w = v.w > 0.f ? v.w : 0.f;
                             }
-                            done = true;
-                        } else if (MODE == 1 && k0 + 3 < in.c) {
-                            v = *reinterpret_cast<const float4 *>(in.feat + ((size_t)ascene[h] * in.n + asrc[h]) * in.c + k0);
-                            done = true;
+                        }
+                        done = true;
+                    } else if (MODE == 1 && k0 + 3 < in.c) {
+                        v = *reinterpret_cast<const float4 *>(in.feat + ((size_t)ascene[h] * in.n + asrc[h]) * in.c + k0);
+                        done = true;
+                    }
+                }
+                if (!done) {
+                    float t[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        t[q] = (k0 + q < cin) ? a_elem<MODE>(in, ar[h], k0 + q, cin, asrc[h], ascene[h]) : 0.0f;
+                    v = make_float4(t[0], t[1], t[2], t[3]);
+                }
+            }
+            ra[h] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; u++) {
+            const int f = tid + u * 256;
+            const int kk = f / (BN / 4), nq = f % (BN / 4);
+            const int k = kt * MLP_BK + kk;
+            const int nn = n0 + nq * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < cin) {
+                const float *wr = w + (size_t)w_row<MODE>(k, in.c) * cout;
+                if (b_vec4 && nn + 3 < cout) {
+                    v = *reinterpret_cast<const float4 *>(wr + nn);
+                } else {
+                    if (nn + 0 < cout) v.x = wr[nn + 0];
+                    if (nn + 1 < cout) v.y = wr[nn + 1];
+                    if (nn + 2 < cout) v.z = wr[nn + 2];
+                    if (nn + 3 < cout) v.w = wr[nn + 3];
+                }
+            }
+            rb[u] = v;
+        }
+    };
+    auto store_slab = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int r = a_row + h * 64;
+            As[buf][a_kq * 4 + 0][r] = ra[h].x;
+            As[buf][a_kq * 4 + 1][r] = ra[h].y;
+            As[buf][a_kq * 4 + 2][r] = ra[h].z;
+            As[buf][a_kq * 4 + 3][r] = ra[h].w;
+        }
+#pragma unroll
+        for (int u = 0; u < B_PER_T; u++) {
+            const int f = tid + u * 256;
+            const int kk = f / (BN / 4), nq = f % (BN / 4);
+            *reinterpret_cast<float4 *>(&Bs[buf][kk][nq * 4]) = rb[u];
+        }
+    };
+
+    f32x16 acc[MT][NT];
+    const int kh = lane >> 5, l31 = lane & 31;
+    long tile = blockIdx.x;
+    if (affine_lds) __syncthreads(); // Ssc / Ssh visible before the first staged load uses them
+    if (tile < ntiles) {
+        set_rows(tile);
+        load_slab(0);
+        store_slab(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    int kt = 0;
+    while (tile < ntiles) {
+        // step (tile, kt); the step after it
+        const bool last_k = (kt + 1 == nk);
+        const long ntile = last_k ? tile + gridDim.x : tile;
+        const int nkt = last_k ? 0 : kt + 1;
+        const bool have_next = ntile < ntiles;
+        if (kt == 0) {
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
+        }
+        if (have_next) {
+            if (last_k) set_rows(ntile);
+            load_slab(nkt); // global loads in flight during the first half of the MFMAs
+        }
+#pragma unroll
+        for (int k2 = 0; k2 < MLP_BK / 2; k2++) {
+            if (k2 == MLP_BK / 4 && have_next) store_slab(buf ^ 1); // other buffer: last read one step ago, behind a barrier
+            float a[MT], b[NT];
+#pragma unroll
+            for (int i = 0; i < MT; i++) a[i] = As[buf][k2 * 2 + kh][(wm * MT + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NT; j++) b[j] = Bs[buf][k2 * 2 + kh][(wn * NT + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        buf ^= 1;
+        if (last_k) {
+            // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+            const long m0 = tile * MLP_BM;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int col = n0 + (wn * NT + j) * 32 + (lane & 31);
+                const bool cok = col < cout;
+                const float bv = (bias && cok) ? bias[col] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const long row = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                        if (cok && row < rows) {
+                            const float v = acc[i][j][e] + bv;
+                            z[(size_t)row * cout + col] = v;
+                            s1[j] += v;
+                            s2[j] += v * v;
                         }
                     }
-                    if (!done) {
-                        float t[4];
-#pragma unroll
-                        for (int q = 0; q < 4; q++)
-                            t[q] = (k0 + q < cin) ? a_elem<MODE>(in, ar[h], k0 + q, cin, asrc[h], ascene[h]) : 0.0f;
-                        v = make_float4(t[0], t[1], t[2], t[3]);
-                    }
-                }
-                ra[h] = v;
-            }
-#pragma unroll
-            for (int u = 0; u < B_PER_T; u++) {
-                const int f = tid + u * 256;
-                const int kk = f / (BN / 4), nq = f % (BN / 4);
-                const int k = kt * MLP_BK + kk;
-                const int nn = n0 + nq * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < cin) {
-                    const float *wr = w + (size_t)w_row<MODE>(k, in.c) * cout;
-                    if (b_vec4 && nn + 3 < cout) {
-                        v = *reinterpret_cast<const float4 *>(wr + nn);
-                    } else {
-                        if (nn + 0 < cout) v.x = wr[nn + 0];
-                        if (nn + 1 < cout) v.y = wr[nn + 1];
-                        if (nn + 2 < cout) v.z = wr[nn + 2];
-                        if (nn + 3 < cout) v.w = wr[nn + 3];
-                    }
-                }
-                rb[u] = v;
-            }
-        };
-        auto store_slab = [&](int buf) {
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                const int r = a_row + h * 64;
-                As[buf][a_kq * 4 + 0][r] = ra[h].x;
-                As[buf][a_kq * 4 + 1][r] = ra[h].y;
-                As[buf][a_kq * 4 + 2][r] = ra[h].z;
-                As[buf][a_kq * 4 + 3][r] = ra[h].w;
-            }
-#pragma unroll
-            for (int u = 0; u < B_PER_T; u++) {
-                const int f = tid + u * 256;
-                const int kk = f / (BN / 4), nq = f % (BN / 4);
-                *reinterpret_cast<float4 *>(&Bs[buf][kk][nq * 4]) = rb[u];
-            }
-        };
-
-        load_slab(0);
-        int buf = 0;
-        for (int kt = 0; kt < nk; kt++) {
-            store_slab(buf);
-            __syncthreads();
-            if (kt + 1 < nk) load_slab(kt + 1); // global loads in flight during the MFMAs
-            const int kh = lane >> 5, l31 = lane & 31;
-#pragma unroll
-            for (int k2 = 0; k2 < MLP_BK / 2; k2++) {
-                float a[MT], b[NT];
-#pragma unroll
-                for (int i = 0; i < MT; i++) a[i] = As[buf][k2 * 2 + kh][(wm * MT + i) * 32 + l31];
-#pragma unroll
-                for (int j = 0; j < NT; j++) b[j] = Bs[buf][k2 * 2 + kh][(wn * NT + j) * 32 + l31];
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int j = 0; j < NT; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
-            }
-            buf ^= 1;
-        }
-        __syncthreads(); // the next tile's first store_slab reuses buffer 0/1
-
-        // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int col = n0 + (wn * NT + j) * 32 + (lane & 31);
-            const bool cok = col < cout;
-            const float bv = (bias && cok) ? bias[col] : 0.0f;
-#pragma unroll
-            for (int i = 0; i < MT; i++) {
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const long row = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                    if (cok && row < rows) {
-                        const float v = acc[i][j][e] + bv;
-                        z[(size_t)row * cout + col] = v;
-                        s1[j] += v;
-                        s2[j] += v * v;
-                    }
                 }
             }
         }
+        tile = ntile;
+        kt = nkt;
     }
     if (stats) {
 #pragma unroll

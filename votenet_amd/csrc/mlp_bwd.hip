@@ -111,38 +111,95 @@ __global__ __launch_bounds__(256) void colsum_kernel(long rows, int c, const flo
 }
 
 // ---------------------------------------------------------------- BN backward: apply
-// dz = gamma*invstd*(da' - s1/N - zhat*s2/N);  also dgamma += s2, dbeta += s1 (block 0 only)
-__global__ void bn_bwd_apply_kernel(long rows, int c, int k /*0: dense*/, const float *__restrict__ da,
-                                    const int *__restrict__ argmax, const float *__restrict__ z,
-                                    const float *__restrict__ scale, const float *__restrict__ shift,
-                                    const float *__restrict__ mean, const float *__restrict__ var, float eps, int relu,
-                                    const float *__restrict__ gamma, const double *__restrict__ sums, float *__restrict__ dz,
-                                    float *__restrict__ dgamma, float *__restrict__ dbeta)
+// dz = gamma*invstd*(da' - s1/N - zhat*s2/N) = A*da' + B + C*z with per-channel A, B, C:
+//   A = gamma*inv, C = -gamma*inv^2*(s2/N), B = -gamma*inv*(s1/N) - C*mean.   coef: [A | B | C | scale | shift], 5*c floats
+__global__ void bn_bwd_coef_kernel(long rows, int c, const float *__restrict__ scale, const float *__restrict__ shift,
+                                   const float *__restrict__ mean, const float *__restrict__ var, float eps,
+                                   const float *__restrict__ gamma, const double *__restrict__ sums, float *__restrict__ coef,
+                                   float *__restrict__ dgamma, float *__restrict__ dbeta)
 {
-    const long total = rows * c;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= c) return;
     const double invn = 1.0 / (double)rows;
+    const float inv = 1.0f / sqrtf(var[col] + eps);
+    const float m1 = (float)(sums[col] * invn), m2 = (float)(sums[c + col] * invn);
+    const float A = gamma[col] * inv;
+    const float C = -A * inv * m2;
+    coef[col] = A;
+    coef[c + col] = -A * m1 - C * mean[col];
+    coef[2 * c + col] = C;
+    coef[3 * c + col] = scale[col];
+    coef[4 * c + col] = shift[col];
+    if (dgamma) dgamma[col] += (float)sums[c + col];
+    if (dbeta) dbeta[col] += (float)sums[col];
+}
+
+// VEC = 4: c % 4 == 0, float4 per thread; VEC = 1: scalar.  k > 0: da is the pooled gout with argmax.
+template <int VEC>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(long rows, int c, int k, const float *__restrict__ da,
+                                                           const int *__restrict__ argmax, const float *__restrict__ z,
+                                                           const float *__restrict__ coef, int relu, float *__restrict__ dz)
+{
+    const int cv = c / VEC;
+    const long total = rows * cv;
+    // the grid stride (gridDim.x * 256) is a multiple of cv whenever cv divides 256: then a thread keeps
+    // the same channels for its whole row sweep and the five per-channel coefficients live in registers
+    const bool fixed_col = (256 % cv) == 0;
+    float cA[VEC], cB[VEC], cC[VEC], cS[VEC], cH[VEC];
+    if (fixed_col) {
+        const int col0 = (int)(((long)blockIdx.x * blockDim.x + threadIdx.x) % cv) * VEC;
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            cA[q] = coef[col0 + q];
+            cB[q] = coef[c + col0 + q];
+            cC[q] = coef[2 * c + col0 + q];
+            cS[q] = coef[3 * c + col0 + q];
+            cH[q] = coef[4 * c + col0 + q];
+        }
+    }
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / c;
-        const int col = (int)(e - r * c);
-        const float inv = 1.0f / sqrtf(var[col] + eps);
-        const float zz = z[e];
-        float g;
+        const long r = e / cv;
+        const int col = (int)(e - r * cv) * VEC;
+        float zz[VEC], g[VEC], out[VEC];
+        if (!fixed_col) {
+#pragma unroll
+            for (int q = 0; q < VEC; q++) {
+                cA[q] = coef[col + q];
+                cB[q] = coef[c + col + q];
+                cC[q] = coef[2 * c + col + q];
+                cS[q] = coef[3 * c + col + q];
+                cH[q] = coef[4 * c + col + q];
+            }
+        }
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(z + (size_t)r * c + col);
+            zz[0] = t.x; zz[VEC > 1 ? 1 : 0] = t.y; zz[VEC > 2 ? 2 : 0] = t.z; zz[VEC > 3 ? 3 : 0] = t.w;
+        } else {
+            zz[0] = z[(size_t)r * c + col];
+        }
         if (k > 0) {
             const long grp = r / k;
-            g = ((int)(r - grp * k) == argmax[(size_t)grp * c + col]) ? da[(size_t)grp * c + col] : 0.0f;
+            const int rk = (int)(r - grp * k);
+#pragma unroll
+            for (int q = 0; q < VEC; q++)
+                g[q] = (rk == argmax[(size_t)grp * c + col + q]) ? da[(size_t)grp * c + col + q] : 0.0f;
+        } else if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4 *>(da + (size_t)r * c + col);
+            g[0] = t.x; g[VEC > 1 ? 1 : 0] = t.y; g[VEC > 2 ? 2 : 0] = t.z; g[VEC > 3 ? 3 : 0] = t.w;
         } else {
-            g = da[e];
+            g[0] = da[(size_t)r * c + col];
         }
-        if (relu && !(zz * scale[col] + shift[col] > 0.0f)) g = 0.0f;
-        const float m1 = (float)(sums[col] * invn), m2 = (float)(sums[c + col] * invn);
-        const float zh = (zz - mean[col]) * inv;
-        dz[e] = gamma[col] * inv * (g - m1 - zh * m2);
+#pragma unroll
+        for (int q = 0; q < VEC; q++) {
+            float gg = g[q];
+            if (relu && !(zz[q] * cS[q] + cH[q] > 0.0f)) gg = 0.0f;
+            out[q] = cA[q] * gg + cB[q] + cC[q] * zz[q];
+        }
+        if (VEC == 4)
+            *reinterpret_cast<float4 *>(dz + (size_t)r * c + col) = make_float4(out[0], out[VEC > 1 ? 1 : 0], out[VEC > 2 ? 2 : 0], out[VEC > 3 ? 3 : 0]);
+        else
+            dz[(size_t)r * c + col] = out[0];
     }
-    if (blockIdx.x == 0)
-        for (int col = threadIdx.x; col < c; col += blockDim.x) {
-            if (dgamma) dgamma[col] += (float)sums[c + col];
-            if (dbeta) dbeta[col] += (float)sums[col];
-        }
 }
 
 // dst[i] += (float)src[i]  (bias gradient from colsum)
@@ -433,13 +490,21 @@ extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *
 extern "C" int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                                          const float *scale, const float *shift, const float *mean, const float *var,
                                          float eps, int relu, const float *gamma, const double *sums, float *dz,
-                                         float *dgamma, float *dbeta, void *stream)
+                                         float *dgamma, float *dbeta, float *coef_scratch, void *stream)
 {
     VN_REQUIRE(rows > 0 && c > 0 && k >= 0, "bn_backward_apply expects rows > 0, c > 0, k >= 0");
-    VN_REQUIRE(da && z && scale && shift && mean && var && gamma && sums && dz, "bn_backward_apply: null buffer");
+    VN_REQUIRE(da && z && scale && shift && mean && var && gamma && sums && dz && coef_scratch, "bn_backward_apply: null buffer");
     VN_REQUIRE(k == 0 || argmax != nullptr, "bn_backward_apply: pooled mode needs argmax");
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, c, k, da, argmax,
-                       z, scale, shift, mean, var, eps, relu, gamma, sums, dz, dgamma, dbeta);
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rows, c, scale, shift, mean, var, eps, gamma,
+                       sums, coef_scratch, dgamma, dbeta);
+    const bool vec = (c % 4 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) && (k > 0 || (uintptr_t)da % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(rows * (c / 4), 256)), dim3(256), 0, st, rows, c, k, da, argmax, z,
+                           coef_scratch, relu, dz);
+    else
+        hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(rows * c, 256)), dim3(256), 0, st, rows, c, k, da, argmax, z,
+                           coef_scratch, relu, dz);
     return check_launch("bn_backward_apply");
 }
 

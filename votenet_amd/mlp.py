@@ -113,6 +113,7 @@ def bn_backward(z, scale, shift, mean, var, gamma, relu, da, dgamma, dbeta, argm
     Returns dz (rows,c); accumulates dgamma / dbeta (views into the gradient bucket)."""
     rows, c = z.shape
     sums = torch.zeros(2 * c, dtype=torch.float64, device=z.device)
+    coef = torch.empty(5 * c, dtype=torch.float32, device=z.device)
     dz = torch.empty_like(z)
     with torch.cuda.device(z.device):
         L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
@@ -120,7 +121,7 @@ def bn_backward(z, scale, shift, mean, var, gamma, relu, da, dgamma, dbeta, argm
                                                    L.stream_ptr()))
         L.check(L.lib().votenet_bn_backward_apply(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
                                                   L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(gamma),
-                                                  L.ptr(sums), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.stream_ptr()))
+                                                  L.ptr(sums), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), L.stream_ptr()))
     return dz
 
 
