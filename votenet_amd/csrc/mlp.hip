@@ -29,7 +29,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define MLP_MIN_WAVES 3
 #endif
 constexpr int MLP_BM = 128; // rows per workgroup tile
-constexpr int MLP_BK = 16;  // k-slab
+#ifndef MLP_BK_DEF
+#define MLP_BK_DEF 16
+#endif
+constexpr int MLP_BK = MLP_BK_DEF;  // k-slab
+constexpr int MLP_KQ = MLP_BK / 4;        // float4 per staged row
+constexpr int MLP_RPP = 256 / MLP_KQ;     // rows staged per pass of the 256 threads
+constexpr int MLP_AP = MLP_BM / MLP_RPP;  // passes (float4 per thread) for the A slab
 constexpr int MLP_LDA = MLP_BM + 2; // [k][row] image; +2 -> conflict-free 4-lane-strided writes
 constexpr int MLP_MAXC = 512;       // input channels whose folded BN scale/shift are staged in LDS
 
@@ -75,7 +81,9 @@ __device__ __forceinline__ int w_row(int k, int c)
 
 // z = A(rows x cin) * W(cin x cout) + bias, stats += column sums of z and z^2.
 // WM x WN waves, each wave MT x NT tiles of 32x32.  BM = WM*MT*32 = 128, BN = WN*NT*32.
-template <int MODE, int WM, int WN, int MT, int NT>
+// FAST: dense input, cin % 16 == 0, cout % BN == 0, rows % 128 == 0, 16-byte aligned operands -- no bounds
+// checks, operand addresses advance by pointer increments (every dense VoteNet layer qualifies).
+template <int MODE, int WM, int WN, int MT, int NT, bool FAST>
 __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel(MlpIn in, long rows, int cin, int cout,
                                                          const float *__restrict__ w, const float *__restrict__ bias,
                                                          float *__restrict__ z, double *__restrict__ stats)
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
     const bool b_vec4 = ((cout & 3) == 0);
 
     // A staging: thread t loads rows (t>>2) and (t>>2)+64 of the tile, k-quad (t&3) of the slab
-    const int a_row = tid >> 2, a_kq = tid & 3;
+    const int a_row = tid / MLP_KQ, a_kq = tid % MLP_KQ;
     // B staging: BK x BN floats = 4*BN float4; thread t loads float4 #t and #t+256 (if BN=128)
     constexpr int B_F4 = MLP_BK * BN / 4;       // 256 (BN=64) or 512 (BN=128)
     constexpr int B_PER_T = B_F4 / 256;         // 1 or 2
@@ -118,14 +126,26 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
     // pipeline never drains between row tiles: while step s runs its MFMAs, the operands of step s+1
     // (possibly the first slab of the NEXT tile) are loaded to registers, and they are written to the
     // other LDS buffer half way through the MFMAs -- one barrier per step, no exposed global latency.
-    long ar[2];     // rows this thread stages for the step being PREFETCHED
-    int asrc[2];
-    long ascene[2];
+    long ar[MLP_AP];     // rows this thread stages for the step being PREFETCHED
+    int asrc[MLP_AP];
+    long ascene[MLP_AP];
+    const float *pa[MLP_AP]; // FAST: this thread's A pointers for the step being prefetched
+    const float *pb[B_PER_T];
     auto set_rows = [&](long tile) {
         const long m0p = tile * MLP_BM;
+        if constexpr (FAST) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            ar[h] = m0p + a_row + h * 64;
+            for (int h = 0; h < MLP_AP; h++) pa[h] = in.x + (size_t)(m0p + a_row + h * MLP_RPP) * cin + a_kq * 4;
+#pragma unroll
+            for (int u = 0; u < B_PER_T; u++) {
+                const int f = tid + u * 256;
+                pb[u] = w + (size_t)(f / (BN / 4)) * cout + n0 + (f % (BN / 4)) * 4;
+            }
+            return;
+        }
+#pragma unroll
+        for (int h = 0; h < MLP_AP; h++) {
+            ar[h] = m0p + a_row + h * MLP_RPP;
             asrc[h] = 0;
             ascene[h] = 0;
             if (MODE == 1 && ar[h] < rows) {
@@ -134,12 +154,41 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
             }
         }
     };
-    float4 ra[2];
+    float4 ra[MLP_AP];
     float4 rb[B_PER_T];
     auto load_slab = [&](int kt) {
+        if constexpr (FAST) {
+            const int kq = kt * MLP_BK + a_kq * 4;
+#pragma unroll
+            for (int h = 0; h < MLP_AP; h++) {
+                float4 v = *reinterpret_cast<const float4 *>(pa[h]);
+                pa[h] += MLP_BK;
+                if (affine) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(&Ssc[kq]);
+                    const float4 sh = *reinterpret_cast<const float4 *>(&Ssh[kq]);
+                    v.x = v.x * sc.x + sh.x;
+                    v.y = v.y * sc.y + sh.y;
+                    v.z = v.z * sc.z + sh.z;
+                    v.w = v.w * sc.w + sh.w;
+                    if (in.in_relu) {
+                        v.x = v.x > 0.f ? v.x : 0.f;
+                        v.y = v.y > 0.f ? v.y : 0.f;
+                        v.z = v.z > 0.f ? v.z : 0.f;
+                        v.w = v.w > 0.f ? v.w : 0.f;
+                    }
+                }
+                ra[h] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < B_PER_T; u++) {
+                rb[u] = *reinterpret_cast<const float4 *>(pb[u]);
+                pb[u] += (size_t)MLP_BK * cout;
+            }
+            return;
+        }
         const int k0 = kt * MLP_BK + a_kq * 4;
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int h = 0; h < MLP_AP; h++) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ar[h] < rows) {
                 bool done = false;
@@ -201,8 +250,8 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int r = a_row + h * 64;
+        for (int h = 0; h < MLP_AP; h++) {
+            const int r = a_row + h * MLP_RPP;
             As[buf][a_kq * 4 + 0][r] = ra[h].x;
             As[buf][a_kq * 4 + 1][r] = ra[h].y;
             As[buf][a_kq * 4 + 2][r] = ra[h].z;
@@ -218,22 +267,34 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
 
     f32x16 acc[MT][NT];
     const int kh = lane >> 5, l31 = lane & 31;
-    long tile = blockIdx.x;
     if (affine_lds) __syncthreads(); // Ssc / Ssh visible before the first staged load uses them
+    // Pipeline over steps s = (tile, kt):  registers hold step s+1 while step s computes; at mid-step they are
+    // written to the other LDS buffer and immediately re-used to fetch step s+2, so every global load has a
+    // full step of MFMAs (not half) to land.
+    long tile = blockIdx.x;  // step being computed
+    int kt = 0;
+    long ptile = tile;       // step whose operands are fetched next
+    int pkt = 0;
+    auto advance = [&](long &t, int &k) {
+        if (++k == nk) {
+            k = 0;
+            t += gridDim.x;
+        }
+    };
     if (tile < ntiles) {
-        set_rows(tile);
-        load_slab(0);
+        set_rows(ptile);
+        load_slab(pkt);
         store_slab(0);
+        advance(ptile, pkt);
+        if (ptile < ntiles) {
+            if (pkt == 0) set_rows(ptile);
+            load_slab(pkt); // step 1 in flight
+        }
     }
     __syncthreads();
     int buf = 0;
-    int kt = 0;
     while (tile < ntiles) {
-        // step (tile, kt); the step after it
         const bool last_k = (kt + 1 == nk);
-        const long ntile = last_k ? tile + gridDim.x : tile;
-        const int nkt = last_k ? 0 : kt + 1;
-        const bool have_next = ntile < ntiles;
         if (kt == 0) {
 #pragma unroll
             for (int i = 0; i < MT; i++)
@@ -242,22 +303,37 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
 #pragma unroll
                     for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
         }
-        if (have_next) {
-            if (last_k) set_rows(ntile);
-            load_slab(nkt); // global loads in flight during the first half of the MFMAs
-        }
+        const bool have_next = ptile < ntiles; // registers hold step s+1
+        // MFMA operand fragments are double-buffered in registers: the ds_reads of sub-step k2+1 are issued
+        // before the MFMAs of sub-step k2, so LDS latency hides under the matrix pipe
+        float fa[2][MT], fb[2][NT];
+#pragma unroll
+        for (int i = 0; i < MT; i++) fa[0][i] = As[buf][kh][(wm * MT + i) * 32 + l31];
+#pragma unroll
+        for (int j = 0; j < NT; j++) fb[0][j] = Bs[buf][kh][(wn * NT + j) * 32 + l31];
 #pragma unroll
         for (int k2 = 0; k2 < MLP_BK / 2; k2++) {
-            if (k2 == MLP_BK / 4 && have_next) store_slab(buf ^ 1); // other buffer: last read one step ago, behind a barrier
-            float a[MT], b[NT];
+            if (k2 == MLP_BK / 4 && have_next) {
+                store_slab(buf ^ 1); // other buffer: last read one step ago, behind a barrier
+                advance(ptile, pkt);
+                if (ptile < ntiles) {
+                    if (pkt == 0) set_rows(ptile);
+                    load_slab(pkt); // step s+2
+                }
+            }
+            if (k2 + 1 < MLP_BK / 2) {
 #pragma unroll
-            for (int i = 0; i < MT; i++) a[i] = As[buf][k2 * 2 + kh][(wm * MT + i) * 32 + l31];
+                for (int i = 0; i < MT; i++) fa[(k2 + 1) & 1][i] = As[buf][(k2 + 1) * 2 + kh][(wm * MT + i) * 32 + l31];
 #pragma unroll
-            for (int j = 0; j < NT; j++) b[j] = Bs[buf][k2 * 2 + kh][(wn * NT + j) * 32 + l31];
+                for (int j = 0; j < NT; j++) fb[(k2 + 1) & 1][j] = Bs[buf][(k2 + 1) * 2 + kh][(wn * NT + j) * 32 + l31];
+            }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
-                for (int j = 0; j < NT; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < NT; j++)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][i], fb[k2 & 1][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
         buf ^= 1;
@@ -274,7 +350,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const long row = m0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                        if (cok && row < rows) {
+                        if (FAST || (cok && row < rows)) {
                             const float v = acc[i][j][e] + bv;
                             z[(size_t)row * cout + col] = v;
                             s1[j] += v;
@@ -284,8 +360,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
                 }
             }
         }
-        tile = ntile;
-        kt = nkt;
+        advance(tile, kt);
     }
     if (stats) {
 #pragma unroll
@@ -369,16 +444,31 @@ static int launch_linear(const MlpIn &in, long rows, int cin, int cout, const fl
                          double *stats, hipStream_t st)
 {
     const long ntiles = (rows + MLP_BM - 1) / MLP_BM;
+    const bool aligned = ((uintptr_t)in.x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
+    const bool fast_in = MODE == 0 && aligned && (cin % MLP_BK == 0) && (rows % MLP_BM == 0) &&
+                         (in.in_scale == nullptr || cin <= MLP_MAXC);
     if (cout > 64) {
         const int ny = (cout + 127) / 128;
         long gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
         if (gx < 1) gx = 1;
-        hipLaunchKernelGGL((mlp_linear_kernel<MODE, 2, 2, 2, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, in, rows, cin, cout,
-                           w, bias, z, stats);
+        if (fast_in && cout % 128 == 0) {
+            if constexpr (MODE == 0)
+                hipLaunchKernelGGL((mlp_linear_kernel<0, 2, 2, 2, 2, true>), dim3((unsigned)gx, ny), dim3(256), 0, st, in, rows, cin,
+                                   cout, w, bias, z, stats);
+        } else {
+            hipLaunchKernelGGL((mlp_linear_kernel<MODE, 2, 2, 2, 2, false>), dim3((unsigned)gx, ny), dim3(256), 0, st, in, rows, cin,
+                               cout, w, bias, z, stats);
+        }
     } else {
         long gx = ntiles < 2048 ? ntiles : 2048;
-        hipLaunchKernelGGL((mlp_linear_kernel<MODE, 4, 1, 1, 2>), dim3((unsigned)gx, 1), dim3(256), 0, st, in, rows, cin, cout,
-                           w, bias, z, stats);
+        if (fast_in && cout == 64) {
+            if constexpr (MODE == 0)
+                hipLaunchKernelGGL((mlp_linear_kernel<0, 4, 1, 1, 2, true>), dim3((unsigned)gx, 1), dim3(256), 0, st, in, rows, cin, cout,
+                                   w, bias, z, stats);
+        } else {
+            hipLaunchKernelGGL((mlp_linear_kernel<MODE, 4, 1, 1, 2, false>), dim3((unsigned)gx, 1), dim3(256), 0, st, in, rows, cin, cout,
+                               w, bias, z, stats);
+        }
     }
     return check_launch("mlp_linear");
 }

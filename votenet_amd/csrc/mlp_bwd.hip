@@ -343,18 +343,28 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
         __syncthreads();
         if (r0 + WG_BR < r_end) load_slab(r0 + WG_BR);
         const int kh = lane >> 5, l31 = lane & 31;
+        float fa[2][2], fb[2][2]; // register double-buffered fragments: reads of k2+1 issued before MFMAs of k2
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+            fa[0][t] = As[buf][kh][(wi * 2 + t) * 32 + l31];
+            fb[0][t] = Bs[buf][kh][(wj * 2 + t) * 32 + l31];
+        }
 #pragma unroll
         for (int k2 = 0; k2 < WG_BR / 2; k2++) {
-            float a[2], b[2];
+            if (k2 + 1 < WG_BR / 2) {
 #pragma unroll
-            for (int t = 0; t < 2; t++) {
-                a[t] = As[buf][k2 * 2 + kh][(wi * 2 + t) * 32 + l31];
-                b[t] = Bs[buf][k2 * 2 + kh][(wj * 2 + t) * 32 + l31];
+                for (int t = 0; t < 2; t++) {
+                    fa[(k2 + 1) & 1][t] = As[buf][(k2 + 1) * 2 + kh][(wi * 2 + t) * 32 + l31];
+                    fb[(k2 + 1) & 1][t] = Bs[buf][(k2 + 1) * 2 + kh][(wj * 2 + t) * 32 + l31];
+                }
             }
+            __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
 #pragma unroll
             for (int s = 0; s < 2; s++)
 #pragma unroll
-                for (int t = 0; t < 2; t++) acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[t], acc[s][t], 0, 0, 0);
+                for (int t = 0; t < 2; t++)
+                    acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][s], fb[k2 & 1][t], acc[s][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         buf ^= 1;
     }
