@@ -204,13 +204,16 @@ int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float 
 int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
                       void *stream);
 
-/* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78)
- * on the feature columns + the gradients of grouped_xyz - tile(new_xyz) on the first three:
- *   d_in (b*m*nsample x (3+c)), columns [dxyz, feat]:
- *   d_feat[b,idx,:] += d_in[:,3:] ; d_xyz[b,idx,:] += d_in[:,:3] ; d_new_xyz[b,j,:] -= sum_k d_in[:,:3]
- * Each output may be NULL (not needed); outputs are accumulated into (pre-zeroed by the caller). */
-int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_in, const int *idx,
-                              float *d_feat, float *d_xyz, float *d_new_xyz, void *stream);
+/* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78) on the
+ * feature columns + the gradients of grouped_xyz - tile(new_xyz) on the xyz columns.  The per-row input
+ * gradients are given separately: d_rows_feat (b*m*nsample x c) and d_rows_xyz (b*m*nsample x 3):
+ *   d_feat[b,idx,:] += d_rows_feat ; d_xyz[b,idx,:] += d_rows_xyz ; d_new_xyz[b,j,:] -= sum_k d_rows_xyz
+ * Either pair may be NULL (not needed); outputs are accumulated into (pre-zeroed by the caller).
+ * pts_cnt (b,m) from votenet_query_ball_point (may be NULL): rows k >= pts_cnt[b,j] are padding that
+ * repeats idx[b,j,0]; they are pre-summed so each group issues pts_cnt instead of nsample atomics. */
+int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_rows_feat,
+                              const float *d_rows_xyz, const int *idx, const int *pts_cnt, float *d_feat, float *d_xyz,
+                              float *d_new_xyz, void *stream);
 
 /* Optimizer of model.py:240-250 over one flat parameter bucket: per-tensor
  * tf.clip_by_average_norm(g, clip) = g*clip/max(||g||_2/numel, clip) (skipped when clip <= 0), then

@@ -383,47 +383,58 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
 }
 
 // ---------------------------------------------------------------- first-layer input gradient scatter
-// d_in (rows x (3+c)), columns [dxyz(3), feat(c)] (the reference's concat order, utils.py:55)
-//   d_feat[s, idx[r], :]  += d_in[r, 3:]
-//   d_xyz [s, idx[r], :]  += d_in[r, :3]          (only when d_xyz != NULL)
-//   d_new_xyz[s, j, :]    -= sum_k d_in[r, :3]    (only when d_new_xyz != NULL)
-__global__ void group_concat_grad_kernel(long rows, int n, int c, long rows_per_scene, int nsample,
-                                         const float *__restrict__ d_in, const int *__restrict__ idx,
-                                         float *__restrict__ d_feat, float *__restrict__ d_xyz, float *__restrict__ d_new_xyz)
+// Gradient of the sample_and_group concat: the per-row input gradients, given separately for the feature
+// columns d_rows_feat (rows x c) and the xyz columns d_rows_xyz (rows x 3), go back to
+//   d_feat[s, idx[r], :]  += d_rows_feat[r, :]
+//   d_xyz [s, idx[r], :]  += d_rows_xyz[r, :] ,   d_new_xyz[s, j, :] -= sum_k d_rows_xyz[r, :]
+// One thread per (group, channel) walks the group's nsample rows.  A ball with fewer than nsample
+// neighbours is padded with its FIRST hit (tf_grouping_g.cu:26-29), so rows k >= pts_cnt all target
+// idx[g,0]: they are summed in a register and cost ONE atomic instead of nsample - pts_cnt.
+__global__ __launch_bounds__(256) void group_concat_grad_kernel(long groups, int n, int cc /* c or 3 */, int groups_per_scene,
+                                                                int nsample, const float *__restrict__ d_rows,
+                                                                const int *__restrict__ idx, const int *__restrict__ pts_cnt,
+                                                                float *__restrict__ d_table, float *__restrict__ d_new_xyz)
 {
-    const int cc = 3 + c;
-    const long total = rows * cc;
+    const long total = groups * cc;
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const long r = e / cc;
-        const int l = (int)(e - r * cc);
-        const long s = r / rows_per_scene;
-        const int ii = idx[r];
-        const float g = d_in[e];
-        if (l >= 3) {
-            if (d_feat) unsafeAtomicAdd(&d_feat[((size_t)s * n + ii) * c + (l - 3)], g);
-        } else {
-            if (d_xyz) unsafeAtomicAdd(&d_xyz[((size_t)s * n + ii) * 3 + l], g);
-            if (d_new_xyz) unsafeAtomicAdd(&d_new_xyz[(size_t)(r / nsample) * 3 + l], -g);
+        const long g = e / cc;
+        const int ch = (int)(e - g * cc);
+        const long s = g / groups_per_scene;
+        const int *__restrict__ gi = idx + (size_t)g * nsample;
+        const float *__restrict__ dr = d_rows + (size_t)g * nsample * cc + ch;
+        float *__restrict__ tab = d_table + (size_t)s * n * cc + ch;
+        int cnt = pts_cnt ? pts_cnt[g] : nsample;
+        if (cnt < 1) cnt = 1;
+        float pad = 0.0f, all = 0.0f;
+        for (int k = 0; k < nsample; k++) {
+            const float v = dr[(size_t)k * cc];
+            all += v;
+            if (k > 0 && k < cnt)
+                unsafeAtomicAdd(&tab[(size_t)gi[k] * cc], v);
+            else
+                pad += v; // row 0 and the padding rows share idx[g,0]
         }
+        unsafeAtomicAdd(&tab[(size_t)gi[0] * cc], pad);
+        if (d_new_xyz) d_new_xyz[(size_t)g * 3 + ch] -= all; // one thread per (group, axis): no atomic needed
     }
 }
 
 // ---------------------------------------------------------------- optimizer
-// one workgroup per tensor: sum of squares of its gradient segment
+// sum of squares of every tensor's gradient segment: grid (8 slices, ntensors), atomics into out[tensor]
 __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict__ g, const long *__restrict__ seg,
                                                         float *__restrict__ out)
 {
     __shared__ float sh[256];
-    const long a = seg[2 * blockIdx.x], b = seg[2 * blockIdx.x + 1];
+    const long a = seg[2 * blockIdx.y], b = seg[2 * blockIdx.y + 1];
     float s = 0;
-    for (long i = a + threadIdx.x; i < b; i += 256) s += g[i] * g[i];
+    for (long i = a + (long)blockIdx.x * 256 + threadIdx.x; i < b; i += 256L * gridDim.x) s += g[i] * g[i];
     sh[threadIdx.x] = s;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+    if (threadIdx.x == 0 && sh[0] != 0.0f) unsafeAtomicAdd(&out[blockIdx.y], sh[0]);
 }
 
 // tf.clip_by_average_norm(g, clip): g * clip / max(||g||/numel, clip)   (model.py:249), then Adam
@@ -557,15 +568,21 @@ extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin
     return check_launch("mlp_wgrad");
 }
 
-extern "C" int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_in, const int *idx,
-                                         float *d_feat, float *d_xyz, float *d_new_xyz, void *stream)
+extern "C" int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_rows_feat,
+                                         const float *d_rows_xyz, const int *idx, const int *pts_cnt, float *d_feat,
+                                         float *d_xyz, float *d_new_xyz, void *stream)
 {
-    VN_REQUIRE(b >= 0 && n > 0 && c >= 0 && m >= 0 && nsample >= 0, "group_concat_grad: bad shape");
-    const long rows = (long)b * m * nsample;
-    if (rows == 0) return VOTENET_OK;
-    VN_REQUIRE(d_in && idx, "group_concat_grad: null buffer");
-    hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(rows * (3 + c), 256)), dim3(256), 0, as_stream(stream), rows, n, c,
-                       (long)m * nsample, nsample, d_in, idx, d_feat, d_xyz, d_new_xyz);
+    VN_REQUIRE(b >= 0 && n > 0 && c >= 0 && m >= 0 && nsample > 0, "group_concat_grad: bad shape");
+    const long groups = (long)b * m;
+    if (groups == 0) return VOTENET_OK;
+    VN_REQUIRE(idx != nullptr, "group_concat_grad: null idx");
+    hipStream_t st = as_stream(stream);
+    if (d_rows_feat && d_feat && c > 0)
+        hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, st, groups, n, c, m, nsample,
+                           d_rows_feat, idx, pts_cnt, d_feat, (float *)nullptr);
+    if (d_rows_xyz && d_xyz)
+        hipLaunchKernelGGL(group_concat_grad_kernel, dim3(grid_for(groups * 3, 256)), dim3(256), 0, st, groups, n, 3, m, nsample,
+                           d_rows_xyz, idx, pts_cnt, d_xyz, d_new_xyz);
     return check_launch("group_concat_grad");
 }
 
@@ -576,7 +593,10 @@ extern "C" int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scr
     VN_REQUIRE(ntensors > 0 && step > 0, "clip_adam expects ntensors > 0 and step >= 1");
     VN_REQUIRE(seg && sumsq_scratch && p && g && m && v, "clip_adam: null buffer");
     hipStream_t st = as_stream(stream);
-    if (clip_avg_norm > 0.0f) hipLaunchKernelGGL(seg_sumsq_kernel, dim3(ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
+    if (clip_avg_norm > 0.0f) {
+        (void)hipMemsetAsync(sumsq_scratch, 0, sizeof(float) * ntensors, st);
+        hipLaunchKernelGGL(seg_sumsq_kernel, dim3(8, ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
+    }
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
     hipLaunchKernelGGL(clip_adam_kernel, dim3(16, ntensors), dim3(256), 0, st, seg, sumsq_scratch, p, g, m, v, lr, beta1, beta2, eps,
                        bc1, bc2, grad_scale, clip_avg_norm);

@@ -149,16 +149,17 @@ def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.stream_ptr()))
 
 
-def group_concat_grad(d_in, idx, n, c, want_feat=True, want_xyz=False):
-    """-> d_feat (b,n,c) or None, d_xyz (b,n,3) or None, d_new_xyz (b,m,3) or None."""
+def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
+    """Per-row input gradients of the first SA layer -> d_feat (b,n,c) or None, d_xyz (b,n,3) or None,
+    d_new_xyz (b,m,3) or None (GroupPointGrad + the gradient of the centre subtraction, utils.py:50-57)."""
     b, m, k = idx.shape
-    dev = d_in.device
-    d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if (want_feat and c) else None
-    d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if want_xyz else None
-    d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if want_xyz else None
+    dev = idx.device
+    d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if d_rows_feat is not None else None
+    d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
+    d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
     with torch.cuda.device(dev):
-        L.check(L.lib().votenet_group_concat_grad(b, n, c, m, k, L.ptr(d_in), L.ptr(idx), L.ptr(d_feat), L.ptr(d_xyz),
-                                                  L.ptr(d_new), L.stream_ptr()))
+        L.check(L.lib().votenet_group_concat_grad(b, n, c, m, k, L.ptr(d_rows_feat), L.ptr(d_rows_xyz), L.ptr(idx), L.ptr(pts_cnt),
+                                                  L.ptr(d_feat), L.ptr(d_xyz), L.ptr(d_new), L.stream_ptr()))
     return d_feat, d_xyz, d_new
 
 

@@ -124,13 +124,15 @@ def mlp_chain_forward(layers, rows, first, tape):
     return z, sc, sh
 
 
-def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
+def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, need_xyz_grad=False):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
          'plain' : g = dz (rows, c) of a last layer without BN / activation    (mlp2, voting)
-    Accumulates parameter gradients into the store's gradient bucket.  Returns the gradient with respect
-    to the chain's input: (rows, cin) in the caller's column order ([dxyz, feat] for a gather input)."""
+    Accumulates parameter gradients into the store's gradient bucket.  Returns the gradient with respect to the
+    chain's input: (rows, cin) for a dense input; for a gather input the pair (d_rows_feat (rows, c) or None,
+    d_rows_xyz (rows, 3) or None) -- the feature block W[3:] is a 128-multiple wide GEMM of its own and the
+    three xyz columns are only computed when the caller needs them (proposal layer)."""
     da = g
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
@@ -148,6 +150,13 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
             M.wgrad_gather(r["xyz"], r["new_xyz"], r["feat"], r["idx"], dz, L.gp("W"))
         else:
             M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
+        if i == 0 and r["kind"] == "gather":
+            d_rows_feat = d_rows_xyz = None
+            if need_input_grad and r["feat"] is not None:
+                d_rows_feat, _ = M.linear_dense(dz, L.p("W")[3:].t().contiguous(), want_stats=False)
+            if need_xyz_grad:
+                d_rows_xyz, _ = M.linear_dense(dz, L.p("W")[:3].t().contiguous(), want_stats=False)
+            return d_rows_feat, d_rows_xyz
         if i > 0 or need_input_grad:
             da, _ = M.linear_dense(dz, L.p("W").t().contiguous(), want_stats=False)  # da_prev = dz W^T
         else:
@@ -175,7 +184,7 @@ class SAModule:
     def forward(self, xyz, points, sample_xyz=None, tape=None):
         """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,C'), idx (B,m,K)."""
         b = xyz.shape[0]
-        fps_idx, new_xyz, idx, _ = sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
+        fps_idx, new_xyz, idx, pts_cnt = sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
         recs = []
         rows = b * self.npoint * self.nsample
         z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs)
@@ -186,7 +195,7 @@ class SAModule:
             z2, sc2, sh2 = mlp_chain_forward(self.mlp2, b * self.npoint, ("dense", pooled), recs2)
             out = z2  # last conv_post layer has no activation (utils.py:153)
         if tape is not None:
-            tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, fps_idx=fps_idx, idx=idx,
+            tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, fps_idx=fps_idx, idx=idx, pts_cnt=pts_cnt,
                              xyz=xyz, points=points, new_xyz=new_xyz, b=b))
         return new_xyz, out.view(b, self.npoint, -1), idx
 
@@ -197,13 +206,14 @@ class SAModule:
         g = g_out.reshape(b * self.npoint, -1).contiguous()
         if self.mlp2:
             g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
-        need_in = (need_feat_grad and rec["points"] is not None) or need_xyz_grad
-        d_in = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_in)
-        if not need_in:
+        need_feat = need_feat_grad and rec["points"] is not None
+        d_rows_feat, d_rows_xyz = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
+                                                     need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
+        if not (need_feat or need_xyz_grad):
             return None, None
         n = rec["xyz"].shape[1]
         c = 0 if rec["points"] is None else rec["points"].shape[2]
-        d_feat, d_xyz, d_new = M.group_concat_grad(d_in, rec["idx"], n, c, want_feat=need_feat_grad, want_xyz=need_xyz_grad)
+        d_feat, d_xyz, d_new = M.group_concat_grad(d_rows_feat, d_rows_xyz, rec["idx"], rec["pts_cnt"], n, c)
         if need_xyz_grad:
             d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
         return d_feat, d_xyz
