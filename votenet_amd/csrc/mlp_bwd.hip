@@ -211,8 +211,6 @@ __global__ void add_f64_to_f32_kernel(int n, const double *__restrict__ src, flo
 
 // ---------------------------------------------------------------- weight gradient
 constexpr int WG_BR = 16;  // rows per slab (the MFMA contraction index)
-constexpr int WG_BI = 128; // dW rows (input channels) per workgroup tile
-constexpr int WG_BJ = 128; // dW cols (output channels) per workgroup tile
 
 template <int MODE>
 __device__ __forceinline__ int w_row(int k, int c)
@@ -222,49 +220,79 @@ __device__ __forceinline__ int w_row(int k, int c)
 }
 
 // dW[w_row(i), j] += sum_r A[r,i] * dz[r,j] over this workgroup's row range.
-// 4 waves as 2x2, each 64x64 (2x2 MFMA tiles).  LDS images are the natural [row][channel] slabs:
-// the A^T operand of lane l is As[k2*2 + (l>>5)][i0 + (l&31)], conflict-free.
-template <int MODE>
+// 4 waves as 2x2, each TI x TJ MFMA tiles of 32x32: the dW tile is (64*TI) x (64*TJ).  LDS images are the
+// natural [row][channel] slabs: the A^T operand of lane l is As[k2*2 + (l>>5)][i0 + (l&31)], conflict-free.
+// Pipeline as in mlp_linear_kernel: registers hold slab s+1 while slab s computes, they are written to the
+// other LDS buffer half way through the MFMAs and re-used at once for slab s+2; in GATHER mode the row
+// indices of slab s+3 are fetched at the same point, so the idx -> feature-row dependency is never exposed.
+template <int MODE, int TI, int TJ>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz,
                                                         float *__restrict__ dw, long rows_per_block)
 {
-    __shared__ float As[2][WG_BR][WG_BI + 4];
-    __shared__ float Bs[2][WG_BR][WG_BJ + 4];
+    constexpr int BI = 64 * TI, BJ = 64 * TJ;
+    constexpr int QA = BI / 4, QB = BJ / 4;          // float4 per slab row
+    constexpr int NA = WG_BR * QA / 256, NB = WG_BR * QB / 256; // float4 per thread per slab (1 or 2)
+    constexpr int RA = 256 / QA, RB = 256 / QB;      // slab rows covered by one pass of the 256 threads
+    __shared__ float As[2][WG_BR][BI + 4];
+    __shared__ float Bs[2][WG_BR][BJ + 4];
+    __shared__ __attribute__((aligned(16))) float Ssc[512], Ssh[512];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wv >> 1, wj = wv & 1;
-    const int i0 = blockIdx.y * WG_BI, j0 = blockIdx.z * WG_BJ;
+    const int i0 = blockIdx.y * BI, j0 = blockIdx.z * BJ;
     const long r_begin = (long)blockIdx.x * rows_per_block;
     long r_end = r_begin + rows_per_block;
     if (r_end > rows) r_end = rows;
     if (r_begin >= r_end) return;
     const bool a_vec4 = (MODE == 0) ? ((cin & 3) == 0) : ((in.c & 3) == 0 && in.c > 0);
     const bool b_vec4 = (cout & 3) == 0;
-    // staging: slab = 16 rows x 128 channels = 512 float4; thread t: row (t>>5) + 8h, quad (t&31)
-    const int s_row = tid >> 5, s_q = tid & 31;
+    const bool affine = (MODE == 0) && in.in_scale != nullptr;
+    const bool affine_lds = affine && cin <= 512;
+    if (affine_lds) {
+        for (int k = tid; k < cin; k += 256) {
+            Ssc[k] = in.in_scale[k];
+            Ssh[k] = in.in_shift[k];
+        }
+        __syncthreads();
+    }
+    const int a_row = tid / QA, a_q = tid % QA;
+    const int b_row = tid / QB, b_q = tid % QB;
+    const int ka = i0 + a_q * 4; // this thread's A channels (internal order)
+    const int nb = j0 + b_q * 4; // this thread's dz channels
 
-    f32x16 acc[2][2];
+    f32x16 acc[TI][TJ];
 #pragma unroll
-    for (int a = 0; a < 2; a++)
+    for (int a = 0; a < TI; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < TJ; b++)
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
 
-    float4 ra[2], rb[2];
+    float4 ra[NA], rb[NB];
+    int pidx[NA]; // GATHER: idx of the rows of the slab loaded NEXT
+    auto load_idx = [&](long r0) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int h = 0; h < NA; h++) {
+                const long r = r0 + a_row + h * RA;
+                pidx[h] = (r < r_end) ? in.idx[r] : 0;
+            }
+        }
+    };
     auto load_slab = [&](long r0) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const long r = r0 + s_row + h * 8;
-            float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int h = 0; h < NA; h++) {
+            const long r = r0 + a_row + h * RA;
+            float4 va = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r_end) {
-                const int k0 = i0 + s_q * 4;
                 if (MODE == 0) {
-                    if (a_vec4 && k0 + 3 < cin) {
-                        va = *reinterpret_cast<const float4 *>(in.x + (size_t)r * cin + k0);
-                        if (in.in_scale) {
-                            const float4 sc = *reinterpret_cast<const float4 *>(in.in_scale + k0);
-                            const float4 sh = *reinterpret_cast<const float4 *>(in.in_shift + k0);
+                    if (a_vec4 && ka + 3 < cin) {
+                        va = *reinterpret_cast<const float4 *>(in.x + (size_t)r * cin + ka);
+                        if (affine) {
+                            const float4 sc = affine_lds ? *reinterpret_cast<const float4 *>(&Ssc[ka])
+                                                         : *reinterpret_cast<const float4 *>(in.in_scale + ka);
+                            const float4 sh = affine_lds ? *reinterpret_cast<const float4 *>(&Ssh[ka])
+                                                         : *reinterpret_cast<const float4 *>(in.in_shift + ka);
                             va.x = va.x * sc.x + sh.x;
                             va.y = va.y * sc.y + sh.y;
                             va.z = va.z * sc.z + sh.z;
@@ -281,10 +309,10 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             float v = 0.0f;
-                            if (k0 + q < cin) {
-                                v = in.x[(size_t)r * cin + k0 + q];
-                                if (in.in_scale) {
-                                    v = v * in.in_scale[k0 + q] + in.in_shift[k0 + q];
+                            if (ka + q < cin) {
+                                v = in.x[(size_t)r * cin + ka + q];
+                                if (affine) {
+                                    v = v * in.in_scale[ka + q] + in.in_shift[ka + q];
                                     if (in.in_relu) v = v > 0.f ? v : 0.f;
                                 }
                             }
@@ -293,15 +321,15 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
                         va = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 } else {
-                    const int src = in.idx[r];
+                    const int src = pidx[h];
                     const long scene = r / ((long)in.m * in.nsample);
-                    if (a_vec4 && k0 + 3 < in.c) {
-                        va = *reinterpret_cast<const float4 *>(in.feat + ((size_t)scene * in.n + src) * in.c + k0);
+                    if (a_vec4 && ka + 3 < in.c) {
+                        va = *reinterpret_cast<const float4 *>(in.feat + ((size_t)scene * in.n + src) * in.c + ka);
                     } else {
                         float t[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
-                            const int k = k0 + q;
+                            const int k = ka + q;
                             float v = 0.0f;
                             if (k < in.c)
                                 v = in.feat[((size_t)scene * in.n + src) * in.c + k];
@@ -313,70 +341,84 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
                         va = make_float4(t[0], t[1], t[2], t[3]);
                     }
                 }
-                const int n0 = j0 + s_q * 4;
-                const float *zr = dz + (size_t)r * cout;
-                if (b_vec4 && n0 + 3 < cout) {
-                    vb = *reinterpret_cast<const float4 *>(zr + n0);
-                } else {
-                    if (n0 + 0 < cout) vb.x = zr[n0 + 0];
-                    if (n0 + 1 < cout) vb.y = zr[n0 + 1];
-                    if (n0 + 2 < cout) vb.z = zr[n0 + 2];
-                    if (n0 + 3 < cout) vb.w = zr[n0 + 3];
-                }
             }
             ra[h] = va;
+        }
+#pragma unroll
+        for (int h = 0; h < NB; h++) {
+            const long r = r0 + b_row + h * RB;
+            float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < r_end) {
+                const float *zr = dz + (size_t)r * cout;
+                if (b_vec4 && nb + 3 < cout) {
+                    vb = *reinterpret_cast<const float4 *>(zr + nb);
+                } else {
+                    if (nb + 0 < cout) vb.x = zr[nb + 0];
+                    if (nb + 1 < cout) vb.y = zr[nb + 1];
+                    if (nb + 2 < cout) vb.z = zr[nb + 2];
+                    if (nb + 3 < cout) vb.w = zr[nb + 3];
+                }
+            }
             rb[h] = vb;
         }
     };
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            *reinterpret_cast<float4 *>(&As[buf][s_row + h * 8][s_q * 4]) = ra[h];
-            *reinterpret_cast<float4 *>(&Bs[buf][s_row + h * 8][s_q * 4]) = rb[h];
-        }
+        for (int h = 0; h < NA; h++) *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = ra[h];
+#pragma unroll
+        for (int h = 0; h < NB; h++) *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = rb[h];
     };
 
+    // prologue: slab 0 -> LDS, slab 1 -> registers, idx of slab 2 -> pidx
+    load_idx(r_begin);
     load_slab(r_begin);
+    store_slab(0);
+    load_idx(r_begin + WG_BR);
+    if (r_begin + WG_BR < r_end) load_slab(r_begin + WG_BR);
+    load_idx(r_begin + 2 * WG_BR);
+    __syncthreads();
     int buf = 0;
+    const int kh = lane >> 5, l31 = lane & 31;
     for (long r0 = r_begin; r0 < r_end; r0 += WG_BR) {
-        store_slab(buf);
-        __syncthreads();
-        if (r0 + WG_BR < r_end) load_slab(r0 + WG_BR);
-        const int kh = lane >> 5, l31 = lane & 31;
-        float fa[2][2], fb[2][2]; // register double-buffered fragments: reads of k2+1 issued before MFMAs of k2
+        const bool have_next = r0 + WG_BR < r_end;
+        float fa[2][TI], fb[2][TJ]; // register double-buffered fragments: reads of k2+1 issued before MFMAs of k2
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            fa[0][t] = As[buf][kh][(wi * 2 + t) * 32 + l31];
-            fb[0][t] = Bs[buf][kh][(wj * 2 + t) * 32 + l31];
-        }
+        for (int t = 0; t < TI; t++) fa[0][t] = As[buf][kh][(wi * TI + t) * 32 + l31];
+#pragma unroll
+        for (int t = 0; t < TJ; t++) fb[0][t] = Bs[buf][kh][(wj * TJ + t) * 32 + l31];
 #pragma unroll
         for (int k2 = 0; k2 < WG_BR / 2; k2++) {
+            if (k2 == WG_BR / 4 && have_next) {
+                store_slab(buf ^ 1); // slab s+1: the other buffer was last read one step ago, behind a barrier
+                if (r0 + 2 * WG_BR < r_end) load_slab(r0 + 2 * WG_BR); // slab s+2 (GATHER: with the idx fetched a step ago)
+                load_idx(r0 + 3 * WG_BR);
+            }
             if (k2 + 1 < WG_BR / 2) {
 #pragma unroll
-                for (int t = 0; t < 2; t++) {
-                    fa[(k2 + 1) & 1][t] = As[buf][(k2 + 1) * 2 + kh][(wi * 2 + t) * 32 + l31];
-                    fb[(k2 + 1) & 1][t] = Bs[buf][(k2 + 1) * 2 + kh][(wj * 2 + t) * 32 + l31];
-                }
+                for (int t = 0; t < TI; t++) fa[(k2 + 1) & 1][t] = As[buf][(k2 + 1) * 2 + kh][(wi * TI + t) * 32 + l31];
+#pragma unroll
+                for (int t = 0; t < TJ; t++) fb[(k2 + 1) & 1][t] = Bs[buf][(k2 + 1) * 2 + kh][(wj * TJ + t) * 32 + l31];
             }
             __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
 #pragma unroll
-            for (int s = 0; s < 2; s++)
+            for (int s = 0; s < TI; s++)
 #pragma unroll
-                for (int t = 0; t < 2; t++)
+                for (int t = 0; t < TJ; t++)
                     acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][s], fb[k2 & 1][t], acc[s][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+        __syncthreads();
         buf ^= 1;
     }
     // epilogue: atomically add the partial tile.  C/D: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)
 #pragma unroll
-    for (int s = 0; s < 2; s++)
+    for (int s = 0; s < TI; s++)
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-            const int j = j0 + (wj * 2 + t) * 32 + (lane & 31);
+        for (int t = 0; t < TJ; t++) {
+            const int j = j0 + (wj * TJ + t) * 32 + (lane & 31);
 #pragma unroll
             for (int e = 0; e < 16; e++) {
-                const int i = i0 + (wi * 2 + s) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
+                const int i = i0 + (wi * TI + s) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
                 if (i < cin && j < cout) unsafeAtomicAdd(&dw[(size_t)w_row<MODE>(i, in.c) * cout + j], acc[s][t][e]);
             }
         }
@@ -541,6 +583,87 @@ extern "C" int votenet_bias_grad(long rows, int c, const float *dz, double *scra
     return check_launch("bias_grad");
 }
 
+// Weight gradient of the few "narrow" input channels of a GATHER layer: the three dxyz columns (W rows 0..2)
+// and, when the layer has at most 5 feature channels (sa1: C = 3), those too (W rows 3..).  A 128-wide MFMA
+// tile would be ~97 % padding here; this is a streaming reduction over dz instead: every workgroup stages the
+// narrow rows of 256 grouped points in LDS, thread (column j, row subset) accumulates nch partial sums.
+__global__ __launch_bounds__(256) void wgrad_narrow_kernel(MlpIn in, long rows, int nch, int cout, const float *__restrict__ dz,
+                                                           float *__restrict__ dw, long rows_per_block)
+{
+    __shared__ __attribute__((aligned(16))) float As[256][8];
+    __shared__ float red[256][8];
+    const int tid = threadIdx.x;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    long r_end = r_begin + rows_per_block;
+    if (r_end > rows) r_end = rows;
+    if (r_begin >= r_end) return;
+    const int nsub = 256 / cout > 0 ? 256 / cout : 1; // row subsets when cout < 256
+    const int j = tid % cout, sub = tid / cout;        // cout in {64,128,256}: every thread has a column
+    const bool active = sub < nsub;
+    float acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) acc[q] = 0.0f;
+    for (long c0 = r_begin; c0 < r_end; c0 += 256) {
+        const long r = c0 + tid;
+        float a[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = 0.0f;
+        if (r < r_end) {
+            const int src = in.idx[r];
+            const long scene = r / ((long)in.m * in.nsample);
+#pragma unroll
+            for (int d = 0; d < 3; d++)
+                a[d] = in.xyz[((size_t)scene * in.n + src) * 3 + d] - in.new_xyz[(size_t)(r / in.nsample) * 3 + d];
+            for (int q = 3; q < nch; q++) a[q] = in.feat[((size_t)scene * in.n + src) * in.c + (q - 3)];
+        }
+        __syncthreads(); // previous chunk fully consumed
+        *reinterpret_cast<float4 *>(&As[tid][0]) = make_float4(a[0], a[1], a[2], a[3]);
+        *reinterpret_cast<float4 *>(&As[tid][4]) = make_float4(a[4], a[5], a[6], a[7]);
+        __syncthreads();
+        const int nrow = (int)((r_end - c0) < 256 ? (r_end - c0) : 256);
+        if (active)
+            for (int rr = sub; rr < nrow; rr += nsub) {
+                const float g = dz[(size_t)(c0 + rr) * cout + j];
+                const float4 a0 = *reinterpret_cast<const float4 *>(&As[rr][0]);
+                const float4 a1 = *reinterpret_cast<const float4 *>(&As[rr][4]);
+                acc[0] += a0.x * g; acc[1] += a0.y * g; acc[2] += a0.z * g; acc[3] += a0.w * g;
+                acc[4] += a1.x * g; acc[5] += a1.y * g; acc[6] += a1.z * g; acc[7] += a1.w * g;
+            }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) red[tid][q] = acc[q];
+    __syncthreads();
+    if (tid < cout) {
+        for (int q = 0; q < nch; q++) {
+            float t = 0.0f;
+            for (int u = 0; u < nsub; u++) t += red[u * cout + tid][q];
+            unsafeAtomicAdd(&dw[(size_t)q * cout + tid], t); // narrow channel q is W row q (dxyz first, utils.py:55)
+        }
+    }
+}
+
+template <int MODE>
+static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const float *dz, float *dw, hipStream_t st)
+{
+    const int TIr = cin <= 64 ? 1 : 2, TJr = cout <= 64 ? 1 : 2;
+    const int BI = 64 * TIr, BJ = 64 * TJr;
+    const int ti = (cin + BI - 1) / BI, tj = (cout + BJ - 1) / BJ;
+    long splits = 768 / (ti * tj);
+    if (splits < 1) splits = 1;
+    long rpb = (rows + splits - 1) / splits;
+    rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
+    if (rpb < 4 * WG_BR) rpb = 4 * WG_BR;
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
+    if (TIr == 2 && TJr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 2>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+    else if (TIr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 1>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+    else if (TJr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 2>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+    else
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 1>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+}
+
 extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
                                  void *stream)
 {
@@ -549,21 +672,26 @@ extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin
     if (rows == 0) return VOTENET_OK;
     VN_REQUIRE(dz && dw, "mlp_wgrad: null buffer");
     MlpIn d = to_dev(in);
-    const int ti = (cin + WG_BI - 1) / WG_BI, tj = (cout + WG_BJ - 1) / WG_BJ;
-    long splits = 768 / (ti * tj);
-    if (splits < 1) splits = 1;
-    long rpb = (rows + splits - 1) / splits;
-    rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
-    if (rpb < 4 * WG_BR) rpb = 4 * WG_BR;
-    const long gx = (rows + rpb - 1) / rpb;
     hipStream_t st = as_stream(stream);
     if (in->x) {
-        hipLaunchKernelGGL((mlp_wgrad_kernel<0>), dim3((unsigned)gx, ti, tj), dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_wgrad: in_scale and in_shift go together");
+        launch_wgrad<0>(d, rows, cin, cout, dz, dw, st);
     } else {
         VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_wgrad: GATHER input needs xyz, new_xyz and idx");
         VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_wgrad: rows must equal b*m*nsample for a GATHER input");
         VN_REQUIRE(cin == 3 + d.c, "mlp_wgrad: cin must equal 3 + c for a GATHER input");
-        hipLaunchKernelGGL((mlp_wgrad_kernel<1>), dim3((unsigned)gx, ti, tj), dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        const bool narrow_ok = (cout == 64 || cout == 128 || cout == 256);
+        if (narrow_ok) {
+            // dxyz (and <= 5 feature) columns: streaming reduction; wide feature block: MFMA kernel on W rows 3..
+            const int nch = d.c <= 5 ? 3 + d.c : 3;
+            long rpb = (rows + 1023) / 1024;
+            rpb = (rpb + 255) / 256 * 256;
+            hipLaunchKernelGGL(wgrad_narrow_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, d, rows, nch, cout, dz,
+                               dw, rpb);
+            if (d.c > 5) launch_wgrad<1>(d, rows, d.c, cout, dz, dw, st); // internal k < c are the feature channels
+        } else {
+            launch_wgrad<1>(d, rows, cin, cout, dz, dw, st);
+        }
     }
     return check_launch("mlp_wgrad");
 }
