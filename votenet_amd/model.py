@@ -40,14 +40,62 @@ class VoteNetHotPath:
         s.materialize(seed)
 
     # ---- forward pieces -------------------------------------------------------------
-    def backbone(self, x, tape=None):
+    def geometry_ahead(self, x):
+        """Every FPS / ball query / three_nn of the backbone depends on coordinates only, never on features.
+        Level 1 stays on the caller's stream (the sa1 MLP needs it first); levels 2-4, both three_nn and the
+        proposal layer's FPS (it samples the SEEDS, utils.py:42-43) run on a side HIP stream underneath the MLP
+        GEMMs -- they are latency-bound chains on 8 workgroups and leave the other CUs to the matrix work."""
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side
+        g = {}
+        g["sa1"] = self.sa1.geometry(x)
+        ev = {}
+        start = torch.cuda.Event()
+        start.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            xyz = g["sa1"][1]
+            for name, mod in (("sa2", self.sa2), ("sa3", self.sa3), ("sa4", self.sa4)):
+                g[name] = mod.geometry(xyz)
+                xyz = g[name][1]
+                if name == "sa2":  # seeds = l2_xyz: the proposal layer's FPS can start as soon as they exist
+                    g["prop_fps"] = P.tf_sampling.farthest_point_sample(self.proposal.npoint, xyz)
+                ev[name] = torch.cuda.Event()
+                ev[name].record(side)
+            g["fp1"] = P.FPModule.geometry(g["sa3"][1], g["sa4"][1])
+            g["fp2"] = P.FPModule.geometry(g["sa2"][1], g["sa3"][1])
+            ev["fp"] = torch.cuda.Event()
+            ev["fp"].record(side)
+        for v in g.values():  # tensors born on the side stream are consumed on the main stream
+            for t in (v if isinstance(v, tuple) else (v,)):
+                if isinstance(t, torch.Tensor):
+                    t.record_stream(main)
+        return g, ev
+
+    def backbone(self, x, tape=None, overlap=True):
         """model.py:35-50.  x (B,n,3) -> seeds_xyz (B,1024,3), seeds_points (B,1024,256)."""
-        l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape)
-        l2_xyz, l2_p, _ = self.sa2.forward(l1_xyz, l1_p, tape=tape)
-        l3_xyz, l3_p, _ = self.sa3.forward(l2_xyz, l2_p, tape=tape)
-        l4_xyz, l4_p, _ = self.sa4.forward(l3_xyz, l3_p, tape=tape)
-        l3_p2 = self.fp1.forward(l3_xyz, l4_xyz, l3_p, l4_p, tape=tape)
-        seeds_p = self.fp2.forward(l2_xyz, l3_xyz, l2_p, l3_p2, tape=tape)
+        main = torch.cuda.current_stream()
+        if overlap:
+            g, ev = self.geometry_ahead(x)
+        else:
+            g, ev = {}, {}
+        self._prop_fps = g.get("prop_fps")
+        l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape, geom=g.get("sa1"))
+        if overlap:
+            main.wait_event(ev["sa2"])
+        l2_xyz, l2_p, _ = self.sa2.forward(l1_xyz, l1_p, tape=tape, geom=g.get("sa2"))
+        if overlap:
+            main.wait_event(ev["sa3"])
+        l3_xyz, l3_p, _ = self.sa3.forward(l2_xyz, l2_p, tape=tape, geom=g.get("sa3"))
+        if overlap:
+            main.wait_event(ev["sa4"])
+        l4_xyz, l4_p, _ = self.sa4.forward(l3_xyz, l3_p, tape=tape, geom=g.get("sa4"))
+        if overlap:
+            main.wait_event(ev["fp"])
+        l3_p2 = self.fp1.forward(l3_xyz, l4_xyz, l3_p, l4_p, tape=tape, geom=g.get("fp1"))
+        seeds_p = self.fp2.forward(l2_xyz, l3_xyz, l2_p, l3_p2, tape=tape, geom=g.get("fp2"))
         return l2_xyz, seeds_p
 
     def vote(self, seeds_xyz, seeds_points, tape=None):
@@ -63,7 +111,10 @@ class VoteNetHotPath:
 
     def propose(self, votes_xyz, votes_points, seeds_xyz, tape=None):
         """model.py:89-93: SA on votes with FPS on the seeds -> proposals_xyz (B,256,3), output (B,256,79)."""
-        p_xyz, p_out, _ = self.proposal.forward(votes_xyz, votes_points, sample_xyz=seeds_xyz, tape=tape)
+        geom = None
+        if getattr(self, "_prop_fps", None) is not None:  # FPS on the seeds was computed ahead (side stream)
+            geom = self.proposal.geometry(votes_xyz, fps_idx=self._prop_fps)
+        p_xyz, p_out, _ = self.proposal.forward(votes_xyz, votes_points, sample_xyz=seeds_xyz, tape=tape, geom=geom)
         return p_xyz, p_out
 
     def forward(self, x, tape=None):

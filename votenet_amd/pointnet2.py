@@ -181,10 +181,19 @@ class SAModule:
         self.mlp = make_mlp(store, scope, 3 + cin, mlp, "conv")
         self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
 
-    def forward(self, xyz, points, sample_xyz=None, tape=None):
-        """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,C'), idx (B,m,K)."""
+    def geometry(self, xyz, sample_xyz=None, fps_idx=None):
+        """The feature-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream."""
+        if fps_idx is None:
+            return sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
+        new_xyz = tf_sampling.gather_point(xyz, fps_idx)
+        idx, pts_cnt = tf_grouping.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        return fps_idx, new_xyz, idx, pts_cnt
+
+    def forward(self, xyz, points, sample_xyz=None, tape=None, geom=None):
+        """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,C'), idx (B,m,K).
+        geom: the tuple returned by geometry() when it was computed ahead of time."""
         b = xyz.shape[0]
-        fps_idx, new_xyz, idx, pts_cnt = sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
+        fps_idx, new_xyz, idx, pts_cnt = geom if geom is not None else self.geometry(xyz, sample_xyz)
         recs = []
         rows = b * self.npoint * self.nsample
         z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs)
@@ -225,10 +234,15 @@ class FPModule:
     def __init__(self, store, scope, cin1, cin2, mlp):
         self.mlp = make_mlp(store, scope, cin1 + cin2, mlp, "conv_")
 
-    def forward(self, xyz1, xyz2, points1, points2, tape=None):
+    @staticmethod
+    def geometry(xyz1, xyz2):
+        """three_nn + inverse-distance weights (utils.py:278-282): feature independent."""
+        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
+        return idx, tf_interpolate.three_nn_weights(dist)
+
+    def forward(self, xyz1, xyz2, points1, points2, tape=None, geom=None):
         b, n1 = xyz1.shape[:2]
-        dist, idx = tf_interpolate.three_nn(xyz1, xyz2)          # utils.py:278
-        weight = tf_interpolate.three_nn_weights(dist)           # utils.py:279-282
+        idx, weight = geom if geom is not None else self.geometry(xyz1, xyz2)  # utils.py:278-282
         interp = tf_interpolate.three_interpolate(points2, idx, weight)  # utils.py:283
         x = torch.cat([interp, points1], dim=2) if points1 is not None else interp  # utils.py:286
         rows = b * n1
