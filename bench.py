@@ -155,7 +155,7 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("fps_reg_kernel", {}).get("hbm_bytes_per_launch")
+                    traffic = json.load(open(pmc)).get("fps_sa1", {}).get("hbm_bytes_per_launch")
                 except Exception:
                     traffic = None
             ach = alg / (avg_ms * 1e-3) / 1e9

@@ -420,6 +420,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx = pts[0], cy = pts[1], cz = pts[2];
+    unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
+    float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
     for (int j = 1; j < m; j++) {
         // (1) which of this wave's buckets can change?  lower bound of the distance to the bucket box,
         //     shrunk by 1e-5 so that it is below every fp32-evaluated point distance of the bucket.
@@ -429,6 +431,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
         const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
         unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
         // (2) update the active buckets, refresh their cached arg-max
+        bool changed = false; // uniform: did any cached bucket entry of this wave change this round?
         while (act) {
             const int i = __ffsll((long long)act) - 1;
             act &= act - 1;
@@ -449,14 +452,19 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
                     bkey = nkey;
                     blane = nl;
                 }
+                changed = true;
             }
         }
-        // (3) wave winner over the cached bucket entries (lanes < P)
-        unsigned wmax, wkey;
-        const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, wmax, wkey); // winning bucket = slot
-        const int fl = __builtin_amdgcn_readlane(blane, ws); // winning lane inside the bucket
-        const FpsWinner win = fps_cross_wave<NW>(wmax, wkey, readlane_f32(X[ws], fl), readlane_f32(Y[ws], fl), readlane_f32(Z[ws], fl),
-                                                 s_ex, j);
+        // (3) wave winner over the cached bucket entries (lanes < P).  It can only change when one of this
+        //     wave's bucket entries changed; otherwise last round's winner (uniform registers) is reused.
+        if (changed || j == 1) {
+            const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, cw_max, cw_key); // winning bucket = slot
+            const int fl = __builtin_amdgcn_readlane(blane, ws);                                            // winning lane inside it
+            cw_x = readlane_f32(X[ws], fl);
+            cw_y = readlane_f32(Y[ws], fl);
+            cw_z = readlane_f32(Z[ws], fl);
+        }
+        const FpsWinner win = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j);
         cx = win.x;
         cy = win.y;
         cz = win.z;
