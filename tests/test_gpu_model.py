@@ -77,3 +77,21 @@ def test_forward_small_vs_oracle(hiplib, dev, O):
     assert (N(out["proposals_xyz"]) == px).all()  # utils.py:42-43: FPS on seeds, centres from votes
     assert relerr(N(out["proposals_output"]), pout) < 1e-4
     assert out["proposals_output"].shape == (2, 256, 79)
+
+
+def test_predict_tail_nms_vs_oracle(hiplib, dev, O):
+    """Predict tower (model.py:98-139): decoded boxes -> device NMS equals the oracle NMS on the same boxes."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    x = torch.from_numpy(synth.room_batch(2, 4096, 5)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=7, npoints=(512, 256, 128, 64))
+    r = net.predict(x, 0.25)
+    boxes, score = N(r["bboxes"]), N(r["scores"])
+    obj = N(r["proposals_output"][..., :2])
+    assert boxes.shape == (2, 256, 8, 3)
+    exp = O.nms3d(boxes, score, obj, 0.25)
+    iou = np.stack([O.iou3d_matrix(boxes[s]) for s in range(2)])
+    got = N(r["nms_idx"])
+    if not (np.abs(iou - 0.25) < 1e-5).any() and len(np.unique(score)) == score.size:
+        assert (got == exp).all()
+    assert got.shape[1] == 2 and (obj[got[:, 0], got[:, 1], 1] > obj[got[:, 0], got[:, 1], 0]).all()

@@ -34,3 +34,13 @@ for (n, m, r, K) in [(20480, 2048, 0.2, 64), (2048, 1024, 0.4, 64), (1024, 512, 
         print("group n=%5d m=%4d c=%3d: %8.3f ms  %8.1f GB/s" % (n, m, c, t, by / t / 1e6))
 x1 = xyz[:, :1024].contiguous(); x2 = xyz[:, :512].contiguous()
 t = timeit(lambda: I.three_nn(x1, x2)); print("three_nn 1024x512: %.3f ms" % t)
+
+# ---- predict tail: 3D IoU matrix + NMS at config-3 size (8 scenes x 256 proposals)
+import time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden"))
+import cases
+from votenet_amd import tf_nms3d as NM
+c = cases.nms_random(b=8, n=256, seed=33, room=6.0)
+bb, sc, ob = (torch.from_numpy(c[k]).to(dev) for k in ("bboxes", "scores", "objectiveness"))
+t = timeit(lambda: NM.iou3d_matrix(bb)); print("iou3d_matrix 8x256x256: %.3f ms (%.0f pair IoUs/us)" % (t, 8 * 256 * 256 / t / 1e3))
+t = timeit(lambda: NM.NMS3D(bb, sc, ob, 0.25)); print("NMS3D 8x256 thr 0.25 (incl. count readback): %.3f ms, kept %d" % (t, len(NM.NMS3D(bb, sc, ob, 0.25))))
