@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate, dense
 
 
 def parse():
@@ -100,6 +101,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from votenet_amd import model as VM
+    from votenet_amd import mlp as vmlp
     from votenet_amd import synth, tf_sampling
     have_train = hasattr(VM.VoteNetHotPath, "train_step")
     workload = args.workload or ("train" if have_train else "fwd")
@@ -128,8 +130,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     tf_sampling.PROFILE_EVENTS = []  # HIP events around every FPS launch, on the launch stream
+    gemm_steps = min(2, args.steps)  # ... and around every MFMA GEMM launch of the first two timed steps only
+    vmlp.PROFILE_EVENTS = []         #     (75 event pairs per step would otherwise perturb the headline time)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        if i == gemm_steps:
+            gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
         step()
     torch.cuda.synchronize()
     if world > 1:
@@ -138,6 +144,8 @@ def main():
     dt = time.perf_counter() - t0
     events = tf_sampling.PROFILE_EVENTS
     tf_sampling.PROFILE_EVENTS = None
+    if vmlp.PROFILE_EVENTS is not None:
+        gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -163,6 +171,15 @@ def main():
                                              "exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg}
+        mfma = None
+        if gemm_events:
+            tot_ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _) in gemm_events)
+            tot_fl = sum(f for (_, _, _, f) in gemm_events)
+            ach = tot_fl / (tot_ms * 1e-3) / 1e12
+            mfma = {"bound": "mfma", "kernel": "mlp_linear_kernel / mlp_wgrad_kernel (all %d GEMM launches of the first two timed steps, "
+                                               "fp32 in / fp32 accumulate)" % len(gemm_events),
+                    "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
+                    "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gflop_per_step": round(tot_fl / gemm_steps / 1e9, 1)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(n, args.scene)
@@ -175,7 +192,7 @@ def main():
                                     "%s scenes" % ("train step (fwd+bwd+Adam, synthetic cotangents in place of the loss graph)"
                                                    if workload == "train" else "forward", B, n, args.scene)),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

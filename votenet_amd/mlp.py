@@ -10,6 +10,26 @@ import torch
 
 from . import _lib as L
 
+# bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
+# entries are (start, end, kind, flops) with kind in {"linear_dense", "linear_gather", "wgrad_dense", "wgrad_gather"}.
+PROFILE_EVENTS = None
+
+
+class _Timed:
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE_EVENTS is not None:
+            self.e0, self.e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+
+    def __exit__(self, *a):
+        if PROFILE_EVENTS is not None:
+            self.e1.record()
+            PROFILE_EVENTS.append((self.e0, self.e1, self.kind, self.flops))
+
+
 BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
 
 
@@ -47,7 +67,7 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     stats = torch.zeros(2 * cout, dtype=torch.float64, device=x.device) if want_stats else None
     d = _desc_dense(x, in_scale, in_shift, in_relu)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -70,7 +90,7 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
     stats = torch.zeros(2 * cout, dtype=torch.float64, device=xyz.device) if want_stats else None
     d = _desc_gather(xyz, new_xyz, feat, idx)
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -137,7 +157,7 @@ def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
     rows, cin = x.shape
     cout = dz.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
-    with torch.cuda.device(x.device):
+    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.stream_ptr()))
 
 
@@ -145,7 +165,7 @@ def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
     b, m, k = idx.shape
     c = feat.shape[2] if feat is not None else 0
     d = _desc_gather(xyz, new_xyz, feat, idx)
-    with torch.cuda.device(xyz.device):
+    with torch.cuda.device(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1]):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.stream_ptr()))
 
 
