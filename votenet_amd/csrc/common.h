@@ -77,6 +77,15 @@ __device__ __forceinline__ float readlane_f32(float v, int lane)
 {
     return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), lane));
 }
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for vmcnt(0), i.e. it
+// drains every global load / store in flight -- fatal for a software pipeline whose prefetched global
+// loads are meant to stay outstanding across the barrier.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ int wave_id_uniform() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 

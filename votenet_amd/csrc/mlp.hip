@@ -156,29 +156,16 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
     };
     float4 ra[MLP_AP];
     float4 rb[B_PER_T];
+    int rk = 0; // first k of the A quad held in ra (FAST path: needed by the deferred BN+ReLU)
     auto load_slab = [&](int kt) {
         if constexpr (FAST) {
             const int kq = kt * MLP_BK + a_kq * 4;
 #pragma unroll
             for (int h = 0; h < MLP_AP; h++) {
-                float4 v = *reinterpret_cast<const float4 *>(pa[h]);
-                pa[h] += MLP_BK;
-                if (affine) {
-                    const float4 sc = *reinterpret_cast<const float4 *>(&Ssc[kq]);
-                    const float4 sh = *reinterpret_cast<const float4 *>(&Ssh[kq]);
-                    v.x = v.x * sc.x + sh.x;
-                    v.y = v.y * sc.y + sh.y;
-                    v.z = v.z * sc.z + sh.z;
-                    v.w = v.w * sc.w + sh.w;
-                    if (in.in_relu) {
-                        v.x = v.x > 0.f ? v.x : 0.f;
-                        v.y = v.y > 0.f ? v.y : 0.f;
-                        v.z = v.z > 0.f ? v.z : 0.f;
-                        v.w = v.w > 0.f ? v.w : 0.f;
-                    }
-                }
-                ra[h] = v;
+                ra[h] = *reinterpret_cast<const float4 *>(pa[h]); // raw: the folded BN+ReLU is applied when the slab
+                pa[h] += MLP_BK;                                  // is written to LDS, so the load stays in flight
             }
+            rk = kq;
 #pragma unroll
             for (int u = 0; u < B_PER_T; u++) {
                 rb[u] = *reinterpret_cast<const float4 *>(pb[u]);
@@ -249,13 +236,31 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
         }
     };
     auto store_slab = [&](int buf) {
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (FAST && affine) {
+            sc = *reinterpret_cast<const float4 *>(&Ssc[rk]);
+            sh = *reinterpret_cast<const float4 *>(&Ssh[rk]);
+        }
 #pragma unroll
         for (int h = 0; h < MLP_AP; h++) {
             const int r = a_row + h * MLP_RPP;
-            As[buf][a_kq * 4 + 0][r] = ra[h].x;
-            As[buf][a_kq * 4 + 1][r] = ra[h].y;
-            As[buf][a_kq * 4 + 2][r] = ra[h].z;
-            As[buf][a_kq * 4 + 3][r] = ra[h].w;
+            float4 v = ra[h];
+            if (FAST && affine) {
+                v.x = v.x * sc.x + sh.x;
+                v.y = v.y * sc.y + sh.y;
+                v.z = v.z * sc.z + sh.z;
+                v.w = v.w * sc.w + sh.w;
+                if (in.in_relu) {
+                    v.x = v.x > 0.f ? v.x : 0.f;
+                    v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f;
+                    v.w = v.w > 0.f ? v.w : 0.f;
+                }
+            }
+            As[buf][a_kq * 4 + 0][r] = v.x;
+            As[buf][a_kq * 4 + 1][r] = v.y;
+            As[buf][a_kq * 4 + 2][r] = v.z;
+            As[buf][a_kq * 4 + 3][r] = v.w;
         }
 #pragma unroll
         for (int u = 0; u < B_PER_T; u++) {
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3)) void mlp_linear_kernel
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][i], fb[k2 & 1][j], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
         buf ^= 1;
         if (last_k) {
             // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -439,10 +444,15 @@ static inline int grid_for(long total, int block)
     return (int)g;
 }
 
+bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
+                            int cout, const float *w, const float *bias, float *z, double *stats, hipStream_t st); // mlp_fast.hip
+
 template <int MODE>
 static int launch_linear(const MlpIn &in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
                          double *stats, hipStream_t st)
 {
+    if (MODE == 0 && mlp_linear_fast_launch(in.x, in.in_scale, in.in_shift, in.in_relu, rows, cin, cout, w, bias, z, stats, st))
+        return check_launch("mlp_linear");
     const long ntiles = (rows + MLP_BM - 1) / MLP_BM;
     const bool aligned = ((uintptr_t)in.x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
     const bool fast_in = MODE == 0 && aligned && (cin % MLP_BK == 0) && (rows % MLP_BM == 0) &&

@@ -235,7 +235,6 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
     constexpr int RA = 256 / QA, RB = 256 / QB;      // slab rows covered by one pass of the 256 threads
     __shared__ float As[2][WG_BR][BI + 4];
     __shared__ float Bs[2][WG_BR][BJ + 4];
-    __shared__ __attribute__((aligned(16))) float Ssc[512], Ssh[512];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wv >> 1, wj = wv & 1;
@@ -247,14 +246,6 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
     const bool a_vec4 = (MODE == 0) ? ((cin & 3) == 0) : ((in.c & 3) == 0 && in.c > 0);
     const bool b_vec4 = (cout & 3) == 0;
     const bool affine = (MODE == 0) && in.in_scale != nullptr;
-    const bool affine_lds = affine && cin <= 512;
-    if (affine_lds) {
-        for (int k = tid; k < cin; k += 256) {
-            Ssc[k] = in.in_scale[k];
-            Ssh[k] = in.in_shift[k];
-        }
-        __syncthreads();
-    }
     const int a_row = tid / QA, a_q = tid % QA;
     const int b_row = tid / QB, b_q = tid % QB;
     const int ka = i0 + a_q * 4; // this thread's A channels (internal order)
@@ -269,6 +260,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
             for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
 
     float4 ra[NA], rb[NB];
+    long cur_store_r0 = 0; // first row of the slab currently held in ra / rb
     int pidx[NA]; // GATHER: idx of the rows of the slab loaded NEXT
     auto load_idx = [&](long r0) {
         if (MODE == 1) {
@@ -280,6 +272,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
         }
     };
     auto load_slab = [&](long r0) {
+        cur_store_r0 = r0;
 #pragma unroll
         for (int h = 0; h < NA; h++) {
             const long r = r0 + a_row + h * RA;
@@ -287,23 +280,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
             if (r < r_end) {
                 if (MODE == 0) {
                     if (a_vec4 && ka + 3 < cin) {
-                        va = *reinterpret_cast<const float4 *>(in.x + (size_t)r * cin + ka);
-                        if (affine) {
-                            const float4 sc = affine_lds ? *reinterpret_cast<const float4 *>(&Ssc[ka])
-                                                         : *reinterpret_cast<const float4 *>(in.in_scale + ka);
-                            const float4 sh = affine_lds ? *reinterpret_cast<const float4 *>(&Ssh[ka])
-                                                         : *reinterpret_cast<const float4 *>(in.in_shift + ka);
-                            va.x = va.x * sc.x + sh.x;
-                            va.y = va.y * sc.y + sh.y;
-                            va.z = va.z * sc.z + sh.z;
-                            va.w = va.w * sc.w + sh.w;
-                            if (in.in_relu) {
-                                va.x = va.x > 0.f ? va.x : 0.f;
-                                va.y = va.y > 0.f ? va.y : 0.f;
-                                va.z = va.z > 0.f ? va.z : 0.f;
-                                va.w = va.w > 0.f ? va.w : 0.f;
-                            }
-                        }
+                        va = *reinterpret_cast<const float4 *>(in.x + (size_t)r * cin + ka); // raw; BN+ReLU at store time
                     } else {
                         float t[4];
 #pragma unroll
@@ -311,10 +288,6 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
                             float v = 0.0f;
                             if (ka + q < cin) {
                                 v = in.x[(size_t)r * cin + ka + q];
-                                if (affine) {
-                                    v = v * in.in_scale[ka + q] + in.in_shift[ka + q];
-                                    if (in.in_relu) v = v > 0.f ? v : 0.f;
-                                }
                             }
                             t[q] = v;
                         }
@@ -362,9 +335,43 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
             rb[h] = vb;
         }
     };
+    // this thread's A channels never change: the folded BN scale/shift of the previous layer sit in registers and
+    // are applied when the slab is written to LDS, so the global loads stay in flight until then
+    float csc[4] = {1.f, 1.f, 1.f, 1.f}, csh[4] = {0.f, 0.f, 0.f, 0.f};
+    if (affine) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (ka + q < cin) {
+                csc[q] = in.in_scale[ka + q];
+                csh[q] = in.in_shift[ka + q];
+            }
+    }
+    const bool do_relu = affine && in.in_relu;
     auto store_slab = [&](int buf) {
 #pragma unroll
-        for (int h = 0; h < NA; h++) *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = ra[h];
+        for (int h = 0; h < NA; h++) {
+            float4 v = ra[h];
+            if (affine) {
+                v.x = v.x * csc[0] + csh[0];
+                v.y = v.y * csc[1] + csh[1];
+                v.z = v.z * csc[2] + csh[2];
+                v.w = v.w * csc[3] + csh[3];
+                if (do_relu) {
+                    v.x = v.x > 0.f ? v.x : 0.f;
+                    v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f;
+                    v.w = v.w > 0.f ? v.w : 0.f;
+                }
+                // rows beyond r_end and channels beyond cin were loaded as 0 and must stay 0
+                const long r = cur_store_r0 + a_row + h * RA;
+                if (r >= r_end) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ka + 0 >= cin) v.x = 0.f;
+                if (ka + 1 >= cin) v.y = 0.f;
+                if (ka + 2 >= cin) v.z = 0.f;
+                if (ka + 3 >= cin) v.w = 0.f;
+            }
+            *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = v;
+        }
 #pragma unroll
         for (int h = 0; h < NB; h++) *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = rb[h];
     };
@@ -407,7 +414,7 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
                     acc[s][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][s], fb[k2 & 1][t], acc[s][t], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
         buf ^= 1;
     }
     // epilogue: atomically add the partial tile.  C/D: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)
