@@ -189,10 +189,8 @@ int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const i
                                const float *scale, const float *shift, const float *mean, const float *var, float eps,
                                int relu, double *sums /* 2*c, pre-zeroed */, void *stream);
 int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
-                              const float *scale, const float *shift, const float *mean, const float *var, float eps,
-                              int relu, const float *gamma, const double *sums, float *dz /* rows x c */,
-                              float *dgamma /* += , may be NULL */, float *dbeta /* += , may be NULL */,
-                              float *coef_scratch /* 5*c floats */, void *stream);
+                              const float *coef /* 5*c, from votenet_bn_backward_coef */, int relu,
+                              float *dz /* rows x c */, void *stream);
 
 /* dbias[c] += column sums of dz (rows x c); scratch: c doubles. */
 int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float *dbias, void *stream);
@@ -203,6 +201,35 @@ int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float 
  * (summation order unspecified, like the reference's cuDNN / atomics-based gradients). */
 int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
                       void *stream);
+
+/* ---- BatchNorm backward folded into the two backward GEMMs (no dz tensor in memory) -----------------
+ * With sums = [sum g', sum g'*zhat] (votenet_bn_backward_reduce, or the fused epilogue below) the
+ * gradient of a BatchNorm'ed layer is per element  dz = A*g' + B + C*z,  g' = g masked by the ReLU
+ * [z*scale+shift > 0] (and, for a max-pooled output, by row%k == argmax[row/k]).
+ * votenet_bn_backward_coef writes coef = [A | B | C | scale | shift] (5*c floats) and accumulates
+ * dgamma += sums[c:], dbeta += sums[:c] (either may be NULL). */
+int votenet_bn_backward_coef(long rows, int c, const float *scale, const float *shift, const float *mean,
+                             const float *var, float eps, const float *gamma, const double *sums,
+                             float *coef /* 5*c */, float *dgamma, float *dbeta, void *stream);
+
+/* votenet_mlp_wgrad with dz formed inside the operand loader.  Exactly one of da (rows x cout, dense
+ * upstream gradient) / gout (rows/pool_k x cout, gradient of the max over pool_k rows, with argmax). */
+int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int cout, const float *da,
+                         const float *gout, const int *argmax, int pool_k, const float *z, const float *coef,
+                         int relu, float *dw, void *stream);
+
+/* da_prev (rows x cout) = dz (rows x c) * wT (c x cout), dz formed as above from (da | gout+argmax, zsrc,
+ * coef).  If p_sums != NULL (2*cout doubles, pre-zeroed) the epilogue also accumulates the
+ * votenet_bn_backward_reduce sums of the layer below: its raw output zprev (rows x cout), statistics
+ * p_scale/p_shift/p_mean/p_var (cout each) and ReLU flag p_relu.
+ * Shapes served: rows % 128 == 0, c % 16 == 0, c <= 512, cout == 64 or cout % 128 == 0, 16-byte aligned
+ * buffers; anything else returns VOTENET_E_INVALID_ARGUMENT (use votenet_bn_backward_apply +
+ * votenet_mlp_linear instead). */
+int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,
+                         int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
+                         float *da_prev, const float *zprev, const float *p_scale, const float *p_shift,
+                         const float *p_mean, const float *p_var, float eps, int p_relu, double *p_sums,
+                         void *stream);
 
 /* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78) on the
  * feature columns + the gradients of grouped_xyz - tile(new_xyz) on the xyz columns.  The per-row input

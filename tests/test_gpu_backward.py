@@ -136,6 +136,56 @@ def test_wgrad_and_input_grad_unit(hiplib, dev):
         assert relerr(store.g(name).double(), params[name].grad) < 1e-4, name
 
 
+@pytest.mark.parametrize("rows,cin,c,k", [(4096, 128, 256, 32), (2048, 64, 64, 0), (8192, 256, 128, 0), (2048, 64, 128, 16),
+                                          (1024, 512, 512, 64), (1152, 128, 48, 0), (1000, 128, 64, 0), (1024, 96, 64, 0)])
+def test_fused_bn_backward_gemms_match_unfused(hiplib, dev, rows, cin, c, k):
+    """votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn (dz rebuilt in the loaders, reduction of the layer below in the
+    epilogue) against the unfused kernels: bn_backward_apply -> mlp_wgrad / mlp_linear -> bn_backward_reduce."""
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + c + k)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    x, w = rnd(rows, cin), rnd(cin, c) * 0.1
+    zprev = rnd(rows, cin)  # pretend x = relu(bn(zprev)): only the backward formulas of the layer below matter
+    p_stats = [rnd(cin) * 0.5 + 1.0, rnd(cin) * 0.1, rnd(cin) * 0.1, rnd(cin).abs() + 0.5]  # scale, shift, mean, var
+    z, stats = M.linear_dense(x, w)
+    gamma, beta = rnd(c) * 0.2 + 1.0, rnd(c) * 0.1
+    sc, sh, mu, var = M.bn_finalize(rows, stats, gamma, beta)
+    if k:
+        _, argmax = M.bn_relu_max(z, k, sc, sh, True, want_argmax=True)
+        up = rnd(rows // k, c)
+        src = dict(gout=up, argmax=argmax, k=k)
+    else:
+        argmax = None
+        up = rnd(rows, c)
+        src = dict(da=up)
+    sums = M.bn_backward_reduce(z, sc, sh, mu, var, True, up, argmax, k)
+    dg = torch.zeros(c, device=dev)
+    db = torch.zeros(c, device=dev)
+    coef = M.bn_backward_coef(rows, sc, sh, mu, var, gamma, sums, dg, db)
+    dz = M.bn_backward_apply(z, coef, True, up, argmax, k)
+    dw_ref = torch.zeros(cin, c, device=dev)
+    M.wgrad_dense(x, dz, dw_ref)
+    dw = torch.zeros(cin, c, device=dev)
+    M.wgrad_dense_bn(x, z, coef, True, dw, **src)
+    assert relerr(dw, dw_ref) < 2e-5
+    assert relerr(dw_ref.double(), x.double().t() @ dz.double()) < 2e-5
+    wT = w.t().contiguous()
+    da_ref, _ = M.linear_dense(dz, wT, want_stats=False)
+    assert M.dgrad_bn_supported(rows, c, cin) == (c % 16 == 0 and rows % 128 == 0 and (cin == 64 or cin % 128 == 0))
+    if not M.dgrad_bn_supported(rows, c, cin):
+        from votenet_amd import _lib
+        with pytest.raises(_lib.InvalidArgumentError):
+            M.dgrad_bn(z, coef, True, wT, **src)
+        return
+    da, none = M.dgrad_bn(z, coef, True, wT, **src)
+    assert none is None
+    assert relerr(da, da_ref) < 2e-5
+    da2, psums = M.dgrad_bn(z, coef, True, wT, below=(zprev, *p_stats, True), **src)
+    assert torch.equal(da2, da)
+    psums_ref = M.bn_backward_reduce(zprev, *p_stats, True, da_ref)
+    assert relerr(psums, psums_ref) < 2e-5
+
+
 def test_clip_adam_vs_reference(hiplib, dev):
     """model.py:240-250: per-tensor tf.clip_by_average_norm(g, 0.5) then Adam(1e-3)."""
     from votenet_amd import model as VM

@@ -225,9 +225,20 @@ __device__ __forceinline__ int w_row(int k, int c)
 // Pipeline as in mlp_linear_kernel: registers hold slab s+1 while slab s computes, they are written to the
 // other LDS buffer half way through the MFMAs and re-used at once for slab s+2; in GATHER mode the row
 // indices of slab s+3 are fetched at the same point, so the idx -> feature-row dependency is never exposed.
-template <int MODE, int TI, int TJ>
+// BSRC selects how the dz operand (rows x cout) is produced:
+//   0: dz read from memory;  1: dz = A*g + B + C*z with g = da masked by [z*S+H > 0]  (BatchNorm backward folded in);
+//   2: the same with g = gout[row/k] where row%k == argmax[row/k] (max-pooled upstream).  coef = [A|B|C|S|H], 5*cout.
+struct BnSrc {
+    const float *da, *gout;
+    const int *argmax;
+    int pool_k, pool_shift; // pool_shift = log2(pool_k) when pool_k is a power of two, else -1
+    const float *z, *coef;
+    int relu;
+};
+
+template <int MODE, int TI, int TJ, int BSRC>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz,
-                                                        float *__restrict__ dw, long rows_per_block)
+                                                        BnSrc bs, float *__restrict__ dw, long rows_per_block)
 {
     constexpr int BI = 64 * TI, BJ = 64 * TJ;
     constexpr int QA = BI / 4, QB = BJ / 4;          // float4 per slab row
@@ -260,7 +271,23 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
             for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
 
     float4 ra[NA], rb[NB];
+    float4 rg[NB];  // BSRC 1: da quads, BSRC 2: gout quads
+    int4 rm[NB];    // BSRC 2: arg-max quads
     long cur_store_r0 = 0; // first row of the slab currently held in ra / rb
+    // this thread's dz channels never change: BatchNorm-backward coefficients in registers
+    float kA[4] = {0.f, 0.f, 0.f, 0.f}, kB[4] = {0.f, 0.f, 0.f, 0.f}, kC[4] = {0.f, 0.f, 0.f, 0.f}, kS[4] = {0.f, 0.f, 0.f, 0.f},
+          kH[4] = {0.f, 0.f, 0.f, 0.f};
+    if (BSRC != 0) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (nb + q < cout) {
+                kA[q] = bs.coef[nb + q];
+                kB[q] = bs.coef[cout + nb + q];
+                kC[q] = bs.coef[2 * cout + nb + q];
+                kS[q] = bs.coef[3 * cout + nb + q];
+                kH[q] = bs.coef[4 * cout + nb + q];
+            }
+    }
     int pidx[NA]; // GATHER: idx of the rows of the slab loaded NEXT
     auto load_idx = [&](long r0) {
         if (MODE == 1) {
@@ -320,19 +347,35 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
 #pragma unroll
         for (int h = 0; h < NB; h++) {
             const long r = r0 + b_row + h * RB;
-            float4 vb = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 vb = make_float4(0.f, 0.f, 0.f, 0.f), vg = make_float4(0.f, 0.f, 0.f, 0.f);
+            int4 vm = make_int4(-1, -1, -1, -1);
             if (r < r_end) {
-                const float *zr = dz + (size_t)r * cout;
+                const float *zr = (BSRC == 0 ? dz : bs.z) + (size_t)r * cout; // BSRC != 0: the raw layer output z
+                // rows < 2^31 (checked by the launcher): 32-bit group arithmetic, a shift for the usual power-of-two k
+                const unsigned grp = (BSRC == 2) ? (bs.pool_shift >= 0 ? (unsigned)r >> bs.pool_shift : (unsigned)r / (unsigned)bs.pool_k) : 0u;
+                const float *gr = (BSRC == 1) ? bs.da + (size_t)r * cout : (BSRC == 2 ? bs.gout + (size_t)grp * cout : nullptr);
                 if (b_vec4 && nb + 3 < cout) {
                     vb = *reinterpret_cast<const float4 *>(zr + nb);
+                    if (BSRC != 0) vg = *reinterpret_cast<const float4 *>(gr + nb);
+                    if (BSRC == 2) vm = *reinterpret_cast<const int4 *>(bs.argmax + (size_t)grp * cout + nb);
                 } else {
-                    if (nb + 0 < cout) vb.x = zr[nb + 0];
-                    if (nb + 1 < cout) vb.y = zr[nb + 1];
-                    if (nb + 2 < cout) vb.z = zr[nb + 2];
-                    if (nb + 3 < cout) vb.w = zr[nb + 3];
+                    float tb[4] = {0.f, 0.f, 0.f, 0.f}, tg[4] = {0.f, 0.f, 0.f, 0.f};
+                    int tm[4] = {-1, -1, -1, -1};
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        if (nb + q < cout) {
+                            tb[q] = zr[nb + q];
+                            if (BSRC != 0) tg[q] = gr[nb + q];
+                            if (BSRC == 2) tm[q] = bs.argmax[(size_t)grp * cout + nb + q];
+                        }
+                    vb = make_float4(tb[0], tb[1], tb[2], tb[3]);
+                    vg = make_float4(tg[0], tg[1], tg[2], tg[3]);
+                    vm = make_int4(tm[0], tm[1], tm[2], tm[3]);
                 }
             }
             rb[h] = vb;
+            if (BSRC != 0) rg[h] = vg;
+            if (BSRC == 2) rm[h] = vm;
         }
     };
     // this thread's A channels never change: the folded BN scale/shift of the previous layer sit in registers and
@@ -373,7 +416,27 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
             *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = v;
         }
 #pragma unroll
-        for (int h = 0; h < NB; h++) *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = rb[h];
+        for (int h = 0; h < NB; h++) {
+            float4 v = rb[h];
+            if (BSRC != 0) {
+                const long r = cur_store_r0 + b_row + h * RB;
+                float zz[4] = {v.x, v.y, v.z, v.w}, gg[4] = {rg[h].x, rg[h].y, rg[h].z, rg[h].w}, o[4];
+                if (BSRC == 2) {
+                    const int ro = bs.pool_shift >= 0 ? (int)((unsigned)r & (unsigned)(bs.pool_k - 1)) : (int)((unsigned)r % (unsigned)bs.pool_k);
+                    const int am[4] = {rm[h].x, rm[h].y, rm[h].z, rm[h].w};
+#pragma unroll
+                    for (int q = 0; q < 4; q++) gg[q] = (am[q] == ro) ? gg[q] : 0.0f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (bs.relu && !(zz[q] * kS[q] + kH[q] > 0.0f)) gg[q] = 0.0f;
+                    o[q] = kA[q] * gg[q] + kB[q] + kC[q] * zz[q];
+                    if (r >= r_end || nb + q >= cout) o[q] = 0.0f; // padding rows / channels stay zero
+                }
+                v = make_float4(o[0], o[1], o[2], o[3]);
+            }
+            *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = v;
+        }
     };
 
     // prologue: slab 0 -> LDS, slab 1 -> registers, idx of slab 2 -> pidx
@@ -558,23 +621,19 @@ extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *
 }
 
 extern "C" int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
-                                         const float *scale, const float *shift, const float *mean, const float *var,
-                                         float eps, int relu, const float *gamma, const double *sums, float *dz,
-                                         float *dgamma, float *dbeta, float *coef_scratch, void *stream)
+                                         const float *coef, int relu, float *dz, void *stream)
 {
     VN_REQUIRE(rows > 0 && c > 0 && k >= 0, "bn_backward_apply expects rows > 0, c > 0, k >= 0");
-    VN_REQUIRE(da && z && scale && shift && mean && var && gamma && sums && dz && coef_scratch, "bn_backward_apply: null buffer");
+    VN_REQUIRE(da && z && coef && dz, "bn_backward_apply: null buffer");
     VN_REQUIRE(k == 0 || argmax != nullptr, "bn_backward_apply: pooled mode needs argmax");
     hipStream_t st = as_stream(stream);
-    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 255) / 256), dim3(256), 0, st, rows, c, scale, shift, mean, var, eps, gamma,
-                       sums, coef_scratch, dgamma, dbeta);
     const bool vec = (c % 4 == 0) && ((uintptr_t)z % 16 == 0) && ((uintptr_t)dz % 16 == 0) && (k > 0 || (uintptr_t)da % 16 == 0);
     if (vec)
         hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(grid_for(rows * (c / 4), 256)), dim3(256), 0, st, rows, c, k, da, argmax, z,
-                           coef_scratch, relu, dz);
+                           coef, relu, dz);
     else
         hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(grid_for(rows * c, 256)), dim3(256), 0, st, rows, c, k, da, argmax, z,
-                           coef_scratch, relu, dz);
+                           coef, relu, dz);
     return check_launch("bn_backward_apply");
 }
 
@@ -649,8 +708,8 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(MlpIn in, long rows, 
     }
 }
 
-template <int MODE>
-static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const float *dz, float *dw, hipStream_t st)
+template <int MODE, int BSRC>
+static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, float *dw, hipStream_t st)
 {
     const int TIr = cin <= 64 ? 1 : 2, TJr = cout <= 64 ? 1 : 2;
     const int BI = 64 * TIr, BJ = 64 * TJr;
@@ -662,32 +721,34 @@ static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const flo
     if (rpb < 4 * WG_BR) rpb = 4 * WG_BR;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
     if (TIr == 2 && TJr == 2)
-        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 2>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else if (TIr == 2)
-        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 1>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else if (TJr == 2)
-        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 2>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else
-        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 1>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, dw, rpb);
+        hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
 }
 
-extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
-                                 void *stream)
+static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc,
+                       float *dw, void *stream)
 {
     VN_REQUIRE(in != nullptr, "mlp_wgrad: null input descriptor");
     VN_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "mlp_wgrad expects rows >= 0, cin > 0, cout > 0");
     if (rows == 0) return VOTENET_OK;
-    VN_REQUIRE(dz && dw, "mlp_wgrad: null buffer");
+    VN_REQUIRE(dw != nullptr, "mlp_wgrad: null buffer");
     MlpIn d = to_dev(in);
     hipStream_t st = as_stream(stream);
     if (in->x) {
         VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_wgrad: in_scale and in_shift go together");
-        launch_wgrad<0>(d, rows, cin, cout, dz, dw, st);
+        if (bsrc == 0) launch_wgrad<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
+        else if (bsrc == 1) launch_wgrad<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
+        else launch_wgrad<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
     } else {
         VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_wgrad: GATHER input needs xyz, new_xyz and idx");
         VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_wgrad: rows must equal b*m*nsample for a GATHER input");
         VN_REQUIRE(cin == 3 + d.c, "mlp_wgrad: cin must equal 3 + c for a GATHER input");
-        const bool narrow_ok = (cout == 64 || cout == 128 || cout == 256);
+        const bool narrow_ok = bsrc == 0 && (cout == 64 || cout == 128 || cout == 256);
         if (narrow_ok) {
             // dxyz (and <= 5 feature) columns: streaming reduction; wide feature block: MFMA kernel on W rows 3..
             const int nch = d.c <= 5 ? 3 + d.c : 3;
@@ -695,12 +756,50 @@ extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin
             rpb = (rpb + 255) / 256 * 256;
             hipLaunchKernelGGL(wgrad_narrow_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, d, rows, nch, cout, dz,
                                dw, rpb);
-            if (d.c > 5) launch_wgrad<1>(d, rows, d.c, cout, dz, dw, st); // internal k < c are the feature channels
+            if (d.c > 5) launch_wgrad<1, 0>(d, rows, d.c, cout, dz, bs, dw, st); // internal k < c are the feature channels
         } else {
-            launch_wgrad<1>(d, rows, cin, cout, dz, dw, st);
+            if (bsrc == 0) launch_wgrad<1, 0>(d, rows, cin, cout, dz, bs, dw, st);
+            else if (bsrc == 1) launch_wgrad<1, 1>(d, rows, cin, cout, dz, bs, dw, st);
+            else launch_wgrad<1, 2>(d, rows, cin, cout, dz, bs, dw, st);
         }
     }
     return check_launch("mlp_wgrad");
+}
+
+extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
+                                 void *stream)
+{
+    VN_REQUIRE(dz != nullptr || rows == 0, "mlp_wgrad: null dz");
+    BnSrc bs = {};
+    return wgrad_entry(in, rows, cin, cout, dz, bs, 0, dw, stream);
+}
+
+// dw += input^T * dz with dz = BatchNorm-backward(da | pooled gout, z, coef) formed inside the dz-operand loader
+extern "C" int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int cout, const float *da, const float *gout,
+                                    const int *argmax, int pool_k, const float *z, const float *coef, int relu, float *dw,
+                                    void *stream)
+{
+    VN_REQUIRE((da != nullptr) != (gout != nullptr), "mlp_wgrad_bn: exactly one of da / gout");
+    VN_REQUIRE(z && coef, "mlp_wgrad_bn: null buffer");
+    VN_REQUIRE(gout == nullptr || (argmax != nullptr && pool_k > 0 && rows % pool_k == 0), "mlp_wgrad_bn: pooled source needs argmax and k");
+    VN_REQUIRE(rows < (1L << 31), "mlp_wgrad_bn: rows must be below 2^31");
+    int shift = -1;
+    if (pool_k > 0 && (pool_k & (pool_k - 1)) == 0) shift = __builtin_ctz((unsigned)pool_k);
+    BnSrc bs = {da, gout, argmax, pool_k, shift, z, coef, relu};
+    return wgrad_entry(in, rows, cin, cout, nullptr, bs, da ? 1 : 2, dw, stream);
+}
+
+// coefficient vector [A | B | C | scale | shift] (5*c floats) of the folded BatchNorm backward, from the reductions
+// sums = [sum g', sum g'*zhat]; also dgamma += sums[c:], dbeta += sums[:c] (each may be NULL)
+extern "C" int votenet_bn_backward_coef(long rows, int c, const float *scale, const float *shift, const float *mean,
+                                        const float *var, float eps, const float *gamma, const double *sums, float *coef,
+                                        float *dgamma, float *dbeta, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0, "bn_backward_coef expects rows > 0, c > 0");
+    VN_REQUIRE(scale && shift && mean && var && gamma && sums && coef, "bn_backward_coef: null buffer");
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((c + 255) / 256), dim3(256), 0, as_stream(stream), rows, c, scale, shift, mean, var,
+                       eps, gamma, sums, coef, dgamma, dbeta);
+    return check_launch("bn_backward_coef");
 }
 
 extern "C" int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const float *d_rows_feat,

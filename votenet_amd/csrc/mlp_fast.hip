@@ -23,14 +23,38 @@ constexpr int FG_BM = 128;
 constexpr int FG_BK = 16;
 constexpr int FG_LDA = FG_BM + 2;
 
+// Everything the kernel needs.  SRC selects how the A operand (rows x cin) is produced:
+//   SRC 0: x, optionally through relu(x*in_scale+in_shift)                      (forward / plain dgrad)
+//   SRC 1: dz = A*g + B + C*zsrc with g = da masked by [zsrc*S+H > 0]           (BatchNorm backward folded in,
+//   SRC 2: same with g = gout[row/pool_k] where row%pool_k == argmax[row/pool_k]  dense / max-pooled upstream)
+//          coef = [A | B | C | S | H], 5*cin floats (votenet_bn_backward_coef)
+// EPI selects the statistics accumulated next to the store of the output z (rows x cout):
+//   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
+//   EPI 1: sum g', sum g'*zhat with g' = z masked by [zprev*ps+pb > 0], zhat = (zprev-pmean)*rsqrt(pvar+eps)
+//          (the BatchNorm-backward reductions of the layer BELOW, whose da this GEMM has just produced)
+struct FastArgs {
+    const float *x, *in_scale, *in_shift;
+    int in_relu;
+    const float *da, *gout;
+    const int *argmax;
+    int pool_k;
+    const float *zsrc, *coef;
+    int src_relu;
+    const float *zprev, *p_scale, *p_shift, *p_mean, *p_var;
+    float eps;
+    int p_relu;
+    double *stats;
+    long rows;
+    int cin, cout;
+    const float *w, *bias;
+    float *z;
+};
+
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
-template <int WM, int WN, int MT, int NT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_linear_fast_kernel(
-    const float *__restrict__ x, const float *__restrict__ in_scale, const float *__restrict__ in_shift, int in_relu,
-    long rows, int cin, int cout, const float *__restrict__ w, const float *__restrict__ bias, float *__restrict__ z,
-    double *__restrict__ stats)
+template <int WM, int WN, int MT, int NT, int SRC, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
@@ -38,20 +62,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     constexpr int NB4 = FG_BK * BN / 4 / 256; // W float4 per thread per slab (1 or 2)
     __shared__ float As[2][FG_BK][FG_LDA];
     __shared__ float Bs[2][FG_BK][LDB];
-    __shared__ __attribute__((aligned(16))) float Ssc[512], Ssh[512];
+    __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
 
+    const long rows = A.rows;
+    const int cin = A.cin, cout = A.cout;
+    const float *__restrict__ w = A.w;
+    float *__restrict__ z = A.z;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WN, wn = wv % WN;
     const int n0 = blockIdx.y * BN;
     const int nk = cin / FG_BK;
     const long ntiles = rows / FG_BM;
-    const bool affine = in_scale != nullptr;
-    if (affine) {
-        for (int k = tid; k < cin; k += 256) {
-            Ssc[k] = in_scale[k];
-            Ssh[k] = in_shift[k];
-        }
+    const bool affine = (SRC == 0) && A.in_scale != nullptr;
+    if (SRC == 0) {
+        if (affine)
+            for (int k = tid; k < cin; k += 256) {
+                Sco[0][k] = A.in_scale[k];
+                Sco[1][k] = A.in_shift[k];
+            }
+    } else {
+        for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
     }
     long my_tiles = 0;
     if ((long)blockIdx.x < ntiles) my_tiles = (ntiles - 1 - blockIdx.x) / gridDim.x + 1;
@@ -59,9 +90,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     // A staging: thread t -> tile rows (t>>2) and (t>>2)+64, k-quad (t&3); W staging: float4 #t (+256)
     const int a_row = tid >> 2, a_kq = tid & 3;
-    const float *pa0 = x + ((size_t)blockIdx.x * FG_BM + a_row) * cin + a_kq * 4;
+    const float *abase = (SRC == 0) ? A.x : A.zsrc; // the array the row pointers walk
+    const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * cin + a_kq * 4;
     const float *pa1 = pa0 + (size_t)64 * cin;
+    const ptrdiff_t da_off = (SRC == 1) ? (A.da - A.zsrc) : 0; // SRC 1: da has the layout of zsrc
     const size_t a_tile_jump = (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
+    // SRC 2: pooled upstream gradient and arg-max of this thread's two rows (group = row / pool_k)
+    const int pk = (SRC == 2) ? A.pool_k : 1;
+    long g0 = 0, g1 = 0;    // groups of the two staged rows of the step being LOADED
+    int ro0 = 0, ro1 = 0;   // their row offsets inside the group
+    if (SRC == 2) {
+        const long r0 = (long)blockIdx.x * FG_BM + a_row;
+        g0 = r0 / pk;
+        ro0 = (int)(r0 - g0 * pk);
+        g1 = (r0 + 64) / pk;
+        ro1 = (int)(r0 + 64 - g1 * pk);
+    }
     const float *pb[NB4];
 #pragma unroll
     for (int u = 0; u < NB4; u++) {
@@ -71,13 +115,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const size_t b_step = (size_t)FG_BK * cout, b_wrap = (size_t)cin * cout;
     int lkt = 0; // k-slab index of the step being loaded
     float4 ra0, ra1, rb[NB4];
-    int rk = 0;
+    float4 rg0 = make_float4(0.f, 0.f, 0.f, 0.f), rg1 = rg0; // SRC 1: da quads; SRC 2: gout quads
+    int4 rm0 = make_int4(0, 0, 0, 0), rm1 = rm0;             // SRC 2: arg-max quads
+    int rk = 0, rro0 = 0, rro1 = 0;                           // k / row offsets of the quads held in registers
     auto issue_loads = [&]() {
         ra0 = *reinterpret_cast<const float4 *>(pa0);
         ra1 = *reinterpret_cast<const float4 *>(pa1);
+        const int kq = lkt * FG_BK + a_kq * 4;
+        if (SRC == 1) {
+            rg0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
+            rg1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
+        } else if (SRC == 2) {
+            rg0 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g0 * cin + kq);
+            rg1 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g1 * cin + kq);
+            rm0 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g0 * cin + kq);
+            rm1 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g1 * cin + kq);
+            rro0 = ro0;
+            rro1 = ro1;
+        }
 #pragma unroll
         for (int u = 0; u < NB4; u++) rb[u] = *reinterpret_cast<const float4 *>(pb[u]);
-        rk = lkt * FG_BK + a_kq * 4;
+        rk = kq;
         pa0 += FG_BK;
         pa1 += FG_BK;
 #pragma unroll
@@ -88,28 +146,60 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             pa1 += a_tile_jump;
 #pragma unroll
             for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
+            if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
+                const long dg = (long)gridDim.x * FG_BM / pk;
+                g0 += dg;
+                g1 += dg;
+            }
         }
         --steps_to_load;
     };
-    auto act4 = [&](float4 v) {
-        if (affine) {
-            const float4 sc = *reinterpret_cast<const float4 *>(&Ssc[rk]);
-            const float4 sh = *reinterpret_cast<const float4 *>(&Ssh[rk]);
-            v.x = v.x * sc.x + sh.x;
-            v.y = v.y * sc.y + sh.y;
-            v.z = v.z * sc.z + sh.z;
-            v.w = v.w * sc.w + sh.w;
-            if (in_relu) {
-                v.x = v.x > 0.f ? v.x : 0.f;
-                v.y = v.y > 0.f ? v.y : 0.f;
-                v.z = v.z > 0.f ? v.z : 0.f;
-                v.w = v.w > 0.f ? v.w : 0.f;
+    auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro) {
+        if (SRC == 0) {
+            if (affine) {
+                const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
+                const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
+                v.x = v.x * sc.x + sh.x;
+                v.y = v.y * sc.y + sh.y;
+                v.z = v.z * sc.z + sh.z;
+                v.w = v.w * sc.w + sh.w;
+                if (A.in_relu) {
+                    v.x = v.x > 0.f ? v.x : 0.f;
+                    v.y = v.y > 0.f ? v.y : 0.f;
+                    v.z = v.z > 0.f ? v.z : 0.f;
+                    v.w = v.w > 0.f ? v.w : 0.f;
+                }
             }
+            return v;
         }
-        return v;
+        // BatchNorm backward: v is the zsrc quad
+        float gg[4] = {g.x, g.y, g.z, g.w};
+        const float zz[4] = {v.x, v.y, v.z, v.w};
+        if (SRC == 2) {
+            gg[0] = (am.x == ro) ? gg[0] : 0.f;
+            gg[1] = (am.y == ro) ? gg[1] : 0.f;
+            gg[2] = (am.z == ro) ? gg[2] : 0.f;
+            gg[3] = (am.w == ro) ? gg[3] : 0.f;
+        }
+        const float4 cA = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
+        const float4 cB = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
+        const float4 cC = *reinterpret_cast<const float4 *>(&Sco[2][rk]);
+        const float cAa[4] = {cA.x, cA.y, cA.z, cA.w}, cBa[4] = {cB.x, cB.y, cB.z, cB.w}, cCa[4] = {cC.x, cC.y, cC.z, cC.w};
+        float o[4];
+        if (A.src_relu) {
+            const float4 cS = *reinterpret_cast<const float4 *>(&Sco[3][rk]);
+            const float4 cH = *reinterpret_cast<const float4 *>(&Sco[4][rk]);
+            const float cSa[4] = {cS.x, cS.y, cS.z, cS.w}, cHa[4] = {cH.x, cH.y, cH.z, cH.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+                if (!(zz[q] * cSa[q] + cHa[q] > 0.0f)) gg[q] = 0.0f;
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) o[q] = cAa[q] * gg[q] + cBa[q] + cCa[q] * zz[q];
+        return make_float4(o[0], o[1], o[2], o[3]);
     };
     auto store_regs = [&](int buf) {
-        const float4 v0 = act4(ra0), v1 = act4(ra1);
+        const float4 v0 = act4(ra0, rg0, rm0, rro0), v1 = act4(ra1, rg1, rm1, rro1);
         As[buf][a_kq * 4 + 0][a_row] = v0.x;
         As[buf][a_kq * 4 + 1][a_row] = v0.y;
         As[buf][a_kq * 4 + 2][a_row] = v0.z;
@@ -129,13 +219,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
     if (my_tiles == 0) return;
-    __syncthreads(); // Ssc / Ssh
+    __syncthreads(); // Sco
     issue_loads();   // step 0
     store_regs(0);
     if (steps_to_load > 0) issue_loads(); // step 1 in flight
     __syncthreads();
 
     const int kh = lane >> 5, l31 = lane & 31;
+    // EPI 1: per-column constants of the layer below (columns of this lane)
+    float ps[NT], pb2[NT], pmu[NT], pinv[NT];
+    if (EPI == 1) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int col = n0 + (wn * NT + j) * 32 + l31;
+            ps[j] = A.p_scale[col];
+            pb2[j] = A.p_shift[col];
+            pmu[j] = A.p_mean[col];
+            pinv[j] = 1.0f / sqrtf(A.p_var[col] + A.eps);
+        }
+    }
     int buf = 0;
     long steps_left = my_tiles * nk; // steps still to compute, including the current one
     for (long t = 0; t < my_tiles; t++) {
@@ -182,55 +284,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const int col = n0 + (wn * NT + j) * 32 + l31;
-            const float bv = bias ? bias[col] : 0.0f;
+            const float bv = A.bias ? A.bias[col] : 0.0f;
 #pragma unroll
             for (int i = 0; i < MT; i++) {
-                float *zr = z + (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
+                const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
+                    const size_t off = off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout;
                     const float v = acc[i][j][e] + bv;
-                    zr[(size_t)((e & 3) + 8 * (e >> 2)) * cout] = v;
-                    s1[j] += v;
-                    s2[j] += v * v;
+                    z[off] = v;
+                    if (EPI == 0) {
+                        s1[j] += v;
+                        s2[j] += v * v;
+                    } else {
+                        const float zz = A.zprev[off];
+                        const float gq = (A.p_relu && !(zz * ps[j] + pb2[j] > 0.0f)) ? 0.0f : v;
+                        s1[j] += gq;
+                        s2[j] += gq * ((zz - pmu[j]) * pinv[j]);
+                    }
                 }
             }
         }
     }
-    if (stats) {
+    if (A.stats) {
+        // combine the WM waves that share a column block in LDS (the operand buffers are free now: every wave is past
+        // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
+        // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
+        float *red = &As[0][0][0]; // [2][WM][BN]
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const float t1 = s1[j] + __shfl_xor(s1[j], 32);
             const float t2 = s2[j] + __shfl_xor(s2[j], 32);
-            const int col = n0 + (wn * NT + j) * 32 + l31;
+            const int c = (wn * NT + j) * 32 + l31;
             if (lane < 32) {
-                unsafeAtomicAdd(&stats[col], (double)t1);
-                unsafeAtomicAdd(&stats[cout + col], (double)t2);
+                red[(0 * WM + wm) * BN + c] = t1;
+                red[(1 * WM + wm) * BN + c] = t2;
             }
         }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, c = tid % BN;
+            float t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < WM; i++) t += red[(which * WM + i) * BN + c];
+            unsafeAtomicAdd(&A.stats[which * cout + n0 + c], (double)t);
+        }
     }
+}
+
+template <int SRC, int EPI>
+static bool fast_dispatch(const FastArgs &a, hipStream_t st)
+{
+    const float *abase = (SRC == 0) ? a.x : a.zsrc;
+    const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
+                         (SRC != 1 || (uintptr_t)a.da % 16 == 0) &&
+                         (SRC != 2 || ((uintptr_t)a.gout % 16 == 0 && (uintptr_t)a.argmax % 16 == 0));
+    if (!aligned || a.cin % FG_BK != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
+    const long ntiles = a.rows / FG_BM;
+    long gx;
+    if (a.cout % 128 == 0) {
+        const int ny = a.cout / 128;
+        gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
+        if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false; // a tile jump must be a whole number of groups
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        return true;
+    }
+    if (a.cout == 64) {
+        gx = ntiles < 2048 ? ntiles : 2048;
+        if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, 1), dim3(256), 0, st, a);
+        return true;
+    }
+    return false;
 }
 
 // returns true when the fast kernel took the launch
 bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
                             int cout, const float *w, const float *bias, float *z, double *stats, hipStream_t st)
 {
-    const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
-    if (!aligned || cin % FG_BK != 0 || cin > 512 || rows % FG_BM != 0 || rows == 0) return false;
-    const long ntiles = rows / FG_BM;
-    if (cout % 128 == 0) {
-        const int ny = cout / 128;
-        long gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, x, in_scale, in_shift,
-                           in_relu, rows, cin, cout, w, bias, z, stats);
-        return true;
-    }
-    if (cout == 64) {
-        long gx = ntiles < 2048 ? ntiles : 2048;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2>), dim3((unsigned)gx, 1), dim3(256), 0, st, x, in_scale, in_shift,
-                           in_relu, rows, cin, cout, w, bias, z, stats);
-        return true;
-    }
-    return false;
+    FastArgs a = {};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = cin;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.stats = stats;
+    return fast_dispatch<0, 0>(a, st);
 }
 
 } // namespace votenet
+
+using namespace votenet;
+
+// da_prev (rows x cout) = dz (rows x c) * wT (c x cout) with dz = BatchNorm-backward(da | pooled gout, zsrc, coef)
+// formed inside the A-operand loader; optionally also the BatchNorm-backward reductions of the layer below.
+extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,
+                                    int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
+                                    float *da_prev, const float *zprev, const float *p_scale, const float *p_shift,
+                                    const float *p_mean, const float *p_var, float eps, int p_relu, double *p_sums, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "mlp_dgrad_bn expects rows > 0, c > 0, cout > 0");
+    VN_REQUIRE((da != nullptr) != (gout != nullptr), "mlp_dgrad_bn: exactly one of da / gout");
+    VN_REQUIRE(zsrc && coef && wT && da_prev, "mlp_dgrad_bn: null buffer");
+    VN_REQUIRE(gout == nullptr || (argmax != nullptr && pool_k > 0 && rows % pool_k == 0), "mlp_dgrad_bn: pooled source needs argmax and k");
+    FastArgs a = {};
+    a.da = da;
+    a.gout = gout;
+    a.argmax = argmax;
+    a.pool_k = pool_k;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = cout;
+    a.w = wT;
+    a.z = da_prev;
+    a.zprev = zprev;
+    a.p_scale = p_scale;
+    a.p_shift = p_shift;
+    a.p_mean = p_mean;
+    a.p_var = p_var;
+    a.eps = eps;
+    a.p_relu = p_relu;
+    a.stats = p_sums;
+    hipStream_t st = as_stream(stream);
+    bool ok;
+    if (p_sums) {
+        VN_REQUIRE(zprev && p_scale && p_shift && p_mean && p_var, "mlp_dgrad_bn: fused reduction needs the statistics of the layer below");
+        ok = da ? fast_dispatch<1, 1>(a, st) : fast_dispatch<2, 1>(a, st);
+    } else {
+        ok = da ? fast_dispatch<1, 0>(a, st) : fast_dispatch<2, 0>(a, st);
+    }
+    if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn: shape not supported by the fused kernel (use votenet_bn_backward_apply + votenet_mlp_linear)");
+    return check_launch("mlp_dgrad_bn");
+}

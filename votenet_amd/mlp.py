@@ -131,18 +131,75 @@ def bn_relu(z, scale, shift, relu=True):
 def bn_backward(z, scale, shift, mean, var, gamma, relu, da, dgamma, dbeta, argmax=None, k=0, eps=BN_EPS):
     """Training-mode BatchNorm (+ReLU) backward.  da: dense (rows,c), or pooled gout (rows/k,c) with argmax.
     Returns dz (rows,c); accumulates dgamma / dbeta (views into the gradient bucket)."""
+    sums = bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax, k, eps)
+    coef = bn_backward_coef(z.shape[0], scale, shift, mean, var, gamma, sums, dgamma, dbeta, eps)
+    return bn_backward_apply(z, coef, relu, da, argmax, k)
+
+
+def bn_backward_apply(z, coef, relu, da, argmax=None, k=0):
+    """dz (rows,c) = A*g' + B + C*z written out (the unfused path)."""
+    rows, c = z.shape
+    dz = torch.empty_like(z)
+    with torch.cuda.device(z.device):
+        L.check(L.lib().votenet_bn_backward_apply(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(coef), 1 if relu else 0,
+                                                  L.ptr(dz), L.stream_ptr()))
+    return dz
+
+
+def bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax=None, k=0, eps=BN_EPS):
+    """sums (2*c f64) = [sum g', sum g'*zhat] of a BatchNorm'ed layer (g' = ReLU / arg-max masked gradient)."""
     rows, c = z.shape
     sums = torch.zeros(2 * c, dtype=torch.float64, device=z.device)
-    coef = torch.empty(5 * c, dtype=torch.float32, device=z.device)
-    dz = torch.empty_like(z)
     with torch.cuda.device(z.device):
         L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
                                                    L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
                                                    L.stream_ptr()))
-        L.check(L.lib().votenet_bn_backward_apply(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
-                                                  L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(gamma),
-                                                  L.ptr(sums), L.ptr(dz), L.ptr(dgamma), L.ptr(dbeta), L.ptr(coef), L.stream_ptr()))
-    return dz
+    return sums
+
+
+def bn_backward_coef(rows, scale, shift, mean, var, gamma, sums, dgamma, dbeta, eps=BN_EPS):
+    """coef (5*c) = [A|B|C|scale|shift] with dz = A*g' + B + C*z; accumulates dgamma / dbeta."""
+    c = gamma.shape[0]
+    coef = torch.empty(5 * c, dtype=torch.float32, device=gamma.device)
+    with torch.cuda.device(gamma.device):
+        L.check(L.lib().votenet_bn_backward_coef(rows, c, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var), float(eps),
+                                                 L.ptr(gamma), L.ptr(sums), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta),
+                                                 L.stream_ptr()))
+    return coef
+
+
+def dgrad_bn_supported(rows, c, cout):
+    """Shapes the fused BatchNorm-backward dgrad kernel serves (see include/votenet_hip.h)."""
+    return rows > 0 and rows % 128 == 0 and c % 16 == 0 and c <= 512 and (cout == 64 or cout % 128 == 0)
+
+
+def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, in_scale=None, in_shift=None, in_relu=True):
+    """dw += act(x)^T dz with dz = BatchNorm-backward(da | pooled gout, z, coef) formed in the loader."""
+    rows, cin = x.shape
+    cout = z.shape[1]
+    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout):
+        L.check(L.lib().votenet_mlp_wgrad_bn(ctypes.byref(d), rows, cin, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z),
+                                             L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.stream_ptr()))
+
+
+def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None, eps=BN_EPS):
+    """da_prev = dz @ wT with dz formed in the loader.  below = (zprev, scale, shift, mean, var, relu) of the layer
+    underneath: its BatchNorm-backward sums are then accumulated by the epilogue.  -> da_prev, sums or None."""
+    rows, c = z.shape
+    cout = wT.shape[1]
+    out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
+    sums = None
+    zp = ps = pb = pm = pv = None
+    prelu = 0
+    if below is not None:
+        zp, ps, pb, pm, pv, prelu = below
+        sums = torch.zeros(2 * cout, dtype=torch.float64, device=z.device)
+    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout):
+        L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
+                                             1 if relu else 0, L.ptr(wT), L.ptr(out), L.ptr(zp), L.ptr(ps), L.ptr(pb), L.ptr(pm),
+                                             L.ptr(pv), float(eps), 1 if prelu else 0, L.ptr(sums), L.stream_ptr()))
+    return out, sums
 
 
 def bias_grad(dz, dbias):

@@ -124,6 +124,12 @@ def mlp_chain_forward(layers, rows, first, tape):
     return z, sc, sh
 
 
+# Let the dgrad GEMM's epilogue also accumulate the BatchNorm-backward sums of the layer below (votenet_mlp_dgrad_bn
+# p_sums).  Measured on MI355X (tools/bench_bwd.py) the epilogue's zprev reads are exposed latency and cost slightly
+# more than the standalone reduction pass they replace, so the default keeps the separate pass.
+FUSE_BN_REDUCE = False
+
+
 def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, need_xyz_grad=False):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
@@ -134,15 +140,35 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
     d_rows_xyz (rows, 3) or None) -- the feature block W[3:] is a 128-multiple wide GEMM of its own and the
     three xyz columns are only computed when the caller needs them (proposal layer)."""
     da = g
+    sums = None  # BatchNorm-backward reductions of the current layer when the GEMM above already produced them
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
         L = r["layer"]
         z = r["z"]
+        rows, c = z.shape
+        pooled = (mode == "pool" and i == len(recs) - 1)
+        want_da = i > 0 or need_input_grad
         if L.bn:
-            pooled = (mode == "pool" and i == len(recs) - 1)
-            dz = M.bn_backward(z, r["scale"], r["shift"], r["mean"], r["var"], L.p("gamma"), L.relu, da, L.gp("gamma"),
-                               L.gp("beta"), argmax=argmax if pooled else None, k=k if pooled else 0)
+            bn = (r["scale"], r["shift"], r["mean"], r["var"])
+            if sums is None:
+                sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
+            coef = M.bn_backward_coef(rows, *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
+            sums = None
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
+            if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
+                # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
+                src = dict(gout=da, argmax=argmax, k=k) if pooled else dict(da=da)
+                M.wgrad_dense_bn(r["x"], z, coef, L.relu, L.gp("W"), in_scale=r["in_scale"], in_shift=r["in_shift"],
+                                 in_relu=r["in_relu"], **src)
+                if not want_da:
+                    return None
+                below = None
+                if FUSE_BN_REDUCE and i > 0 and recs[i - 1]["layer"].bn:
+                    rp = recs[i - 1]
+                    below = (rp["z"], rp["scale"], rp["shift"], rp["mean"], rp["var"], rp["layer"].relu)
+                da, sums = M.dgrad_bn(z, coef, L.relu, L.p("W").t().contiguous(), below=below, **src)
+                continue
+            dz = M.bn_backward_apply(z, coef, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
         else:
             dz = da
             M.bias_grad(dz, L.gp("b"))
@@ -157,7 +183,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
             if need_xyz_grad:
                 d_rows_xyz, _ = M.linear_dense(dz, L.p("W")[:3].t().contiguous(), want_stats=False)
             return d_rows_feat, d_rows_xyz
-        if i > 0 or need_input_grad:
+        if want_da:
             da, _ = M.linear_dense(dz, L.p("W").t().contiguous(), want_stats=False)  # da_prev = dz W^T
         else:
             da = None
