@@ -222,7 +222,7 @@ int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int co
  * coef).  If p_sums != NULL (2*cout doubles, pre-zeroed) the epilogue also accumulates the
  * votenet_bn_backward_reduce sums of the layer below: its raw output zprev (rows x cout), statistics
  * p_scale/p_shift/p_mean/p_var (cout each) and ReLU flag p_relu.
- * Shapes served: rows % 128 == 0, c % 16 == 0, c <= 512, cout == 64 or cout % 128 == 0, 16-byte aligned
+ * Shapes served: rows % 128 == 0, c % 32 == 0, c <= 512, cout == 64 or cout % 128 == 0, 16-byte aligned
  * buffers; anything else returns VOTENET_E_INVALID_ARGUMENT (use votenet_bn_backward_apply +
  * votenet_mlp_linear instead). */
 int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,

@@ -1,13 +1,24 @@
-"""One GEMM layer in isolation for PMC collection (scratch tool)."""
+"""Representative MLP GEMM launches in isolation for PMC collection (MFMA busy cycles, HBM bytes).  GPU box only.
+sa1 L2 (1 048 576 x 64 -> 128: HBM-bound, 21 flop/B) and sa2 L2 (262 144 x 128 -> 256: MFMA-bound, 43 flop/B):
+forward (folded BN+ReLU on the input, statistics epilogue), fused BatchNorm-backward dgrad and wgrad."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from votenet_amd import mlp as M
 dev = torch.device("cuda:0")
-rows, ci, co = 524288, 256, 128
-x = torch.randn(rows, ci, device=dev); w = torch.randn(ci, co, device=dev)
-sc = torch.ones(ci, device=dev); sh = torch.zeros(ci, device=dev)
-for _ in range(3):
-    M.linear_dense(x, w, want_stats=False)          # dgrad-like
-    M.linear_dense(x, w, None, sc, sh, True)        # forward-like
+for rows, ci, co, k in [(8 * 2048 * 64, 64, 128, 64), (8 * 1024 * 32, 128, 256, 32)]:
+    x = torch.randn(rows, ci, device=dev); w = torch.randn(ci, co, device=dev) * 0.1
+    sc = torch.ones(ci, device=dev); sh = torch.zeros(ci, device=dev)
+    gamma, beta = torch.ones(co, device=dev), torch.zeros(co, device=dev)
+    for _ in range(3):
+        z, stats = M.linear_dense(x, w, None, sc, sh, True)
+    s, h, mu, var = M.bn_finalize(rows, stats, gamma, beta)
+    _, argmax = M.bn_relu_max(z, k, s, h, True, want_argmax=True)
+    gout = torch.randn(rows // k, co, device=dev)
+    sums = M.bn_backward_reduce(z, s, h, mu, var, True, gout, argmax, k)
+    coef = M.bn_backward_coef(rows, s, h, mu, var, gamma, sums, None, None)
+    wT = w.t().contiguous(); dw = torch.zeros_like(w)
+    for _ in range(3):
+        M.dgrad_bn(z, coef, True, wT, gout=gout, argmax=argmax, k=k)
+        M.wgrad_dense_bn(x, z, coef, True, dw, gout=gout, argmax=argmax, k=k, in_scale=sc, in_shift=sh)
 torch.cuda.synchronize()

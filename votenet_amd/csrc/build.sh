@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-u
 pids=()
 for src in "$HERE"/*.hip; do
   obj="$HERE/obj/$(basename "${src%.hip}").o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/../../include/votenet_hip.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/mlp_types.h" -nt "$obj" ] || [ "$HERE/../../include/votenet_hip.h" -nt "$obj" ]; then
     extra=""
     # fps.hip: no NaN can occur (distances of finite points); dropping NaN canonicalisation shortens the
     # serial per-round instruction chain.  Infinities (empty bucket boxes) are still honoured.

@@ -19,7 +19,7 @@
 // Internal K order of GATHER mode is [feat(c), dxyz(3)] (features first, so feature rows load
 // as aligned float4); row k of the caller's W (whose order is the reference's [dxyz, feat],
 // utils.py:55) is fetched through the same permutation, so the result is the reference's.
-#include "common.h"
+#include "mlp_types.h"
 
 namespace votenet {
 
@@ -39,19 +39,6 @@ constexpr int MLP_AP = MLP_BM / MLP_RPP;  // passes (float4 per thread) for the 
 constexpr int MLP_LDA = MLP_BM + 2; // [k][row] image; +2 -> conflict-free 4-lane-strided writes
 constexpr int MLP_MAXC = 512;       // input channels whose folded BN scale/shift are staged in LDS
 
-struct MlpIn {
-    // DENSE
-    const float *x;
-    const float *in_scale;
-    const float *in_shift;
-    int in_relu;
-    // GATHER
-    const float *xyz;
-    const float *new_xyz;
-    const float *feat;
-    const int *idx;
-    int n, m, nsample, c;
-};
 
 // One element of the implicit A matrix, internal k order.  Bounds are the caller's job.
 template <int MODE>

@@ -12,23 +12,10 @@
 //   votenet_group_concat_grad  : scatter of the first layer's input gradient back to the feature
 //                                and xyz tables (GroupPointGrad + the tile/subtract of utils.py:51)
 //   votenet_clip_adam          : per-tensor clip_by_average_norm + Adam over the flat bucket (model.py:240-250)
-#include "common.h"
+#include "mlp_types.h"
 
 namespace votenet {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-struct MlpIn {
-    const float *x;
-    const float *in_scale;
-    const float *in_shift;
-    int in_relu;
-    const float *xyz;
-    const float *new_xyz;
-    const float *feat;
-    const int *idx;
-    int n, m, nsample, c;
-};
 
 // ---------------------------------------------------------------- BN backward: reductions
 // block = 64 columns x 4 row-lanes; grid.x strides over rows, grid.y over column tiles of 64
@@ -225,17 +212,7 @@ __device__ __forceinline__ int w_row(int k, int c)
 // Pipeline as in mlp_linear_kernel: registers hold slab s+1 while slab s computes, they are written to the
 // other LDS buffer half way through the MFMAs and re-used at once for slab s+2; in GATHER mode the row
 // indices of slab s+3 are fetched at the same point, so the idx -> feature-row dependency is never exposed.
-// BSRC selects how the dz operand (rows x cout) is produced:
-//   0: dz read from memory;  1: dz = A*g + B + C*z with g = da masked by [z*S+H > 0]  (BatchNorm backward folded in);
-//   2: the same with g = gout[row/k] where row%k == argmax[row/k] (max-pooled upstream).  coef = [A|B|C|S|H], 5*cout.
-struct BnSrc {
-    const float *da, *gout;
-    const int *argmax;
-    int pool_k, pool_shift; // pool_shift = log2(pool_k) when pool_k is a power of two, else -1
-    const float *z, *coef;
-    int relu;
-};
-
+// BSRC selects how the dz operand (rows x cout) is produced (struct BnSrc, mlp_types.h): 0 memory, 1 dense, 2 pooled
 template <int MODE, int TI, int TJ, int BSRC>
 __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz,
                                                         BnSrc bs, float *__restrict__ dw, long rows_per_block)
@@ -718,7 +695,7 @@ static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const flo
     if (splits < 1) splits = 1;
     long rpb = (rows + splits - 1) / splits;
     rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
-    if (rpb < 4 * WG_BR) rpb = 4 * WG_BR;
+    if (rpb < 8 * WG_BR) rpb = 8 * WG_BR; // short row ranges are dominated by the atomic flush of the dW tile (measured)
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
     if (TIr == 2 && TJr == 2)
         hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);

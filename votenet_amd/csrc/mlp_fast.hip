@@ -1,15 +1,18 @@
 // mlp_fast.hip -- lean fp32 MFMA GEMM for the dense layers of the grouped-point MLP (gfx950).
 //
 // Same contract as mlp_linear_kernel (mlp.hip) for the case every dense VoteNet layer is in:
-//   DENSE input, cin % 16 == 0, cout % BN == 0, rows % 128 == 0, 16-byte aligned operands, cin <= 512.
+//   DENSE input, cin % 32 == 0, cout % BN == 0, rows % 128 == 0, 16-byte aligned operands, cin <= 512.
 // Written separately so that the hot loop carries no bounds checks, no mode branches and few live
 // registers (the generic kernel needs > 220 VGPRs and spills its prefetch registers, which turns the
 // "asynchronous" global loads into synchronous ones):
 //   * operand addresses are two pointers per thread that advance by constants;
-//   * a (tile, k-slab) step loads the NEXT step's A / W quads raw into registers right after the LDS
-//     barrier, writes them to the other LDS buffer half way through the step's MFMAs -- applying the
-//     previous layer's folded BN scale/shift + ReLU at that point, so the global loads stay in flight for
-//     half a step of matrix work -- and the barrier waits for LDS only (lgkmcnt), never for vmcnt;
+//   * two register sets hold the raw A / W quads of the next two (tile, k-slab) steps: half way through a step's
+//     MFMAs the older set goes to the other LDS buffer -- the previous layer's folded BN scale/shift + ReLU are
+//     applied at that point -- and is refilled with the slab three steps ahead, so every global load has two steps
+//     of matrix work (~2 x 2048 MFMA cycles per wave) to arrive.  With one step of lead the loaded HBM latency was
+//     longer than a step and memory time simply added to matrix time (sa2 L1: 68 -> 91 TFLOP/s with two);
+//     the loop body has no memory operation under a branch, which keeps the compiler's vmcnt bookkeeping exact,
+//     and the barrier waits for LDS only (lgkmcnt), never for vmcnt;
 //   * the pipeline runs across row tiles of a persistent workgroup (no drain at tile boundaries);
 //   * MFMA operand fragments are double-buffered in registers (ds_reads of sub-step k2+1 before the MFMAs
 //     of k2); LDS images are [k][row] / [k][col], conflict-free for both operand reads.
@@ -114,47 +117,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     const size_t b_step = (size_t)FG_BK * cout, b_wrap = (size_t)cin * cout;
     int lkt = 0; // k-slab index of the step being loaded
-    float4 ra0, ra1, rb[NB4];
-    float4 rg0 = make_float4(0.f, 0.f, 0.f, 0.f), rg1 = rg0; // SRC 1: da quads; SRC 2: gout quads
-    int4 rm0 = make_int4(0, 0, 0, 0), rm1 = rm0;             // SRC 2: arg-max quads
-    int rk = 0, rro0 = 0, rro1 = 0;                           // k / row offsets of the quads held in registers
-    auto issue_loads = [&]() {
-        ra0 = *reinterpret_cast<const float4 *>(pa0);
-        ra1 = *reinterpret_cast<const float4 *>(pa1);
+    // One k-slab step of raw operands in registers.  Two sets alternate: a set is filled two steps before its slab
+    // is needed in LDS, so the global loads have two steps of matrix work (2 x 2048 MFMA cycles) to arrive -- one step
+    // is less than the loaded HBM latency, which serialised memory time and matrix time.
+    struct Regs {
+        float4 a0, a1, b[NB4];
+        float4 g0, g1; // SRC 1: da quads; SRC 2: gout quads
+        int4 m0, m1;   // SRC 2: arg-max quads
+        int k, ro0, ro1; // k / row offsets of the quads
+    };
+    Regs R[2];
+    auto issue_loads = [&](Regs &r) {
+        r.a0 = *reinterpret_cast<const float4 *>(pa0);
+        r.a1 = *reinterpret_cast<const float4 *>(pa1);
         const int kq = lkt * FG_BK + a_kq * 4;
         if (SRC == 1) {
-            rg0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
-            rg1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
+            r.g0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
+            r.g1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
         } else if (SRC == 2) {
-            rg0 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g0 * cin + kq);
-            rg1 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g1 * cin + kq);
-            rm0 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g0 * cin + kq);
-            rm1 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g1 * cin + kq);
-            rro0 = ro0;
-            rro1 = ro1;
+            r.g0 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g0 * cin + kq);
+            r.g1 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g1 * cin + kq);
+            r.m0 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g0 * cin + kq);
+            r.m1 = *reinterpret_cast<const int4 *>(A.argmax + (size_t)g1 * cin + kq);
+            r.ro0 = ro0;
+            r.ro1 = ro1;
         }
 #pragma unroll
-        for (int u = 0; u < NB4; u++) rb[u] = *reinterpret_cast<const float4 *>(pb[u]);
-        rk = kq;
-        pa0 += FG_BK;
-        pa1 += FG_BK;
+        for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
+        r.k = kq;
+        // Advance to the next slab only if there is one: past the end the same (valid) slab is simply loaded again, so
+        // the loop body has no memory operation under a branch and the compiler's s_waitcnt bookkeeping stays exact
+        // (a conditional load makes it wait for vmcnt(0), which collapses the two-deep pipeline to one).
+        if (steps_to_load > 1) {
+            pa0 += FG_BK;
+            pa1 += FG_BK;
 #pragma unroll
-        for (int u = 0; u < NB4; u++) pb[u] += b_step;
-        if (++lkt == nk) {
-            lkt = 0;
-            pa0 += a_tile_jump;
-            pa1 += a_tile_jump;
+            for (int u = 0; u < NB4; u++) pb[u] += b_step;
+            if (++lkt == nk) {
+                lkt = 0;
+                pa0 += a_tile_jump;
+                pa1 += a_tile_jump;
 #pragma unroll
-            for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
-            if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
-                const long dg = (long)gridDim.x * FG_BM / pk;
-                g0 += dg;
-                g1 += dg;
+                for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
+                if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
+                    const long dg = (long)gridDim.x * FG_BM / pk;
+                    g0 += dg;
+                    g1 += dg;
+                }
             }
         }
         --steps_to_load;
     };
-    auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro) {
+    auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk) {
         if (SRC == 0) {
             if (affine) {
                 const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
@@ -198,8 +212,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         for (int q = 0; q < 4; q++) o[q] = cAa[q] * gg[q] + cBa[q] + cCa[q] * zz[q];
         return make_float4(o[0], o[1], o[2], o[3]);
     };
-    auto store_regs = [&](int buf) {
-        const float4 v0 = act4(ra0, rg0, rm0, rro0), v1 = act4(ra1, rg1, rm1, rro1);
+    auto store_regs = [&](int buf, const Regs &r) {
+        const float4 v0 = act4(r.a0, r.g0, r.m0, r.ro0, r.k), v1 = act4(r.a1, r.g1, r.m1, r.ro1, r.k);
         As[buf][a_kq * 4 + 0][a_row] = v0.x;
         As[buf][a_kq * 4 + 1][a_row] = v0.y;
         As[buf][a_kq * 4 + 2][a_row] = v0.z;
@@ -211,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
         for (int u = 0; u < NB4; u++) {
             const int f = tid + u * 256;
-            *reinterpret_cast<float4 *>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = rb[u];
+            *reinterpret_cast<float4 *>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = r.b[u];
         }
     };
 
@@ -220,9 +234,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
     if (my_tiles == 0) return;
     __syncthreads(); // Sco
-    issue_loads();   // step 0
-    store_regs(0);
-    if (steps_to_load > 0) issue_loads(); // step 1 in flight
+    // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
+    issue_loads(R[0]);
+    store_regs(0, R[0]);
+    issue_loads(R[1]);
+    __builtin_amdgcn_sched_barrier(0); // same issue order as in the loop: set 1, then set 0
+    issue_loads(R[0]);
     __syncthreads();
 
     const int kh = lane >> 5, l31 = lane & 31;
@@ -248,36 +265,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             for (int j = 0; j < NT; j++)
 #pragma unroll
                 for (int e = 0; e < 16; e++) acc[i][j][e] = 0.0f;
-        for (int kt = 0; kt < nk; kt++) {
-            const bool have_next = steps_left > 1; // registers hold the next step
-            float fa[2][MT], fb[2][NT];
+        // nk is even (launcher): step parity == kt parity, so the register set of a step is a compile-time constant.
+        // During step g the set (g+1)&1 holds slab g+1: half way through it goes to the other LDS buffer and the set is
+        // refilled with slab g+3.
+        for (int kt = 0; kt < nk; kt += 2) {
 #pragma unroll
-            for (int i = 0; i < MT; i++) fa[0][i] = As[buf][kh][(wm * MT + i) * 32 + l31];
+            for (int par = 0; par < 2; par++) {
+                Regs &rs = R[par ^ 1];
+                float fa[2][MT], fb[2][NT];
 #pragma unroll
-            for (int j = 0; j < NT; j++) fb[0][j] = Bs[buf][kh][(wn * NT + j) * 32 + l31];
+                for (int i = 0; i < MT; i++) fa[0][i] = As[buf][kh][(wm * MT + i) * 32 + l31];
 #pragma unroll
-            for (int k2 = 0; k2 < FG_BK / 2; k2++) {
-                if (k2 == FG_BK / 4 && have_next) {
-                    store_regs(buf ^ 1); // the other buffer was last read one step ago, behind a barrier
-                    if (steps_to_load > 0) issue_loads();
+                for (int j = 0; j < NT; j++) fb[0][j] = Bs[buf][kh][(wn * NT + j) * 32 + l31];
+#pragma unroll
+                for (int k2 = 0; k2 < FG_BK / 2; k2++) {
+                    if (k2 == FG_BK / 4) {
+                        store_regs(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
+                        issue_loads(rs);
+                    }
+                    if (k2 + 1 < FG_BK / 2) {
+#pragma unroll
+                        for (int i = 0; i < MT; i++) fa[(k2 + 1) & 1][i] = As[buf][(k2 + 1) * 2 + kh][(wm * MT + i) * 32 + l31];
+#pragma unroll
+                        for (int j = 0; j < NT; j++) fb[(k2 + 1) & 1][j] = Bs[buf][(k2 + 1) * 2 + kh][(wn * NT + j) * 32 + l31];
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
+#pragma unroll
+                    for (int i = 0; i < MT; i++)
+#pragma unroll
+                        for (int j = 0; j < NT; j++)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][i], fb[k2 & 1][j], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                if (k2 + 1 < FG_BK / 2) {
-#pragma unroll
-                    for (int i = 0; i < MT; i++) fa[(k2 + 1) & 1][i] = As[buf][(k2 + 1) * 2 + kh][(wm * MT + i) * 32 + l31];
-#pragma unroll
-                    for (int j = 0; j < NT; j++) fb[(k2 + 1) & 1][j] = Bs[buf][(k2 + 1) * 2 + kh][(wn * NT + j) * 32 + l31];
-                }
-                __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
-#pragma unroll
-                for (int i = 0; i < MT; i++)
-#pragma unroll
-                    for (int j = 0; j < NT; j++)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][i], fb[k2 & 1][j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
+                buf ^= 1;
+                --steps_left;
             }
-            lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
-            buf ^= 1;
-            --steps_left;
         }
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
         const long m0 = ((long)blockIdx.x + t * gridDim.x) * FG_BM;
@@ -339,7 +362,7 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
     const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
                          (SRC != 1 || (uintptr_t)a.da % 16 == 0) &&
                          (SRC != 2 || ((uintptr_t)a.gout % 16 == 0 && (uintptr_t)a.argmax % 16 == 0));
-    if (!aligned || a.cin % FG_BK != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
+    if (!aligned || a.cin % (2 * FG_BK) != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
     const long ntiles = a.rows / FG_BM;
     long gx;
     if (a.cout % 128 == 0) {

@@ -1,0 +1,37 @@
+// mlp_types.h -- device-side descriptors shared by the grouped-point MLP kernels (mlp*.hip).
+#pragma once
+#include "common.h"
+
+namespace votenet {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// The implicit input matrix of a layer (mirror of struct votenet_mlp_input, include/votenet_hip.h)
+struct MlpIn {
+    // DENSE
+    const float *x;
+    const float *in_scale;
+    const float *in_shift;
+    int in_relu;
+    // GATHER
+    const float *xyz;
+    const float *new_xyz;
+    const float *feat;
+    const int *idx;
+    int n, m, nsample, c;
+};
+
+// How a backward GEMM obtains its dz operand (rows x cout):
+//   da == gout == NULL: dz read from memory;
+//   da   : dz = A*g + B + C*z with g = da masked by [z*S+H > 0]                    (BatchNorm backward folded in)
+//   gout : the same with g = gout[row/k] where row%k == argmax[row/k]              (max-pooled upstream)
+// coef = [A|B|C|S|H], 5*cout floats (votenet_bn_backward_coef)
+struct BnSrc {
+    const float *da, *gout;
+    const int *argmax;
+    int pool_k, pool_shift; // pool_shift = log2(pool_k) when pool_k is a power of two, else -1
+    const float *z, *coef;
+    int relu;
+};
+
+} // namespace votenet

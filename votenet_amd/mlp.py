@@ -170,7 +170,7 @@ def bn_backward_coef(rows, scale, shift, mean, var, gamma, sums, dgamma, dbeta, 
 
 def dgrad_bn_supported(rows, c, cout):
     """Shapes the fused BatchNorm-backward dgrad kernel serves (see include/votenet_hip.h)."""
-    return rows > 0 and rows % 128 == 0 and c % 16 == 0 and c <= 512 and (cout == 64 or cout % 128 == 0)
+    return rows > 0 and rows % 128 == 0 and c % 32 == 0 and c <= 512 and (cout == 64 or cout % 128 == 0)
 
 
 def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, in_scale=None, in_shift=None, in_relu=True):
