@@ -707,6 +707,11 @@ static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const flo
         hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
 }
 
+namespace votenet {
+bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
+                       hipStream_t st); // mlp_wgrad_fast.hip
+}
+
 static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc,
                        float *dw, void *stream)
 {
@@ -718,6 +723,7 @@ static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout
     hipStream_t st = as_stream(stream);
     if (in->x) {
         VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_wgrad: in_scale and in_shift go together");
+        if (wgrad_fast_launch(0, d, rows, cin, cout, dz, bs, bsrc, dw, st)) return check_launch("mlp_wgrad");
         if (bsrc == 0) launch_wgrad<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
         else if (bsrc == 1) launch_wgrad<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
         else launch_wgrad<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
@@ -733,7 +739,8 @@ static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout
             rpb = (rpb + 255) / 256 * 256;
             hipLaunchKernelGGL(wgrad_narrow_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, d, rows, nch, cout, dz,
                                dw, rpb);
-            if (d.c > 5) launch_wgrad<1, 0>(d, rows, d.c, cout, dz, bs, dw, st); // internal k < c are the feature channels
+            if (d.c > 5 && !wgrad_fast_launch(1, d, rows, d.c, cout, dz, bs, 0, dw, st))
+                launch_wgrad<1, 0>(d, rows, d.c, cout, dz, bs, dw, st); // internal k < c are the feature channels
         } else {
             if (bsrc == 0) launch_wgrad<1, 0>(d, rows, cin, cout, dz, bs, dw, st);
             else if (bsrc == 1) launch_wgrad<1, 1>(d, rows, cin, cout, dz, bs, dw, st);

@@ -1,0 +1,277 @@
+// mlp_wgrad_fast.hip -- lean weight-gradient GEMM  dW (cin x cout) += X^T * dZ  for the aligned shapes every wide
+// VoteNet layer has (gfx950).  Same contract as mlp_wgrad_kernel (mlp_bwd.hip), which keeps serving the ragged shapes:
+//   cin % (64*TI) == 0, cout % (64*TJ) == 0, 16-byte aligned operands; GATHER input: the feature block only
+//   (X = feat[scene, idx[row], :], dW rows offset by 3 -- the xyz columns go through wgrad_narrow_kernel).
+// What the lean form buys, as in mlp_fast.hip:
+//   * the loop body has NO memory operation under a branch (rows past the end re-read the last row and are zeroed on
+//     the dZ side when the slab is written to LDS), so the compiler's s_waitcnt bookkeeping stays exact;
+//   * two register sets hold the raw quads of the next two 16-row slabs: half way through a slab's MFMAs the older set
+//     is written to the other LDS buffer (folded BN+ReLU of the layer below on X; BatchNorm backward rebuilt from
+//     (da | pooled gout, z, coef) on dZ -- struct BnSrc) and refilled with the slab three steps ahead.  Loads lead by
+//     two slabs of matrix work; one slab is shorter than the loaded HBM latency;
+//   * GATHER: the idx of a slab is loaded one refill BEFORE the feature rows that need it, and ahead of that refill's
+//     other loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.
+// LDS images are the natural [row][channel] slabs; lane l reads As[k2*2 + (l>>5)][i0 + (l&31)]: conflict-free.
+#include "mlp_types.h"
+
+namespace votenet {
+
+constexpr int WF_BR = 16; // rows per slab (the MFMA contraction index)
+
+template <int MODE, int TI, int TJ, int BSRC>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_wgrad_fast_kernel(
+    MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz, BnSrc bs, float *__restrict__ dw, long rows_per_block)
+{
+    constexpr int BI = 64 * TI, BJ = 64 * TJ;
+    constexpr int QA = BI / 4, QB = BJ / 4;                       // float4 per slab row
+    constexpr int NA = WF_BR * QA / 256, NB = WF_BR * QB / 256;   // float4 per thread per slab (1 or 2)
+    constexpr int RA = 256 / QA, RB = 256 / QB;                   // slab rows covered by one pass of the 256 threads
+    __shared__ float As[2][WF_BR][BI + 4];
+    __shared__ float Bs[2][WF_BR][BJ + 4];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int i0 = blockIdx.y * BI, j0 = blockIdx.z * BJ;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    if (r_begin >= rows) return;
+    const int nrow = (int)((r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows) - r_begin);
+    const int nslab = (nrow + WF_BR - 1) / WF_BR;
+    const int a_row = tid / QA, a_q = tid % QA;
+    const int b_row = tid / QB, b_q = tid % QB;
+    const int ka = i0 + a_q * 4; // this thread's X channels
+    const int nb = j0 + b_q * 4; // this thread's dZ channels
+    const int xc = (MODE == 0) ? cin : in.c;
+
+    // per-thread channel constants in registers
+    const bool affine = (MODE == 0) && in.in_scale != nullptr;
+    float4 csc = make_float4(1.f, 1.f, 1.f, 1.f), csh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (affine) {
+        csc = *reinterpret_cast<const float4 *>(in.in_scale + ka);
+        csh = *reinterpret_cast<const float4 *>(in.in_shift + ka);
+    }
+    const float x_floor = (affine && in.in_relu) ? 0.0f : -__builtin_inff(); // ReLU as a floor: branch-free
+    float4 kA, kB, kC, kS, kH;
+    kA = kB = kC = kS = kH = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (BSRC != 0) {
+        kA = *reinterpret_cast<const float4 *>(bs.coef + nb);
+        kB = *reinterpret_cast<const float4 *>(bs.coef + cout + nb);
+        kC = *reinterpret_cast<const float4 *>(bs.coef + 2 * cout + nb);
+        kS = *reinterpret_cast<const float4 *>(bs.coef + 3 * cout + nb);
+        kH = *reinterpret_cast<const float4 *>(bs.coef + 4 * cout + nb);
+    }
+    // wave-uniform bases at the workgroup's first row; threads carry 32-bit element offsets (checked by the launcher)
+    const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : in.feat + ka;
+    const float *zb = (BSRC == 0 ? dz : bs.z) + (size_t)r_begin * cout + nb;
+    const float *gb = (BSRC == 1) ? bs.da + (size_t)r_begin * cout + nb : nullptr;
+    const int *idxb = (MODE == 1) ? in.idx + r_begin : nullptr;
+    const unsigned grows = (MODE == 1) ? (unsigned)in.m * (unsigned)in.nsample : 1u; // rows per scene
+
+    struct Regs {
+        float4 a[NA], b[NB], g[NB];
+        int4 m[NB];
+        int s; // slab index (local)
+    };
+    Regs R[2];
+    int pidx[NA]; // GATHER: feat row (scene*n + idx) of this thread's rows of the slab loaded by the NEXT refill
+    auto clampr = [&](int lr) { return lr < nrow ? lr : nrow - 1; };
+    auto load_idx = [&](int s) {
+        if (MODE == 1) {
+#pragma unroll
+            for (int h = 0; h < NA; h++) {
+                const int lr = clampr(s * WF_BR + a_row + h * RA);
+                pidx[h] = idxb[lr];
+            }
+        }
+    };
+    auto load_slab = [&](Regs &r, int s, const int (&pi)[NA]) {
+        r.s = s;
+#pragma unroll
+        for (int h = 0; h < NA; h++) {
+            const int lr = clampr(s * WF_BR + a_row + h * RA);
+            if (MODE == 0) {
+                r.a[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * (unsigned)cin));
+            } else {
+                const unsigned scene = (unsigned)(r_begin + lr) / grows;
+                r.a[h] = *reinterpret_cast<const float4 *>(xb + ((size_t)scene * in.n + pi[h]) * xc);
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < NB; h++) {
+            const int lr = clampr(s * WF_BR + b_row + h * RB);
+            const unsigned off = (unsigned)lr * (unsigned)cout;
+            r.b[h] = *reinterpret_cast<const float4 *>(zb + (size_t)off);
+            if (BSRC == 1) r.g[h] = *reinterpret_cast<const float4 *>(gb + (size_t)off);
+            if (BSRC == 2) {
+                const unsigned gr = (unsigned)(r_begin + lr);
+                const unsigned grp = bs.pool_shift >= 0 ? gr >> bs.pool_shift : gr / (unsigned)bs.pool_k;
+                r.g[h] = *reinterpret_cast<const float4 *>(bs.gout + (size_t)grp * cout + nb);
+                r.m[h] = *reinterpret_cast<const int4 *>(bs.argmax + (size_t)grp * cout + nb);
+            }
+        }
+    };
+    auto store_slab = [&](int buf, const Regs &r) {
+#pragma unroll
+        for (int h = 0; h < NA; h++) {
+            float4 v = r.a[h];
+            v.x = fmaxf(v.x * csc.x + csh.x, x_floor);
+            v.y = fmaxf(v.y * csc.y + csh.y, x_floor);
+            v.z = fmaxf(v.z * csc.z + csh.z, x_floor);
+            v.w = fmaxf(v.w * csc.w + csh.w, x_floor);
+            *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = v;
+        }
+#pragma unroll
+        for (int h = 0; h < NB; h++) {
+            const int lr = r.s * WF_BR + b_row + h * RB;
+            float4 v = r.b[h];
+            if (BSRC != 0) {
+                float4 g = r.g[h];
+                if (BSRC == 2) {
+                    const unsigned gr = (unsigned)(r_begin + lr);
+                    const int ro = bs.pool_shift >= 0 ? (int)(gr & (unsigned)(bs.pool_k - 1)) : (int)(gr % (unsigned)bs.pool_k);
+                    g.x = (r.m[h].x == ro) ? g.x : 0.0f;
+                    g.y = (r.m[h].y == ro) ? g.y : 0.0f;
+                    g.z = (r.m[h].z == ro) ? g.z : 0.0f;
+                    g.w = (r.m[h].w == ro) ? g.w : 0.0f;
+                }
+                if (bs.relu) {
+                    if (!(v.x * kS.x + kH.x > 0.0f)) g.x = 0.0f;
+                    if (!(v.y * kS.y + kH.y > 0.0f)) g.y = 0.0f;
+                    if (!(v.z * kS.z + kH.z > 0.0f)) g.z = 0.0f;
+                    if (!(v.w * kS.w + kH.w > 0.0f)) g.w = 0.0f;
+                }
+                v.x = kA.x * g.x + kB.x + kC.x * v.x;
+                v.y = kA.y * g.y + kB.y + kC.y * v.y;
+                v.z = kA.z * g.z + kB.z + kC.z * v.z;
+                v.w = kA.w * g.w + kB.w + kC.w * v.w;
+            }
+            if (lr >= nrow) v = make_float4(0.f, 0.f, 0.f, 0.f); // padding rows contribute nothing
+            *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = v;
+        }
+    };
+
+    f32x16 acc[TI][TJ];
+#pragma unroll
+    for (int a = 0; a < TI; a++)
+#pragma unroll
+        for (int b = 0; b < TJ; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
+
+    // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in sets 1 and 0; idx of slab 3 in pidx.
+    // Slab numbers past the end are clamped row by row (they re-read the last row and are stored as zeros).
+    int pcur[NA];
+    load_idx(0);
+#pragma unroll
+    for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
+    load_idx(1);
+    load_slab(R[0], 0, pcur);
+    store_slab(0, R[0]);
+#pragma unroll
+    for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
+    load_idx(2);
+    load_slab(R[1], 1, pcur);
+    __builtin_amdgcn_sched_barrier(0); // same issue order as in the loop: idx, set 1, idx, set 0
+#pragma unroll
+    for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
+    load_idx(3);
+    load_slab(R[0], 2, pcur);
+    __syncthreads();
+
+    int buf = 0;
+    const int kh = lane >> 5, l31 = lane & 31;
+    const int nslab2 = (nslab + 1) & ~1; // the loop runs slab pairs; a padding slab multiplies zeros
+    for (int s = 0; s < nslab2; s += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            Regs &rs = R[par ^ 1]; // holds slab s+par+1
+            float fa[2][TI], fb[2][TJ]; // register double-buffered fragments: reads of k2+1 issued before MFMAs of k2
+#pragma unroll
+            for (int t = 0; t < TI; t++) fa[0][t] = As[buf][kh][(wi * TI + t) * 32 + l31];
+#pragma unroll
+            for (int t = 0; t < TJ; t++) fb[0][t] = Bs[buf][kh][(wj * TJ + t) * 32 + l31];
+#pragma unroll
+            for (int k2 = 0; k2 < WF_BR / 2; k2++) {
+                if (k2 == WF_BR / 4) {
+                    store_slab(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
+#pragma unroll
+                    for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
+                    load_idx(s + par + 4);           // idx first: it must be OLDER than the loads that follow
+                    load_slab(rs, s + par + 3, pcur); // refill with the slab three steps ahead
+                }
+                if (k2 + 1 < WF_BR / 2) {
+#pragma unroll
+                    for (int t = 0; t < TI; t++) fa[(k2 + 1) & 1][t] = As[buf][(k2 + 1) * 2 + kh][(wi * TI + t) * 32 + l31];
+#pragma unroll
+                    for (int t = 0; t < TJ; t++) fb[(k2 + 1) & 1][t] = Bs[buf][(k2 + 1) * 2 + kh][(wj * TJ + t) * 32 + l31];
+                }
+                __builtin_amdgcn_sched_barrier(0); // keep the reads of k2+1 ahead of the MFMAs of k2
+#pragma unroll
+                for (int a = 0; a < TI; a++)
+#pragma unroll
+                    for (int b = 0; b < TJ; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[k2 & 1][a], fb[k2 & 1][b], acc[a][b], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
+            buf ^= 1;
+        }
+    }
+    // epilogue: atomically add the partial tile.  C/D: col = lane&31, row = (e&3)+8*(e>>2)+4*(lane>>5)
+    const int wrow0 = (MODE == 1) ? 3 : 0;
+#pragma unroll
+    for (int a = 0; a < TI; a++)
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+            const int j = j0 + (wj * TJ + b) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = i0 + (wi * TI + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                unsafeAtomicAdd(&dw[(size_t)(wrow0 + i) * cout + j], acc[a][b][e]);
+            }
+        }
+}
+
+template <int MODE, int BSRC>
+static bool launch(const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, float *dw, hipStream_t st)
+{
+    const int TIr = cin % 128 == 0 ? 2 : 1, TJr = cout % 128 == 0 ? 2 : 1;
+    const int ti = cin / (64 * TIr), tj = cout / (64 * TJr);
+    long splits = 768 / (ti * tj);
+    if (splits < 1) splits = 1;
+    long rpb = (rows + splits - 1) / splits;
+    rpb = (rpb + 2 * WF_BR - 1) / (2 * WF_BR) * (2 * WF_BR);
+    if (rpb < 8 * WF_BR) rpb = 8 * WF_BR; // short row ranges are dominated by the atomic flush of the dW tile (measured)
+    const int wide = cin > cout ? cin : cout;
+    if (rpb * wide >= (1L << 31)) return false; // 32-bit element offsets inside a workgroup's row range
+    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
+    if (TIr == 2 && TJr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    else if (TIr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    else if (TJr == 2)
+        hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    else
+        hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    return true;
+}
+
+// Takes the launch when the shape fits; mode 1: cin = the feature channels of the GATHER input (d.c).
+bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
+                       hipStream_t st)
+{
+    if (cin % 64 != 0 || cout % 64 != 0 || rows <= 0 || rows >= (1L << 31)) return false;
+    auto al = [](const void *p) { return ((uintptr_t)p % 16) == 0; };
+    if (!al(dw) || (bsrc == 0 && !al(dz)) || (bsrc != 0 && (!al(bs.z) || !al(bs.coef))) || (bsrc == 1 && !al(bs.da)) ||
+        (bsrc == 2 && (!al(bs.gout) || !al(bs.argmax))))
+        return false;
+    if (mode == 0) {
+        if (!al(d.x) || (d.in_scale && (!al(d.in_scale) || !al(d.in_shift)))) return false;
+        if (bsrc == 0) return launch<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
+        if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
+        return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
+    }
+    if (d.c != cin || !al(d.feat) || bsrc != 0) return false;
+    return launch<1, 0>(d, rows, cin, cout, dz, bs, dw, st);
+}
+
+} // namespace votenet
