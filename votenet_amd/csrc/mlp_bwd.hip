@@ -50,6 +50,64 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_kernel(long rows, int
     }
 }
 
+// The same reduction for c % 4 == 0 (c <= 1024), 16-byte accesses: thread = one channel quad, QC = c/4 threads per row,
+// 256/QC rows per pass, four passes in flight per loop trip.  Partial sums meet in LDS, one fp64 atomic per channel,
+// statistic and workgroup.
+__global__ __launch_bounds__(256) void bn_bwd_reduce_dense_vec_kernel(long rows, int c, const float *__restrict__ da,
+                                                                      const float *__restrict__ z, const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                      const float *__restrict__ var, float eps, int relu,
+                                                                      double *__restrict__ sums)
+{
+    __shared__ float red[2][256][4];
+    const int qc = c >> 2;             // quads per row (a divisor of 256, checked by the launcher)
+    const int rpp = 256 / qc;          // rows per pass
+    const int q = threadIdx.x % qc, rl = threadIdx.x / qc;
+    const float4 sc = *reinterpret_cast<const float4 *>(scale + 4 * q), sf = *reinterpret_cast<const float4 *>(shift + 4 * q);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + 4 * q), vr = *reinterpret_cast<const float4 *>(var + 4 * q);
+    const float4 inv = make_float4(1.0f / sqrtf(vr.x + eps), 1.0f / sqrtf(vr.y + eps), 1.0f / sqrtf(vr.z + eps), 1.0f / sqrtf(vr.w + eps));
+    const float thr = relu ? 0.0f : -__builtin_inff(); // no ReLU: every element passes
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    auto acc = [&](const float4 &zz, float4 g) {
+        if (!(zz.x * sc.x + sf.x > thr)) g.x = 0.0f;
+        if (!(zz.y * sc.y + sf.y > thr)) g.y = 0.0f;
+        if (!(zz.z * sc.z + sf.z > thr)) g.z = 0.0f;
+        if (!(zz.w * sc.w + sf.w > thr)) g.w = 0.0f;
+        s1.x += g.x;
+        s1.y += g.y;
+        s1.z += g.z;
+        s1.w += g.w;
+        s2.x += g.x * ((zz.x - mu.x) * inv.x);
+        s2.y += g.y * ((zz.y - mu.y) * inv.y);
+        s2.z += g.z * ((zz.z - mu.z) * inv.z);
+        s2.w += g.w * ((zz.w - mu.w) * inv.w);
+    };
+    const long stride = (long)gridDim.x * rpp;
+    long r = (long)blockIdx.x * rpp + rl;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+        float4 zz[4], gg[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            zz[u] = *reinterpret_cast<const float4 *>(z + (size_t)(r + u * stride) * c + 4 * q);
+            gg[u] = *reinterpret_cast<const float4 *>(da + (size_t)(r + u * stride) * c + 4 * q);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) acc(zz[u], gg[u]);
+    }
+    for (; r < rows; r += stride)
+        acc(*reinterpret_cast<const float4 *>(z + (size_t)r * c + 4 * q), *reinterpret_cast<const float4 *>(da + (size_t)r * c + 4 * q));
+    *reinterpret_cast<float4 *>(&red[0][threadIdx.x][0]) = s1;
+    *reinterpret_cast<float4 *>(&red[1][threadIdx.x][0]) = s2;
+    __syncthreads();
+    // thread t < 2*c: statistic t / c, channel t % c; sum over the rpp row-lanes
+    for (int t = threadIdx.x; t < 2 * c; t += 256) {
+        const int which = t / c, ch = t % c;
+        float v = 0.0f;
+        for (int i = 0; i < rpp; i++) v += red[which][i * qc + (ch >> 2)][ch & 3];
+        unsafeAtomicAdd(&sums[which * c + ch], (double)v);
+    }
+}
+
 // max-pool mode: da'[g*k+argmax[g,col], col] = gout[g,col] * [act > 0], zero elsewhere
 __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(long groups, int k, int c, const float *__restrict__ gout,
                                                                  const int *__restrict__ argmax, const float *__restrict__ z,
@@ -590,6 +648,13 @@ extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *
         const long groups = rows / k;
         hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(grid_for(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, st, groups, k, c,
                            da, argmax, z, scale, shift, mean, var, eps, relu, sums);
+    } else if (c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0 && (uintptr_t)da % 16 == 0 && (uintptr_t)z % 16 == 0 &&
+               (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0 && (uintptr_t)mean % 16 == 0 && (uintptr_t)var % 16 == 0) {
+        const long rpp = 256 / (c / 4);
+        long gx = (rows + 32 * rpp - 1) / (32 * rpp); // >= 8 loop trips per workgroup: its 2*c atomics must amortise
+        if (gx > 2048) gx = 2048;
+        hipLaunchKernelGGL(bn_bwd_reduce_dense_vec_kernel, dim3((unsigned)gx), dim3(256), 0, st, rows, c, da, z, scale, shift, mean,
+                           var, eps, relu, sums);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_dense_kernel, dim3(grid_for(rows, 4, 2048 / ny + 1), ny), dim3(256), 0, st, rows, c, da,
                            z, scale, shift, mean, var, eps, relu, sums);
