@@ -412,6 +412,51 @@ __global__ void bn_relu_max_kernel(long groups, int k, int c, const float *__res
     }
 }
 
+// c % 4 == 0: one thread per (group, channel quad), 16-byte loads, eight rows in flight.  Same comparison order as above
+// (first maximum wins), so out / argmax are identical.
+__global__ __launch_bounds__(256) void bn_relu_max_vec_kernel(long groups, int k, int c, const float *__restrict__ z,
+                                                              const float *__restrict__ scale, const float *__restrict__ shift,
+                                                              int relu, float *__restrict__ out, int *__restrict__ argmax)
+{
+    const int qc = c >> 2;
+    const long total = groups * qc;
+    const float floor_v = relu ? 0.0f : -__builtin_inff();
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / qc;
+        const int q = (int)(e - g * qc);
+        const float4 sc = *reinterpret_cast<const float4 *>(scale + 4 * q), sh = *reinterpret_cast<const float4 *>(shift + 4 * q);
+        const float *__restrict__ p = z + (size_t)g * k * c + 4 * q;
+        float4 best = make_float4(0.f, 0.f, 0.f, 0.f);
+        int4 bi = make_int4(0, 0, 0, 0);
+        auto take = [&](const float4 &raw, int j) {
+            float4 v;
+            v.x = raw.x * sc.x + sh.x;
+            v.y = raw.y * sc.y + sh.y;
+            v.z = raw.z * sc.z + sh.z;
+            v.w = raw.w * sc.w + sh.w;
+            if (!(v.x > floor_v)) v.x = floor_v; // ReLU (NaN -> 0 like the scalar kernel); no ReLU: the floor is -inf
+            if (!(v.y > floor_v)) v.y = floor_v;
+            if (!(v.z > floor_v)) v.z = floor_v;
+            if (!(v.w > floor_v)) v.w = floor_v;
+            if (j == 0 || v.x > best.x) { best.x = v.x; bi.x = j; }
+            if (j == 0 || v.y > best.y) { best.y = v.y; bi.y = j; }
+            if (j == 0 || v.z > best.z) { best.z = v.z; bi.z = j; }
+            if (j == 0 || v.w > best.w) { best.w = v.w; bi.w = j; }
+        };
+        int j = 0;
+        for (; j + 8 <= k; j += 8) {
+            float4 r[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) r[u] = *reinterpret_cast<const float4 *>(p + (size_t)(j + u) * c);
+#pragma unroll
+            for (int u = 0; u < 8; u++) take(r[u], j + u);
+        }
+        for (; j < k; j++) take(*reinterpret_cast<const float4 *>(p + (size_t)j * c), j);
+        *reinterpret_cast<float4 *>(out + (size_t)g * c + 4 * q) = best;
+        if (argmax) *reinterpret_cast<int4 *>(argmax + (size_t)g * c + 4 * q) = bi;
+    }
+}
+
 __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, const float *__restrict__ scale,
                                const float *__restrict__ shift, int relu, float *__restrict__ y)
 {
@@ -522,8 +567,14 @@ extern "C" int votenet_bn_relu_max(long groups, int k, int c, const float *z, co
     VN_REQUIRE(groups >= 0 && k > 0 && c > 0, "bn_relu_max expects groups >= 0, k > 0, c > 0");
     if (groups == 0) return VOTENET_OK;
     VN_REQUIRE(z && scale && shift && out, "bn_relu_max: null buffer");
-    hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups, k, c, z,
-                       scale, shift, relu, out, argmax);
+    const bool vec = c % 4 == 0 && (uintptr_t)z % 16 == 0 && (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0 &&
+                     (uintptr_t)out % 16 == 0 && (uintptr_t)argmax % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(bn_relu_max_vec_kernel, dim3(grid_for(groups * (c / 4), 256)), dim3(256), 0, as_stream(stream), groups, k,
+                           c, z, scale, shift, relu, out, argmax);
+    else
+        hipLaunchKernelGGL(bn_relu_max_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups, k, c, z,
+                           scale, shift, relu, out, argmax);
     return check_launch("bn_relu_max");
 }
 

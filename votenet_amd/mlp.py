@@ -30,6 +30,38 @@ class _Timed:
             PROFILE_EVENTS.append((self.e0, self.e1, self.kind, self.flops))
 
 
+class _StatsArena:
+    """Zero-initialised fp64 accumulators (BatchNorm statistics, backward reductions) come out of one device buffer that
+    is cleared by ONE fill per pass instead of one torch.zeros launch per layer (about 45 tiny launches per train step).
+    The owner (VoteNetHotPath.forward / backward) calls arena_begin() on the stream the layers run on; without it every
+    request falls back to torch.zeros."""
+    buf = None
+    off = 0
+    active = False
+
+
+def arena_begin(device, ndoubles=1 << 16):
+    a = _StatsArena
+    if a.buf is None or a.buf.device != device or a.buf.numel() < ndoubles:
+        a.buf = torch.empty(ndoubles, dtype=torch.float64, device=device)
+    a.buf.zero_()
+    a.off = 0
+    a.active = True
+
+
+def arena_end():
+    _StatsArena.active = False
+
+
+def _zeros_f64(n, device):
+    a = _StatsArena
+    if a.active and a.buf.device == device and a.off + n <= a.buf.numel():
+        v = a.buf[a.off:a.off + n]
+        a.off += (n + 1) & ~1  # keep 16-byte alignment
+        return v
+    return torch.zeros(n, dtype=torch.float64, device=device)
+
+
 BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
 
 
@@ -65,7 +97,7 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
         raise L.InvalidArgumentError("mlp_linear: w has %d rows, input has %d channels" % (w.shape[0], cin))
     cout = w.shape[1]
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=x.device) if want_stats else None
+    stats = _zeros_f64(2 * cout, x.device) if want_stats else None
     d = _desc_dense(x, in_scale, in_shift, in_relu)
     with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
@@ -88,7 +120,7 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
         raise L.InvalidArgumentError("mlp_linear: w has %d rows, grouped input has %d channels" % (w.shape[0], cin))
     rows = b * m * k
     z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
-    stats = torch.zeros(2 * cout, dtype=torch.float64, device=xyz.device) if want_stats else None
+    stats = _zeros_f64(2 * cout, xyz.device) if want_stats else None
     d = _desc_gather(xyz, new_xyz, feat, idx)
     with torch.cuda.device(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
@@ -149,7 +181,7 @@ def bn_backward_apply(z, coef, relu, da, argmax=None, k=0):
 def bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax=None, k=0, eps=BN_EPS):
     """sums (2*c f64) = [sum g', sum g'*zhat] of a BatchNorm'ed layer (g' = ReLU / arg-max masked gradient)."""
     rows, c = z.shape
-    sums = torch.zeros(2 * c, dtype=torch.float64, device=z.device)
+    sums = _zeros_f64(2 * c, z.device)
     with torch.cuda.device(z.device):
         L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
                                                    L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
@@ -194,7 +226,7 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
     prelu = 0
     if below is not None:
         zp, ps, pb, pm, pv, prelu = below
-        sums = torch.zeros(2 * cout, dtype=torch.float64, device=z.device)
+        sums = _zeros_f64(2 * cout, z.device)
     with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.ptr(zp), L.ptr(ps), L.ptr(pb), L.ptr(pm),

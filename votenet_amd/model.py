@@ -118,9 +118,13 @@ class VoteNetHotPath:
         return p_xyz, p_out
 
     def forward(self, x, tape=None):
-        seeds_xyz, seeds_p = self.backbone(x, tape)
-        v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape)
-        p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
+        M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
+        try:
+            seeds_xyz, seeds_p = self.backbone(x, tape)
+            v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape)
+            p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
+        finally:
+            M.arena_end()
         return dict(seeds_xyz=seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
                     proposals_xyz=p_xyz, proposals_output=p_out)
 
@@ -171,6 +175,13 @@ class VoteNetHotPath:
 
     def backward(self, tape, cot):
         """Reverse sweep over the tape of forward(); parameter gradients accumulate into store.grad."""
+        M.arena_begin(self.device)  # one fill for all BatchNorm-backward reductions of the pass
+        try:
+            self._backward(tape, cot)
+        finally:
+            M.arena_end()
+
+    def _backward(self, tape, cot):
         recs = {i: r for i, r in enumerate(tape)}
         sa1, sa2, sa3, sa4, fp1, fp2, vote, prop = [recs[i] for i in range(8)]
         # proposal layer: gradients reach the vote features AND the vote xyz (grouped xyz, gathered centres)
