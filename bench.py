@@ -176,7 +176,7 @@ def main():
             tot_ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _) in gemm_events)
             tot_fl = sum(f for (_, _, _, f) in gemm_events)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            mfma = {"bound": "mfma", "kernel": "mlp_linear_kernel / mlp_wgrad_kernel (all %d GEMM launches of the first two timed steps, "
+            mfma = {"bound": "mfma", "kernel": "mlp_linear_fast_kernel / mlp_linear_kernel / mlp_wgrad_fast_kernel (all %d GEMM launches of the first two timed steps, "
                                                "fp32 in / fp32 accumulate)" % len(gemm_events),
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                     "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gflop_per_step": round(tot_fl / gemm_steps / 1e9, 1)}

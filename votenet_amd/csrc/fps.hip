@@ -593,7 +593,14 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
 }
 
 // the reference's own launcher name, C++ linkage, exact signature (tf_sampling.cpp:94)
+// The reference's scratch is TensorShape{32, n} whatever the batch (tf_sampling.cpp:115): the bucket path needs about
+// 1.1*n floats per scene, so larger batches go through in slices that fit 32*n floats (launches are stream-ordered).
 void farthestpointsamplingLauncher(int b, int n, int m, const float *inp, float *temp, int *out)
 {
-    votenet_farthest_point_sample(b, n, m, inp, temp, out, nullptr);
+    int chunk = b;
+    while (chunk > 1 && votenet_fps_temp_floats(chunk, n) > (size_t)32 * (size_t)n) chunk--;
+    for (int b0 = 0; b0 < b; b0 += chunk) {
+        const int nb = b - b0 < chunk ? b - b0 : chunk;
+        votenet_farthest_point_sample(nb, n, m, inp + (size_t)b0 * n * 3, temp, out + (size_t)b0 * m, nullptr);
+    }
 }
