@@ -77,6 +77,26 @@ def test_fps_full_size_properties(ops, dev):
         assert td[idx[s, j]] >= td.max() * (1 - 1e-5)
 
 
+def test_fps_reference_launcher_shim_large_batch(ops, dev, hiplib):
+    """tf_sampling.cpp:94,115: the reference calls farthestpointsamplingLauncher with a TensorShape{32,n} scratch whatever
+    the batch.  The exported shim (C++ linkage, the reference's exact signature) must give the op's result with exactly
+    that much scratch, also for a batch whose bucket tables would not fit at once."""
+    import ctypes
+    fn = getattr(hiplib, "_Z29farthestpointsamplingLauncheriiiPKfPfPi")
+    fn.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 3
+    fn.restype = None
+    for b, n, m in [(40, 5000, 64), (3, 700, 50), (33, 24577, 8)]:
+        xyz = T(np.random.default_rng(b + n).random((b, n, 3), dtype=np.float32) * 4, dev)
+        temp = torch.full((32, n), float("nan"), dtype=torch.float32, device=dev)
+        guard = torch.zeros(1024, dtype=torch.float32, device=dev)  # allocated right after: catches an overrun in practice
+        out = torch.full((b, m), -1, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        fn(b, n, m, xyz.data_ptr(), temp.data_ptr(), out.data_ptr())  # null stream, like the reference
+        torch.cuda.synchronize()
+        assert (out == ops.s.farthest_point_sample(m, xyz)).all(), (b, n, m)
+        assert (guard == 0).all()
+
+
 # ------------------------------------------------------------------ gather
 def test_gather_point_and_grad(ops, dev, O):
     rng = np.random.default_rng(3)
