@@ -25,6 +25,8 @@ PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
 class VoteNetHotPath:
     def __init__(self, device, seed=0, npoints=(2048, 1024, 512, 256)):
         self.device = device
+        self.overlap_wgrad = True  # weight gradients on a second stream, next to the input-gradient chain
+        self._wgrad_stream = None
         s = P.ParamStore(device)
         self.store = s
         n1, n2, n3, n4 = npoints
@@ -176,9 +178,15 @@ class VoteNetHotPath:
     def backward(self, tape, cot):
         """Reverse sweep over the tape of forward(); parameter gradients accumulate into store.grad."""
         M.arena_begin(self.device)  # one fill for all BatchNorm-backward reductions of the pass
+        if self.overlap_wgrad:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=self.device)
+            P.WGRAD_STREAM = self._wgrad_stream
         try:
             self._backward(tape, cot)
+            P.wgrad_join()  # the optimizer (and the next pass's arena fill) come after every weight gradient
         finally:
+            P.WGRAD_STREAM = None
             M.arena_end()
 
     def _backward(self, tape, cot):

@@ -130,6 +130,49 @@ def mlp_chain_forward(layers, rows, first, tape):
 FUSE_BN_REDUCE = False
 
 
+# Weight gradients hang off the backward chain (reduce -> coef -> dgrad -> reduce ...): nothing downstream needs them before
+# the optimizer.  When the owner sets WGRAD_STREAM (a second HIP stream) they are launched there, concurrently with the input
+# gradient of the same layer; wgrad_join() makes the current stream wait for them.  Tensors a side-stream kernel reads are
+# tagged with record_stream so the caching allocator does not hand their memory out early.
+WGRAD_STREAM = None
+_wgrad_pending = False
+
+
+class _OnWgradStream:
+    """Context: run the enclosed launches on WGRAD_STREAM after everything issued so far on the current stream."""
+
+    def __init__(self, *tensors):
+        self.tensors = [t for t in tensors if isinstance(t, torch.Tensor)]
+
+    def __enter__(self):
+        global _wgrad_pending
+        self.ctx = None
+        if WGRAD_STREAM is not None:
+            main = torch.cuda.current_stream()
+            ev = torch.cuda.Event()
+            ev.record(main)
+            WGRAD_STREAM.wait_event(ev)
+            for t in self.tensors:
+                t.record_stream(WGRAD_STREAM)
+            self.ctx = torch.cuda.stream(WGRAD_STREAM)
+            self.ctx.__enter__()
+            _wgrad_pending = True
+
+    def __exit__(self, *a):
+        if self.ctx is not None:
+            self.ctx.__exit__(*a)
+
+
+def wgrad_join():
+    """The current stream waits for every weight-gradient kernel launched on WGRAD_STREAM so far."""
+    global _wgrad_pending
+    if WGRAD_STREAM is not None and _wgrad_pending:
+        ev = torch.cuda.Event()
+        ev.record(WGRAD_STREAM)
+        torch.cuda.current_stream().wait_event(ev)
+        _wgrad_pending = False
+
+
 def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, need_xyz_grad=False):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
@@ -158,8 +201,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
                 # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
                 src = dict(gout=da, argmax=argmax, k=k) if pooled else dict(da=da)
-                M.wgrad_dense_bn(r["x"], z, coef, L.relu, L.gp("W"), in_scale=r["in_scale"], in_shift=r["in_shift"],
-                                 in_relu=r["in_relu"], **src)
+                with _OnWgradStream(r["x"], z, coef, da, argmax if pooled else None):
+                    M.wgrad_dense_bn(r["x"], z, coef, L.relu, L.gp("W"), in_scale=r["in_scale"], in_shift=r["in_shift"],
+                                     in_relu=r["in_relu"], **src)
                 if not want_da:
                     return None
                 below = None
@@ -172,10 +216,11 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
         else:
             dz = da
             M.bias_grad(dz, L.gp("b"))
-        if r["kind"] == "gather":
-            M.wgrad_gather(r["xyz"], r["new_xyz"], r["feat"], r["idx"], dz, L.gp("W"))
-        else:
-            M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
+        with _OnWgradStream(dz, r.get("x"), r.get("feat")):
+            if r["kind"] == "gather":
+                M.wgrad_gather(r["xyz"], r["new_xyz"], r["feat"], r["idx"], dz, L.gp("W"))
+            else:
+                M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
         if i == 0 and r["kind"] == "gather":
             d_rows_feat = d_rows_xyz = None
             if need_input_grad and r["feat"] is not None:
