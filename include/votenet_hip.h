@@ -48,7 +48,10 @@ const char *votenet_version(void);
 /* Replaces farthestpointsamplingLauncher (decl tf_sampling.cpp:94, def tf_sampling_g.cu:203-205,
  * kernel :105-170).  inp (b,n,3) -> out (b,m) int32.  temp: scratch of at least
  * votenet_fps_temp_floats(b,n) floats (the reference allocates 32*n, tf_sampling.cpp:115);
- * may be NULL when that function returns 0.  Requires m > 0 (tf_sampling.cpp:99).
+ * may be NULL when that function returns 0 (n <= 4096: the cloud lives in registers).  Above that the
+ * scratch holds a Morton permutation + bucket boxes (about 1.1*n floats per scene, n <= 24 576) and
+ * additionally the sorted points with their running distance (about 5.1*n floats per scene,
+ * n <= 262 144); beyond, the reference's running-distance rows.  Requires m > 0 (tf_sampling.cpp:99).
  * Bit-exact with the reference rule: start at 0, running distance 1e38, arg-max of
  * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
 int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);

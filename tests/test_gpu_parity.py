@@ -45,7 +45,8 @@ def test_fps_golden_cases(ops, dev, golden):
 
 @pytest.mark.parametrize("b,n,m", [(1, 1, 1), (2, 64, 64), (3, 511, 77), (2, 512, 128), (2, 513, 128), (1, 1024, 256),
                                    (2, 2048, 1024), (1, 2049, 100), (1, 4096, 512), (1, 8192, 300), (1, 12288, 200),
-                                   (1, 16384, 200), (2, 20480, 300), (1, 24576, 150), (1, 24577, 60), (1, 40000, 40)])
+                                   (1, 16384, 200), (2, 20480, 300), (1, 24576, 150), (1, 24577, 60), (1, 40000, 40), (2, 65536, 50),
+                                   (2, 80000, 120), (1, 140000, 30), (1, 262144, 12), (1, 262145, 6)])
 def test_fps_vs_oracle(ops, dev, O, b, n, m):
     xyz = np.random.default_rng(n * 7 + m).random((b, n, 3), dtype=np.float32) * 5
     got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
@@ -54,7 +55,7 @@ def test_fps_vs_oracle(ops, dev, O, b, n, m):
 
 def test_fps_exact_ties_vs_oracle(ops, dev, O):
     rng = np.random.default_rng(5)
-    for n, m in [(700, 300), (3000, 500), (20000, 200)]:
+    for n, m in [(700, 300), (3000, 500), (20000, 200), (70000, 150)]:
         xyz = np.round(rng.random((2, n, 3), dtype=np.float32) * 6) / 2  # coarse lattice: many equal distances, duplicates
         got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
         assert (got == O.farthest_point_sample(m, xyz)).all(), (n, m)

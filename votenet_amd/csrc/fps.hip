@@ -472,6 +472,150 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     }
 }
 
+// ------------------------------------------------------------------ exact bucket-pruned FPS, L2-resident points
+// 24 576 < n <= NW*64*64*NBL.  The same pruning as fps_bucket_kernel, but only the bucket METADATA lives in registers
+// (NBL buckets per lane: box, cached max / key / lane and the coordinates of that arg-max point); the Morton-sorted
+// points with their running distance are a float4 array in the caller's scratch (16 B per point, 1.3 MB for 80 000
+// points: resident in the XCD's L2).  A touched bucket costs one coalesced 1 KB read, a distance update and a 256 B
+// write-back of the changed running distances; the loads of up to FB touched buckets are issued together so their
+// L2 latency overlaps.  Bucket g is slot (g / NW) / 64 of lane (g / NW) % 64 of wave g % NW.
+// The reference scans all n points every round (tf_sampling_g.cu:130-147): 80 000 points -> a few hundred touched.
+template <int NW, int NBL>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, const float *__restrict__ xyz,
+                                                                const int *__restrict__ perm, const float *__restrict__ bbox,
+                                                                float4 *__restrict__ sorted, int *__restrict__ out)
+{
+    constexpr int FB = 4; // buckets fetched together
+    __shared__ unsigned s_ex[2 * 16 * 5];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    const int nb = (n + 63) / 64;
+    float4 *__restrict__ sp = sorted + (size_t)blockIdx.x * nb * 64;
+    int *__restrict__ o = out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id_uniform();
+
+    // sorted copy: (x, y, z, running distance); padding points of the last bucket can never win (distance 0)
+    for (int p = tid; p < nb * 64; p += NW * 64) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < n) {
+            const int k = pm[p];
+            v = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], 1e38f); // tf_sampling_g.cu:118
+        }
+        sp[p] = v;
+    }
+    // metadata of this lane's buckets
+    float bxl[NBL], byl[NBL], bzl[NBL], bxh[NBL], byh[NBL], bzh[NBL], wx[NBL], wy[NBL], wz[NBL];
+    unsigned bmax[NBL], bkey[NBL];
+    int blane[NBL];
+    bool hasb[NBL];
+#pragma unroll
+    for (int s = 0; s < NBL; s++) {
+        const int g = (s * 64 + lane) * NW + w;
+        hasb[s] = g < nb;
+        const float *__restrict__ bb = bbox + ((size_t)blockIdx.x * nb + (hasb[s] ? g : 0)) * 6;
+        bxl[s] = hasb[s] ? bb[0] : INFINITY;
+        byl[s] = hasb[s] ? bb[1] : INFINITY;
+        bzl[s] = hasb[s] ? bb[2] : INFINITY;
+        bxh[s] = hasb[s] ? bb[3] : -INFINITY;
+        byh[s] = hasb[s] ? bb[4] : -INFINITY;
+        bzh[s] = hasb[s] ? bb[5] : -INFINITY;
+        bmax[s] = hasb[s] ? fbits(1e38f) : 0u;
+        bkey[s] = 0xFFFFFFFFu;
+        blane[s] = 0;
+        wx[s] = wy[s] = wz[s] = 0.0f;
+    }
+    __syncthreads(); // the sorted copy (written by other waves) is read below: block-scope release / acquire
+    FpsOut fo = {o, m, 0};
+    fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
+    float cx = pts[0], cy = pts[1], cz = pts[2];
+    unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
+    float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+    for (int j = 1; j < m; j++) {
+        bool changed = false;
+#pragma unroll
+        for (int s = 0; s < NBL; s++) {
+            // (1) which buckets of slot s can change?  (see fps_bucket_kernel)
+            const float ex = fmaxf(fmaxf(bxl[s] - cx, cx - bxh[s]), 0.0f);
+            const float ey = fmaxf(fmaxf(byl[s] - cy, cy - byh[s]), 0.0f);
+            const float ez = fmaxf(fmaxf(bzl[s] - cz, cz - bzh[s]), 0.0f);
+            const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+            unsigned long long act = __ballot(hasb[s] && !(lb >= __uint_as_float(bmax[s])));
+            // (2) fetch up to FB touched buckets at once, then update them one by one
+            while (act) {
+                int li[FB];
+                float4 pv[FB];
+                int pk[FB];
+                int cnt = 0;
+#pragma unroll
+                for (int f = 0; f < FB; f++) {
+                    li[f] = -1;
+                    if (act) {
+                        li[f] = __ffsll((long long)act) - 1;
+                        act &= act - 1;
+                        const size_t base = (size_t)((s * 64 + li[f]) * NW + w) * 64 + lane;
+                        pv[f] = sp[base];
+                        pk[f] = (base < (size_t)n) ? pm[base] : -1;
+                        cnt = f + 1;
+                    }
+                }
+#pragma unroll
+                for (int f = 0; f < FB; f++) {
+                    if (f < cnt) {
+                        const int i = li[f];
+                        const float4 v = pv[f];
+                        const float dx = v.x - cx, dy = v.y - cy, dz = v.z - cz;
+                        const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
+                        const unsigned t0 = fbits(v.w);
+                        const unsigned d2 = min(fbits(d), t0);       // :143
+                        if (d2 != t0) sp[(size_t)((s * 64 + i) * NW + w) * 64 + lane].w = __uint_as_float(d2);
+                        const int ol = __builtin_amdgcn_readlane(blane[s], i);
+                        const unsigned omax = (unsigned)__builtin_amdgcn_readlane((int)bmax[s], i);
+                        if ((unsigned)__builtin_amdgcn_readlane((int)d2, ol) != omax) {
+                            const unsigned key = pk[f] >= 0 ? fps_tiekey((unsigned)pk[f]) : 0xFFFFFFFFu;
+                            unsigned nmax, nkey;
+                            const int nl = wave_argmax(d2, key, nmax, nkey);
+                            const float nx = readlane_f32(v.x, nl), ny = readlane_f32(v.y, nl), nz = readlane_f32(v.z, nl);
+                            if (lane == i) {
+                                bmax[s] = nmax;
+                                bkey[s] = nkey;
+                                blane[s] = nl;
+                                wx[s] = nx;
+                                wy[s] = ny;
+                                wz[s] = nz;
+                            }
+                            changed = true;
+                        }
+                    }
+                }
+            }
+        }
+        // (3) wave winner over the cached bucket entries; unchanged entries -> last round's winner is still valid
+        if (changed || j == 1) {
+            unsigned lm = bmax[0], lk = bkey[0];
+            float lx = wx[0], ly = wy[0], lz = wz[0];
+#pragma unroll
+            for (int s = 1; s < NBL; s++) {
+                const bool better = bmax[s] > lm || (bmax[s] == lm && bkey[s] < lk);
+                lm = better ? bmax[s] : lm;
+                lk = better ? bkey[s] : lk;
+                lx = better ? wx[s] : lx;
+                ly = better ? wy[s] : ly;
+                lz = better ? wz[s] : lz;
+            }
+            const int wl = wave_argmax(lm, lk, cw_max, cw_key);
+            cw_x = readlane_f32(lx, wl);
+            cw_y = readlane_f32(ly, wl);
+            cw_z = readlane_f32(lz, wl);
+        }
+        const FpsWinner win = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j);
+        cx = win.x;
+        cy = win.y;
+        cz = win.z;
+        fo.put(j, (int)win.k, tid);
+    }
+}
+
 // ------------------------------------------------------------------ streaming fallback (n > 24576)
 template <int NW>
 __global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m, const float *__restrict__ xyz,
@@ -525,6 +669,7 @@ __global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m
 
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
+static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)
 
 } // namespace votenet
 
@@ -534,6 +679,7 @@ extern "C" size_t votenet_fps_temp_floats(int b, int n)
 {
     if (n <= kFpsRegMax) return 0;
     if (n <= kFpsBucketMax) return (size_t)b * ((size_t)n + 6 * (size_t)((n + 63) / 64)); // Morton permutation + bucket boxes
+    if (n <= kFpsL2Max) return (size_t)b * ((size_t)n + 6 * (size_t)((n + 63) / 64) + 4 * 64 * (size_t)((n + 63) / 64) + 4); // + sorted float4
     return (size_t)(b < 32 ? b : 32) * (size_t)n;                                          // running distances, tf_sampling.cpp:115
 }
 
@@ -585,6 +731,18 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
         } else {
             FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
         }
+    } else if (n <= kFpsL2Max) {
+        const int nb = (n + 63) / 64;
+        float *boxes = temp + (size_t)b * n;
+        // 16-byte aligned float4 area behind the permutation and the boxes
+        float4 *sorted = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(boxes + (size_t)b * nb * 6) + 15) & ~(uintptr_t)15);
+        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(b), dim3(1024), 0, st, n, inp, (int *)temp, boxes);
+        if (nb <= 16 * 64)
+            hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 1>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
+        else if (nb <= 16 * 64 * 2)
+            hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 2>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
+        else
+            hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 4>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
     } else {
         const int grid = b < 32 ? b : 32; // tf_sampling_g.cu:204
         hipLaunchKernelGGL((fps_stream_kernel<16>), dim3(grid), dim3(1024), 0, st, b, n, m, inp, temp, out);
