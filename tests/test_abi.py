@@ -82,7 +82,7 @@ def test_workspace_queries(hiplib):
     assert hiplib.votenet_fps_temp_floats(8, 20480) == 8 * (20480 + 6 * 320)    # Morton permutation + bucket boxes
     assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * (80000 + 6 * 1250 + 256 * 1250 + 4)  # + sorted float4 points (L2)
     assert hiplib.votenet_fps_temp_floats(4, 300000) == 4 * 300000              # unpruned streaming fallback
-    assert hiplib.votenet_fps_temp_floats(64, 80000) == 32 * 80000
+    assert hiplib.votenet_fps_temp_floats(64, 300000) == 32 * 300000            # tf_sampling.cpp:115: 32 rows whatever the batch
     assert hiplib.votenet_nms3d_workspace_bytes(8, 256) >= 8 * 256 * 256 * 4
 
 
