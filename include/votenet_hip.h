@@ -169,6 +169,18 @@ int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int cin, int cout
 int votenet_bn_finalize(long rows, int c, const double *stats, const float *gamma, const float *beta, float eps,
                         float *scale, float *shift, float *mean, float *var, void *stream);
 
+/* First SA layer with the linear map applied before the grouping (a gather commutes with a per-point
+ * linear map): with P (b*n x cout) = feat . W[3:] from votenet_mlp_linear over the b*n points,
+ *   z[b,j,k,:] = P[b, idx[b,j,k], :] + (xyz[b,idx[b,j,k]] - new_xyz[b,j]) . w_xyz + bias
+ * is the layer output over the b*m*nsample grouped rows (the conv2d of utils.py:125-127 over the
+ * sample_and_group concat, utils.py:50-57) -- nsample-times fewer multiply-adds than the grouped GEMM.
+ * w_xyz (3 x cout) = W[0:3].  stats as for votenet_mlp_linear (may be NULL).  cout: a power of two
+ * in [4, 1024].  The summation order differs from the fused GATHER GEMM (xyz terms last): results
+ * agree to fp32 rounding, not bit for bit. */
+int votenet_group_linear(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                         const int *idx, const float *P, const float *w_xyz, const float *bias, float *z,
+                         double *stats /* 2*cout, pre-zeroed, may be NULL */, void *stream);
+
 /* out (groups x c) = max over the k rows of each group of max(0?, z*scale+shift);
  * argmax (groups x c, int32 row offset inside the group, may be NULL) for the backward pass. */
 int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *scale, const float *shift,

@@ -76,6 +76,43 @@ def test_linear_gather_vs_oracle(hiplib, dev, O, b, n, m, k, c, cout):
     assert np.allclose(N(st)[:cout], oz.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
 
 
+@pytest.mark.parametrize("b,n,m,k,c,cout", [(2, 300, 20, 16, 3, 64), (1, 500, 33, 64, 128, 128), (2, 256, 16, 64, 256, 128),
+                                            (3, 97, 5, 7, 8, 32), (1, 64, 3, 5, 16, 4)])
+def test_group_linear_vs_oracle(hiplib, dev, O, b, n, m, k, c, cout):
+    """First SA layer with the linear map applied before the grouping (votenet_group_linear): P = feat W[3:] per point, then
+    z = P[idx] + dxyz W[0:3] + bias per grouped row -- against the oracle's convolution over the sample_and_group concat
+    (utils.py:50-57,125-127), to fp32 rounding (1e-5 of the term bound), and against the fused GATHER GEMM."""
+    from votenet_amd import mlp
+    rng = np.random.default_rng(n + c + cout)
+    xyz = rng.random((b, n, 3), dtype=np.float32)
+    new_xyz = rng.random((b, m, 3), dtype=np.float32)
+    feat = rng.normal(size=(b, n, c)).astype(np.float32)
+    idx = rng.integers(0, n, (b, m, k)).astype(np.int32)
+    w = (rng.normal(size=(3 + c, cout)) * 0.3).astype(np.float32)
+    bias = rng.normal(size=cout).astype(np.float32)
+    x = O.group_concat(xyz, new_xyz, feat, idx).reshape(b * m * k, 3 + c)
+    oz = O.linear(x, w, bias)
+    wd = T(w, dev)
+    P, _ = mlp.linear_dense(T(feat.reshape(b * n, c), dev), wd[3:], want_stats=False)
+    z, st = mlp.group_linear(T(xyz, dev), T(new_xyz, dev), T(idx, dev), P, wd[:3], T(bias, dev))
+    bound = (np.abs(x) @ np.abs(w)).max()
+    assert close(N(z), oz, bound)
+    assert np.allclose(N(st)[:cout], oz.astype(np.float64).sum(0), rtol=1e-5, atol=1e-3)
+    assert np.allclose(N(st)[cout:], (oz.astype(np.float64) ** 2).sum(0), rtol=1e-5, atol=1e-3)
+    zg, _ = mlp.linear_gather(T(xyz, dev), T(new_xyz, dev), T(feat, dev), T(idx, dev), wd, T(bias, dev))
+    assert close(N(z), N(zg), bound)
+    z2, none = mlp.group_linear(T(xyz, dev), T(new_xyz, dev), T(idx, dev), P, wd[:3], None, want_stats=False)
+    assert none is None and close(N(z2) + bias, N(z), bound)
+
+
+def test_group_linear_argument_errors(hiplib, dev):
+    from votenet_amd import mlp, _lib
+    xyz = torch.rand(1, 10, 3, device=dev)
+    idx = torch.zeros(1, 2, 4, dtype=torch.int32, device=dev)
+    with pytest.raises(_lib.InvalidArgumentError):  # cout must be a power of two in [4, 1024]
+        mlp.group_linear(xyz, xyz[:, :2].contiguous(), idx, torch.zeros(10, 12, device=dev), torch.zeros(3, 12, device=dev))
+
+
 def test_sa_mlp_stack_cfg1(hiplib, dev, O):
     """BASELINE config 1 end to end: 2048 pts -> FPS 512 -> ball r=0.2 K=32 -> MLP 64,64,128 (BNReLU) -> max over K."""
     import cases

@@ -128,6 +128,20 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     return z, stats
 
 
+def group_linear(xyz, new_xyz, idx, P, w_xyz, bias=None, want_stats=True):
+    """z (b*m*k, cout) = P[b, idx] + (xyz[idx] - new_xyz) @ w_xyz + bias with P (b, n, cout) = feat @ W[3:] computed per POINT
+    (first SA layer, linear map before the grouping).  -> z, stats."""
+    b, m, k = idx.shape
+    n, cout = xyz.shape[1], w_xyz.shape[1]
+    rows = b * m * k
+    z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
+    stats = _zeros_f64(2 * cout, xyz.device) if want_stats else None
+    with torch.cuda.device(xyz.device):
+        L.check(L.lib().votenet_group_linear(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(P), L.ptr(w_xyz),
+                                             L.ptr(bias), L.ptr(z), L.ptr(stats), L.stream_ptr()))
+    return z, stats
+
+
 def bn_finalize(rows, stats, gamma, beta, eps=BN_EPS):
     """-> scale, shift, mean, var (each (c,) f32): scale=gamma*rsqrt(var+eps), shift=beta-mean*scale."""
     c = gamma.shape[0]

@@ -95,6 +95,11 @@ def make_mlp(store, scope, cin, widths, prefix="conv", last_plain=False):
 
 
 # --------------------------------------------------------------------------- MLP chains
+# First SA layer: linear map before the grouping (see mlp_chain_forward).  False = the fused GATHER GEMM over the grouped
+# rows (votenet_mlp_linear with a GATHER input), kept for comparison and tests.
+PRE_LINEAR = True
+
+
 def mlp_chain_forward(layers, rows, first, tape):
     """Run a chain of layers over `rows` rows.  first = ('gather', xyz, new_xyz, feat, idx) or ('dense', x).
     Returns (z_last, scale_last, shift_last): the last layer's RAW output and its folded BN
@@ -104,8 +109,17 @@ def mlp_chain_forward(layers, rows, first, tape):
     for i, L in enumerate(layers):
         w, b = L.p("W"), L.p("b")
         if i == 0 and first[0] == "gather":
+            # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
+            # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
+            # and the layer output is assembled per grouped row: z = P[idx] + dxyz W[0:3] + bias (votenet_group_linear).
             _, xyz, new_xyz, feat, idx = first
-            zn, st = M.linear_gather(xyz, new_xyz, feat, idx, w, b, want_stats=L.bn)
+            co = w.shape[1]
+            if feat is not None and PRE_LINEAR and co % 4 == 0 and co <= 1024 and 256 % (co // 4) == 0:
+                bb, nn, cc = feat.shape
+                P, _ = M.linear_dense(feat.reshape(bb * nn, cc), w[3:], None, want_stats=False)
+                zn, st = M.group_linear(xyz, new_xyz, idx, P, w[:3], b, want_stats=L.bn)
+            else:
+                zn, st = M.linear_gather(xyz, new_xyz, feat, idx, w, b, want_stats=L.bn)
             rec = dict(layer=L, kind="gather", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx)
         elif i == 0:
             zn, st = M.linear_dense(first[1], w, b, want_stats=L.bn)
@@ -179,9 +193,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
          'plain' : g = dz (rows, c) of a last layer without BN / activation    (mlp2, voting)
     Accumulates parameter gradients into the store's gradient bucket.  Returns the gradient with respect to the
-    chain's input: (rows, cin) for a dense input; for a gather input the pair (d_rows_feat (rows, c) or None,
-    d_rows_xyz (rows, 3) or None) -- the feature block W[3:] is a 128-multiple wide GEMM of its own and the
-    three xyz columns are only computed when the caller needs them (proposal layer)."""
+    chain's input (rows, cin) for a dense input.  For a gather input it stops after the BatchNorm backward of the first
+    layer and returns that layer's dz (rows, cout): SAModule.backward finishes it (weight gradient, point gradients)."""
     da = g
     sums = None  # BatchNorm-backward reductions of the current layer when the GEMM above already produced them
     for i in range(len(recs) - 1, -1, -1):
@@ -216,18 +229,10 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
         else:
             dz = da
             M.bias_grad(dz, L.gp("b"))
-        with _OnWgradStream(dz, r.get("x"), r.get("feat")):
-            if r["kind"] == "gather":
-                M.wgrad_gather(r["xyz"], r["new_xyz"], r["feat"], r["idx"], dz, L.gp("W"))
-            else:
-                M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
         if i == 0 and r["kind"] == "gather":
-            d_rows_feat = d_rows_xyz = None
-            if need_input_grad and r["feat"] is not None:
-                d_rows_feat, _ = M.linear_dense(dz, L.p("W")[3:].t().contiguous(), want_stats=False)
-            if need_xyz_grad:
-                d_rows_xyz, _ = M.linear_dense(dz, L.p("W")[:3].t().contiguous(), want_stats=False)
-            return d_rows_feat, d_rows_xyz
+            return dz  # the caller (SAModule.backward) finishes the first layer: it owns idx / pts_cnt / the point tables
+        with _OnWgradStream(dz, r.get("x")):
+            M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
         if want_da:
             da, _ = M.linear_dense(dz, L.p("W").t().contiguous(), want_stats=False)  # da_prev = dz W^T
         else:
@@ -287,14 +292,45 @@ class SAModule:
         if self.mlp2:
             g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
         need_feat = need_feat_grad and rec["points"] is not None
-        d_rows_feat, d_rows_xyz = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
-                                                     need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
-        if not (need_feat or need_xyz_grad):
-            return None, None
-        n = rec["xyz"].shape[1]
-        c = 0 if rec["points"] is None else rec["points"].shape[2]
-        d_feat, d_xyz, d_new = M.group_concat_grad(d_rows_feat, d_rows_xyz, rec["idx"], rec["pts_cnt"], n, c)
+        dz0 = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
+                                 need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
+        return self._first_layer_backward(rec, dz0, need_feat, need_xyz_grad)
+
+    def _first_layer_backward(self, rec, dz, need_feat, need_xyz_grad):
+        """Backward of z = P[idx] + dxyz W[0:3] (P = feat W[3:]) given dz (rows, cout):
+             dW[0:3] += dxyz^T dz                     (narrow streaming kernel over the grouped rows)
+             S = scatter-add of dz rows by idx        (b, n, cout)  -- GroupPointGrad on the layer OUTPUT width
+             dW[3:]  += feat^T S ,  d_feat = S W[3:]^T                (two GEMMs over the b*n points, not the grouped rows)
+             d_xyz / d_new_xyz from dz W[0:3]^T       (proposal layer only)"""
+        r0 = rec["recs"][0]
+        L0 = r0["layer"]
+        W, gW = L0.p("W"), L0.gp("W")
+        xyz, new_xyz, feat, idx, pts_cnt = r0["xyz"], r0["new_xyz"], r0["feat"], r0["idx"], rec["pts_cnt"]
+        b, n = xyz.shape[:2]
+        cout = dz.shape[1]
+        d_feat = d_xyz = None
+        if feat is None or PRE_LINEAR:
+            with _OnWgradStream(dz):
+                M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW)  # rows 0..2 of dW (no feature block in the descriptor)
+        if feat is not None:
+            c = feat.shape[2]
+            if PRE_LINEAR:
+                S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
+                S2, feat2 = S.view(b * n, cout), feat.reshape(b * n, c)
+                with _OnWgradStream(S2, feat2):
+                    M.wgrad_dense(feat2, S2, gW[3:])
+                if need_feat:
+                    d2, _ = M.linear_dense(S2, W[3:].t().contiguous(), want_stats=False)
+                    d_feat = d2.view(b, n, c)
+            else:  # the fused GATHER GEMMs over the grouped rows
+                with _OnWgradStream(dz, feat):
+                    M.wgrad_gather(xyz, new_xyz, feat, idx, dz, gW)
+                if need_feat:
+                    d_rows_feat, _ = M.linear_dense(dz, W[3:].t().contiguous(), want_stats=False)
+                    d_feat, _, _ = M.group_concat_grad(d_rows_feat, None, idx, pts_cnt, n, c)
         if need_xyz_grad:
+            d_rows_xyz, _ = M.linear_dense(dz, W[:3].t().contiguous(), want_stats=False)
+            _, d_xyz, d_new = M.group_concat_grad(None, d_rows_xyz, idx, pts_cnt, n, 0)
             d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
         return d_feat, d_xyz
 
