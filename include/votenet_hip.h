@@ -181,6 +181,17 @@ int votenet_group_linear(int b, int n, int m, int nsample, int cout, const float
                          const int *idx, const float *P, const float *w_xyz, const float *bias, float *z,
                          double *stats /* 2*cout, pre-zeroed, may be NULL */, void *stream);
 
+/* Backward of votenet_group_linear for a BatchNorm'ed layer, one pass over (z, da) (rows = b*m*nsample):
+ *   dz = A*g' + B + C*z with g' = da masked by [z*S+H > 0] when relu   (coef = [A|B|C|S|H] from votenet_bn_backward_coef)
+ *   s_points[b, idx[b,j,k], :] += dz[b,j,k,:]      (b x n x cout, pre-zeroed: GroupPointGrad, tf_grouping_g.cu:61-78,
+ *                                                   at the layer OUTPUT width; then dW[3:] += feat^T S, d_feat = S W[3:]^T)
+ *   dw_xyz[d, :] += sum_rows (xyz[b,idx]-new_xyz[b,j])[d] * dz       (3 x cout: the xyz rows of the weight gradient)
+ *   dz_out = dz (rows x cout) if not NULL.
+ * pts_cnt as for votenet_group_concat_grad (may be NULL).  cout in {32,64,128,256}, nsample <= 128. */
+int votenet_group_linear_backward(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                  const int *idx, const int *pts_cnt, const float *z, const float *da, const float *coef,
+                                  int relu, float *s_points, float *dw_xyz, float *dz_out, void *stream);
+
 /* out (groups x c) = max over the k rows of each group of max(0?, z*scale+shift);
  * argmax (groups x c, int32 row offset inside the group, may be NULL) for the backward pass. */
 int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *scale, const float *shift,

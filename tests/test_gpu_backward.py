@@ -186,6 +186,40 @@ def test_fused_bn_backward_gemms_match_unfused(hiplib, dev, rows, cin, c, k):
     assert relerr(psums, psums_ref) < 2e-5
 
 
+@pytest.mark.parametrize("b,n,m,k,cout", [(2, 300, 20, 16, 64), (1, 500, 33, 64, 128), (2, 256, 16, 7, 32), (1, 100, 9, 128, 256)])
+def test_group_linear_backward_matches_unfused(hiplib, dev, b, n, m, k, cout):
+    """votenet_group_linear_backward (dz formed, scattered by idx and reduced against dxyz in one pass) against the separate
+    kernels: bn_backward_apply -> group_concat_grad (GroupPointGrad, tf_grouping_g.cu:61-78) / wgrad on the xyz columns;
+    and the scatter against a float64 index_add."""
+    from votenet_amd import mlp as M
+    from votenet_amd import tf_grouping as G
+    g = torch.Generator().manual_seed(b * n + k)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    xyz = torch.rand(b, n, 3, generator=g).to(dev)
+    new_xyz = xyz[:, :m].contiguous()
+    idx, cnt = G.query_ball_point(0.35, k, xyz, new_xyz)  # real neighbour lists: padded balls included
+    rows = b * m * k
+    z, da = rnd(rows, cout), rnd(rows, cout)
+    stats = [rnd(cout) * 0.5 + 1.0, rnd(cout) * 0.1, rnd(cout) * 0.1, rnd(cout).abs() + 0.5]  # scale, shift, mean, var
+    gamma = rnd(cout) * 0.2 + 1.0
+    sums = M.bn_backward_reduce(z, *stats, True, da)
+    coef = M.bn_backward_coef(rows, *stats, gamma, sums, None, None)
+    dz_ref = M.bn_backward_apply(z, coef, True, da)
+    S_ref, _, _ = M.group_concat_grad(dz_ref, None, idx, cnt, n, cout)
+    dw_ref = torch.zeros(3, cout, device=dev)
+    M.wgrad_gather(xyz, new_xyz, None, idx, dz_ref, dw_ref)
+    dw = torch.zeros(3, cout, device=dev)
+    S, dz = M.group_linear_backward(xyz, new_xyz, idx, cnt, z, da, coef, True, dw, want_dz=True)
+    assert torch.equal(dz, dz_ref)
+    assert relerr(S, S_ref) < 1e-5 and relerr(dw, dw_ref) < 1e-5
+    S64 = torch.zeros(b * n, cout, dtype=torch.float64, device=dev)
+    flat = (idx.long() + torch.arange(b, device=dev)[:, None, None] * n).reshape(-1)
+    S64.index_add_(0, flat, dz_ref.double())
+    assert relerr(S.double().view(b * n, cout), S64) < 1e-5
+    S2, none = M.group_linear_backward(xyz, new_xyz, idx, None, z, da, coef, True, torch.zeros(3, cout, device=dev))
+    assert none is None and relerr(S2, S_ref) < 1e-5  # without pts_cnt: every row scattered on its own
+
+
 def test_clip_adam_vs_reference(hiplib, dev):
     """model.py:240-250: per-tensor tf.clip_by_average_norm(g, 0.5) then Adam(1e-3)."""
     from votenet_amd import model as VM

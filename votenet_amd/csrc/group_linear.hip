@@ -105,3 +105,125 @@ extern "C" int votenet_group_linear(int b, int n, int m, int nsample, int cout, 
                        new_xyz, idx, P, w_xyz, bias, z, stats);
     return check_launch("group_linear");
 }
+
+// ---------------------------------------------------------------- backward of the assembled first layer
+namespace votenet {
+
+// One pass over (z, da) of a BatchNorm'ed first SA layer z = P[idx] + dxyz W[0:3]:
+//   dz   = A*g' + B + C*z,  g' = da masked by [z*S+H > 0]                       (BatchNorm + ReLU backward, coef = [A|B|C|S|H])
+//   S_pt[scene, idx[row], ch] += dz[row, ch]                                   (GroupPointGrad at the layer output width)
+//   dW[d, ch]                 += sum_rows dxyz[row, d] * dz[row, ch], d < 3     (the xyz rows of the weight gradient)
+//   dz_out[row, ch]            = dz                                             (optional: the proposal layer also needs dz W[0:3]^T)
+// so that neither dz nor the per-row input gradient is ever written.  Thread = (group, channel): it walks the group's
+// nsample rows; the group's idx and dxyz rows are staged in LDS once per group.  A ball with fewer than nsample
+// neighbours is padded with its first hit (tf_grouping_g.cu:26-29): rows k >= pts_cnt all target idx[g,0] and are summed
+// in a register, one atomic instead of nsample - pts_cnt.  Workgroups are persistent over groups so that the 3*cout
+// atomics of dW amortise.
+template <int GPB /* groups per workgroup pass = 256 / cout */>
+__global__ __launch_bounds__(256) void group_linear_bwd_kernel(long groups, int n, int groups_per_scene, int nsample, int cout,
+                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const int *__restrict__ idx, const int *__restrict__ pts_cnt,
+                                                               const float *__restrict__ z, const float *__restrict__ da,
+                                                               const float *__restrict__ coef, int relu, float *__restrict__ spt,
+                                                               float *__restrict__ dw_xyz, float *__restrict__ dz_out)
+{
+    constexpr int KMAX = 128; // nsample <= 128 (launcher)
+    __shared__ int s_idx[GPB][KMAX];
+    __shared__ float s_dx[GPB][KMAX][3];
+    __shared__ float red[256][3];
+    const int tid = threadIdx.x;
+    const int ch = tid % cout, gl = tid / cout; // channel, group lane inside the pass
+    const float kA = coef[ch], kB = coef[cout + ch], kC = coef[2 * cout + ch], kS = coef[3 * cout + ch], kH = coef[4 * cout + ch];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (long g0 = (long)blockIdx.x * GPB; g0 < groups; g0 += (long)gridDim.x * GPB) {
+        __syncthreads(); // previous pass's LDS fully consumed
+        // stage idx and dxyz of the pass's groups: GPB * nsample rows over 256 threads
+        for (int t = tid; t < GPB * nsample; t += 256) {
+            const int q = t / nsample, k = t - q * nsample;
+            const long g = g0 + q;
+            if (g < groups) {
+                const int id = idx[(size_t)g * nsample + k];
+                const size_t p = ((size_t)(g / groups_per_scene) * n + id) * 3;
+                s_idx[q][k] = id;
+                s_dx[q][k][0] = xyz[p + 0] - new_xyz[(size_t)g * 3 + 0]; // utils.py:55
+                s_dx[q][k][1] = xyz[p + 1] - new_xyz[(size_t)g * 3 + 1];
+                s_dx[q][k][2] = xyz[p + 2] - new_xyz[(size_t)g * 3 + 2];
+            }
+        }
+        __syncthreads();
+        const long g = g0 + gl;
+        if (g < groups) {
+            const size_t row0 = (size_t)g * nsample;
+            float *__restrict__ tab = spt + (size_t)(g / groups_per_scene) * n * cout + ch;
+            int cnt = pts_cnt ? pts_cnt[g] : nsample;
+            if (cnt < 1) cnt = 1;
+            float pad = 0.0f;
+            for (int k0 = 0; k0 < nsample; k0 += 8) {
+                float zz[8], gg[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + u < nsample ? k0 + u : nsample - 1;
+                    zz[u] = z[(row0 + k) * cout + ch];
+                    gg[u] = da[(row0 + k) * cout + ch];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int k = k0 + u;
+                    if (k < nsample) {
+                        float gq = gg[u];
+                        if (relu && !(zz[u] * kS + kH > 0.0f)) gq = 0.0f;
+                        const float d = kA * gq + kB + kC * zz[u];
+                        if (dz_out) dz_out[(row0 + k) * cout + ch] = d;
+                        a0 += s_dx[gl][k][0] * d;
+                        a1 += s_dx[gl][k][1] * d;
+                        a2 += s_dx[gl][k][2] * d;
+                        if (k > 0 && k < cnt)
+                            unsafeAtomicAdd(&tab[(size_t)s_idx[gl][k] * cout], d);
+                        else
+                            pad += d; // row 0 and the padding rows share idx[g,0]
+                    }
+                }
+            }
+            unsafeAtomicAdd(&tab[(size_t)s_idx[gl][0] * cout], pad);
+        }
+    }
+    red[tid][0] = a0;
+    red[tid][1] = a1;
+    red[tid][2] = a2;
+    __syncthreads();
+    if (tid < cout) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float t = 0.0f;
+            for (int q = 0; q < GPB; q++) t += red[q * cout + tid][d];
+            unsafeAtomicAdd(&dw_xyz[(size_t)d * cout + tid], t);
+        }
+    }
+}
+
+} // namespace votenet
+
+extern "C" int votenet_group_linear_backward(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                             const int *idx, const int *pts_cnt, const float *z, const float *da, const float *coef,
+                                             int relu, float *s_points, float *dw_xyz, float *dz_out, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0 && m >= 0 && nsample > 0 && cout > 0, "group_linear_backward: bad shape");
+    VN_REQUIRE(nsample <= 128, "group_linear_backward expects nsample <= 128");
+    VN_REQUIRE(cout == 32 || cout == 64 || cout == 128 || cout == 256, "group_linear_backward expects cout in {32, 64, 128, 256}");
+    const long groups = (long)b * m;
+    if (groups == 0) return VOTENET_OK;
+    VN_REQUIRE(xyz && new_xyz && idx && z && da && coef && s_points && dw_xyz, "group_linear_backward: null buffer");
+    hipStream_t st = as_stream(stream);
+    const int gpb = 256 / cout;
+    long gx = (groups + gpb - 1) / gpb;
+    if (gx > 2048) gx = 2048;
+#define GLB_LAUNCH(G)                                                                                                             \
+    hipLaunchKernelGGL(group_linear_bwd_kernel<G>, dim3((unsigned)gx), dim3(256), 0, st, groups, n, m, nsample, cout, xyz, new_xyz, \
+                       idx, pts_cnt, z, da, coef, relu, s_points, dw_xyz, dz_out)
+    if (gpb == 8) GLB_LAUNCH(8);
+    else if (gpb == 4) GLB_LAUNCH(4);
+    else if (gpb == 2) GLB_LAUNCH(2);
+    else GLB_LAUNCH(1);
+#undef GLB_LAUNCH
+    return check_launch("group_linear_backward");
+}

@@ -142,6 +142,24 @@ def group_linear(xyz, new_xyz, idx, P, w_xyz, bias=None, want_stats=True):
     return z, stats
 
 
+def group_linear_backward_supported(cout, nsample):
+    return cout in (32, 64, 128, 256) and nsample <= 128
+
+
+def group_linear_backward(xyz, new_xyz, idx, pts_cnt, z, da, coef, relu, dw_xyz, want_dz=False):
+    """One pass over (z, da) of a BatchNorm'ed first SA layer: -> S (b, n, cout) = scatter-add of dz by idx, dz or None;
+    accumulates the xyz rows of the weight gradient into dw_xyz (3, cout) (a view of the gradient bucket)."""
+    b, m, k = idx.shape
+    n, cout = xyz.shape[1], z.shape[1]
+    S = torch.zeros((b, n, cout), dtype=torch.float32, device=z.device)
+    dz = torch.empty_like(z) if want_dz else None
+    with torch.cuda.device(z.device):
+        L.check(L.lib().votenet_group_linear_backward(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
+                                                      L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
+                                                      L.ptr(dz), L.stream_ptr()))
+    return S, dz
+
+
 def bn_finalize(rows, stats, gamma, beta, eps=BN_EPS):
     """-> scale, shift, mean, var (each (c,) f32): scale=gamma*rsqrt(var+eps), shift=beta-mean*scale."""
     c = gamma.shape[0]

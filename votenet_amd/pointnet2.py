@@ -193,8 +193,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
          'plain' : g = dz (rows, c) of a last layer without BN / activation    (mlp2, voting)
     Accumulates parameter gradients into the store's gradient bucket.  Returns the gradient with respect to the
-    chain's input (rows, cin) for a dense input.  For a gather input it stops after the BatchNorm backward of the first
-    layer and returns that layer's dz (rows, cout): SAModule.backward finishes it (weight gradient, point gradients)."""
+    chain's input (rows, cin) for a dense input.  For a gather input it stops at the first layer and returns either
+    dict(dz=...) (rows, cout) or dict(da=, coef=, relu=) when the fused first-layer backward kernel will form dz itself:
+    SAModule.backward finishes the layer (weight gradient, point gradients)."""
     da = g
     sums = None  # BatchNorm-backward reductions of the current layer when the GEMM above already produced them
     for i in range(len(recs) - 1, -1, -1):
@@ -225,12 +226,15 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
                     below = (rp["z"], rp["scale"], rp["shift"], rp["mean"], rp["var"], rp["layer"].relu)
                 da, sums = M.dgrad_bn(z, coef, L.relu, L.p("W").t().contiguous(), below=below, **src)
                 continue
+            if i == 0 and r["kind"] == "gather" and PRE_LINEAR and not pooled and r["feat"] is not None and \
+                    M.group_linear_backward_supported(c, r["idx"].shape[2]):
+                return dict(da=da, coef=coef, relu=L.relu)  # dz is formed inside votenet_group_linear_backward
             dz = M.bn_backward_apply(z, coef, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
         else:
             dz = da
             M.bias_grad(dz, L.gp("b"))
         if i == 0 and r["kind"] == "gather":
-            return dz  # the caller (SAModule.backward) finishes the first layer: it owns idx / pts_cnt / the point tables
+            return dict(dz=dz)  # the caller (SAModule.backward) finishes the first layer: it owns idx / pts_cnt / the tables
         with _OnWgradStream(dz, r.get("x")):
             M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
         if want_da:
@@ -292,30 +296,39 @@ class SAModule:
         if self.mlp2:
             g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
         need_feat = need_feat_grad and rec["points"] is not None
-        dz0 = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
-                                 need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
-        return self._first_layer_backward(rec, dz0, need_feat, need_xyz_grad)
+        h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
+                               need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
+        return self._first_layer_backward(rec, h, need_feat, need_xyz_grad)
 
-    def _first_layer_backward(self, rec, dz, need_feat, need_xyz_grad):
+    def _first_layer_backward(self, rec, h, need_feat, need_xyz_grad):
         """Backward of z = P[idx] + dxyz W[0:3] (P = feat W[3:]) given dz (rows, cout):
-             dW[0:3] += dxyz^T dz                     (narrow streaming kernel over the grouped rows)
+             dW[0:3] += dxyz^T dz                     (over the grouped rows)
              S = scatter-add of dz rows by idx        (b, n, cout)  -- GroupPointGrad on the layer OUTPUT width
              dW[3:]  += feat^T S ,  d_feat = S W[3:]^T                (two GEMMs over the b*n points, not the grouped rows)
-             d_xyz / d_new_xyz from dz W[0:3]^T       (proposal layer only)"""
+             d_xyz / d_new_xyz from dz W[0:3]^T       (proposal layer only)
+        h = dict(dz=) or dict(da=, coef=, relu=): in the second form one kernel forms dz from (z, da), scatters it and
+        reduces the xyz rows of dW in a single pass (votenet_group_linear_backward)."""
         r0 = rec["recs"][0]
         L0 = r0["layer"]
         W, gW = L0.p("W"), L0.gp("W")
         xyz, new_xyz, feat, idx, pts_cnt = r0["xyz"], r0["new_xyz"], r0["feat"], r0["idx"], rec["pts_cnt"]
         b, n = xyz.shape[:2]
-        cout = dz.shape[1]
+        cout = W.shape[1]
         d_feat = d_xyz = None
-        if feat is None or PRE_LINEAR:
-            with _OnWgradStream(dz):
-                M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW)  # rows 0..2 of dW (no feature block in the descriptor)
+        S = None
+        if "dz" in h:
+            dz = h["dz"]
+            if feat is None or PRE_LINEAR:
+                with _OnWgradStream(dz):
+                    M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW)  # rows 0..2 of dW (no feature block in the descriptor)
+            if feat is not None and PRE_LINEAR:
+                S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
+        else:
+            S, dz = M.group_linear_backward(xyz, new_xyz, idx, pts_cnt, r0["z"], h["da"], h["coef"], h["relu"], gW[:3],
+                                            want_dz=need_xyz_grad)
         if feat is not None:
             c = feat.shape[2]
             if PRE_LINEAR:
-                S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
                 S2, feat2 = S.view(b * n, cout), feat.reshape(b * n, c)
                 with _OnWgradStream(S2, feat2):
                     M.wgrad_dense(feat2, S2, gW[3:])
