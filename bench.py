@@ -102,7 +102,7 @@ def main():
 
     from votenet_amd import model as VM
     from votenet_amd import mlp as vmlp
-    from votenet_amd import synth, tf_sampling
+    from votenet_amd import synth, tf_grouping, tf_sampling
     have_train = hasattr(VM.VoteNetHotPath, "train_step")
     workload = args.workload or ("train" if have_train else "fwd")
 
@@ -129,12 +129,19 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    tf_sampling.PROFILE_EVENTS = []  # HIP events around every FPS launch, on the launch stream
-    gemm_steps = min(2, args.steps)  # ... and around every MFMA GEMM launch of the first two timed steps only
-    vmlp.PROFILE_EVENTS = []         #     (75 event pairs per step would otherwise perturb the headline time)
+    # HIP events (recorded on the launch stream) around every FPS, ball-query and MFMA GEMM launch of the FIRST TWO timed
+    # steps only: a timing event is a barrier packet in the queue -- about 90 pairs per step cost 0.5-1 ms of a 11 ms step
+    prof_steps = min(2, args.steps)
+    gemm_steps = prof_steps
+    tf_sampling.PROFILE_EVENTS = []
+    tf_grouping.PROFILE_EVENTS = []
+    vmlp.PROFILE_EVENTS = []
+    events, bq_events, gemm_events = [], [], []
     t0 = time.perf_counter()
     for i in range(args.steps):
-        if i == gemm_steps:
+        if i == prof_steps:
+            events, tf_sampling.PROFILE_EVENTS = tf_sampling.PROFILE_EVENTS, None
+            bq_events, tf_grouping.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS, None
             gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
         step()
     torch.cuda.synchronize()
@@ -142,9 +149,9 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    events = tf_sampling.PROFILE_EVENTS
-    tf_sampling.PROFILE_EVENTS = None
-    if vmlp.PROFILE_EVENTS is not None:
+    if tf_sampling.PROFILE_EVENTS is not None:  # steps <= 2
+        events, tf_sampling.PROFILE_EVENTS = tf_sampling.PROFILE_EVENTS, None
+        bq_events, tf_grouping.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS, None
         gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -171,15 +178,45 @@ def main():
                                              "exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg}
+        # the sa1 ball query (n=20480 candidates, 2048 centres, K=64) and the pair the north star names: FPS + ball query
+        bq = None
+        K1 = net.sa1.nsample
+        bdurs = [e0.elapsed_time(e1) for (e0, e1, b_, n_, m_, k_) in bq_events if n_ == n and m_ == m1]
+        if bdurs and roof:
+            bq_ms = sum(bdurs) / len(bdurs)
+            bq_alg = B * m1 * n * 12 + B * m1 * (K1 + 1) * 4  # B*m*n*12 + B*m*(K+1)*4
+            ach = bq_alg / (bq_ms * 1e-3) / 1e9
+            both = (alg + bq_alg) / ((avg_ms + bq_ms) * 1e-3) / 1e9
+            bq = {"bound": "hbm", "kernel": "ball_query_kernel<16> (sa1: %d candidates x %d centres, r=0.2, K=%d; candidates through the "
+                                            "scalar cache, on-chip)" % (n, m1, K1),
+                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                  "avg_launch_ms": round(bq_ms, 4), "algorithmic_bytes": bq_alg,
+                  "fps_plus_ball_query": {"achieved": round(both, 1), "frac": round(both / HBM_PEAK_GBS, 4),
+                                          "ms": round(avg_ms + bq_ms, 4), "algorithmic_bytes": alg + bq_alg}}
         mfma = None
         if gemm_events:
-            tot_ms = sum(e0.elapsed_time(e1) for (e0, e1, _, _) in gemm_events)
+            # GEMMs run on two streams (weight gradients beside the input-gradient chain): the time the matrix pipes are
+            # in use is the UNION of the launch intervals, not their sum.  All events are placed on one time axis by
+            # their distance from the first one.
+            base = gemm_events[0][0]
+            iv = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for (e0, e1, _, _) in gemm_events)
+            tot_ms, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
+            for a, b in iv[1:]:
+                if a > cur_e:
+                    tot_ms += cur_e - cur_s
+                    cur_s, cur_e = a, b
+                else:
+                    cur_e = max(cur_e, b)
+            tot_ms += cur_e - cur_s
+            sum_ms = sum(b - a for a, b in iv)
             tot_fl = sum(f for (_, _, _, f) in gemm_events)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
-            mfma = {"bound": "mfma", "kernel": "mlp_linear_fast_kernel / mlp_linear_kernel / mlp_wgrad_fast_kernel (all %d GEMM launches of the first two timed steps, "
-                                               "fp32 in / fp32 accumulate)" % len(gemm_events),
+            mfma = {"bound": "mfma", "kernel": "mlp_linear_fast_kernel / mlp_linear_kernel / mlp_wgrad_fast_kernel (all %d GEMM launches of "
+                                               "the first two timed steps, fp32 in / fp32 accumulate; executed flops / union of the "
+                                               "launch intervals over both streams)" % len(gemm_events),
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
-                    "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gflop_per_step": round(tot_fl / gemm_steps / 1e9, 1)}
+                    "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gemm_ms_per_step_summed": round(sum_ms / gemm_steps, 3),
+                    "gflop_per_step": round(tot_fl / gemm_steps / 1e9, 1)}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(n, args.scene)
@@ -192,7 +229,7 @@ def main():
                                     "%s scenes" % ("train step (fwd+bwd+Adam, synthetic cotangents in place of the loss graph)"
                                                    if workload == "train" else "forward", B, n, args.scene)),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
-            "roofline": roof, "roofline_mlp": mfma, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -9,6 +9,11 @@ import torch
 from . import _lib as L
 
 
+# bench.py sets this to a list to bracket every ball-query launch with HIP events recorded on the launch stream:
+# entries are (start, end, b, n, m, nsample).
+PROFILE_EVENTS = None
+
+
 def query_ball_point(radius, nsample, xyz1, xyz2):
     """tf_grouping.py:8-20.  float, int, (B,n,3), (B,m,3) -> (idx (B,m,nsample) i32, pts_cnt (B,m) i32)."""
     xyz1 = L.dev_f32(xyz1.detach(), "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.", 3, 3)
@@ -19,8 +24,14 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     idx = torch.empty((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
     with torch.cuda.device(xyz1.device):
+        if PROFILE_EVENTS is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         L.check(L.lib().votenet_query_ball_point(b, n, m, float(radius), nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx),
                                                  L.ptr(cnt), L.stream_ptr()))
+        if PROFILE_EVENTS is not None:
+            e1.record()
+            PROFILE_EVENTS.append((e0, e1, b, n, m, nsample))
     return idx, cnt
 
 
