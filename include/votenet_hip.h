@@ -197,6 +197,21 @@ int votenet_group_linear_backward(int b, int n, int m, int nsample, int cout, co
 int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *scale, const float *shift,
                         int relu, float *out, int *argmax, void *stream);
 
+/* votenet_mlp_linear with the max-pool of utils.py:132 started in its epilogue: besides z and stats it writes, per group
+ * of pool_k consecutive rows and channel, the RAW maximum and minimum of z and the row offsets where they are attained
+ * (zmax / zmin / amax / amin, each rows/pool_k x cout).  The layer's BatchNorm scale needs the statistics of the whole
+ * launch, but max_k act(s*z+h) = act(s * max_k z + h) for s >= 0 and act(s * min_k z + h) for s < 0, so
+ * votenet_bn_pool_finalize completes the pool without another pass over z (same values as votenet_bn_relu_max; among
+ * rows that tie after BatchNorm the arg-max may name a different one).  z may be NULL when only the pooled result is
+ * wanted (inference).  Served: DENSE input, pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, cout % 128 == 0,
+ * 16-byte aligned buffers; anything else returns VOTENET_E_INVALID_ARGUMENT. */
+int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
+                            float *z /* may be NULL */, double *stats, int pool_k, float *zmax, float *zmin, int *amax,
+                            int *amin, void *stream);
+int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
+                             const float *scale, const float *shift, int relu, float *out, int *argmax /* may be NULL */,
+                             void *stream);
+
 /* y = max(0?, z*scale+shift) materialised (rows x c); used where the next consumer is not a
  * votenet_mlp_linear (e.g. the FP-layer output that feeds the voting head). */
 int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,

@@ -113,6 +113,42 @@ def test_group_linear_argument_errors(hiplib, dev):
         mlp.group_linear(xyz, xyz[:, :2].contiguous(), idx, torch.zeros(10, 12, device=dev), torch.zeros(3, 12, device=dev))
 
 
+@pytest.mark.parametrize("rows,cin,cout", [(1024, 64, 128), (4096, 128, 256), (640, 32, 128)])
+def test_linear_pool_epilogue_matches_separate_pass(hiplib, dev, rows, cin, cout):
+    """votenet_mlp_linear_pool + votenet_bn_pool_finalize (max-pool started in the GEMM epilogue on raw z) against
+    votenet_mlp_linear + votenet_bn_relu_max (utils.py:132), including negative and zero BatchNorm scales."""
+    from votenet_amd import mlp, _lib
+    g = torch.Generator().manual_seed(rows + cout)
+    x = torch.randn(rows, cin, generator=g).to(dev)
+    w = (torch.randn(cin, cout, generator=g) * 0.2).to(dev)
+    sc_in = (torch.randn(cin, generator=g) * 0.3 + 1).to(dev)
+    sh_in = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    z_ref, st_ref = mlp.linear_dense(x, w, None, sc_in, sh_in, True)
+    z, st, pool = mlp.linear_dense_pool(x, w, 64, None, sc_in, sh_in, True)
+    assert torch.equal(z, z_ref)
+    assert np.allclose(N(st), N(st_ref), rtol=1e-6, atol=1e-4)
+    scale = (torch.randn(cout, generator=g)).to(dev)
+    scale[::7] = 0.0  # a zero scale: every row ties
+    shift = (torch.randn(cout, generator=g) * 0.5).to(dev)
+    for relu in (True, False):
+        out_ref, arg_ref = mlp.bn_relu_max(z_ref, 64, scale, shift, relu, want_argmax=True)
+        out, arg = mlp.bn_pool_finalize(pool, scale, shift, relu, want_argmax=True)
+        assert torch.equal(out, out_ref)
+        # the arg-max may differ among rows that tie AFTER BatchNorm(+ReLU); the value at it must be the maximum
+        act = z_ref.view(rows // 64, 64, cout) * scale + shift
+        if relu:
+            act = torch.where(act > 0, act, torch.zeros_like(act))
+        picked = act.gather(1, arg.long()[:, None, :])[:, 0, :]
+        assert torch.equal(picked, out_ref)
+        if not relu:  # without the ReLU plateau only exact float ties can differ
+            assert (arg == arg_ref).float().mean() > 0.99
+    z2, _, pool2 = mlp.linear_dense_pool(x, w, 64, None, sc_in, sh_in, True, keep_z=False)
+    assert z2 is None and all(torch.equal(a, b) for a, b in zip(pool, pool2))
+    assert not mlp.linear_pool_supported(rows, cin, 64, 64) and not mlp.linear_pool_supported(rows, cin, cout, 32)
+    with pytest.raises(_lib.InvalidArgumentError):
+        mlp.linear_dense_pool(x, w, 32)
+
+
 def test_sa_mlp_stack_cfg1(hiplib, dev, O):
     """BASELINE config 1 end to end: 2048 pts -> FPS 512 -> ball r=0.2 K=32 -> MLP 64,64,128 (BNReLU) -> max over K."""
     import cases

@@ -468,6 +468,24 @@ __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, c
     }
 }
 
+// Second half of the max-pool fused into the last GEMM's epilogue (mlp_fast.hip, EPI 2): with the layer's BatchNorm
+// scale/shift known, out = act(s * (s >= 0 ? zmax : zmin) + h) and argmax = the matching row offset.  s == 0: every row
+// gives act(h), the first row is the arg-max (what the separate pass returns).
+__global__ void bn_pool_finalize_kernel(long total, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
+                                        const int *__restrict__ amax, const int *__restrict__ amin, const float *__restrict__ scale,
+                                        const float *__restrict__ shift, int relu, float *__restrict__ out, int *__restrict__ argmax)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(e % c);
+        const float s = scale[ch], h = shift[ch];
+        float v = (s >= 0.0f ? zmax[e] : zmin[e]) * s + h;
+        int a = s > 0.0f ? amax[e] : (s < 0.0f ? amin[e] : 0);
+        if (relu && !(v > 0.0f)) v = 0.0f;
+        out[e] = v;
+        if (argmax) argmax[e] = a;
+    }
+}
+
 static inline int grid_for(long total, int block)
 {
     long g = (total + block - 1) / block;
@@ -549,6 +567,39 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
     VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_linear: rows must equal b*m*nsample for a GATHER input");
     VN_REQUIRE(cin == 3 + d.c, "mlp_linear: cin must equal 3 + c for a GATHER input (utils.py:55)");
     return launch_linear<1>(d, rows, cin, cout, w, bias, z, stats, st);
+}
+
+namespace votenet {
+bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
+                            int cout, const float *w, const float *bias, float *z, double *stats, float *zmax, float *zmin,
+                            int *amax, int *amin, hipStream_t st); // mlp_fast.hip
+}
+
+extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
+                                       const float *bias, float *z, double *stats, int pool_k, float *zmax, float *zmin,
+                                       int *amax, int *amin, void *stream)
+{
+    VN_REQUIRE(in != nullptr && in->x != nullptr, "mlp_linear_pool: DENSE input descriptor required");
+    VN_REQUIRE(rows > 0 && cin > 0 && cout > 0, "mlp_linear_pool expects rows > 0, cin > 0, cout > 0");
+    VN_REQUIRE(w && zmax && zmin && amax && amin, "mlp_linear_pool: null buffer");
+    VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_linear_pool: in_scale and in_shift go together");
+    if (pool_k != 64 || !votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, in->in_relu, rows, cin, cout, w, bias, z,
+                                                         stats, zmax, zmin, amax, amin, as_stream(stream)))
+        return votenet::set_error(VOTENET_E_INVALID_ARGUMENT,
+                                  "mlp_linear_pool: shape not served (pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, "
+                                  "cout % 128 == 0, 16-byte aligned): use votenet_mlp_linear + votenet_bn_relu_max");
+    return check_launch("mlp_linear_pool");
+}
+
+extern "C" int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
+                                        const float *scale, const float *shift, int relu, float *out, int *argmax, void *stream)
+{
+    VN_REQUIRE(groups >= 0 && c > 0, "bn_pool_finalize expects groups >= 0, c > 0");
+    if (groups == 0) return VOTENET_OK;
+    VN_REQUIRE(zmax && zmin && amax && amin && scale && shift && out, "bn_pool_finalize: null buffer");
+    hipLaunchKernelGGL(bn_pool_finalize_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups * c, c, zmax,
+                       zmin, amax, amin, scale, shift, relu, out, argmax);
+    return check_launch("bn_pool_finalize");
 }
 
 extern "C" int votenet_bn_finalize(long rows, int c, const double *stats, const float *gamma, const float *beta, float eps,

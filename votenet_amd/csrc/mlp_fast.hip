@@ -35,6 +35,11 @@ constexpr int FG_LDA = FG_BM + 2;
 //   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
 //   EPI 1: sum g', sum g'*zhat with g' = z masked by [zprev*ps+pb > 0], zhat = (zprev-pmean)*rsqrt(pvar+eps)
 //          (the BatchNorm-backward reductions of the layer BELOW, whose da this GEMM has just produced)
+//   EPI 2: EPI 0 plus the max-pool of utils.py:132 over groups of 64 rows, BEFORE BatchNorm: the layer's scale/shift
+//          need the statistics of the whole launch, but max_k relu(s*z+h) = relu(s*max_k z + h) for s >= 0 and
+//          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
+//          group (+ arg rows) and votenet_bn_pool_finalize picks by the sign of the scale.  A wave's 2 x 32 rows
+//          are exactly one group (2x2 variant, WM = 2, MT = 2).
 struct FastArgs {
     const float *x, *in_scale, *in_shift;
     int in_relu;
@@ -50,7 +55,9 @@ struct FastArgs {
     long rows;
     int cin, cout;
     const float *w, *bias;
-    float *z;
+    float *z;              // may be NULL with EPI 2 (inference: only the pooled result is wanted)
+    float *zmax, *zmin;    // EPI 2: per 64-row group and channel, raw max / min of z ...
+    int *amax, *amin;      //        ... and the row offsets (first occurrence) where they are attained
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
@@ -304,6 +311,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         }
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
         const long m0 = ((long)blockIdx.x + t * gridDim.x) * FG_BM;
+        float pmaxv[NT], pminv[NT];
+        int pmaxi[NT], pmini[NT];
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            pmaxv[j] = pminv[j] = 0.0f;
+            pmaxi[j] = pmini[j] = 0;
+        }
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const int col = n0 + (wn * NT + j) * 32 + l31;
@@ -315,8 +329,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 for (int e = 0; e < 16; e++) {
                     const size_t off = off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout;
                     const float v = acc[i][j][e] + bv;
-                    z[off] = v;
-                    if (EPI == 0) {
+                    if (EPI != 2 || z != nullptr) z[off] = v;
+                    if (EPI == 2) {
+                        const int rloc = i * 32 + 4 * kh + (e & 3) + 8 * (e >> 2); // ascending in (i, e): strict compares keep
+                        if ((i == 0 && e == 0) || v > pmaxv[j]) {                  // the first occurrence
+                            pmaxv[j] = v;
+                            pmaxi[j] = rloc;
+                        }
+                        if ((i == 0 && e == 0) || v < pminv[j]) {
+                            pminv[j] = v;
+                            pmini[j] = rloc;
+                        }
+                    }
+                    if (EPI == 0 || EPI == 2) {
                         s1[j] += v;
                         s2[j] += v * v;
                     } else {
@@ -325,6 +350,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                         s1[j] += gq;
                         s2[j] += gq * ((zz - pmu[j]) * pinv[j]);
                     }
+                }
+            }
+        }
+        if (EPI == 2) {
+            // the other half-wave holds the interleaved rows of the same group: combine, smaller row wins ties
+            const long grp = m0 / 64 + wm;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const float ov = __shfl_xor(pmaxv[j], 32), uv = __shfl_xor(pminv[j], 32);
+                const int oi = __shfl_xor(pmaxi[j], 32), ui = __shfl_xor(pmini[j], 32);
+                if (ov > pmaxv[j] || (ov == pmaxv[j] && oi < pmaxi[j])) {
+                    pmaxv[j] = ov;
+                    pmaxi[j] = oi;
+                }
+                if (uv < pminv[j] || (uv == pminv[j] && ui < pmini[j])) {
+                    pminv[j] = uv;
+                    pmini[j] = ui;
+                }
+                if (lane < 32) {
+                    const size_t o = (size_t)grp * cout + n0 + (wn * NT + j) * 32 + l31;
+                    A.zmax[o] = pmaxv[j];
+                    A.zmin[o] = pminv[j];
+                    A.amax[o] = pmaxi[j];
+                    A.amin[o] = pmini[j];
                 }
             }
         }
@@ -398,6 +447,36 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
     a.z = z;
     a.stats = stats;
     return fast_dispatch<0, 0>(a, st);
+}
+
+// forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
+bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
+                            int cout, const float *w, const float *bias, float *z, double *stats, float *zmax, float *zmin,
+                            int *amax, int *amin, hipStream_t st)
+{
+    FastArgs a = {};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = cin;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.stats = stats;
+    a.zmax = zmax;
+    a.zmin = zmin;
+    a.amax = amax;
+    a.amin = amin;
+    const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
+    if (!aligned || cin % (2 * FG_BK) != 0 || cin > 512 || rows % FG_BM != 0 || rows == 0 || cout % 128 != 0) return false;
+    const long ntiles = rows / FG_BM;
+    const int ny = cout / 128;
+    const long gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
+    hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+    return true;
 }
 
 } // namespace votenet

@@ -128,6 +128,39 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     return z, stats
 
 
+def linear_pool_supported(rows, cin, cout, k):
+    """Shapes votenet_mlp_linear_pool serves (see include/votenet_hip.h)."""
+    return k == 64 and rows > 0 and rows % 128 == 0 and cin % 32 == 0 and cin <= 512 and cout % 128 == 0
+
+
+def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True):
+    """linear_dense whose epilogue also emits the raw max / min of every group of k rows: -> z or None, stats, pool where
+    pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool."""
+    rows, cin = x.shape
+    cout = w.shape[1]
+    g = rows // k
+    z = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if keep_z else None
+    stats = _zeros_f64(2 * cout, x.device)
+    vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
+    args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
+    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
+        L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
+                                                L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
+    return z, stats, (vals[0], vals[1], args[0], args[1])
+
+
+def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False):
+    zmax, zmin, amax, amin = pool
+    g, c = zmax.shape
+    out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
+    arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
+    with torch.cuda.device(zmax.device):
+        L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
+                                                 1 if relu else 0, L.ptr(out), L.ptr(arg), L.stream_ptr()))
+    return out, arg
+
+
 def group_linear(xyz, new_xyz, idx, P, w_xyz, bias=None, want_stats=True):
     """z (b*m*k, cout) = P[b, idx] + (xyz[idx] - new_xyz) @ w_xyz + bias with P (b, n, cout) = feat @ W[3:] computed per POINT
     (first SA layer, linear map before the grouping).  -> z, stats."""

@@ -16,6 +16,8 @@ single RCCL all-reduce over one contiguous gradient buffer per step.
 """
 import math
 
+import os
+
 import torch
 
 from . import mlp as M
@@ -98,16 +100,23 @@ def make_mlp(store, scope, cin, widths, prefix="conv", last_plain=False):
 # First SA layer: linear map before the grouping (see mlp_chain_forward).  False = the fused GATHER GEMM over the grouped
 # rows (votenet_mlp_linear with a GATHER input), kept for comparison and tests.
 PRE_LINEAR = True
+# Max-pool over the nsample rows of a group started in the last GEMM's epilogue (votenet_mlp_linear_pool) instead of a
+# separate pass over z (votenet_bn_relu_max).
+POOL_IN_EPILOGUE = os.environ.get('VOTENET_POOL_EPI', '1') != '0'
 
 
-def mlp_chain_forward(layers, rows, first, tape):
+def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
     """Run a chain of layers over `rows` rows.  first = ('gather', xyz, new_xyz, feat, idx) or ('dense', x).
     Returns (z_last, scale_last, shift_last): the last layer's RAW output and its folded BN
-    (None, None for a plain last layer).  Appends one record per layer to `tape`."""
+    (None, None for a plain last layer).  Appends one record per layer to `tape`.
+    pool_k > 0: the chain is followed by a max over groups of pool_k rows (utils.py:132); where the shape allows, the last
+    GEMM's epilogue starts the pool (raw max / min per group) and the last record carries 'pool' for bn_pool_finalize;
+    keep_z=False then skips the store of the last layer's z altogether (nothing downstream reads it in inference)."""
     z = sc = sh = None
     prev_relu = False
     for i, L in enumerate(layers):
         w, b = L.p("W"), L.p("b")
+        pool = None
         if i == 0 and first[0] == "gather":
             # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
             # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
@@ -124,6 +133,10 @@ def mlp_chain_forward(layers, rows, first, tape):
         elif i == 0:
             zn, st = M.linear_dense(first[1], w, b, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=first[1], in_scale=None, in_shift=None, in_relu=False)
+        elif pool_k and i == len(layers) - 1 and L.bn and POOL_IN_EPILOGUE and \
+                M.linear_pool_supported(rows, w.shape[0], w.shape[1], pool_k):
+            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, sc, sh, prev_relu, keep_z=keep_z)
+            rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
         else:
             zn, st = M.linear_dense(z, w, b, sc, sh, prev_relu, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
@@ -132,7 +145,7 @@ def mlp_chain_forward(layers, rows, first, tape):
             rec.update(scale=sc, shift=sh, mean=mean, var=var)
         else:
             sc = sh = None
-        rec.update(z=zn, rows=rows)
+        rec.update(z=zn, rows=rows, pool=pool)
         tape.append(rec)
         z, prev_relu = zn, L.relu
     return z, sc, sh
@@ -276,8 +289,12 @@ class SAModule:
         fps_idx, new_xyz, idx, pts_cnt = geom if geom is not None else self.geometry(xyz, sample_xyz)
         recs = []
         rows = b * self.npoint * self.nsample
-        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs)
-        pooled, argmax = M.bn_relu_max(z, self.nsample, sc, sh, True, want_argmax=tape is not None)  # utils.py:132
+        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs, pool_k=self.nsample,
+                                      keep_z=tape is not None)
+        if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
+            pooled, argmax = M.bn_pool_finalize(recs[-1]["pool"], sc, sh, True, want_argmax=tape is not None)
+        else:
+            pooled, argmax = M.bn_relu_max(z, self.nsample, sc, sh, True, want_argmax=tape is not None)
         recs2 = []
         out = pooled
         if self.mlp2:
