@@ -95,3 +95,72 @@ def test_predict_tail_nms_vs_oracle(hiplib, dev, O):
     if not (np.abs(iou - 0.25) < 1e-5).any() and len(np.unique(score)) == score.size:
         assert (got == exp).all()
     assert got.shape[1] == 2 and (obj[got[:, 0], got[:, 1], 1] > obj[got[:, 0], got[:, 1], 0]).all()
+
+
+def _brute_ball(xyz, centre, r, k):
+    """First-k-in-index-order neighbours of one centre, float32 arithmetic as tf_grouping_g.cu:14-24 (torch reference)."""
+    d = xyz - centre
+    s = (d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]) + d[:, 2] * d[:, 2]
+    hit = torch.nonzero(torch.sqrt(s).clamp_min(1e-20) < r)[:, 0]
+    return hit[:k]
+
+
+def test_config5_dense_scan_forward_properties(hiplib, dev):
+    """BASELINE config 5 (4 x 80 000-point scenes, 2048 -> 1024 seeds -> 512 -> 256, 256 proposals) at full size: the CPU
+    oracle would take minutes, so the checks are size-independent properties of the path's pieces."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth, tf_sampling as S
+    x = torch.from_numpy(synth.room_batch(4, 80000, 77, size=(8.0, 3.0, 8.0), nbox=(15, 25))).to(dev)  # SURVEY 8d, config 5
+    net = VM.VoteNetHotPath(dev, seed=3)
+    tape = []
+    out = net.forward(x, tape)
+    assert out["proposals_output"].shape == (4, 256, 79) and out["seeds_xyz"].shape == (4, 1024, 3)
+    for v in out.values():
+        assert torch.isfinite(v).all()
+    sa1 = tape[0]
+    fidx = sa1["fps_idx"].long()
+    assert (fidx[:, 0] == 0).all() and all(len(torch.unique(fidx[s])) == 2048 for s in range(4))
+    assert (S.farthest_point_sample(300, x).long() == fidx[:, :300]).all()  # FPS prefixes nest
+    # every FPS pick attains the maximum of the running min distance (float64 recomputation, first 200 picks of a scene)
+    p = x[1].double()
+    td = torch.full((80000,), float("inf"), dtype=torch.float64, device=dev)
+    for j in range(1, 200):
+        td = torch.minimum(td, ((p - p[fidx[1, j - 1]]) ** 2).sum(1))
+        assert td[fidx[1, j]] >= td.max() * (1 - 1e-5)
+    # ball query rows = first-K-in-index-order neighbours, padded with the first hit (sample of centres)
+    idx, cnt, new_xyz = sa1["idx"], sa1["pts_cnt"], sa1["new_xyz"]
+    assert torch.equal(new_xyz, torch.gather(x, 1, fidx[..., None].expand(-1, -1, 3)))
+    g = torch.Generator().manual_seed(0)
+    for s, j in zip(torch.randint(0, 4, (40,), generator=g).tolist(), torch.randint(0, 2048, (40,), generator=g).tolist()):
+        ref = _brute_ball(x[s], new_xyz[s, j], 0.2, 64)
+        c = int(cnt[s, j])
+        assert c == len(ref) and torch.equal(idx[s, j, :c].long(), ref)
+        assert (idx[s, j, c:] == idx[s, j, 0]).all()
+    # the pooled layer output is permutation-invariant inside a group only through max: recompute one group by hand
+    r2 = sa1["recs"][-1]
+    act = r2["z"].view(4 * 2048, 64, -1) * r2["scale"] + r2["shift"]
+    pooled = torch.where(act > 0, act, torch.zeros_like(act)).amax(1)
+    assert torch.equal(pooled.view(4, 2048, -1), net.sa1.forward(x, x, tape=None, geom=(sa1["fps_idx"], new_xyz, idx, cnt))[1])
+
+
+def test_full_size_train_steps(hiplib, dev):
+    """BASELINE config 3 shape (8 x 20 480 points): two optimizer steps run, gradients are finite and non-trivial, the
+    parameters move, and the forward output of an unchanged input changes accordingly."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    x = torch.from_numpy(synth.room_batch(8, 20480, 1000)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=0)
+    cot = net.make_cotangents(8, seed=0)
+    net.init_optimizer(1e-3)
+    before = net.store.flat.clone()
+    out0 = net.forward(x)["proposals_output"].clone()
+    for _ in range(2):
+        net.train_step(x, cot, 1)
+    torch.cuda.synchronize()
+    g = net.store.grad
+    assert torch.isfinite(g).all() and torch.isfinite(net.store.flat).all()
+    assert float((g != 0).float().mean()) > 0.5
+    step = (net.store.flat - before).abs()
+    assert float(step.max()) <= 2.0e-3 * 1.001 and float(step.mean()) > 1e-4  # Adam: |delta| <= lr per step
+    out1 = net.forward(x)["proposals_output"]
+    assert not torch.equal(out0, out1) and torch.isfinite(out1).all()
