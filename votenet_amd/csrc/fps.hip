@@ -373,6 +373,18 @@ __global__ __launch_bounds__(1024) void fps_bucket_sort_kernel(int n, const floa
 // NW waves per scene, P = VW (16 or 32) slots per lane.  Bucket g (64 consecutive Morton-sorted points) is slot
 // g / NW of wave g % NW, so spatial neighbours sit in different waves.  Lane i (< P) of a wave additionally
 // holds the metadata of that wave's bucket i: bounding box, max running distance, arg-max key and lane.
+#ifdef FPS_TRACE
+__device__ unsigned long long g_fps_trace[8]; // cycles summed over rounds, per phase, wave 0 of block 0
+#define FPS_T(i)                                                                        \
+    do {                                                                                \
+        const unsigned long long _t = __builtin_amdgcn_s_memtime();                     \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                              \
+        if (blockIdx.x == 0 && tid == 0) g_fps_trace[i] += _t - _tprev;                 \
+        _tprev = _t;                                                                    \
+    } while (0)
+#else
+#define FPS_T(i)
+#endif
 template <int NW, int VW>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
                                                              const int *__restrict__ perm, const float *__restrict__ bbox,
@@ -427,7 +439,11 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     float cx = pts[0], cy = pts[1], cz = pts[2];
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+#ifdef FPS_TRACE
+    unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
     for (int j = 1; j < m; j++) {
+        FPS_T(0); // loop back-edge + output bookkeeping
         // (1) which of this wave's buckets can change?  lower bound of the distance to the bucket box,
         //     shrunk by 1e-5 so that it is below every fp32-evaluated point distance of the bucket.
         const float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
@@ -435,6 +451,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
         const float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
         const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
         unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+        FPS_T(1); // box tests + ballot
         // (2) update the active buckets, refresh their cached arg-max
         bool changed = false; // uniform: did any cached bucket entry of this wave change this round?
         while (act) {
@@ -460,6 +477,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
                 changed = true;
             }
         }
+        FPS_T(2); // touched buckets
         // (3) wave winner over the cached bucket entries (lanes < P).  It can only change when one of this
         //     wave's bucket entries changed; otherwise last round's winner (uniform registers) is reused.
         if (changed || j == 1) {
@@ -469,7 +487,9 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
             cw_y = readlane_f32(Y[ws], fl);
             cw_z = readlane_f32(Z[ws], fl);
         }
+        FPS_T(3); // wave winner
         const FpsWinner win = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j);
+        FPS_T(4); // cross-wave stage (includes the wait for the slowest wave)
         cx = win.x;
         cy = win.y;
         cz = win.z;
@@ -675,6 +695,17 @@ __global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m
     }
 }
 
+#ifdef FPS_TRACE
+extern "C" void votenet_fps_trace_read(unsigned long long *out, int reset)
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(votenet::g_fps_trace), sizeof(unsigned long long) * 8);
+    if (reset) {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(votenet::g_fps_trace), z, sizeof(z));
+    }
+}
+#endif
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
 static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)

@@ -154,7 +154,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
 # Let the dgrad GEMM's epilogue also accumulate the BatchNorm-backward sums of the layer below (votenet_mlp_dgrad_bn
 # p_sums).  Measured on MI355X (tools/bench_bwd.py) the epilogue's zprev reads are exposed latency and cost slightly
 # more than the standalone reduction pass they replace, so the default keeps the separate pass.
-FUSE_BN_REDUCE = False
+FUSE_BN_REDUCE = os.environ.get('VOTENET_FUSE_REDUCE', '0') == '1'
 
 
 # Weight gradients hang off the backward chain (reduce -> coef -> dgrad -> reduce ...): nothing downstream needs them before
