@@ -244,7 +244,7 @@ int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout,
                       void *stream);
 
 /* ---- BatchNorm backward folded into the two backward GEMMs (no dz tensor in memory) -----------------
- * With sums = [sum g', sum g'*zhat] (votenet_bn_backward_reduce, or the fused epilogue below) the
+ * With sums = [sum g', sum g'*zhat] (votenet_bn_backward_reduce) the
  * gradient of a BatchNorm'ed layer is per element  dz = A*g' + B + C*z,  g' = g masked by the ReLU
  * [z*scale+shift > 0] (and, for a max-pooled output, by row%k == argmax[row/k]).
  * votenet_bn_backward_coef writes coef = [A | B | C | scale | shift] (5*c floats) and accumulates
@@ -260,17 +260,13 @@ int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int co
                          int relu, float *dw, void *stream);
 
 /* da_prev (rows x cout) = dz (rows x c) * wT (c x cout), dz formed as above from (da | gout+argmax, zsrc,
- * coef).  If p_sums != NULL (2*cout doubles, pre-zeroed) the epilogue also accumulates the
- * votenet_bn_backward_reduce sums of the layer below: its raw output zprev (rows x cout), statistics
- * p_scale/p_shift/p_mean/p_var (cout each) and ReLU flag p_relu.
+ * coef) inside the operand loader.
  * Shapes served: rows % 128 == 0, c % 32 == 0, c <= 512, cout == 64 or cout % 128 == 0, 16-byte aligned
  * buffers; anything else returns VOTENET_E_INVALID_ARGUMENT (use votenet_bn_backward_apply +
  * votenet_mlp_linear instead). */
 int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,
                          int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
-                         float *da_prev, const float *zprev, const float *p_scale, const float *p_shift,
-                         const float *p_mean, const float *p_var, float eps, int p_relu, double *p_sums,
-                         void *stream);
+                         float *da_prev, void *stream);
 
 /* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78) on the
  * feature columns + the gradients of grouped_xyz - tile(new_xyz) on the xyz columns.  The per-row input

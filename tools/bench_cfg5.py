@@ -1,8 +1,8 @@
-import sys, torch, time
-sys.path.insert(0, "/root/repo")
+import os, sys, torch, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from votenet_amd import synth, tf_sampling as S, tf_grouping as G
 from votenet_amd.model import VoteNetHotPath
-sys.path.insert(0, "/root/repo/tools")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from bench_mlp_util import timeit
 dev = torch.device("cuda:0")
 x = torch.from_numpy(synth.room_batch(4, 80000, 5)).to(dev)

@@ -1,5 +1,5 @@
 import sys, time, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from votenet_amd import synth
 from votenet_amd.model import VoteNetHotPath
 dev = torch.device("cuda:0")

@@ -81,7 +81,7 @@ _SIGS.update({
     "votenet_mlp_wgrad_bn": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int]
                             + [_c_f] * 2 + [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_mlp_dgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int]
-                            + [_c_f] * 7 + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.c_void_p],
+                            + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
     "votenet_clip_adam": [ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                                               ctypes.c_void_p],

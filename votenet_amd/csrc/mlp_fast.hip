@@ -33,8 +33,7 @@ constexpr int FG_LDA = FG_BM + 2;
 //          coef = [A | B | C | S | H], 5*cin floats (votenet_bn_backward_coef)
 // EPI selects the statistics accumulated next to the store of the output z (rows x cout):
 //   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
-//   EPI 1: sum g', sum g'*zhat with g' = z masked by [zprev*ps+pb > 0], zhat = (zprev-pmean)*rsqrt(pvar+eps)
-//          (the BatchNorm-backward reductions of the layer BELOW, whose da this GEMM has just produced)
+//   EPI 1: no statistics (input-gradient GEMMs)
 //   EPI 2: EPI 0 plus the max-pool of utils.py:132 over groups of 64 rows, BEFORE BatchNorm: the layer's scale/shift
 //          need the statistics of the whole launch, but max_k relu(s*z+h) = relu(s*max_k z + h) for s >= 0 and
 //          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
@@ -48,9 +47,6 @@ struct FastArgs {
     int pool_k;
     const float *zsrc, *coef;
     int src_relu;
-    const float *zprev, *p_scale, *p_shift, *p_mean, *p_var;
-    float eps;
-    int p_relu;
     double *stats;
     long rows;
     int cin, cout;
@@ -250,20 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     __syncthreads();
 
     const int kh = lane >> 5, l31 = lane & 31;
-    // EPI 1: per-column constants of the layer below (columns of this lane)
-    float ps[NT], pb2[NT], pmu[NT], pinv[NT];
-    if (EPI == 1) {
-#pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int col = n0 + (wn * NT + j) * 32 + l31;
-            ps[j] = A.p_scale[col];
-            pb2[j] = A.p_shift[col];
-            pmu[j] = A.p_mean[col];
-            pinv[j] = 1.0f / sqrtf(A.p_var[col] + A.eps);
-        }
-    }
     int buf = 0;
-    long steps_left = my_tiles * nk; // steps still to compute, including the current one
     for (long t = 0; t < my_tiles; t++) {
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -306,7 +289,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 }
                 lds_barrier(); // LDS only: the prefetched global loads stay in flight across it
                 buf ^= 1;
-                --steps_left;
             }
         }
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
@@ -344,11 +326,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                     if (EPI == 0 || EPI == 2) {
                         s1[j] += v;
                         s2[j] += v * v;
-                    } else {
-                        const float zz = A.zprev[off];
-                        const float gq = (A.p_relu && !(zz * ps[j] + pb2[j] > 0.0f)) ? 0.0f : v;
-                        s1[j] += gq;
-                        s2[j] += gq * ((zz - pmu[j]) * pinv[j]);
                     }
                 }
             }
@@ -378,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             }
         }
     }
-    if (A.stats) {
+    if (EPI != 1 && A.stats) {
         // combine the WM waves that share a column block in LDS (the operand buffers are free now: every wave is past
         // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
         // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
@@ -446,7 +423,7 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
     a.bias = bias;
     a.z = z;
     a.stats = stats;
-    return fast_dispatch<0, 0>(a, st);
+    return stats ? fast_dispatch<0, 0>(a, st) : fast_dispatch<0, 1>(a, st); // no statistics wanted: skip their arithmetic
 }
 
 // forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
@@ -484,11 +461,10 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
 using namespace votenet;
 
 // da_prev (rows x cout) = dz (rows x c) * wT (c x cout) with dz = BatchNorm-backward(da | pooled gout, zsrc, coef)
-// formed inside the A-operand loader; optionally also the BatchNorm-backward reductions of the layer below.
+// formed inside the A-operand loader.
 extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,
                                     int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
-                                    float *da_prev, const float *zprev, const float *p_scale, const float *p_shift,
-                                    const float *p_mean, const float *p_var, float eps, int p_relu, double *p_sums, void *stream)
+                                    float *da_prev, void *stream)
 {
     VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "mlp_dgrad_bn expects rows > 0, c > 0, cout > 0");
     VN_REQUIRE((da != nullptr) != (gout != nullptr), "mlp_dgrad_bn: exactly one of da / gout");
@@ -507,22 +483,8 @@ extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da,
     a.cout = cout;
     a.w = wT;
     a.z = da_prev;
-    a.zprev = zprev;
-    a.p_scale = p_scale;
-    a.p_shift = p_shift;
-    a.p_mean = p_mean;
-    a.p_var = p_var;
-    a.eps = eps;
-    a.p_relu = p_relu;
-    a.stats = p_sums;
     hipStream_t st = as_stream(stream);
-    bool ok;
-    if (p_sums) {
-        VN_REQUIRE(zprev && p_scale && p_shift && p_mean && p_var, "mlp_dgrad_bn: fused reduction needs the statistics of the layer below");
-        ok = da ? fast_dispatch<1, 1>(a, st) : fast_dispatch<2, 1>(a, st);
-    } else {
-        ok = da ? fast_dispatch<1, 0>(a, st) : fast_dispatch<2, 0>(a, st);
-    }
+    const bool ok = da ? fast_dispatch<1, 1>(a, st) : fast_dispatch<2, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn: shape not supported by the fused kernel (use votenet_bn_backward_apply + votenet_mlp_linear)");
     return check_launch("mlp_dgrad_bn");
 }

@@ -280,23 +280,15 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
                                              L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.stream_ptr()))
 
 
-def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None, eps=BN_EPS):
-    """da_prev = dz @ wT with dz formed in the loader.  below = (zprev, scale, shift, mean, var, relu) of the layer
-    underneath: its BatchNorm-backward sums are then accumulated by the epilogue.  -> da_prev, sums or None."""
+def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0):
+    """da_prev = dz @ wT with dz = BatchNorm-backward(da | pooled gout, z, coef) formed in the loader."""
     rows, c = z.shape
     cout = wT.shape[1]
     out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
-    sums = None
-    zp = ps = pb = pm = pv = None
-    prelu = 0
-    if below is not None:
-        zp, ps, pb, pm, pv, prelu = below
-        sums = _zeros_f64(2 * cout, z.device)
     with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
-                                             1 if relu else 0, L.ptr(wT), L.ptr(out), L.ptr(zp), L.ptr(ps), L.ptr(pb), L.ptr(pm),
-                                             L.ptr(pv), float(eps), 1 if prelu else 0, L.ptr(sums), L.stream_ptr()))
-    return out, sums
+                                             1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))
+    return out
 
 
 def bias_grad(dz, dbias):

@@ -151,12 +151,6 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
     return z, sc, sh
 
 
-# Let the dgrad GEMM's epilogue also accumulate the BatchNorm-backward sums of the layer below (votenet_mlp_dgrad_bn
-# p_sums).  Measured on MI355X (tools/bench_bwd.py) the epilogue's zprev reads are exposed latency and cost slightly
-# more than the standalone reduction pass they replace, so the default keeps the separate pass.
-FUSE_BN_REDUCE = os.environ.get('VOTENET_FUSE_REDUCE', '0') == '1'
-
-
 # Weight gradients hang off the backward chain (reduce -> coef -> dgrad -> reduce ...): nothing downstream needs them before
 # the optimizer.  When the owner sets WGRAD_STREAM (a second HIP stream) they are launched there, concurrently with the input
 # gradient of the same layer; wgrad_join() makes the current stream wait for them.  Tensors a side-stream kernel reads are
@@ -200,7 +194,7 @@ def wgrad_join():
         _wgrad_pending = False
 
 
-def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, need_xyz_grad=False):
+def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
@@ -210,7 +204,6 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
     dict(dz=...) (rows, cout) or dict(da=, coef=, relu=) when the fused first-layer backward kernel will form dz itself:
     SAModule.backward finishes the layer (weight gradient, point gradients)."""
     da = g
-    sums = None  # BatchNorm-backward reductions of the current layer when the GEMM above already produced them
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
         L = r["layer"]
@@ -220,10 +213,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
         want_da = i > 0 or need_input_grad
         if L.bn:
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
-            if sums is None:
-                sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
+            sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
             coef = M.bn_backward_coef(rows, *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
-            sums = None
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
                 # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
@@ -233,11 +224,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, ne
                                      in_relu=r["in_relu"], **src)
                 if not want_da:
                     return None
-                below = None
-                if FUSE_BN_REDUCE and i > 0 and recs[i - 1]["layer"].bn:
-                    rp = recs[i - 1]
-                    below = (rp["z"], rp["scale"], rp["shift"], rp["mean"], rp["var"], rp["layer"].relu)
-                da, sums = M.dgrad_bn(z, coef, L.relu, L.p("W").t().contiguous(), below=below, **src)
+                da = M.dgrad_bn(z, coef, L.relu, L.p("W").t().contiguous(), **src)
                 continue
             if i == 0 and r["kind"] == "gather" and PRE_LINEAR and not pooled and r["feat"] is not None and \
                     M.group_linear_backward_supported(c, r["idx"].shape[2]):
@@ -313,8 +300,7 @@ class SAModule:
         if self.mlp2:
             g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
         need_feat = need_feat_grad and rec["points"] is not None
-        h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample,
-                               need_input_grad=need_feat, need_xyz_grad=need_xyz_grad)
+        h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_feat)
         return self._first_layer_backward(rec, h, need_feat, need_xyz_grad)
 
     def _first_layer_backward(self, rec, h, need_feat, need_xyz_grad):
