@@ -300,30 +300,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             pmaxv[j] = pminv[j] = 0.0f;
             pmaxi[j] = pmini[j] = 0;
         }
+        const bool store_z = (EPI != 2) || z != nullptr; // wave-uniform: the stores sit in their own loop nest so that the
+        if (store_z) {                                   // pooling arithmetic below is not scheduled around 64 addresses
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            const int col = n0 + (wn * NT + j) * 32 + l31;
-            const float bv = A.bias ? A.bias[col] : 0.0f;
+            for (int j = 0; j < NT; j++) {
+                const int col = n0 + (wn * NT + j) * 32 + l31;
+                const float bv = A.bias ? A.bias[col] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < MT; i++) {
-                const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
+                for (int i = 0; i < MT; i++) {
+                    const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
 #pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const size_t off = off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout;
-                    const float v = acc[i][j][e] + bv;
-                    if (EPI != 2 || z != nullptr) z[off] = v;
-                    if (EPI == 2) {
-                        const int rloc = i * 32 + 4 * kh + (e & 3) + 8 * (e >> 2); // ascending in (i, e): strict compares keep
-                        if ((i == 0 && e == 0) || v > pmaxv[j]) {                  // the first occurrence
-                            pmaxv[j] = v;
-                            pmaxi[j] = rloc;
+                    for (int e = 0; e < 16; e++) z[off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout] = acc[i][j][e] + bv;
+                }
+            }
+        }
+        if (EPI == 0 || EPI == 2) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int col = n0 + (wn * NT + j) * 32 + l31;
+                const float bv = A.bias ? A.bias[col] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+#pragma unroll
+                    for (int e = 0; e < 16; e++) {
+                        const float v = acc[i][j][e] + bv;
+                        if (EPI == 2) {
+                            const int rloc = i * 32 + 4 * kh + (e & 3) + 8 * (e >> 2); // ascending in (i, e): strict compares
+                            if ((i == 0 && e == 0) || v > pmaxv[j]) {                  // keep the first occurrence
+                                pmaxv[j] = v;
+                                pmaxi[j] = rloc;
+                            }
+                            if ((i == 0 && e == 0) || v < pminv[j]) {
+                                pminv[j] = v;
+                                pmini[j] = rloc;
+                            }
                         }
-                        if ((i == 0 && e == 0) || v < pminv[j]) {
-                            pminv[j] = v;
-                            pmini[j] = rloc;
-                        }
-                    }
-                    if (EPI == 0 || EPI == 2) {
                         s1[j] += v;
                         s2[j] += v * v;
                     }
