@@ -237,6 +237,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
     if (my_tiles == 0) return;
     __syncthreads(); // Sco
+    // bias of this lane's columns, loaded ONCE and consumed (the empty asm) before any prefetch is in flight: a load inside
+    // the per-tile epilogue -- or one still pending in the compiler's bookkeeping -- costs an s_waitcnt vmcnt(0) there,
+    // i.e. drains both prefetch sets at every tile boundary (every 4 slabs at cin = 64)
+    float bvs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        bvs[j] = A.bias ? A.bias[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 0.0f;
+        asm volatile("" : "+v"(bvs[j]));
+    }
     // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
     issue_loads(R[0]);
     store_regs(0, R[0]);
@@ -305,7 +314,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const int col = n0 + (wn * NT + j) * 32 + l31;
-                const float bv = A.bias ? A.bias[col] : 0.0f;
+                const float bv = bvs[j];
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
                     const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
@@ -317,8 +326,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         if (EPI == 0 || EPI == 2) {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const int col = n0 + (wn * NT + j) * 32 + l31;
-                const float bv = A.bias ? A.bias[col] : 0.0f;
+                const float bv = bvs[j];
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
 #pragma unroll
