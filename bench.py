@@ -6,7 +6,7 @@
 One "step" = one pass of the hot path over one batch of 8 synthetic 20480-point scenes per GPU
 (BASELINE.json configs[2]/[3]: VoteNet layer stack sa1..sa4, fp1, fp2, voting, proposal).
 Workloads:
-    train : forward + backward + (N>1: one RCCL all-reduce of the flat gradient bucket) + Adam
+    train : forward + the reference's loss graph + backward + (N>1: one RCCL all-reduce of the flat gradient bucket) + Adam
     fwd   : forward only (BASELINE.json configs[1] plus voting + proposal)
 Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
 """
@@ -111,14 +111,18 @@ def main():
     from votenet_amd import dp
     x = torch.from_numpy(gen(B, n, dp.scene_seeds(rank, B)[0])).to(dev)  # disjoint seeds per rank, resident in HBM
     net = VM.VoteNetHotPath(dev, seed=0)
-    cot = None
+    cot = gt = None
     if workload == "train":
-        cot = net.make_cotangents(B, seed=rank)
+        if args.scene == "room":  # the generating boxes are the ground truth: the reference's loss graph drives the backward
+            from votenet_amd import loss as vloss
+            gt = vloss.gt_to_device(synth.room_gt(B, n, dp.scene_seeds(rank, B)[0]), dev)
+        else:                     # uniform cubes have no objects: fixed cotangents instead
+            cot = net.make_cotangents(B, seed=rank)
         dp.broadcast_params(net.store)
 
     def step():
         if workload == "train":
-            net.train_step(x, cot, world)
+            net.train_step(x, cot, world, gt=gt)
         else:
             net.forward(x)
 
@@ -226,7 +230,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VoteNet hot path %s: sa1-4 + fp1-2 + voting + proposal, %d scenes x %d pts per GPU, "
-                                    "%s scenes" % ("train step (fwd+bwd+Adam, synthetic cotangents in place of the loss graph)"
+                                    "%s scenes" % (("train step (fwd + loss graph of model.py:61-84,141-231 + bwd + clip/Adam)" if args.scene == "room" else
+                                                    "train step (fwd+bwd+Adam, fixed cotangents)")
                                                    if workload == "train" else "forward", B, n, args.scene)),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,

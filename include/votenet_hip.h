@@ -288,6 +288,25 @@ int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scratch, float
                       float lr, float beta1, float beta2, float eps, int step, float grad_scale, float clip_avg_norm,
                       void *stream);
 
+/* ---------------------------------------------------------------- loss graph (caller of the hot path: SURVEY 8f-1)
+ * The reference's total cost (model.py:61-84 vote targets + vote regression, :147-212 proposal assignment,
+ * objectness, centre + Chamfer centre, heading, size, semantic losses, :205,228 weights) and its cotangents
+ * with respect to votes_xyz (b,n_seeds,3), proposals_xyz (b,n_prop,3) and proposals_output
+ * (b,n_prop,5+2*nh+4*ns+nc) -- the three tensors through which the cost reaches the hot path.  Ground
+ * truth in the reference's input layout (model.py:22-32): bboxes_xyz / bboxes_lwh (b,n_box,3), bboxes_roty,
+ * semantic / heading / size labels (b,n_box), heading_residuals (b,n_box), size_residuals (b,n_box,3); ragged
+ * scenes are padded by repeating a box (run.py:14-24).  The three d_* buffers must be zero on entry.
+ * losses (12 floats): total_cost, vote_reg_loss, obj_cls_loss, center_loss (incl. the dual term),
+ * heading_cls_loss, heading_residual_loss, size_cls_loss, size_residual_loss, sem_cls_loss, box_loss,
+ * #positive, #negative proposals.  No positive (or no negative) proposal: the affected means are NaN, as
+ * tf.reduce_mean of an empty tensor. */
+int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
+                 const float *votes_xyz, const float *proposals_xyz, const float *proposals_output,
+                 const float *bboxes_xyz, const float *bboxes_lwh, const float *bboxes_roty,
+                 const int *semantic_labels, const int *heading_labels, const float *heading_residuals,
+                 const int *size_labels, const float *size_residuals, float pos_thr, float neg_thr, float *losses,
+                 float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,13 +149,15 @@ def test_full_size_train_steps(hiplib, dev):
     from votenet_amd import model as VM
     from votenet_amd import synth
     x = torch.from_numpy(synth.room_batch(8, 20480, 1000)).to(dev)
+    from votenet_amd import loss as VL
     net = VM.VoteNetHotPath(dev, seed=0)
-    cot = net.make_cotangents(8, seed=0)
+    gt = VL.gt_to_device(synth.room_gt(8, 20480, 1000), dev)
     net.init_optimizer(1e-3)
     before = net.store.flat.clone()
     out0 = net.forward(x)["proposals_output"].clone()
     for _ in range(2):
-        net.train_step(x, cot, 1)
+        net.train_step(x, gt=gt)
+    assert torch.isfinite(net.last_losses[1]) and net.last_losses[11] > 0  # vote loss finite, negatives exist
     torch.cuda.synchronize()
     g = net.store.grad
     assert torch.isfinite(g).all() and torch.isfinite(net.store.flat).all()

@@ -1,0 +1,260 @@
+// loss.hip -- the reference's loss graph (model.py:61-84, 141-231) as ONE kernel: vote targets (rotated-box membership,
+// nearest ground-truth centre), proposal assignment (nearest centre, positive / negative by distance), objectness,
+// centre + Chamfer ("dual") centre, heading, size and semantic losses, the total cost -- and the cotangents of that cost
+// with respect to votes_xyz, proposals_xyz and proposals_output, which is what the backward pass of the hot path needs.
+// The reference spends ~120 TensorFlow ops (gather_nd / where / one_hot / reduce_mean ...) on a few thousand elements; here
+// one workgroup walks them (B*1024 seeds, B*256 proposals, <= 16 boxes per scene): the step is launch-latency, not work.
+// Reductions are wave shuffles + a fixed-order combine: the loss values are reproducible bit for bit.
+#include "common.h"
+
+namespace votenet {
+
+constexpr int LOSS_T = 1024;
+constexpr int LOSS_MAXC = 32;  // nh, ns, nc <= 32
+constexpr int LOSS_NACC = 12;
+
+struct LossArgs {
+    int b, n, p, bb, nh, ns, nc;
+    const float *seeds, *votes, *pxyz, *pout;
+    const float *gxyz, *glwh, *groty;
+    const int *sem, *hlab, *slab;
+    const float *hres, *sres;
+    float pos_thr, neg_thr;
+    float *losses, *d_votes, *d_pxyz, *d_pout;
+};
+
+__device__ __forceinline__ float huber(float e, float &grad) // tf.losses.huber_loss, delta = 1: e = prediction - label
+{
+    const float a = fabsf(e);
+    grad = a <= 1.0f ? e : (e > 0.0f ? 1.0f : -1.0f);
+    return a <= 1.0f ? 0.5f * e * e : a - 0.5f;
+}
+
+// softmax cross entropy of `c` logits (stride 1) against `label`; probs[] receives softmax - onehot
+__device__ __forceinline__ float softmax_ce(const float *lg, int c, int label, float *probs)
+{
+    float m = lg[0];
+    for (int i = 1; i < c; i++) m = fmaxf(m, lg[i]);
+    float s = 0.0f;
+    for (int i = 0; i < c; i++) {
+        probs[i] = expf(lg[i] - m);
+        s += probs[i];
+    }
+    const float inv = 1.0f / s;
+    for (int i = 0; i < c; i++) probs[i] = probs[i] * inv - (i == label ? 1.0f : 0.0f);
+    return logf(s) + m - lg[label];
+}
+
+__global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
+{
+    __shared__ int s_np, s_nn;
+    __shared__ float s_red[LOSS_T / 64][LOSS_NACC];
+    const int tid = threadIdx.x;
+    const int B = A.b, N = A.n, P = A.p, BB = A.bb, NH = A.nh, NS = A.ns, NC = A.nc;
+    const int W = 5 + 2 * NH + 4 * NS + NC; // width of proposals_output (79)
+    // per-box constants once: cos / sin of -roty (the seed loop would otherwise evaluate them B*N*BB times)
+    __shared__ float s_cs[256][2];
+    for (int e = tid; e < B * BB && e < 256; e += LOSS_T) {
+        s_cs[e][0] = cosf(-A.groty[e]);
+        s_cs[e][1] = sinf(-A.groty[e]);
+    }
+    if (tid == 0) s_np = s_nn = 0;
+    __syncthreads();
+    // ---- proposals: nearest ground-truth centre, positive / negative (model.py:147-153)
+    int np_local = 0, nn_local = 0;
+    for (int q = tid; q < B * P; q += LOSS_T) {
+        const int b = q / P;
+        const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
+        float best = 0.0f;
+        for (int j = 0; j < BB; j++) {
+            const float dx = px - A.gxyz[(b * BB + j) * 3 + 0], dy = py - A.gxyz[(b * BB + j) * 3 + 1],
+                        dz = pz - A.gxyz[(b * BB + j) * 3 + 2];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (j == 0 || d < best) best = d;
+        }
+        np_local += best < A.pos_thr;
+        nn_local += best > A.neg_thr;
+    }
+    if (np_local) atomicAdd(&s_np, np_local);
+    if (nn_local) atomicAdd(&s_nn, nn_local);
+    __syncthreads();
+    const float inv_np = 1.0f / (float)s_np, inv_nn = 1.0f / (float)s_nn; // empty set -> inf -> NaN loss, as reduce_mean of []
+    // accumulators: 0 vote, 1 obj_pos, 2 obj_neg, 3 center, 4 center_dual, 5 hcls, 6 hres, 7 scls, 8 sres, 9 sem
+    float acc[LOSS_NACC];
+#pragma unroll
+    for (int i = 0; i < LOSS_NACC; i++) acc[i] = 0.0f;
+    float pr[LOSS_MAXC];
+    // ---- proposals: losses and cotangents (model.py:156-212); every weight of model.py:205,228 folded in
+    for (int q = tid; q < B * P; q += LOSS_T) {
+        const int b = q / P;
+        const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
+        float best = 0.0f;
+        int g = 0;
+        for (int j = 0; j < BB; j++) {
+            const float dx = px - A.gxyz[(b * BB + j) * 3 + 0], dy = py - A.gxyz[(b * BB + j) * 3 + 1],
+                        dz = pz - A.gxyz[(b * BB + j) * 3 + 2];
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (j == 0 || d < best) { // tf.argmin: first minimum
+                best = d;
+                g = j;
+            }
+        }
+        const float *o = A.pout + (size_t)q * W;
+        float *go = A.d_pout + (size_t)q * W;
+        const bool pos = best < A.pos_thr, neg = best > A.neg_thr;
+        if (pos || neg) { // objectness, weight 0.5 (a proposal can only be one of the two: pos_thr < neg_thr)
+            const float l = softmax_ce(o, 2, pos ? 1 : 0, pr);
+            const float w = 0.5f * (pos ? inv_np : inv_nn);
+            acc[pos ? 1 : 2] += l;
+            go[0] = pr[0] * w;
+            go[1] = pr[1] * w;
+        }
+        if (pos) {
+            const int gi = b * BB + g;
+            // centre (weight 1): error = prediction - (gt centre - proposal centre)
+            const float cg[3] = {A.gxyz[gi * 3 + 0] - px, A.gxyz[gi * 3 + 1] - py, A.gxyz[gi * 3 + 2] - pz};
+            for (int k = 0; k < 3; k++) {
+                float gr;
+                acc[3] += huber(o[2 + k] - cg[k], gr);
+                unsafeAtomicAdd(&go[2 + k], gr * inv_np);                  // the dual term may add to the same entries
+                unsafeAtomicAdd(&A.d_pxyz[q * 3 + k], gr * inv_np);        // d(error)/d(proposal centre) = +1
+            }
+            // heading class (0.1) and residual (1)
+            const int hl = A.hlab[gi];
+            acc[5] += softmax_ce(o + 5, NH, hl, pr);
+            for (int i = 0; i < NH; i++) go[5 + i] = pr[i] * (0.1f * inv_np);
+            {
+                float gr;
+                acc[6] += huber(o[5 + NH + hl] - A.hres[gi], gr);
+                go[5 + NH + hl] = gr * inv_np;
+            }
+            // size class (0.1) and residual (1)
+            const int sl = A.slab[gi], so = 5 + 2 * NH;
+            acc[7] += softmax_ce(o + so, NS, sl, pr);
+            for (int i = 0; i < NS; i++) go[so + i] = pr[i] * (0.1f * inv_np);
+            for (int k = 0; k < 3; k++) {
+                float gr;
+                acc[8] += huber(o[so + NS + sl * 3 + k] - A.sres[gi * 3 + k], gr);
+                go[so + NS + sl * 3 + k] = gr * inv_np;
+            }
+            // semantic class (0.1)
+            const int co = W - NC;
+            acc[9] += softmax_ce(o + co, NC, A.sem[gi], pr);
+            for (int i = 0; i < NC; i++) go[co + i] = pr[i] * (0.1f * inv_np);
+        }
+    }
+    // ---- Chamfer / dual centre term (model.py:172-177): every ground-truth box pulls its nearest proposal
+    const float inv_bbb = 1.0f / (float)(B * BB);
+    for (int e = tid; e < B * BB; e += LOSS_T) {
+        const int b = e / BB;
+        const float gx = A.gxyz[e * 3 + 0], gy = A.gxyz[e * 3 + 1], gz = A.gxyz[e * 3 + 2];
+        float best = 0.0f;
+        int bp = 0;
+        for (int p = 0; p < P; p++) {
+            const float dx = A.pxyz[(b * P + p) * 3 + 0] - gx, dy = A.pxyz[(b * P + p) * 3 + 1] - gy,
+                        dz = A.pxyz[(b * P + p) * 3 + 2] - gz;
+            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+            if (p == 0 || d < best) {
+                best = d;
+                bp = p;
+            }
+        }
+        const int q = b * P + bp;
+        const float cg[3] = {gx - A.pxyz[q * 3 + 0], gy - A.pxyz[q * 3 + 1], gz - A.pxyz[q * 3 + 2]};
+        for (int k = 0; k < 3; k++) {
+            float gr;
+            acc[4] += huber(A.pout[(size_t)q * W + 2 + k] - cg[k], gr);
+            unsafeAtomicAdd(&A.d_pout[(size_t)q * W + 2 + k], gr * inv_bbb);
+            unsafeAtomicAdd(&A.d_pxyz[q * 3 + k], gr * inv_bbb);
+        }
+    }
+    // ---- seeds: vote targets and vote regression loss (model.py:61-84)
+    const float inv_bn = 1.0f / (float)(B * N);
+    for (int e = tid; e < B * N; e += LOSS_T) {
+        const int b = e / N;
+        const float sx = A.seeds[e * 3 + 0], sy = A.seeds[e * 3 + 1], sz = A.seeds[e * 3 + 2];
+        float best = 0.0f;
+        int g = 0;
+        bool surface = false;
+        for (int j = 0; j < BB; j++) {
+            const int gi = b * BB + j;
+            // |seed - centre| first, THEN the rotation by -roty (the reference's order, model.py:61,74)
+            const float dx = fabsf(sx - A.gxyz[gi * 3 + 0]), dy = fabsf(sy - A.gxyz[gi * 3 + 1]), dz = fabsf(sz - A.gxyz[gi * 3 + 2]);
+            const float c = gi < 256 ? s_cs[gi][0] : cosf(-A.groty[gi]), s = gi < 256 ? s_cs[gi][1] : sinf(-A.groty[gi]);
+            const float rx = c * dx + s * dz, ry = dy, rz = -s * dx + c * dz;
+            surface = surface || (rx < A.glwh[gi * 3 + 0] * 0.5f && ry < A.glwh[gi * 3 + 1] * 0.5f && rz < A.glwh[gi * 3 + 2] * 0.5f);
+            const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+            if (j == 0 || d < best) {
+                best = d;
+                g = j;
+            }
+        }
+        if (surface) {
+            const int gi = b * BB + g;
+            for (int k = 0; k < 3; k++) {
+                const float df = A.votes[e * 3 + k] - A.gxyz[gi * 3 + k];
+                acc[0] += fabsf(df);
+                A.d_votes[e * 3 + k] = (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f)) * inv_bn;
+            }
+        }
+    }
+    // ---- fixed-order reduction of the accumulators
+#pragma unroll
+    for (int i = 0; i < LOSS_NACC; i++) {
+        float v = acc[i];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+        if ((tid & 63) == 0) s_red[tid >> 6][i] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        float t[LOSS_NACC];
+        for (int i = 0; i < LOSS_NACC; i++) {
+            float v = 0.0f;
+            for (int w = 0; w < LOSS_T / 64; w++) v += s_red[w][i];
+            t[i] = v;
+        }
+        const float vote = t[0] * inv_bn;
+        const float obj = t[1] * inv_np + t[2] * inv_nn;
+        const float center = t[3] * inv_np + t[4] * inv_bbb;
+        const float hcls = t[5] * inv_np, hres = t[6] * inv_np, scls = t[7] * inv_np, sres = t[8] * inv_np, sem = t[9] * inv_np;
+        const float box = center + 0.1f * hcls + hres + 0.1f * scls + sres; // model.py:205
+        float *L = A.losses;
+        L[0] = vote + 0.5f * obj + box + 0.1f * sem;                        // model.py:228
+        L[1] = vote;
+        L[2] = obj;
+        L[3] = center;
+        L[4] = hcls;
+        L[5] = hres;
+        L[6] = scls;
+        L[7] = sres;
+        L[8] = sem;
+        L[9] = box;
+        L[10] = (float)s_np;
+        L[11] = (float)s_nn;
+    }
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
+                            const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, const float *bboxes_xyz,
+                            const float *bboxes_lwh, const float *bboxes_roty, const int *semantic_labels, const int *heading_labels,
+                            const float *heading_residuals, const int *size_labels, const float *size_residuals, float pos_thr,
+                            float neg_thr, float *losses, float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output,
+                            void *stream)
+{
+    VN_REQUIRE(b > 0 && n_seeds > 0 && n_prop > 0 && n_box > 0, "votenet_loss expects b, n_seeds, n_prop, n_box > 0");
+    VN_REQUIRE(nh > 0 && ns > 0 && nc > 0 && nh <= LOSS_MAXC && ns <= LOSS_MAXC && nc <= LOSS_MAXC, "votenet_loss expects 0 < nh, ns, nc <= 32");
+    VN_REQUIRE(pos_thr < neg_thr, "votenet_loss expects pos_thr < neg_thr (config.py)");
+    VN_REQUIRE(seeds_xyz && votes_xyz && proposals_xyz && proposals_output && bboxes_xyz && bboxes_lwh && bboxes_roty &&
+                   semantic_labels && heading_labels && heading_residuals && size_labels && size_residuals && losses &&
+                   d_votes_xyz && d_proposals_xyz && d_proposals_output,
+               "votenet_loss: null buffer");
+    LossArgs a = {b, n_seeds, n_prop, n_box, nh, ns, nc, seeds_xyz, votes_xyz, proposals_xyz, proposals_output, bboxes_xyz, bboxes_lwh,
+                  bboxes_roty, semantic_labels, heading_labels, size_labels, heading_residuals, size_residuals, pos_thr, neg_thr, losses,
+                  d_votes_xyz, d_proposals_xyz, d_proposals_output};
+    hipLaunchKernelGGL(votenet_loss_kernel, dim3(1), dim3(LOSS_T), 0, as_stream(stream), a);
+    return check_launch("votenet_loss");
+}

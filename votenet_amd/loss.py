@@ -1,0 +1,41 @@
+"""The reference's loss graph on the device: one kernel (votenet_loss, csrc/loss.hip) for the total cost of model.py:228
+and its cotangents with respect to the three tensors through which it reaches the hot path."""
+import torch
+
+from . import _lib as L
+from .synth import NC, NH, NS
+
+POSITIVE_THRES, NEGATIVE_THRES = 0.3, 0.6  # config.py
+NAMES = ("total_cost", "vote_reg_loss", "obj_cls_loss", "center_loss", "heading_cls_loss", "heading_residual_loss",
+         "size_cls_loss", "size_residual_loss", "sem_cls_loss", "box_loss", "n_pos", "n_neg")
+GT_KEYS = ("bboxes_xyz", "bboxes_lwh", "bboxes_roty", "semantic_labels", "heading_labels", "heading_residuals", "size_labels",
+           "size_residuals")
+
+
+def gt_to_device(gt, device):
+    """numpy ground-truth dict (synth.room_gt) -> contiguous device tensors."""
+    return {k: torch.from_numpy(gt[k]).contiguous().to(device) for k in GT_KEYS}
+
+
+def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
+    """out: the dict VoteNetHotPath.forward returns; gt: device tensors (gt_to_device).
+    -> losses (12,) f32 on the device (NAMES), cotangents dict(votes_xyz, proposals_xyz, proposals_output)."""
+    seeds = L.dev_f32(out["seeds_xyz"], "loss seeds_xyz", 3, 3)
+    votes = L.dev_f32(out["votes_xyz"], "loss votes_xyz", 3, 3)
+    pxyz = L.dev_f32(out["proposals_xyz"], "loss proposals_xyz", 3, 3)
+    pout = L.dev_f32(out["proposals_output"], "loss proposals_output", 3)
+    b, n = seeds.shape[:2]
+    p = pxyz.shape[1]
+    bb = gt["bboxes_xyz"].shape[1]
+    if pout.shape[2] != 5 + 2 * nh + 4 * ns + nc:
+        raise L.InvalidArgumentError("loss: proposals_output has %d channels, expected %d" % (pout.shape[2], 5 + 2 * nh + 4 * ns + nc))
+    dev = seeds.device
+    losses = torch.empty(12, dtype=torch.float32, device=dev)
+    d_votes, d_pxyz, d_pout = torch.zeros_like(votes), torch.zeros_like(pxyz), torch.zeros_like(pout)
+    with torch.cuda.device(dev):
+        L.check(L.lib().votenet_loss(b, n, p, bb, nh, ns, nc, L.ptr(seeds), L.ptr(votes), L.ptr(pxyz), L.ptr(pout),
+                                     L.ptr(gt["bboxes_xyz"]), L.ptr(gt["bboxes_lwh"]), L.ptr(gt["bboxes_roty"]),
+                                     L.ptr(gt["semantic_labels"]), L.ptr(gt["heading_labels"]), L.ptr(gt["heading_residuals"]),
+                                     L.ptr(gt["size_labels"]), L.ptr(gt["size_residuals"]), POSITIVE_THRES, NEGATIVE_THRES,
+                                     L.ptr(losses), L.ptr(d_votes), L.ptr(d_pxyz), L.ptr(d_pout), L.stream_ptr()))
+    return losses, dict(votes_xyz=d_votes, proposals_xyz=d_pxyz, proposals_output=d_pout)

@@ -196,6 +196,8 @@ class VoteNetHotPath:
         d_vp, d_vx = self.proposal.backward(prop, cot["proposals_output"], need_feat_grad=True, need_xyz_grad=True)
         if cot.get("votes_xyz") is not None:
             d_vx = d_vx + cot["votes_xyz"]
+        if cot.get("proposals_xyz") is not None:  # proposals_xyz = gather(votes_xyz, fps_idx), utils.py:42-47
+            d_vx = d_vx + P.tf_sampling.gather_point_grad_raw(d_vx.shape[1], prop["fps_idx"], cot["proposals_xyz"])
         # voting: votes = x + FC(x), x = [seeds_xyz, seeds_points]
         b, n = vote["b"], vote["n"]
         d_votes = torch.cat([d_vx, d_vp], dim=2).view(b * n, 259)
@@ -227,13 +229,18 @@ class VoteNetHotPath:
         self._step = 0
         self._lr = lr
 
-    def train_step(self, x, cot, world=1):
-        """forward + backward + (world>1: ONE RCCL all-reduce of the flat gradient bucket) + clip/Adam."""
+    def train_step(self, x, cot=None, world=1, gt=None):
+        """forward + loss + backward + (world>1: ONE RCCL all-reduce of the flat gradient bucket) + clip/Adam.
+        gt: ground truth on the device (loss.gt_to_device): the reference's total cost (model.py:228) drives the backward
+        pass, its components are left in self.last_losses (device, loss.NAMES).  cot: fixed cotangents instead (tests)."""
         if not hasattr(self, "_seg"):
             self.init_optimizer()
         self.store.grad.zero_()
         tape = []
         out = self.forward(x, tape)
+        if gt is not None:
+            from . import loss as VL
+            self.last_losses, cot = VL.votenet_loss(out, gt)
         self.backward(tape, cot)
         gscale = dp.sync_gradients(self.store)  # ONE all-reduce (sum) of the flat bucket; 1/world goes to the optimizer
         self._step += 1

@@ -33,7 +33,8 @@ def room_scene(n, seed, size=(5.0, 3.0, 5.0), nbox=(6, 10)):
     o = n_struct
     boxes = []
     for i in range(k):
-        l, w, h = MEAN_SIZES[rng.integers(0, 10)] * rng.uniform(0.8, 1.2, 3)
+        cls = int(rng.integers(0, 10))  # SUN RGB-D class of the box (dataset.py:31-32); same draw as before: clouds unchanged
+        l, w, h = MEAN_SIZES[cls] * rng.uniform(0.8, 1.2, 3)
         ang = rng.uniform(0, 2 * np.pi)
         cx, cz = rng.uniform(-sx / 2 + 0.8, sx / 2 - 0.8), rng.uniform(0.8, sz - 0.8)
         cy = -1.2 + h / 2
@@ -49,7 +50,7 @@ def room_scene(n, seed, size=(5.0, 3.0, 5.0), nbox=(6, 10)):
         z = -s * q[:, 0] + c * q[:, 2]
         pts[o:o + per[i]] = np.stack([x + cx, q[:, 1] + cy, z + cz], 1)
         o += per[i]
-        boxes.append((cx, cy, cz, l, w, h, ang))
+        boxes.append((cx, cy, cz, l, w, h, ang, cls))
     pts += rng.normal(0, 0.005, pts.shape)
     rng.shuffle(pts)  # the reference subsamples at random: no spatial order in the index
     return pts.astype(np.float32), np.array(boxes, np.float32)
@@ -62,3 +63,39 @@ def room_batch(b, n, seed0=1000, **kw):
 def uniform_batch(b, n, seed0=1000, extent=5.0):
     """Worst case for the ball query: uniform in a cube, no ball fills K -> full n-scan."""
     return np.stack([np.random.default_rng(seed0 + i).random((n, 3), dtype=np.float32) * extent for i in range(b)])
+
+
+NH, NS, NC = 12, 10, 10  # config.py: heading bins, size classes, semantic classes
+
+
+def angle2class(angle, num_class=NH):
+    """dataset.py:52-67: heading angle -> (bin, residual from the bin centre)."""
+    angle = angle % (2 * np.pi)
+    per = 2 * np.pi / float(num_class)
+    shifted = (angle + per / 2) % (2 * np.pi)
+    cid = int(shifted / per)
+    return cid, shifted - (cid * per + per / 2)
+
+
+def room_gt(b, n, seed0=1000, **kw):
+    """Ground truth of room_batch(b, n, seed0) in the reference's input layout (model.py:22-32, dataset.py:279-299): the
+    generating boxes, ragged lists padded to the longest by repeating the last box (run.py:14-24, np.pad mode='edge').
+    -> dict of float32 / int32 arrays: bboxes_xyz (b,BB,3), bboxes_lwh (b,BB,3), bboxes_roty (b,BB), semantic_labels,
+    heading_labels (b,BB), heading_residuals (b,BB), size_labels (b,BB), size_residuals (b,BB,3)."""
+    per_scene = []
+    for i in range(b):
+        boxes = room_scene(n, seed0 + i, **kw)[1].astype(np.float64)
+        rows = []
+        for cx, cy, cz, l, w, h, ang, cls in boxes:
+            cls = int(cls)
+            hc, hr = angle2class(ang)
+            size = np.array([l, w, h])
+            rows.append((np.array([cx, cy, cz]), size, ang, cls, hc, hr / (np.pi / NH), cls, (size - MEAN_SIZES[cls]) / MEAN_SIZES[cls]))
+        per_scene.append(rows)
+    bb = max(len(r) for r in per_scene)
+    for r in per_scene:
+        r += [r[-1]] * (bb - len(r))
+    col = lambda k, dt: np.array([[row[k] for row in r] for r in per_scene], dtype=dt)
+    return dict(bboxes_xyz=col(0, np.float32), bboxes_lwh=col(1, np.float32), bboxes_roty=col(2, np.float32),
+                semantic_labels=col(3, np.int32), heading_labels=col(4, np.int32), heading_residuals=col(5, np.float32),
+                size_labels=col(6, np.int32), size_residuals=col(7, np.float32))
