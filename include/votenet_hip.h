@@ -307,6 +307,13 @@ int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int 
                  const int *size_labels, const float *size_residuals, float pos_thr, float neg_thr, float *losses,
                  float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, void *stream);
 
+/* Box decode of the predict tower (model.py:100-129): proposals_xyz (b,n_prop,3), proposals_output
+ * (b,n_prop,5+2*nh+4*ns+nc), class_mean_size (ns,3; dataset.py:47-49) -> bboxes (b,n_prop,8,3) in the corner
+ * order of get_3d_bbox (first four = top face: what votenet_nms3d expects) and scores (b,n_prop) = max class logit. */
+int votenet_decode_boxes(int b, int n_prop, int nh, int ns, int nc, const float *proposals_xyz,
+                         const float *proposals_output, const float *class_mean_size, float *bboxes, float *scores,
+                         void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,3 +89,27 @@ def votenet_loss(seeds_xyz, votes_xyz, proposals_xyz, proposals_output, gt, nh=1
                 heading_residual_loss=hres, size_cls_loss=scls, size_residual_loss=sres, sem_cls_loss=sem, box_loss=box,
                 n_pos=int(pos.sum()), n_neg=int(neg.sum()), votes_assignment=vassign, surface_ind=surface,
                 bboxes_assignment=passign, positive=pos, negative=neg, dual_assignment=dual)
+
+
+def decode_boxes(proposals_xyz, proposals_output, class_mean_size, nh=12, ns=10, nc=10):
+    """model.py:100-129: -> bboxes (B,P,8,3) float32, scores (B,P) = max class logit."""
+    o = proposals_output.astype(F)
+    B, P = o.shape[:2]
+    size_cls = o[..., 5 + 2 * nh:5 + 2 * nh + ns].argmax(-1)                                           # :115
+    res = o[..., 5 + 2 * nh + ns:5 + 2 * nh + 4 * ns].reshape(B, P, ns, 3)
+    res = np.take_along_axis(res, size_cls[..., None, None].repeat(3, -1), 2)[:, :, 0]                 # :116-118
+    size = (class_mean_size.astype(F)[size_cls] * np.maximum(F(1) + res, F(1e-6))).astype(F)           # :119
+    center = (proposals_xyz + o[..., 2:5]).astype(F)                                                   # :121
+    hcls = o[..., 5:5 + nh].argmax(-1)                                                                 # :122
+    hres = np.take_along_axis(o[..., 5 + nh:5 + 2 * nh], hcls[..., None], -1)[..., 0]                  # :123-125
+    heading = np.mod(((hcls.astype(F) * F(2) + hres) * F(np.pi / nh)).astype(F), F(2 * np.pi)).astype(F)  # :126 floormod
+    c, s = np.cos(heading).astype(F), np.sin(heading).astype(F)
+    l, w, h = size[..., 0], size[..., 1], size[..., 2]
+    sx = np.array([1, 1, -1, -1, 1, 1, -1, -1], F) * F(0.5)                                            # :107-110
+    sy = np.array([1, 1, 1, 1, -1, -1, -1, -1], F) * F(0.5)
+    sz = np.array([1, -1, -1, 1, 1, -1, -1, 1], F) * F(0.5)
+    x0, y0, z0 = l[..., None] * sx, h[..., None] * sy, w[..., None] * sz
+    xr = c[..., None] * x0 + s[..., None] * z0                                                         # :111 einsum with the y rotation
+    zr = -s[..., None] * x0 + c[..., None] * z0
+    boxes = np.stack([xr, y0, zr], -1).astype(F) + center[:, :, None, :]
+    return boxes.astype(F), o[..., -nc:].max(-1)

@@ -76,3 +76,21 @@ def test_train_step_with_the_loss_graph(hiplib, dev):
     fin = costs[np.isfinite(costs)]
     assert len(fin) >= 8 and fin[-3:].mean() < fin[:3].mean()
     assert torch.isfinite(net.store.flat).all()
+
+
+def test_decode_boxes_vs_oracle(hiplib, dev):
+    """votenet_decode_boxes against the numpy restatement of model.py:100-129, and its corner order against what NMS3D
+    expects (first four corners = top face, [0] / [4] span the height)."""
+    from oracle import oracle_loss
+    from votenet_amd import loss as VL
+    from votenet_amd import synth
+    rng = np.random.default_rng(11)
+    prop = (rng.random((3, 50, 3)) * 4).astype(np.float32)
+    out = rng.normal(0, 1.0, (3, 50, 79)).astype(np.float32)
+    out[0, 0, 5 + 24 + 10:5 + 24 + 40] = -5.0  # residual below -1: the 1e-6 floor of model.py:119
+    boxes, scores = VL.decode_boxes(torch.from_numpy(prop).to(dev), torch.from_numpy(out).to(dev))
+    eb, es = oracle_loss.decode_boxes(prop, out, synth.MEAN_SIZES.astype(np.float32))
+    assert np.abs(boxes.cpu().numpy() - eb).max() <= 1e-5 * max(1.0, np.abs(eb).max())
+    assert (scores.cpu().numpy() == es).all()
+    b = boxes.cpu().numpy()
+    assert np.allclose(b[:, :, :4, 1], b[:, :, :1, 1], atol=1e-6) and (b[:, :, 0, 1] >= b[:, :, 4, 1]).all()

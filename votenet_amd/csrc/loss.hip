@@ -258,3 +258,59 @@ extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, i
     hipLaunchKernelGGL(votenet_loss_kernel, dim3(1), dim3(LOSS_T), 0, as_stream(stream), a);
     return check_launch("votenet_loss");
 }
+
+// ---------------------------------------------------------------- box decode of the predict tower (model.py:100-129)
+namespace votenet {
+
+// One thread per proposal: size class arg-max -> class mean size * max(1 + residual, 1e-6); centre = proposal + offset;
+// heading bin arg-max + residual -> angle = floormod((2*bin + residual) * pi/NH, 2*pi); the 8 corners of get_3d_bbox
+// (model.py:100-112: x = +-l/2, y = +-h/2 (first four = top face), z = +-w/2, rotated about y) and the NMS score
+// (max class logit) -- what NonMaxSuppression3D consumes, without the reference's one_hot / gather_nd / einsum nodes.
+__global__ void decode_boxes_kernel(int total, int nh, int ns, int nc, const float *__restrict__ pxyz, const float *__restrict__ pout,
+                                    const float *__restrict__ mean_size, float *__restrict__ boxes, float *__restrict__ scores)
+{
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= total) return;
+    const int W = 5 + 2 * nh + 4 * ns + nc;
+    const float *o = pout + (size_t)q * W;
+    int sc = 0;
+    for (int i = 1; i < ns; i++)
+        if (o[5 + 2 * nh + i] > o[5 + 2 * nh + sc]) sc = i; // tf.argmax: first maximum
+    int hc = 0;
+    for (int i = 1; i < nh; i++)
+        if (o[5 + i] > o[5 + hc]) hc = i;
+    float size[3];
+    for (int k = 0; k < 3; k++) size[k] = mean_size[sc * 3 + k] * fmaxf(1.0f + o[5 + 2 * nh + ns + sc * 3 + k], 1e-6f);
+    const float cx = pxyz[q * 3 + 0] + o[2], cy = pxyz[q * 3 + 1] + o[3], cz = pxyz[q * 3 + 2] + o[4];
+    const float PI_F = 3.14159265358979323846f;
+    const float t = ((float)hc * 2.0f + o[5 + nh + hc]) * (PI_F / (float)nh);
+    float ang = fmodf(t, 2.0f * PI_F); // tf.floormod: the result takes the sign of the divisor
+    if (ang < 0.0f) ang += 2.0f * PI_F;
+    const float c = cosf(ang), s = sinf(ang);
+    const float l = size[0], w = size[1], h = size[2]; // lwh = (x, z, y) extents
+    const float sx[8] = {1, 1, -1, -1, 1, 1, -1, -1}, sy[8] = {1, 1, 1, 1, -1, -1, -1, -1}, sz[8] = {1, -1, -1, 1, 1, -1, -1, 1};
+    float *bx = boxes + (size_t)q * 24;
+    for (int m = 0; m < 8; m++) {
+        const float x0 = sx[m] * l * 0.5f, y0 = sy[m] * h * 0.5f, z0 = sz[m] * w * 0.5f;
+        bx[m * 3 + 0] = c * x0 + s * z0 + cx;
+        bx[m * 3 + 1] = y0 + cy;
+        bx[m * 3 + 2] = -s * x0 + c * z0 + cz;
+    }
+    float best = o[W - nc];
+    for (int i = 1; i < nc; i++) best = fmaxf(best, o[W - nc + i]);
+    scores[q] = best;
+}
+
+} // namespace votenet
+
+extern "C" int votenet_decode_boxes(int b, int n_prop, int nh, int ns, int nc, const float *proposals_xyz, const float *proposals_output,
+                                    const float *class_mean_size, float *bboxes, float *scores, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n_prop >= 0 && nh > 0 && ns > 0 && nc > 0, "decode_boxes: bad shape");
+    const int total = b * n_prop;
+    if (total == 0) return VOTENET_OK;
+    VN_REQUIRE(proposals_xyz && proposals_output && class_mean_size && bboxes && scores, "decode_boxes: null buffer");
+    hipLaunchKernelGGL(votenet::decode_boxes_kernel, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), total, nh, ns, nc,
+                       proposals_xyz, proposals_output, class_mean_size, bboxes, scores);
+    return check_launch("decode_boxes");
+}

@@ -39,3 +39,20 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
                                      L.ptr(gt["size_labels"]), L.ptr(gt["size_residuals"]), POSITIVE_THRES, NEGATIVE_THRES,
                                      L.ptr(losses), L.ptr(d_votes), L.ptr(d_pxyz), L.ptr(d_pout), L.stream_ptr()))
     return losses, dict(votes_xyz=d_votes, proposals_xyz=d_pxyz, proposals_output=d_pout)
+
+
+def decode_boxes(proposals_xyz, proposals_output, nh=NH, ns=NS, nc=NC):
+    """model.py:100-129 on the device: -> bboxes (B,P,8,3), scores (B,P) = max class logit (the inputs of NMS3D)."""
+    from .synth import MEAN_SIZES
+    pxyz = L.dev_f32(proposals_xyz, "decode_boxes proposals_xyz", 3, 3)
+    pout = L.dev_f32(proposals_output, "decode_boxes proposals_output", 3)
+    b, p = pxyz.shape[:2]
+    if pout.shape[2] != 5 + 2 * nh + 4 * ns + nc:
+        raise L.InvalidArgumentError("decode_boxes: proposals_output has %d channels" % pout.shape[2])
+    mean = torch.tensor(MEAN_SIZES, dtype=torch.float32, device=pxyz.device).contiguous()
+    boxes = torch.empty((b, p, 8, 3), dtype=torch.float32, device=pxyz.device)
+    scores = torch.empty((b, p), dtype=torch.float32, device=pxyz.device)
+    with torch.cuda.device(pxyz.device):
+        L.check(L.lib().votenet_decode_boxes(b, p, nh, ns, nc, L.ptr(pxyz), L.ptr(pout), L.ptr(mean), L.ptr(boxes), L.ptr(scores),
+                                             L.stream_ptr()))
+    return boxes, scores

@@ -132,31 +132,9 @@ class VoteNetHotPath:
 
     # ---- inference tail: box decode (caller side, torch glue) + 3D NMS (hot path) ------
     def decode_boxes(self, proposals_xyz, proposals_output):
-        """model.py:100-129 restated with torch ops (caller-side glue, NOT part of the hot path):
-        size class arg-max x (1 + residual) on the SUN RGB-D class mean sizes, heading bin + residual,
-        corner order of get_3d_bbox (first four = top face).  -> bboxes (B,N,8,3), class score (B,N)."""
-        import math
-        from .synth import MEAN_SIZES
-        o = proposals_output
-        mean = torch.tensor(MEAN_SIZES, dtype=torch.float32, device=o.device)  # (NS,3) l,w,h
-        size_cls = o[..., 5 + 2 * NH:5 + 2 * NH + NS].argmax(-1)
-        res = o[..., 5 + 2 * NH + NS:5 + 2 * NH + 4 * NS].reshape(*o.shape[:2], NS, 3)
-        res = torch.gather(res, 2, size_cls[..., None, None].expand(-1, -1, 1, 3))[:, :, 0]
-        size = mean[size_cls] * torch.clamp(1 + res, min=1e-6)
-        center = proposals_xyz + o[..., 2:5]
-        hcls = o[..., 5:5 + NH].argmax(-1)
-        hres = torch.gather(o[..., 5 + NH:5 + 2 * NH], 2, hcls[..., None])[..., 0]
-        heading = torch.remainder((hcls.float() * 2 + hres) * math.pi / NH, 2 * math.pi)
-        c, s = torch.cos(heading), torch.sin(heading)
-        l, w, h = size[..., 0], size[..., 1], size[..., 2]
-        sx = torch.tensor([1, 1, -1, -1, 1, 1, -1, -1], device=o.device, dtype=torch.float32) * 0.5
-        sy = torch.tensor([1, 1, 1, 1, -1, -1, -1, -1], device=o.device, dtype=torch.float32) * 0.5
-        sz = torch.tensor([1, -1, -1, 1, 1, -1, -1, 1], device=o.device, dtype=torch.float32) * 0.5
-        x0, y0, z0 = l[..., None] * sx, h[..., None] * sy, w[..., None] * sz
-        xr = c[..., None] * x0 + s[..., None] * z0
-        zr = -s[..., None] * x0 + c[..., None] * z0
-        boxes = torch.stack([xr, y0, zr], -1) + center[:, :, None, :]
-        return boxes.contiguous(), o[..., -NC:].max(-1)[0].contiguous()
+        """model.py:100-129 (votenet_decode_boxes): -> bboxes (B,N,8,3) in get_3d_bbox's corner order, class score (B,N)."""
+        from . import loss as VL
+        return VL.decode_boxes(proposals_xyz, proposals_output)
 
     def predict(self, x, iou_threshold=0.25):
         """Predict tower of model.py:98-139: forward -> decode -> NMS3D(bboxes, max class logit, objectness, 0.25)."""
