@@ -314,6 +314,10 @@ int votenet_decode_boxes(int b, int n_prop, int nh, int ns, int nc, const float 
                          const float *proposals_output, const float *class_mean_size, float *bboxes, float *scores,
                          void *stream);
 
+/* 3D IoU (the arithmetic of tf_nms3d.cpp:178-192) of every box of set A (b,n,8,3) against every box of set B
+ * (b,m,8,3) of the same scene -> iou (b,n,m): the detections-vs-ground-truth overlaps of evaluator.py:26-39,122-132. */
+int votenet_iou3d_cross(int b, int n, int m, const float *boxes_a, const float *boxes_b, float *iou, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

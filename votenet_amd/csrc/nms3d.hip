@@ -156,6 +156,23 @@ __global__ __launch_bounds__(64) void iou3d_matrix_kernel(int n, const float *__
     iou[((size_t)scene * n + i) * n + j] = iou3d_pair(bi, bj);
 }
 
+// IoU of every box of set A against every box of set B of the same scene (detections x ground truth: evaluator.py:26-39)
+__global__ __launch_bounds__(64) void iou3d_cross_kernel(int n, int m, const float *__restrict__ a, const float *__restrict__ bset,
+                                                         float *__restrict__ iou)
+{
+    const int scene = blockIdx.z;
+    const int i = blockIdx.y;
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    float bi[24], bj[24];
+#pragma unroll
+    for (int t = 0; t < 24; t++) {
+        bi[t] = a[((size_t)scene * n + i) * 24 + t];
+        bj[t] = bset[((size_t)scene * m + j) * 24 + t];
+    }
+    iou[((size_t)scene * n + i) * m + j] = iou3d_pair(bi, bj);
+}
+
 // visit order: rank[e] = number of candidates visited before flat element e; -1 if not a candidate
 __global__ void nms_rank_kernel(int total, const float *__restrict__ scores, const float *__restrict__ obj,
                                 int *__restrict__ order /* rank -> flat index */, int *__restrict__ ncand)
@@ -280,6 +297,16 @@ extern "C" int votenet_iou3d_matrix(int b, int n, const float *bboxes, float *io
     VN_REQUIRE(n <= 65535 && b <= 65535, "iou3d_matrix: n and b must be <= 65535");
     hipLaunchKernelGGL(iou3d_matrix_kernel, dim3((n + 63) / 64, n, b), dim3(64), 0, as_stream(stream), n, bboxes, iou);
     return check_launch("iou3d_matrix");
+}
+
+extern "C" int votenet_iou3d_cross(int b, int n, int m, const float *boxes_a, const float *boxes_b, float *iou, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n >= 0 && m >= 0, "iou3d_cross expects (batch, n, 8, 3) and (batch, m, 8, 3) boxes");
+    if (b == 0 || n == 0 || m == 0) return VOTENET_OK;
+    VN_REQUIRE(boxes_a && boxes_b && iou, "iou3d_cross: null buffer");
+    VN_REQUIRE(n <= 65535 && b <= 65535, "iou3d_cross: n and b must be <= 65535");
+    hipLaunchKernelGGL(iou3d_cross_kernel, dim3((m + 63) / 64, n, b), dim3(64), 0, as_stream(stream), n, m, boxes_a, boxes_b, iou);
+    return check_launch("iou3d_cross");
 }
 
 extern "C" size_t votenet_nms3d_workspace_bytes(int b, int n)

@@ -142,7 +142,7 @@ class VoteNetHotPath:
         out = self.forward(x)
         boxes, score = self.decode_boxes(out["proposals_xyz"], out["proposals_output"])
         keep = tf_nms3d.NMS3D(boxes, score, out["proposals_output"][..., :2].contiguous(), iou_threshold)
-        return dict(bboxes=boxes, scores=score, nms_idx=keep, **out)
+        return dict(bboxes=boxes, scores=score, nms_idx=keep, class_scores=out["proposals_output"][..., -NC:].contiguous(), **out)
 
     # ---- backward / training --------------------------------------------------------
     def make_cotangents(self, b, seed=0):

@@ -16,6 +16,19 @@ def iou3d_matrix(bboxes):
     return iou
 
 
+def iou3d_cross(boxes_a, boxes_b):
+    """(B,n,8,3), (B,m,8,3) corner boxes -> (B,n,m) 3D IoU of every pair across the two sets (evaluator.py:26-39)."""
+    a = L.dev_f32(boxes_a.detach(), "iou3d_cross expects (batch, n, 8, 3) boxes", 4, 3)
+    bset = L.dev_f32(boxes_b.detach(), "iou3d_cross expects (batch, m, 8, 3) boxes", 4, 3)
+    if a.shape[2] != 8 or bset.shape[2] != 8 or a.shape[0] != bset.shape[0]:
+        raise L.InvalidArgumentError("iou3d_cross expects (batch, n, 8, 3) and (batch, m, 8, 3) boxes")
+    b, n, m = a.shape[0], a.shape[1], bset.shape[1]
+    iou = torch.empty((b, n, m), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        L.check(L.lib().votenet_iou3d_cross(b, n, m, L.ptr(a), L.ptr(bset), L.ptr(iou), L.stream_ptr()))
+    return iou
+
+
 def NMS3D(bboxes, scores, objectiveness, iou_threshold):
     """tf_nms3d.py:11-12.  (B,N,8,3), (B,N), (B,N,2) f32, scalar in [0,1] -> (Nsel,2) int32 [batch, box]
     in descending-score visit order over the whole batch (tf_nms3d.cpp:202-273).  No gradient."""
