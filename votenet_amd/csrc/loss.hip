@@ -52,12 +52,21 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
     const int tid = threadIdx.x;
     const int B = A.b, N = A.n, P = A.p, BB = A.bb, NH = A.nh, NS = A.ns, NC = A.nc;
     const int W = 5 + 2 * NH + 4 * NS + NC; // width of proposals_output (79)
-    // per-box constants once: cos / sin of -roty (the seed loop would otherwise evaluate them B*N*BB times)
-    __shared__ float s_cs[256][2];
-    for (int e = tid; e < B * BB && e < 256; e += LOSS_T) {
-        s_cs[e][0] = cosf(-A.groty[e]);
-        s_cs[e][1] = sinf(-A.groty[e]);
+    // per-box constants once, in LDS: centre, half extents, cos / sin of -roty (the loops below touch them B*(N+P)*BB times)
+    constexpr int MAXBOX = 256;
+    __shared__ float s_box[MAXBOX][8];
+    const bool staged = B * BB <= MAXBOX;
+    for (int e = tid; e < B * BB && staged; e += LOSS_T) {
+        s_box[e][0] = A.gxyz[e * 3 + 0];
+        s_box[e][1] = A.gxyz[e * 3 + 1];
+        s_box[e][2] = A.gxyz[e * 3 + 2];
+        s_box[e][3] = A.glwh[e * 3 + 0] * 0.5f;
+        s_box[e][4] = A.glwh[e * 3 + 1] * 0.5f;
+        s_box[e][5] = A.glwh[e * 3 + 2] * 0.5f;
+        s_box[e][6] = cosf(-A.groty[e]);
+        s_box[e][7] = sinf(-A.groty[e]);
     }
+    auto bx = [&](int gi, int k) { return staged ? s_box[gi][k] : A.gxyz[gi * 3 + k]; };
     if (tid == 0) s_np = s_nn = 0;
     __syncthreads();
     // ---- proposals: nearest ground-truth centre, positive / negative (model.py:147-153)
@@ -67,8 +76,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
         float best = 0.0f;
         for (int j = 0; j < BB; j++) {
-            const float dx = px - A.gxyz[(b * BB + j) * 3 + 0], dy = py - A.gxyz[(b * BB + j) * 3 + 1],
-                        dz = pz - A.gxyz[(b * BB + j) * 3 + 2];
+            const float dx = px - bx(b * BB + j, 0), dy = py - bx(b * BB + j, 1), dz = pz - bx(b * BB + j, 2);
             const float d = sqrtf(dx * dx + dy * dy + dz * dz);
             if (j == 0 || d < best) best = d;
         }
@@ -91,8 +99,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         float best = 0.0f;
         int g = 0;
         for (int j = 0; j < BB; j++) {
-            const float dx = px - A.gxyz[(b * BB + j) * 3 + 0], dy = py - A.gxyz[(b * BB + j) * 3 + 1],
-                        dz = pz - A.gxyz[(b * BB + j) * 3 + 2];
+            const float dx = px - bx(b * BB + j, 0), dy = py - bx(b * BB + j, 1), dz = pz - bx(b * BB + j, 2);
             const float d = sqrtf(dx * dx + dy * dy + dz * dz);
             if (j == 0 || d < best) { // tf.argmin: first minimum
                 best = d;
@@ -145,25 +152,33 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
     }
     // ---- Chamfer / dual centre term (model.py:172-177): every ground-truth box pulls its nearest proposal
     const float inv_bbb = 1.0f / (float)(B * BB);
-    for (int e = tid; e < B * BB; e += LOSS_T) {
-        const int b = e / BB;
-        const float gx = A.gxyz[e * 3 + 0], gy = A.gxyz[e * 3 + 1], gz = A.gxyz[e * 3 + 2];
-        float best = 0.0f;
-        int bp = 0;
-        for (int p = 0; p < P; p++) {
+    for (int e = tid >> 6; e < B * BB; e += LOSS_T / 64) { // one wave per box: lanes scan the proposals, wave arg-min
+        const int b = e / BB, lane = tid & 63;
+        const float gx = bx(e, 0), gy = bx(e, 1), gz = bx(e, 2);
+        float best = INFINITY;
+        int bp = 0x7FFFFFFF;
+        for (int p = lane; p < P; p += 64) {
             const float dx = A.pxyz[(b * P + p) * 3 + 0] - gx, dy = A.pxyz[(b * P + p) * 3 + 1] - gy,
                         dz = A.pxyz[(b * P + p) * 3 + 2] - gz;
             const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (p == 0 || d < best) {
+            if (d < best) { // ascending p inside a lane: first minimum of the lane
                 best = d;
                 bp = p;
             }
         }
-        const int q = b * P + bp;
-        const float cg[3] = {gx - A.pxyz[q * 3 + 0], gy - A.pxyz[q * 3 + 1], gz - A.pxyz[q * 3 + 2]};
-        for (int k = 0; k < 3; k++) {
+        for (int off = 32; off > 0; off >>= 1) { // smallest distance, then smallest index: tf.argmin's first minimum
+            const float ob = __shfl_xor(best, off);
+            const int op = __shfl_xor(bp, off);
+            if (ob < best || (ob == best && op < bp)) {
+                best = ob;
+                bp = op;
+            }
+        }
+        if (lane < 3) {
+            const int k = lane, q = b * P + bp;
+            const float cgk = (k == 0 ? gx : (k == 1 ? gy : gz)) - A.pxyz[q * 3 + k];
             float gr;
-            acc[4] += huber(A.pout[(size_t)q * W + 2 + k] - cg[k], gr);
+            acc[4] += huber(A.pout[(size_t)q * W + 2 + k] - cgk, gr);
             unsafeAtomicAdd(&A.d_pout[(size_t)q * W + 2 + k], gr * inv_bbb);
             unsafeAtomicAdd(&A.d_pxyz[q * 3 + k], gr * inv_bbb);
         }
@@ -179,10 +194,12 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         for (int j = 0; j < BB; j++) {
             const int gi = b * BB + j;
             // |seed - centre| first, THEN the rotation by -roty (the reference's order, model.py:61,74)
-            const float dx = fabsf(sx - A.gxyz[gi * 3 + 0]), dy = fabsf(sy - A.gxyz[gi * 3 + 1]), dz = fabsf(sz - A.gxyz[gi * 3 + 2]);
-            const float c = gi < 256 ? s_cs[gi][0] : cosf(-A.groty[gi]), s = gi < 256 ? s_cs[gi][1] : sinf(-A.groty[gi]);
+            const float dx = fabsf(sx - bx(gi, 0)), dy = fabsf(sy - bx(gi, 1)), dz = fabsf(sz - bx(gi, 2));
+            const float c = staged ? s_box[gi][6] : cosf(-A.groty[gi]), s = staged ? s_box[gi][7] : sinf(-A.groty[gi]);
+            const float hx = staged ? s_box[gi][3] : A.glwh[gi * 3 + 0] * 0.5f, hy = staged ? s_box[gi][4] : A.glwh[gi * 3 + 1] * 0.5f,
+                        hz = staged ? s_box[gi][5] : A.glwh[gi * 3 + 2] * 0.5f;
             const float rx = c * dx + s * dz, ry = dy, rz = -s * dx + c * dz;
-            surface = surface || (rx < A.glwh[gi * 3 + 0] * 0.5f && ry < A.glwh[gi * 3 + 1] * 0.5f && rz < A.glwh[gi * 3 + 2] * 0.5f);
+            surface = surface || (rx < hx && ry < hy && rz < hz);
             const float d = sqrtf(rx * rx + ry * ry + rz * rz);
             if (j == 0 || d < best) {
                 best = d;
