@@ -438,6 +438,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx = pts[0], cy = pts[1], cz = pts[2];
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
+    int cw_slot = -1;                           // ... and the slot (bucket) it lives in
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
 #ifdef FPS_TRACE
     unsigned long long _tprev = __builtin_amdgcn_s_memtime();
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
         unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
         FPS_T(1); // box tests + ballot
         // (2) update the active buckets, refresh their cached arg-max
-        bool changed = false; // uniform: did any cached bucket entry of this wave change this round?
+        bool changed = false; // uniform: did the cached entry of this wave's WINNING bucket change this round?
         while (act) {
             const int i = __ffsll((long long)act) - 1;
             act &= act - 1;
@@ -474,14 +475,16 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
                     bkey = nkey;
                     blane = nl;
                 }
-                changed = true;
+                changed = changed || (i == cw_slot);
             }
         }
         FPS_T(2); // touched buckets
-        // (3) wave winner over the cached bucket entries (lanes < P).  It can only change when one of this
-        //     wave's bucket entries changed; otherwise last round's winner (uniform registers) is reused.
+        // (3) wave winner over the cached bucket entries (lanes < P).  Bucket maxima only ever decrease, so the winner
+        //     can only change when the winning bucket's OWN entry changed; otherwise last round's winner (uniform
+        //     registers) is still the maximum -- the buckets touched in a round are the ones near the new centre, rarely it.
         if (changed || j == 1) {
             const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, cw_max, cw_key); // winning bucket = slot
+            cw_slot = ws;
             const int fl = __builtin_amdgcn_readlane(blane, ws);                                            // winning lane inside it
             cw_x = readlane_f32(X[ws], fl);
             cw_y = readlane_f32(Y[ws], fl);
@@ -556,6 +559,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx = pts[0], cy = pts[1], cz = pts[2];
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
+    int cw_slot = -1;                           // ... and its bucket (slot * 64 + lane)
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
     for (int j = 1; j < m; j++) {
         bool changed = false;
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
                                 wy[s] = ny;
                                 wz[s] = nz;
                             }
-                            changed = true;
+                            changed = changed || (s * 64 + i == cw_slot); // only the winning bucket's change matters
                         }
                     }
                 }
@@ -629,7 +633,12 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
                 ly = better ? wy[s] : ly;
                 lz = better ? wz[s] : lz;
             }
+            int ls = 0; // the slot the lane's best entry comes from
+#pragma unroll
+            for (int s = 1; s < NBL; s++)
+                if (bmax[s] == lm && bkey[s] == lk) ls = s;
             const int wl = wave_argmax(lm, lk, cw_max, cw_key);
+            cw_slot = __builtin_amdgcn_readlane(ls, wl) * 64 + wl;
             cw_x = readlane_f32(lx, wl);
             cw_y = readlane_f32(ly, wl);
             cw_z = readlane_f32(lz, wl);
