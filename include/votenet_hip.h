@@ -295,7 +295,8 @@ int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scratch, float
  * (b,n_prop,5+2*nh+4*ns+nc) -- the three tensors through which the cost reaches the hot path.  Ground
  * truth in the reference's input layout (model.py:22-32): bboxes_xyz / bboxes_lwh (b,n_box,3), bboxes_roty,
  * semantic / heading / size labels (b,n_box), heading_residuals (b,n_box), size_residuals (b,n_box,3); ragged
- * scenes are padded by repeating a box (run.py:14-24).  The three d_* buffers must be zero on entry.
+ * scenes are padded by repeating a box (run.py:14-24; at most 256 boxes per scene).  The three d_* buffers and the
+ * workspace (votenet_loss_workspace_floats(b) floats) must be zero on entry.
  * losses (12 floats): total_cost, vote_reg_loss, obj_cls_loss, center_loss (incl. the dual term),
  * heading_cls_loss, heading_residual_loss, size_cls_loss, size_residual_loss, sem_cls_loss, box_loss,
  * #positive, #negative proposals.  No positive (or no negative) proposal: the affected means are NaN, as
@@ -305,7 +306,8 @@ int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int 
                  const float *bboxes_xyz, const float *bboxes_lwh, const float *bboxes_roty,
                  const int *semantic_labels, const int *heading_labels, const float *heading_residuals,
                  const int *size_labels, const float *size_residuals, float pos_thr, float neg_thr, float *losses,
-                 float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, void *stream);
+                 float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, float *workspace, void *stream);
+size_t votenet_loss_workspace_floats(int b);
 
 /* Box decode of the predict tower (model.py:100-129): proposals_xyz (b,n_prop,3), proposals_output
  * (b,n_prop,5+2*nh+4*ns+nc), class_mean_size (ns,3; dataset.py:47-49) -> bboxes (b,n_prop,8,3) in the corner

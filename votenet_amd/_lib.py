@@ -69,7 +69,7 @@ _SIGS.update({
     "votenet_mlp_linear_pool": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
                                + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
-    "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
@@ -104,6 +104,8 @@ def lib():
         L.votenet_version.restype = ctypes.c_char_p
         L.votenet_fps_temp_floats.restype = ctypes.c_size_t
         L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_loss_workspace_floats.restype = ctypes.c_size_t
+        L.votenet_loss_workspace_floats.argtypes = [ctypes.c_int]
         L.votenet_nms3d_workspace_bytes.restype = ctypes.c_size_t
         L.votenet_nms3d_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_ball_threshold.restype = ctypes.c_float

@@ -45,67 +45,87 @@ __device__ __forceinline__ float softmax_ce(const float *lg, int c, int label, f
     return logf(s) + m - lg[label];
 }
 
-__global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
+// nearest ground-truth centre of proposal (px,py,pz) among the scene's boxes staged in LDS: -> distance, box index
+__device__ __forceinline__ float nearest_box(const float (*s_box)[8], int BB, float px, float py, float pz, int &g)
 {
-    __shared__ int s_np, s_nn;
-    __shared__ float s_red[LOSS_T / 64][LOSS_NACC];
-    const int tid = threadIdx.x;
-    const int B = A.b, N = A.n, P = A.p, BB = A.bb, NH = A.nh, NS = A.ns, NC = A.nc;
-    const int W = 5 + 2 * NH + 4 * NS + NC; // width of proposals_output (79)
-    // per-box constants once, in LDS: centre, half extents, cos / sin of -roty (the loops below touch them B*(N+P)*BB times)
-    constexpr int MAXBOX = 256;
-    __shared__ float s_box[MAXBOX][8];
-    const bool staged = B * BB <= MAXBOX;
-    for (int e = tid; e < B * BB && staged; e += LOSS_T) {
-        s_box[e][0] = A.gxyz[e * 3 + 0];
-        s_box[e][1] = A.gxyz[e * 3 + 1];
-        s_box[e][2] = A.gxyz[e * 3 + 2];
-        s_box[e][3] = A.glwh[e * 3 + 0] * 0.5f;
-        s_box[e][4] = A.glwh[e * 3 + 1] * 0.5f;
-        s_box[e][5] = A.glwh[e * 3 + 2] * 0.5f;
-        s_box[e][6] = cosf(-A.groty[e]);
-        s_box[e][7] = sinf(-A.groty[e]);
-    }
-    auto bx = [&](int gi, int k) { return staged ? s_box[gi][k] : A.gxyz[gi * 3 + k]; };
-    if (tid == 0) s_np = s_nn = 0;
-    __syncthreads();
-    // ---- proposals: nearest ground-truth centre, positive / negative (model.py:147-153)
-    int np_local = 0, nn_local = 0;
-    for (int q = tid; q < B * P; q += LOSS_T) {
-        const int b = q / P;
-        const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
-        float best = 0.0f;
-        for (int j = 0; j < BB; j++) {
-            const float dx = px - bx(b * BB + j, 0), dy = py - bx(b * BB + j, 1), dz = pz - bx(b * BB + j, 2);
-            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (j == 0 || d < best) best = d;
+    float best = 0.0f;
+    g = 0;
+    for (int j = 0; j < BB; j++) {
+        const float dx = px - s_box[j][0], dy = py - s_box[j][1], dz = pz - s_box[j][2];
+        const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+        if (j == 0 || d < best) { // tf.argmin: first minimum
+            best = d;
+            g = j;
         }
+    }
+    return best;
+}
+
+constexpr int LOSS_MAXBOX = 256; // boxes per scene
+
+// pass 1: one workgroup per scene counts its positive / negative proposals (model.py:147-153); the means of the loss are
+// over the counts of the WHOLE batch, so they have to exist before any cotangent can be written.
+__global__ __launch_bounds__(256) void votenet_loss_count_kernel(LossArgs A, int *counts)
+{
+    __shared__ float s_box[LOSS_MAXBOX][8];
+    const int b = blockIdx.x, tid = threadIdx.x, BB = A.bb, P = A.p;
+    for (int j = tid; j < BB; j += 256)
+        for (int k = 0; k < 3; k++) s_box[j][k] = A.gxyz[(b * BB + j) * 3 + k];
+    __syncthreads();
+    int np_local = 0, nn_local = 0;
+    for (int pq = tid; pq < P; pq += 256) {
+        const int q = b * P + pq;
+        int g;
+        const float best = nearest_box(s_box, BB, A.pxyz[q * 3 + 0], A.pxyz[q * 3 + 1], A.pxyz[q * 3 + 2], g);
         np_local += best < A.pos_thr;
         nn_local += best > A.neg_thr;
     }
-    if (np_local) atomicAdd(&s_np, np_local);
-    if (nn_local) atomicAdd(&s_nn, nn_local);
+    for (int off = 32; off > 0; off >>= 1) {
+        np_local += __shfl_down(np_local, off);
+        nn_local += __shfl_down(nn_local, off);
+    }
+    if ((tid & 63) == 0) {
+        if (np_local) atomicAdd(&counts[0], np_local);
+        if (nn_local) atomicAdd(&counts[1], nn_local);
+    }
+}
+
+// pass 2: one workgroup per scene: every loss term and cotangent of its proposals, boxes and seeds; the per-scene partial
+// sums are combined by the last workgroup to finish, in scene order (bit-reproducible).
+__global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *counts, float *partial /* b x LOSS_NACC */)
+{
+    __shared__ float s_box[LOSS_MAXBOX][8];
+    __shared__ float s_red[LOSS_T / 64][LOSS_NACC];
+    __shared__ int s_last;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int B = A.b, N = A.n, P = A.p, BB = A.bb, NH = A.nh, NS = A.ns, NC = A.nc;
+    const int W = 5 + 2 * NH + 4 * NS + NC; // width of proposals_output (79)
+    // per-box constants once, in LDS: centre, half extents, cos / sin of -roty (the loops below touch them (N+P)*BB times)
+    for (int j = tid; j < BB; j += LOSS_T) {
+        const int e = b * BB + j;
+        s_box[j][0] = A.gxyz[e * 3 + 0];
+        s_box[j][1] = A.gxyz[e * 3 + 1];
+        s_box[j][2] = A.gxyz[e * 3 + 2];
+        s_box[j][3] = A.glwh[e * 3 + 0] * 0.5f;
+        s_box[j][4] = A.glwh[e * 3 + 1] * 0.5f;
+        s_box[j][5] = A.glwh[e * 3 + 2] * 0.5f;
+        s_box[j][6] = cosf(-A.groty[e]);
+        s_box[j][7] = sinf(-A.groty[e]);
+    }
     __syncthreads();
-    const float inv_np = 1.0f / (float)s_np, inv_nn = 1.0f / (float)s_nn; // empty set -> inf -> NaN loss, as reduce_mean of []
+    const int n_pos = counts[0], n_neg = counts[1];
+    const float inv_np = 1.0f / (float)n_pos, inv_nn = 1.0f / (float)n_neg; // empty set -> inf -> NaN loss, as reduce_mean of []
     // accumulators: 0 vote, 1 obj_pos, 2 obj_neg, 3 center, 4 center_dual, 5 hcls, 6 hres, 7 scls, 8 sres, 9 sem
     float acc[LOSS_NACC];
 #pragma unroll
     for (int i = 0; i < LOSS_NACC; i++) acc[i] = 0.0f;
     float pr[LOSS_MAXC];
     // ---- proposals: losses and cotangents (model.py:156-212); every weight of model.py:205,228 folded in
-    for (int q = tid; q < B * P; q += LOSS_T) {
-        const int b = q / P;
+    for (int pq = tid; pq < P; pq += LOSS_T) {
+        const int q = b * P + pq;
         const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
-        float best = 0.0f;
-        int g = 0;
-        for (int j = 0; j < BB; j++) {
-            const float dx = px - bx(b * BB + j, 0), dy = py - bx(b * BB + j, 1), dz = pz - bx(b * BB + j, 2);
-            const float d = sqrtf(dx * dx + dy * dy + dz * dz);
-            if (j == 0 || d < best) { // tf.argmin: first minimum
-                best = d;
-                g = j;
-            }
-        }
+        int g;
+        const float best = nearest_box(s_box, BB, px, py, pz, g);
         const float *o = A.pout + (size_t)q * W;
         float *go = A.d_pout + (size_t)q * W;
         const bool pos = best < A.pos_thr, neg = best > A.neg_thr;
@@ -119,7 +139,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         if (pos) {
             const int gi = b * BB + g;
             // centre (weight 1): error = prediction - (gt centre - proposal centre)
-            const float cg[3] = {A.gxyz[gi * 3 + 0] - px, A.gxyz[gi * 3 + 1] - py, A.gxyz[gi * 3 + 2] - pz};
+            const float cg[3] = {s_box[g][0] - px, s_box[g][1] - py, s_box[g][2] - pz};
             for (int k = 0; k < 3; k++) {
                 float gr;
                 acc[3] += huber(o[2 + k] - cg[k], gr);
@@ -152,9 +172,9 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
     }
     // ---- Chamfer / dual centre term (model.py:172-177): every ground-truth box pulls its nearest proposal
     const float inv_bbb = 1.0f / (float)(B * BB);
-    for (int e = tid >> 6; e < B * BB; e += LOSS_T / 64) { // one wave per box: lanes scan the proposals, wave arg-min
-        const int b = e / BB, lane = tid & 63;
-        const float gx = bx(e, 0), gy = bx(e, 1), gz = bx(e, 2);
+    for (int j = tid >> 6; j < BB; j += LOSS_T / 64) { // one wave per box: lanes scan the proposals, wave arg-min
+        const int lane = tid & 63;
+        const float gx = s_box[j][0], gy = s_box[j][1], gz = s_box[j][2];
         float best = INFINITY;
         int bp = 0x7FFFFFFF;
         for (int p = lane; p < P; p += 64) {
@@ -185,21 +205,18 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
     }
     // ---- seeds: vote targets and vote regression loss (model.py:61-84)
     const float inv_bn = 1.0f / (float)(B * N);
-    for (int e = tid; e < B * N; e += LOSS_T) {
-        const int b = e / N;
+    for (int i = tid; i < N; i += LOSS_T) {
+        const int e = b * N + i;
         const float sx = A.seeds[e * 3 + 0], sy = A.seeds[e * 3 + 1], sz = A.seeds[e * 3 + 2];
         float best = 0.0f;
         int g = 0;
         bool surface = false;
         for (int j = 0; j < BB; j++) {
-            const int gi = b * BB + j;
             // |seed - centre| first, THEN the rotation by -roty (the reference's order, model.py:61,74)
-            const float dx = fabsf(sx - bx(gi, 0)), dy = fabsf(sy - bx(gi, 1)), dz = fabsf(sz - bx(gi, 2));
-            const float c = staged ? s_box[gi][6] : cosf(-A.groty[gi]), s = staged ? s_box[gi][7] : sinf(-A.groty[gi]);
-            const float hx = staged ? s_box[gi][3] : A.glwh[gi * 3 + 0] * 0.5f, hy = staged ? s_box[gi][4] : A.glwh[gi * 3 + 1] * 0.5f,
-                        hz = staged ? s_box[gi][5] : A.glwh[gi * 3 + 2] * 0.5f;
+            const float dx = fabsf(sx - s_box[j][0]), dy = fabsf(sy - s_box[j][1]), dz = fabsf(sz - s_box[j][2]);
+            const float c = s_box[j][6], s = s_box[j][7];
             const float rx = c * dx + s * dz, ry = dy, rz = -s * dx + c * dz;
-            surface = surface || (rx < hx && ry < hy && rz < hz);
+            surface = surface || (rx < s_box[j][3] && ry < s_box[j][4] && rz < s_box[j][5]);
             const float d = sqrtf(rx * rx + ry * ry + rz * rz);
             if (j == 0 || d < best) {
                 best = d;
@@ -207,15 +224,14 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
             }
         }
         if (surface) {
-            const int gi = b * BB + g;
             for (int k = 0; k < 3; k++) {
-                const float df = A.votes[e * 3 + k] - A.gxyz[gi * 3 + k];
+                const float df = A.votes[e * 3 + k] - s_box[g][k];
                 acc[0] += fabsf(df);
                 A.d_votes[e * 3 + k] = (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f)) * inv_bn;
             }
         }
     }
-    // ---- fixed-order reduction of the accumulators
+    // ---- fixed-order reduction: lanes -> waves -> scene partial -> (last workgroup) scenes in order
 #pragma unroll
     for (int i = 0; i < LOSS_NACC; i++) {
         float v = acc[i];
@@ -223,11 +239,21 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         if ((tid & 63) == 0) s_red[tid >> 6][i] = v;
     }
     __syncthreads();
-    if (tid == 0) {
+    if (tid < LOSS_NACC) {
+        float v = 0.0f;
+        for (int w = 0; w < LOSS_T / 64; w++) v += s_red[w][tid];
+        partial[b * LOSS_NACC + tid] = v;
+    }
+    __threadfence(); // the partial sums are visible device-wide before the ticket is taken
+    __syncthreads();
+    if (tid == 0) s_last = (atomicAdd(&counts[2], 1) == B - 1);
+    __syncthreads();
+    if (s_last && tid == 0) {
+        __threadfence();
         float t[LOSS_NACC];
         for (int i = 0; i < LOSS_NACC; i++) {
             float v = 0.0f;
-            for (int w = 0; w < LOSS_T / 64; w++) v += s_red[w][i];
+            for (int sc = 0; sc < B; sc++) v += __builtin_nontemporal_load(&partial[sc * LOSS_NACC + i]);
             t[i] = v;
         }
         const float vote = t[0] * inv_bn;
@@ -246,8 +272,8 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
         L[7] = sres;
         L[8] = sem;
         L[9] = box;
-        L[10] = (float)s_np;
-        L[11] = (float)s_nn;
+        L[10] = (float)n_pos;
+        L[11] = (float)n_neg;
     }
 }
 
@@ -255,24 +281,30 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A)
 
 using namespace votenet;
 
+extern "C" size_t votenet_loss_workspace_floats(int b) { return 4 + (size_t)(b > 0 ? b : 0) * LOSS_NACC; }
+
 extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
                             const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, const float *bboxes_xyz,
                             const float *bboxes_lwh, const float *bboxes_roty, const int *semantic_labels, const int *heading_labels,
                             const float *heading_residuals, const int *size_labels, const float *size_residuals, float pos_thr,
                             float neg_thr, float *losses, float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output,
-                            void *stream)
+                            float *workspace, void *stream)
 {
     VN_REQUIRE(b > 0 && n_seeds > 0 && n_prop > 0 && n_box > 0, "votenet_loss expects b, n_seeds, n_prop, n_box > 0");
+    VN_REQUIRE(n_box <= LOSS_MAXBOX, "votenet_loss expects at most 256 boxes per scene");
     VN_REQUIRE(nh > 0 && ns > 0 && nc > 0 && nh <= LOSS_MAXC && ns <= LOSS_MAXC && nc <= LOSS_MAXC, "votenet_loss expects 0 < nh, ns, nc <= 32");
     VN_REQUIRE(pos_thr < neg_thr, "votenet_loss expects pos_thr < neg_thr (config.py)");
     VN_REQUIRE(seeds_xyz && votes_xyz && proposals_xyz && proposals_output && bboxes_xyz && bboxes_lwh && bboxes_roty &&
                    semantic_labels && heading_labels && heading_residuals && size_labels && size_residuals && losses &&
-                   d_votes_xyz && d_proposals_xyz && d_proposals_output,
+                   d_votes_xyz && d_proposals_xyz && d_proposals_output && workspace,
                "votenet_loss: null buffer");
     LossArgs a = {b, n_seeds, n_prop, n_box, nh, ns, nc, seeds_xyz, votes_xyz, proposals_xyz, proposals_output, bboxes_xyz, bboxes_lwh,
                   bboxes_roty, semantic_labels, heading_labels, size_labels, heading_residuals, size_residuals, pos_thr, neg_thr, losses,
                   d_votes_xyz, d_proposals_xyz, d_proposals_output};
-    hipLaunchKernelGGL(votenet_loss_kernel, dim3(1), dim3(LOSS_T), 0, as_stream(stream), a);
+    int *counts = reinterpret_cast<int *>(workspace); // [positives, negatives, finished workgroups, pad], zero on entry
+    hipStream_t st = as_stream(stream);
+    hipLaunchKernelGGL(votenet_loss_count_kernel, dim3(b), dim3(256), 0, st, a, counts);
+    hipLaunchKernelGGL(votenet_loss_kernel, dim3(b), dim3(LOSS_T), 0, st, a, counts, workspace + 4);
     return check_launch("votenet_loss");
 }
 

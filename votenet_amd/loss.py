@@ -31,13 +31,17 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
         raise L.InvalidArgumentError("loss: proposals_output has %d channels, expected %d" % (pout.shape[2], 5 + 2 * nh + 4 * ns + nc))
     dev = seeds.device
     losses = torch.empty(12, dtype=torch.float32, device=dev)
-    d_votes, d_pxyz, d_pout = torch.zeros_like(votes), torch.zeros_like(pxyz), torch.zeros_like(pout)
+    # the three cotangents and the kernel's workspace are ONE buffer cleared by ONE fill
+    nv, npx, npo, nws = votes.numel(), pxyz.numel(), pout.numel(), int(L.lib().votenet_loss_workspace_floats(b))
+    flat = torch.zeros(nv + npx + npo + nws, dtype=torch.float32, device=dev)
+    d_votes, d_pxyz = flat[:nv].view_as(votes), flat[nv:nv + npx].view_as(pxyz)
+    d_pout, ws = flat[nv + npx:nv + npx + npo].view_as(pout), flat[nv + npx + npo:]
     with torch.cuda.device(dev):
         L.check(L.lib().votenet_loss(b, n, p, bb, nh, ns, nc, L.ptr(seeds), L.ptr(votes), L.ptr(pxyz), L.ptr(pout),
                                      L.ptr(gt["bboxes_xyz"]), L.ptr(gt["bboxes_lwh"]), L.ptr(gt["bboxes_roty"]),
                                      L.ptr(gt["semantic_labels"]), L.ptr(gt["heading_labels"]), L.ptr(gt["heading_residuals"]),
                                      L.ptr(gt["size_labels"]), L.ptr(gt["size_residuals"]), POSITIVE_THRES, NEGATIVE_THRES,
-                                     L.ptr(losses), L.ptr(d_votes), L.ptr(d_pxyz), L.ptr(d_pout), L.stream_ptr()))
+                                     L.ptr(losses), L.ptr(d_votes), L.ptr(d_pxyz), L.ptr(d_pout), L.ptr(ws), L.stream_ptr()))
     return losses, dict(votes_xyz=d_votes, proposals_xyz=d_pxyz, proposals_output=d_pout)
 
 
