@@ -268,6 +268,10 @@ int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const floa
                          int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
                          float *da_prev, void *stream);
 
+/* dst[dst_off + c*rows + r] = src[src_off + r*cols + c] for every entry table[e] = {src_off, dst_off, rows, cols}
+ * (device array of 4*nseg longs, element offsets): all W^T blocks the input-gradient GEMMs need, in one launch. */
+int votenet_transpose_segments(int nseg, const long *table, const float *src, float *dst, void *stream);
+
 /* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78) on the
  * feature columns + the gradients of grouped_xyz - tile(new_xyz) on the xyz columns.  The per-row input
  * gradients are given separately: d_rows_feat (b*m*nsample x c) and d_rows_xyz (b*m*nsample x 3):

@@ -885,3 +885,44 @@ extern "C" int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scr
                        bc1, bc2, grad_scale, clip_avg_norm);
     return check_launch("clip_adam");
 }
+
+// ---------------------------------------------------------------- weight transposes for the input-gradient GEMMs
+// da = dz . W^T wants W^T (cout x cin) row-major.  One launch transposes every weight block of the flat parameter bucket
+// into a parallel bucket: table[e] = {src offset, dst offset, rows, cols} (elements); one workgroup per entry, 32 x 32
+// tiles through LDS (coalesced on both sides).  The weights do not change between the forward and the backward pass of a
+// step, so the launch rides on a side stream underneath the sa1 farthest-point sampling.
+namespace votenet {
+__global__ __launch_bounds__(256) void transpose_segments_kernel(const long *__restrict__ table, const float *__restrict__ src,
+                                                                float *__restrict__ dst)
+{
+    __shared__ float tile[32][33];
+    const long so = table[4 * blockIdx.x + 0], dof = table[4 * blockIdx.x + 1];
+    const int rows = (int)table[4 * blockIdx.x + 2], cols = (int)table[4 * blockIdx.x + 3];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
+    const int tr = (rows + 31) / 32, tc = (cols + 31) / 32;
+    for (int t = 0; t < tr * tc; t++) {
+        const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int r = r0 + ty + 8 * k, c = c0 + tx;
+            tile[ty + 8 * k][tx] = (r < rows && c < cols) ? src[so + (long)r * cols + c] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = c0 + ty + 8 * k, r = r0 + tx; // dst[c][r]
+            if (c < cols && r < rows) dst[dof + (long)c * rows + r] = tile[tx][ty + 8 * k];
+        }
+        __syncthreads();
+    }
+}
+} // namespace votenet
+
+extern "C" int votenet_transpose_segments(int nseg, const long *table, const float *src, float *dst, void *stream)
+{
+    VN_REQUIRE(nseg >= 0, "transpose_segments expects nseg >= 0");
+    if (nseg == 0) return VOTENET_OK;
+    VN_REQUIRE(table && src && dst, "transpose_segments: null buffer");
+    hipLaunchKernelGGL(votenet::transpose_segments_kernel, dim3(nseg), dim3(256), 0, as_stream(stream), table, src, dst);
+    return check_launch("transpose_segments");
+}

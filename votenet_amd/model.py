@@ -11,6 +11,8 @@ driven, checked and timed end to end:
     voting FC 259->256->256->259 (BNReLU,BNReLU,none); votes = [seed_xyz, seed_feat] + offset
     proposal SA on votes, FPS on seeds (utils.py:42-43), 256 x r0.3 K64 [128,128,128] + [128,128,79]
 """
+import os
+
 import torch
 
 from . import dp
@@ -214,12 +216,17 @@ class VoteNetHotPath:
         if not hasattr(self, "_seg"):
             self.init_optimizer()
         self.store.grad.zero_()
+        # every W^T of the backward pass's input-gradient GEMMs: one launch on the geometry stream, under the sa1 FPS
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        self.store.refresh_transposes(self._side)
         tape = []
         out = self.forward(x, tape)
         if gt is not None:
             from . import loss as VL
             self.last_losses, cot = VL.votenet_loss(out, gt)
         self.backward(tape, cot)
+        self.store.invalidate_transposes()      # the optimizer changes W
         gscale = dp.sync_gradients(self.store)  # ONE all-reduce (sum) of the flat bucket; 1/world goes to the optimizer
         self._step += 1
         M.clip_adam(self._seg, self._sumsq, self.store.flat, self.store.grad, self._m, self._v, self._lr, self._step,

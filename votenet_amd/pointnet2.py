@@ -35,6 +35,59 @@ class ParamStore:
         self.grad = None
         self.views = {}
         self.gviews = {}
+        self._tspecs = []   # (tensor name, row_lo, row_hi): W^T blocks wanted by the input-gradient GEMMs
+        self._tviews = {}
+        self._tflat = self._ttable = None
+        self.t_event = None  # recorded after the transposes of the current step; None = stale
+
+    def want_transpose(self, name, lo=0, hi=None):
+        """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
+        refresh_transposes() fills with a single launch per step."""
+        self._tspecs.append((name, lo, hi))
+
+    def refresh_transposes(self, stream=None):
+        """One launch for every registered W^T block, on `stream` (default: the current one); transposed() makes the
+        current stream wait for it.  Call again whenever the parameters changed (once per training step)."""
+        if not self._tspecs:
+            return
+        if self._tflat is None:
+            base = self.flat.data_ptr()
+            table, total = [], 0
+            for name, lo, hi in self._tspecs:
+                v = self.views[name]
+                hi_ = v.shape[0] if hi is None else hi
+                rows, cols = hi_ - lo, v.shape[1]
+                table += [(v.data_ptr() - base) // 4 + lo * cols, total, rows, cols]
+                self._tviews[(name, lo, hi)] = (total, cols, rows)
+                total += (rows * cols + 3) // 4 * 4
+            self._tflat = torch.empty(total, dtype=torch.float32, device=self.device)
+            self._ttable = torch.tensor(table, dtype=torch.int64, device=self.device)
+            for key, (off, r, c) in list(self._tviews.items()):
+                self._tviews[key] = self._tflat[off:off + r * c].view(r, c)
+        from . import _lib as L_
+        cur = torch.cuda.current_stream()
+        st = stream if stream is not None else cur
+        if st is not cur:
+            st.wait_stream(cur)  # the optimizer's update of the parameters is on the caller's stream
+        with torch.cuda.device(self.device), torch.cuda.stream(st):
+            L_.check(L_.lib().votenet_transpose_segments(len(self._tspecs), L_.ptr(self._ttable), L_.ptr(self.flat),
+                                                         L_.ptr(self._tflat), L_.stream_ptr()))
+            self.t_event = torch.cuda.Event()
+            self.t_event.record(st)
+        self._t_waited = False
+
+    def invalidate_transposes(self):
+        self.t_event = None
+
+    def transposed(self, name, lo=0, hi=None):
+        """W[lo:hi]^T, contiguous: from the per-step bucket when registered and fresh, else an ad-hoc copy."""
+        v = self._tviews.get((name, lo, hi)) if self.t_event is not None else None
+        if v is None or not isinstance(v, torch.Tensor):
+            return self.views[name][lo:hi].t().contiguous()
+        if not self._t_waited:
+            torch.cuda.current_stream().wait_event(self.t_event)
+            self._t_waited = True
+        return v
 
     def declare(self, name, shape, init):
         self._specs.append((name, tuple(shape), init))
@@ -75,6 +128,7 @@ class Layer:
     def __init__(self, store, name, cin, cout, bn=True, relu=True):
         self.store, self.name, self.cin, self.cout, self.bn, self.relu = store, name, cin, cout, bn, relu
         store.declare(name + "/W", (cin, cout), "he")
+        store.want_transpose(name + "/W")
         store.declare(name + "/b", (cout,), "zeros")
         if bn:
             store.declare(name + "/gamma", (cout,), "ones")
@@ -82,6 +136,9 @@ class Layer:
 
     def p(self, k):
         return self.store[self.name + "/" + k]
+
+    def wT(self, lo=0, hi=None):
+        return self.store.transposed(self.name + "/W", lo, hi)
 
     def gp(self, k):
         return self.store.g(self.name + "/" + k)
@@ -224,7 +281,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
                                      in_relu=r["in_relu"], **src)
                 if not want_da:
                     return None
-                da = M.dgrad_bn(z, coef, L.relu, L.p("W").t().contiguous(), **src)
+                da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
                 continue
             if i == 0 and r["kind"] == "gather" and PRE_LINEAR and not pooled and r["feat"] is not None and \
                     M.group_linear_backward_supported(c, r["idx"].shape[2]):
@@ -238,7 +295,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
         with _OnWgradStream(dz, r.get("x")):
             M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
         if want_da:
-            da, _ = M.linear_dense(dz, L.p("W").t().contiguous(), want_stats=False)  # da_prev = dz W^T
+            da, _ = M.linear_dense(dz, L.wT(), want_stats=False)  # da_prev = dz W^T
         else:
             da = None
     return da
@@ -259,6 +316,8 @@ class SAModule:
     def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None):
         self.npoint, self.radius, self.nsample = npoint, radius, nsample
         self.mlp = make_mlp(store, scope, 3 + cin, mlp, "conv")
+        store.want_transpose(self.mlp[0].name + "/W", 3, None)  # W[3:]^T: the per-point feature gradient
+        store.want_transpose(self.mlp[0].name + "/W", 0, 3)     # W[:3]^T: the xyz gradient (proposal layer)
         self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
 
     def geometry(self, xyz, sample_xyz=None, fps_idx=None):
@@ -336,16 +395,16 @@ class SAModule:
                 with _OnWgradStream(S2, feat2):
                     M.wgrad_dense(feat2, S2, gW[3:])
                 if need_feat:
-                    d2, _ = M.linear_dense(S2, W[3:].t().contiguous(), want_stats=False)
+                    d2, _ = M.linear_dense(S2, L0.wT(3, None), want_stats=False)
                     d_feat = d2.view(b, n, c)
             else:  # the fused GATHER GEMMs over the grouped rows
                 with _OnWgradStream(dz, feat):
                     M.wgrad_gather(xyz, new_xyz, feat, idx, dz, gW)
                 if need_feat:
-                    d_rows_feat, _ = M.linear_dense(dz, W[3:].t().contiguous(), want_stats=False)
+                    d_rows_feat, _ = M.linear_dense(dz, L0.wT(3, None), want_stats=False)
                     d_feat, _, _ = M.group_concat_grad(d_rows_feat, None, idx, pts_cnt, n, c)
         if need_xyz_grad:
-            d_rows_xyz, _ = M.linear_dense(dz, W[:3].t().contiguous(), want_stats=False)
+            d_rows_xyz, _ = M.linear_dense(dz, L0.wT(0, 3), want_stats=False)
             _, d_xyz, d_new = M.group_concat_grad(None, d_rows_xyz, idx, pts_cnt, n, 0)
             d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
         return d_feat, d_xyz
