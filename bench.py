@@ -82,6 +82,7 @@ def cpu_baseline(points, scene_kind):
     px, pp = sa(vx, vp, 256, 0.3, 64, [128, 128, 128], sample_xyz=l2x)
     mlp(pp.reshape(-1, 128), [128, 128, 128, 79], last_plain=True)
     dt = time.perf_counter() - t0
+    gc.enable()
     return {"value": 1.0 / dt, "unit": "scenes/s", "cores": 1, "kind": "port",
             "sample": "forward pass of 1 synthetic %d-pt scene through the same layer stack on the CPU oracle "
                       "(single thread, %.1f s; the oracle has no backward)" % (points, dt)}
@@ -141,6 +142,9 @@ def main():
     tf_grouping.PROFILE_EVENTS = []
     vmlp.PROFILE_EVENTS = []
     events, bq_events, gemm_events = [], [], []
+    import gc
+    gc.collect()
+    gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
     t0 = time.perf_counter()
     for i in range(args.steps):
         if i == prof_steps:
