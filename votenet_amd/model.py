@@ -1,9 +1,9 @@
-"""Minimal driver of the hot path in VoteNet's layer configuration (the caller side of the path).
+"""Driver of the hot path in VoteNet's layer configuration (the caller side of the path).
 
-This is NOT a reimplementation of the reference's model.py (losses, GT assignment and box decode
-are out of scope): it wires the SA / FP / voting / proposal layers with the
-exact shapes and hyper-parameters of model.py:39-49,53-61,89-93 so that the hot path can be
-driven, checked and timed end to end:
+It wires the SA / FP / voting / proposal layers with the exact shapes and hyper-parameters of
+model.py:39-49,53-61,89-93, the reference's loss graph (loss.py: model.py:61-84,141-231 as one kernel),
+the predict tower (box decode -> 3D NMS, model.py:98-139) and the optimizer (model.py:240-250), so that
+the hot path can be driven, checked and timed end to end:
 
     sa1 20480->2048 r0.2 K64 [64,64,128]     sa2 ->1024 r0.4 [128,128,256]
     sa3 ->512 r0.8 [128,128,256]             sa4 ->256 r1.2 [128,128,256]
@@ -11,7 +11,6 @@ driven, checked and timed end to end:
     voting FC 259->256->256->259 (BNReLU,BNReLU,none); votes = [seed_xyz, seed_feat] + offset
     proposal SA on votes, FPS on seeds (utils.py:42-43), 256 x r0.3 K64 [128,128,128] + [128,128,79]
 """
-import os
 
 import torch
 
@@ -148,8 +147,8 @@ class VoteNetHotPath:
 
     # ---- backward / training --------------------------------------------------------
     def make_cotangents(self, b, seed=0):
-        """Synthetic upstream gradients standing in for the reference's loss graph (model.py:141-231,
-        out of scope): d loss / d proposals_output (B,256,79) and d loss / d votes_xyz (B,1024,3)."""
+        """Fixed upstream gradients (tests of the backward pass, scenes without ground truth): d loss / d proposals_output
+        (B,256,79) and d loss / d votes_xyz (B,1024,3).  Training uses the loss graph instead (train_step(gt=...))."""
         g = torch.Generator(device="cpu").manual_seed(1234 + seed)
         n_seed = self.sa2.npoint
         return dict(proposals_output=(torch.randn(b, PROPOSAL_NUM, PROPOSAL_OUT, generator=g) / (b * PROPOSAL_NUM)).to(self.device),

@@ -16,7 +16,6 @@ single RCCL all-reduce over one contiguous gradient buffer per step.
 """
 import math
 
-import os
 
 import torch
 
@@ -159,7 +158,7 @@ def make_mlp(store, scope, cin, widths, prefix="conv", last_plain=False):
 PRE_LINEAR = True
 # Max-pool over the nsample rows of a group started in the last GEMM's epilogue (votenet_mlp_linear_pool) instead of a
 # separate pass over z (votenet_bn_relu_max).
-POOL_IN_EPILOGUE = os.environ.get('VOTENET_POOL_EPI', '1') != '0'
+POOL_IN_EPILOGUE = True
 
 
 def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
