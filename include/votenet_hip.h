@@ -142,12 +142,24 @@ size_t votenet_nms3d_workspace_bytes(int b, int n);
  * and the output is z = row * W + bias, plus per-channel sum / sum of squares of z
  * (the BatchNorm batch statistics of this layer) accumulated into stats[2*cout].
  */
+/* The BatchNorm of a tensor, given by the RAW column sums of the launch that produced it (votenet_mlp_linear stats):
+ * the consumer derives mean / var / scale / shift itself (votenet_bn_finalize's arithmetic) in its prologue, so no
+ * separate finalize launch exists, and one of its workgroups writes them to out for the backward pass. */
+typedef struct votenet_bn_raw {
+    const double *stats;       /* 2*c: column sums of z, of z*z */
+    const float *gamma, *beta; /* c each */
+    long rows;                 /* rows the sums run over */
+    float eps;
+    float *out;                /* 4*c floats: scale | shift | mean | var (may be NULL) */
+} votenet_bn_raw;
+
 typedef struct votenet_mlp_input {
     /* DENSE source (rows x cin); NULL for GATHER */
     const float *x;
     const float *in_scale; /* cin, or NULL: no affine+relu on load */
     const float *in_shift; /* cin */
     int in_relu;           /* apply max(0,.) after the affine */
+    const votenet_bn_raw *in_bn; /* alternative to in_scale / in_shift: the affine comes from raw statistics, or NULL */
     /* GATHER source */
     const float *xyz;     /* (b,n,3) */
     const float *new_xyz; /* (b,m,3) */
@@ -209,13 +221,13 @@ int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int
                             float *z /* may be NULL */, double *stats, int pool_k, float *zmax, float *zmin, int *amax,
                             int *amin, void *stream);
 int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
-                             const float *scale, const float *shift, int relu, float *out, int *argmax /* may be NULL */,
-                             void *stream);
+                             const float *scale, const float *shift, const votenet_bn_raw *bn /* instead of scale / shift, or NULL */,
+                             int relu, float *out, int *argmax /* may be NULL */, void *stream);
 
 /* y = max(0?, z*scale+shift) materialised (rows x c); used where the next consumer is not a
  * votenet_mlp_linear (e.g. the FP-layer output that feeds the voting head). */
-int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,
-                    void *stream);
+int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift,
+                    const votenet_bn_raw *bn /* instead of scale / shift, or NULL */, int relu, float *y, void *stream);
 
 
 /* ---------------------------------------------------------------- grouped-point MLP, backward

@@ -188,3 +188,42 @@ def test_sa_mlp_stack_cfg1(hiplib, dev, O):
     # argmax points at a row attaining the max
     full = N(mlp.bn_relu(z, sc, sh)).reshape(512, 32, 128)
     assert (np.take_along_axis(full, N(arg)[:, None, :].astype(np.int64), 1)[:, 0, :] == got).all()
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4096, 64, 128), (2048, 128, 256), (777, 48, 79), (640, 256, 128)])
+def test_consumer_side_bn_finalize(hiplib, dev, rows, cin, cout):
+    """struct votenet_bn_raw: a consumer that derives BatchNorm scale / shift from the producer's raw sums in its prologue
+    (and records scale | shift | mean | var) against the stand-alone votenet_bn_finalize + the same consumer."""
+    from votenet_amd import mlp
+    g = torch.Generator().manual_seed(rows + cin)
+    x0 = torch.randn(rows, 32, generator=g).to(dev)
+    w0 = (torch.randn(32, cin, generator=g) * 0.3).to(dev)
+    gamma = (torch.randn(cin, generator=g) * 0.3 + 1).to(dev)
+    beta = (torch.randn(cin, generator=g) * 0.2).to(dev)
+    w = (torch.randn(cin, cout, generator=g) * 0.2).to(dev)
+    zp, st = mlp.linear_dense(x0, w0)
+    sc, sh, mean, var = mlp.bn_finalize(rows, st, gamma, beta)
+    z_ref, st_ref = mlp.linear_dense(zp, w, None, sc, sh, True)
+    pend = mlp.PendingBN(st, gamma, beta, rows)
+    z, st2 = mlp.linear_dense(zp, w, None, None, None, True, in_bn=pend)
+    assert pend.done and torch.equal(z, z_ref) and torch.equal(st2, st_ref)
+    for got, exp in zip(pend.out, (sc, sh, mean, var)):
+        assert torch.equal(got, exp)
+    # a second consumer of the same BatchNorm reads the recorded vectors
+    z3, _ = mlp.linear_dense(zp, w, None, None, None, True, in_bn=pend)
+    assert torch.equal(z3, z_ref)
+    # the activation pass and the pooled finalize as consumers
+    pend = mlp.PendingBN(st, gamma, beta, rows)
+    assert torch.equal(mlp.bn_relu(zp, None, None, True, bn=pend), mlp.bn_relu(zp, sc, sh, True))
+    assert torch.equal(pend.out[2], mean) and torch.equal(pend.out[3], var)
+    if mlp.linear_pool_supported(rows, 32, cin, 64):
+        _, stp, pool = mlp.linear_dense_pool(x0, w0, 64)
+        pend = mlp.PendingBN(stp, gamma, beta, rows)
+        out, arg = mlp.bn_pool_finalize(pool, None, None, True, want_argmax=True, bn=pend)
+        scp, shp, _, _ = mlp.bn_finalize(rows, stp, gamma, beta)
+        out_ref, arg_ref = mlp.bn_pool_finalize(pool, scp, shp, True, want_argmax=True)
+        assert torch.equal(out, out_ref) and torch.equal(arg, arg_ref) and torch.equal(pend.out[0], scp)
+    # finalize() on a BatchNorm nobody consumed launches the stand-alone kernel
+    pend = mlp.PendingBN(st, gamma, beta, rows)
+    s2, h2 = pend.finalize()
+    assert torch.equal(s2, sc) and torch.equal(h2, sh)

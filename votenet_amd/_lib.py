@@ -54,10 +54,16 @@ _SIGS = {
 }
 
 
+class BnRaw(ctypes.Structure):
+    """struct votenet_bn_raw (include/votenet_hip.h)."""
+    _fields_ = [("stats", ctypes.c_void_p), ("gamma", ctypes.c_void_p), ("beta", ctypes.c_void_p), ("rows", ctypes.c_long),
+                ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
+
+
 class MlpInput(ctypes.Structure):
     """struct votenet_mlp_input (include/votenet_hip.h)."""
     _fields_ = [("x", ctypes.c_void_p), ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p),
-                ("in_relu", ctypes.c_int),
+                ("in_relu", ctypes.c_int), ("in_bn", ctypes.POINTER(BnRaw)),
                 ("xyz", ctypes.c_void_p), ("new_xyz", ctypes.c_void_p), ("feat", ctypes.c_void_p), ("idx", ctypes.c_void_p),
                 ("b", ctypes.c_int), ("n", ctypes.c_int), ("m", ctypes.c_int), ("nsample", ctypes.c_int), ("c", ctypes.c_int)]
 
@@ -68,14 +74,15 @@ _SIGS.update({
     "votenet_group_linear_backward": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_mlp_linear_pool": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
                                + [_c_f] * 4 + [ctypes.c_void_p],
-    "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.POINTER(BnRaw), ctypes.c_int] + [_c_f] * 2
+                                + [ctypes.c_void_p],
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
-    "votenet_bn_relu": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_bn_relu": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.POINTER(BnRaw), ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_bn_backward_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 7 + [ctypes.c_float, ctypes.c_int, _c_f,
                                                                                              ctypes.c_void_p],
     "votenet_bn_backward_apply": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],

@@ -17,6 +17,37 @@ inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s);
         if (!(cond)) return ::votenet::set_error(VOTENET_E_INVALID_ARGUMENT, __VA_ARGS__); \
     } while (0)
 
+// ---- BatchNorm from raw sums in the consumer's prologue (struct votenet_bn_raw) ----
+struct BnRaw {
+    const double *stats;
+    const float *gamma, *beta;
+    long rows;
+    float eps;
+    float *out;
+};
+inline BnRaw to_raw(const votenet_bn_raw *b)
+{
+    BnRaw r = {};
+    if (b) r = BnRaw{b->stats, b->gamma, b->beta, b->rows, b->eps, b->out};
+    return r;
+}
+// scale / shift of channel o (bn_finalize_kernel's arithmetic); `writer`: this thread also records the four vectors
+__device__ __forceinline__ void bn_raw_channel(const BnRaw &r, int c, int o, bool writer, float &sc, float &sh)
+{
+    const double mu = r.stats[o] / (double)r.rows;
+    double v = r.stats[c + o] / (double)r.rows - mu * mu;
+    if (v < 0) v = 0;
+    const float muf = (float)mu, vf = (float)v;
+    sc = r.gamma[o] / sqrtf(vf + r.eps);
+    sh = r.beta[o] - muf * sc;
+    if (writer && r.out) {
+        r.out[o] = sc;
+        r.out[c + o] = sh;
+        r.out[2 * c + o] = muf;
+        r.out[3 * c + o] = vf;
+    }
+}
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) ----
 // dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_mirror 0x140,
 // row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.

@@ -458,11 +458,17 @@ __global__ __launch_bounds__(256) void bn_relu_max_vec_kernel(long groups, int k
 }
 
 __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, const float *__restrict__ scale,
-                               const float *__restrict__ shift, int relu, float *__restrict__ y)
+                               const float *__restrict__ shift, BnRaw raw, int relu, float *__restrict__ y)
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(e % c);
-        float v = z[e] * scale[ch] + shift[ch];
+        float sc, sh;
+        if (raw.stats) bn_raw_channel(raw, c, ch, e < c, sc, sh); // the first c elements also record the four vectors
+        else {
+            sc = scale[ch];
+            sh = shift[ch];
+        }
+        float v = z[e] * sc + sh;
         if (relu && !(v > 0.0f)) v = 0.0f;
         y[e] = v;
     }
@@ -473,11 +479,17 @@ __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, c
 // gives act(h), the first row is the arg-max (what the separate pass returns).
 __global__ void bn_pool_finalize_kernel(long total, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
                                         const int *__restrict__ amax, const int *__restrict__ amin, const float *__restrict__ scale,
-                                        const float *__restrict__ shift, int relu, float *__restrict__ out, int *__restrict__ argmax)
+                                        const float *__restrict__ shift, BnRaw raw, int relu, float *__restrict__ out,
+                                        int *__restrict__ argmax)
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(e % c);
-        const float s = scale[ch], h = shift[ch];
+        float s, h;
+        if (raw.stats) bn_raw_channel(raw, c, ch, e < c, s, h);
+        else {
+            s = scale[ch];
+            h = shift[ch];
+        }
         float v = (s >= 0.0f ? zmax[e] : zmin[e]) * s + h;
         int a = s > 0.0f ? amax[e] : (s < 0.0f ? amin[e] : 0);
         if (relu && !(v > 0.0f)) v = 0.0f;
@@ -494,15 +506,23 @@ static inline int grid_for(long total, int block)
     return (int)g;
 }
 
-bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
-                            int cout, const float *w, const float *bias, float *z, double *stats, hipStream_t st); // mlp_fast.hip
+bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
+                            long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats,
+                            hipStream_t st); // mlp_fast.hip
 
 template <int MODE>
-static int launch_linear(const MlpIn &in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
-                         double *stats, hipStream_t st)
+static int launch_linear(const MlpIn &in_, long rows, int cin, int cout, const float *w, const float *bias, float *z,
+                         double *stats, const BnRaw &in_raw, hipStream_t st)
 {
-    if (MODE == 0 && mlp_linear_fast_launch(in.x, in.in_scale, in.in_shift, in.in_relu, rows, cin, cout, w, bias, z, stats, st))
+    if (MODE == 0 && mlp_linear_fast_launch(in_.x, in_.in_scale, in_.in_shift, in_raw, in_.in_relu, rows, cin, cout, w, bias, z, stats, st))
         return check_launch("mlp_linear");
+    MlpIn in = in_;
+    if (in_raw.stats) { // the generic kernel takes the affine as vectors: finalize into the caller's out first (one more launch)
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((cin + 255) / 256), dim3(256), 0, st, in_raw.rows, cin, in_raw.stats, in_raw.gamma,
+                           in_raw.beta, in_raw.eps, in_raw.out, in_raw.out + cin, in_raw.out + 2 * cin, in_raw.out + 3 * cin);
+        in.in_scale = in_raw.out;
+        in.in_shift = in_raw.out + cin;
+    }
     const long ntiles = (rows + MLP_BM - 1) / MLP_BM;
     const bool aligned = ((uintptr_t)in.x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
     const bool fast_in = MODE == 0 && aligned && (cin % MLP_BK == 0) && (rows % MLP_BM == 0) &&
@@ -549,6 +569,9 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
     d.in_scale = in->in_scale;
     d.in_shift = in->in_shift;
     d.in_relu = in->in_relu;
+    const BnRaw raw = to_raw(in->in_bn);
+    VN_REQUIRE(in->in_bn == nullptr || (in->x && raw.stats && raw.gamma && raw.beta && raw.out && raw.rows > 0 && in->in_scale == nullptr),
+               "mlp_linear: in_bn needs a DENSE input, stats, gamma, beta, out, rows > 0 and no in_scale");
     d.xyz = in->xyz;
     d.new_xyz = in->new_xyz;
     d.feat = in->feat;
@@ -560,19 +583,19 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
     hipStream_t st = as_stream(stream);
     if (in->x) {
         VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_linear: in_scale and in_shift go together");
-        return launch_linear<0>(d, rows, cin, cout, w, bias, z, stats, st);
+        return launch_linear<0>(d, rows, cin, cout, w, bias, z, stats, raw, st);
     }
     VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_linear: GATHER input needs xyz, new_xyz and idx");
     VN_REQUIRE(in->b > 0 && in->n > 0 && in->m > 0 && in->nsample > 0, "mlp_linear: GATHER input needs b, n, m, nsample > 0");
     VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_linear: rows must equal b*m*nsample for a GATHER input");
     VN_REQUIRE(cin == 3 + d.c, "mlp_linear: cin must equal 3 + c for a GATHER input (utils.py:55)");
-    return launch_linear<1>(d, rows, cin, cout, w, bias, z, stats, st);
+    return launch_linear<1>(d, rows, cin, cout, w, bias, z, stats, BnRaw{}, st);
 }
 
 namespace votenet {
-bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
-                            int cout, const float *w, const float *bias, float *z, double *stats, float *zmax, float *zmin,
-                            int *amax, int *amin, hipStream_t st); // mlp_fast.hip
+bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
+                            long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
+                            float *zmin, int *amax, int *amin, hipStream_t st); // mlp_fast.hip
 }
 
 extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
@@ -583,7 +606,10 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
     VN_REQUIRE(rows > 0 && cin > 0 && cout > 0, "mlp_linear_pool expects rows > 0, cin > 0, cout > 0");
     VN_REQUIRE(w && zmax && zmin && amax && amin, "mlp_linear_pool: null buffer");
     VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_linear_pool: in_scale and in_shift go together");
-    if (pool_k != 64 || !votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, in->in_relu, rows, cin, cout, w, bias, z,
+    const BnRaw raw = to_raw(in->in_bn);
+    VN_REQUIRE(in->in_bn == nullptr || (raw.stats && raw.gamma && raw.beta && raw.rows > 0 && in->in_scale == nullptr),
+               "mlp_linear_pool: in_bn needs stats, gamma, beta, rows > 0 and no in_scale");
+    if (pool_k != 64 || !votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, raw, in->in_relu, rows, cin, cout, w, bias, z,
                                                          stats, zmax, zmin, amax, amin, as_stream(stream)))
         return votenet::set_error(VOTENET_E_INVALID_ARGUMENT,
                                   "mlp_linear_pool: shape not served (pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, "
@@ -592,13 +618,16 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
 }
 
 extern "C" int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
-                                        const float *scale, const float *shift, int relu, float *out, int *argmax, void *stream)
+                                        const float *scale, const float *shift, const votenet_bn_raw *bn, int relu, float *out,
+                                        int *argmax, void *stream)
 {
     VN_REQUIRE(groups >= 0 && c > 0, "bn_pool_finalize expects groups >= 0, c > 0");
     if (groups == 0) return VOTENET_OK;
-    VN_REQUIRE(zmax && zmin && amax && amin && scale && shift && out, "bn_pool_finalize: null buffer");
+    const BnRaw raw = to_raw(bn);
+    VN_REQUIRE(zmax && zmin && amax && amin && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
+               "bn_pool_finalize: null buffer");
     hipLaunchKernelGGL(bn_pool_finalize_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups * c, c, zmax,
-                       zmin, amax, amin, scale, shift, relu, out, argmax);
+                       zmin, amax, amin, scale, shift, raw, relu, out, argmax);
     return check_launch("bn_pool_finalize");
 }
 
@@ -629,13 +658,14 @@ extern "C" int votenet_bn_relu_max(long groups, int k, int c, const float *z, co
     return check_launch("bn_relu_max");
 }
 
-extern "C" int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, int relu, float *y,
-                               void *stream)
+extern "C" int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const float *shift, const votenet_bn_raw *bn,
+                               int relu, float *y, void *stream)
 {
     VN_REQUIRE(rows >= 0 && c > 0, "bn_relu expects rows >= 0, c > 0");
     if (rows == 0) return VOTENET_OK;
-    VN_REQUIRE(z && scale && shift && y, "bn_relu: null buffer");
+    const BnRaw raw = to_raw(bn);
+    VN_REQUIRE(z && y && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)), "bn_relu: null buffer");
     hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows * c, c, z, scale,
-                       shift, relu, y);
+                       shift, raw, relu, y);
     return check_launch("bn_relu");
 }

@@ -41,6 +41,7 @@ constexpr int FG_LDA = FG_BM + 2;
 //          are exactly one group (2x2 variant, WM = 2, MT = 2).
 struct FastArgs {
     const float *x, *in_scale, *in_shift;
+    BnRaw in_raw; // alternative to in_scale / in_shift: derived here from the producer's raw sums
     int in_relu;
     const float *da, *gout;
     const int *argmax;
@@ -80,9 +81,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int n0 = blockIdx.y * BN;
     const int nk = cin / FG_BK;
     const long ntiles = rows / FG_BM;
-    const bool affine = (SRC == 0) && A.in_scale != nullptr;
+    const bool affine = (SRC == 0) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
     if (SRC == 0) {
-        if (affine)
+        if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+            for (int k = tid; k < cin; k += 256) {
+                float sc, sh;
+                bn_raw_channel(A.in_raw, cin, k, writer, sc, sh);
+                Sco[0][k] = sc;
+                Sco[1][k] = sh;
+            }
+        } else if (affine)
             for (int k = tid; k < cin; k += 256) {
                 Sco[0][k] = A.in_scale[k];
                 Sco[1][k] = A.in_shift[k];
@@ -427,13 +436,14 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
 }
 
 // returns true when the fast kernel took the launch
-bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
-                            int cout, const float *w, const float *bias, float *z, double *stats, hipStream_t st)
+bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
+                            long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, hipStream_t st)
 {
     FastArgs a = {};
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
+    a.in_raw = in_raw;
     a.in_relu = in_relu;
     a.rows = rows;
     a.cin = cin;
@@ -446,14 +456,15 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
 }
 
 // forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
-bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
-                            int cout, const float *w, const float *bias, float *z, double *stats, float *zmax, float *zmin,
-                            int *amax, int *amin, hipStream_t st)
+bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
+                            long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
+                            float *zmin, int *amax, int *amin, hipStream_t st)
 {
     FastArgs a = {};
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
+    a.in_raw = in_raw;
     a.in_relu = in_relu;
     a.rows = rows;
     a.cin = cin;

@@ -65,12 +65,53 @@ def _zeros_f64(n, device):
 BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
 
 
-def _desc_dense(x, scale=None, shift=None, relu=True):
+class PendingBN:
+    """The BatchNorm of a layer output whose finalize has not been launched: raw sums + gamma / beta.  The kernel that
+    consumes the layer output derives scale / shift in its prologue (struct votenet_bn_raw) and fills `out`
+    (scale | shift | mean | var, kept for the backward pass); finalize() launches the stand-alone kernel instead."""
+
+    def __init__(self, stats, gamma, beta, rows, eps=None):
+        self.stats, self.gamma, self.beta, self.rows = stats, gamma, beta, rows
+        self.eps = BN_EPS if eps is None else eps
+        self.out = torch.empty((4, gamma.shape[0]), dtype=torch.float32, device=gamma.device)
+        self.done = False
+
+    scale = property(lambda self: self.out[0])
+    shift = property(lambda self: self.out[1])
+    mean = property(lambda self: self.out[2])
+    var = property(lambda self: self.out[3])
+
+    def raw(self):
+        """ctypes struct for a consumer (None once the vectors exist: a second consumer reads them)."""
+        r = L.BnRaw()
+        r.stats, r.gamma, r.beta = self.stats.data_ptr(), self.gamma.data_ptr(), self.beta.data_ptr()
+        r.rows, r.eps, r.out = self.rows, self.eps, self.out.data_ptr()
+        self.done = True
+        return r
+
+    def finalize(self):
+        if not self.done:
+            c = self.gamma.shape[0]
+            with torch.cuda.device(self.gamma.device):
+                L.check(L.lib().votenet_bn_finalize(self.rows, c, L.ptr(self.stats), L.ptr(self.gamma), L.ptr(self.beta), float(self.eps),
+                                                    L.ptr(self.out[0]), L.ptr(self.out[1]), L.ptr(self.out[2]), L.ptr(self.out[3]),
+                                                    L.stream_ptr()))
+            self.done = True
+        return self.out[0], self.out[1]
+
+
+def _desc_dense(x, scale=None, shift=None, relu=True, in_bn=None):
     d = L.MlpInput()
+    if in_bn is not None:
+        if in_bn.done:  # already finalized by an earlier consumer
+            scale, shift = in_bn.scale, in_bn.shift
+        else:
+            d._raw = in_bn.raw()
+            d.in_bn = ctypes.pointer(d._raw)
     d.x = x.data_ptr()
     d.in_scale = scale.data_ptr() if scale is not None else None
     d.in_shift = shift.data_ptr() if shift is not None else None
-    d.in_relu = 1 if (relu and scale is not None) else 0
+    d.in_relu = 1 if (relu and (scale is not None or bool(d.in_bn))) else 0
     return d
 
 
@@ -87,7 +128,7 @@ def _desc_gather(xyz, new_xyz, feat, idx):
     return d
 
 
-def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, want_stats=True):
+def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, want_stats=True, in_bn=None):
     """z = act(x) @ w + bias with act = relu(x*in_scale+in_shift) folded into the load (or identity).
     x (rows, cin) f32 -> z (rows, cout), stats (2*cout) f64 [column sums of z, of z*z] or None."""
     x = L.dev_f32(x, "mlp_linear x", 2)
@@ -98,7 +139,7 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
     cout = w.shape[1]
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     stats = _zeros_f64(2 * cout, x.device) if want_stats else None
-    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
     with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
@@ -133,7 +174,7 @@ def linear_pool_supported(rows, cin, cout, k):
     return k == 64 and rows > 0 and rows % 128 == 0 and cin % 32 == 0 and cin <= 512 and cout % 128 == 0
 
 
-def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True):
+def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True, in_bn=None):
     """linear_dense whose epilogue also emits the raw max / min of every group of k rows: -> z or None, stats, pool where
     pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool."""
     rows, cin = x.shape
@@ -143,21 +184,29 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
     stats = _zeros_f64(2 * cout, x.device)
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
     args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
-    d = _desc_dense(x, in_scale, in_shift, in_relu)
+    d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
     with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
         L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
                                                 L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
     return z, stats, (vals[0], vals[1], args[0], args[1])
 
 
-def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False):
+def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None):
+    """bn: a PendingBN instead of scale / shift (the kernel finalizes it)."""
     zmax, zmin, amax, amin = pool
+    raw = None
+    if bn is not None:
+        if bn.done:
+            scale, shift = bn.scale, bn.shift
+        else:
+            raw = bn.raw()
     g, c = zmax.shape
     out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
     arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
     with torch.cuda.device(zmax.device):
         L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
-                                                 1 if relu else 0, L.ptr(out), L.ptr(arg), L.stream_ptr()))
+                                                 ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),
+                                                 L.ptr(arg), L.stream_ptr()))
     return out, arg
 
 
@@ -215,12 +264,19 @@ def bn_relu_max(z, k, scale, shift, relu=True, want_argmax=False):
     return out, arg
 
 
-def bn_relu(z, scale, shift, relu=True):
+def bn_relu(z, scale, shift, relu=True, bn=None):
+    """bn: a PendingBN instead of scale / shift (the kernel finalizes it)."""
     rows, c = z.shape
     y = torch.empty_like(z)
+    raw = None
+    if bn is not None:
+        if bn.done:
+            scale, shift = bn.scale, bn.shift
+        else:
+            raw = bn.raw()
     with torch.cuda.device(z.device):
-        L.check(L.lib().votenet_bn_relu(rows, c, L.ptr(z), L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(y),
-                                        L.stream_ptr()))
+        L.check(L.lib().votenet_bn_relu(rows, c, L.ptr(z), L.ptr(scale), L.ptr(shift), ctypes.byref(raw) if raw is not None else None,
+                                        1 if relu else 0, L.ptr(y), L.stream_ptr()))
     return y
 
 

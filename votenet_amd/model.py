@@ -106,7 +106,7 @@ class VoteNetHotPath:
         b, n = seeds_xyz.shape[:2]
         x = torch.cat([seeds_xyz, seeds_points], dim=2).view(b * n, 259)
         recs = []
-        off, _, _ = P.mlp_chain_forward(self.voting, b * n, ("dense", x), recs)
+        off, _ = P.mlp_chain_forward(self.voting, b * n, ("dense", x), recs)
         votes = (x + off).view(b, n, 259)
         if tape is not None:
             tape.append(dict(op="vote", recs=recs, b=b, n=n))

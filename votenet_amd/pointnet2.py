@@ -163,16 +163,21 @@ POOL_IN_EPILOGUE = True
 
 def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
     """Run a chain of layers over `rows` rows.  first = ('gather', xyz, new_xyz, feat, idx) or ('dense', x).
-    Returns (z_last, scale_last, shift_last): the last layer's RAW output and its folded BN
-    (None, None for a plain last layer).  Appends one record per layer to `tape`.
+    Returns (z_last, pend): the last layer's RAW output and its BatchNorm as an mlp.PendingBN (None for a plain last
+    layer) -- nobody has launched a finalize: every BatchNorm is derived from the raw sums in the prologue of the kernel
+    that consumes it (the next GEMM inside the chain; the pooling / activation kernel of the caller for the last layer).
+    Appends one record per layer to `tape`.
     pool_k > 0: the chain is followed by a max over groups of pool_k rows (utils.py:132); where the shape allows, the last
     GEMM's epilogue starts the pool (raw max / min per group) and the last record carries 'pool' for bn_pool_finalize;
     keep_z=False then skips the store of the last layer's z altogether (nothing downstream reads it in inference)."""
-    z = sc = sh = None
+    z = None
+    pend = None  # BatchNorm of z whose finalize rides in the prologue of z's consumer (mlp.PendingBN)
     prev_relu = False
     for i, L in enumerate(layers):
         w, b = L.p("W"), L.p("b")
         pool = None
+        sc = pend.scale if pend is not None else None  # views: filled when the consumer below has run
+        sh = pend.shift if pend is not None else None
         if i == 0 and first[0] == "gather":
             # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
             # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
@@ -191,20 +196,20 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             rec = dict(layer=L, kind="dense", x=first[1], in_scale=None, in_shift=None, in_relu=False)
         elif pool_k and i == len(layers) - 1 and L.bn and POOL_IN_EPILOGUE and \
                 M.linear_pool_supported(rows, w.shape[0], w.shape[1], pool_k):
-            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, sc, sh, prev_relu, keep_z=keep_z)
+            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
         else:
-            zn, st = M.linear_dense(z, w, b, sc, sh, prev_relu, want_stats=L.bn)
+            zn, st = M.linear_dense(z, w, b, None, None, prev_relu, want_stats=L.bn, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
         if L.bn:
-            sc, sh, mean, var = M.bn_finalize(rows, st, L.p("gamma"), L.p("beta"))
-            rec.update(scale=sc, shift=sh, mean=mean, var=var)
+            pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows)
+            rec.update(scale=pend.scale, shift=pend.shift, mean=pend.mean, var=pend.var)
         else:
-            sc = sh = None
+            pend = None
         rec.update(z=zn, rows=rows, pool=pool)
         tape.append(rec)
         z, prev_relu = zn, L.relu
-    return z, sc, sh
+    return z, pend
 
 
 # Weight gradients hang off the backward chain (reduce -> coef -> dgrad -> reduce ...): nothing downstream needs them before
@@ -334,16 +339,17 @@ class SAModule:
         fps_idx, new_xyz, idx, pts_cnt = geom if geom is not None else self.geometry(xyz, sample_xyz)
         recs = []
         rows = b * self.npoint * self.nsample
-        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs, pool_k=self.nsample,
-                                      keep_z=tape is not None)
+        z, pend = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs, pool_k=self.nsample,
+                                    keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
-            pooled, argmax = M.bn_pool_finalize(recs[-1]["pool"], sc, sh, True, want_argmax=tape is not None)
+            pooled, argmax = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend)
         else:
+            sc, sh = pend.finalize()
             pooled, argmax = M.bn_relu_max(z, self.nsample, sc, sh, True, want_argmax=tape is not None)
         recs2 = []
         out = pooled
         if self.mlp2:
-            z2, sc2, sh2 = mlp_chain_forward(self.mlp2, b * self.npoint, ("dense", pooled), recs2)
+            z2, _ = mlp_chain_forward(self.mlp2, b * self.npoint, ("dense", pooled), recs2)
             out = z2  # last conv_post layer has no activation (utils.py:153)
         if tape is not None:
             tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, fps_idx=fps_idx, idx=idx, pts_cnt=pts_cnt,
@@ -428,8 +434,8 @@ class FPModule:
         x = torch.cat([interp, points1], dim=2) if points1 is not None else interp  # utils.py:286
         rows = b * n1
         recs = []
-        z, sc, sh = mlp_chain_forward(self.mlp, rows, ("dense", x.view(rows, -1)), recs)
-        y = M.bn_relu(z, sc, sh, True)
+        z, pend = mlp_chain_forward(self.mlp, rows, ("dense", x.view(rows, -1)), recs)
+        y = M.bn_relu(z, None, None, True, bn=pend)
         if tape is not None:
             tape.append(dict(op="fp", module=self, recs=recs, idx=idx, weight=weight, m=xyz2.shape[1],
                              c2=points2.shape[2], c1=0 if points1 is None else points1.shape[2], b=b, n1=n1))
