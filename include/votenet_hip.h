@@ -332,6 +332,41 @@ int votenet_decode_boxes(int b, int n_prop, int nh, int ns, int nc, const float 
                          const float *proposals_output, const float *class_mean_size, float *bboxes, float *scores,
                          void *stream);
 
+/* ---- input pipeline (the step before the path): random subsample + augmentation + ragged ground-truth padding ----
+ * Replaces the per-scene numpy code of MyDataFlow.__iter__ (dataset.py:183-189 subsample + depth->camera axes,
+ * :219-231 the draws, :262-276 boxes, :302-308 points) and the batch padding of run.py:14-24,60-64.  The DRAWS stay on the
+ * host (votenet_amd/input_pipeline.py mirrors the reference's draw order); the kernels apply them.  Per-scene parameters
+ * are HOST arrays (they travel as kernel arguments: no staging copies); the bulk data is device memory.
+ *
+ * Points: scene s owns the raw rows [raw_offset[s], raw_offset[s+1]) of `raw` (raw_stride elements per row, xyz first;
+ * doubles when raw_f64 -- np.loadtxt gives float64, sunutils.py:178-180 -- else floats).  Output row j of scene s is raw
+ * row choice[s*n_out+j] (the rng.choice(n, POINT_NUM, replace=False) of dataset.py:185-186, drawn by the caller), or, with
+ * choice == NULL, row perm_s(j) of a keyed pseudo-random PERMUTATION of the scene's rows (6-round Feistel network with
+ * cycle walking; key from `seed` and the scene number s + scene0): a sample without replacement in random order, drawn on
+ * the device.  Then, in double precision and in the reference's order: (x,y,z) -> (x,-z,y) when depth_to_camera
+ * (sunutils.py:70-77); x = -x when flip[s]&1; z = -z when flip[s]&2; rotation about y by the angle whose cosine / sine
+ * are rot_cos[s] / rot_sin[s] (sunutils.py:133-139: x' = c x + s z, z' = -s x + c z); times scale[s]; rounded once to
+ * float.  flip == NULL: evaluation, none of the four is applied (dataset.py:302 `if self.training`).
+ * Every scene needs at least n_out raw rows (numpy raises for replace=False otherwise). */
+int votenet_subsample_augment(int b, int n_out, const void *raw, int raw_f64, int raw_stride, const long *raw_offset,
+                              const int *choice, unsigned long long seed, long scene0, int depth_to_camera, const int *flip,
+                              const double *rot_cos, const double *rot_sin, const double *scale, float *out, void *stream);
+
+/* Ground truth: scene s owns boxes [box_offset[s], box_offset[s+1]) of center (nbox,3), size (nbox,3; full l,w,h as
+ * dataset.py:258), heading (nbox), cls (nbox), all device memory, doubles / ints.  Applies dataset.py:262-276 (flip_x:
+ * x = -x, heading = pi - heading; flip_z: z = -z, heading = -heading; rotation of the centre, heading += angle[s]; centre
+ * and size times scale[s]), size2class (dataset.py:80-84), angle2class (dataset.py:52-67, python float modulo), the
+ * residual normalisations of dataset.py:294-298, and pads every scene to n_box_out rows by repeating its last box
+ * (run.py:14-24, np.pad mode='edge').  mean_size: HOST (nc,3) doubles (dataset.py:36-45), nc <= 32.  A scene without
+ * boxes is an error (the reference skips such scenes, dataset.py:300).  Outputs are the eight model inputs of
+ * model.py:22-32, float / int. */
+int votenet_augment_boxes(int b, int n_box_out, const long *box_offset, const double *center, const double *size,
+                          const double *heading, const int *cls, const int *flip, const double *angle, const double *rot_cos,
+                          const double *rot_sin, const double *scale, const double *mean_size, int nc, int nh,
+                          float *bboxes_xyz, float *bboxes_lwh, float *bboxes_roty, int *semantic_labels,
+                          int *heading_labels, float *heading_residuals, int *size_labels, float *size_residuals,
+                          void *stream);
+
 /* 3D IoU (the arithmetic of tf_nms3d.cpp:178-192) of every box of set A (b,n,8,3) against every box of set B
  * (b,m,8,3) of the same scene -> iou (b,n,m): the detections-vs-ground-truth overlaps of evaluator.py:26-39,122-132. */
 int votenet_iou3d_cross(int b, int n, int m, const float *boxes_a, const float *boxes_b, float *iou, void *stream);

@@ -79,6 +79,9 @@ _SIGS.update({
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_subsample_augment": [ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, _c_f, _c_f, ctypes.c_ulonglong,
+                                  ctypes.c_long, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_augment_boxes": [ctypes.c_int, ctypes.c_int] + [_c_f] * 11 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
