@@ -332,6 +332,32 @@ int votenet_decode_boxes(int b, int n_prop, int nh, int ns, int nc, const float 
                          const float *proposals_output, const float *class_mean_size, float *bboxes, float *scores,
                          void *stream);
 
+/* ---- PointNet++ ops the reference ships but model.py never reaches (kNN grouping, ProbSample) ----
+ *
+ * Replaces selectionSortLauncher (tf_grouping.cpp:108, kernel tf_grouping_g.cu:83-123; op SelectionSort, Python
+ * select_top_k(k, dist), tf_grouping.py:22-32).  dist (b,m,n) -> outi (b,m,n) int, out (b,m,n): each row starts as a copy
+ * of the distances / 0..n-1 and goes through k steps of selection sort (the FIRST position of the minimum of [s,n), strict
+ * '<', is swapped into s): the first k columns are the k smallest, ascending; the tail is the swapped remainder, exactly
+ * as the reference leaves it.  One wavefront per row (row in LDS up to n = 16384, in place in `out` above; four wavefronts per row beyond n = 2048). */
+int votenet_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out, void *stream);
+
+/* knn_point(k, xyz1, xyz2) (tf_grouping.py:47-73) as ONE kernel: the reference tiles both clouds to (b,m,n,c), forms the
+ * (b,m,n) squared distances and runs SelectionSort on them, then slices the first k columns.  Here a wavefront builds its
+ * row of distances in LDS (channel sum left to right), does the same k selection steps and writes only val (b,m,k) and
+ * idx (b,m,k): the (b,m,n) tensors never exist.  xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries.  n > 16384: the rows live
+ * in `workspace` (votenet_knn_workspace_bytes(b, n, m) bytes of device memory; may be NULL below that size). */
+int votenet_knn_point(int b, int n, int m, int c, int k, const float *xyz1, const float *xyz2, float *val, int *idx,
+                      void *workspace, void *stream);
+size_t votenet_knn_workspace_bytes(int b, int n, int m);
+
+/* Replaces probsampleLauncher (tf_sampling.cpp:65, kernels tf_sampling_g.cu:7-104,197-200; op ProbSample, Python
+ * prob_sample(inp, inpr), tf_sampling.py:13-21).  inp_p (b,n) non-negative category weights, inp_r (b,m) uniform draws in
+ * [0,1) -> out (b,m) int: the category whose running-sum interval holds r * total.  temp: b*n floats (the running sums,
+ * tf_sampling.cpp:83).  The running sum is the reference's float scan with the same association (4-element groups, the
+ * scan tree over group totals, compensated carry between 8192-element chunks), so the category boundaries -- and with
+ * them every result -- are bit-identical. */
+int votenet_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out, void *stream);
+
 /* ---- input pipeline (the step before the path): random subsample + augmentation + ragged ground-truth padding ----
  * Replaces the per-scene numpy code of MyDataFlow.__iter__ (dataset.py:183-189 subsample + depth->camera axes,
  * :219-231 the draws, :262-276 boxes, :302-308 points) and the batch padding of run.py:14-24,60-64.  The DRAWS stay on the

@@ -25,6 +25,12 @@
  *                                       by the known answer of the reference's own smoke
  *                                       input and an independent
  *                                       polygon-clipping cross-check: PARITY PARTIAL
+ *   SelectionSort ..................... pinned against oracle/_ref built from
+ *                                       tf_ops/grouping/test/selection_sort.cpp
+ *   ProbSample ........................ restatement of a CUDA-only kernel, no reference
+ *                                       test: PARITY UNPINNED (the scan tree is checked
+ *                                       against a literal simulation of the kernel's index
+ *                                       loops in tests/test_oracle_variants.py)
  *   grouped MLP ....................... arithmetic lives in Tensorpack/TensorFlow 1.x
  *                                       (not in the reference tree, versions unpinned):
  *                                       PARITY UNPINNED, semantics defined here
@@ -95,6 +101,16 @@ void oracle_bn_stats(long rows, int c, const float *z, float *mean, float *var);
 void oracle_bn_relu(long rows, int c, const float *z, const float *mean, const float *var,
                     const float *gamma, const float *beta, float eps, int relu, float *y);
 void oracle_max_over_k(long groups, int k, int c, const float *y, float *out);
+
+/* ---- ops the reference ships but model.py never reaches (oracle_variants.c) ---- */
+/* tf_ops/grouping/tf_grouping_g.cu:83-123 / test/selection_sort.cpp:19-62 (pinned against oracle/_ref) */
+void oracle_selection_sort(int b, int n, int m, int k, const float *dist, int *outi, float *out);
+/* tf_ops/grouping/tf_grouping.py:61-63 : squared distances of knn_point, (b,m,n) */
+void oracle_knn_dist(int b, int n, int m, int c, const float *xyz1, const float *xyz2, float *dist);
+/* tf_ops/sampling/tf_sampling_g.cu:7-86 : float running sum with the kernel's scan-tree association */
+void oracle_cumsum(int b, int n, const float *inp, float *out);
+/* tf_sampling_g.cu:88-104,197-200 ; temp = b*n floats (the running sums) */
+void oracle_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out);
 
 #ifdef __cplusplus
 }

@@ -240,7 +240,57 @@ def max_over_k(y, k):
     return out
 
 
+# ---------------------------------------------------------------- unused-by-VoteNet variants
+def select_top_k(k, dist):
+    dist = _f32(dist)
+    b, m, n = dist.shape
+    outi, out = np.zeros((b, m, n), np.int32), np.zeros((b, m, n), np.float32)
+    lib().oracle_selection_sort(b, n, m, k, _fp(dist), _ip(outi), _fp(out))
+    return outi, out
+
+
+def knn_dist(xyz1, xyz2):
+    xyz1, xyz2 = _f32(xyz1), _f32(xyz2)
+    b, n, c = xyz1.shape
+    m = xyz2.shape[1]
+    dist = np.zeros((b, m, n), np.float32)
+    lib().oracle_knn_dist(b, n, m, c, _fp(xyz1), _fp(xyz2), _fp(dist))
+    return dist
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:47-71 -> (val (b,m,k), idx (b,m,k))."""
+    outi, out = select_top_k(k, knn_dist(xyz1, xyz2))
+    return out[:, :, :k].copy(), outi[:, :, :k].copy()
+
+
+def cumsum(inp):
+    inp = _f32(inp)
+    b, n = inp.shape
+    out = np.zeros((b, n), np.float32)
+    lib().oracle_cumsum(b, n, _fp(inp), _fp(out))
+    return out
+
+
+def prob_sample(inp, inpr):
+    inp, inpr = _f32(inp), _f32(inpr)
+    b, n = inp.shape
+    m = inpr.shape[1]
+    temp, out = np.zeros((b, n), np.float32), np.zeros((b, m), np.int32)
+    lib().oracle_prob_sample(b, n, m, _fp(inp), _fp(inpr), _fp(temp), _ip(out))
+    return out
+
+
 # ---------------------------------------------------------------- reference (oracle/_ref)
+def ref_select_top_k(k, dist):
+    r = ref("selection_sort")
+    dist = _f32(dist)
+    b, m, n = dist.shape
+    outi, out = np.zeros((b, m, n), np.int32), np.zeros((b, m, n), np.float32)
+    r.ref_selection_sort(b, n, m, k, _fp(dist), _ip(outi), _fp(out))
+    return outi, out
+
+
 def ref_query_ball_point(radius, nsample, xyz1, xyz2):
     r = ref("grouping")
     xyz1, xyz2 = _f32(xyz1), _f32(xyz2)

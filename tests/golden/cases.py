@@ -102,3 +102,35 @@ def fps_cases():
     cases["lattice"] = (grid.astype(np.float32), 200)                                 # many exact distance ties
     cases["exhaust"] = (rng.random((1, 40, 3), dtype=np.float32), 64)                 # m > n: index 0 repeats
     return cases
+
+
+def selection_sort_cases():
+    """SelectionSort inputs: the reference twin's own main() (test/selection_sort.cpp:66-77: b=2,n=4,m=2,k=3,
+    dist[i] = 10-i), the kNN demo of tf_grouping.py:75-90 (squared distances of the demo clouds, k = 64; first 4 scenes),
+    and rows with many exact ties (the swap order decides which tied index comes first)."""
+    out = {"twin_main": (np.array([10.0 - i for i in range(16)], np.float32).reshape(2, 2, 4), 3)}
+    c = grouping_demo()
+    a, q = c["xyz1"][:4], c["xyz2"][:4]
+    d = np.zeros((4, 128, 512), np.float32)
+    for ch in range(3):  # left-to-right channel sum in float32 (oracle_knn_dist)
+        t = (a[:, None, :, ch] - q[:, :, None, ch]).astype(np.float32)
+        d = (t * t).astype(np.float32) if ch == 0 else (d + t * t).astype(np.float32)
+    out["knn_demo"] = (d, 64)
+    rs = np.random.RandomState(5)
+    out["ties"] = (rs.randint(0, 6, (3, 7, 50)).astype(np.float32), 20)
+    out["k_equals_n"] = (rs.random_sample((1, 3, 33)).astype(np.float32), 33)
+    return out
+
+
+def prob_sample_cases():
+    """ProbSample inputs: the triangle-area demo of tf_sampling.py:60-72 (5 categories, 8192 draws; the draws come from
+    tf.random_uniform there, numpy here), and category counts that cross the kernel's 8192-element chunk and 4-element
+    group boundaries."""
+    rs = np.random.RandomState(100)  # np.random.seed(100), tf_sampling.py:62
+    tri = rs.rand(1, 5, 3, 3).astype("float32")
+    ab, ac = tri[:, :, 1] - tri[:, :, 0], tri[:, :, 2] - tri[:, :, 0]
+    areas = np.sqrt((np.cross(ab, ac) ** 2).sum(2) + 1e-9).astype(np.float32)
+    out = {"triangles": (areas, rs.rand(1, 8192).astype(np.float32))}
+    for n in (1, 2, 3, 4, 5, 7, 8, 1000, 8191, 8192, 8193, 8195, 20000):
+        out["n%d" % n] = (rs.rand(2, n).astype(np.float32) + 1e-3, rs.rand(2, 257).astype(np.float32))
+    return out

@@ -3,7 +3,7 @@
     python tests/golden/make_golden.py
 
 Expected outputs come from the REFERENCE's own compiled code (oracle/_ref, built by
-oracle/Makefile from tf_ops/grouping/test/query_ball_point.cpp and
+oracle/Makefile from tf_ops/grouping/test/query_ball_point.cpp, tf_ops/grouping/test/selection_sort.cpp and
 tf_ops/3d_interpolation/interpolate.cpp) wherever it exists, and are tagged source="ref".
 Where the reference cannot run here (FPS: CUDA only; NMS: needs TensorFlow headers) they come
 from the oracle restatement and are tagged source="oracle" -- plus the known answer of the
@@ -100,6 +100,23 @@ def main():
         assert (a == O.farthest_point_sample(m, xyz, closed=True)).all(), name
         out[name] = a
     np.savez_compressed(os.path.join(HERE, "fps_cases.npz"), source="oracle", **out)
+    # ---- SelectionSort (reference CPU twin, tf_ops/grouping/test/selection_sort.cpp)
+    assert O.ref("selection_sort") is not None
+    out = {}
+    for name, (dist, k) in cases.selection_sort_cases().items():
+        outi, val = O.ref_select_top_k(k, dist)
+        if dist.size <= 4096:
+            out[name + "_idx"], out[name + "_val"] = outi, val
+        else:
+            out[name + "_idx_sha"], out[name + "_val_sha"], out[name + "_idx_head"] = sha(outi), sha(val), outi[0, :2, :k]
+    np.savez_compressed(os.path.join(HERE, "selection_sort.npz"), source="ref", **out)
+
+    # ---- ProbSample (oracle; CUDA-only in the reference, no reference test: parity unpinned)
+    out = {}
+    for name, (p, r) in cases.prob_sample_cases().items():
+        out[name] = O.prob_sample(p, r)
+        out[name + "_cumsum_sha"] = sha(O.cumsum(p))
+    np.savez_compressed(os.path.join(HERE, "prob_sample.npz"), source="oracle", **out)
     print("golden fixtures written to", HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -79,6 +79,9 @@ _SIGS.update({
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_selection_sort": [ctypes.c_int] * 4 + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_knn_point": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_prob_sample": [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_subsample_augment": [ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_int, ctypes.c_int, _c_f, _c_f, ctypes.c_ulonglong,
                                   ctypes.c_long, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_augment_boxes": [ctypes.c_int, ctypes.c_int] + [_c_f] * 11 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
@@ -117,6 +120,8 @@ def lib():
         L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_loss_workspace_floats.restype = ctypes.c_size_t
         L.votenet_loss_workspace_floats.argtypes = [ctypes.c_int]
+        L.votenet_knn_workspace_bytes.restype = ctypes.c_size_t
+        L.votenet_knn_workspace_bytes.argtypes = [ctypes.c_int] * 3
         L.votenet_nms3d_workspace_bytes.restype = ctypes.c_size_t
         L.votenet_nms3d_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_ball_threshold.restype = ctypes.c_float

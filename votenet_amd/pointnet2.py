@@ -1,8 +1,9 @@
 """PointNet++ SA / FP layers of VoteNet on the HIP hot path -- mirror of the reference's utils.py.
 
     sample_and_group     utils.py:25-61
-    pointnet_sa_module   utils.py:93-158   (group_all=False, pooling='max', knn=False: the only
-                                            configuration model.py uses)
+    pointnet_sa_module   utils.py:93-158   (group_all=False, pooling='max'; knn=False is the only
+                                            configuration model.py uses, knn=True is served too)
+    pointnet_sa_module_msg utils.py:161-201 (multi-scale grouping; never reached by model.py)
     pointnet_fp_module   utils.py:266-294
 
 The reference builds these from ~6 TF graph nodes per MLP layer on a materialised
@@ -306,20 +307,28 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
 
 
 # --------------------------------------------------------------------------- SA / FP modules
-def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None):
+def _group_indices(radius, nsample, xyz, new_xyz, knn):
+    """utils.py:46-49: ball query, or the nsample nearest points with knn=True (every slot then holds a distinct point)."""
+    if knn:
+        _, idx = tf_grouping.knn_point(nsample, xyz, new_xyz)
+        return idx, torch.full(idx.shape[:2], nsample, dtype=torch.int32, device=idx.device)
+    return tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+
+
+def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None, knn=False):
     """utils.py:42-49 (geometry part): FPS on sample_xyz if given, centres gathered from xyz."""
     fps_idx = tf_sampling.farthest_point_sample(npoint, sample_xyz if sample_xyz is not None else xyz)
     new_xyz = tf_sampling.gather_point(xyz, fps_idx)
-    idx, pts_cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    idx, pts_cnt = _group_indices(radius, nsample, xyz, new_xyz, knn)
     return fps_idx, new_xyz, idx, pts_cnt
 
 
 class SAModule:
-    """pointnet_sa_module (utils.py:93-158) with group_all=False, pooling='max', knn=False, use_xyz=True."""
+    """pointnet_sa_module (utils.py:93-158) with group_all=False, pooling='max', use_xyz=True."""
 
-    def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None):
-        self.npoint, self.radius, self.nsample = npoint, radius, nsample
-        self.mlp = make_mlp(store, scope, 3 + cin, mlp, "conv")
+    def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None, knn=False, prefix="conv"):
+        self.npoint, self.radius, self.nsample, self.knn = npoint, radius, nsample, knn
+        self.mlp = make_mlp(store, scope, 3 + cin, mlp, prefix)
         store.want_transpose(self.mlp[0].name + "/W", 3, None)  # W[3:]^T: the per-point feature gradient
         store.want_transpose(self.mlp[0].name + "/W", 0, 3)     # W[:3]^T: the xyz gradient (proposal layer)
         self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
@@ -327,9 +336,9 @@ class SAModule:
     def geometry(self, xyz, sample_xyz=None, fps_idx=None):
         """The feature-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream."""
         if fps_idx is None:
-            return sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz)
+            return sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz, self.knn)
         new_xyz = tf_sampling.gather_point(xyz, fps_idx)
-        idx, pts_cnt = tf_grouping.query_ball_point(self.radius, self.nsample, xyz, new_xyz)
+        idx, pts_cnt = _group_indices(self.radius, self.nsample, xyz, new_xyz, self.knn)
         return fps_idx, new_xyz, idx, pts_cnt
 
     def forward(self, xyz, points, sample_xyz=None, tape=None, geom=None):
@@ -413,6 +422,54 @@ class SAModule:
             _, d_xyz, d_new = M.group_concat_grad(None, d_rows_xyz, idx, pts_cnt, n, 0)
             d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
         return d_feat, d_xyz
+
+
+class SAModuleMSG:
+    """pointnet_sa_module_msg (utils.py:161-201): one FPS, then per scale i a ball query (radius_list[i], nsample_list[i]),
+    the MLP mlp_list[i] (layers "conv<i>_<j>") and a max-pool; the per-scale features are concatenated.
+    Each scale is an SAModule sharing the sampled centres, so it runs through the same fused kernels.
+
+    Weight layout: the reference concatenates [grouped_points, grouped_xyz] here (utils.py:186-187) -- features first --
+    while the fused first layer takes its rows as [xyz (3) | features (c)] like sample_and_group.  The first-layer W of a
+    scale is therefore stored with the three xyz rows FIRST; reference_rows() / from_reference_rows() convert."""
+
+    def __init__(self, store, scope, npoint, radius_list, nsample_list, cin, mlp_list):
+        self.npoint, self.cin = npoint, cin
+        self.scales = [SAModule(store, scope, npoint, r, k, cin, mlp, prefix="conv%d_" % i)
+                       for i, (r, k, mlp) in enumerate(zip(radius_list, nsample_list, mlp_list))]
+        self.widths = [mlp[-1] for mlp in mlp_list]
+
+    @staticmethod
+    def reference_rows(w):
+        """first-layer W stored here ([xyz | feat] rows) -> the reference's row order ([feat | xyz])."""
+        return torch.cat([w[3:], w[:3]], 0)
+
+    @staticmethod
+    def from_reference_rows(w):
+        return torch.cat([w[-3:], w[:-3]], 0)
+
+    def forward(self, xyz, points, tape=None):
+        """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,sum of the scales' last widths)."""
+        fps_idx = tf_sampling.farthest_point_sample(self.npoint, xyz)  # utils.py:179
+        subs, outs, new_xyz = [], [], None
+        for sc in self.scales:
+            sub = [] if tape is not None else None
+            new_xyz, o, _ = sc.forward(xyz, points, tape=sub, geom=sc.geometry(xyz, fps_idx=fps_idx))
+            outs.append(o)
+            subs.append(sub[0] if sub else None)
+        if tape is not None:
+            tape.append(dict(op="sa_msg", module=self, subs=subs))
+        return new_xyz, torch.cat(outs, -1)
+
+    def backward(self, rec, g_out, need_feat_grad=True):
+        """g_out (B,m,sum widths) -> d_points (B,n,C) or None (summed over the scales)."""
+        d_feat, o = None, 0
+        for sc, sub, w in zip(self.scales, rec["subs"], self.widths):
+            d, _ = sc.backward(sub, g_out[..., o:o + w].contiguous(), need_feat_grad=need_feat_grad)
+            o += w
+            if d is not None:
+                d_feat = d if d_feat is None else d_feat + d
+        return d_feat
 
 
 class FPModule:

@@ -1,8 +1,8 @@
 """Mirror of the reference's tf_ops/grouping/tf_grouping.py on torch (ROCm) tensors.
 
 query_ball_point has no gradient (tf_grouping.py:21); group_point's gradient w.r.t. points is
-GroupPointGrad (tf_grouping.py:42-46).  select_top_k / knn_point are reachable only with
-knn=True (utils.py:46-47), never set by model.py: out of scope.
+GroupPointGrad (tf_grouping.py:42-46).  select_top_k / knn_point (tf_grouping.py:22-32,47-73) are reachable only with
+knn=True (utils.py:46-47), which model.py never sets; they are provided for tf_ops API parity.
 """
 import torch
 
@@ -70,3 +70,33 @@ def group_point_grad_raw(n, idx, grad_out):
 def group_point(points, idx):
     """tf_grouping.py:33-41.  (B,n,c) f32, (B,m,nsample) i32 -> (B,m,nsample,c) f32."""
     return _GroupPoint.apply(points, idx)
+
+
+def select_top_k(k, dist):
+    """tf_grouping.py:22-32.  int, (b,m,n) f32 -> (idx (b,m,n) i32, dist_out (b,m,n) f32): the first k columns are the k
+    smallest distances, ascending, with their indices; the rest is the remainder as SelectionSort's swaps leave it."""
+    dist = L.dev_f32(dist.detach(), "SelectionSort expects (b,m,n) dist shape.", 3)
+    b, m, n = dist.shape
+    outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
+    out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
+    with torch.cuda.device(dist.device):
+        L.check(L.lib().votenet_selection_sort(b, n, m, int(k), L.ptr(dist), L.ptr(outi), L.ptr(out), L.stream_ptr()))
+    return outi, out
+
+
+def knn_point(k, xyz1, xyz2):
+    """tf_grouping.py:47-73.  int, xyz1 (b,n,c) dataset, xyz2 (b,m,c) queries -> (val (b,m,k) squared L2 distances,
+    idx (b,m,k) i32).  One kernel: the (b,m,n) distance tensor of the reference is never formed."""
+    xyz1 = L.dev_f32(xyz1.detach(), "knn_point expects (batch_size, ndataset, c) xyz1 shape.", 3)
+    xyz2 = L.dev_f32(xyz2.detach(), "knn_point expects (batch_size, npoint, c) xyz2 shape.", 3)
+    b, n, c = xyz1.shape
+    if xyz2.shape[0] != b or xyz2.shape[2] != c:
+        raise L.InvalidArgumentError("knn_point expects xyz1 (b,n,c) and xyz2 (b,m,c) with the same b and c")
+    m, k = xyz2.shape[1], int(k)
+    val = torch.empty((b, m, max(k, 0)), dtype=torch.float32, device=xyz1.device)
+    idx = torch.empty((b, m, max(k, 0)), dtype=torch.int32, device=xyz1.device)
+    nws = int(L.lib().votenet_knn_workspace_bytes(b, n, m))
+    ws = torch.empty(nws, dtype=torch.uint8, device=xyz1.device) if nws else None
+    with torch.cuda.device(xyz1.device):
+        L.check(L.lib().votenet_knn_point(b, n, m, c, k, L.ptr(xyz1), L.ptr(xyz2), L.ptr(val), L.ptr(idx), L.ptr(ws), L.stream_ptr()))
+    return val, idx

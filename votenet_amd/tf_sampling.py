@@ -68,3 +68,19 @@ def gather_point_grad_raw(n, idx, out_g):
 def gather_point(inp, idx):
     """tf_sampling.py:29-36.  (B,n,3) f32, (B,m) int32 -> (B,m,3) f32; d/d inp registered."""
     return _GatherPoint.apply(inp, idx)
+
+
+def prob_sample(inp, inpr):
+    """tf_sampling.py:13-21.  (batch_size, ncategory) f32 weights, (batch_size, npoints) f32 uniform draws ->
+    (batch_size, npoints) i32 category ids; no gradient (tf_sampling.py:22)."""
+    inp = L.dev_f32(inp.detach(), "ProbSample expects (batch_size,num_choices) inp shape", 2)
+    inpr = L.dev_f32(inpr.detach(), "ProbSample expects (batch_size,num_points) inpr shape", 2)
+    b, n = inp.shape
+    if inpr.shape[0] != b:
+        raise L.InvalidArgumentError("ProbSample expects (batch_size,num_points) inpr shape")
+    m = inpr.shape[1]
+    temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)  # tf_sampling.cpp:83 allocate_temp
+    out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
+    with torch.cuda.device(inp.device):
+        L.check(L.lib().votenet_prob_sample(b, n, m, L.ptr(inp), L.ptr(inpr), L.ptr(temp), L.ptr(out), L.stream_ptr()))
+    return out
