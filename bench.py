@@ -33,6 +33,8 @@ def parse():
     ap.add_argument("--workload", default=None, choices=["train", "fwd"])
     ap.add_argument("--scene", default="room", choices=["room", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="do not compute the coordinate-only geometry of the next batch underneath the current step")
     return ap.parse_args()
 
 
@@ -110,22 +112,31 @@ def main():
     B, n = args.batch, args.points
     gen = synth.room_batch if args.scene == "room" else synth.uniform_batch
     from votenet_amd import dp
-    x = torch.from_numpy(gen(B, n, dp.scene_seeds(rank, B)[0])).to(dev)  # disjoint seeds per rank, resident in HBM
+    # TWO different batches, alternated: step i trains on batch i % 2 while the coordinate-only geometry (FPS, ball query,
+    # three_nn) of batch (i+1) % 2 is computed on a side stream -- every step computes one full geometry, none is reused
+    seeds = [dp.scene_seeds(rank, B)[0], dp.scene_seeds(rank, B, base=500000)[0]]
+    xs = [torch.from_numpy(gen(B, n, sd)).to(dev) for sd in seeds]  # disjoint seeds per rank, resident in HBM
     net = VM.VoteNetHotPath(dev, seed=0)
-    cot = gt = None
+    cot = None
+    gts = [None, None]
     if workload == "train":
         if args.scene == "room":  # the generating boxes are the ground truth: the reference's loss graph drives the backward
             from votenet_amd import loss as vloss
-            gt = vloss.gt_to_device(synth.room_gt(B, n, dp.scene_seeds(rank, B)[0]), dev)
+            gts = [vloss.gt_to_device(synth.room_gt(B, n, sd), dev) for sd in seeds]
         else:                     # uniform cubes have no objects: fixed cotangents instead
             cot = net.make_cotangents(B, seed=rank)
         dp.broadcast_params(net.store)
+    pipeline = not args.no_pipeline
+    counter = [0]
 
     def step():
+        i = counter[0]
+        counter[0] += 1
+        x, nxt = xs[i % 2], (xs[(i + 1) % 2] if pipeline else None)
         if workload == "train":
-            net.train_step(x, cot, world, gt=gt)
+            net.train_step(x, cot, world, gt=gts[i % 2], next_x=nxt)
         else:
-            net.forward(x)
+            net.forward(x, next_x=nxt)
 
     tf_sampling.PROFILE_EVENTS = None
     for _ in range(args.warmup):
@@ -236,7 +247,9 @@ def main():
             "config": {"workload": ("VoteNet hot path %s: sa1-4 + fp1-2 + voting + proposal, %d scenes x %d pts per GPU, "
                                     "%s scenes" % (("train step (fwd + loss graph of model.py:61-84,141-231 + bwd + clip/Adam)" if args.scene == "room" else
                                                     "train step (fwd+bwd+Adam, fixed cotangents)")
-                                                   if workload == "train" else "forward", B, n, args.scene)),
+                                                   if workload == "train" else "forward", B, n, args.scene)
+                                    + ("; two batches alternate, the coordinate-only geometry of the next batch (FPS, ball query, "
+                                       "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }

@@ -166,3 +166,28 @@ def test_full_size_train_steps(hiplib, dev):
     assert float(step.max()) <= 2.0e-3 * 1.001 and float(step.mean()) > 1e-4  # Adam: |delta| <= lr per step
     out1 = net.forward(x)["proposals_output"]
     assert not torch.equal(out0, out1) and torch.isfinite(out1).all()
+
+
+def test_prefetched_geometry_is_the_same_computation(hiplib, dev):
+    """prefetch_geometry(next_x) during a step, then the step on next_x: bit-identical outputs to the unpipelined call; a
+    prefetch for another tensor (or a tensor modified since) is not used."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    xa = torch.from_numpy(synth.room_batch(2, 4096, 11)).to(dev)
+    xb = torch.from_numpy(synth.room_batch(2, 4096, 21)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=3, npoints=(512, 256, 128, 64))
+    ref_b = net.forward(xb)
+    net.forward(xa, next_x=xb)
+    assert net._prefetched is not None and net._prefetched[0] is xb
+    got_b = net.forward(xb)
+    assert net._prefetched is None
+    for k in ref_b:
+        assert torch.equal(ref_b[k], got_b[k]), k
+    net.forward(xa, next_x=xb)
+    xb.add_(0.0)  # bumps the version: the prefetched geometry is dropped, not trusted
+    again = net.forward(xb)
+    for k in ref_b:
+        assert torch.equal(ref_b[k], again[k]), k
+    net.forward(xa, next_x=xa)
+    other = net.forward(xb)  # prefetched for xa: ignored
+    assert torch.equal(other["proposals_output"], ref_b["proposals_output"])

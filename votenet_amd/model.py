@@ -43,47 +43,89 @@ class VoteNetHotPath:
         s.materialize(seed)
 
     # ---- forward pieces -------------------------------------------------------------
-    def geometry_ahead(self, x):
-        """Every FPS / ball query / three_nn of the backbone depends on coordinates only, never on features.
-        Level 1 stays on the caller's stream (the sa1 MLP needs it first); levels 2-4, both three_nn and the
-        proposal layer's FPS (it samples the SEEDS, utils.py:42-43) run on a side HIP stream underneath the MLP
-        GEMMs -- they are latency-bound chains on 8 workgroups and leave the other CUs to the matrix work."""
-        main = torch.cuda.current_stream()
+    def _side_stream(self):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
-        side = self._side
-        g = {}
-        g["sa1"] = self.sa1.geometry(x)
-        ev = {}
-        start = torch.cuda.Event()
-        start.record(main)
-        with torch.cuda.stream(side):
-            side.wait_event(start)
-            xyz = g["sa1"][1]
-            for name, mod in (("sa2", self.sa2), ("sa3", self.sa3), ("sa4", self.sa4)):
-                g[name] = mod.geometry(xyz)
-                xyz = g[name][1]
-                if name == "sa2":  # seeds = l2_xyz: the proposal layer's FPS can start as soon as they exist
-                    g["prop_fps"] = P.tf_sampling.farthest_point_sample(self.proposal.npoint, xyz)
-                ev[name] = torch.cuda.Event()
-                ev[name].record(side)
-            g["fp1"] = P.FPModule.geometry(g["sa3"][1], g["sa4"][1])
-            g["fp2"] = P.FPModule.geometry(g["sa2"][1], g["sa3"][1])
-            ev["fp"] = torch.cuda.Event()
-            ev["fp"].record(side)
+        return self._side
+
+    def _geometry_chain(self, x, g, ev, levels):
+        """FPS / ball query of `levels`, the proposal layer's FPS (it samples the SEEDS, utils.py:42-43) and both three_nn on
+        the current stream; an event per level so that a consumer waits only for what it needs."""
+        xyz = x if "sa1" in levels else g["sa1"][1]
+        for name in levels:
+            g[name] = getattr(self, name).geometry(xyz)
+            xyz = g[name][1]
+            if name == "sa2":  # seeds = l2_xyz: the proposal layer's FPS can start as soon as they exist
+                g["prop_fps"] = P.tf_sampling.farthest_point_sample(self.proposal.npoint, xyz)
+            ev[name] = torch.cuda.Event()
+            ev[name].record()
+        g["fp1"] = P.FPModule.geometry(g["sa3"][1], g["sa4"][1])
+        g["fp2"] = P.FPModule.geometry(g["sa2"][1], g["sa3"][1])
+        ev["fp"] = torch.cuda.Event()
+        ev["fp"].record()
+
+    @staticmethod
+    def _hand_over(g, main):
         for v in g.values():  # tensors born on the side stream are consumed on the main stream
             for t in (v if isinstance(v, tuple) else (v,)):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
+
+    def geometry_ahead(self, x):
+        """Every FPS / ball query / three_nn of the backbone depends on coordinates only, never on features.
+        Level 1 stays on the caller's stream (the sa1 MLP needs it first); levels 2-4, both three_nn and the
+        proposal layer's FPS run on a side HIP stream underneath the MLP GEMMs -- they are latency-bound chains on 8
+        workgroups and leave the other CUs to the matrix work."""
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        g, ev = {}, {}
+        g["sa1"] = self.sa1.geometry(x)
+        start = torch.cuda.Event()
+        start.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            self._geometry_chain(x, g, ev, ("sa2", "sa3", "sa4"))
+        self._hand_over(g, main)
         return g, ev
 
-    def backbone(self, x, tape=None, overlap=True):
+    def prefetch_geometry(self, next_x):
+        """Software pipelining across steps: the WHOLE coordinate-only part of the next batch (all four FPS + ball queries,
+        the proposal FPS, both three_nn) is launched now on the side stream, underneath this step's GEMMs -- FPS is a
+        latency chain on one workgroup per scene (8 of 256 CUs), the one thing a step cannot hide from itself because
+        everything waits for sa1's centres.  backbone(next_x) picks the result up; every step still computes one full
+        geometry.  The input pipeline knows the next batch a step ahead (the reference prefetches batches through
+        QueueInput, run.py:121-122)."""
+        main = torch.cuda.current_stream()
+        side = self._side_stream()
+        g, ev = {}, {}
+        start = torch.cuda.Event()
+        start.record(main)  # next_x may have been produced on the main stream
+        with torch.cuda.stream(side):
+            side.wait_event(start)
+            self._geometry_chain(next_x, g, ev, ("sa1", "sa2", "sa3", "sa4"))
+        self._hand_over(g, main)
+        self._prefetched = (next_x, next_x._version, g, ev)
+
+    def _take_prefetched(self, x):
+        pf, self._prefetched = getattr(self, "_prefetched", None), None
+        if pf is not None and pf[0] is x and pf[1] == x._version:
+            return pf[2], pf[3]
+        return None
+
+    def backbone(self, x, tape=None, overlap=True, next_x=None):
         """model.py:35-50.  x (B,n,3) -> seeds_xyz (B,1024,3), seeds_points (B,1024,256)."""
         main = torch.cuda.current_stream()
-        if overlap:
+        pf = self._take_prefetched(x)
+        if pf is not None:
+            g, ev = pf
+            main.wait_event(ev["sa1"])
+        elif overlap:
             g, ev = self.geometry_ahead(x)
         else:
             g, ev = {}, {}
+        if next_x is not None:
+            self.prefetch_geometry(next_x)
+        overlap = overlap or pf is not None
         self._prop_fps = g.get("prop_fps")
         l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape, geom=g.get("sa1"))
         if overlap:
@@ -120,10 +162,11 @@ class VoteNetHotPath:
         p_xyz, p_out, _ = self.proposal.forward(votes_xyz, votes_points, sample_xyz=seeds_xyz, tape=tape, geom=geom)
         return p_xyz, p_out
 
-    def forward(self, x, tape=None):
+    def forward(self, x, tape=None, next_x=None):
+        """next_x: the batch of the NEXT call, if known: its geometry is computed underneath this pass (prefetch_geometry)."""
         M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
         try:
-            seeds_xyz, seeds_p = self.backbone(x, tape)
+            seeds_xyz, seeds_p = self.backbone(x, tape, next_x=next_x)
             v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape)
             p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
         finally:
@@ -208,7 +251,7 @@ class VoteNetHotPath:
         self._step = 0
         self._lr = lr
 
-    def train_step(self, x, cot=None, world=1, gt=None):
+    def train_step(self, x, cot=None, world=1, gt=None, next_x=None):
         """forward + loss + backward + (world>1: ONE RCCL all-reduce of the flat gradient bucket) + clip/Adam.
         gt: ground truth on the device (loss.gt_to_device): the reference's total cost (model.py:228) drives the backward
         pass, its components are left in self.last_losses (device, loss.NAMES).  cot: fixed cotangents instead (tests)."""
@@ -216,11 +259,9 @@ class VoteNetHotPath:
             self.init_optimizer()
         self.store.grad.zero_()
         # every W^T of the backward pass's input-gradient GEMMs: one launch on the geometry stream, under the sa1 FPS
-        if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
-        self.store.refresh_transposes(self._side)
+        self.store.refresh_transposes(self._side_stream())
         tape = []
-        out = self.forward(x, tape)
+        out = self.forward(x, tape, next_x=next_x)
         if gt is not None:
             from . import loss as VL
             self.last_losses, cot = VL.votenet_loss(out, gt)
