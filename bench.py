@@ -10,6 +10,7 @@ Workloads:
     fwd   : forward only (BASELINE.json configs[1] plus voting + proposal)
 Inputs are resident in HBM before the timed region.  One JSON line on rank 0.
 """
+import gc
 import argparse
 import json
 import os
@@ -84,7 +85,6 @@ def cpu_baseline(points, scene_kind):
     px, pp = sa(vx, vp, 256, 0.3, 64, [128, 128, 128], sample_xyz=l2x)
     mlp(pp.reshape(-1, 128), [128, 128, 128, 79], last_plain=True)
     dt = time.perf_counter() - t0
-    gc.enable()
     return {"value": 1.0 / dt, "unit": "scenes/s", "cores": 1, "kind": "port",
             "sample": "forward pass of 1 synthetic %d-pt scene through the same layer stack on the CPU oracle "
                       "(single thread, %.1f s; the oracle has no backward)" % (points, dt)}
@@ -153,7 +153,6 @@ def main():
     tf_grouping.PROFILE_EVENTS = []
     vmlp.PROFILE_EVENTS = []
     events, bq_events, gemm_events = [], [], []
-    import gc
     gc.collect()
     gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
     t0 = time.perf_counter()
@@ -168,6 +167,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    gc.enable()
     if tf_sampling.PROFILE_EVENTS is not None:  # steps <= 2
         events, tf_sampling.PROFILE_EVENTS = tf_sampling.PROFILE_EVENTS, None
         bq_events, tf_grouping.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS, None
