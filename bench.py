@@ -125,13 +125,14 @@ def main():
     B, n = args.batch, args.points
     gen = synth.room_batch if args.scene == "room" else synth.uniform_batch
     from votenet_amd import dp
-    # TWO different batches, alternated: step i trains on batch i % 2 while the coordinate-only geometry (FPS, ball query,
-    # three_nn) of batch (i+1) % 2 is computed on a side stream -- every step computes one full geometry, none is reused
-    seeds = [dp.scene_seeds(rank, B)[0], dp.scene_seeds(rank, B, base=500000)[0]]
+    # THREE different batches in rotation: step i works on batch i % 3 while the coordinate-only geometry (FPS, ball query,
+    # three_nn) of the batches after it is computed on side streams -- every step computes one full geometry, none is
+    # reused.  Lookahead: 1 for the train step; 2 for the forward pass, which is shorter than one geometry chain
+    seeds = [dp.scene_seeds(rank, B, base=bs)[0] for bs in (1000, 500000, 900000)]
     xs = [torch.from_numpy(gen(B, n, sd)).to(dev) for sd in seeds]  # disjoint seeds per rank, resident in HBM
     net = VM.VoteNetHotPath(dev, seed=0)
     cot = None
-    gts = [None, None]
+    gts = [None] * len(seeds)
     if workload == "train":
         if args.scene == "room":  # the generating boxes are the ground truth: the reference's loss graph drives the backward
             from votenet_amd import loss as vloss
@@ -145,9 +146,11 @@ def main():
     def step():
         i = counter[0]
         counter[0] += 1
-        x, nxt = xs[i % 2], (xs[(i + 1) % 2] if pipeline else None)
+        nb = len(xs)
+        x = xs[i % nb]
+        nxt = ([xs[(i + 1) % nb]] + ([xs[(i + 2) % nb]] if workload == "fwd" else [])) if pipeline else None
         if workload == "train":
-            net.train_step(x, cot, world, gt=gts[i % 2], next_x=nxt)
+            net.train_step(x, cot, world, gt=gts[i % nb], next_x=nxt)
         else:
             net.forward(x, next_x=nxt)
 
@@ -275,7 +278,7 @@ def main():
                                     "%s scenes" % (("train step (fwd + loss graph of model.py:61-84,141-231 + bwd + clip/Adam)" if args.scene == "room" else
                                                     "train step (fwd+bwd+Adam, fixed cotangents)")
                                                    if workload == "train" else "forward", B, n, args.scene)
-                                    + ("; two batches alternate, the coordinate-only geometry of the next batch (FPS, ball query, "
+                                    + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
                                        "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,

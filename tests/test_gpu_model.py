@@ -178,9 +178,9 @@ def test_prefetched_geometry_is_the_same_computation(hiplib, dev):
     net = VM.VoteNetHotPath(dev, seed=3, npoints=(512, 256, 128, 64))
     ref_b = net.forward(xb)
     net.forward(xa, next_x=xb)
-    assert net._prefetched is not None and net._prefetched[0] is xb
+    assert id(xb) in net._prefetched and net._prefetched[id(xb)][0] is xb
     got_b = net.forward(xb)
-    assert net._prefetched is None
+    assert not net._prefetched
     for k in ref_b:
         assert torch.equal(ref_b[k], got_b[k]), k
     net.forward(xa, next_x=xb)
@@ -191,3 +191,13 @@ def test_prefetched_geometry_is_the_same_computation(hiplib, dev):
     net.forward(xa, next_x=xa)
     other = net.forward(xb)  # prefetched for xa: ignored
     assert torch.equal(other["proposals_output"], ref_b["proposals_output"])
+    # a lookahead of two on alternating prefetch streams
+    xc = torch.from_numpy(synth.room_batch(2, 4096, 31)).to(dev)
+    ref_c = net.forward(xc)
+    net._prefetched.clear()
+    net.forward(xa, next_x=[xb, xc])
+    assert len(net._prefetched) == 2
+    b2 = net.forward(xb, next_x=[xc, xa])
+    c2 = net.forward(xc)
+    for k in ref_b:
+        assert torch.equal(ref_b[k], b2[k]) and torch.equal(ref_c[k], c2[k]), k

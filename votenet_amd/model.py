@@ -89,14 +89,22 @@ class VoteNetHotPath:
         return g, ev
 
     def prefetch_geometry(self, next_x):
-        """Software pipelining across steps: the WHOLE coordinate-only part of the next batch (all four FPS + ball queries,
-        the proposal FPS, both three_nn) is launched now on the side stream, underneath this step's GEMMs -- FPS is a
+        """Software pipelining across steps: the WHOLE coordinate-only part of an upcoming batch (all four FPS + ball queries,
+        the proposal FPS, both three_nn) is launched now on a side stream, underneath this step's GEMMs -- FPS is a
         latency chain on one workgroup per scene (8 of 256 CUs), the one thing a step cannot hide from itself because
         everything waits for sa1's centres.  backbone(next_x) picks the result up; every step still computes one full
-        geometry.  The input pipeline knows the next batch a step ahead (the reference prefetches batches through
-        QueueInput, run.py:121-122)."""
+        geometry.  Several batches may be in flight (two prefetch streams, used alternately): a forward-only pass is shorter
+        than one geometry chain, so it wants a lookahead of two.  The input pipeline knows the next batches ahead (the
+        reference prefetches them through QueueInput, run.py:121-122)."""
+        pool = self.__dict__.setdefault("_prefetched", {})
+        if id(next_x) in pool and pool[id(next_x)][0] is next_x and pool[id(next_x)][1] == next_x._version:
+            return
         main = torch.cuda.current_stream()
-        side = self._side_stream()
+        if getattr(self, "_pf_streams", None) is None:
+            self._pf_streams = [self._side_stream(), torch.cuda.Stream(device=self.device)]
+            self._pf_turn = 0
+        side = self._pf_streams[self._pf_turn]
+        self._pf_turn ^= 1
         g, ev = {}, {}
         start = torch.cuda.Event()
         start.record(main)  # next_x may have been produced on the main stream
@@ -104,10 +112,12 @@ class VoteNetHotPath:
             side.wait_event(start)
             self._geometry_chain(next_x, g, ev, ("sa1", "sa2", "sa3", "sa4"))
         self._hand_over(g, main)
-        self._prefetched = (next_x, next_x._version, g, ev)
+        while len(pool) >= 4:  # never picked up: drop the oldest
+            pool.pop(next(iter(pool)))
+        pool[id(next_x)] = (next_x, next_x._version, g, ev)
 
     def _take_prefetched(self, x):
-        pf, self._prefetched = getattr(self, "_prefetched", None), None
+        pf = self.__dict__.setdefault("_prefetched", {}).pop(id(x), None)
         if pf is not None and pf[0] is x and pf[1] == x._version:
             return pf[2], pf[3]
         return None
@@ -123,8 +133,8 @@ class VoteNetHotPath:
             g, ev = self.geometry_ahead(x)
         else:
             g, ev = {}, {}
-        if next_x is not None:
-            self.prefetch_geometry(next_x)
+        for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
+            self.prefetch_geometry(nx)
         overlap = overlap or pf is not None
         self._prop_fps = g.get("prop_fps")
         l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape, geom=g.get("sa1"))
@@ -163,7 +173,8 @@ class VoteNetHotPath:
         return p_xyz, p_out
 
     def forward(self, x, tape=None, next_x=None):
-        """next_x: the batch of the NEXT call, if known: its geometry is computed underneath this pass (prefetch_geometry)."""
+        """next_x: the batch of the NEXT call (or a list of the next few), if known: their geometry is computed underneath this
+        pass (prefetch_geometry)."""
         M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
         try:
             seeds_xyz, seeds_p = self.backbone(x, tape, next_x=next_x)
