@@ -27,13 +27,14 @@ MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, fp32 in / fp32 a
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=6)
     ap.add_argument("--batch", type=int, default=8, help="scenes per GPU")
     ap.add_argument("--points", type=int, default=20480, help="points per scene (config.py:1)")
     ap.add_argument("--workload", default=None, choices=["train", "fwd"])
     ap.add_argument("--scene", default="room", choices=["room", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gram", action="store_true", help="pooled layers: direct backward GEMMs on the stored z instead of the Gram form")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not compute the coordinate-only geometry of the next batch underneath the current step")
     return ap.parse_args()
@@ -154,6 +155,9 @@ def main():
         else:
             net.forward(x, next_x=nxt)
 
+    if args.no_gram:
+        from votenet_amd import pointnet2
+        pointnet2.POOL_GRAM_BACKWARD = False
     tf_sampling.PROFILE_EVENTS = None
     for _ in range(args.warmup):
         step()

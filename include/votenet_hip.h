@@ -214,15 +214,51 @@ int votenet_bn_relu_max(long groups, int k, int c, const float *z, const float *
  * (zmax / zmin / amax / amin, each rows/pool_k x cout).  The layer's BatchNorm scale needs the statistics of the whole
  * launch, but max_k act(s*z+h) = act(s * max_k z + h) for s >= 0 and act(s * min_k z + h) for s < 0, so
  * votenet_bn_pool_finalize completes the pool without another pass over z (same values as votenet_bn_relu_max; among
- * rows that tie after BatchNorm the arg-max may name a different one).  z may be NULL when only the pooled result is
- * wanted (inference).  Served: DENSE input, pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, cout % 128 == 0,
+ * rows that tie after BatchNorm the arg-max may name a different one; with a zero scale -- every row ties -- it names the
+ * row of the raw maximum).  zsel (groups x c, may be NULL) receives the raw z at the arg-max row, which is all the
+ * backward pass of the layer needs from z (votenet_bn_backward_reduce_pool ...).  z may be NULL when nothing else reads it
+ * (inference; training through the Gram-form backward below).  Served: DENSE input, pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, cout % 128 == 0,
  * 16-byte aligned buffers; anything else returns VOTENET_E_INVALID_ARGUMENT. */
 int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
                             float *z /* may be NULL */, double *stats, int pool_k, float *zmax, float *zmin, int *amax,
                             int *amin, void *stream);
 int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
                              const float *scale, const float *shift, const votenet_bn_raw *bn /* instead of scale / shift, or NULL */,
-                             int relu, float *out, int *argmax /* may be NULL */, void *stream);
+                             int relu, float *out, int *argmax /* may be NULL */, float *zsel /* may be NULL */, void *stream);
+
+/* ---- backward of the pooled (last) layer of an SA chain in "Gram form" (pool_bwd.hip) ----
+ * Layer: z = x W + b (x = the layer's input activation, rows x cin, given as raw xz + folded BatchNorm/ReLU), BatchNorm,
+ * ReLU, max over the k rows of each group.  The folded BatchNorm backward is dz = A g' + B + C z with g' non-zero only at
+ * the arg-max rows (coef = [A|B|C|scale|shift], votenet_bn_backward_coef).  Substituting z = x W + b:
+ *     da = dz W^T = x (W diag(C) W^T) + (B + C.b) W^T  +  scatter: da[g*k + argmax[g,c], :] += A[c] g'[g,c] W[:,c]^T
+ *     dW = x^T dz = ((x^T x) W) . C + (sum_r x)^T (B + C.b)  +  gather: dW[:,c] += x[g*k + argmax[g,c], :]^T A[c] g'[g,c]
+ * so both big GEMMs are rows x cin x cin instead of rows x cin x cout, z is never read, and x^T x depends on the forward
+ * pass only.  Call order for one layer:
+ *   reduce_pool -> votenet_bn_backward_coef -> dgrad_prepare -> votenet_mlp_linear(x, mmat, bias = cvec) -> dgrad_scatter
+ *   mlp_gram (any time after the forward pass) ; wgrad_sparse -> wgrad_finish (after coef)
+ * Served shapes: votenet_pool_backward_supported (k = 64; cin x cout = 128x256, 128x128, 64x128: every pooled layer of
+ * VoteNet); other layers keep votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn. */
+int votenet_pool_backward_supported(int cin, int cout, int k);
+/* sums (2c doubles, pre-zeroed) += [sum g', sum g' zhat] over the arg-max entries: g' = gout masked by the ReLU */
+int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const float *zsel, const float *scale,
+                                    const float *shift, const float *mean, const float *var, float eps, int relu,
+                                    double *sums, void *stream);
+/* mmat (cin x cin) = W diag(C) W^T, cvec (cin) = (B + C.b) W^T; w (cin x cout), bias may be NULL */
+int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                               float *cvec, void *stream);
+/* da (groups*k x cin) += the scattered rows; wT = W^T (cout x cin) */
+int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
+                               const float *zsel, const float *coef, int relu, const float *wT, float *da, void *stream);
+/* gram (c x c, pre-zeroed or accumulating) += a^T a with a = act(z * scale + shift); scale_shift = [scale | shift] (2c) */
+int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, void *stream);
+/* dw (cin x cout) += the gathered rows; colsum (cin, pre-zeroed) += sum_r x[r,:]; xz / in_scale / in_shift / in_relu
+ * describe x as in votenet_mlp_input */
+int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
+                              const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
+                              const float *coef, int relu, float *dw, float *colsum, void *stream);
+/* dw[j,c] += C[c] (gram[j,:] . W[:,c]) + colsum[j] (B[c] + C[c] b[c]) */
+int votenet_pool_wgrad_finish(int cin, int cout, const float *gram, const float *colsum, const float *w, const float *bias,
+                              const float *coef, float *dw, void *stream);
 
 /* y = max(0?, z*scale+shift) materialised (rows x c); used where the next consumer is not a
  * votenet_mlp_linear (e.g. the FP-layer output that feeds the voting head). */

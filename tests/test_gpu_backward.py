@@ -21,7 +21,10 @@ def ref_chain(x, layers, params, recs):
             var = z.var(0, unbiased=False)
             z = params[L.name + "/gamma"] * (z - mu) / torch.sqrt(var + EPS) + params[L.name + "/beta"]
         if L.relu:
-            mask = (r["z"] * r["scale"] + r["shift"] > 0).double()
+            if r["z"] is None:  # pooled layer in Gram form: the device keeps no z; ref_sa applies the active set after the max
+                mask = 1.0
+            else:
+                mask = (r["z"] * r["scale"] + r["shift"] > 0).double()
             z = z * mask
         x = z
     return x
@@ -37,6 +40,9 @@ def ref_sa(mod, params, xyz, pts, rec):
         g = torch.cat([g, pts[bi, idx]], -1)
     y = ref_chain(g.reshape(b * m * k, -1), mod.mlp, params, rec["recs"]).view(b * m, k, -1)
     y = y.gather(1, rec["argmax"].long()[:, None, :])[:, 0, :]  # max over k through the device argmax
+    last = rec["recs"][-1]
+    if last["z"] is None:  # the device's active set at the arg-max entries (raw z there = zsel)
+        y = y * (rec["zsel"] * last["scale"] + last["shift"] > 0).double()
     if mod.mlp2:
         y = ref_chain(y, mod.mlp2, params, rec["recs2"])
     return new_xyz, y.view(b, m, -1)
@@ -240,3 +246,77 @@ def test_clip_adam_vs_reference(hiplib, dev):
             p0[k] = p0[k] - 1e-3 * (m[k] / (1 - 0.9 ** step)) / (torch.sqrt(v2[k] / (1 - 0.999 ** step)) + 1e-8)
     for k in p0:
         assert torch.allclose(net.store[k], p0[k], rtol=1e-4, atol=1e-6), k
+
+
+@pytest.mark.parametrize("groups,cin,cout", [(512, 128, 256), (300, 128, 128), (1024, 64, 128)])
+def test_pooled_layer_gram_form_equals_the_direct_form(hiplib, dev, groups, cin, cout):
+    """pool_bwd.hip against votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn on the stored z: same da and dW (the two forms
+    differ only in floating-point association), including negative BatchNorm scales and inactive ReLUs."""
+    from votenet_amd import mlp as M
+    k, rows = 64, groups * 64
+    g = torch.Generator().manual_seed(groups + cin)
+    xz = torch.randn(rows, cin, generator=g).to(dev)
+    aff = torch.stack([torch.randn(cin, generator=g) * 0.3 + 1, torch.randn(cin, generator=g) * 0.2]).to(dev).contiguous()
+    w = (torch.randn(cin, cout, generator=g) * 0.15).to(dev)
+    b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    gamma = (torch.randn(cout, generator=g) * 0.5 + 0.8).to(dev)  # some negative
+    beta = (torch.randn(cout, generator=g) * 0.3 - 0.2).to(dev)
+    z, st, pool = M.linear_dense_pool(xz, w, k, b, aff[0], aff[1], True)
+    sc, sh, mean, var = M.bn_finalize(rows, st, gamma, beta)
+    out, arg, zsel = M.bn_pool_finalize(pool, sc, sh, True, want_argmax=True, want_zsel=True)
+    gout = torch.randn(groups, cout, generator=g).to(dev)
+    # direct form
+    sums = M.bn_backward_reduce(z, sc, sh, mean, var, True, gout, argmax=arg, k=k)
+    dga, dbe = torch.zeros(cout, device=dev), torch.zeros(cout, device=dev)
+    coef = M.bn_backward_coef(rows, sc, sh, mean, var, gamma, sums, dga, dbe)
+    dw_ref = torch.zeros(cin, cout, device=dev)
+    M.wgrad_dense_bn(xz, z, coef, True, dw_ref, gout=gout, argmax=arg, k=k, in_scale=aff[0], in_shift=aff[1], in_relu=True)
+    wT = w.t().contiguous()
+    da_ref = M.dgrad_bn(z, coef, True, wT, gout=gout, argmax=arg, k=k)
+    # Gram form: never touches z
+    sums2 = M.bn_backward_reduce_pool(gout, zsel, sc, sh, mean, var, True)
+    assert torch.allclose(sums2, sums, rtol=1e-9, atol=1e-9)
+    G = M.gram(xz, aff, True)
+    a = torch.relu(xz.double() * aff[0].double() + aff[1].double())
+    assert relerr(G[:cin].double(), a.t() @ a) < 1e-5
+    dw = torch.zeros(cin, cout, device=dev)
+    M.pool_wgrad(xz, aff[0], aff[1], True, G, w, b, coef, True, gout, arg, zsel, k, dw)
+    assert relerr(G[cin].double(), a.sum(0)) < 1e-5
+    da = M.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k)
+    assert relerr(da.double(), da_ref.double()) < 2e-5
+    assert relerr(dw.double(), dw_ref.double()) < 2e-5
+    assert M.pool_backward_supported(cin, cout, 64) and not M.pool_backward_supported(cin, cout, 32)
+    assert not M.pool_backward_supported(256, 256, 64)
+
+
+@pytest.mark.parametrize("gram", [True, False])
+def test_sa_module_with_a_gram_form_last_layer_vs_autograd(hiplib, dev, gram):
+    """An SA module whose pooled layer has a Gram-form shape (128 -> 256, k = 64), both backward forms, against autograd."""
+    from votenet_amd import pointnet2 as P
+    old = P.POOL_GRAM_BACKWARD
+    P.POOL_GRAM_BACKWARD = gram
+    try:
+        store = P.ParamStore(dev)
+        mod = P.SAModule(store, "t", 32, 0.5, 64, 16, [64, 128, 256])
+        store.materialize(4)
+        perturb(type("N", (), {"store": store})(), dev)
+        g = torch.Generator().manual_seed(3)
+        xyz = torch.rand(2, 400, 3, generator=g).to(dev)
+        pts = torch.randn(2, 400, 16, generator=g).to(dev)
+        tape = []
+        _, out, _ = mod.forward(xyz, pts, tape=tape)
+        assert (tape[0]["recs"][-1]["z"] is None) == gram
+        gout = torch.randn(out.shape, generator=g).to(dev)
+        d_feat, _ = mod.backward(tape[0], gout, need_feat_grad=True)
+        P.wgrad_join()
+        params = {k: v.detach().double().clone().requires_grad_(True) for k, v in store.views.items()}
+        xd, pd = xyz.double(), pts.double().requires_grad_(True)
+        _, y = ref_sa(mod, params, xd, pd, tape[0])
+        (y * gout.double()).sum().backward()
+        assert relerr(out.double(), y.detach()) < 1e-5
+        assert relerr(d_feat.double(), pd.grad) < 1e-4
+        for name in store.views:
+            if not name.endswith("/b"):
+                assert relerr(store.g(name).double(), params[name].grad) < 1e-4, name
+    finally:
+        P.POOL_GRAM_BACKWARD = old

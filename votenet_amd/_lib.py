@@ -74,8 +74,16 @@ _SIGS.update({
     "votenet_group_linear_backward": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_mlp_linear_pool": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
                                + [_c_f] * 4 + [ctypes.c_void_p],
-    "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.POINTER(BnRaw), ctypes.c_int] + [_c_f] * 2
+    "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.POINTER(BnRaw), ctypes.c_int] + [_c_f] * 3
                                 + [ctypes.c_void_p],
+    "votenet_pool_backward_supported": [ctypes.c_int] * 3,
+    "votenet_bn_backward_reduce_pool": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_pool_dgrad_prepare": [ctypes.c_int] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_pool_dgrad_scatter": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_mlp_gram": [ctypes.c_long, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_pool_wgrad_sparse": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
+                                 + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_pool_wgrad_finish": [ctypes.c_int] * 2 + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],

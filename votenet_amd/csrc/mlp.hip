@@ -480,7 +480,7 @@ __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, c
 __global__ void bn_pool_finalize_kernel(long total, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
                                         const int *__restrict__ amax, const int *__restrict__ amin, const float *__restrict__ scale,
                                         const float *__restrict__ shift, BnRaw raw, int relu, float *__restrict__ out,
-                                        int *__restrict__ argmax)
+                                        int *__restrict__ argmax, float *__restrict__ zsel)
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(e % c);
@@ -490,11 +490,12 @@ __global__ void bn_pool_finalize_kernel(long total, int c, const float *__restri
             s = scale[ch];
             h = shift[ch];
         }
-        float v = (s >= 0.0f ? zmax[e] : zmin[e]) * s + h;
-        int a = s > 0.0f ? amax[e] : (s < 0.0f ? amin[e] : 0);
+        const float zr = s >= 0.0f ? zmax[e] : zmin[e]; // a zero scale ties every row: the row of the raw maximum stands for them
+        float v = zr * s + h;
         if (relu && !(v > 0.0f)) v = 0.0f;
         out[e] = v;
-        if (argmax) argmax[e] = a;
+        if (argmax) argmax[e] = s >= 0.0f ? amax[e] : amin[e];
+        if (zsel) zsel[e] = zr;
     }
 }
 
@@ -619,7 +620,7 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
 
 extern "C" int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
                                         const float *scale, const float *shift, const votenet_bn_raw *bn, int relu, float *out,
-                                        int *argmax, void *stream)
+                                        int *argmax, float *zsel, void *stream)
 {
     VN_REQUIRE(groups >= 0 && c > 0, "bn_pool_finalize expects groups >= 0, c > 0");
     if (groups == 0) return VOTENET_OK;
@@ -627,7 +628,7 @@ extern "C" int votenet_bn_pool_finalize(long groups, int c, const float *zmax, c
     VN_REQUIRE(zmax && zmin && amax && amin && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
                "bn_pool_finalize: null buffer");
     hipLaunchKernelGGL(bn_pool_finalize_kernel, dim3(grid_for(groups * c, 256)), dim3(256), 0, as_stream(stream), groups * c, c, zmax,
-                       zmin, amax, amin, scale, shift, raw, relu, out, argmax);
+                       zmin, amax, amin, scale, shift, raw, relu, out, argmax, zsel);
     return check_launch("bn_pool_finalize");
 }
 

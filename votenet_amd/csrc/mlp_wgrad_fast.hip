@@ -7,7 +7,8 @@
 //     the dZ side when the slab is written to LDS), so the compiler's s_waitcnt bookkeeping stays exact;
 //   * two register sets hold the raw quads of the next two 16-row slabs: half way through a slab's MFMAs the older set
 //     is written to the other LDS buffer (folded BN+ReLU of the layer below on X; BatchNorm backward rebuilt from
-//     (da | pooled gout, z, coef) on dZ -- struct BnSrc) and refilled with the slab three steps ahead.  Loads lead by
+//     (da | pooled gout, z, coef) on dZ -- struct BnSrc; BSRC 3: dZ is itself a folded activation, for the Gram matrix of
+//     votenet_mlp_gram) and refilled with the slab three steps ahead.  Loads lead by
 //     two slabs of matrix work; one slab is shorter than the loaded HBM latency;
 //   * GATHER: the idx of a slab is loaded one refill BEFORE the feature rows that need it, and ahead of that refill's
 //     other loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.
@@ -52,13 +53,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float x_floor = (affine && in.in_relu) ? 0.0f : -__builtin_inff(); // ReLU as a floor: branch-free
     float4 kA, kB, kC, kS, kH;
     kA = kB = kC = kS = kH = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (BSRC != 0) {
+    if (BSRC == 1 || BSRC == 2) {
         kA = *reinterpret_cast<const float4 *>(bs.coef + nb);
         kB = *reinterpret_cast<const float4 *>(bs.coef + cout + nb);
         kC = *reinterpret_cast<const float4 *>(bs.coef + 2 * cout + nb);
         kS = *reinterpret_cast<const float4 *>(bs.coef + 3 * cout + nb);
         kH = *reinterpret_cast<const float4 *>(bs.coef + 4 * cout + nb);
     }
+    if (BSRC == 3) { // the right operand is an ACTIVATION: act(z * scale + shift); coef = [scale | shift]
+        kS = *reinterpret_cast<const float4 *>(bs.coef + nb);
+        kH = *reinterpret_cast<const float4 *>(bs.coef + cout + nb);
+    }
+    const float b_floor = (BSRC == 3 && bs.relu) ? 0.0f : -__builtin_inff();
     // wave-uniform bases at the workgroup's first row; threads carry 32-bit element offsets (checked by the launcher)
     const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : in.feat + ka;
     const float *zb = (BSRC == 0 ? dz : bs.z) + (size_t)r_begin * cout + nb;
@@ -123,7 +129,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         for (int h = 0; h < NB; h++) {
             const int lr = r.s * WF_BR + b_row + h * RB;
             float4 v = r.b[h];
-            if (BSRC != 0) {
+            if (BSRC == 3) {
+                v.x = fmaxf(v.x * kS.x + kH.x, b_floor);
+                v.y = fmaxf(v.y * kS.y + kH.y, b_floor);
+                v.z = fmaxf(v.z * kS.z + kH.z, b_floor);
+                v.w = fmaxf(v.w * kS.w + kH.w, b_floor);
+            }
+            if (BSRC == 1 || BSRC == 2) {
                 float4 g = r.g[h];
                 if (BSRC == 2) {
                     const unsigned gr = (unsigned)(r_begin + lr);
@@ -268,6 +280,7 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         if (!al(d.x) || (d.in_scale && (!al(d.in_scale) || !al(d.in_shift)))) return false;
         if (bsrc == 0) return launch<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
         if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
+        if (bsrc == 3) return launch<0, 3>(d, rows, cin, cout, dz, bs, dw, st);
         return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
     }
     if (d.c != cin || !al(d.feat) || bsrc != 0) return false;

@@ -1,0 +1,407 @@
+// pool_bwd.hip -- backward of the LAST layer of an SA chain (conv + BatchNorm + ReLU + max over the nsample rows of a group)
+// in "Gram form".  With x = the layer's input activation (rows x cin), z = x W + b, and the folded BatchNorm backward
+//     dz[r,c] = A[c] g'[r,c] + B[c] + C[c] z[r,c]
+// the pooled upstream gradient g' has ONE non-zero per (group, channel) -- the arg-max row -- while B + C z is dense only
+// because BatchNorm couples the rows.  Substituting z = x W + b turns the dense part into products with cin x cin matrices:
+//     da  = dz W^T   = x (W diag(C) W^T) + (B + C.b) W^T                    + scatter of A g' W^T rows
+//     dW  = x^T dz   = ((x^T x) W) . C  + (sum_r x)^T (B + C.b)             + gather of x rows by arg-max
+// The two big GEMMs of the layer shrink from (rows x cout x cin) to (rows x cin x cin) -- half the flops for VoteNet's
+// 128 -> 256 layers -- z of the layer is never read again (training does not store it any more), and x^T x depends on the
+// forward pass only, so it runs early on the weight-gradient stream.  The sparse parts touch cout values per group.
+#include "mlp_types.h"
+
+namespace votenet {
+
+bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
+                       hipStream_t st); // mlp_wgrad_fast.hip
+
+static inline int pb_grid(long total, int block, int cap)
+{
+    long g = (total + block - 1) / block;
+    if (g > cap) g = cap;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// sums = [sum g', sum g' zhat] of the pooled gradient: g' lives at the arg-max rows, whose raw z is zsel
+__global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, int c, const float *__restrict__ gout,
+                                                                 const float *__restrict__ zsel, const float *__restrict__ scale,
+                                                                 const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                 const float *__restrict__ var, float eps, int relu,
+                                                                 double *__restrict__ sums)
+{
+    __shared__ float sh1[4][64], sh2[4][64];
+    const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+    const int col = blockIdx.y * 64 + cx;
+    float s1 = 0, s2 = 0;
+    if (col < c) {
+        const float sc = scale[col], sf = shift[col], mu = mean[col], inv = 1.0f / sqrtf(var[col] + eps);
+        for (long g = (long)blockIdx.x * 4 + ry; g < groups; g += (long)gridDim.x * 4) {
+            const float zz = zsel[(size_t)g * c + col];
+            float gg = gout[(size_t)g * c + col];
+            if (relu && !(zz * sc + sf > 0.0f)) gg = 0.0f;
+            s1 += gg;
+            s2 += gg * ((zz - mu) * inv);
+        }
+    }
+    sh1[ry][cx] = s1;
+    sh2[ry][cx] = s2;
+    __syncthreads();
+    if (ry == 0 && col < c) {
+        const float t1 = (sh1[0][cx] + sh1[1][cx]) + (sh1[2][cx] + sh1[3][cx]);
+        const float t2 = (sh2[0][cx] + sh2[1][cx]) + (sh2[2][cx] + sh2[3][cx]);
+        unsafeAtomicAdd(&sums[col], (double)t1);
+        unsafeAtomicAdd(&sums[c + col], (double)t2);
+    }
+}
+
+// mmat (cin x cin) = W diag(C) W^T ; cvec (cin) = (B + C.b) W^T.  W is cin x cout row-major; coef = [A|B|C|S|H].
+__global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, int cout, const float *__restrict__ w,
+                                                                 const float *__restrict__ bias, const float *__restrict__ coef,
+                                                                 float *__restrict__ mmat, float *__restrict__ cvec)
+{
+    __shared__ float Wj[16][33], Wk[16][33], Cs[32], Ds[32];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+    float acc = 0.0f, accv = 0.0f;
+    for (int c0 = 0; c0 < cout; c0 += 32) {
+        for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+            const int r = e >> 5, cc = e & 31;
+            Wj[r][cc] = (j0 + r < cin && c0 + cc < cout) ? w[(size_t)(j0 + r) * cout + c0 + cc] : 0.0f;
+            Wk[r][cc] = (k0 + r < cin && c0 + cc < cout) ? w[(size_t)(k0 + r) * cout + c0 + cc] : 0.0f;
+        }
+        if (threadIdx.x < 32) {
+            const int cc = c0 + threadIdx.x;
+            const float Cc = cc < cout ? coef[2 * cout + cc] : 0.0f;
+            Cs[threadIdx.x] = Cc;
+            Ds[threadIdx.x] = cc < cout ? coef[cout + cc] + Cc * (bias ? bias[cc] : 0.0f) : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int cc = 0; cc < 32; cc++) {
+            acc += Wj[ty][cc] * Cs[cc] * Wk[tx][cc];
+            accv += Ds[cc] * Wk[tx][cc];
+        }
+        __syncthreads();
+    }
+    if (j0 + ty < cin && k0 + tx < cin) mmat[(size_t)(j0 + ty) * cin + k0 + tx] = acc;
+    if (blockIdx.y == 0 && ty == 0 && k0 + tx < cin) cvec[k0 + tx] = accv;
+}
+
+// da[g*k + argmax[g,c], :] += A[c] g'[g,c] W[:,c]^T.  One persistent workgroup per CU keeps W^T (cout x CIN) in LDS and walks
+// groups: the group's cout channels are bucketed by their arg-max row (counting sort in LDS), then every wavefront takes
+// rows, sums the W^T rows of the row's channels in registers and adds the result to the da row in one coalesced
+// read-modify-write -- no floating-point atomics, rows without an arg-max are not touched.
+template <int CIN, int COUT, int K>
+__global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, const float *__restrict__ gout,
+                                                                 const int *__restrict__ argmax, const float *__restrict__ zsel,
+                                                                 const float *__restrict__ coef, int relu, const float *__restrict__ wT,
+                                                                 float *__restrict__ da)
+{
+    static_assert(K == 64, "one lane per row in the prefix scan");
+    constexpr int PL = CIN / 64; // floats per lane of a row
+    constexpr int RW = K / 8;    // rows per wavefront
+    extern __shared__ __attribute__((aligned(16))) float pds_smem[];
+    float *Wl = pds_smem;                                    // [COUT][CIN]
+    float *sv = Wl + COUT * CIN;                              // [2][COUT]   (everything below is double-buffered by group parity)
+    int *lst = reinterpret_cast<int *>(sv + 2 * COUT);        // [2][COUT] channels ordered by row
+    int *cnt = lst + 2 * COUT;                                // [2][K]
+    int *start = cnt + 2 * K;                                 // [2][K]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int e = tid; e < COUT * CIN / 4; e += 512)
+        reinterpret_cast<float4 *>(Wl)[e] = reinterpret_cast<const float4 *>(wT)[e];
+    float cA = 0.f, cS = 0.f, cH = 0.f;
+    const bool own = tid < COUT;
+    if (own) {
+        cA = coef[tid];
+        cS = coef[3 * COUT + tid];
+        cH = coef[4 * COUT + tid];
+    }
+    if (tid < 2 * K) cnt[tid] = 0;
+    float n_z = 0.f, n_g = 0.f;
+    int n_a = 0;
+    auto fetch = [&](long g) {
+        if (own) {
+            n_z = zsel[(size_t)g * COUT + tid];
+            n_g = gout[(size_t)g * COUT + tid];
+            n_a = argmax[(size_t)g * COUT + tid];
+        }
+    };
+    if ((long)blockIdx.x < groups) fetch(blockIdx.x);
+    __syncthreads();
+    int par = 0;
+    for (long g = blockIdx.x; g < groups; g += gridDim.x, par ^= 1) {
+        float *svp = sv + par * COUT;
+        int *lstp = lst + par * COUT, *cntp = cnt + par * K, *startp = start + par * K;
+        const float zz = n_z;
+        float gg = n_g;
+        const int myrow = n_a;
+        // this wavefront's da rows travel while the channels are bucketed
+        float pre[RW][PL];
+#pragma unroll
+        for (int ri = 0; ri < RW; ri++)
+#pragma unroll
+            for (int q = 0; q < PL; q++) pre[ri][q] = da[((size_t)g * K + wv + 8 * ri) * CIN + lane * PL + q];
+        const long gn = g + gridDim.x;
+        if (gn < groups) fetch(gn);
+        int mypos = 0;
+        if (own) {
+            if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
+            svp[tid] = cA * gg;
+            mypos = atomicAdd(&cntp[myrow], 1);
+        }
+        __syncthreads();
+        if (wv == 0) { // exclusive prefix of the K counters: one lane per row
+            const int c0 = cntp[lane];
+            int x = c0;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const int t = __shfl_up(x, off);
+                if (lane >= off) x += t;
+            }
+            startp[lane] = x - c0;
+        } else if (wv == 1) {
+            cnt[(par ^ 1) * K + lane] = 0; // the other parity's counters: last read before this group's first barrier
+        }
+        __syncthreads();
+        if (own) lstp[startp[myrow] + mypos] = tid;
+        __syncthreads();
+#pragma unroll
+        for (int ri = 0; ri < RW; ri++) {
+            const int r = wv + 8 * ri;
+            const int n = cntp[r], s0 = startp[r];
+            if (n == 0) continue;
+            float acc[PL];
+#pragma unroll
+            for (int q = 0; q < PL; q++) acc[q] = pre[ri][q];
+            for (int i = 0; i < n; i += 4) {
+                int c[4];
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool ok = i + u < n;
+                    c[u] = lstp[s0 + (ok ? i + u : i)];
+                    v[u] = ok ? svp[c[u]] : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int q = 0; q < PL; q++) acc[q] += v[u] * Wl[c[u] * CIN + lane * PL + q];
+            }
+            float *drow = da + ((size_t)g * K + r) * CIN + lane * PL;
+#pragma unroll
+            for (int q = 0; q < PL; q++) drow[q] = acc[q];
+        }
+    }
+}
+
+// dW[:, c] += sum_g x[g*k + argmax[g,c], :] * A[c] g'[g,c]   and   colsum[j] += sum_r x[r, j]
+// x = act(xz * in_scale + in_shift) staged per group in LDS; thread c owns output column c (CIN accumulators).
+template <int CIN, int K>
+__global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int cout, const float *__restrict__ xz,
+                                                                const float *__restrict__ in_scale, const float *__restrict__ in_shift,
+                                                                int in_relu, const float *__restrict__ gout,
+                                                                const int *__restrict__ argmax, const float *__restrict__ zsel,
+                                                                const float *__restrict__ coef, int relu, float *__restrict__ dw,
+                                                                float *__restrict__ colsum)
+{
+    constexpr int LD = CIN + 4;
+    __shared__ __attribute__((aligned(16))) float xs[K][LD];
+    const int tid = threadIdx.x;
+    float acc[CIN];
+#pragma unroll
+    for (int i = 0; i < CIN; i++) acc[i] = 0.0f;
+    float csum = 0.0f;
+    const bool own = tid < cout;
+    const float cA = own ? coef[tid] : 0.0f, cS = own ? coef[3 * cout + tid] : 0.0f, cH = own ? coef[4 * cout + tid] : 0.0f;
+    constexpr int Q = CIN / 4;
+    const int q = tid % Q;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_scale) {
+        sc = *reinterpret_cast<const float4 *>(in_scale + q * 4);
+        sh = *reinterpret_cast<const float4 *>(in_shift + q * 4);
+    }
+    const float fl = (in_scale && in_relu) ? 0.0f : -__builtin_inff();
+    constexpr int NL = K * Q / 256; // float4 per thread per group tile
+    float4 nxt[NL];
+    auto fetch = [&](long g) {
+        const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)g * K * CIN);
+#pragma unroll
+        for (int h = 0; h < NL; h++) nxt[h] = src[tid + h * 256];
+    };
+    if ((long)blockIdx.x < groups) fetch(blockIdx.x);
+    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
+#pragma unroll
+        for (int h = 0; h < NL; h++) { // (tid + h*256) % Q == q: 256 % Q == 0
+            float4 v = nxt[h];
+            v.x = fmaxf(v.x * sc.x + sh.x, fl);
+            v.y = fmaxf(v.y * sc.y + sh.y, fl);
+            v.z = fmaxf(v.z * sc.z + sh.z, fl);
+            v.w = fmaxf(v.w * sc.w + sh.w, fl);
+            *reinterpret_cast<float4 *>(&xs[(tid + h * 256) / Q][q * 4]) = v;
+        }
+        const long gn = g + gridDim.x;
+        fetch(gn < groups ? gn : g); // the next tile travels while this one is used
+        float gg = 0.0f, zz = 0.0f;
+        int ar = 0;
+        if (own) {
+            zz = zsel[(size_t)g * cout + tid];
+            gg = gout[(size_t)g * cout + tid];
+            ar = argmax[(size_t)g * cout + tid];
+        }
+        __syncthreads();
+        if (own) {
+            if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
+            const float v = cA * gg;
+            if (v != 0.0f) {
+                const float4 *row = reinterpret_cast<const float4 *>(&xs[ar][0]);
+#pragma unroll
+                for (int i = 0; i < Q; i++) {
+                    const float4 a = row[i];
+                    acc[4 * i] += a.x * v;
+                    acc[4 * i + 1] += a.y * v;
+                    acc[4 * i + 2] += a.z * v;
+                    acc[4 * i + 3] += a.w * v;
+                }
+            }
+        }
+        if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
+            const int jc = tid - (256 - CIN);
+#pragma unroll 8
+            for (int r = 0; r < K; r++) csum += xs[r][jc];
+        }
+        __syncthreads();
+    }
+    if (own) {
+#pragma unroll
+        for (int i = 0; i < CIN; i++) unsafeAtomicAdd(&dw[(size_t)i * cout + tid], acc[i]);
+    }
+    if (tid >= 256 - CIN) unsafeAtomicAdd(&colsum[tid - (256 - CIN)], csum);
+}
+
+// dW[j,c] += C[c] * (gram[j,:] . W[:,c]) + colsum[j] * (B[c] + C[c] b[c])
+__global__ __launch_bounds__(256) void pool_wgrad_finish_kernel(int cin, int cout, const float *__restrict__ gram,
+                                                                const float *__restrict__ colsum, const float *__restrict__ w,
+                                                                const float *__restrict__ bias, const float *__restrict__ coef,
+                                                                float *__restrict__ dw)
+{
+    __shared__ float Gs[16][33], Ws[32][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int j0 = blockIdx.y * 16, c0 = blockIdx.x * 16;
+    float acc = 0.0f;
+    for (int i0 = 0; i0 < cin; i0 += 32) {
+        for (int e = threadIdx.x; e < 16 * 32; e += 256) {
+            const int r = e >> 5, ii = e & 31;
+            Gs[r][ii] = (j0 + r < cin && i0 + ii < cin) ? gram[(size_t)(j0 + r) * cin + i0 + ii] : 0.0f;
+            const int wr = e >> 4, wc = e & 15;
+            Ws[wr][wc] = (i0 + wr < cin && c0 + wc < cout) ? w[(size_t)(i0 + wr) * cout + c0 + wc] : 0.0f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int ii = 0; ii < 32; ii++) acc += Gs[ty][ii] * Ws[ii][tx];
+        __syncthreads();
+    }
+    const int j = j0 + ty, c = c0 + tx;
+    if (j < cin && c < cout) {
+        const float Cc = coef[2 * cout + c];
+        dw[(size_t)j * cout + c] += Cc * acc + colsum[j] * (coef[cout + c] + Cc * (bias ? bias[c] : 0.0f));
+    }
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_pool_backward_supported(int cin, int cout, int k)
+{
+    return k == 64 && ((cin == 128 && (cout == 256 || cout == 128)) || (cin == 64 && cout == 128));
+}
+
+extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const float *zsel, const float *scale,
+                                               const float *shift, const float *mean, const float *var, float eps, int relu,
+                                               double *sums, void *stream)
+{
+    VN_REQUIRE(groups > 0 && c > 0, "bn_backward_reduce_pool expects groups > 0, c > 0");
+    VN_REQUIRE(gout && zsel && scale && shift && mean && var && sums, "bn_backward_reduce_pool: null buffer");
+    const int ny = (c + 63) / 64;
+    hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, as_stream(stream), groups,
+                       c, gout, zsel, scale, shift, mean, var, eps, relu, sums);
+    return check_launch("bn_backward_reduce_pool");
+}
+
+extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                                          float *cvec, void *stream)
+{
+    VN_REQUIRE(cin > 0 && cout > 0 && w && coef && mmat && cvec, "pool_dgrad_prepare: bad arguments");
+    hipLaunchKernelGGL(pool_dgrad_prepare_kernel, dim3((cin + 15) / 16, (cin + 15) / 16), dim3(256), 0, as_stream(stream), cin, cout, w,
+                       bias, coef, mmat, cvec);
+    return check_launch("pool_dgrad_prepare");
+}
+
+extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
+                                          const float *zsel, const float *coef, int relu, const float *wT, float *da, void *stream)
+{
+    VN_REQUIRE(groups > 0 && gout && argmax && zsel && coef && wT && da, "pool_dgrad_scatter: bad arguments");
+    VN_REQUIRE(votenet_pool_backward_supported(cin, cout, k), "pool_dgrad_scatter: unsupported shape cin=%d cout=%d k=%d", cin, cout, k);
+    VN_REQUIRE((uintptr_t)wT % 16 == 0, "pool_dgrad_scatter: wT must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    auto go = [&](auto kern, int ci, int co) {
+        const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
+        const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(512), smem, st, groups, gout, argmax, zsel, coef, relu,
+                           wT, da);
+    };
+    if (cin == 128 && cout == 256)
+        go(pool_dgrad_scatter_kernel<128, 256, 64>, 128, 256);
+    else if (cin == 128)
+        go(pool_dgrad_scatter_kernel<128, 128, 64>, 128, 128);
+    else
+        go(pool_dgrad_scatter_kernel<64, 128, 64>, 64, 128);
+    return check_launch("pool_dgrad_scatter");
+}
+
+extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && z && scale_shift && gram, "mlp_gram: bad arguments");
+    MlpIn d = {};
+    d.x = z;
+    d.in_scale = scale_shift;
+    d.in_shift = scale_shift + c;
+    d.in_relu = relu;
+    BnSrc bs = {};
+    bs.z = z;
+    bs.coef = scale_shift;
+    bs.relu = relu;
+    VN_REQUIRE(wgrad_fast_launch(0, d, rows, c, c, nullptr, bs, 3, gram, as_stream(stream)),
+               "mlp_gram: shape not served (c %% 64 == 0, 16-byte aligned operands), got c = %d", c);
+    return check_launch("mlp_gram");
+}
+
+extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
+                                         const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
+                                         const float *coef, int relu, float *dw, float *colsum, void *stream)
+{
+    VN_REQUIRE(groups > 0 && xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse: bad arguments");
+    VN_REQUIRE(votenet_pool_backward_supported(cin, cout, k), "pool_wgrad_sparse: unsupported shape cin=%d cout=%d k=%d", cin, cout, k);
+    VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse: in_scale and in_shift go together");
+    VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
+               "pool_wgrad_sparse: operands must be 16-byte aligned");
+    const int grid = pb_grid(groups, 8, 768);
+    hipStream_t st = as_stream(stream);
+    if (cin == 128)
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum);
+    else
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum);
+    return check_launch("pool_wgrad_sparse");
+}
+
+extern "C" int votenet_pool_wgrad_finish(int cin, int cout, const float *gram, const float *colsum, const float *w, const float *bias,
+                                         const float *coef, float *dw, void *stream)
+{
+    VN_REQUIRE(cin > 0 && cout > 0 && gram && colsum && w && coef && dw, "pool_wgrad_finish: bad arguments");
+    hipLaunchKernelGGL(pool_wgrad_finish_kernel, dim3((cout + 15) / 16, (cin + 15) / 16), dim3(256), 0, as_stream(stream), cin, cout,
+                       gram, colsum, w, bias, coef, dw);
+    return check_launch("pool_wgrad_finish");
+}

@@ -191,8 +191,8 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
     return z, stats, (vals[0], vals[1], args[0], args[1])
 
 
-def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None):
-    """bn: a PendingBN instead of scale / shift (the kernel finalizes it)."""
+def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, want_zsel=False):
+    """bn: a PendingBN instead of scale / shift (the kernel finalizes it).  -> out, argmax [, zsel = raw z at the arg-max]."""
     zmax, zmin, amax, amin = pool
     raw = None
     if bn is not None:
@@ -203,11 +203,62 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None):
     g, c = zmax.shape
     out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
     arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
+    zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None
     with torch.cuda.device(zmax.device):
         L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
                                                  ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),
-                                                 L.ptr(arg), L.stream_ptr()))
-    return out, arg
+                                                 L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
+    return (out, arg, zsel) if want_zsel else (out, arg)
+
+
+# ---- backward of a pooled last layer in Gram form (pool_bwd.hip; see include/votenet_hip.h)
+def pool_backward_supported(cin, cout, k):
+    return bool(L.lib().votenet_pool_backward_supported(cin, cout, k))
+
+
+def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EPS):
+    g, c = gout.shape
+    sums = _zeros_f64(2 * c, gout.device)
+    with torch.cuda.device(gout.device):
+        L.check(L.lib().votenet_bn_backward_reduce_pool(g, c, L.ptr(gout), L.ptr(zsel), L.ptr(scale), L.ptr(shift), L.ptr(mean),
+                                                        L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums), L.stream_ptr()))
+    return sums
+
+
+def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k):
+    """da (rows, cin) of the pooled layer: x (W diag(C) W^T) + (B + C.b) W^T as ONE forward-type GEMM on the layer's input,
+    then the cout scattered rows per group."""
+    rows, cin = xz.shape
+    cout = w.shape[1]
+    mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=xz.device)  # [mmat ; cvec]
+    with torch.cuda.device(xz.device):
+        L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
+    da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
+    with torch.cuda.device(xz.device):
+        L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
+                                                   1 if relu else 0, L.ptr(wT), L.ptr(da), L.stream_ptr()))
+    return da
+
+
+def gram(xz, scale_shift, relu):
+    """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c)."""
+    rows, c = xz.shape
+    g = torch.zeros((c + 1, c), dtype=torch.float32, device=xz.device)  # [gram ; column sums (filled by pool_wgrad)]
+    with torch.cuda.device(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c):
+        L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.stream_ptr()))
+    return g
+
+
+def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, gout, argmax, zsel, k, dw):
+    """dw += x^T dz of the pooled layer from the Gram matrix (gram()), the gathered arg-max rows and the column sums."""
+    rows, cin = xz.shape
+    cout = w.shape[1]
+    with torch.cuda.device(xz.device):
+        L.check(L.lib().votenet_pool_wgrad_sparse(rows // k, k, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0,
+                                                  L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
+                                                  L.ptr(gram_buf[cin]), L.stream_ptr()))
+        L.check(L.lib().votenet_pool_wgrad_finish(cin, cout, L.ptr(gram_buf), L.ptr(gram_buf[cin]), L.ptr(w), L.ptr(bias), L.ptr(coef),
+                                                  L.ptr(dw), L.stream_ptr()))
 
 
 def group_linear(xyz, new_xyz, idx, P, w_xyz, bias=None, want_stats=True):

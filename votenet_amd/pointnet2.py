@@ -160,6 +160,9 @@ PRE_LINEAR = True
 # Max-pool over the nsample rows of a group started in the last GEMM's epilogue (votenet_mlp_linear_pool) instead of a
 # separate pass over z (votenet_bn_relu_max).
 POOL_IN_EPILOGUE = True
+# Backward of that pooled layer in Gram form (pool_bwd.hip): both GEMMs contract over cin x cin instead of cin x cout and z
+# of the layer is neither stored nor read.  False = votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn on the stored z.
+POOL_GRAM_BACKWARD = True
 
 
 def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
@@ -197,8 +200,11 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             rec = dict(layer=L, kind="dense", x=first[1], in_scale=None, in_shift=None, in_relu=False)
         elif pool_k and i == len(layers) - 1 and L.bn and POOL_IN_EPILOGUE and \
                 M.linear_pool_supported(rows, w.shape[0], w.shape[1], pool_k):
-            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z, in_bn=pend)
-            rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
+            # training does not store z of this layer either when its backward runs in Gram form (it never reads z)
+            gram_form = POOL_GRAM_BACKWARD and pend is not None and M.pool_backward_supported(w.shape[0], w.shape[1], pool_k)
+            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend)
+            rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, gram_form=gram_form,
+                       in_affine=pend.out if pend is not None else None, cout=w.shape[1])
         else:
             zn, st = M.linear_dense(z, w, b, None, None, prev_relu, want_stats=L.bn, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
@@ -256,7 +262,7 @@ def wgrad_join():
         _wgrad_pending = False
 
 
-def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
+def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zsel=None):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
@@ -270,9 +276,23 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True):
         r = recs[i]
         L = r["layer"]
         z = r["z"]
-        rows, c = z.shape
         pooled = (mode == "pool" and i == len(recs) - 1)
         want_da = i > 0 or need_input_grad
+        if pooled and r.get("gram_form") and zsel is not None:
+            # Gram form (pool_bwd.hip): x^T x early on the weight-gradient stream, the rest once the coefficients exist
+            x, aff, W, b = r["x"], r["in_affine"], L.p("W"), L.p("b")
+            with _OnWgradStream(x, aff):
+                G = M.gram(x, aff[:2], r["in_relu"])
+            bn = (r["scale"], r["shift"], r["mean"], r["var"])
+            sums = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu)
+            coef = M.bn_backward_coef(r["rows"], *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
+            with _OnWgradStream(x, aff, coef, da, argmax, zsel, G):
+                M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
+            if not want_da:
+                return None
+            da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k)
+            continue
+        rows, c = z.shape
         if L.bn:
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
             sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
@@ -351,8 +371,11 @@ class SAModule:
         z, pend = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs, pool_k=self.nsample,
                                     keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
-            pooled, argmax = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend)
+            res = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend,
+                                     want_zsel=tape is not None and bool(recs[-1].get("gram_form")))
+            pooled, argmax, zsel = res if len(res) == 3 else (res[0], res[1], None)
         else:
+            zsel = None
             sc, sh = pend.finalize()
             pooled, argmax = M.bn_relu_max(z, self.nsample, sc, sh, True, want_argmax=tape is not None)
         recs2 = []
@@ -361,7 +384,7 @@ class SAModule:
             z2, _ = mlp_chain_forward(self.mlp2, b * self.npoint, ("dense", pooled), recs2)
             out = z2  # last conv_post layer has no activation (utils.py:153)
         if tape is not None:
-            tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, fps_idx=fps_idx, idx=idx, pts_cnt=pts_cnt,
+            tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, zsel=zsel, fps_idx=fps_idx, idx=idx, pts_cnt=pts_cnt,
                              xyz=xyz, points=points, new_xyz=new_xyz, b=b))
         return new_xyz, out.view(b, self.npoint, -1), idx
 
@@ -373,7 +396,8 @@ class SAModule:
         if self.mlp2:
             g = mlp_chain_backward(rec["recs2"], g, "plain", need_input_grad=True)
         need_feat = need_feat_grad and rec["points"] is not None
-        h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_feat)
+        h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_feat,
+                               zsel=rec.get("zsel"))
         return self._first_layer_backward(rec, h, need_feat, need_xyz_grad)
 
     def _first_layer_backward(self, rec, h, need_feat, need_xyz_grad):
