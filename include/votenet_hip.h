@@ -246,9 +246,14 @@ int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const
 /* mmat (cin x cin) = W diag(C) W^T, cvec (cin) = (B + C.b) W^T; w (cin x cout), bias may be NULL */
 int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                float *cvec, void *stream);
-/* da (groups*k x cin) += the scattered rows; wT = W^T (cout x cin) */
+/* da (groups*k x cin) += the scattered rows; wT = W^T (cout x cin).  With below_z != NULL (the raw output, rows x cin, of
+ * the layer BELOW, whose output gradient da is) the same pass also performs that layer's votenet_bn_backward_reduce:
+ * below_sums (2*cin doubles, pre-zeroed) += [sum g', sum g' zhat] with g' = the final da masked by the layer's ReLU. */
 int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
-                               const float *zsel, const float *coef, int relu, const float *wT, float *da, void *stream);
+                               const float *zsel, const float *coef, int relu, const float *wT, float *da,
+                               const float *below_z, const float *below_scale, const float *below_shift,
+                               const float *below_mean, const float *below_var, float eps, int below_relu,
+                               double *below_sums, void *stream);
 /* gram (c x c, pre-zeroed or accumulating) += a^T a with a = act(z * scale + shift); scale_shift = [scale | shift] (2c) */
 int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, void *stream);
 /* dw (cin x cout) += the gathered rows; colsum (cin, pre-zeroed) += sum_r x[r,:]; xz / in_scale / in_shift / in_relu

@@ -285,6 +285,12 @@ def test_pooled_layer_gram_form_equals_the_direct_form(hiplib, dev, groups, cin,
     da = M.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k)
     assert relerr(da.double(), da_ref.double()) < 2e-5
     assert relerr(dw.double(), dw_ref.double()) < 2e-5
+    # the scatter pass can also reduce the BatchNorm backward of the layer below (whose raw output xz is)
+    bmean, bvar = torch.randn(cin, generator=g).to(dev) * 0.1, (torch.rand(cin, generator=g) + 0.5).to(dev)
+    da2, bsums = M.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k, below=(aff[0], aff[1], bmean, bvar, True))
+    assert torch.equal(da2, da)
+    bref = M.bn_backward_reduce(xz, aff[0], aff[1], bmean, bvar, True, da)
+    assert torch.allclose(bsums, bref, rtol=2e-5, atol=1e-3 * float(bref.abs().max()))
     assert M.pool_backward_supported(cin, cout, 64) and not M.pool_backward_supported(cin, cout, 32)
     assert not M.pool_backward_supported(256, 256, 64)
 

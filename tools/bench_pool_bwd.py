@@ -25,7 +25,7 @@ for name, groups, cin, cout in (("sa2", 8192, 128, 256), ("sa3", 4096, 128, 256)
     t["direct wgrad"] = timeit(lambda: M.wgrad_dense_bn(xz, z, coef, True, dw, gout=gout, argmax=arg, k=k, in_scale=aff[0], in_shift=aff[1], in_relu=True), it=20)
     t["prepare"] = timeit(lambda: lib.votenet_pool_dgrad_prepare(cin, cout, P(w), P(b), P(coef), P(mm), P(mm[cin]), S()), it=20)
     t["dense dgrad"] = timeit(lambda: M.linear_dense(xz, mm[:cin], mm[cin], aff[0], aff[1], True, want_stats=False), it=20)
-    t["scatter"] = timeit(lambda: lib.votenet_pool_dgrad_scatter(groups, k, cin, cout, P(gout), P(arg), P(zsel), P(coef), 1, P(wT), P(da), S()), it=20)
+    t["scatter"] = timeit(lambda: lib.votenet_pool_dgrad_scatter(groups, k, cin, cout, P(gout), P(arg), P(zsel), P(coef), 1, P(wT), P(da), None, None, None, None, None, 1e-5, 0, None, S()), it=20)
     t["gram"] = timeit(lambda: M.gram(xz, aff, True), it=20)
     t["sparse wgrad + finish"] = timeit(lambda: M.pool_wgrad(xz, aff[0], aff[1], True, G, w, b, coef, True, gout, arg, zsel, k, dw), it=20)
     print(name, "  ".join("%s %.3f" % kv for kv in t.items()))

@@ -91,11 +91,21 @@ __global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, int co
 // groups: the group's cout channels are bucketed by their arg-max row (counting sort in LDS), then every wavefront takes
 // rows, sums the W^T rows of the row's channels in registers and adds the result to the da row in one coalesced
 // read-modify-write -- no floating-point atomics, rows without an arg-max are not touched.
-template <int CIN, int COUT, int K>
+// RED: the same pass also reduces the BatchNorm backward of the layer BELOW (whose output gradient da is): with pz = that
+// layer's raw output, sums += [sum g', sum g' zhat], g' = da masked by its ReLU -- the separate votenet_bn_backward_reduce
+// pass over (da, z) disappears.
+struct PoolBelow {
+    const float *z, *scale, *shift, *mean, *var;
+    float eps;
+    int relu;
+    double *sums;
+};
+
+template <int CIN, int COUT, int K, bool RED>
 __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, const float *__restrict__ gout,
                                                                  const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                  const float *__restrict__ coef, int relu, const float *__restrict__ wT,
-                                                                 float *__restrict__ da)
+                                                                 float *__restrict__ da, PoolBelow pb)
 {
     static_assert(K == 64, "one lane per row in the prefix scan");
     constexpr int PL = CIN / 64; // floats per lane of a row
@@ -117,6 +127,18 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
         cH = coef[4 * COUT + tid];
     }
     if (tid < 2 * K) cnt[tid] = 0;
+    float bS[PL], bH[PL], bM[PL], bI[PL], s1[PL], s2[PL];
+#pragma unroll
+    for (int q = 0; q < PL; q++) {
+        s1[q] = s2[q] = 0.0f;
+        if (RED) {
+            const int j = lane * PL + q;
+            bS[q] = pb.scale[j];
+            bH[q] = pb.shift[j];
+            bM[q] = pb.mean[j];
+            bI[q] = 1.0f / sqrtf(pb.var[j] + pb.eps);
+        }
+    }
     float n_z = 0.f, n_g = 0.f;
     int n_a = 0;
     auto fetch = [&](long g) {
@@ -136,20 +158,29 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
         float gg = n_g;
         const int myrow = n_a;
         // this wavefront's da rows travel while the channels are bucketed
-        float pre[RW][PL];
+        float pre[RW][PL], zpre[RW][PL];
 #pragma unroll
         for (int ri = 0; ri < RW; ri++)
 #pragma unroll
-            for (int q = 0; q < PL; q++) pre[ri][q] = da[((size_t)g * K + wv + 8 * ri) * CIN + lane * PL + q];
+            for (int q = 0; q < PL; q++) {
+                const size_t off = ((size_t)g * K + wv + 8 * ri) * CIN + lane * PL + q;
+                pre[ri][q] = da[off];
+                if (RED) zpre[ri][q] = pb.z[off];
+            }
         const long gn = g + gridDim.x;
         if (gn < groups) fetch(gn);
         int mypos = 0;
         if (own) {
             if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
             svp[tid] = cA * gg;
-            mypos = atomicAdd(&cntp[myrow], 1);
         }
-        __syncthreads();
+        // slots are claimed wavefront by wavefront (lanes of one ds_add_rtn are served in lane order), so a row's channels sit in
+        // ascending order and the floating-point sum below has ONE order: da is reproducible bit for bit
+#pragma unroll
+        for (int w2 = 0; w2 < COUT / 64; w2++) {
+            if (wv == w2) mypos = atomicAdd(&cntp[myrow], 1);
+            __syncthreads();
+        }
         if (wv == 0) { // exclusive prefix of the K counters: one lane per row
             const int c0 = cntp[lane];
             int x = c0;
@@ -169,7 +200,7 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
         for (int ri = 0; ri < RW; ri++) {
             const int r = wv + 8 * ri;
             const int n = cntp[r], s0 = startp[r];
-            if (n == 0) continue;
+            if (!RED && n == 0) continue;
             float acc[PL];
 #pragma unroll
             for (int q = 0; q < PL; q++) acc[q] = pre[ri][q];
@@ -187,9 +218,36 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
 #pragma unroll
                     for (int q = 0; q < PL; q++) acc[q] += v[u] * Wl[c[u] * CIN + lane * PL + q];
             }
-            float *drow = da + ((size_t)g * K + r) * CIN + lane * PL;
+            if (n != 0) {
+                float *drow = da + ((size_t)g * K + r) * CIN + lane * PL;
 #pragma unroll
-            for (int q = 0; q < PL; q++) drow[q] = acc[q];
+                for (int q = 0; q < PL; q++) drow[q] = acc[q];
+            }
+            if (RED) {
+#pragma unroll
+                for (int q = 0; q < PL; q++) {
+                    const float zz2 = zpre[ri][q];
+                    const float gp = (pb.relu && !(zz2 * bS[q] + bH[q] > 0.0f)) ? 0.0f : acc[q];
+                    s1[q] += gp;
+                    s2[q] += gp * ((zz2 - bM[q]) * bI[q]);
+                }
+            }
+        }
+    }
+    if (RED) { // combine the 8 wavefronts' column sums in LDS (W^T is no longer needed), one fp64 atomic per column and workgroup
+        __syncthreads();
+        float *red = Wl; // [8][2][CIN]
+#pragma unroll
+        for (int q = 0; q < PL; q++) {
+            red[(wv * 2 + 0) * CIN + lane * PL + q] = s1[q];
+            red[(wv * 2 + 1) * CIN + lane * PL + q] = s2[q];
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * CIN; e += 512) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < 8; w8++) t += red[w8 * 2 * CIN + e];
+            unsafeAtomicAdd(&pb.sums[e], (double)t);
         }
     }
 }
@@ -338,25 +396,40 @@ extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, con
 }
 
 extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
-                                          const float *zsel, const float *coef, int relu, const float *wT, float *da, void *stream)
+                                          const float *zsel, const float *coef, int relu, const float *wT, float *da,
+                                          const float *below_z, const float *below_scale, const float *below_shift,
+                                          const float *below_mean, const float *below_var, float eps, int below_relu,
+                                          double *below_sums, void *stream)
 {
     VN_REQUIRE(groups > 0 && gout && argmax && zsel && coef && wT && da, "pool_dgrad_scatter: bad arguments");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, k), "pool_dgrad_scatter: unsupported shape cin=%d cout=%d k=%d", cin, cout, k);
     VN_REQUIRE((uintptr_t)wT % 16 == 0, "pool_dgrad_scatter: wT must be 16-byte aligned");
+    VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
+               "pool_dgrad_scatter: below_z given without the layer's BatchNorm vectors / sums");
     hipStream_t st = as_stream(stream);
+    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums};
     auto go = [&](auto kern, int ci, int co) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(512), smem, st, groups, gout, argmax, zsel, coef, relu,
-                           wT, da);
+                           wT, da, pb);
     };
-    if (cin == 128 && cout == 256)
-        go(pool_dgrad_scatter_kernel<128, 256, 64>, 128, 256);
-    else if (cin == 128)
-        go(pool_dgrad_scatter_kernel<128, 128, 64>, 128, 128);
-    else
-        go(pool_dgrad_scatter_kernel<64, 128, 64>, 64, 128);
+    if (below_z) {
+        if (cin == 128 && cout == 256)
+            go(pool_dgrad_scatter_kernel<128, 256, 64, true>, 128, 256);
+        else if (cin == 128)
+            go(pool_dgrad_scatter_kernel<128, 128, 64, true>, 128, 128);
+        else
+            go(pool_dgrad_scatter_kernel<64, 128, 64, true>, 64, 128);
+    } else {
+        if (cin == 128 && cout == 256)
+            go(pool_dgrad_scatter_kernel<128, 256, 64, false>, 128, 256);
+        else if (cin == 128)
+            go(pool_dgrad_scatter_kernel<128, 128, 64, false>, 128, 128);
+        else
+            go(pool_dgrad_scatter_kernel<64, 128, 64, false>, 64, 128);
+    }
     return check_launch("pool_dgrad_scatter");
 }
 

@@ -225,19 +225,24 @@ def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EP
     return sums
 
 
-def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k):
+def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS):
     """da (rows, cin) of the pooled layer: x (W diag(C) W^T) + (B + C.b) W^T as ONE forward-type GEMM on the layer's input,
-    then the cout scattered rows per group."""
+    then the cout scattered rows per group.  below = (scale, shift, mean, var, relu) of the layer that produced xz: the
+    scatter pass then also reduces that layer's BatchNorm backward -> returns (da, sums)."""
     rows, cin = xz.shape
     cout = w.shape[1]
     mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=xz.device)  # [mmat ; cvec]
     with torch.cuda.device(xz.device):
         L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
     da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
+    sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
+    bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)
     with torch.cuda.device(xz.device):
         L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
-                                                   1 if relu else 0, L.ptr(wT), L.ptr(da), L.stream_ptr()))
-    return da
+                                                   1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(xz if below is not None else None),
+                                                   L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), float(eps), 1 if brelu else 0,
+                                                   L.ptr(sums), L.stream_ptr()))
+    return (da, sums) if below is not None else da
 
 
 def gram(xz, scale_shift, relu):

@@ -272,6 +272,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
     dict(dz=...) (rows, cout) or dict(da=, coef=, relu=) when the fused first-layer backward kernel will form dz itself:
     SAModule.backward finishes the layer (weight gradient, point gradients)."""
     da = g
+    sums_ahead = None  # BatchNorm-backward sums of layer i already reduced by the layer above (pool_dgrad's scatter pass)
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
         L = r["layer"]
@@ -290,12 +291,21 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
             if not want_da:
                 return None
-            da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k)
+            below = recs[i - 1]
+            if below["layer"].bn and below["z"] is x:
+                da, sums_ahead = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax,
+                                              zsel, k, below=(below["scale"], below["shift"], below["mean"], below["var"],
+                                                              below["layer"].relu))
+            else:
+                da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k)
             continue
         rows, c = z.shape
         if L.bn:
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
-            sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
+            if sums_ahead is not None:
+                sums, sums_ahead = sums_ahead, None
+            else:
+                sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
             coef = M.bn_backward_coef(rows, *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
