@@ -225,15 +225,24 @@ def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EP
     return sums
 
 
-def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS):
+def pool_dgrad_prepare(w, bias, coef):
+    """-> (cin + 1, cin): [W diag(C) W^T ; (B + C.b) W^T], the weights / bias of the dense part of pool_dgrad."""
+    cin, cout = w.shape
+    mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
+    return mm
+
+
+def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS, mm=None):
     """da (rows, cin) of the pooled layer: x (W diag(C) W^T) + (B + C.b) W^T as ONE forward-type GEMM on the layer's input,
     then the cout scattered rows per group.  below = (scale, shift, mean, var, relu) of the layer that produced xz: the
-    scatter pass then also reduces that layer's BatchNorm backward -> returns (da, sums)."""
+    scatter pass then also reduces that layer's BatchNorm backward -> returns (da, sums).  mm: pool_dgrad_prepare's result
+    when it was launched ahead."""
     rows, cin = xz.shape
     cout = w.shape[1]
-    mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=xz.device)  # [mmat ; cvec]
-    with torch.cuda.device(xz.device):
-        L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
+    if mm is None:
+        mm = pool_dgrad_prepare(w, bias, coef)
     da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
     sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
     bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)

@@ -280,14 +280,15 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
         pooled = (mode == "pool" and i == len(recs) - 1)
         want_da = i > 0 or need_input_grad
         if pooled and r.get("gram_form") and zsel is not None:
-            # Gram form (pool_bwd.hip): x^T x early on the weight-gradient stream, the rest once the coefficients exist
+            # Gram form (pool_bwd.hip).  The short dependent chain reduce -> coef -> prepare goes first, alone on the GPU; the
+            # weight-gradient stream (x^T x, arg-max rows, finish) starts beside the dense GEMM that follows it
             x, aff, W, b = r["x"], r["in_affine"], L.p("W"), L.p("b")
-            with _OnWgradStream(x, aff):
-                G = M.gram(x, aff[:2], r["in_relu"])
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
             sums = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu)
             coef = M.bn_backward_coef(r["rows"], *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
-            with _OnWgradStream(x, aff, coef, da, argmax, zsel, G):
+            mm = M.pool_dgrad_prepare(W, b, coef) if want_da else None
+            with _OnWgradStream(x, aff, coef, da, argmax, zsel):
+                G = M.gram(x, aff[:2], r["in_relu"])
                 M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
             if not want_da:
                 return None
@@ -295,9 +296,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             if below["layer"].bn and below["z"] is x:
                 da, sums_ahead = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax,
                                               zsel, k, below=(below["scale"], below["shift"], below["mean"], below["var"],
-                                                              below["layer"].relu))
+                                                              below["layer"].relu), mm=mm)
             else:
-                da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k)
+                da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k, mm=mm)
             continue
         rows, c = z.shape
         if L.bn:
