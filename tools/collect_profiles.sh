@@ -15,7 +15,7 @@ rocprofv3 --pmc WRITE_SIZE -d $O/mlp_write -o p -- python3 $R/tools/pmc_mlp.py >
 cd $R
 for d in train fwd; do python tools/rocpd_stats.py $(ls $O/$d/*.db | head -1) 60 > $O/${d}_kernel_stats.txt; done
 for d in fps_fetch fps_write mlp_sq mlp_fetch mlp_write; do python tools/rocpd_pmc.py $(ls $O/$d/*.db | head -1) > $O/${d}.txt 2>&1; done
-python bench.py --steps 20 --warmup 3 > $O/train_bench_line.json 2> $O/train_bench.err
-python bench.py --workload fwd --steps 20 --warmup 3 > $O/fwd_bench_line.json 2> $O/fwd_bench.err
+python bench.py > $O/train_bench_line.json 2> $O/train_bench.err
+python bench.py --workload fwd > $O/fwd_bench_line.json 2> $O/fwd_bench.err
 rm -rf $O/*/*.db   # keep the merge small: the summaries are what is judged
 tail -c 600 $O/train_bench_line.json
