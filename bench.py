@@ -143,13 +143,14 @@ def main():
         dp.broadcast_params(net.store)
     pipeline = not args.no_pipeline
     counter = [0]
+    pipe_on = [pipeline]
 
     def step():
         i = counter[0]
         counter[0] += 1
         nb = len(xs)
         x = xs[i % nb]
-        nxt = ([xs[(i + 1) % nb]] + ([xs[(i + 2) % nb]] if workload == "fwd" else [])) if pipeline else None
+        nxt = ([xs[(i + 1) % nb]] + ([xs[(i + 2) % nb]] if workload == "fwd" else [])) if pipe_on[0] else None
         if workload == "train":
             net.train_step(x, cot, world, gt=gts[i % nb], next_x=nxt)
         else:
@@ -196,6 +197,34 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # the same step with every batch's geometry computed inside its own step (nothing carried across steps): reported beside
+    # the headline value, not instead of it
+    in_step = None
+    if pipeline:
+        pipe_on[0] = False
+        k2 = max(2, min(args.steps, 20))
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(k2):
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt2 = time.perf_counter() - t1
+        if world > 1:
+            t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt2 = float(t.item())
+        in_step = {"value": round(B * world * k2 / dt2, 2), "ms_per_step": round(dt2 / k2 * 1e3, 3), "steps": k2,
+                   "what": "same workload, no geometry prefetch: FPS / ball query / three_nn of a batch inside its own step"}
+        pipe_on[0] = True
 
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None
@@ -285,6 +314,7 @@ def main():
                                     + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
                                        "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
+            "without_cross_step_pipelining": in_step,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)
