@@ -419,6 +419,14 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
     if (!aligned || a.cin % (2 * FG_BK) != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
     const long ntiles = a.rows / FG_BM;
     long gx;
+    // few row tiles (FP layers, voting, mlp2): 128 x 64 tiles double the number of workgroups
+    if (EPI != 2 && a.cout % 128 == 0 && ntiles * (a.cout / 128) < 200) {
+        const int ny = a.cout / 64;
+        gx = ntiles;
+        if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        return true;
+    }
     if (a.cout % 128 == 0) {
         const int ny = a.cout / 128;
         gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
