@@ -55,6 +55,9 @@ const char *votenet_version(void);
  * Bit-exact with the reference rule: start at 0, running distance 1e38, arg-max of
  * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
 int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
+/* Experiment hook (not part of the drop-in surface): route 4096 < n <= 24576 through the kernel that emits up to two samples
+ * per round (same indices, same order).  Off by default: measured slower than the one-sample rounds. */
+void votenet_fps_debug_two_pick(int on);
 size_t votenet_fps_temp_floats(int b, int n);
 
 /* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:172-181,206-208).

@@ -61,6 +61,24 @@ def test_fps_exact_ties_vs_oracle(ops, dev, O):
         assert (got == O.farthest_point_sample(m, xyz)).all(), (n, m)
 
 
+def test_fps_two_samples_per_round_experiment_is_the_same_sequence(ops, dev, O, hiplib):
+    """fps_bucket2_kernel (votenet_fps_debug_two_pick): up to two picks per round when the runner-up is provably the next
+    arg-max.  Off by default (slower); the indices must be the oracle's, duplicates and exact ties included."""
+    from votenet_amd import synth
+    hiplib.votenet_fps_debug_two_pick.restype = None
+    hiplib.votenet_fps_debug_two_pick(1)
+    try:
+        rng = np.random.default_rng(11)
+        cases = [rng.random((2, 20480, 3), dtype=np.float32) * 5, synth.room_batch(2, 20480, 77),
+                 np.round(rng.random((1, 9000, 3), dtype=np.float32) * 6) / 2,                       # lattice: ties, duplicates
+                 np.repeat(rng.random((1, 50, 3), dtype=np.float32), 100, axis=1)]                   # 50 distinct points only
+        for xyz, m in zip(cases, (700, 2048, 400, 120)):
+            got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
+            assert (got == O.farthest_point_sample(m, xyz)).all()
+    finally:
+        hiplib.votenet_fps_debug_two_pick(0)
+
+
 def test_fps_full_size_properties(ops, dev):
     """BASELINE config 2 size (8 x 20480 -> 2048): size-independent properties, checked on the device."""
     xyz = T(np.random.default_rng(0).random((8, 20480, 3), dtype=np.float32) * 5, dev)

@@ -20,8 +20,8 @@ for kind in ("room", "uniform"):
     L.votenet_fps_trace_read(buf, 1)
     L.votenet_farthest_point_sample(b, n, m, x.data_ptr(), temp.data_ptr(), out.data_ptr(), None)
     L.votenet_fps_trace_read(buf, 1)
-    names = ["loop/out", "box tests", "touched buckets", "wave winner", "cross-wave"]
-    tot = sum(buf[:5])
+    names = ["loop/out", "box tests", "touched buckets", "wave winner", "cross-wave", "stage 2 (two-pick kernel)"]
+    tot = sum(buf[:6])
     print(kind, "cycles per round (s_memtime ticks, 100 MHz = 10 ns each?):", round(tot / (m - 1), 1))
     for i, nm in enumerate(names):
         print("   %-16s %8.1f per round  %5.1f%%" % (nm, buf[i] / (m - 1), 100.0 * buf[i] / tot))

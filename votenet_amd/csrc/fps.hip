@@ -501,6 +501,212 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
 }
 
 // ------------------------------------------------------------------ exact bucket-pruned FPS, L2-resident points
+// ------------------------------------------------------------------ two samples per round
+// fps_bucket_kernel with up to TWO picks per round.  If q1 is the arg-max of a round and q2 the runner-up (in the full order:
+// running distance, then tie key), and the distance from q2 to q1 -- evaluated exactly as the update would evaluate it -- is
+// not below q2's running distance, then adding q1 leaves q2's running distance untouched while every other one can only
+// decrease: q2 IS the arg-max of the next round, so it is emitted now and the round after next starts with both centres.
+// (q2's running distance must be positive: at 0 the just-picked q1, whose own distance is 0 too, still has the smaller
+// key.)  The sampled indices are the same, in the same order; on room scenes 94 % of the rounds emit two.
+// The price per round: every wave also keeps its runner-up POINT (second-best bucket entry or the second-best point inside
+// its best bucket, recomputed only when one of those two buckets was touched), and the exchange has a second ds_max_u64
+// stage in which the winner's wave posts its runner-up and every other wave its best again.
+template <int NW>
+__device__ __forceinline__ unsigned long long fps_pack(unsigned dmax, unsigned key, int w)
+{
+    const unsigned key28 = ((key >> 23) << 19) | (key & 0x7FFFFu);
+    return ((unsigned long long)dmax << 32) | (((0xFFFFFFFu - key28) << 4) | (unsigned)w);
+}
+__device__ __forceinline__ unsigned fps_unpack_index(unsigned low)
+{
+    const unsigned key28 = 0xFFFFFFFu - (low >> 4);
+    return (key28 >> 19) | ((key28 & 0x7FFFFu) << 9);
+}
+
+template <int NW, int VW>
+__global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, const float *__restrict__ xyz,
+                                                              const int *__restrict__ perm, const float *__restrict__ bbox,
+                                                              int *__restrict__ out)
+{
+    constexpr int P = VW;
+    typedef typename SlotVec<VW>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *s_key = reinterpret_cast<unsigned *>(smem);                          // NW*P*64 tie keys by (slot, wave, lane)
+    unsigned *s_ex = reinterpret_cast<unsigned *>(smem + (size_t)NW * P * 64 * 4); // exchange area (below)
+    // exchange area: 6 atomic words (3 per stage, by round % 3) | 2 parities x 2 tables (best, runner-up) x 16 float4
+    unsigned long long *slot1 = reinterpret_cast<unsigned long long *>(s_ex);
+    unsigned long long *slot2 = slot1 + 3;
+    float4 *tab = reinterpret_cast<float4 *>(s_ex + 16);
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    int *__restrict__ o = out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id_uniform();
+    const int nb = (n + 63) / 64;
+
+    vec_t X, Y, Z, TD;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int g = i * NW + w;
+        const int p = g * 64 + lane;
+        const bool valid = p < n;
+        unsigned key = 0xFFFFFFFFu;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) {
+            const int k = pm[p];
+            px = pts[(size_t)k * 3 + 0];
+            py = pts[(size_t)k * 3 + 1];
+            pz = pts[(size_t)k * 3 + 2];
+            key = fps_tiekey((unsigned)k);
+        }
+        X[i] = px;
+        Y[i] = py;
+        Z[i] = pz;
+        TD[i] = valid ? 1e38f : 0.0f;
+        s_key[(size_t)(i * NW + w) * 64 + lane] = key;
+    }
+    const int myg = lane * NW + w;
+    const bool hasb = lane < P && myg < nb;
+    const float *__restrict__ bb = bbox + ((size_t)blockIdx.x * nb + (hasb ? myg : 0)) * 6;
+    const float bxl = hasb ? bb[0] : INFINITY, byl = hasb ? bb[1] : INFINITY, bzl = hasb ? bb[2] : INFINITY;
+    const float bxh = hasb ? bb[3] : -INFINITY, byh = hasb ? bb[4] : -INFINITY, bzh = hasb ? bb[5] : -INFINITY;
+    unsigned bmax = hasb ? fbits(1e38f) : 0u;
+    unsigned bkey = 0xFFFFFFFFu;
+    int blane = 0;
+    if (tid < 6) slot1[tid] = 0ull; // slot1[0..2], slot2[0..2]
+    __syncthreads();
+    FpsOut fo = {o, m, 0};
+    fo.put(0, 0, tid);
+    float cx = pts[0], cy = pts[1], cz = pts[2]; // first centre of the round
+    float ex2 = cx, ey2 = cy, ez2 = cz;          // second centre (valid when two)
+    bool two = false;
+    unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's best point (uniform) ...
+    int cw_slot = -1;
+    float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+    int round = 0;
+#ifdef FPS_TRACE
+    unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
+    for (int j = 1; j < m; round++) {
+        FPS_T(0);
+        // (1) buckets that can change, for either centre
+        float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
+        float ey = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
+        float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
+        float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+        if (two) {
+            ex = fmaxf(fmaxf(bxl - ex2, ex2 - bxh), 0.0f);
+            ey = fmaxf(fmaxf(byl - ey2, ey2 - byh), 0.0f);
+            ez = fmaxf(fmaxf(bzl - ez2, ez2 - bzh), 0.0f);
+            lb = fminf(lb, (ex * ex + ey * ey + ez * ez) * 0.99999f);
+        }
+        unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+        FPS_T(1);
+        // (2) update them
+        bool changed = false;
+        while (act) {
+            const int i = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            const float px = X[i], py = Y[i], pz = Z[i];
+            const float dx = px - cx, dy = py - cy, dz = pz - cz;
+            const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
+            unsigned d2 = min(fbits(d), fbits(TD[i]));  // :143
+            if (two) {
+                const float fx = px - ex2, fy = py - ey2, fz = pz - ez2;
+                d2 = min(d2, fbits(fx * fx + fy * fy + fz * fz));
+            }
+            TD[i] = __uint_as_float(d2);
+            const int ol = __builtin_amdgcn_readlane(blane, i);
+            const unsigned omax = (unsigned)__builtin_amdgcn_readlane((int)bmax, i);
+            if ((unsigned)__builtin_amdgcn_readlane((int)d2, ol) != omax) {
+                const unsigned key = s_key[(size_t)(i * NW + w) * 64 + lane];
+                unsigned nmax, nkey;
+                const int nl = wave_argmax(d2, key, nmax, nkey);
+                if (lane == i) {
+                    bmax = nmax;
+                    bkey = nkey;
+                    blane = nl;
+                }
+                changed = changed || (i == cw_slot);
+            }
+        }
+        FPS_T(2);
+        // (3) the wave's best point and its runner-up
+        const bool first = round == 0;
+        if (changed || first) {
+            const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, cw_max, cw_key);
+            cw_slot = ws;
+            const int fl = __builtin_amdgcn_readlane(blane, ws);
+            cw_x = readlane_f32(X[ws], fl);
+            cw_y = readlane_f32(Y[ws], fl);
+            cw_z = readlane_f32(Z[ws], fl);
+        }
+        FPS_T(3);
+        // (4) exchange, stage 1: the block's best point
+        const int cur = round % 3, nxt = cur == 2 ? 0 : cur + 1;
+        float4 *best_t = tab + (round & 1) * 32, *run_t = best_t + 16;
+        if (lane == 0) {
+            best_t[w] = make_float4(cw_x, cw_y, cw_z, 0.0f);
+            atomicMax(&slot1[cur], fps_pack<NW>(cw_max, cw_key, w));
+            if (w == 0) {
+                slot1[nxt] = 0ull;
+                slot2[nxt] = 0ull;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned long long v1 = slot1[cur];
+        FPS_T(4);
+        const int w1 = (int)((unsigned)v1 & 15u);
+        // stage 2: the block's second-best point = the best of the other waves or the winner wave's runner-up, which only that
+        // wave computes, now: its second-best bucket entry or the second-best point inside its best bucket
+        if (w == w1) {
+            unsigned b2max, b2key;
+            const bool other = lane < P && lane != cw_slot;
+            const int ws2 = wave_argmax(other ? bmax : 0u, other ? bkey : 0xFFFFFFFFu, b2max, b2key);
+            const int fl = __builtin_amdgcn_readlane(blane, cw_slot);
+            const unsigned tdb = fbits(TD[cw_slot]);
+            const unsigned kb = s_key[(size_t)(cw_slot * NW + w) * 64 + lane];
+            unsigned i2max, i2key;
+            const int l2 = wave_argmax(lane == fl ? 0u : tdb, lane == fl ? 0xFFFFFFFFu : kb, i2max, i2key);
+            const bool inner = i2max > b2max || (i2max == b2max && i2key < b2key);
+            const int rs = inner ? cw_slot : (ws2 < P ? ws2 : P - 1);
+            const int rl = inner ? l2 : __builtin_amdgcn_readlane(blane, rs);
+            const float rx = readlane_f32(X[rs], rl), ry = readlane_f32(Y[rs], rl), rz = readlane_f32(Z[rs], rl);
+            if (lane == 0) {
+                run_t[w] = make_float4(rx, ry, rz, 0.0f);
+                atomicMax(&slot2[cur], fps_pack<NW>(inner ? i2max : b2max, inner ? i2key : b2key, w));
+            }
+        } else if (lane == 0) {
+            atomicMax(&slot2[cur], fps_pack<NW>(cw_max, cw_key, w));
+        }
+        const float4 c1 = best_t[w1];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        const unsigned long long v2 = slot2[cur];
+        FPS_T(5);
+        const int w2 = (int)((unsigned)v2 & 15u);
+        const unsigned td2 = (unsigned)(v2 >> 32);
+        const float4 c2 = (w2 == w1) ? run_t[w1] : best_t[w2];
+        // (5) one pick or two
+        const float gx = c2.x - c1.x, gy = c2.y - c1.y, gz = c2.z - c1.z; // q2 as a point, q1 as the centre: the update's expression
+        const float d12 = gx * gx + gy * gy + gz * gz;
+        const bool both = (j + 1 < m) && td2 != 0u && fbits(d12) >= td2;
+        fo.put(j, (int)fps_unpack_index((unsigned)v1), tid);
+        if (both) fo.put(j + 1, (int)fps_unpack_index((unsigned)v2), tid);
+        cx = c1.x;
+        cy = c1.y;
+        cz = c1.z;
+        ex2 = c2.x;
+        ey2 = c2.y;
+        ez2 = c2.z;
+        two = both;
+        j += both ? 2 : 1;
+    }
+}
+
 // 24 576 < n <= NW*64*64*NBL.  The same pruning as fps_bucket_kernel, but only the bucket METADATA lives in registers
 // (NBL buckets per lane: box, cached max / key / lane and the coordinates of that arg-max point); the Morton-sorted
 // points with their running distance are a float4 array in the caller's scratch (16 B per point, 1.3 MB for 80 000
@@ -733,11 +939,28 @@ extern "C" size_t votenet_fps_temp_floats(int b, int n)
 
 #define FPS_LAUNCH(NW, P) hipLaunchKernelGGL((fps_reg_kernel<NW, P>), dim3(b), dim3(NW * 64), 0, st, n, m, inp, out)
 static int g_fps_dbg_nw = 0, g_fps_dbg_p = 0;
+static bool g_fps_two_pick = false;
+extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
+{
+    g_fps_two_pick = on != 0;
+}
 extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a brute-force configuration (0,0 = automatic)
 {
     g_fps_dbg_nw = nw;
     g_fps_dbg_p = p;
 }
+#define FPS_BUCKET2_LAUNCH(NW, VW)                                                                                 \
+    do {                                                                                                           \
+        constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 64 + 2 * 2 * 16 * 16;                                    \
+        static bool attr_set2 = false;                                                                             \
+        if (!attr_set2) {                                                                                          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket2_kernel<NW, VW>),                  \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            attr_set2 = true;                                                                                      \
+        }                                                                                                          \
+        hipLaunchKernelGGL((fps_bucket2_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
+                           (const float *)(temp + (size_t)b * n), out);                                            \
+    } while (0)
 #define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
     do {                                                                                                           \
         constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;                                          \
@@ -774,10 +997,13 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
         FPS_LAUNCH(8, 8);
     } else if (n <= kFpsBucketMax) {
         hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(b), dim3(1024), 0, st, n, inp, (int *)temp, temp + (size_t)b * n);
+        const bool single = !g_fps_two_pick; // measured: the two-pick rounds are 1.9x as long as the plain ones
         if (n <= 16 * 16 * 64) {
-            FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
+            if (single) FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
+            else FPS_BUCKET2_LAUNCH(16, 16);
         } else {
-            FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
+            if (single) FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
+            else FPS_BUCKET2_LAUNCH(12, 32);
         }
     } else if (n <= kFpsL2Max) {
         const int nb = (n + 63) / 64;
