@@ -9,6 +9,8 @@ L = ctypes.CDLL(os.path.join(ROOT, "tools", "probe", "lib", "libfps_trace.so"))
 L.votenet_fps_temp_floats.restype = ctypes.c_size_t
 L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
 L.votenet_farthest_point_sample.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p] * 4
+L.votenet_fps_debug_two_pick.restype = None
+L.votenet_fps_debug_two_pick(int(os.environ.get("TWO_PICK", "0")))
 dev = torch.device("cuda:0")
 for kind in ("room", "uniform"):
     b, n, m = 8, 20480, 2048

@@ -509,8 +509,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
 // (q2's running distance must be positive: at 0 the just-picked q1, whose own distance is 0 too, still has the smaller
 // key.)  The sampled indices are the same, in the same order; on room scenes 94 % of the rounds emit two.
 // The price per round: every wave also keeps its runner-up POINT (second-best bucket entry or the second-best point inside
-// its best bucket, recomputed only when one of those two buckets was touched), and the exchange has a second ds_max_u64
-// stage in which the winner's wave posts its runner-up and every other wave its best again.
+// its best bucket, recomputed only when one of those two buckets was touched), the update runs for two centres, and the
+// exchange carries eight words instead of one (still one ds_max_u64 instruction and one barrier: see (4) in the kernel).
 template <int NW>
 __device__ __forceinline__ unsigned long long fps_pack(unsigned dmax, unsigned key, int w)
 {
@@ -526,17 +526,18 @@ __device__ __forceinline__ unsigned fps_unpack_index(unsigned low)
 template <int NW, int VW>
 __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, const float *__restrict__ xyz,
                                                               const int *__restrict__ perm, const float *__restrict__ bbox,
-                                                              int *__restrict__ out)
+                                                              int *__restrict__ out, int allow_two)
 {
+    static_assert(NW <= 16, "wave number in 4 bits");
     constexpr int P = VW;
     typedef typename SlotVec<VW>::type vec_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned *s_key = reinterpret_cast<unsigned *>(smem);                          // NW*P*64 tie keys by (slot, wave, lane)
-    unsigned *s_ex = reinterpret_cast<unsigned *>(smem + (size_t)NW * P * 64 * 4); // exchange area (below)
-    // exchange area: 6 atomic words (3 per stage, by round % 3) | 2 parities x 2 tables (best, runner-up) x 16 float4
-    unsigned long long *slot1 = reinterpret_cast<unsigned long long *>(s_ex);
-    unsigned long long *slot2 = slot1 + 3;
-    float4 *tab = reinterpret_cast<float4 *>(s_ex + 16);
+    unsigned char *ex = smem + (size_t)NW * P * 64 * 4;
+    // exchange area: [3 rounds][4 bits][2 classes] atomic words | per round parity: best xyz[16], runner xyz[16], runner word[16]
+    unsigned long long *slot = reinterpret_cast<unsigned long long *>(ex);             // 24 words = 192 B
+    float4 *tab = reinterpret_cast<float4 *>(ex + 192);                                 // 2 x 32 float4 = 1024 B
+    unsigned long long *rword = reinterpret_cast<unsigned long long *>(ex + 192 + 1024); // 2 x 16 words = 256 B
     const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
     const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
     int *__restrict__ o = out + (size_t)blockIdx.x * m;
@@ -573,7 +574,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
     unsigned bmax = hasb ? fbits(1e38f) : 0u;
     unsigned bkey = 0xFFFFFFFFu;
     int blane = 0;
-    if (tid < 6) slot1[tid] = 0ull; // slot1[0..2], slot2[0..2]
+    if (tid < 24) slot[tid] = 0ull;
     __syncthreads();
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid);
@@ -581,8 +582,11 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
     float ex2 = cx, ey2 = cy, ez2 = cz;          // second centre (valid when two)
     bool two = false;
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's best point (uniform) ...
-    int cw_slot = -1;
+    int cw_slot = 0;
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+    unsigned r_max = 0u, r_key = 0xFFFFFFFFu;   // ... and its runner-up point
+    int r_slot = 0;
+    float r_x = 0.f, r_y = 0.f, r_z = 0.f;
     int round = 0;
 #ifdef FPS_TRACE
     unsigned long long _tprev = __builtin_amdgcn_s_memtime();
@@ -590,17 +594,20 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
     for (int j = 1; j < m; round++) {
         FPS_T(0);
         // (1) buckets that can change, for either centre
-        float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
-        float ey = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
-        float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
-        float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+        float ax = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
+        float ay = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
+        float az = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
+        float lb = (ax * ax + ay * ay + az * az) * 0.99999f;
         if (two) {
-            ex = fmaxf(fmaxf(bxl - ex2, ex2 - bxh), 0.0f);
-            ey = fmaxf(fmaxf(byl - ey2, ey2 - byh), 0.0f);
-            ez = fmaxf(fmaxf(bzl - ez2, ez2 - bzh), 0.0f);
-            lb = fminf(lb, (ex * ex + ey * ey + ez * ez) * 0.99999f);
+            ax = fmaxf(fmaxf(bxl - ex2, ex2 - bxh), 0.0f);
+            ay = fmaxf(fmaxf(byl - ey2, ey2 - byh), 0.0f);
+            az = fmaxf(fmaxf(bzl - ez2, ez2 - bzh), 0.0f);
+            lb = fminf(lb, (ax * ax + ay * ay + az * az) * 0.99999f);
         }
         unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+        const bool first = round == 0;
+        // the runner-up is stale as soon as its bucket or the best bucket was touched (running distances inside may have dropped)
+        bool need_r = first || ((act >> cw_slot) & 1ull) || ((act >> r_slot) & 1ull);
         FPS_T(1);
         // (2) update them
         bool changed = false;
@@ -632,7 +639,6 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
         }
         FPS_T(2);
         // (3) the wave's best point and its runner-up
-        const bool first = round == 0;
         if (changed || first) {
             const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, cw_max, cw_key);
             cw_slot = ws;
@@ -640,62 +646,69 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
             cw_x = readlane_f32(X[ws], fl);
             cw_y = readlane_f32(Y[ws], fl);
             cw_z = readlane_f32(Z[ws], fl);
+            need_r = true;
         }
-        FPS_T(3);
-        // (4) exchange, stage 1: the block's best point
-        const int cur = round % 3, nxt = cur == 2 ? 0 : cur + 1;
-        float4 *best_t = tab + (round & 1) * 32, *run_t = best_t + 16;
-        if (lane == 0) {
-            best_t[w] = make_float4(cw_x, cw_y, cw_z, 0.0f);
-            atomicMax(&slot1[cur], fps_pack<NW>(cw_max, cw_key, w));
-            if (w == 0) {
-                slot1[nxt] = 0ull;
-                slot2[nxt] = 0ull;
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const unsigned long long v1 = slot1[cur];
-        FPS_T(4);
-        const int w1 = (int)((unsigned)v1 & 15u);
-        // stage 2: the block's second-best point = the best of the other waves or the winner wave's runner-up, which only that
-        // wave computes, now: its second-best bucket entry or the second-best point inside its best bucket
-        if (w == w1) {
-            unsigned b2max, b2key;
+        if (need_r) {
+            unsigned b2max, b2key; // second-best bucket entry
             const bool other = lane < P && lane != cw_slot;
             const int ws2 = wave_argmax(other ? bmax : 0u, other ? bkey : 0xFFFFFFFFu, b2max, b2key);
-            const int fl = __builtin_amdgcn_readlane(blane, cw_slot);
+            const int fl = __builtin_amdgcn_readlane(blane, cw_slot); // second-best point inside the best bucket
             const unsigned tdb = fbits(TD[cw_slot]);
             const unsigned kb = s_key[(size_t)(cw_slot * NW + w) * 64 + lane];
             unsigned i2max, i2key;
             const int l2 = wave_argmax(lane == fl ? 0u : tdb, lane == fl ? 0xFFFFFFFFu : kb, i2max, i2key);
             const bool inner = i2max > b2max || (i2max == b2max && i2key < b2key);
-            const int rs = inner ? cw_slot : (ws2 < P ? ws2 : P - 1);
-            const int rl = inner ? l2 : __builtin_amdgcn_readlane(blane, rs);
-            const float rx = readlane_f32(X[rs], rl), ry = readlane_f32(Y[rs], rl), rz = readlane_f32(Z[rs], rl);
-            if (lane == 0) {
-                run_t[w] = make_float4(rx, ry, rz, 0.0f);
-                atomicMax(&slot2[cur], fps_pack<NW>(inner ? i2max : b2max, inner ? i2key : b2key, w));
-            }
-        } else if (lane == 0) {
-            atomicMax(&slot2[cur], fps_pack<NW>(cw_max, cw_key, w));
+            r_max = inner ? i2max : b2max;
+            r_key = inner ? i2key : b2key;
+            r_slot = inner ? cw_slot : (ws2 < P ? ws2 : P - 1); // no second bucket: r_max is 0 and the point is never used
+            const int rl = inner ? l2 : __builtin_amdgcn_readlane(blane, r_slot);
+            r_x = readlane_f32(X[r_slot], rl);
+            r_y = readlane_f32(Y[r_slot], rl);
+            r_z = readlane_f32(Z[r_slot], rl);
         }
-        const float4 c1 = best_t[w1];
+        FPS_T(3);
+        // (4) ONE exchange for the block's two best points.  The best of every wave goes, by a single ds_max_u64, into four
+        // pairs of words: pair b is split by bit b of the wave number.  The overall maximum is max(pair 0); the best of the
+        // OTHER waves is the maximum over b of the word of pair b on the opposite side of the winner's bit b (every other wave
+        // differs from the winner in some bit, and none of those words contains the winner).  The block's second point is
+        // that or the winner wave's runner-up.
+        const int cur = round % 3, nxt = cur == 2 ? 0 : cur + 1;
+        unsigned long long *sl = slot + cur * 8;
+        float4 *best_t = tab + (round & 1) * 32, *run_t = best_t + 16;
+        unsigned long long *rw = rword + (round & 1) * 16;
+        const unsigned long long mine = fps_pack<NW>(cw_max, cw_key, w);
+        if (lane < 4) atomicMax(&sl[lane * 2 + ((w >> lane) & 1)], mine);
+        if (lane == 0) {
+            best_t[w] = make_float4(cw_x, cw_y, cw_z, 0.0f);
+            run_t[w] = make_float4(r_x, r_y, r_z, 0.0f);
+            rw[w] = fps_pack<NW>(r_max, r_key, w);
+        }
+        if (w == 0 && lane < 8) slot[nxt * 8 + lane] = 0ull;
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        const unsigned long long v2 = slot2[cur];
-        FPS_T(5);
-        const int w2 = (int)((unsigned)v2 & 15u);
-        const unsigned td2 = (unsigned)(v2 >> 32);
+        unsigned long long v[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = sl[e];
+        const unsigned long long g1 = v[0] > v[1] ? v[0] : v[1];
+        const int w1 = (int)((unsigned)g1 & 15u);
+        unsigned long long g2 = rw[w1];
+#pragma unroll
+        for (int b2 = 0; b2 < 4; b2++) {
+            const unsigned long long c = ((w1 >> b2) & 1) ? v[2 * b2] : v[2 * b2 + 1];
+            g2 = c > g2 ? c : g2;
+        }
+        const int w2 = (int)((unsigned)g2 & 15u);
+        const unsigned td2 = (unsigned)(g2 >> 32);
+        const float4 c1 = best_t[w1];
         const float4 c2 = (w2 == w1) ? run_t[w1] : best_t[w2];
+        FPS_T(4);
         // (5) one pick or two
         const float gx = c2.x - c1.x, gy = c2.y - c1.y, gz = c2.z - c1.z; // q2 as a point, q1 as the centre: the update's expression
         const float d12 = gx * gx + gy * gy + gz * gz;
-        const bool both = (j + 1 < m) && td2 != 0u && fbits(d12) >= td2;
-        fo.put(j, (int)fps_unpack_index((unsigned)v1), tid);
-        if (both) fo.put(j + 1, (int)fps_unpack_index((unsigned)v2), tid);
+        const bool both = allow_two && (j + 1 < m) && td2 != 0u && fbits(d12) >= td2;
+        fo.put(j, (int)fps_unpack_index((unsigned)g1), tid);
+        if (both) fo.put(j + 1, (int)fps_unpack_index((unsigned)g2), tid);
         cx = c1.x;
         cy = c1.y;
         cz = c1.z;
@@ -939,10 +952,10 @@ extern "C" size_t votenet_fps_temp_floats(int b, int n)
 
 #define FPS_LAUNCH(NW, P) hipLaunchKernelGGL((fps_reg_kernel<NW, P>), dim3(b), dim3(NW * 64), 0, st, n, m, inp, out)
 static int g_fps_dbg_nw = 0, g_fps_dbg_p = 0;
-static bool g_fps_two_pick = false;
+static int g_fps_two_pick = 0; // 1: two samples per round; 2: that kernel with the second pick disabled (measurement)
 extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
 {
-    g_fps_two_pick = on != 0;
+    g_fps_two_pick = on;
 }
 extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a brute-force configuration (0,0 = automatic)
 {
@@ -951,7 +964,7 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
 }
 #define FPS_BUCKET2_LAUNCH(NW, VW)                                                                                 \
     do {                                                                                                           \
-        constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 64 + 2 * 2 * 16 * 16;                                    \
+        constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 192 + 1024 + 256;                                        \
         static bool attr_set2 = false;                                                                             \
         if (!attr_set2) {                                                                                          \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket2_kernel<NW, VW>),                  \
@@ -959,7 +972,7 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
             attr_set2 = true;                                                                                      \
         }                                                                                                          \
         hipLaunchKernelGGL((fps_bucket2_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
-                           (const float *)(temp + (size_t)b * n), out);                                            \
+                           (const float *)(temp + (size_t)b * n), out, g_fps_two_pick == 1 ? 1 : 0);               \
     } while (0)
 #define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
     do {                                                                                                           \
