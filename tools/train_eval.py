@@ -33,7 +33,7 @@ def evaluate():
 t0 = time.time()
 print("step 0: mAP", evaluate())
 for i in range(steps):
-    net.train_step(xs[i % nb], gt=gts[i % nb])
+    net.train_step(xs[i % nb], gt=gts[i % nb], next_x=xs[(i + 1) % nb])  # geometry of the next batch under this step
     if (i + 1) % 100 == 0:
         l = net.last_losses.cpu().numpy()
         print("step %d  cost %.3f  vote %.3f obj %.3f box %.3f sem %.3f  pos %d  (%.1f s)" % (i + 1, l[0], l[1], l[2], l[9], l[8], int(l[10]),
