@@ -9,6 +9,8 @@
 // 128 -> 256 layers -- z of the layer is never read again (training does not store it any more), and x^T x depends on the
 // forward pass only, so it runs early on the weight-gradient stream.  The sparse parts touch cout values per group.
 #include "mlp_types.h"
+#include <mutex>
+#include <set>
 
 namespace votenet {
 
@@ -411,7 +413,15 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
     auto go = [&](auto kern, int ci, int co) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        static std::set<const void *> raised; // the attribute is per kernel: set once
+        static std::mutex raised_mu;          // entry points may be called from several host threads
+        bool fresh;
+        {
+            std::lock_guard<std::mutex> lock(raised_mu);
+            fresh = raised.insert(reinterpret_cast<const void *>(kern)).second;
+        }
+        if (fresh)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(512), smem, st, groups, gout, argmax, zsel, coef, relu,
                            wT, da, pb);
     };
