@@ -10,7 +10,7 @@ xs = [torch.from_numpy(synth.room_batch(8, 20480, 1000 + 8 * i)).to(dev) for i i
 net.init_optimizer(1e-3)
 t0 = time.time()
 for i in range(300):
-    out = net.train_step(xs[i % 4], gt=gts[i % 4])
+    out = net.train_step(xs[i % 4], gt=gts[i % 4], next_x=xs[(i + 1) % 4])
     if i % 50 == 49:
         torch.cuda.synchronize()
         print(i + 1, "steps, cost %.3f (pos %d), %.1f s, mem %.2f GB (peak %.2f), |param| %.4f, finite %s" % (
