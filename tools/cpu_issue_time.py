@@ -1,0 +1,24 @@
+"""Host time to ENQUEUE one train step (no synchronisation inside): if it approaches the GPU time of a step, the step is
+launch-bound on the host and faster kernels will not show."""
+import sys, time, torch
+import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
+from votenet_amd import synth, loss as VL
+from votenet_amd.model import VoteNetHotPath
+dev = torch.device("cuda:0")
+net = VoteNetHotPath(dev, seed=0)
+xs = [torch.from_numpy(synth.room_batch(8, 20480, 1000 + 8 * i)).to(dev) for i in range(3)]
+gts = [VL.gt_to_device(synth.room_gt(8, 20480, 1000 + 8 * i), dev) for i in range(3)]
+for i in range(6):
+    net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+import gc; gc.collect(); gc.disable()
+host, gpu = [], []
+for i in range(6, 36):
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    host.append(t1 - t0); gpu.append(t2 - t0)
+host.sort(); gpu.sort()
+print("host enqueue time per step: median %.2f ms (min %.2f); step from an idle GPU to done: median %.2f ms" % (host[15] * 1e3, host[0] * 1e3, gpu[15] * 1e3))
