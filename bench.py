@@ -34,6 +34,7 @@ def parse():
     ap.add_argument("--workload", default=None, choices=["train", "fwd"])
     ap.add_argument("--scene", default="room", choices=["room", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra unpipelined / alone-on-the-GPU measurements (profiling)")
     ap.add_argument("--no-gram", action="store_true", help="pooled layers: direct backward GEMMs on the stored z instead of the Gram form")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not compute the coordinate-only geometry of the next batch underneath the current step")
@@ -201,7 +202,7 @@ def main():
     # the same step with every batch's geometry computed inside its own step (nothing carried across steps): reported beside
     # the headline value, not instead of it
     in_step = None
-    if pipeline:
+    if pipeline and not args.headline_only:
         pipe_on[0] = False
         k2 = max(2, min(args.steps, 20))
         for _ in range(2):
@@ -228,7 +229,7 @@ def main():
 
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None
-    if rank == 0:
+    if rank == 0 and not args.headline_only:
         tf_sampling.PROFILE_EVENTS, tf_grouping.PROFILE_EVENTS = [], []
         for _ in range(5):
             net.sa1.geometry(xs[0])
@@ -257,7 +258,8 @@ def main():
                                              "exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg,
-                    "alone_on_the_gpu": {"avg_launch_ms": round(iso_fps, 4), "frac": round(alg / (iso_fps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+                    "alone_on_the_gpu": ({"avg_launch_ms": round(iso_fps, 4), "frac": round(alg / (iso_fps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                         if iso_fps else None)}
         # the sa1 ball query (n=20480 candidates, 2048 centres, K=64) and the pair the north star names: FPS + ball query
         bq = None
         K1 = net.sa1.nsample
@@ -273,8 +275,9 @@ def main():
                   "avg_launch_ms": round(bq_ms, 4), "algorithmic_bytes": bq_alg,
                   "fps_plus_ball_query": {"achieved": round(both, 1), "frac": round(both / HBM_PEAK_GBS, 4),
                                           "ms": round(avg_ms + bq_ms, 4), "algorithmic_bytes": alg + bq_alg,
-                                          "alone_on_the_gpu": {"ms": round(iso_fps + iso_bq, 4),
-                                                               "frac": round((alg + bq_alg) / ((iso_fps + iso_bq) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
+                                          "alone_on_the_gpu": ({"ms": round(iso_fps + iso_bq, 4),
+                                                                "frac": round((alg + bq_alg) / ((iso_fps + iso_bq) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                                                               if iso_fps else None)}}
         mfma = None
         if gemm_events:
             # GEMMs run on two streams (weight gradients beside the input-gradient chain): the time the matrix pipes are

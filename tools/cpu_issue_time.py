@@ -22,3 +22,16 @@ for i in range(6, 36):
     host.append(t1 - t0); gpu.append(t2 - t0)
 host.sort(); gpu.sort()
 print("host enqueue time per step: median %.2f ms (min %.2f); step from an idle GPU to done: median %.2f ms" % (host[15] * 1e3, host[0] * 1e3, gpu[15] * 1e3))
+
+# how far ahead of the GPU does the host run in a free-running loop?
+torch.cuda.synchronize()
+evs, ts = [], []
+e0 = torch.cuda.Event(enable_timing=True); e0.record(); t0 = time.perf_counter()
+for i in range(36, 76):
+    net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+    e = torch.cuda.Event(enable_timing=True); e.record(); evs.append(e); ts.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+lead = [e0.elapsed_time(e) - t * 1e3 for e, t in zip(evs, ts)]
+print("free-running: host finishes enqueuing step k this many ms before the GPU finishes it: after 5 steps %.1f, 20 steps %.1f, 40 steps %.1f"
+      % (lead[4], lead[19], lead[39]))
+print("GPU ms per step over the last 30: %.3f ; host ms per step: %.3f" % ((e0.elapsed_time(evs[39]) - e0.elapsed_time(evs[9])) / 30, (ts[39] - ts[9]) / 30 * 1e3))

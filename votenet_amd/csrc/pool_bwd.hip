@@ -57,33 +57,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
 }
 
 // mmat (cin x cin) = W diag(C) W^T ; cvec (cin) = (B + C.b) W^T.  W is cin x cout row-major; coef = [A|B|C|S|H].
-__global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, int cout, const float *__restrict__ w,
-                                                                 const float *__restrict__ bias, const float *__restrict__ coef,
-                                                                 float *__restrict__ mmat, float *__restrict__ cvec)
+// A 16 x 16 output tile per workgroup; its two 16 x cout panels of W go to LDS in ONE round of loads (this kernel sits on the
+// step's critical chain and runs beside the weight-gradient GEMMs: every dependent load phase costs a loaded-memory latency).
+template <int COUT>
+__global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, const float *__restrict__ w, const float *__restrict__ bias,
+                                                                 const float *__restrict__ coef, float *__restrict__ mmat,
+                                                                 float *__restrict__ cvec)
 {
-    __shared__ float Wj[16][33], Wk[16][33], Cs[32], Ds[32];
-    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    constexpr int LD = COUT + 4;
+    __shared__ __attribute__((aligned(16))) float Wj[16][LD], Wk[16][LD];
+    __shared__ float Cs[COUT], Ds[COUT];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
     const int j0 = blockIdx.y * 16, k0 = blockIdx.x * 16;
+    constexpr int Q = COUT / 4;
+    for (int e = tid; e < 16 * Q; e += 256) {
+        const int r = e / Q, q = e % Q;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        *reinterpret_cast<float4 *>(&Wj[r][q * 4]) = j0 + r < cin ? *reinterpret_cast<const float4 *>(w + (size_t)(j0 + r) * COUT + q * 4) : z4;
+        *reinterpret_cast<float4 *>(&Wk[r][q * 4]) = k0 + r < cin ? *reinterpret_cast<const float4 *>(w + (size_t)(k0 + r) * COUT + q * 4) : z4;
+    }
+    for (int c = tid; c < COUT; c += 256) {
+        const float Cc = coef[2 * COUT + c];
+        Cs[c] = Cc;
+        Ds[c] = coef[COUT + c] + Cc * (bias ? bias[c] : 0.0f);
+    }
+    __syncthreads();
     float acc = 0.0f, accv = 0.0f;
-    for (int c0 = 0; c0 < cout; c0 += 32) {
-        for (int e = threadIdx.x; e < 16 * 32; e += 256) {
-            const int r = e >> 5, cc = e & 31;
-            Wj[r][cc] = (j0 + r < cin && c0 + cc < cout) ? w[(size_t)(j0 + r) * cout + c0 + cc] : 0.0f;
-            Wk[r][cc] = (k0 + r < cin && c0 + cc < cout) ? w[(size_t)(k0 + r) * cout + c0 + cc] : 0.0f;
-        }
-        if (threadIdx.x < 32) {
-            const int cc = c0 + threadIdx.x;
-            const float Cc = cc < cout ? coef[2 * cout + cc] : 0.0f;
-            Cs[threadIdx.x] = Cc;
-            Ds[threadIdx.x] = cc < cout ? coef[cout + cc] + Cc * (bias ? bias[cc] : 0.0f) : 0.0f;
-        }
-        __syncthreads();
 #pragma unroll 8
-        for (int cc = 0; cc < 32; cc++) {
-            acc += Wj[ty][cc] * Cs[cc] * Wk[tx][cc];
-            accv += Ds[cc] * Wk[tx][cc];
-        }
-        __syncthreads();
+    for (int c = 0; c < COUT; c++) {
+        const float wk = Wk[tx][c];
+        acc += Wj[ty][c] * Cs[c] * wk;
+        accv += Ds[c] * wk;
     }
     if (j0 + ty < cin && k0 + tx < cin) mmat[(size_t)(j0 + ty) * cin + k0 + tx] = acc;
     if (blockIdx.y == 0 && ty == 0 && k0 + tx < cin) cvec[k0 + tx] = accv;
@@ -391,9 +395,13 @@ extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *
 extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                           float *cvec, void *stream)
 {
-    VN_REQUIRE(cin > 0 && cout > 0 && w && coef && mmat && cvec, "pool_dgrad_prepare: bad arguments");
-    hipLaunchKernelGGL(pool_dgrad_prepare_kernel, dim3((cin + 15) / 16, (cin + 15) / 16), dim3(256), 0, as_stream(stream), cin, cout, w,
-                       bias, coef, mmat, cvec);
+    VN_REQUIRE(cin > 0 && w && coef && mmat && cvec, "pool_dgrad_prepare: bad arguments");
+    VN_REQUIRE((cout == 128 || cout == 256) && (uintptr_t)w % 16 == 0, "pool_dgrad_prepare: cout must be 128 or 256 (got %d), w 16-byte aligned", cout);
+    const dim3 grid((cin + 15) / 16, (cin + 15) / 16);
+    if (cout == 256)
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<256>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec);
+    else
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<128>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec);
     return check_launch("pool_dgrad_prepare");
 }
 
