@@ -477,7 +477,7 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse: in_scale and in_shift go together");
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse: operands must be 16-byte aligned");
-    const int grid = pb_grid(groups, 8, 768);
+    const int grid = pb_grid(groups, 8, 384); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
     if (cin == 128)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
