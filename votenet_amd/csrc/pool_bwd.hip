@@ -7,7 +7,8 @@
 //     dW  = x^T dz   = ((x^T x) W) . C  + (sum_r x)^T (B + C.b)             + gather of x rows by arg-max
 // The two big GEMMs of the layer shrink from (rows x cout x cin) to (rows x cin x cin) -- half the flops for VoteNet's
 // 128 -> 256 layers -- z of the layer is never read again (training does not store it any more), and x^T x depends on the
-// forward pass only, so it runs early on the weight-gradient stream.  The sparse parts touch cout values per group.
+// forward pass only: it belongs to the weight-gradient stream, off the critical chain.  The sparse parts touch cout values
+// per group.
 #include "mlp_types.h"
 #include <mutex>
 #include <set>
