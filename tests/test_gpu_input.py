@@ -126,3 +126,31 @@ def test_boxes_argument_errors(hiplib, dev):
         IP.augment_boxes(z3, z3, z1, k, np.array([0, 2, 6]))
     out = IP.augment_boxes(z3, z3 + 1, z1, k, np.array([0, 1, 4]))
     assert out["bboxes_lwh"].shape == (2, 3, 3) and torch.equal(out["bboxes_lwh"][0, 2], out["bboxes_lwh"][0, 0])
+
+
+def test_pipeline_output_feeds_the_train_step(hiplib, dev):
+    """raw clouds + ragged boxes -> subsample / augment / encode / pad on the device -> one train step on the result: the
+    eight ground-truth tensors have the layout and dtypes the loss graph takes, the points the layout the backbone takes."""
+    from votenet_amd import input_pipeline as IP, synth
+    from votenet_amd.model import VoteNetHotPath
+    b, n_raw, n_out = 2, 30000, 20480
+    raws, cen, siz, hed, cls = [], [], [], [], []
+    for s in range(b):
+        pts, boxes = synth.room_scene(n_raw, 4000 + s)
+        cam = pts.astype(np.float64)
+        raws.append(np.stack([cam[:, 0], cam[:, 2], -cam[:, 1]], 1))  # camera -> upright depth axes (sunutils.py:79-84)
+        bx = boxes.astype(np.float64)
+        cen.append(bx[:, :3]), siz.append(bx[:, 3:6]), hed.append(bx[:, 6]), cls.append(bx[:, 7].astype(np.int32))
+    raw, off = IP.pack_ragged(raws, dev)
+    aug = IP.draw_augmentation(b, np.random.RandomState(3))
+    x = IP.subsample_augment(raw, off, n_out, aug, None, seed=9)
+    dc, boff = IP.pack_ragged(cen, dev)
+    gt = IP.augment_boxes(dc, IP.pack_ragged(siz, dev)[0], IP.pack_ragged(hed, dev)[0], IP.pack_ragged(cls, dev)[0], boff, aug)
+    assert x.shape == (b, n_out, 3) and gt["bboxes_xyz"].shape[0] == b
+    # augmented points still lie on their augmented boxes: every box centre has points within half its diagonal
+    d = (x[:, :, None, :] - gt["bboxes_xyz"][:, None, :, :]).norm(dim=-1)
+    assert bool((d.min(1).values < gt["bboxes_lwh"].norm(dim=-1) * 0.75).all())
+    net = VoteNetHotPath(dev, seed=1)
+    net.train_step(x, gt=gt)
+    assert bool(torch.isfinite(net.last_losses[:10]).all()) and float(net.last_losses[10]) > 0  # positives were assigned
+    assert bool(torch.isfinite(net.store.flat).all())
