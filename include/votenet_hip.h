@@ -58,6 +58,9 @@ int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *
 /* Experiment hook (not part of the drop-in surface): route 4096 < n <= 24576 through the kernel that emits up to two samples
  * per round (same indices, same order).  Off by default: measured slower than the one-sample rounds. */
 void votenet_fps_debug_two_pick(int on);
+/* Measurement hook: 0 disables the parallel "already in farthest-point order?" check that precedes the sampling rounds for
+ * n <= 2048; the result is the same either way. */
+void votenet_fps_debug_prefix_check(int on);
 size_t votenet_fps_temp_floats(int b, int n);
 
 /* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:172-181,206-208).

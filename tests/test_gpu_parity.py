@@ -79,6 +79,30 @@ def test_fps_two_samples_per_round_experiment_is_the_same_sequence(ops, dev, O, 
         hiplib.votenet_fps_debug_two_pick(0)
 
 
+def test_fps_of_an_fps_ordered_subset_short_cut_is_exact(ops, dev, O, hiplib):
+    """Levels 2-4 sample from centres that are already in farthest-point order: the parallel check confirms 0..m-1 (or, after an
+    exact tie that the subset's tie key resolves differently, lets the sampling rounds run).  Against the oracle on the
+    gathered subset, with the check on and off; lattice clouds provoke the ties."""
+    from votenet_amd import synth
+    hiplib.votenet_fps_debug_prefix_check.restype = None
+    rng = np.random.default_rng(3)
+    clouds = [synth.room_batch(2, 20480, 5), rng.random((2, 6000, 3), dtype=np.float32) * 4,
+              np.round(rng.random((2, 5000, 3), dtype=np.float32) * 8) / 2,    # lattice: exact ties and duplicates
+              np.round(rng.random((1, 3000, 3), dtype=np.float32) * 3)]         # 64 distinct positions only
+    identity = 0
+    for xyz in clouds:
+        for s_n, m in ((2048, 1024), (1024, 512), (512, 256), (1024, 256), (300, 300)):
+            sub = O.gather_point(xyz, O.farthest_point_sample(s_n, xyz))
+            exp = O.farthest_point_sample(m, sub)
+            identity += int((exp == np.arange(m)).all())
+            for on in (1, 0):
+                hiplib.votenet_fps_debug_prefix_check(on)
+                got = N(ops.s.farthest_point_sample(m, T(sub, dev)))
+                assert (got == exp).all(), (s_n, m, on)
+    hiplib.votenet_fps_debug_prefix_check(1)
+    assert 8 <= identity < 20  # both outcomes were exercised: confirmed prefixes and ties that break them
+
+
 def test_fps_full_size_properties(ops, dev):
     """BASELINE config 2 size (8 x 20480 -> 2048): size-independent properties, checked on the device."""
     xyz = T(np.random.default_rng(0).random((8, 20480, 3), dtype=np.float32) * 5, dev)

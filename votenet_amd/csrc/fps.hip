@@ -206,13 +206,133 @@ __device__ __forceinline__ int fps_slot_to_k(int tid, int i)
     return (i % Q) * 512 + (i / Q) * T + tid;
 }
 
+// ------------------------------------------------------------------ "is the input already in farthest-point order?"
+// In PointNet++ every level below the first samples from the previous level's centres, which ARE in farthest-point order:
+// greedy FPS restricted to its own first picks reproduces them, so the answer is 0, 1, ..., m-1 -- unless an exact tie is
+// resolved differently by the tie key on the subset's indices.  Two kernels CHECK every greedy step in parallel, spread
+// over the GPU, instead of performing the steps one after the other on one CU (n <= 2048):
+//   fps_prefix_t_kernel:     T[k] = running distance of point k when it would be picked = min_{i<k} d(k, i)   (thread per k)
+//   fps_prefix_check_kernel: every point q follows its own running distance td_k(q) = min_{i<k} d(q, i) along k and confirms
+//                            that point k beats it at step k: td_k(q) < T[k], or equal with the larger tie key (thread per q)
+// Same fp32 expression, same order as the sampling kernels.  T lives in the output buffer itself (out[1..m-1]; out[0] is the
+// verdict word: 0 = confirmed so far).  The sampling kernel then reads out[0]: confirmed -> it writes 0..m-1 and returns;
+// otherwise it runs its rounds.  The check is exact, not a heuristic: it IS the greedy algorithm, evaluated for one
+// candidate answer.
+constexpr int kFpsPrefixMax = 2048;
+// Step 1 alone (is point 1 the farthest from point 0?) settles almost every input that is NOT in farthest-point order; every
+// workgroup of both kernels evaluates it over all n points itself (a handful of distances per thread, no communication) and
+// leaves at once when it fails: an unordered cloud pays two near-empty launches, not the full check.
+__device__ __forceinline__ bool fps_step1_fails(const float *__restrict__ pts, int n, int tid, int nthreads)
+{
+    const float x0 = pts[0], y0 = pts[1], z0 = pts[2];
+    const float ex = pts[3] - x0, ey = pts[4] - y0, ez = pts[5] - z0;
+    const unsigned t1 = fbits(ex * ex + ey * ey + ez * ez), k1 = fps_tiekey(1u);
+    int bad = 0;
+    for (int q = tid; q < n; q += nthreads) {
+        const float dx = pts[(size_t)q * 3] - x0, dy = pts[(size_t)q * 3 + 1] - y0, dz = pts[(size_t)q * 3 + 2] - z0;
+        const unsigned d = fbits(dx * dx + dy * dy + dz * dz);
+        if (q != 1 && !(d < t1 || (d == t1 && fps_tiekey((unsigned)q) > k1))) bad = 1;
+    }
+    return __syncthreads_or(bad) != 0;
+}
+
+// Both kernels give every k (every q) to EIGHT lanes: a serial walk over a thousand centres is an instruction-latency chain
+// (about 50 us per wavefront however few wavefronts there are); eight interleaved (T) or consecutive (check) slices of it
+// and a shuffle reduction / scan cut it to an eighth.
+__global__ __launch_bounds__(256) void fps_prefix_t_kernel(int n, int m, const float *__restrict__ xyz, int *__restrict__ out)
+{
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.y * n * 3;
+    int *__restrict__ o = out + (size_t)blockIdx.y * m;
+    const int tid = threadIdx.x, sub = tid & 7;
+    if (fps_step1_fails(pts, n, tid, 256)) {
+        if (blockIdx.x == 0 && tid == 0) o[0] = 1; // verdict: not 0..m-1
+        return;
+    }
+    // group g of 8 lanes owns k = g and k = m-1-g: every group walks about m centres
+    const int k0 = blockIdx.x * 32 + (tid >> 3);
+    const bool live = 2 * k0 < m;
+    const int ka = live ? k0 : 0, kb = live ? m - 1 - k0 : 0;
+    const float ax0 = pts[(size_t)ka * 3], ay0 = pts[(size_t)ka * 3 + 1], az0 = pts[(size_t)ka * 3 + 2];
+    const float bx0 = pts[(size_t)kb * 3], by0 = pts[(size_t)kb * 3 + 1], bz0 = pts[(size_t)kb * 3 + 2];
+    unsigned ta = fbits(1e38f), tb = ta;
+    for (int i = sub; i < kb; i += 8) {
+        const float cx = pts[(size_t)i * 3], cy = pts[(size_t)i * 3 + 1], cz = pts[(size_t)i * 3 + 2];
+        const float bx = bx0 - cx, by = by0 - cy, bz = bz0 - cz; // point minus centre, tf_sampling_g.cu:142
+        tb = min(tb, fbits(bx * bx + by * by + bz * bz));
+        if (i < ka) {
+            const float ax = ax0 - cx, ay = ay0 - cy, az = az0 - cz;
+            ta = min(ta, fbits(ax * ax + ay * ay + az * az));
+        }
+    }
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        ta = min(ta, (unsigned)__shfl_xor((int)ta, d));
+        tb = min(tb, (unsigned)__shfl_xor((int)tb, d));
+    }
+    if (live && sub == 0) {
+        if (ka == 0) ta = 0u; // out[0] doubles as the verdict word: 0 = confirmed so far
+        o[ka] = (int)ta;
+        if (kb != ka) o[kb] = (int)tb;
+    }
+}
+
+__global__ __launch_bounds__(128) void fps_prefix_check_kernel(int n, int m, const float *__restrict__ xyz, int *__restrict__ out)
+{
+    __shared__ float4 P4[kFpsPrefixMax]; // centres 0..m-1: x, y, z, T (bits): one ds_read_b128 per greedy step
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.y * n * 3;
+    int *__restrict__ o = out + (size_t)blockIdx.y * m;
+    const int tid = threadIdx.x, sub = tid & 7;
+    if (fps_step1_fails(pts, n, tid, 128)) return; // fps_prefix_t_kernel has set the verdict
+    for (int k = tid; k < m; k += 128)
+        P4[k] = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k ? o[k] : 0));
+    __syncthreads();
+    const int q = blockIdx.x * 16 + (tid >> 3);
+    const bool live = q < n;
+    const int qq = live ? q : 0;
+    const float x = pts[(size_t)qq * 3], y = pts[(size_t)qq * 3 + 1], z = pts[(size_t)qq * 3 + 2];
+    const unsigned qkey = fps_tiekey((unsigned)qq);
+    // lane `sub` owns the steps k in [k_lo, k_hi): step k uses centre k-1
+    const int L = (m - 1 + 7) / 8;
+    const int k_lo = 1 + sub * L, k_hi = min(m, k_lo + L);
+    unsigned cm = fbits(1e38f); // min over this slice's centres ...
+    for (int k = k_lo; k < k_hi; k++) {
+        const float4 c = P4[k - 1];
+        const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+        cm = min(cm, fbits(dx * dx + dy * dy + dz * dz));
+    }
+    unsigned td = fbits(1e38f); // ... exclusive prefix over the slices before it = the running distance at k_lo
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+        const unsigned t = (unsigned)__shfl_up((int)cm, d, 8);
+        if (sub >= d) cm = min(cm, t);
+    }
+    {
+        const unsigned t = (unsigned)__shfl_up((int)cm, 1, 8);
+        if (sub > 0) td = t;
+    }
+    bool bad = false;
+    for (int k = k_lo; k < k_hi; k++) {
+        const float4 c = P4[k - 1];
+        const float dx = x - c.x, dy = y - c.y, dz = z - c.z;
+        td = min(td, fbits(dx * dx + dy * dy + dz * dz));
+        const unsigned tk = __float_as_uint(P4[k].w);
+        if (qq != k && !(td < tk || (td == tk && qkey > fps_tiekey((unsigned)k)))) bad = true;
+    }
+    if (live && bad) atomicOr(&o[0], 1);
+}
+
 template <int NW, int P>
-__global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const float *__restrict__ xyz, int *__restrict__ out)
+__global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const float *__restrict__ xyz, int *__restrict__ out,
+                                                          int check_prefix)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_ex[2 * 16 * 5];
     const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
     int *__restrict__ o = out + (size_t)blockIdx.x * m;
     const int tid = threadIdx.x;
+    if (check_prefix && o[0] == 0) { // fps_prefix_check_kernel confirmed every greedy step of 0..m-1 (uniform: one scene per block)
+        for (int jj = tid; jj < m; jj += NW * 64) o[jj] = jj;
+        return;
+    }
 
     float x[P], y[P], z[P];
     unsigned td[P];
@@ -950,8 +1070,13 @@ extern "C" size_t votenet_fps_temp_floats(int b, int n)
     return (size_t)(b < 32 ? b : 32) * (size_t)n;                                          // running distances, tf_sampling.cpp:115
 }
 
-#define FPS_LAUNCH(NW, P) hipLaunchKernelGGL((fps_reg_kernel<NW, P>), dim3(b), dim3(NW * 64), 0, st, n, m, inp, out)
+#define FPS_LAUNCH(NW, P) hipLaunchKernelGGL((fps_reg_kernel<NW, P>), dim3(b), dim3(NW * 64), 0, st, n, m, inp, out, check_prefix)
 static int g_fps_dbg_nw = 0, g_fps_dbg_p = 0;
+static int g_fps_prefix_check = 1;
+extern "C" void votenet_fps_debug_prefix_check(int on) // measurement hook: 0 = always run the sampling rounds
+{
+    g_fps_prefix_check = on;
+}
 static int g_fps_two_pick = 0; // 1: two samples per round; 2: that kernel with the second pick disabled (measurement)
 extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
 {
@@ -997,6 +1122,13 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
     if (n > kFpsRegMax)
         VN_REQUIRE(temp != nullptr, "FarthestPointSample: temp scratch of %zu floats required for n=%d",
                    votenet_fps_temp_floats(b, n), n);
+    // inputs that may already be in farthest-point order (every PointNet++ level below the first): check all greedy steps in
+    // parallel first; the sampling kernel then returns at once or, after an exact tie, runs as usual
+    const int check_prefix = (g_fps_prefix_check && n <= kFpsPrefixMax && m <= n && m > 1) ? 1 : 0;
+    if (check_prefix) {
+        hipLaunchKernelGGL(fps_prefix_t_kernel, dim3((m / 2 + 32) / 32, b), dim3(256), 0, st, n, m, inp, out);
+        hipLaunchKernelGGL(fps_prefix_check_kernel, dim3((n + 15) / 16, b), dim3(128), 0, st, n, m, inp, out);
+    }
     if (g_fps_dbg_nw && n <= 64 * g_fps_dbg_nw * g_fps_dbg_p) {
 #define FPS_DBG(NW, P) if (g_fps_dbg_nw == NW && g_fps_dbg_p == P) { FPS_LAUNCH(NW, P); return check_launch("farthest_point_sample"); }
         FPS_DBG(1, 8) FPS_DBG(1, 16) FPS_DBG(2, 4) FPS_DBG(2, 8) FPS_DBG(2, 16) FPS_DBG(4, 2) FPS_DBG(4, 4) FPS_DBG(4, 8) FPS_DBG(4, 16)
