@@ -191,13 +191,17 @@ class VoteNetHotPath:
         from . import loss as VL
         return VL.decode_boxes(proposals_xyz, proposals_output)
 
-    def predict(self, x, iou_threshold=0.25):
-        """Predict tower of model.py:98-139: forward -> decode -> NMS3D(bboxes, max class logit, objectness, 0.25)."""
+    def predict(self, x, iou_threshold=0.25, next_x=None, sync=True):
+        """Predict tower of model.py:98-139: forward -> decode -> NMS3D(bboxes, max class logit, objectness, 0.25).
+        next_x: the batch(es) of the next call(s), as in forward().  sync=False: nms_idx stays padded on the device with its
+        length in nms_count (no host synchronisation: calls pipeline)."""
         from . import tf_nms3d
-        out = self.forward(x)
+        out = self.forward(x, next_x=next_x)
         boxes, score = self.decode_boxes(out["proposals_xyz"], out["proposals_output"])
-        keep = tf_nms3d.NMS3D(boxes, score, out["proposals_output"][..., :2].contiguous(), iou_threshold)
-        return dict(bboxes=boxes, scores=score, nms_idx=keep, class_scores=out["proposals_output"][..., -NC:].contiguous(), **out)
+        keep = tf_nms3d.NMS3D(boxes, score, out["proposals_output"][..., :2].contiguous(), iou_threshold, padded=not sync)
+        extra = {} if sync else dict(nms_count=keep[1])
+        return dict(bboxes=boxes, scores=score, nms_idx=keep if sync else keep[0], class_scores=out["proposals_output"][..., -NC:].contiguous(),
+                    **extra, **out)
 
     # ---- backward / training --------------------------------------------------------
     def make_cotangents(self, b, seed=0):

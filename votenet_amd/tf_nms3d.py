@@ -29,9 +29,11 @@ def iou3d_cross(boxes_a, boxes_b):
     return iou
 
 
-def NMS3D(bboxes, scores, objectiveness, iou_threshold):
+def NMS3D(bboxes, scores, objectiveness, iou_threshold, padded=False):
     """tf_nms3d.py:11-12.  (B,N,8,3), (B,N), (B,N,2) f32, scalar in [0,1] -> (Nsel,2) int32 [batch, box]
-    in descending-score visit order over the whole batch (tf_nms3d.cpp:202-273).  No gradient."""
+    in descending-score visit order over the whole batch (tf_nms3d.cpp:202-273).  No gradient.
+    padded=True: -> (rows (B*N,2), count (1,) int32) both on the device, rows[:count] valid -- no host synchronisation
+    (the (Nsel,2) shape of the reference needs the count on the host, which stalls a pipelined inference loop)."""
     bboxes = L.dev_f32(bboxes.detach(), "3D NMS expects (batch_size, nbbox, 8, 3) bbox shape.", 4, 3)
     if bboxes.shape[2] != 8:
         raise L.InvalidArgumentError("3D NMS expects (batch_size, nbbox, 8, 3) bbox shape.")
@@ -53,5 +55,7 @@ def NMS3D(bboxes, scores, objectiveness, iou_threshold):
     with torch.cuda.device(bboxes.device):
         L.check(L.lib().votenet_nms3d(b, n, L.ptr(bboxes), L.ptr(scores), L.ptr(objectiveness), float(iou_threshold),
                                       L.ptr(out), L.ptr(count), L.ptr(ws), wbytes, L.stream_ptr()))
+    if padded:
+        return out, count
     nsel = int(count.item())  # dynamic output length (the TF op allocates (Nsel,2) the same way)
     return out[:nsel]
