@@ -316,6 +316,9 @@ def test_nms_random_golden(ops, dev, golden):
     for thr, key in [(0.25, "keep_025"), (0.5, "keep_050")]:
         assert not (np.abs(g["iou"] - thr) < 1e-5).any()
         assert (N(ops.n.NMS3D(bb, sc, ob, thr)) == g[key]).all()
+        rows, count = ops.n.NMS3D(bb, sc, ob, thr, padded=True)  # no host synchronisation: padded rows + device count
+        assert rows.shape == (bb.shape[0] * bb.shape[1], 2) and int(count) == len(g[key])
+        assert (N(rows)[:int(count)] == g[key]).all()
 
 
 def test_nms_full_size_vs_oracle(ops, dev, O):
