@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path's headline benchmark (contract: see the task statement / DESIGN.md).
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N>1: either launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or -- when WORLD_SIZE is
+not set -- bench.py starts the N ranks itself as child processes before anything touches the GPU (launch_ranks).
 
 One "step" = one pass of the hot path over one batch of 8 synthetic 20480-point scenes per GPU
 (BASELINE.json configs[2]/[3]: VoteNet layer stack sa1..sa4, fp1, fp2, voting, proposal).
@@ -34,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default=None, choices=["train", "fwd"])
     ap.add_argument("--scene", default="room", choices=["room", "uniform"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="launcher self-test on CPU (gloo rendezvous, no kernels, nothing measured)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra unpipelined / alone-on-the-GPU measurements (profiling)")
     ap.add_argument("--no-gram", action="store_true", help="pooled layers: direct backward GEMMs on the stored z instead of the Gram form")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -105,11 +109,85 @@ def cpu_baseline_scene(points, scene_kind, seed=1000):
                       "(single thread, %.1f s; the oracle has no backward)" % (points, dt)}
 
 
-def main():
-    args = parse()
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes (one per GPU,
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and forward rank 0's JSON line.  The parent
+    never touches the GPU (no HIP call, no torch.cuda.is_available(): only device_count(), which does not initialise it
+    on this image) and never re-execs itself.  A failed child ends the others and makes the whole run fail."""
+    import socket
+    import subprocess
+    import tempfile
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible\n" % (args.gpus, have))
+            return 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    out0 = tempfile.TemporaryFile(mode="w+")
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
+    codes = [None] * len(procs)
+    while any(c is None for c in codes):
+        for r, p in enumerate(procs):
+            if codes[r] is None:
+                codes[r] = p.poll()
+        if any(c not in (None, 0) for c in codes):  # one rank died: the others would wait in the collective forever
+            for r, p in enumerate(procs):
+                if codes[r] is None:
+                    p.kill()  # exactly the PIDs started above
+                    codes[r] = p.wait()
+            break
+        time.sleep(0.05)
+    out0.seek(0)
+    sys.stdout.write(out0.read())
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
+        return 1
+    return 0
+
+
+def dry_run(args):
+    """Launcher self-test without a GPU (`--dry-run`, used by tests/): the ranks rendezvous over gloo exactly as the real run
+    does over RCCL, all-reduce one number and rank 0 prints a line with n_gpus; no kernel runs, nothing is measured."""
     import torch
     import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if os.environ.get("VOTENET_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        sys.exit(3)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([float(rank + 1)])
+    if world > 1:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"metric": "dry run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
+                          "rank_sum": float(t.item())}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args)
+    import torch
+    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
