@@ -7,7 +7,8 @@
  * pinned by (i) the known answer for the reference's own smoke input
  * (tf_ops/3d_nms/tf_nms3d.py:21-46; SURVEY.md section 4: thr 0.5 -> [[0,1],[0,0]],
  * thr 0.25 -> [[0,1]], BEV intersection 0.6227418) and (ii) an independent
- * Sutherland-Hodgman clipping cross-check in tests/test_oracle_nms.py.
+ * Sutherland-Hodgman clipping cross-check in tests/test_oracle_properties.py
+ * (test_iou_against_independent_clipping, test_nms_semantics).
  *
  * C++ (not C) on purpose: the reference's vertex ordering goes through std::sort and its
  * visit order through std::priority_queue; using the same libstdc++ containers keeps the

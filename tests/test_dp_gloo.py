@@ -78,3 +78,139 @@ def test_single_process_is_noop():
     P.make_mlp(store, "m", 4, [4], "fc")
     store.materialize(0)
     assert dp.world_size() == 1 and dp.sync_gradients(store) == 1.0
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The REAL train_step host path on two ranks (CPU, gloo), kernels stubbed: forward / the modules' backward / the optimizer
+# kernel are replaced by torch stand-ins that produce rank-dependent gradients; everything between them -- the tape walk of
+# _backward, dp.GradSync (tail all-reduce started after sa3's backward, head after the last weight gradient), the 1/world
+# scale handed to the optimizer -- is the product code.
+def _torch_clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5, beta1=0.9, beta2=0.999, eps=1e-8):
+    """model.py:240-250 as votenet_clip_adam computes it (per-tensor clip_by_average_norm, then TensorFlow's Adam)."""
+    seg = seg.tolist()
+    lr_t = lr * (1 - beta2 ** step) ** 0.5 / (1 - beta1 ** step)
+    for a, b in zip(seg[0::2], seg[1::2]):
+        gg = g[a:b] * grad_scale
+        avg = gg.norm() / (b - a)
+        gg = gg * clip / max(float(avg), clip)
+        m[a:b] = beta1 * m[a:b] + (1 - beta1) * gg
+        v[a:b] = beta2 * v[a:b] + (1 - beta2) * gg * gg
+        p[a:b] -= lr_t * m[a:b] / (v[a:b].sqrt() + eps)
+
+
+def _stub_grad(name, shape, rank, step):
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000 + 1000 * rank + step)
+    return torch.randn(shape, generator=g) * (3.0 if "sa1" in name else 0.01)
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from votenet_amd import dp
+    from votenet_amd import mlp as M
+    from votenet_amd import model as VM
+    from votenet_amd import pointnet2 as P
+    cpu = torch.device("cpu")
+    net = VM.VoteNetHotPath(cpu, seed=rank)     # replicas start different ...
+    dp.broadcast_params(net.store)              # ... one broadcast makes them identical
+    p_start = net.store.flat.clone()
+    net.overlap_wgrad = False
+    net._side_stream = lambda: None
+    net.store.refresh_transposes = lambda stream=None: None
+    net.update_moving_averages = lambda tape: None
+    events, step_no = [], [0]
+    B, NS = 2, net.sa2.npoint
+
+    def fill(layers):
+        for L in layers:
+            for k in ("W", "b") + (("gamma", "beta") if L.bn else ()):
+                L.gp(k).add_(_stub_grad(L.name + "/" + k, L.gp(k).shape, rank, step_no[0]))
+
+    def stub_forward(x, tape=None, next_x=None):
+        for op in ("sa", "sa", "sa", "sa", "fp", "fp"):
+            tape.append(dict(op=op))
+        tape.append(dict(op="vote", recs=[], b=B, n=NS))
+        tape.append(dict(op="sa", fps_idx=None))
+        return dict(proposals_output=torch.zeros(B, 256, 79))
+
+    def sa_backward(mod, name, n_in, c_in):
+        def f(rec, g_out, need_feat_grad=True, need_xyz_grad=False):
+            events.append(name + ".backward")
+            fill(mod.mlp + (mod.mlp2 or []))
+            return (torch.zeros(B, n_in, c_in) if need_feat_grad else None), (torch.zeros(B, n_in, 3) if need_xyz_grad else None)
+        return f
+
+    def fp_backward(mod, name, n1, c1, m, c2):
+        def f(rec, dy):
+            events.append(name + ".backward")
+            fill(mod.mlp)
+            return torch.zeros(B, n1, c1), torch.zeros(B, m, c2)
+        return f
+
+    net.forward = stub_forward
+    net.proposal.backward = sa_backward(net.proposal, "proposal", NS, 256)
+    net.sa4.backward = sa_backward(net.sa4, "sa4", net.sa3.npoint, 256)
+    net.sa3.backward = sa_backward(net.sa3, "sa3", net.sa2.npoint, 256)
+    net.sa2.backward = sa_backward(net.sa2, "sa2", net.sa1.npoint, 128)
+    net.sa1.backward = sa_backward(net.sa1, "sa1", 64, 3)
+    net.fp2.backward = fp_backward(net.fp2, "fp2", net.sa2.npoint, 256, net.sa3.npoint, 256)
+    net.fp1.backward = fp_backward(net.fp1, "fp1", net.sa3.npoint, 256, net.sa4.npoint, 256)
+
+    def chain_backward(recs, g, mode, **kw):
+        events.append("voting.backward")
+        fill(net.voting)
+        return torch.zeros_like(g)
+    P.mlp_chain_backward = chain_backward
+    M.clip_adam = _torch_clip_adam
+    net._gsync = dp.GradSync(net.store, net.store.offset_of("sa3/"))
+    real_tail = net._gsync.start_tail
+    net._gsync.start_tail = lambda streams=None: (events.append("tail all-reduce issued"), real_tail(streams))[1]
+
+    net.init_optimizer(lr=1e-3)
+    # expected: the same optimizer on the MEAN of the two ranks' gradients
+    p_exp = p_start.clone()
+    m_exp, v_exp = torch.zeros_like(p_exp), torch.zeros_like(p_exp)
+    logs = []
+    cot = dict(proposals_output=torch.zeros(B, 256, 79), votes_xyz=None)
+    for step in (1, 2):
+        step_no[0] = step
+        events.clear()
+        net.train_step(torch.zeros(B, 64, 3), cot, world)
+        logs.append((list(events), list(net._gsync.log)))
+        g_sum = torch.zeros_like(p_exp)
+        for r in range(world):
+            for name, v in net.store.gviews.items():
+                off = v.storage_offset()
+                g_sum[off:off + v.numel()] += _stub_grad(name, v.shape, r, step).reshape(-1)
+        _torch_clip_adam(net._seg, None, p_exp, g_sum, m_exp, v_exp, 1e-3, step, grad_scale=1.0 / world)
+    q.put((rank, net.store.flat.clone(), p_exp, p_start, logs, net.store.grad.numel(), net.store.offset_of("sa3/")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_step_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, f0, e0, s0, logs0, numel, split), (_, f1, e1, s1, logs1, _, _) = res
+    assert torch.equal(s0, s1)                       # identical replicas at the start (broadcast)
+    assert torch.equal(f0, f1)                       # ... and after two optimizer steps: bit-identical parameters
+    assert not torch.equal(f0, s0)
+    assert torch.allclose(f0, e0, rtol=1e-6, atol=1e-9) and torch.allclose(f1, e1, rtol=1e-6, atol=1e-9)  # the mean-gradient update
+    for events, colls in logs0 + logs1:
+        # two collectives per step, contiguous slices of the one flat bucket: tail = sa3 ... proposal, head = sa1 + sa2
+        assert colls == [("tail", numel - split), ("head", split)]
+        order = [e for e in events if e.endswith(".backward") or e.startswith("tail")]
+        assert order == ["proposal.backward", "voting.backward", "fp2.backward", "fp1.backward", "sa4.backward", "sa3.backward",
+                         "tail all-reduce issued", "sa2.backward", "sa1.backward"]
+    assert 0 < split < 0.1 * numel                   # the part that cannot be overlapped is small (sa1 + sa2: 8 % of the bucket)

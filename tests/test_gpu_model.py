@@ -206,3 +206,65 @@ def test_prefetched_geometry_is_the_same_computation(hiplib, dev):
     c2 = net.forward(xc)
     for k in ref_b:
         assert torch.equal(ref_b[k], b2[k]) and torch.equal(ref_c[k], c2[k]), k
+
+
+def test_moving_averages_follow_tensorflows_update(hiplib, dev):
+    """The BatchNorm moving averages (reference: Tensorpack BNReLU, momentum 0.9): after a training-mode forward pass
+    moving = 0.9 * moving + 0.1 * (batch mean | unbiased batch variance) for every BatchNorm layer, starting from 0 / 1; the
+    batch statistics themselves are checked against torch on the stored z of a layer."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    x = torch.from_numpy(synth.room_batch(2, 4096, 9)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=4, npoints=(512, 256, 128, 64))
+    names = [L.name for L in net._bn_layers()]
+    assert len(names) == 23 and len(set(names)) == 23
+    exp = {n: (torch.zeros(L.cout, device=dev), torch.ones(L.cout, device=dev)) for n, L in zip(names, net._bn_layers())}
+    for _ in range(2):
+        tape = []
+        net.forward(x, tape)
+        seen = 0
+        for r in net._bn_records(tape):
+            rows = r["rows"]
+            m, v = exp[r["layer"].name]
+            exp[r["layer"].name] = (0.9 * m + 0.1 * r["mean"], 0.9 * v + 0.1 * r["var"] * (rows / (rows - 1.0)))
+            if r["z"] is not None and r["kind"] == "dense":
+                z = r["z"].double()
+                assert torch.allclose(r["mean"].double(), z.mean(0), rtol=1e-4, atol=1e-6)
+                assert torch.allclose(r["var"].double(), z.var(0, unbiased=False), rtol=1e-4, atol=1e-7)
+            seen += 1
+        assert seen == 23
+        net.update_moving_averages(tape)
+    for n in names:
+        assert torch.allclose(net._ema[n][2], exp[n][0], rtol=1e-6, atol=1e-7), n
+        assert torch.allclose(net._ema[n][3], exp[n][1], rtol=1e-6, atol=1e-7), n
+
+
+def test_predict_uses_moving_averages_so_a_scene_does_not_depend_on_its_batch_mates(hiplib, dev):
+    """model.py:98-139 runs under `not is_training`: BatchNorm uses the moving averages, so the detections of a scene are
+    the same whatever shares its batch (round-1 advice: predict() normalised with the batch's own statistics)."""
+    from votenet_amd import loss as VL
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    sa, sb, sc = (synth.room_batch(1, 4096, s) for s in (41, 42, 43))
+    net = VM.VoteNetHotPath(dev, seed=5, npoints=(512, 256, 128, 64))
+    xt = torch.from_numpy(synth.room_batch(2, 4096, 7)).to(dev)
+    gt = VL.gt_to_device(synth.room_gt(2, 4096, 7), dev)
+    for _ in range(3):  # a few optimizer steps: moving averages and weights away from their initial values
+        net.train_step(xt, gt=gt)
+    T = lambda *s: torch.from_numpy(np.concatenate(s)).to(dev)
+    r_ab, r_ac, r_a = net.predict(T(sa, sb)), net.predict(T(sa, sc)), net.predict(T(sa))
+    for k in ("proposals_output", "bboxes", "scores", "votes_xyz"):
+        assert torch.equal(r_ab[k][0], r_ac[k][0]), k
+        assert torch.allclose(r_ab[k][0], r_a[k][0], rtol=1e-5, atol=1e-6), k
+        assert torch.isfinite(r_ab[k]).all()
+    keep = lambda r: [int(b) for s, b in N(r["nms_idx"]) if s == 0]
+    assert keep(r_ab) == keep(r_ac) == keep(r_a)
+    # the training-mode normalisation does depend on the batch (what predict() did before)
+    o_ab = net.predict(T(sa, sb), batch_statistics=True)["proposals_output"][0]
+    o_ac = net.predict(T(sa, sc), batch_statistics=True)["proposals_output"][0]
+    assert not torch.equal(o_ab, o_ac)
+    # frozen scale / shift are cached until the weights or the averages change
+    f1 = net.inference_bn()
+    assert net.inference_bn() is f1
+    net.train_step(xt, gt=gt)
+    assert net.inference_bn() is not f1

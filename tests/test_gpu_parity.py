@@ -120,6 +120,59 @@ def test_fps_full_size_properties(ops, dev):
         assert td[idx[s, j]] >= td.max() * (1 - 1e-5)
 
 
+def _headline_cloud(kind):
+    from votenet_amd import synth
+    return synth.room_batch(8, 20480, 1000) if kind == "room" else synth.uniform_batch(8, 20480, 1000)
+
+
+@pytest.mark.parametrize("kind", ["room", "uniform"])
+def test_fps_sa1_full_size_default_mode_bit_exact(ops, dev, O, kind):
+    """The headline launch itself -- fps_bucket_sort_kernel + fps_bucket_kernel<12,32> in its DEFAULT mode, 8 x 20480 -> 2048
+    (BASELINE configs[1]/[2], the shape bench.py's roofline is quoted on) -- equals the oracle's restatement of
+    tf_sampling_g.cu:105-170 on every one of the 8 x 2048 indices, on the bench's own room scenes and on the uniform cube."""
+    xyz = _headline_cloud(kind)
+    got = N(ops.s.farthest_point_sample(2048, T(xyz, dev)))
+    exp = O.farthest_point_sample(2048, xyz)
+    assert got.shape == (8, 2048) and (got == exp).all(), int((got != exp).sum())
+
+
+@pytest.mark.parametrize("kind", ["room", "uniform"])
+def test_ball_query_sa1_full_size_bit_exact(ops, dev, O, kind):
+    """sa1's ball query at full size (8 x 2048 centres x 20480 candidates, r = 0.2, K = 64; tf_grouping_g.cu:3-36): every
+    neighbour list and every pts_cnt equals the oracle (itself equal to the reference's compiled CPU twin,
+    tests/test_oracle_golden.py).  Room scenes have full balls (10 % reach K), the uniform cube none (full scan)."""
+    xyz = _headline_cloud(kind)
+    new_xyz = O.gather_point(xyz, O.farthest_point_sample(2048, xyz))
+    idx, cnt = ops.g.query_ball_point(0.2, 64, T(xyz, dev), T(new_xyz, dev))
+    oi, oc = O.query_ball_point(0.2, 64, xyz, new_xyz)
+    assert (N(cnt) == oc).all() and (N(idx) == oi).all()
+    assert oc.min() >= 1 and ((oc == 64).mean() > 0.05 if kind == "room" else (oc == 64).mean() < 0.01)  # full balls only in rooms
+
+
+def test_config5_scene_fps_and_ball_query_bit_exact(ops, dev, O):
+    """BASELINE config 5's first level on full-size scenes (80 000 points -> 2048 centres, r = 0.2, K = 64): the L2-resident
+    FPS variant (fps_bucket_l2_kernel) and the ball query against the oracle, index for index, on two scenes of the batch
+    (the oracle needs ~0.6 s per scene for these two ops; it is the MLP stack that takes minutes)."""
+    from votenet_amd import synth
+    xyz = synth.room_batch(2, 80000, 77, size=(8.0, 3.0, 8.0), nbox=(15, 25))
+    x = T(xyz, dev)
+    fidx = ops.s.farthest_point_sample(2048, x)
+    exp = O.farthest_point_sample(2048, xyz)
+    assert (N(fidx) == exp).all()
+    new_xyz = ops.s.gather_point(x, fidx)
+    idx, cnt = ops.g.query_ball_point(0.2, 64, x, new_xyz)
+    oi, oc = O.query_ball_point(0.2, 64, xyz, O.gather_point(xyz, exp))
+    assert (N(cnt) == oc).all() and (N(idx) == oi).all()
+    # levels below: 2048 -> 1024 (seeds) through the prefix check, r = 0.4
+    l1 = N(new_xyz)
+    f2 = ops.s.farthest_point_sample(1024, new_xyz)
+    e2 = O.farthest_point_sample(1024, l1)
+    assert (N(f2) == e2).all()
+    i2, c2 = ops.g.query_ball_point(0.4, 64, new_xyz, ops.s.gather_point(new_xyz, f2))
+    oi2, oc2 = O.query_ball_point(0.4, 64, l1, O.gather_point(l1, e2))
+    assert (N(c2) == oc2).all() and (N(i2) == oi2).all()
+
+
 def test_fps_reference_launcher_shim_large_batch(ops, dev, hiplib):
     """tf_sampling.cpp:94,115: the reference calls farthestpointsamplingLauncher with a TensorShape{32,n} scratch whatever
     the batch.  The exported shim (C++ linkage, the reference's exact signature) must give the op's result with exactly
@@ -331,6 +384,25 @@ def test_nms_full_size_vs_oracle(ops, dev, O):
     if not (np.abs(iou - 0.25) < 1e-5).any():
         assert (keep == exp).all()
     assert np.allclose(N(ops.n.iou3d_matrix(bb)), iou, rtol=0, atol=1e-5, equal_nan=True)
+
+
+def test_nms_nan_scores_are_ordered_last_not_out_of_bounds(ops, dev, O):
+    """A diverged model emits NaN logits.  The visit order must stay a permutation of the candidates (NaN ranks with -inf,
+    ties by flat index): before, every NaN candidate took rank 0 and the tail of the order buffer was uninitialised memory
+    used as an index.  Expected result = the oracle's on the same boxes with NaN replaced by -inf."""
+    c = cases.nms_random(b=2, n=64, seed=5)
+    sc = c["scores"].copy()
+    sc[0, 3] = sc[0, 40] = sc[1, 7] = sc[1, 8] = sc[1, 63] = np.nan
+    allobj = np.tile(np.array([0.0, 1.0], np.float32), (2, 64, 1))
+    for _ in range(3):
+        keep = N(ops.n.NMS3D(T(c["bboxes"], dev), T(sc, dev), T(allobj, dev), 0.25))
+        assert len(keep) and (keep[:, 0] >= 0).all() and (keep[:, 0] < 2).all() and (keep[:, 1] >= 0).all() and (keep[:, 1] < 64).all()
+        assert len({(int(a), int(b)) for a, b in keep}) == len(keep)
+        finite = [(int(a), int(b)) for a, b in keep if np.isfinite(sc[a, b])]
+        exp = O.nms3d(c["bboxes"], np.where(np.isnan(sc), -np.inf, sc).astype(np.float32), allobj, 0.25)
+        exp_f = [(int(a), int(b)) for a, b in exp if np.isfinite(sc[a, b])]
+        assert finite == exp_f  # the finite-score part of the visit order is untouched, NaN boxes come after it
+        assert [tuple(r) for r in keep.tolist()][:len(finite)] == finite
 
 
 def test_nms_edge_cases(ops, dev):

@@ -567,7 +567,9 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(long groups, int
 }
 
 // ---------------------------------------------------------------- optimizer
-// sum of squares of every tensor's gradient segment: grid (8 slices, ntensors), atomics into out[tensor]
+// sum of squares of every tensor's gradient segment: grid (8 slices, ntensors) -> out[tensor * 8 + slice]; the optimizer adds
+// the eight partials in slice order (no atomics: every data-parallel replica must compute bit-identical clip factors from
+// the same all-reduced gradient, or the replicas drift apart)
 __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict__ g, const long *__restrict__ seg,
                                                         float *__restrict__ out)
 {
@@ -581,10 +583,12 @@ __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict_
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0 && sh[0] != 0.0f) unsafeAtomicAdd(&out[blockIdx.y], sh[0]);
+    if (threadIdx.x == 0) out[blockIdx.y * 8 + blockIdx.x] = sh[0];
 }
 
-// tf.clip_by_average_norm(g, clip): g * clip / max(||g||/numel, clip)   (model.py:249), then Adam
+// tf.clip_by_average_norm(g, clip): g * clip / max(||g||/numel, clip)   (model.py:249), then tf.train.AdamOptimizer
+// (model.py:246) in TensorFlow's form: lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t);  p -= lr_t * m / (sqrt(v) + eps)
+// -- epsilon is NOT rescaled by the bias correction there ("epsilon hat" of the Adam paper, section 2)
 __global__ void clip_adam_kernel(const long *__restrict__ seg, const float *__restrict__ sumsq, float *__restrict__ p,
                                  const float *__restrict__ g, float *__restrict__ m, float *__restrict__ v, float lr, float b1,
                                  float b2, float eps, float bc1, float bc2, float gscale, float clip)
@@ -592,16 +596,20 @@ __global__ void clip_adam_kernel(const long *__restrict__ seg, const float *__re
     const long a = seg[2 * blockIdx.y], b = seg[2 * blockIdx.y + 1];
     float factor = gscale;
     if (clip > 0.0f) {
-        const float avg = sqrtf(sumsq[blockIdx.y]) * gscale / (float)(b - a);
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; t++) ss += sumsq[blockIdx.y * 8 + t];
+        const float avg = sqrtf(ss) * gscale / (float)(b - a);
         factor = gscale * clip / (avg > clip ? avg : clip);
     }
+    const float lr_t = lr * sqrtf(bc2) / bc1;
     for (long i = a + (long)blockIdx.x * blockDim.x + threadIdx.x; i < b; i += (long)gridDim.x * blockDim.x) {
         const float gg = g[i] * factor;
         const float mm = b1 * m[i] + (1.0f - b1) * gg;
         const float vv = b2 * v[i] + (1.0f - b2) * gg * gg;
         m[i] = mm;
         v[i] = vv;
-        p[i] -= lr * (mm / bc1) / (sqrtf(vv / bc2) + eps);
+        p[i] -= lr_t * mm / (sqrtf(vv) + eps);
     }
 }
 
@@ -877,7 +885,6 @@ extern "C" int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scr
     VN_REQUIRE(seg && sumsq_scratch && p && g && m && v, "clip_adam: null buffer");
     hipStream_t st = as_stream(stream);
     if (clip_avg_norm > 0.0f) {
-        (void)hipMemsetAsync(sumsq_scratch, 0, sizeof(float) * ntensors, st);
         hipLaunchKernelGGL(seg_sumsq_kernel, dim3(8, ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
     }
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);

@@ -181,11 +181,15 @@ __global__ void nms_rank_kernel(int total, const float *__restrict__ scores, con
     if (e >= total) return;
     const bool cand = obj[e * 2 + 1] > obj[e * 2]; // tf_nms3d.cpp:230
     if (!cand) return;
-    const float s = scores[e];
+    // a TOTAL order even for the scores of a diverged model: NaN ranks with -inf (visited last), ties by flat index --
+    // every candidate gets its own rank, so order[0 .. ncand) is a permutation of the candidates
+    const float s0 = scores[e];
+    const float s = (s0 != s0) ? -__builtin_inff() : s0;
     int rank = 0;
     for (int f = 0; f < total; f++) {
         const bool fc = obj[f * 2 + 1] > obj[f * 2];
-        const float t = scores[f];
+        const float t0 = scores[f];
+        const float t = (t0 != t0) ? -__builtin_inff() : t0;
         if (fc && (t > s || (t == s && f < e))) rank++;
     }
     order[rank] = e;

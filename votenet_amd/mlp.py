@@ -100,6 +100,22 @@ class PendingBN:
         return self.out[0], self.out[1]
 
 
+class FrozenBN:
+    """Inference-mode BatchNorm of a layer (the reference's BNReLU with is_training=False uses the moving averages):
+    scale = gamma * rsqrt(moving_var + eps), shift = beta - moving_mean * scale, computed once per set of weights
+    (VoteNetHotPath.inference_bn).  Same interface as a finalized PendingBN: every consumer takes `done` -> scale / shift."""
+    done = True
+
+    def __init__(self, out):
+        self.out = out  # (2, c): scale | shift
+
+    scale = property(lambda self: self.out[0])
+    shift = property(lambda self: self.out[1])
+
+    def finalize(self):
+        return self.out[0], self.out[1]
+
+
 def _desc_dense(x, scale=None, shift=None, relu=True, in_bn=None):
     d = L.MlpInput()
     if in_bn is not None:

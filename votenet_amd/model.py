@@ -191,12 +191,83 @@ class VoteNetHotPath:
         from . import loss as VL
         return VL.decode_boxes(proposals_xyz, proposals_output)
 
-    def predict(self, x, iou_threshold=0.25, next_x=None, sync=True):
-        """Predict tower of model.py:98-139: forward -> decode -> NMS3D(bboxes, max class logit, objectness, 0.25).
+    # ---- BatchNorm moving averages (training) and the inference-mode BatchNorm built from them ----------------------
+    BN_MOMENTUM = 0.9  # Tensorpack BatchNorm default (`momentum=0.9`, epsilon 1e-5); Tensorpack is not in the reference tree
+
+    def _bn_layers(self):
+        mods = [self.sa1, self.sa2, self.sa3, self.sa4, self.fp1, self.fp2, self.proposal]
+        layers = [L for m in mods for L in m.mlp + (getattr(m, "mlp2", None) or [])] + list(self.voting)
+        return [L for L in layers if L.bn]
+
+    def _ema_state(self):
+        """name -> (4, c) tensor [unused | unused | moving_mean | moving_var] (the layout of PendingBN.out, so that one
+        multi-tensor launch updates every layer); initial values 0 / 1 as TensorFlow initialises them.  Kept OUTSIDE the
+        gradient bucket: the moving averages are not trained and never all-reduced (statistics stay per replica)."""
+        if getattr(self, "_ema", None) is None:
+            self._ema = {}
+            for L in self._bn_layers():
+                t = torch.zeros((4, L.cout), dtype=torch.float32, device=self.device)
+                t[3].fill_(1.0)
+                self._ema[L.name] = t
+            self._ema_fac = {}
+            self._ema_version = 0
+        return self._ema
+
+    @staticmethod
+    def _bn_records(tape):
+        for t in tape:
+            for r in t.get("recs", []) + t.get("recs2", []):
+                if r.get("bn_out") is not None:
+                    yield r
+
+    def update_moving_averages(self, tape):
+        """moving = momentum * moving + (1 - momentum) * batch for the mean and the UNBIASED batch variance (what
+        tf.nn.fused_batch_norm hands to the moving-average update) of every BatchNorm layer of this forward pass: two
+        multi-tensor launches per step on the (scale | shift | mean | var) blocks the consumers' prologues left behind."""
+        ema = self._ema_state()
+        dst, src, fac = [], [], []
+        for r in self._bn_records(tape):
+            name, rows = r["layer"].name, r["rows"]
+            key = (name, rows)
+            if key not in self._ema_fac:
+                f = torch.full((4, r["layer"].cout), 1.0 - self.BN_MOMENTUM, dtype=torch.float32, device=self.device)
+                f[3].mul_(rows / max(rows - 1.0, 1.0))
+                self._ema_fac[key] = f
+            dst.append(ema[name])
+            src.append(r["bn_out"])
+            fac.append(self._ema_fac[key])
+        if dst:
+            torch._foreach_mul_(dst, self.BN_MOMENTUM)
+            torch._foreach_addcmul_(dst, src, fac)
+            self._ema_version += 1
+
+    def inference_bn(self):
+        """name -> mlp.FrozenBN (scale = gamma rsqrt(moving_var + eps), shift = beta - moving_mean scale); rebuilt only when
+        the parameters or the moving averages changed since the last call."""
+        ema = self._ema_state()
+        key = (self._ema_version, getattr(self, "_step", 0), self.store.flat._version)
+        if getattr(self, "_frozen_key", None) != key:
+            self._frozen = {}
+            for L in self._bn_layers():
+                e = ema[L.name]
+                sc = L.p("gamma") * torch.rsqrt(e[3] + M.BN_EPS)
+                self._frozen[L.name] = M.FrozenBN(torch.stack([sc, L.p("beta") - e[2] * sc]).contiguous())
+            self._frozen_key = key
+        return self._frozen
+
+    def predict(self, x, iou_threshold=0.25, next_x=None, sync=True, batch_statistics=False):
+        """Predict tower of model.py:98-139: forward -> decode -> NMS3D(bboxes, max class logit, objectness, 0.25), every
+        BatchNorm in inference mode (moving averages, as the reference's BNReLU under `not is_training`): a scene's
+        detections do not depend on its batch-mates.  batch_statistics=True normalises with the current batch instead
+        (what a model without trained moving averages needs, e.g. random-init benchmarks).
         next_x: the batch(es) of the next call(s), as in forward().  sync=False: nms_idx stays padded on the device with its
         length in nms_count (no host synchronisation: calls pipeline)."""
         from . import tf_nms3d
-        out = self.forward(x, next_x=next_x)
+        P.FROZEN_BN = None if batch_statistics else self.inference_bn()
+        try:
+            out = self.forward(x, next_x=next_x)
+        finally:
+            P.FROZEN_BN = None
         boxes, score = self.decode_boxes(out["proposals_xyz"], out["proposals_output"])
         keep = tf_nms3d.NMS3D(boxes, score, out["proposals_output"][..., :2].contiguous(), iou_threshold, padded=not sync)
         extra = {} if sync else dict(nms_count=keep[1])
@@ -248,6 +319,10 @@ class VoteNetHotPath:
         d_l3p = d_l3p + g3
         g2, _ = self.sa3.backward(sa3, d_l3p)
         d_l2p = d_l2p + g2
+        # every gradient of sa3 ... proposal (the tail of the flat bucket) is enqueued: its all-reduce runs on the
+        # communication stream underneath the backward pass of sa2 and sa1 (dp.GradSync; a no-op on one GPU)
+        if getattr(self, "_gsync", None) is not None:
+            self._gsync.start_tail([P.WGRAD_STREAM])
         g1, _ = self.sa2.backward(sa2, d_l2p)
         self.sa1.backward(sa1, g1, need_feat_grad=False)
 
@@ -260,14 +335,15 @@ class VoteNetHotPath:
             a = (s.views[name].data_ptr() - base) // 4
             seg += [a, a + math.prod(shape)]
         self._seg = torch.tensor(seg, dtype=torch.int64, device=self.device)
-        self._sumsq = torch.zeros(len(seg) // 2, dtype=torch.float32, device=self.device)
+        self._sumsq = torch.zeros(8 * (len(seg) // 2), dtype=torch.float32, device=self.device)  # 8 ordered partials per tensor
         self._m = torch.zeros_like(s.flat)
         self._v = torch.zeros_like(s.flat)
         self._step = 0
         self._lr = lr
 
     def train_step(self, x, cot=None, world=1, gt=None, next_x=None):
-        """forward + loss + backward + (world>1: ONE RCCL all-reduce of the flat gradient bucket) + clip/Adam.
+        """forward + loss + backward + (world>1: the RCCL all-reduce of the flat gradient bucket, its tail overlapped with the
+        backward pass of sa2 / sa1: dp.GradSync) + clip/Adam.
         gt: ground truth on the device (loss.gt_to_device): the reference's total cost (model.py:228) drives the backward
         pass, its components are left in self.last_losses (device, loss.NAMES).  cot: fixed cotangents instead (tests)."""
         if not hasattr(self, "_seg"):
@@ -277,12 +353,16 @@ class VoteNetHotPath:
         self.store.refresh_transposes(self._side_stream())
         tape = []
         out = self.forward(x, tape, next_x=next_x)
+        self.update_moving_averages(tape)
         if gt is not None:
             from . import loss as VL
             self.last_losses, cot = VL.votenet_loss(out, gt)
-        self.backward(tape, cot)
+        if getattr(self, "_gsync", None) is None:
+            self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))
+        self._gsync.begin()
+        self.backward(tape, cot)                # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
         self.store.invalidate_transposes()      # the optimizer changes W
-        gscale = dp.sync_gradients(self.store)  # ONE all-reduce (sum) of the flat bucket; 1/world goes to the optimizer
+        gscale = self._gsync.finish()           # head all-reduce + wait for both; 1/world goes to the optimizer
         self._step += 1
         M.clip_adam(self._seg, self._sumsq, self.store.flat, self.store.grad, self._m, self._v, self._lr, self._step,
                     grad_scale=gscale)

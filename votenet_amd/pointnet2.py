@@ -112,6 +112,13 @@ class ParamStore:
             self.gviews[name] = self.grad[off:off + n].view(shape)
         return self
 
+    def offset_of(self, prefix):
+        """Element offset inside the flat bucket of the first tensor whose name starts with `prefix` (declaration order)."""
+        for name, _, _ in self._specs:
+            if name.startswith(prefix):
+                return self.views[name].storage_offset()
+        raise KeyError(prefix)
+
     def __getitem__(self, name):
         return self.views[name]
 
@@ -163,6 +170,9 @@ POOL_IN_EPILOGUE = True
 # Backward of that pooled layer in Gram form (pool_bwd.hip): both GEMMs contract over cin x cin instead of cin x cout and z
 # of the layer is neither stored nor read.  False = votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn on the stored z.
 POOL_GRAM_BACKWARD = True
+# Inference mode of every BatchNorm (model.py:98-139 runs with is_training=False): dict layer name -> mlp.FrozenBN built from the
+# moving averages (VoteNetHotPath.inference_bn); None = training mode (batch statistics).  Set by VoteNetHotPath.predict.
+FROZEN_BN = None
 
 
 def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
@@ -208,9 +218,12 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
         else:
             zn, st = M.linear_dense(z, w, b, None, None, prev_relu, want_stats=L.bn, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
-        if L.bn:
+        if L.bn and FROZEN_BN is not None:
+            pend = FROZEN_BN[L.name]  # moving averages: the batch sums of this launch are ignored
+            rec.update(scale=pend.scale, shift=pend.shift)
+        elif L.bn:
             pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows)
-            rec.update(scale=pend.scale, shift=pend.shift, mean=pend.mean, var=pend.var)
+            rec.update(scale=pend.scale, shift=pend.shift, mean=pend.mean, var=pend.var, bn_out=pend.out)
         else:
             pend = None
         rec.update(z=zn, rows=rows, pool=pool)
