@@ -45,68 +45,12 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(points, scene_kind, min_seconds=10.0, max_scenes=4):
-    """cpu_baseline_scene repeated until about min_seconds of CPU work have been timed (bounded sample)."""
-    tot, k = 0.0, 0
-    while k == 0 or (k < max_scenes and tot < min_seconds):
-        r = cpu_baseline_scene(points, scene_kind, 1000 + k)
-        tot += 1.0 / r["value"]
-        k += 1
-    r["value"] = k / tot
-    r["sample"] = r["sample"].replace("1 synthetic", "%d synthetic" % k).replace("scene through", "scene%s through" % ("s" if k > 1 else ""))
-    r["sample"] = r["sample"][:r["sample"].index("(single thread")] + "(single thread, %.1f s in total; the oracle has no backward)" % tot
-    return r
-
-
-def cpu_baseline_scene(points, scene_kind, seed=1000):
-    """The CPU oracle (the restatement of the reference's CPU path, oracle/) timed on ONE scene of the
-    same workload, forward only, single thread.  Bounded: ~10-30 s."""
-    import numpy as np
-    from oracle import oracle as O
-    from votenet_amd import synth
-    xyz = (synth.room_batch(1, points, seed) if scene_kind == "room" else synth.uniform_batch(1, points, seed))
-    rng = np.random.default_rng(0)
-
-    def mlp(x, dims, k=None, last_plain=False):
-        for i in range(len(dims) - 1):
-            w = (rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i])).astype(np.float32)
-            z = O.linear(x, w, np.zeros(dims[i + 1], np.float32))
-            if last_plain and i == len(dims) - 2:
-                x = z
-            else:
-                mean, var = O.bn_stats(z)
-                x = O.bn_relu(z, mean, var, np.ones(dims[i + 1], np.float32), np.zeros(dims[i + 1], np.float32))
-        return O.max_over_k(x, k) if k else x
-
-    def sa(xyz_, pts, m, r, k, widths, sample_xyz=None):
-        fidx = O.farthest_point_sample(m, sample_xyz if sample_xyz is not None else xyz_)
-        new_xyz = O.gather_point(xyz_, fidx)
-        idx, _ = O.query_ball_point(r, k, xyz_, new_xyz)
-        g = O.group_concat(xyz_, new_xyz, pts, idx).reshape(-1, 3 + pts.shape[2])
-        return new_xyz, mlp(g, [g.shape[1]] + widths, k).reshape(1, m, -1)
-
-    def fp(x1, x2, p1, p2, widths):
-        dist, idx = O.three_nn(x1, x2)
-        itp = O.three_interpolate(p2, idx, O.three_nn_weights(dist))
-        x = np.concatenate([itp, p1], 2).reshape(-1, itp.shape[2] + p1.shape[2])
-        return mlp(x, [x.shape[1]] + widths).reshape(1, x1.shape[1], -1)
-
-    t0 = time.perf_counter()
-    l1x, l1p = sa(xyz, xyz, 2048, 0.2, 64, [64, 64, 128])
-    l2x, l2p = sa(l1x, l1p, 1024, 0.4, 64, [128, 128, 256])
-    l3x, l3p = sa(l2x, l2p, 512, 0.8, 64, [128, 128, 256])
-    l4x, l4p = sa(l3x, l3p, 256, 1.2, 64, [128, 128, 256])
-    l3p2 = fp(l3x, l4x, l3p, l4p, [256, 256])
-    seeds = fp(l2x, l3x, l2p, l3p2, [256, 256])
-    x = np.concatenate([l2x, seeds], 2).reshape(-1, 259)
-    votes = (x + mlp(x, [259, 256, 256, 259], last_plain=True)).reshape(1, 1024, 259)
-    vx, vp = np.ascontiguousarray(votes[..., :3]), np.ascontiguousarray(votes[..., 3:])
-    px, pp = sa(vx, vp, 256, 0.3, 64, [128, 128, 128], sample_xyz=l2x)
-    mlp(pp.reshape(-1, 128), [128, 128, 128, 79], last_plain=True)
-    dt = time.perf_counter() - t0
-    return {"value": 1.0 / dt, "unit": "scenes/s", "cores": 1, "kind": "port",
-            "sample": "forward pass of 1 synthetic %d-pt scene through the same layer stack on the CPU oracle "
-                      "(single thread, %.1f s; the oracle has no backward)" % (points, dt)}
+def cpu_baseline(points, scene_kind, min_seconds=8.0, max_scenes=3, ops=True):
+    """The CPU oracle timed on this host (tools/bench_legs.cpu_baseline): forward of whole scenes single-thread and on all cores
+    (OpenMP), CPU model / core counts, per-op medians.  Bounded sample (~25 s)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_legs
+    return bench_legs.cpu_baseline(points, scene_kind, min_seconds=min_seconds, max_scenes=max_scenes, ops=ops)
 
 
 def launch_ranks(args):
@@ -261,13 +205,16 @@ def main():
     events, bq_events, gemm_events = [], [], []
     gc.collect()
     gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
     t0 = time.perf_counter()
+    marks[0].record()
     for i in range(args.steps):
         if i == prof_steps:
             events, tf_sampling.PROFILE_EVENTS = tf_sampling.PROFILE_EVENTS, None
             bq_events, tf_grouping.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS, None
             gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
         step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -282,6 +229,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(prof_steps, args.steps))  # un-instrumented steps, main stream
+    spread = ({"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
+               "steps": len(per_step), "what": "ms between consecutive step boundaries on the main stream (HIP events), steps without "
+                                               "kernel-level timing events"} if per_step else None)
 
     # the same step with every batch's geometry computed inside its own step (nothing carried across steps): reported beside
     # the headline value, not instead of it
@@ -330,18 +281,22 @@ def main():
         if durs:
             avg_ms = sum(durs) / len(durs)
             alg = B * (m1 - 1) * n * 16 + B * n * 12 + B * m1 * 4  # B*(m-1)*n*16 + B*n*12 + B*m*4
-            traffic = None
+            # HBM bytes per launch come from a separate rocprofv3 --pmc pass (PMC counters cannot be read inside this process):
+            # the committed summary profiles/pmc_latest.json, labelled as such -- null when the file is absent
+            traffic, traffic_src = None, None
             pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
             if os.path.exists(pmc):
                 try:
-                    traffic = json.load(open(pmc)).get("fps_sa1", {}).get("hbm_bytes_per_launch")
+                    pj = json.load(open(pmc))
+                    traffic = pj.get("fps_sa1", {}).get("hbm_bytes_per_launch")
+                    traffic_src = "profiles/pmc_latest.json (%s): separate rocprofv3 --pmc passes, not measured in this run" % pj.get("source", "")
                 except Exception:
                     traffic = None
             ach = alg / (avg_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "kernel": "fps_bucket_sort_kernel + fps_bucket_kernel<12,32> (sa1 FPS %d->%d, register resident, "
                                              "exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                    "traffic": traffic, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg,
+                    "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg,
                     "alone_on_the_gpu": ({"avg_launch_ms": round(iso_fps, 4), "frac": round(alg / (iso_fps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
                                          if iso_fps else None)}
         # the sa1 ball query (n=20480 candidates, 2048 centres, K=64) and the pair the north star names: FPS + ball query
@@ -389,6 +344,18 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(n, args.scene)
+        # every BASELINE.json configuration in this line (1: single SA layer, 2: backbone forward, 3b: predict tower + NMS,
+        # 5: dense 80000-pt scan; 3a = the headline value, 4 = this command with --gpus 8) + what the ball query really scans
+        cfgs = bq_detail = None
+        if world == 1 and not args.headline_only:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_legs
+            cfgs = bench_legs.config_legs(net, xs, gts, dev, B, n, cpu=not args.no_cpu_baseline)
+            cfgs["config3_train_step"] = "= the headline value of this line (forward + loss graph + backward + clip/Adam)"
+            cfgs["config4_dp8"] = "python bench.py --gpus 8 (one rank per GPU, RCCL all-reduce of the flat gradient bucket, tail overlapped with backward)"
+            bq_detail = bench_legs.ball_query_detail(net.sa1, xs[0], torch.from_numpy(synth.uniform_batch(B, n, 1000)).to(dev))
+            if bq is not None:
+                bq["alone_on_the_gpu_detail"] = bq_detail
         out = {
             "metric": "SUN RGB-D 20k-pt scenes/sec (%s)" % ("fwd+bwd" if workload == "train" else "fwd"),
             "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
@@ -401,7 +368,7 @@ def main():
                                     + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
                                        "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
-            "without_cross_step_pipelining": in_step,
+            "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "configs": cfgs,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

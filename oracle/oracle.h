@@ -112,6 +112,10 @@ void oracle_cumsum(int b, int n, const float *inp, float *out);
 /* tf_sampling_g.cu:88-104,197-200 ; temp = b*n floats (the running sums) */
 void oracle_prob_sample(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out);
 
+/* liboracle_omp.so (the same sources with -fopenmp, oracle/Makefile): OpenMP thread count of the parallel-for loops over
+ * independent queries / rows / FPS lanes; a no-op in liboracle.so.  bench.py's all-core cpu_baseline only. */
+void oracle_set_threads(int n);
+
 #ifdef __cplusplus
 }
 #endif

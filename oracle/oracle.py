@@ -30,16 +30,41 @@ def build(quiet=True):
         print(out.stdout)
 
 
+def _load(name):
+    path = os.path.join(_DIR, name)
+    if not os.path.exists(path):
+        build()
+    L = ctypes.CDLL(path)
+    L.oracle_bev_intersection.restype = ctypes.c_float
+    L.oracle_iou3d.restype = ctypes.c_float
+    L.oracle_nms3d.restype = ctypes.c_int
+    return L
+
+
+_OMP = None
+_THREADS = 1
+
+
+def set_threads(n):
+    """n == 1 (default): liboracle.so, the single-thread restatement with the reference's loop structure.  n > 1: the same
+    sources built with -fopenmp (liboracle_omp.so) on n threads -- bit-identical results (tests/test_oracle_omp.py); this is
+    bench.py's all-core cpu_baseline figure.  Returns the previous setting."""
+    global _THREADS, _OMP
+    prev, _THREADS = _THREADS, max(1, int(n))
+    if _THREADS > 1:
+        if _OMP is None:
+            _OMP = _load("liboracle_omp.so")
+            _OMP.oracle_set_threads.restype = None
+        _OMP.oracle_set_threads(_THREADS)
+    return prev
+
+
 def lib():
     global _LIB
+    if _THREADS > 1:
+        return _OMP
     if _LIB is None:
-        path = os.path.join(_DIR, "liboracle.so")
-        if not os.path.exists(path):
-            build()
-        _LIB = ctypes.CDLL(path)
-        _LIB.oracle_bev_intersection.restype = ctypes.c_float
-        _LIB.oracle_iou3d.restype = ctypes.c_float
-        _LIB.oracle_nms3d.restype = ctypes.c_int
+        _LIB = _load("liboracle.so")
     return _LIB
 
 

@@ -20,6 +20,7 @@ void oracle_query_ball_point(int b, int n, int m, float radius, int nsample,
                              const float *xyz1, const float *xyz2, int *idx, int *pts_cnt)
 {
     for (int i = 0; i < b; ++i) {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp): independent queries */
         for (int j = 0; j < m; ++j) {
             int cnt = 0;
             for (int l = 0; l < nsample; ++l) idx[j * nsample + l] = 0;
@@ -90,6 +91,7 @@ void oracle_group_concat(int b, int n, int c, int m, int nsample, const float *x
 {
     int co = 3 + c;
     for (int i = 0; i < b; ++i) {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp): independent queries */
         for (int j = 0; j < m; ++j)
             for (int k = 0; k < nsample; ++k) {
                 int ii = idx[j * nsample + k];

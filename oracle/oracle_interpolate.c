@@ -16,6 +16,7 @@ void oracle_three_nn(int b, int n, int m, const float *xyz1, const float *xyz2,
                      float *dist, int *idx)
 {
     for (int i = 0; i < b; ++i) {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp): independent queries */
         for (int j = 0; j < n; ++j) {
             float x1 = xyz1[j * 3 + 0];
             float y1 = xyz1[j * 3 + 1];
@@ -74,6 +75,7 @@ void oracle_three_interpolate(int b, int m, int c, int n, const float *points,
                               const int *idx, const float *weight, float *out)
 {
     for (int i = 0; i < b; ++i) {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp): independent queries */
         for (int j = 0; j < n; ++j) {
             float w1 = weight[j * 3], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
             int i1 = idx[j * 3], i2 = idx[j * 3 + 1], i3 = idx[j * 3 + 2];
@@ -93,6 +95,7 @@ void oracle_three_interpolate_grad(int b, int n, int c, int m, const float *grad
                                    const int *idx, const float *weight, float *grad_points)
 {
     for (int i = 0; i < b; ++i) {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp): independent queries */
         for (int j = 0; j < n; ++j) {
             float w1 = weight[j * 3], w2 = weight[j * 3 + 1], w3 = weight[j * 3 + 2];
             int i1 = idx[j * 3], i2 = idx[j * 3 + 1], i3 = idx[j * 3 + 2];

@@ -20,6 +20,7 @@
 
 void oracle_linear(long rows, int cin, int cout, const float *x, const float *w, const float *bias, float *z)
 {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
     for (long r = 0; r < rows; r++) {
         const float *xr = x + (size_t)r * cin;
         float *zr = z + (size_t)r * cout;
@@ -36,6 +37,7 @@ void oracle_linear(long rows, int cin, int cout, const float *x, const float *w,
 
 void oracle_bn_stats(long rows, int c, const float *z, float *mean, float *var)
 {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
     for (int o = 0; o < c; o++) {
         double s = 0;
         for (long r = 0; r < rows; r++) s += z[(size_t)r * c + o];
@@ -53,6 +55,7 @@ void oracle_bn_stats(long rows, int c, const float *z, float *mean, float *var)
 void oracle_bn_relu(long rows, int c, const float *z, const float *mean, const float *var,
                     const float *gamma, const float *beta, float eps, int relu, float *y)
 {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
     for (int o = 0; o < c; o++) {
         float scale = gamma[o] / sqrtf(var[o] + eps);
         float shift = beta[o] - mean[o] * scale;
@@ -67,6 +70,7 @@ void oracle_bn_relu(long rows, int c, const float *z, const float *mean, const f
 /* utils.py:132 reduce_max over the nsample axis */
 void oracle_max_over_k(long groups, int k, int c, const float *y, float *out)
 {
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
     for (long g = 0; g < groups; g++)
         for (int o = 0; o < c; o++) {
             float m = y[((size_t)g * k) * c + o];

@@ -33,6 +33,7 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int
             float x1 = pts[old * 3 + 0];
             float y1 = pts[old * 3 + 1];
             float z1 = pts[old * 3 + 2];
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so: the 512 "threads" of a round are independent */
             for (int t = 0; t < FPS_BLOCK; t++) {
                 int besti = 0;
                 float best = -1;
@@ -132,3 +133,11 @@ void oracle_gather_point_grad(int b, int n, int m, const float *out_g, const int
             inp_g[((size_t)i * n + a) * 3 + 2] += out_g[((size_t)i * m + j) * 3 + 2];
         }
 }
+
+/* liboracle_omp.so only: number of OpenMP threads for the `parallel for` loops (a no-op in liboracle.so) */
+#ifdef _OPENMP
+#include <omp.h>
+void oracle_set_threads(int n) { omp_set_num_threads(n > 0 ? n : 1); }
+#else
+void oracle_set_threads(int n) { (void)n; }
+#endif

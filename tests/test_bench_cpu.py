@@ -6,9 +6,29 @@ import bench
 
 
 def test_cpu_baseline_leg_runs_and_reports_the_contract_fields():
-    out = bench.cpu_baseline(2560, "room", min_seconds=0.0)
-    assert set(out) == {"value", "unit", "cores", "kind", "sample"}
-    assert out["unit"] == "scenes/s" and out["cores"] == 1 and out["kind"] == "port" and out["value"] > 0
+    out = bench.cpu_baseline(2560, "room", min_seconds=0.0, max_scenes=1, ops=False)
+    assert {"value", "unit", "cores", "kind", "sample", "value_1t", "value_all", "cpu_model", "physical_cores"} <= set(out)
+    assert out["unit"] == "scenes/s" and out["cores"] >= 1 and out["kind"] == "port" and out["value_1t"] > 0 and out["value_all"] > 0
+    assert out["value"] == out["value_all"] and isinstance(out["cpu_model"], str)
+
+
+def test_ball_query_scanned_pair_count_from_the_outputs():
+    """bench_legs.ball_query_pairs: the reference stops a query at its K-th hit; the kernel stops a 64-query workgroup when all are
+    full, in 4096-candidate super-chunks."""
+    import os
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import bench_legs
+    n, k = 10000, 4
+    idx = torch.zeros(1, 128, k, dtype=torch.int32)
+    cnt = torch.full((1, 128), k, dtype=torch.int32)
+    idx[0, :, k - 1] = 99                      # every query of both workgroups full after candidate 99
+    idx[0, 70, k - 1] = 5000                   # ... except one query of the second workgroup: needs two super-chunks
+    cnt[0, 3] = 2                              # a query of the first workgroup never fills: full scan for its workgroup
+    p = bench_legs.ball_query_pairs(idx, cnt, n)
+    assert p["all_pairs"] == 128 * n
+    assert p["reference_algorithm"] == 126 * 100 + 5001 + n
+    assert p["kernel"] == 64 * n + 64 * 8192
 
 
 def test_default_arguments_are_one_gpu_and_a_short_run(monkeypatch):
