@@ -13,11 +13,12 @@ from . import _lib as L
 # bench.py sets this to a list to bracket every GEMM launch with HIP events on the launch stream:
 # entries are (start, end, kind, flops) with kind in {"linear_dense", "linear_gather", "wgrad_dense", "wgrad_gather"}.
 PROFILE_EVENTS = None
+PROFILE_SHAPES = None  # tools/gemm_table.py: not None -> entries also carry (rows, cin, cout, note)
 
 
 class _Timed:
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, shape=None):
+        self.kind, self.flops, self.shape = kind, flops, shape
 
     def __enter__(self):
         if PROFILE_EVENTS is not None:
@@ -27,7 +28,7 @@ class _Timed:
     def __exit__(self, *a):
         if PROFILE_EVENTS is not None:
             self.e1.record()
-            PROFILE_EVENTS.append((self.e0, self.e1, self.kind, self.flops))
+            PROFILE_EVENTS.append((self.e0, self.e1, self.kind, self.flops) if PROFILE_SHAPES is None else (self.e0, self.e1, self.kind, self.flops, self.shape))
 
 
 class _StatsArena:
@@ -156,7 +157,7 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     stats = _zeros_f64(2 * cout, x.device) if want_stats else None
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
-    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
+    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd" + ("+bn" if (in_scale is not None or in_bn is not None) else ""))):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -179,7 +180,7 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
     stats = _zeros_f64(2 * cout, xyz.device) if want_stats else None
     d = _desc_gather(xyz, new_xyz, feat, idx)
-    with torch.cuda.device(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout):
+    with torch.cuda.device(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout, (rows, cin, cout, "gather")):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -201,7 +202,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
     args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
-    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout):
+    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool")):
         L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
                                                 L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
     return z, stats, (vals[0], vals[1], args[0], args[1])
@@ -274,7 +275,7 @@ def gram(xz, scale_shift, relu):
     """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c)."""
     rows, c = xz.shape
     g = torch.zeros((c + 1, c), dtype=torch.float32, device=xz.device)  # [gram ; column sums (filled by pool_wgrad)]
-    with torch.cuda.device(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c):
+    with torch.cuda.device(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
         L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.stream_ptr()))
     return g
 
@@ -412,7 +413,7 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
     rows, cin = x.shape
     cout = z.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
-    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout):
+    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad_bn")):
         L.check(L.lib().votenet_mlp_wgrad_bn(ctypes.byref(d), rows, cin, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z),
                                              L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.stream_ptr()))
 
@@ -422,7 +423,7 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0):
     rows, c = z.shape
     cout = wT.shape[1]
     out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout):
+    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))
     return out
@@ -440,7 +441,7 @@ def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
     rows, cin = x.shape
     cout = dz.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
-    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout):
+    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad")):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.stream_ptr()))
 
 
@@ -448,7 +449,7 @@ def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
     b, m, k = idx.shape
     c = feat.shape[2] if feat is not None else 0
     d = _desc_gather(xyz, new_xyz, feat, idx)
-    with torch.cuda.device(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1]):
+    with torch.cuda.device(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1], (b * m * k, 3 + c, dz.shape[1], "wgrad_gather")):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.stream_ptr()))
 
 
