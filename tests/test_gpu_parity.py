@@ -326,6 +326,19 @@ def test_interpolate_demo_golden(ops, dev, golden):
     assert sha(N(out)) == str(g["out_sha"])
 
 
+@pytest.mark.parametrize("n,m", [(77, 3), (100, 9), (1000, 1024), (333, 1025), (2050, 2500), (64, 7)])
+def test_three_nn_ties_and_tiles_vs_oracle(ops, dev, O, n, m):
+    """three_nn splits the known points over eight lanes per query and over LDS tiles of 1024: the merge must rank equal
+    distances by index exactly as the reference's serial strict-'<' cascade (tf_interpolate.cpp:74-89).  Lattice clouds:
+    most queries see many exactly equal distances, in different lanes and in different tiles; duplicated known points."""
+    rng = np.random.default_rng(n * 31 + m)
+    xyz1 = (np.round(rng.random((2, n, 3), dtype=np.float32) * 4) / 2).astype(np.float32)
+    xyz2 = (np.round(rng.random((2, m, 3), dtype=np.float32) * 4) / 2).astype(np.float32)
+    dist, idx = ops.i.three_nn(T(xyz1, dev), T(xyz2, dev))
+    od, oi = O.three_nn(xyz1, xyz2)
+    assert (N(idx) == oi).all() and (N(dist) == od).all()
+
+
 @pytest.mark.parametrize("b,n,m,c", [(2, 300, 40, 8), (1, 1024, 512, 256), (1, 50, 2, 4), (1, 50, 1, 5), (8, 512, 256, 256)])
 def test_three_nn_interpolate_vs_oracle(ops, dev, O, b, n, m, c):
     rng = np.random.default_rng(n + m)
