@@ -620,6 +620,310 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     }
 }
 
+// ------------------------------------------------------------------ exact bucket-pruned FPS, asynchronous director / workers
+// fps_bucket_kernel runs every round in lock step: all waves test their boxes, update their touched buckets, reduce, meet
+// at a barrier, exchange -- about 2000 cycles of dependent latency per round, most of it on waves whose buckets cannot
+// hold the next sample anyway.  Here the round's critical path is ONE wave:
+//
+//   director (wave 0)   holds, for every bucket, its box and an UPPER BOUND of its largest running distance with the tie
+//                       key and the coordinates of the point that attained it.  A round: arg-max over the bounds (per-lane
+//                       compare over its slots + one DPP wave arg-max), emit the sample, publish its coordinates in the LDS
+//                       centre log, box-test all buckets against it and mark the touched ones (need[bucket] = number of
+//                       centres it must have seen).  No barrier, no LDS read, nothing waits for a worker -- unless the
+//                       arg-max bucket itself is marked: then the director asks for exactly that bucket (hint) and waits
+//                       until it has been brought up to date, takes its new entry and repeats the arg-max.
+//   workers (waves 1..) own the points (registers, as before).  Each polls need[] of its buckets and FLUSHES a marked one:
+//                       applies every centre of the log it has not seen yet (min with the un-fused fp32 distance,
+//                       tf_sampling_g.cu:142-143), re-reduces the bucket's (max, tie key, second max, arg-max coordinates)
+//                       and publishes the entry with applied = centres seen.
+//
+// Exactness.  Running distances only decrease, so a stale entry is an upper bound of its bucket; an unmarked bucket's
+// entry is exact (a centre that fails the conservative box test cannot lower any of its distances).  The director emits a
+// sample only from an UNMARKED bucket whose exact (max, key) is first among all bounds in the order (value descending,
+// key ascending) -- hence first among all true values: the brute-force arg-max with the reference's tie rule.  A stale
+// key never wins wrongly: the points of a bucket that still hold its old maximum are a subset of those that held it, so
+// the true key is not smaller than the stale one.  After a pick the director lowers that bucket's bound to its second
+// maximum (every other point is <= it) and always marks the bucket.  Results are bit-identical to fps_bucket_kernel and
+// to the oracle (tests/test_gpu_parity.py); what changes is that buckets near a new centre -- whose distances have just
+// dropped, i.e. the ones least likely to hold the next sample -- are brought up to date off the critical path.
+struct FaEntry {
+    unsigned bmax, sec, key;
+    float x, y, z;
+    int applied;
+    int pad;
+};
+constexpr int FA_NS = 6; // director slots per lane: up to 384 buckets
+__device__ unsigned long long g_fa_dbg[8]; // scene 0: rounds, pulls, spin iterations, cycles waiting, cycles total (votenet_fps_async_stats)
+
+__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <int NWK, int VW>
+__global__ __launch_bounds__((NWK + 1) * 64) void fps_async_kernel(int n, int m, const float *__restrict__ xyz,
+                                                                   const int *__restrict__ perm, const float *__restrict__ bbox,
+                                                                   int *__restrict__ out)
+{
+    constexpr int P = VW;
+    constexpr int NBC = NWK * P; // bucket capacity
+    typedef typename SlotVec<VW>::type vec_t;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float4 *s_cent = reinterpret_cast<float4 *>(smem);                                   // m centres (the samples' coordinates)
+    FaEntry *s_entry = reinterpret_cast<FaEntry *>(smem + (size_t)m * 16);               // NBC entries
+    int *s_need = reinterpret_cast<int *>(smem + (size_t)m * 16 + (size_t)NBC * 32);     // NBC
+    int *s_ctl = s_need + NBC;                                                           // [0] head (-1: done), [1 + worker] hint
+    unsigned *s_key = reinterpret_cast<unsigned *>(s_ctl + 16);                          // NBC * 64 tie keys by (slot, worker, lane)
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
+    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    int *__restrict__ o = out + (size_t)blockIdx.x * m;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id_uniform();
+    const int nb = (n + 63) / 64;
+    const float c0x = pts[0], c0y = pts[1], c0z = pts[2];
+    for (int i = tid; i < NBC; i += (NWK + 1) * 64) s_need[i] = 0;
+    if (tid < 16) s_ctl[tid] = tid == 0 ? 1 : (tid == 15 ? 0 : -1);
+    if (tid == 0) s_cent[0] = make_float4(c0x, c0y, c0z, 0.0f);
+
+    if (w > 0) {
+        // ================================================================ worker
+        const int wk = w - 1;
+        vec_t X, Y, Z, TD;
+#pragma unroll
+        for (int i = 0; i < P; i++) {
+            const int g = i * NWK + wk;
+            const int p = g * 64 + lane;
+            const bool valid = p < n;
+            unsigned key = 0xFFFFFFFFu;
+            float px = 0.f, py = 0.f, pz = 0.f;
+            if (valid) {
+                const int k = pm[p];
+                px = pts[(size_t)k * 3 + 0];
+                py = pts[(size_t)k * 3 + 1];
+                pz = pts[(size_t)k * 3 + 2];
+                key = fps_tiekey((unsigned)k);
+            }
+            X[i] = px;
+            Y[i] = py;
+            Z[i] = pz;
+            TD[i] = valid ? 1e38f : 0.0f; // tf_sampling_g.cu:118; an empty slot never wins
+            s_key[(size_t)(i * NWK + wk) * 64 + lane] = key;
+        }
+        // bring slot i from `a` centres seen to `h` and publish its entry
+        auto flush = [&](int i, int a, int h) {
+            const float px = X[i], py = Y[i], pz = Z[i]; // uniform i: s_set_gpr_idx reads
+            unsigned td = fbits(TD[i]);
+            for (int r = a; r < h; r++) {
+                const float4 c = s_cent[r];
+                const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
+                const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
+                td = min(fbits(d), td);                      // :143
+            }
+            TD[i] = __uint_as_float(td);
+            const unsigned key = s_key[(size_t)(i * NWK + wk) * 64 + lane];
+            unsigned nmax, nkey;
+            const int nl = wave_argmax(td, key, nmax, nkey);
+            const float ax = readlane_f32(px, nl), ay = readlane_f32(py, nl), az = readlane_f32(pz, nl);
+            // what the bucket can still hold once its arg-max point q has been sampled: a point closer to q than t = max / 4
+            // drops below t (the update evaluates exactly this expression), any other point keeps at most its value ->
+            // bound = max(sec, t) with sec = largest running distance among the points NOT closer than t
+            const float fx = px - ax, fy = py - ay, fz = pz - az;
+            const float fd = fx * fx + fy * fy + fz * fz;
+            const unsigned sec = wmax_u32(fd < 0.25f * __uint_as_float(nmax) ? 0u : td);
+            if (lane == 0) {
+                FaEntry *e = &s_entry[i * NWK + wk];
+                e->bmax = nmax;
+                e->sec = sec;
+                e->key = nkey;
+                e->x = ax;
+                e->y = ay;
+                e->z = az;
+                lds_order(); // the fields land before the count that releases them (LDS executes a wave's accesses in order)
+                lds_st(&e->applied, h);
+            }
+        };
+        __syncthreads(); // s_cent[0], s_ctl, s_need
+#pragma unroll 1
+        for (int i = 0; i < P; i++)
+            if (i * NWK + wk < nb) flush(i, 0, 1);
+        __syncthreads(); // every entry holds "centre 0 applied": the director reads them all
+        const int myg = lane * NWK + wk; // lane i < P watches the bucket of slot i
+        const bool has = lane < P && myg < nb;
+        int applied_l = 1;
+        int seen = 0; // value of the marks counter at the last scan that found nothing to do
+        while (true) {
+            if (lds_ld(&s_ctl[0]) < 0) break;
+            const int mk = lds_ld(&s_ctl[15]);       // centres whose box tests are complete (all their needs are written)
+            const int hint = lds_ld(&s_ctl[1 + wk]); // the slot the director wants first (its last sample's bucket / a leading bucket)
+            int i = -1;
+            if (hint >= 0 && lds_ld(&s_need[hint * NWK + wk]) > __builtin_amdgcn_readlane(applied_l, hint)) i = hint;
+            if (i < 0) {
+                if (mk == seen) {
+                    __builtin_amdgcn_s_sleep(2);
+                    continue;
+                }
+                const int nd = has ? lds_ld(&s_need[myg]) : 0;
+                const unsigned long long mask = __ballot(nd > applied_l);
+                if (!mask) {
+                    seen = mk;
+                    continue;
+                }
+                i = __ffsll((long long)mask) - 1;
+            }
+            lds_order();
+            const int h = lds_ld(&s_ctl[0]); // read after the need: head >= every need published before it
+            if (h < 0) break;
+            flush(i, __builtin_amdgcn_readlane(applied_l, i), h);
+            if (lane == i) applied_l = h;
+        }
+        return;
+    }
+    // ==================================================================== director
+    __builtin_amdgcn_s_setprio(3);
+    float bxl[FA_NS], byl[FA_NS], bzl[FA_NS], bxh[FA_NS], byh[FA_NS], bzh[FA_NS];
+    unsigned bnd[FA_NS], bky[FA_NS], sec[FA_NS];
+    float ax[FA_NS], ay[FA_NS], az[FA_NS];
+    int nd[FA_NS];
+    bool hasb[FA_NS];
+#pragma unroll
+    for (int s = 0; s < FA_NS; s++) {
+        const int g = s * 64 + lane;
+        hasb[s] = g < nb;
+        const float *__restrict__ bb = bbox + ((size_t)blockIdx.x * nb + (hasb[s] ? g : 0)) * 6;
+        bxl[s] = hasb[s] ? bb[0] : INFINITY;
+        byl[s] = hasb[s] ? bb[1] : INFINITY;
+        bzl[s] = hasb[s] ? bb[2] : INFINITY;
+        bxh[s] = hasb[s] ? bb[3] : -INFINITY;
+        byh[s] = hasb[s] ? bb[4] : -INFINITY;
+        bzh[s] = hasb[s] ? bb[5] : -INFINITY;
+    }
+    __syncthreads();
+    __syncthreads(); // the workers' first flush
+#pragma unroll
+    for (int s = 0; s < FA_NS; s++) {
+        const int g = s * 64 + lane;
+        bnd[s] = 0u;
+        bky[s] = 0xFFFFFFFFu;
+        sec[s] = 0u;
+        ax[s] = ay[s] = az[s] = 0.0f;
+        nd[s] = 0;
+        if (hasb[s]) {
+            const FaEntry e = s_entry[g];
+            bnd[s] = e.bmax;
+            bky[s] = e.key;
+            sec[s] = e.sec;
+            ax[s] = e.x;
+            ay[s] = e.y;
+            az[s] = e.z;
+        }
+    }
+    FpsOut fo = {o, m, 0};
+    fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
+    unsigned long long dbg_pulls = 0, dbg_spins = 0, dbg_wait = 0, dbg_arg = 0, dbg_box = 0;
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
+    for (int j = 1; j < m; j++) {
+        int L, S;
+        unsigned kmin;
+        float cx, cy, cz;
+        while (true) {
+            const unsigned long long ta = __builtin_amdgcn_s_memtime();
+            // this lane's best slot under (bound descending, key ascending)
+            unsigned bv = bnd[0], bk = bky[0];
+            int bs = 0, bn = nd[0];
+            float px = ax[0], py = ay[0], pz = az[0];
+#pragma unroll
+            for (int s = 1; s < FA_NS; s++) {
+                const bool better = bnd[s] > bv || (bnd[s] == bv && bky[s] < bk);
+                bv = better ? bnd[s] : bv;
+                bk = better ? bky[s] : bk;
+                bs = better ? s : bs;
+                bn = better ? nd[s] : bn;
+                px = better ? ax[s] : px;
+                py = better ? ay[s] : py;
+                pz = better ? az[s] : pz;
+            }
+            unsigned vmax;
+            L = wave_argmax(bv, bk, vmax, kmin);
+            S = __builtin_amdgcn_readlane(bs, L);
+            const int pend = __builtin_amdgcn_readlane(bn, L);
+            dbg_arg += __builtin_amdgcn_s_memtime() - ta;
+            if (pend == 0) { // an unmarked bucket: its entry is exact and it is first among all bounds -> the sample
+                cx = readlane_f32(px, L);
+                cy = readlane_f32(py, L);
+                cz = readlane_f32(pz, L);
+                break;
+            }
+            // the leading bucket has centres to catch up with: ask its worker for it, wait, take the new entry, look again
+            const int g = S * 64 + L;
+            const int wk = g % NWK;
+            lds_st(&s_ctl[1 + wk], g / NWK);
+            const unsigned long long tw = __builtin_amdgcn_s_memtime();
+            dbg_pulls++;
+            while (lds_ld(&s_entry[g].applied) < pend) {
+                dbg_spins++;
+                __builtin_amdgcn_s_sleep(0);
+            }
+            dbg_wait += __builtin_amdgcn_s_memtime() - tw;
+            lds_order();
+            const FaEntry e = s_entry[g]; // no flush of g can be running: applied >= every need published for it
+            if (lane == L) {
+#pragma unroll
+                for (int s = 0; s < FA_NS; s++)
+                    if (s == S) {
+                        bnd[s] = e.bmax;
+                        bky[s] = e.key;
+                        sec[s] = e.sec;
+                        ax[s] = e.x;
+                        ay[s] = e.y;
+                        az[s] = e.z;
+                        nd[s] = 0;
+                    }
+            }
+        }
+        const unsigned long long tb = __builtin_amdgcn_s_memtime();
+        fo.put(j, (int)fps_key_to_index(kmin), tid);
+        if (j == m - 1) break;
+        // publish the centre, then mark what it can change (head before need: a worker that sees a need sees its centres)
+        s_cent[j] = make_float4(cx, cy, cz, 0.0f);
+        lds_order();
+        lds_st(&s_ctl[0], j + 1);
+        { // the sample's own bucket first: its worker starts on it while the boxes are tested
+            const int g = S * 64 + L;
+            lds_st(&s_need[g], j + 1);
+            lds_st(&s_ctl[1 + g % NWK], g / NWK);
+        }
+#pragma unroll
+        for (int s = 0; s < FA_NS; s++) {
+            const bool own = lane == L && s == S;
+            if (own) { // the sample's running distance becomes 0; see flush(): what is left is <= max(sec, max / 4)
+                const unsigned t = fbits(0.25f * __uint_as_float(bnd[s]));
+                bnd[s] = sec[s] > t ? sec[s] : t;
+            }
+            const float ex = fmaxf(fmaxf(bxl[s] - cx, cx - bxh[s]), 0.0f);
+            const float ey = fmaxf(fmaxf(byl[s] - cy, cy - byh[s]), 0.0f);
+            const float ez = fmaxf(fmaxf(bzl[s] - cz, cz - bzh[s]), 0.0f);
+            const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f; // below every fp32-evaluated point distance of the bucket
+            if (own || (hasb[s] && !(lb >= __uint_as_float(bnd[s])))) {
+                nd[s] = j + 1;
+                lds_st(&s_need[s * 64 + lane], j + 1);
+            }
+        }
+        lds_order();
+        lds_st(&s_ctl[15], j + 1); // every need of centre j is written: the workers scan
+        dbg_box += __builtin_amdgcn_s_memtime() - tb;
+    }
+    lds_order();
+    lds_st(&s_ctl[0], -1);
+    if (blockIdx.x == 0 && tid == 0) {
+        g_fa_dbg[0] = (unsigned long long)(m - 1);
+        g_fa_dbg[1] = dbg_pulls;
+        g_fa_dbg[2] = dbg_spins;
+        g_fa_dbg[3] = dbg_wait;
+        g_fa_dbg[4] = __builtin_amdgcn_s_memtime() - dbg_t0;
+        g_fa_dbg[5] = dbg_arg;
+        g_fa_dbg[6] = dbg_box;
+    }
+}
+
 // ------------------------------------------------------------------ exact bucket-pruned FPS, L2-resident points
 // ------------------------------------------------------------------ two samples per round
 // fps_bucket_kernel with up to TWO picks per round.  If q1 is the arg-max of a round and q2 the runner-up (in the full order:
@@ -1054,6 +1358,11 @@ extern "C" void votenet_fps_trace_read(unsigned long long *out, int reset)
     }
 }
 #endif
+extern "C" void votenet_fps_async_stats(unsigned long long *out) // of the last fps_async_kernel launch, scene 0
+{
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(votenet::g_fa_dbg), sizeof(unsigned long long) * 8);
+}
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
 static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)
@@ -1077,6 +1386,8 @@ extern "C" void votenet_fps_debug_prefix_check(int on) // measurement hook: 0 = 
 {
     g_fps_prefix_check = on;
 }
+static int g_fps_async = 1; // 0: the lock-step fps_bucket_kernel instead of the director / worker kernel (A/B measurements, tests)
+extern "C" void votenet_fps_debug_async(int on) { g_fps_async = on; }
 static int g_fps_two_pick = 0; // 1: two samples per round; 2: that kernel with the second pick disabled (measurement)
 extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
 {
@@ -1098,6 +1409,18 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
         }                                                                                                          \
         hipLaunchKernelGGL((fps_bucket2_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
                            (const float *)(temp + (size_t)b * n), out, g_fps_two_pick == 1 ? 1 : 0);               \
+    } while (0)
+#define FPS_ASYNC_LAUNCH(NWK, VW)                                                                                  \
+    do {                                                                                                           \
+        const size_t lds = (size_t)m * 16 + (size_t)NWK * VW * 36 + 64 + (size_t)NWK * VW * 64 * 4;                \
+        static size_t attr_lds = 0;                                                                                \
+        if (lds > attr_lds) {                                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_async_kernel<NWK, VW>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+            attr_lds = lds;                                                                                        \
+        }                                                                                                          \
+        hipLaunchKernelGGL((fps_async_kernel<NWK, VW>), dim3(b), dim3((NWK + 1) * 64), lds, st, n, m, inp, (const int *)temp, \
+                           (const float *)(temp + (size_t)b * n), out);                                            \
     } while (0)
 #define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
     do {                                                                                                           \
@@ -1146,6 +1469,8 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
         if (n <= 16 * 16 * 64) {
             if (single) FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
             else FPS_BUCKET2_LAUNCH(16, 16);
+        } else if (single && g_fps_async && n <= 11 * 32 * 64 && (size_t)m * 16 + 11 * 32 * 36 + 64 + 11 * 32 * 64 * 4 <= 160 * 1024) {
+            FPS_ASYNC_LAUNCH(11, 32); // director + 11 workers x 32 slots (n <= 22 528, m <= 3 700)
         } else {
             if (single) FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
             else FPS_BUCKET2_LAUNCH(12, 32);
