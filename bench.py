@@ -293,8 +293,8 @@ def main():
                 except Exception:
                     traffic = None
             ach = alg / (avg_ms * 1e-3) / 1e9
-            roof = {"bound": "hbm", "kernel": "fps_bucket_sort_kernel + fps_bucket_kernel<12,32> (sa1 FPS %d->%d, register resident, "
-                                             "exact bucket pruning)" % (n, m1),
+            roof = {"bound": "hbm", "kernel": "sidx_* (spatial index: 5 launches) + fps_bucket_kernel<12,32> (sa1 FPS %d->%d, register "
+                                             "resident, exact bucket pruning)" % (n, m1),
                     "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                     "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes": alg,
                     "alone_on_the_gpu": ({"avg_launch_ms": round(iso_fps, 4), "frac": round(alg / (iso_fps * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
@@ -308,8 +308,9 @@ def main():
             bq_alg = B * m1 * n * 12 + B * m1 * (K1 + 1) * 4  # B*m*n*12 + B*m*(K+1)*4
             ach = bq_alg / (bq_ms * 1e-3) / 1e9
             both = (alg + bq_alg) / ((avg_ms + bq_ms) * 1e-3) / 1e9
-            bq = {"bound": "hbm", "kernel": "ball_query_kernel<16> (sa1: %d candidates x %d centres, r=0.2, K=%d; candidates through the "
-                                            "scalar cache, on-chip)" % (n, m1, K1),
+            bq = {"bound": "hbm", "kernel": "ball_query_indexed_kernel<4> (sa1: %d candidates x %d centres, r=0.2, K=%d; only the buckets of "
+                                            "the FPS's spatial index that reach into the ball, index-ordered read-out through an LDS bitmap)"
+                                            % (n, m1, K1),
                   "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                   "avg_launch_ms": round(bq_ms, 4), "algorithmic_bytes": bq_alg,
                   "fps_plus_ball_query": {"achieved": round(both, 1), "frac": round(both / HBM_PEAK_GBS, 4),

@@ -49,8 +49,9 @@ const char *votenet_version(void);
  * kernel :105-170).  inp (b,n,3) -> out (b,m) int32.  temp: scratch of at least
  * votenet_fps_temp_floats(b,n) floats (the reference allocates 32*n, tf_sampling.cpp:115);
  * may be NULL when that function returns 0 (n <= 4096: the cloud lives in registers).  Above that the
- * scratch holds a Morton permutation + bucket boxes (about 1.1*n floats per scene, n <= 24 576) and
- * additionally the sorted points with their running distance (about 5.1*n floats per scene,
+ * scratch holds the cloud's SPATIAL INDEX (see votenet_spatial_index: about 5.3*n floats per scene), which the call
+ * builds and leaves behind for votenet_query_ball_point_indexed on the same cloud (was: 1.1*n floats per scene, n <= 24 576;
+ * about 5.1*n floats per scene,
  * n <= 262 144); beyond, the reference's running-distance rows.  Requires m > 0 (tf_sampling.cpp:99).
  * Bit-exact with the reference rule: start at 0, running distance 1e38, arg-max of
  * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
@@ -72,6 +73,21 @@ int votenet_gather_point(int b, int n, int m, const float *inp, const int *idx, 
 int votenet_gather_point_grad(int b, int n, int m, const float *out_g, const int *idx, float *inp_g, void *stream);
 
 /* ---------------------------------------------------------------- tf_ops/grouping */
+
+/* Spatial index of a batch of clouds (no reference counterpart: the reference scans every candidate for every query,
+ * tf_grouping_g.cu:13-35 / tf_sampling_g.cu:130-147).  Points sorted by Morton cell (16^3 grid over the cloud's bounding
+ * box) into buckets of 64 consecutive sorted points with their bounding boxes.  index: scratch of
+ * votenet_spatial_index_floats(b, n) floats, laid out as [perm b*n int | boxes b*nb*6 | sorted float4 b*nb*64 (16-byte
+ * aligned) | work], nb = ceil(n/64).  votenet_farthest_point_sample builds the same structure in its temp scratch for
+ * 4096 < n <= 262144, so a ball query on the cloud that was just sampled needs no second build. */
+size_t votenet_spatial_index_floats(int b, int n);
+int votenet_spatial_index(int b, int n, const float *xyz, float *index, void *stream);
+
+/* votenet_query_ball_point with the candidates' spatial index: identical idx / pts_cnt, but only the buckets whose box
+ * reaches into the query ball are tested (first-nsample-in-index-order through an n-bit LDS bitmap per query).
+ * index == NULL or n > 131072: falls back to votenet_query_ball_point. */
+int votenet_query_ball_point_indexed(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                     const float *xyz2, const float *index, int *idx, int *pts_cnt, void *stream);
 
 /* Replaces queryBallPointLauncher (tf_grouping.cpp:66, tf_grouping_g.cu:3-36,125-128).
  * xyz1 (b,n,3) candidates, xyz2 (b,m,3) queries -> idx (b,m,nsample), pts_cnt (b,m).

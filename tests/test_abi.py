@@ -79,8 +79,11 @@ def test_ball_threshold_table(hiplib):
 
 def test_workspace_queries(hiplib):
     assert hiplib.votenet_fps_temp_floats(8, 2048) == 0                         # register-resident, brute force
-    assert hiplib.votenet_fps_temp_floats(8, 20480) == 8 * (20480 + 6 * 320)    # Morton permutation + bucket boxes
-    assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * (80000 + 6 * 1250 + 256 * 1250 + 4)  # + sorted float4 points (L2)
+    work = 16 * 4096 + 6 * 16 + 8                                               # per-workgroup cell histograms + partial bounds
+    # the spatial index: Morton permutation + bucket boxes + sorted float4 points + work (also what the indexed ball query reads)
+    assert hiplib.votenet_fps_temp_floats(8, 20480) == 8 * (20480 + 6 * 320 + 256 * 320 + work) + 4
+    assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * (80000 + 6 * 1250 + 256 * 1250 + work) + 4
+    assert hiplib.votenet_spatial_index_floats(8, 20480) == hiplib.votenet_fps_temp_floats(8, 20480)
     assert hiplib.votenet_fps_temp_floats(4, 300000) == 4 * 300000              # unpruned streaming fallback
     assert hiplib.votenet_fps_temp_floats(64, 300000) == 32 * 300000            # tf_sampling.cpp:115: 32 rows whatever the batch
     assert hiplib.votenet_nms3d_workspace_bytes(8, 256) >= 8 * 256 * 256 * 4

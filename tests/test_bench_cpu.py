@@ -13,8 +13,8 @@ def test_cpu_baseline_leg_runs_and_reports_the_contract_fields():
 
 
 def test_ball_query_scanned_pair_count_from_the_outputs():
-    """bench_legs.ball_query_pairs: the reference stops a query at its K-th hit; the kernel stops a 64-query workgroup when all are
-    full, in 4096-candidate super-chunks."""
+    """bench_legs.ball_query_pairs: the reference stops a query at its K-th hit; the full-scan kernel stops a 64-query workgroup
+    when all are full, in 4096-candidate super-chunks."""
     import os
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

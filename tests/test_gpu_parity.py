@@ -251,6 +251,40 @@ def test_ball_query_vs_oracle(ops, dev, O, b, n, m, r, k):
     assert (N(idx) == oi).all()  # includes all-zero rows for queries with no neighbour
 
 
+@pytest.mark.parametrize("b,n,m,r,k,scale", [(2, 4097, 130, 0.25, 64, 1.0), (1, 9000, 257, 0.3, 16, 2.0), (2, 20480, 500, 0.2, 64, 5.0),
+                                             (1, 20480, 64, 9.0, 32, 5.0), (1, 24577, 100, 0.15, 8, 3.0), (1, 80000, 300, 0.2, 64, 8.0),
+                                             (1, 131072, 40, 0.1, 200, 4.0), (1, 5000, 33, 0.01, 4, 1.0)])
+def test_ball_query_over_the_spatial_index_equals_the_full_scan(ops, dev, O, b, n, m, r, k, scale):
+    """votenet_query_ball_point_indexed (bucket culling + index-ordered read-out through an LDS bitmap) against the full scan
+    and the oracle: same neighbour lists, same pts_cnt -- index built on its own, and the one a farthest-point sampling of
+    the same tensor leaves behind (n <= 24576: register kernel; above: the L2 kernel, which rewrites the sorted copy)."""
+    from votenet_amd import tf_sampling as S
+    rng = np.random.default_rng(n + m)
+    xyz1 = rng.random((b, n, 3), dtype=np.float32) * scale
+    xyz1[:, 7] = xyz1[:, 3]  # duplicates
+    xyz2 = rng.random((b, m, 3), dtype=np.float32) * scale
+    xyz2[:, 0] = 50.0        # a query with no neighbour: all-zero row, count 0
+    oi, oc = O.query_ball_point(r, k, xyz1, xyz2)
+    x1, x2 = T(xyz1, dev), T(xyz2, dev)
+    ops.g.USE_INDEX = False
+    try:
+        bi, bc = ops.g.query_ball_point(r, k, x1, x2)
+    finally:
+        ops.g.USE_INDEX = True
+    assert (N(bi) == oi).all() and (N(bc) == oc).all()
+    S._INDEX_CACHE.clear()
+    ii, ic = ops.g.query_ball_point(r, k, x1, x2)          # builds the index itself
+    assert S.cached_index(x1) is not None
+    assert (N(ii) == oi).all() and (N(ic) == oc).all()
+    S._INDEX_CACHE.clear()
+    S.farthest_point_sample(min(64, n), x1)                  # leaves the index behind
+    assert S.cached_index(x1) is not None
+    fi, fc = ops.g.query_ball_point(r, k, x1, x2)
+    assert (N(fi) == oi).all() and (N(fc) == oc).all()
+    x1.add_(0.0)                                             # version bump: the cached index is not trusted
+    assert S.cached_index(x1) is None
+
+
 def test_ball_query_boundary_radius(ops, dev, O):
     """Pairs at distance exactly r, one ulp below, one ulp above: sqrtf(s) < r must be decided as the reference does."""
     for r in [0.2, 0.4, 0.8, 1.2, 0.3, 0.1]:

@@ -186,7 +186,8 @@ def gpu_ms(fn, it=10, warm=3):
 def ball_query_pairs(idx, cnt, n, chunk=4096, wg_queries=64):
     """Scanned (query, candidate) pairs of a ball query, from its outputs:
       reference  tf_grouping_g.cu:13-35 stops a query at its K-th hit: sum over queries of (index of the K-th hit + 1, else n)
-      kernel     ball_query_kernel<16> scans super-chunks of 4096 candidates for a workgroup of 64 queries until all 64 are full
+      full_scan  ball_query_kernel<16> (no index) scans super-chunks of 4096 candidates for a workgroup of 64 queries until all
+                 64 are full
       all        m * n per scene."""
     import torch
     b, m, k = idx.shape
@@ -203,29 +204,51 @@ def ball_query_pairs(idx, cnt, n, chunk=4096, wg_queries=64):
     return dict(reference_algorithm=ref, kernel=kern, all_pairs=b * m * n)
 
 
-VALU_OPS_PER_PAIR = 11        # v_sub x3, v_mul x3, v_add x2 (un-fused), v_cmp, v_cndmask, v_lshl_or per (query, candidate) lane
-VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9  # 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md: v_fma_f32 2 cycles per wave64)
+def indexed_pairs(index, xyz2, n, radius):
+    """(query, candidate) pairs ball_query_indexed_kernel tests: 64 per bucket whose box passes the kernel's conservative
+    test, recomputed here from the index's boxes with the same fp32 expression."""
+    import ctypes
+    import torch
+    from votenet_amd import _lib as L
+    b, m, _ = xyz2.shape
+    nb = (n + 63) // 64
+    L.lib().votenet_ball_threshold.restype = ctypes.c_float
+    L.lib().votenet_ball_threshold.argtypes = [ctypes.c_float]
+    thr = float(L.lib().votenet_ball_threshold(float(radius)))
+    box = index[b * n:b * n + b * nb * 6].view(b, 1, nb, 6)
+    q = xyz2.view(b, m, 1, 3)
+    e = torch.clamp(torch.maximum(box[..., :3] - q, q - box[..., 3:]), min=0.0)
+    lb = ((e[..., 0] * e[..., 0] + e[..., 1] * e[..., 1]) + e[..., 2] * e[..., 2]) * 0.99999
+    return int((~(lb >= thr)).sum().item()) * 64
 
 
 def ball_query_detail(sa, x_room, x_unif):
-    """Timing alone on the GPU + scanned pairs for sa1's ball query on the bench's room scenes and on the uniform cube."""
-    import torch
+    """sa1's ball query alone on the GPU, room scenes and the uniform cube: over the spatial index (what the path runs) and
+    the full scan, with the pairs each of them tests."""
     from votenet_amd import tf_grouping as G
     from votenet_amd import tf_sampling as S
     out = {}
     for name, x in (("room", x_room), ("uniform", x_unif)):
-        n = x.shape[1]
-        ctr = S.gather_point(x, S.farthest_point_sample(sa.npoint, x))
-        ms = gpu_ms(lambda: G.query_ball_point(sa.radius, sa.nsample, x, ctr), it=10)
+        b, n = x.shape[:2]
+        ctr = S.gather_point(x, S.farthest_point_sample(sa.npoint, x))  # leaves the index of x behind
+        ms_i = gpu_ms(lambda: G.query_ball_point(sa.radius, sa.nsample, x, ctr), it=20)
         idx, cnt = G.query_ball_point(sa.radius, sa.nsample, x, ctr)
+        G.USE_INDEX = False
+        try:
+            ms_f = gpu_ms(lambda: G.query_ball_point(sa.radius, sa.nsample, x, ctr), it=10)
+        finally:
+            G.USE_INDEX = True
         p = ball_query_pairs(idx, cnt, n)
-        out[name] = dict(ms_alone=round(ms, 4), scanned_pairs=p, mean_pts_cnt=round(float(cnt.float().mean()), 2),
-                         kernel_pairs_per_s=round(p["kernel"] / (ms * 1e-3), 1),
-                         valu_frac=round(p["kernel"] * VALU_OPS_PER_PAIR / (ms * 1e-3) / VALU_PEAK_LANE_OPS, 4),
-                         hbm_model_frac=round((x.shape[0] * sa.npoint * n * 12 + x.shape[0] * sa.npoint * (sa.nsample + 1) * 4) / (ms * 1e-3) / 8e12, 4))
-    out["note"] = ("the kernel is on-chip (candidates through the scalar cache) and VALU-bound: valu_frac = kernel-scanned pairs x %d VALU "
-                   "lane-ops / time / (256 CU x 4 SIMD x 32 lanes x 2.4 GHz); hbm_model_frac is SURVEY 8d's all-pairs byte model and "
-                   "exceeds 1 because nothing is re-read from HBM and full workgroups stop early" % VALU_OPS_PER_PAIR)
+        pi = indexed_pairs(S.cached_index(x), ctr, n, sa.radius)
+        alg = b * sa.npoint * n * 12 + b * sa.npoint * (sa.nsample + 1) * 4
+        out[name] = dict(ms_alone=round(ms_i, 4), ms_alone_full_scan=round(ms_f, 4), mean_pts_cnt=round(float(cnt.float().mean()), 2),
+                         scanned_pairs=dict(reference_algorithm=p["reference_algorithm"], full_scan_kernel=p["kernel"],
+                                            indexed_kernel=pi, all_pairs=p["all_pairs"]),
+                         indexed_pairs_per_s=round(pi / (ms_i * 1e-3), 1), hbm_model_frac=round(alg / (ms_i * 1e-3) / 8e12, 4),
+                         hbm_model_frac_full_scan=round(alg / (ms_f * 1e-3) / 8e12, 4))
+    out["note"] = ("hbm_model_frac is SURVEY 8d's all-pairs byte model (B m n 12 + B m (K+1) 4) / time / 8 TB/s: it exceeds 1 because the "
+                   "kernel tests only the buckets of the candidates' spatial index whose box reaches into the ball (scanned_pairs."
+                   "indexed_kernel of all_pairs), and those from L2; the full scan (no index) is the same figure for every pair tested")
     return out
 
 

@@ -43,6 +43,8 @@ _SIGS = {
     "votenet_gather_point": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_gather_point_grad": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_query_ball_point": [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_query_ball_point_indexed": [ctypes.c_int] * 3 + [ctypes.c_float, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_spatial_index": [ctypes.c_int] * 2 + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_group_point": [ctypes.c_int] * 5 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_group_point_grad": [ctypes.c_int] * 5 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_three_nn": [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_void_p],
@@ -127,6 +129,8 @@ def lib():
         L.votenet_version.restype = ctypes.c_char_p
         L.votenet_fps_temp_floats.restype = ctypes.c_size_t
         L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_spatial_index_floats.restype = ctypes.c_size_t
+        L.votenet_spatial_index_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_loss_workspace_floats.restype = ctypes.c_size_t
         L.votenet_loss_workspace_floats.argtypes = [ctypes.c_int]
         L.votenet_knn_workspace_bytes.restype = ctypes.c_size_t

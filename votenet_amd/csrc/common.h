@@ -48,6 +48,39 @@ __device__ __forceinline__ void bn_raw_channel(const BnRaw &r, int c, int o, boo
     }
 }
 
+// ---- spatial index of a batch of clouds (fps.hip builds it, grouping.hip reads it; include/votenet_hip.h) ----
+// Points sorted by Morton cell into buckets of 64 consecutive sorted points.  One float scratch, four regions:
+//   perm    b * n ints          original index of the p-th sorted point
+//   bbox    b * nb * 6 floats   (xmin, ymin, zmin, xmax, ymax, zmax) of every bucket, nb = ceil(n / 64)
+//   sorted  b * nb * 64 float4  16-byte aligned; (x, y, z, w): w = bits of the original index until a sampling kernel
+//                               replaces it by its running distance -- readers take indices from perm
+//   work    b * kSidxWork ints  per-workgroup cell histograms / offsets + partial bounds while the index is built
+struct SpatialIndex {
+    int *perm;
+    float *bbox;
+    float4 *sorted;
+    int *work;
+};
+constexpr int kSidxCells = 4096;
+constexpr int kSidxParts = 16;  // workgroups per scene: each counts / places its own slice of the points through LDS
+constexpr int kSidxWork = kSidxCells * kSidxParts + 6 * kSidxParts + 8;
+inline size_t spatial_index_floats(int b, int n)
+{
+    const size_t nb = (size_t)(n + 63) / 64;
+    return (size_t)b * ((size_t)n + 6 * nb + 4 * 64 * nb + kSidxWork) + 4;
+}
+inline SpatialIndex spatial_index_view(float *base, int b, int n)
+{
+    const size_t nb = (size_t)(n + 63) / 64;
+    SpatialIndex v;
+    v.perm = reinterpret_cast<int *>(base);
+    v.bbox = base + (size_t)b * n;
+    v.sorted = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(v.bbox + (size_t)b * nb * 6) + 15) & ~(uintptr_t)15);
+    v.work = reinterpret_cast<int *>(v.sorted + (size_t)b * nb * 64);
+    return v;
+}
+int build_spatial_index(int b, int n, const float *xyz, float *index, hipStream_t st); // fps.hip
+
 // ---- wave64 cross-lane helpers (DPP; no LDS traffic) ----
 // dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_shr:n 0x110+n, row_mirror 0x140,
 // row_half_mirror 0x141, row_bcast:15 0x142, row_bcast:31 0x143.

@@ -12,7 +12,7 @@
 //                      a few un-fused distance updates per lane, a DPP wave arg-max and ONE barrier.
 //   fps_bucket_kernel  4096 < n <= 24576.  Same residency, plus EXACT spatial pruning: points are
 //                      pre-sorted into buckets of 64 (one register slot of one wave) by a Morton cell
-//                      sort (fps_bucket_sort_kernel); every bucket keeps its bounding box and the max of
+//                      sort (build_spatial_index); every bucket keeps its bounding box and the max of
 //                      its running distances.  A new sample can only lower distances of points closer
 //                      than their current running distance, so a bucket whose box is farther than its
 //                      max running distance is skipped -- nothing in it can change.  The skip test is
@@ -389,27 +389,47 @@ __device__ __forceinline__ unsigned part1by2_4(unsigned v) // spread 4 bits: abc
     return v;
 }
 
-// perm[scene, p] = original index of the p-th point in Morton-cell order (order inside a cell is arbitrary:
-// FPS results do not depend on it, ties are resolved on original indices).
-// Also writes the bounding box of every bucket of 64 consecutive sorted points: bbox[scene, g, 0..5] =
-// (xmin, ymin, zmin, xmax, ymax, zmax).
-__global__ __launch_bounds__(1024) void fps_bucket_sort_kernel(int n, const float *__restrict__ xyz, int *__restrict__ perm,
-                                                               float *__restrict__ bbox)
+// The index is built by five small launches spread over the GPU (one workgroup per scene took 65 us for 8 x 20480
+// points: three latency-bound passes and two rounds of LDS atomics on 8 of 256 CUs; global atomics on one histogram per
+// scene are no better -- device-scope atomics are executed behind the XCDs' L2s):
+//   bounds   16 workgroups per scene: partial bounding boxes of the cloud
+//   hist     16 workgroups per scene: Morton cells (16 x 16 x 16 grid over the box) of a slice of the points counted in
+//            LDS -> one histogram row per workgroup
+//   scan     per scene: exclusive scan of the 16 x 4096 counters in (cell, workgroup) order
+//   scatter  the same slices: position = LDS atomic increment of the workgroup's own offset row; perm[position] = k,
+//            sorted[position] = (x, y, z, k)  (the order inside a cell is arbitrary: no result depends on it, ties are
+//            resolved on original indices)
+//   boxes    per bucket of 64 consecutive sorted points: bounding box (one wave per bucket)
+__device__ __forceinline__ unsigned sidx_cell(const float *__restrict__ pts, int k, const float *lo, const float *inv)
 {
-    __shared__ unsigned cnt[4096];
-    __shared__ float sred[6][16];
-    __shared__ unsigned wsum[16];
-    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
-    int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
+    unsigned c = 0;
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+        int q = (int)((pts[(size_t)k * 3 + a] - lo[a]) * inv[a]);
+        q = q < 0 ? 0 : (q > 15 ? 15 : q);
+        c |= part1by2_4((unsigned)q) << a;
+    }
+    return c;
+}
+
+// work layout per scene: [kSidxParts rows of kSidxCells counters | kSidxParts x 6 partial bounds (min xyz, max xyz)]
+__global__ __launch_bounds__(256) void sidx_bounds_kernel(int n, const float *__restrict__ xyz, int *__restrict__ work)
+{
+    __shared__ float sred[6][4];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.y * n * 3;
+    int *__restrict__ wk = work + (size_t)blockIdx.y * kSidxWork;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int k = tid; k < n; k += 1024)
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            const float v = pts[(size_t)k * 3 + a];
-            mn[a] = fminf(mn[a], v);
-            mx[a] = fmaxf(mx[a], v);
-        }
+    for (int i = blockIdx.x * 256 + tid; i < n * 3; i += 256 * kSidxParts) { // coalesced: component a = i % 3
+        const float v = pts[i];
+        const int a = i % 3;
+        mn[0] = a == 0 ? fminf(mn[0], v) : mn[0];
+        mx[0] = a == 0 ? fmaxf(mx[0], v) : mx[0];
+        mn[1] = a == 1 ? fminf(mn[1], v) : mn[1];
+        mx[1] = a == 1 ? fmaxf(mx[1], v) : mx[1];
+        mn[2] = a == 2 ? fminf(mn[2], v) : mn[2];
+        mx[2] = a == 2 ? fmaxf(mx[2], v) : mx[2];
+    }
 #pragma unroll
     for (int a = 0; a < 3; a++) {
         const float lo = wave_min_f32(mn[a]), hi = wave_max_f32(mx[a]);
@@ -418,34 +438,68 @@ __global__ __launch_bounds__(1024) void fps_bucket_sort_kernel(int n, const floa
             sred[3 + a][w] = hi;
         }
     }
-    for (int c = tid; c < 4096; c += 1024) cnt[c] = 0;
     __syncthreads();
-    float lo[3], inv[3];
+    if (tid < 6) {
+        float v = sred[tid][0];
+        for (int i = 1; i < 4; i++) v = tid < 3 ? fminf(v, sred[tid][i]) : fmaxf(v, sred[tid][i]);
+        reinterpret_cast<float *>(wk + kSidxCells * kSidxParts)[blockIdx.x * 6 + tid] = v;
+    }
+}
+
+// lower corner and cells-per-unit of the scene's grid from the partial bounds: 96 threads fetch one float each, three reduce
+__device__ __forceinline__ void sidx_grid(const int *__restrict__ wk, float *lo, float *inv)
+{
+    __shared__ float s_part[6 * kSidxParts];
+    __shared__ float s_grid[6];
+    const float *part = reinterpret_cast<const float *>(wk + kSidxCells * kSidxParts);
+    const int tid = threadIdx.x;
+    if (tid < 6 * kSidxParts) s_part[tid] = part[tid];
+    __syncthreads();
+    if (tid < 3) {
+        float l = s_part[tid], h = s_part[3 + tid];
+        for (int i = 1; i < kSidxParts; i++) {
+            l = fminf(l, s_part[i * 6 + tid]);
+            h = fmaxf(h, s_part[i * 6 + 3 + tid]);
+        }
+        s_grid[tid] = l;
+        s_grid[3 + tid] = (h > l) ? 16.0f / (h - l) : 0.0f;
+    }
+    __syncthreads();
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        float l = sred[a][0], h = sred[3 + a][0];
-        for (int i = 1; i < 16; i++) {
-            l = fminf(l, sred[a][i]);
-            h = fmaxf(h, sred[3 + a][i]);
-        }
-        lo[a] = l;
-        inv[a] = (h > l) ? 16.0f / (h - l) : 0.0f;
+        lo[a] = s_grid[a];
+        inv[a] = s_grid[3 + a];
     }
-    auto cell_of = [&](int k) -> unsigned {
-        unsigned c = 0;
-#pragma unroll
-        for (int a = 0; a < 3; a++) {
-            int q = (int)((pts[(size_t)k * 3 + a] - lo[a]) * inv[a]);
-            q = q < 0 ? 0 : (q > 15 ? 15 : q);
-            c |= part1by2_4((unsigned)q) << a;
-        }
-        return c;
-    };
-    for (int k = tid; k < n; k += 1024) atomicAdd(&cnt[cell_of(k)], 1u);
+}
+
+__global__ __launch_bounds__(256) void sidx_hist_kernel(int n, const float *__restrict__ xyz, int *__restrict__ work)
+{
+    __shared__ int s_cnt[kSidxCells];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.y * n * 3;
+    int *__restrict__ wk = work + (size_t)blockIdx.y * kSidxWork;
+    float lo[3], inv[3];
+    for (int c = threadIdx.x; c < kSidxCells; c += 256) s_cnt[c] = 0;
+    sidx_grid(wk, lo, inv); // (its barriers also order the clear above)
+    const int chunk = (n + kSidxParts - 1) / kSidxParts;
+    const int k1 = min(n, (int)(blockIdx.x + 1) * chunk);
+    for (int k = blockIdx.x * chunk + threadIdx.x; k < k1; k += 256) atomicAdd(&s_cnt[sidx_cell(pts, k, lo, inv)], 1);
     __syncthreads();
-    // exclusive scan of 4096 counters: 4 per thread
-    unsigned c0 = cnt[tid * 4 + 0], c1 = cnt[tid * 4 + 1], c2 = cnt[tid * 4 + 2], c3 = cnt[tid * 4 + 3];
-    const unsigned tsum = c0 + c1 + c2 + c3;
+    int4 *__restrict__ row = reinterpret_cast<int4 *>(wk + (size_t)blockIdx.x * kSidxCells);
+    for (int c = threadIdx.x; c < kSidxCells / 4; c += 256) row[c] = reinterpret_cast<const int4 *>(s_cnt)[c];
+}
+
+__global__ __launch_bounds__(1024) void sidx_scan_kernel(int *__restrict__ work)
+{
+    __shared__ unsigned wsum[16];
+    int *__restrict__ cnt = work + (size_t)blockIdx.x * kSidxWork;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    uint4 c[kSidxParts]; // thread t: cells 4t .. 4t+3 of every workgroup row (coalesced 16-byte accesses)
+    unsigned tsum = 0;
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) {
+        c[p] = *reinterpret_cast<const uint4 *>(cnt + (size_t)p * kSidxCells + tid * 4);
+        tsum += c[p].x + c[p].y + c[p].z + c[p].w;
+    }
     unsigned incl = tsum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) {
@@ -454,38 +508,60 @@ __global__ __launch_bounds__(1024) void fps_bucket_sort_kernel(int n, const floa
     }
     if (lane == 63) wsum[w] = incl;
     __syncthreads();
-    unsigned woff = 0;
-    for (int i = 0; i < w; i++) woff += wsum[i];
-    const unsigned base = woff + incl - tsum;
-    cnt[tid * 4 + 0] = base;
-    cnt[tid * 4 + 1] = base + c0;
-    cnt[tid * 4 + 2] = base + c0 + c1;
-    cnt[tid * 4 + 3] = base + c0 + c1 + c2;
-    __syncthreads();
-    for (int k = tid; k < n; k += 1024) {
-        const unsigned pos = atomicAdd(&cnt[cell_of(k)], 1u);
-        pm[pos] = k;
-    }
-    __syncthreads(); // workgroup-scope release/acquire: the permutation written above is visible to the block
+    unsigned run = incl - tsum;
+    for (int i = 0; i < w; i++) run += wsum[i];
+    uint4 o[kSidxParts];
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) { o[p].x = run; run += c[p].x; }
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) { o[p].y = run; run += c[p].y; }
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) { o[p].z = run; run += c[p].z; }
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) { o[p].w = run; run += c[p].w; }
+#pragma unroll
+    for (int p = 0; p < kSidxParts; p++) *reinterpret_cast<uint4 *>(cnt + (size_t)p * kSidxCells + tid * 4) = o[p];
+}
+
+__global__ __launch_bounds__(256) void sidx_scatter_kernel(int n, const float *__restrict__ xyz, int *__restrict__ work,
+                                                           int *__restrict__ perm, float4 *__restrict__ sorted)
+{
+    __shared__ int s_off[kSidxCells];
+    const float *__restrict__ pts = xyz + (size_t)blockIdx.y * n * 3;
+    int *__restrict__ wk = work + (size_t)blockIdx.y * kSidxWork;
+    float lo[3], inv[3];
+    const int4 *__restrict__ row = reinterpret_cast<const int4 *>(wk + (size_t)blockIdx.x * kSidxCells);
+    for (int c = threadIdx.x; c < kSidxCells / 4; c += 256) reinterpret_cast<int4 *>(s_off)[c] = row[c];
+    sidx_grid(wk, lo, inv);
     const int nb = (n + 63) / 64;
-    float *__restrict__ bb = bbox + (size_t)blockIdx.x * nb * 6;
-    for (int g = w; g < nb; g += 16) {
-        const int p = g * 64 + lane;
-        const bool valid = p < n;
-        float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) {
-            const int k = pm[p];
-            px = pts[(size_t)k * 3 + 0];
-            py = pts[(size_t)k * 3 + 1];
-            pz = pts[(size_t)k * 3 + 2];
-        }
-        const float xl = wave_min_f32(valid ? px : INFINITY), xh = wave_max_f32(valid ? px : -INFINITY);
-        const float yl = wave_min_f32(valid ? py : INFINITY), yh = wave_max_f32(valid ? py : -INFINITY);
-        const float zl = wave_min_f32(valid ? pz : INFINITY), zh = wave_max_f32(valid ? pz : -INFINITY);
-        if (lane == 0) {
-            bb[g * 6 + 0] = xl; bb[g * 6 + 1] = yl; bb[g * 6 + 2] = zl;
-            bb[g * 6 + 3] = xh; bb[g * 6 + 4] = yh; bb[g * 6 + 5] = zh;
-        }
+    const int chunk = (n + kSidxParts - 1) / kSidxParts;
+    const int k1 = min(n, (int)(blockIdx.x + 1) * chunk);
+    for (int k = blockIdx.x * chunk + threadIdx.x; k < k1; k += 256) {
+        const int pos = atomicAdd(&s_off[sidx_cell(pts, k, lo, inv)], 1);
+        perm[(size_t)blockIdx.y * n + pos] = k;
+        sorted[(size_t)blockIdx.y * nb * 64 + pos] =
+            make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k));
+    }
+}
+
+__global__ __launch_bounds__(256) void sidx_boxes_kernel(int n, float4 *__restrict__ sorted, float *__restrict__ bbox)
+{
+    const int nb = (n + 63) / 64;
+    const int g = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (g >= nb) return;
+    float4 *__restrict__ sp = sorted + ((size_t)blockIdx.y * nb + g) * 64;
+    const int p = g * 64 + lane;
+    const bool valid = p < n;
+    float4 v = make_float4(0.f, 0.f, 0.f, __int_as_float(-1));
+    if (valid) v = sp[lane];
+    else sp[lane] = v; // padding of the last bucket
+    const float xl = wave_min_f32(valid ? v.x : INFINITY), xh = wave_max_f32(valid ? v.x : -INFINITY);
+    const float yl = wave_min_f32(valid ? v.y : INFINITY), yh = wave_max_f32(valid ? v.y : -INFINITY);
+    const float zl = wave_min_f32(valid ? v.z : INFINITY), zh = wave_max_f32(valid ? v.z : -INFINITY);
+    if (lane == 0) {
+        float *__restrict__ bb = bbox + ((size_t)blockIdx.y * nb + g) * 6;
+        bb[0] = xl; bb[1] = yl; bb[2] = zl;
+        bb[3] = xh; bb[4] = yh; bb[5] = zh;
     }
 }
 
@@ -508,7 +584,7 @@ __device__ unsigned long long g_fps_trace[8]; // cycles summed over rounds, per 
 template <int NW, int VW>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
                                                              const int *__restrict__ perm, const float *__restrict__ bbox,
-                                                             int *__restrict__ out)
+                                                             const float4 *__restrict__ sorted, int *__restrict__ out)
 {
     constexpr int P = VW;
     typedef typename SlotVec<VW>::type vec_t;
@@ -516,7 +592,6 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     unsigned *s_key = reinterpret_cast<unsigned *>(smem);                          // NW*P*64 tie keys by (slot, wave, lane)
     unsigned *s_ex = reinterpret_cast<unsigned *>(smem + (size_t)NW * P * 64 * 4); // 2 x 16 x 5 exchange
     const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
-    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
     int *__restrict__ o = out + (size_t)blockIdx.x * m;
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = wave_id_uniform();
@@ -530,12 +605,12 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
         const bool valid = p < n;
         unsigned key = 0xFFFFFFFFu;
         float px = 0.f, py = 0.f, pz = 0.f;
-        if (valid) {
-            const int k = pm[p];
-            px = pts[(size_t)k * 3 + 0];
-            py = pts[(size_t)k * 3 + 1];
-            pz = pts[(size_t)k * 3 + 2];
-            key = fps_tiekey((unsigned)k);
+        if (valid) { // one coalesced 16-byte load: the index's sorted copy carries (x, y, z, original index)
+            const float4 v = sorted[(size_t)blockIdx.x * nb * 64 + p];
+            px = v.x;
+            py = v.y;
+            pz = v.z;
+            key = fps_tiekey((unsigned)__float_as_int(v.w));
         }
         X[i] = px;
         Y[i] = py;
@@ -570,8 +645,16 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
         const float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
         const float ey = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
         const float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
+#if defined(FPS_ABLATE) && FPS_ABLATE == 2 // 2: additionally no box tests
+        const float lb = INFINITY;
+        (void)ex; (void)ey; (void)ez;
+#else
         const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+#endif
         unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+#if defined(FPS_ABLATE) && FPS_ABLATE >= 1 // timing ablation (tools/probe/fps_round_trace.sh): results are NOT the FPS indices
+        if (j > 1) act = 0;                 // 1: no touched-bucket work after the first round
+#endif
         FPS_T(1); // box tests + ballot
         // (2) update the active buckets, refresh their cached arg-max
         bool changed = false; // uniform: did the cached entry of this wave's WINNING bucket change this round?
@@ -611,316 +694,20 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
             cw_z = readlane_f32(Z[ws], fl);
         }
         FPS_T(3); // wave winner
+#if defined(FPS_ABLATE) && FPS_ABLATE == 3 // 3: additionally no cross-wave exchange (every wave follows its own winner)
+        FpsWinner win;
+        win.k = fps_key_to_index(cw_key);
+        win.x = cw_x;
+        win.y = cw_y;
+        win.z = cw_z;
+#else
         const FpsWinner win = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j);
+#endif
         FPS_T(4); // cross-wave stage (includes the wait for the slowest wave)
         cx = win.x;
         cy = win.y;
         cz = win.z;
         fo.put(j, (int)win.k, tid);
-    }
-}
-
-// ------------------------------------------------------------------ exact bucket-pruned FPS, asynchronous director / workers
-// fps_bucket_kernel runs every round in lock step: all waves test their boxes, update their touched buckets, reduce, meet
-// at a barrier, exchange -- about 2000 cycles of dependent latency per round, most of it on waves whose buckets cannot
-// hold the next sample anyway.  Here the round's critical path is ONE wave:
-//
-//   director (wave 0)   holds, for every bucket, its box and an UPPER BOUND of its largest running distance with the tie
-//                       key and the coordinates of the point that attained it.  A round: arg-max over the bounds (per-lane
-//                       compare over its slots + one DPP wave arg-max), emit the sample, publish its coordinates in the LDS
-//                       centre log, box-test all buckets against it and mark the touched ones (need[bucket] = number of
-//                       centres it must have seen).  No barrier, no LDS read, nothing waits for a worker -- unless the
-//                       arg-max bucket itself is marked: then the director asks for exactly that bucket (hint) and waits
-//                       until it has been brought up to date, takes its new entry and repeats the arg-max.
-//   workers (waves 1..) own the points (registers, as before).  Each polls need[] of its buckets and FLUSHES a marked one:
-//                       applies every centre of the log it has not seen yet (min with the un-fused fp32 distance,
-//                       tf_sampling_g.cu:142-143), re-reduces the bucket's (max, tie key, second max, arg-max coordinates)
-//                       and publishes the entry with applied = centres seen.
-//
-// Exactness.  Running distances only decrease, so a stale entry is an upper bound of its bucket; an unmarked bucket's
-// entry is exact (a centre that fails the conservative box test cannot lower any of its distances).  The director emits a
-// sample only from an UNMARKED bucket whose exact (max, key) is first among all bounds in the order (value descending,
-// key ascending) -- hence first among all true values: the brute-force arg-max with the reference's tie rule.  A stale
-// key never wins wrongly: the points of a bucket that still hold its old maximum are a subset of those that held it, so
-// the true key is not smaller than the stale one.  After a pick the director lowers that bucket's bound to its second
-// maximum (every other point is <= it) and always marks the bucket.  Results are bit-identical to fps_bucket_kernel and
-// to the oracle (tests/test_gpu_parity.py); what changes is that buckets near a new centre -- whose distances have just
-// dropped, i.e. the ones least likely to hold the next sample -- are brought up to date off the critical path.
-struct FaEntry {
-    unsigned bmax, sec, key;
-    float x, y, z;
-    int applied;
-    int pad;
-};
-constexpr int FA_NS = 6; // director slots per lane: up to 384 buckets
-__device__ unsigned long long g_fa_dbg[8]; // scene 0: rounds, pulls, spin iterations, cycles waiting, cycles total (votenet_fps_async_stats)
-
-__device__ __forceinline__ int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ void lds_order() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
-
-template <int NWK, int VW>
-__global__ __launch_bounds__((NWK + 1) * 64) void fps_async_kernel(int n, int m, const float *__restrict__ xyz,
-                                                                   const int *__restrict__ perm, const float *__restrict__ bbox,
-                                                                   int *__restrict__ out)
-{
-    constexpr int P = VW;
-    constexpr int NBC = NWK * P; // bucket capacity
-    typedef typename SlotVec<VW>::type vec_t;
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float4 *s_cent = reinterpret_cast<float4 *>(smem);                                   // m centres (the samples' coordinates)
-    FaEntry *s_entry = reinterpret_cast<FaEntry *>(smem + (size_t)m * 16);               // NBC entries
-    int *s_need = reinterpret_cast<int *>(smem + (size_t)m * 16 + (size_t)NBC * 32);     // NBC
-    int *s_ctl = s_need + NBC;                                                           // [0] head (-1: done), [1 + worker] hint
-    unsigned *s_key = reinterpret_cast<unsigned *>(s_ctl + 16);                          // NBC * 64 tie keys by (slot, worker, lane)
-    const float *__restrict__ pts = xyz + (size_t)blockIdx.x * n * 3;
-    const int *__restrict__ pm = perm + (size_t)blockIdx.x * n;
-    int *__restrict__ o = out + (size_t)blockIdx.x * m;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = wave_id_uniform();
-    const int nb = (n + 63) / 64;
-    const float c0x = pts[0], c0y = pts[1], c0z = pts[2];
-    for (int i = tid; i < NBC; i += (NWK + 1) * 64) s_need[i] = 0;
-    if (tid < 16) s_ctl[tid] = tid == 0 ? 1 : (tid == 15 ? 0 : -1);
-    if (tid == 0) s_cent[0] = make_float4(c0x, c0y, c0z, 0.0f);
-
-    if (w > 0) {
-        // ================================================================ worker
-        const int wk = w - 1;
-        vec_t X, Y, Z, TD;
-#pragma unroll
-        for (int i = 0; i < P; i++) {
-            const int g = i * NWK + wk;
-            const int p = g * 64 + lane;
-            const bool valid = p < n;
-            unsigned key = 0xFFFFFFFFu;
-            float px = 0.f, py = 0.f, pz = 0.f;
-            if (valid) {
-                const int k = pm[p];
-                px = pts[(size_t)k * 3 + 0];
-                py = pts[(size_t)k * 3 + 1];
-                pz = pts[(size_t)k * 3 + 2];
-                key = fps_tiekey((unsigned)k);
-            }
-            X[i] = px;
-            Y[i] = py;
-            Z[i] = pz;
-            TD[i] = valid ? 1e38f : 0.0f; // tf_sampling_g.cu:118; an empty slot never wins
-            s_key[(size_t)(i * NWK + wk) * 64 + lane] = key;
-        }
-        // bring slot i from `a` centres seen to `h` and publish its entry
-        auto flush = [&](int i, int a, int h) {
-            const float px = X[i], py = Y[i], pz = Z[i]; // uniform i: s_set_gpr_idx reads
-            unsigned td = fbits(TD[i]);
-            for (int r = a; r < h; r++) {
-                const float4 c = s_cent[r];
-                const float dx = px - c.x, dy = py - c.y, dz = pz - c.z;
-                const float d = dx * dx + dy * dy + dz * dz; // tf_sampling_g.cu:142, un-fused
-                td = min(fbits(d), td);                      // :143
-            }
-            TD[i] = __uint_as_float(td);
-            const unsigned key = s_key[(size_t)(i * NWK + wk) * 64 + lane];
-            unsigned nmax, nkey;
-            const int nl = wave_argmax(td, key, nmax, nkey);
-            const float ax = readlane_f32(px, nl), ay = readlane_f32(py, nl), az = readlane_f32(pz, nl);
-            // what the bucket can still hold once its arg-max point q has been sampled: a point closer to q than t = max / 4
-            // drops below t (the update evaluates exactly this expression), any other point keeps at most its value ->
-            // bound = max(sec, t) with sec = largest running distance among the points NOT closer than t
-            const float fx = px - ax, fy = py - ay, fz = pz - az;
-            const float fd = fx * fx + fy * fy + fz * fz;
-            const unsigned sec = wmax_u32(fd < 0.25f * __uint_as_float(nmax) ? 0u : td);
-            if (lane == 0) {
-                FaEntry *e = &s_entry[i * NWK + wk];
-                e->bmax = nmax;
-                e->sec = sec;
-                e->key = nkey;
-                e->x = ax;
-                e->y = ay;
-                e->z = az;
-                lds_order(); // the fields land before the count that releases them (LDS executes a wave's accesses in order)
-                lds_st(&e->applied, h);
-            }
-        };
-        __syncthreads(); // s_cent[0], s_ctl, s_need
-#pragma unroll 1
-        for (int i = 0; i < P; i++)
-            if (i * NWK + wk < nb) flush(i, 0, 1);
-        __syncthreads(); // every entry holds "centre 0 applied": the director reads them all
-        const int myg = lane * NWK + wk; // lane i < P watches the bucket of slot i
-        const bool has = lane < P && myg < nb;
-        int applied_l = 1;
-        int seen = 0; // value of the marks counter at the last scan that found nothing to do
-        while (true) {
-            if (lds_ld(&s_ctl[0]) < 0) break;
-            const int mk = lds_ld(&s_ctl[15]);       // centres whose box tests are complete (all their needs are written)
-            const int hint = lds_ld(&s_ctl[1 + wk]); // the slot the director wants first (its last sample's bucket / a leading bucket)
-            int i = -1;
-            if (hint >= 0 && lds_ld(&s_need[hint * NWK + wk]) > __builtin_amdgcn_readlane(applied_l, hint)) i = hint;
-            if (i < 0) {
-                if (mk == seen) {
-                    __builtin_amdgcn_s_sleep(2);
-                    continue;
-                }
-                const int nd = has ? lds_ld(&s_need[myg]) : 0;
-                const unsigned long long mask = __ballot(nd > applied_l);
-                if (!mask) {
-                    seen = mk;
-                    continue;
-                }
-                i = __ffsll((long long)mask) - 1;
-            }
-            lds_order();
-            const int h = lds_ld(&s_ctl[0]); // read after the need: head >= every need published before it
-            if (h < 0) break;
-            flush(i, __builtin_amdgcn_readlane(applied_l, i), h);
-            if (lane == i) applied_l = h;
-        }
-        return;
-    }
-    // ==================================================================== director
-    __builtin_amdgcn_s_setprio(3);
-    float bxl[FA_NS], byl[FA_NS], bzl[FA_NS], bxh[FA_NS], byh[FA_NS], bzh[FA_NS];
-    unsigned bnd[FA_NS], bky[FA_NS], sec[FA_NS];
-    float ax[FA_NS], ay[FA_NS], az[FA_NS];
-    int nd[FA_NS];
-    bool hasb[FA_NS];
-#pragma unroll
-    for (int s = 0; s < FA_NS; s++) {
-        const int g = s * 64 + lane;
-        hasb[s] = g < nb;
-        const float *__restrict__ bb = bbox + ((size_t)blockIdx.x * nb + (hasb[s] ? g : 0)) * 6;
-        bxl[s] = hasb[s] ? bb[0] : INFINITY;
-        byl[s] = hasb[s] ? bb[1] : INFINITY;
-        bzl[s] = hasb[s] ? bb[2] : INFINITY;
-        bxh[s] = hasb[s] ? bb[3] : -INFINITY;
-        byh[s] = hasb[s] ? bb[4] : -INFINITY;
-        bzh[s] = hasb[s] ? bb[5] : -INFINITY;
-    }
-    __syncthreads();
-    __syncthreads(); // the workers' first flush
-#pragma unroll
-    for (int s = 0; s < FA_NS; s++) {
-        const int g = s * 64 + lane;
-        bnd[s] = 0u;
-        bky[s] = 0xFFFFFFFFu;
-        sec[s] = 0u;
-        ax[s] = ay[s] = az[s] = 0.0f;
-        nd[s] = 0;
-        if (hasb[s]) {
-            const FaEntry e = s_entry[g];
-            bnd[s] = e.bmax;
-            bky[s] = e.key;
-            sec[s] = e.sec;
-            ax[s] = e.x;
-            ay[s] = e.y;
-            az[s] = e.z;
-        }
-    }
-    FpsOut fo = {o, m, 0};
-    fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
-    unsigned long long dbg_pulls = 0, dbg_spins = 0, dbg_wait = 0, dbg_arg = 0, dbg_box = 0;
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memtime();
-    for (int j = 1; j < m; j++) {
-        int L, S;
-        unsigned kmin;
-        float cx, cy, cz;
-        while (true) {
-            const unsigned long long ta = __builtin_amdgcn_s_memtime();
-            // this lane's best slot under (bound descending, key ascending)
-            unsigned bv = bnd[0], bk = bky[0];
-            int bs = 0, bn = nd[0];
-            float px = ax[0], py = ay[0], pz = az[0];
-#pragma unroll
-            for (int s = 1; s < FA_NS; s++) {
-                const bool better = bnd[s] > bv || (bnd[s] == bv && bky[s] < bk);
-                bv = better ? bnd[s] : bv;
-                bk = better ? bky[s] : bk;
-                bs = better ? s : bs;
-                bn = better ? nd[s] : bn;
-                px = better ? ax[s] : px;
-                py = better ? ay[s] : py;
-                pz = better ? az[s] : pz;
-            }
-            unsigned vmax;
-            L = wave_argmax(bv, bk, vmax, kmin);
-            S = __builtin_amdgcn_readlane(bs, L);
-            const int pend = __builtin_amdgcn_readlane(bn, L);
-            dbg_arg += __builtin_amdgcn_s_memtime() - ta;
-            if (pend == 0) { // an unmarked bucket: its entry is exact and it is first among all bounds -> the sample
-                cx = readlane_f32(px, L);
-                cy = readlane_f32(py, L);
-                cz = readlane_f32(pz, L);
-                break;
-            }
-            // the leading bucket has centres to catch up with: ask its worker for it, wait, take the new entry, look again
-            const int g = S * 64 + L;
-            const int wk = g % NWK;
-            lds_st(&s_ctl[1 + wk], g / NWK);
-            const unsigned long long tw = __builtin_amdgcn_s_memtime();
-            dbg_pulls++;
-            while (lds_ld(&s_entry[g].applied) < pend) {
-                dbg_spins++;
-                __builtin_amdgcn_s_sleep(0);
-            }
-            dbg_wait += __builtin_amdgcn_s_memtime() - tw;
-            lds_order();
-            const FaEntry e = s_entry[g]; // no flush of g can be running: applied >= every need published for it
-            if (lane == L) {
-#pragma unroll
-                for (int s = 0; s < FA_NS; s++)
-                    if (s == S) {
-                        bnd[s] = e.bmax;
-                        bky[s] = e.key;
-                        sec[s] = e.sec;
-                        ax[s] = e.x;
-                        ay[s] = e.y;
-                        az[s] = e.z;
-                        nd[s] = 0;
-                    }
-            }
-        }
-        const unsigned long long tb = __builtin_amdgcn_s_memtime();
-        fo.put(j, (int)fps_key_to_index(kmin), tid);
-        if (j == m - 1) break;
-        // publish the centre, then mark what it can change (head before need: a worker that sees a need sees its centres)
-        s_cent[j] = make_float4(cx, cy, cz, 0.0f);
-        lds_order();
-        lds_st(&s_ctl[0], j + 1);
-        { // the sample's own bucket first: its worker starts on it while the boxes are tested
-            const int g = S * 64 + L;
-            lds_st(&s_need[g], j + 1);
-            lds_st(&s_ctl[1 + g % NWK], g / NWK);
-        }
-#pragma unroll
-        for (int s = 0; s < FA_NS; s++) {
-            const bool own = lane == L && s == S;
-            if (own) { // the sample's running distance becomes 0; see flush(): what is left is <= max(sec, max / 4)
-                const unsigned t = fbits(0.25f * __uint_as_float(bnd[s]));
-                bnd[s] = sec[s] > t ? sec[s] : t;
-            }
-            const float ex = fmaxf(fmaxf(bxl[s] - cx, cx - bxh[s]), 0.0f);
-            const float ey = fmaxf(fmaxf(byl[s] - cy, cy - byh[s]), 0.0f);
-            const float ez = fmaxf(fmaxf(bzl[s] - cz, cz - bzh[s]), 0.0f);
-            const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f; // below every fp32-evaluated point distance of the bucket
-            if (own || (hasb[s] && !(lb >= __uint_as_float(bnd[s])))) {
-                nd[s] = j + 1;
-                lds_st(&s_need[s * 64 + lane], j + 1);
-            }
-        }
-        lds_order();
-        lds_st(&s_ctl[15], j + 1); // every need of centre j is written: the workers scan
-        dbg_box += __builtin_amdgcn_s_memtime() - tb;
-    }
-    lds_order();
-    lds_st(&s_ctl[0], -1);
-    if (blockIdx.x == 0 && tid == 0) {
-        g_fa_dbg[0] = (unsigned long long)(m - 1);
-        g_fa_dbg[1] = dbg_pulls;
-        g_fa_dbg[2] = dbg_spins;
-        g_fa_dbg[3] = dbg_wait;
-        g_fa_dbg[4] = __builtin_amdgcn_s_memtime() - dbg_t0;
-        g_fa_dbg[5] = dbg_arg;
-        g_fa_dbg[6] = dbg_box;
     }
 }
 
@@ -1286,7 +1073,15 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
             cw_y = readlane_f32(ly, wl);
             cw_z = readlane_f32(lz, wl);
         }
+#if defined(FPS_ABLATE) && FPS_ABLATE == 3 // 3: additionally no cross-wave exchange (every wave follows its own winner)
+        FpsWinner win;
+        win.k = fps_key_to_index(cw_key);
+        win.x = cw_x;
+        win.y = cw_y;
+        win.z = cw_z;
+#else
         const FpsWinner win = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j);
+#endif
         cx = win.x;
         cy = win.y;
         cz = win.z;
@@ -1358,24 +1153,40 @@ extern "C" void votenet_fps_trace_read(unsigned long long *out, int reset)
     }
 }
 #endif
-extern "C" void votenet_fps_async_stats(unsigned long long *out) // of the last fps_async_kernel launch, scene 0
-{
-    (void)hipDeviceSynchronize();
-    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(votenet::g_fa_dbg), sizeof(unsigned long long) * 8);
-}
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
 static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)
 
 } // namespace votenet
 
+int votenet::build_spatial_index(int b, int n, const float *xyz, float *index, hipStream_t st)
+{
+    const SpatialIndex v = spatial_index_view(index, b, n);
+    const int nb = (n + 63) / 64;
+    hipLaunchKernelGGL(sidx_bounds_kernel, dim3(kSidxParts, b), dim3(256), 0, st, n, xyz, v.work);
+    hipLaunchKernelGGL(sidx_hist_kernel, dim3(kSidxParts, b), dim3(256), 0, st, n, xyz, v.work);
+    hipLaunchKernelGGL(sidx_scan_kernel, dim3(b), dim3(1024), 0, st, v.work);
+    hipLaunchKernelGGL(sidx_scatter_kernel, dim3(kSidxParts, b), dim3(256), 0, st, n, xyz, v.work, v.perm, v.sorted);
+    hipLaunchKernelGGL(sidx_boxes_kernel, dim3((nb + 3) / 4, b), dim3(256), 0, st, n, v.sorted, v.bbox);
+    return check_launch("spatial_index");
+}
+
 using namespace votenet;
+
+extern "C" size_t votenet_spatial_index_floats(int b, int n) { return spatial_index_floats(b, n); }
+
+extern "C" int votenet_spatial_index(int b, int n, const float *xyz, float *index, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0, "spatial_index expects (batch_size, num_points, 3) xyz shape");
+    if (b == 0) return VOTENET_OK;
+    VN_REQUIRE(xyz && index, "spatial_index: null buffer");
+    return build_spatial_index(b, n, xyz, index, as_stream(stream));
+}
 
 extern "C" size_t votenet_fps_temp_floats(int b, int n)
 {
     if (n <= kFpsRegMax) return 0;
-    if (n <= kFpsBucketMax) return (size_t)b * ((size_t)n + 6 * (size_t)((n + 63) / 64)); // Morton permutation + bucket boxes
-    if (n <= kFpsL2Max) return (size_t)b * ((size_t)n + 6 * (size_t)((n + 63) / 64) + 4 * 64 * (size_t)((n + 63) / 64) + 4); // + sorted float4
+    if (n <= kFpsL2Max) return spatial_index_floats(b, n); // the spatial index: permutation, bucket boxes, sorted float4, work
     return (size_t)(b < 32 ? b : 32) * (size_t)n;                                          // running distances, tf_sampling.cpp:115
 }
 
@@ -1386,8 +1197,6 @@ extern "C" void votenet_fps_debug_prefix_check(int on) // measurement hook: 0 = 
 {
     g_fps_prefix_check = on;
 }
-static int g_fps_async = 1; // 0: the lock-step fps_bucket_kernel instead of the director / worker kernel (A/B measurements, tests)
-extern "C" void votenet_fps_debug_async(int on) { g_fps_async = on; }
 static int g_fps_two_pick = 0; // 1: two samples per round; 2: that kernel with the second pick disabled (measurement)
 extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
 {
@@ -1407,20 +1216,8 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
             attr_set2 = true;                                                                                      \
         }                                                                                                          \
-        hipLaunchKernelGGL((fps_bucket2_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
-                           (const float *)(temp + (size_t)b * n), out, g_fps_two_pick == 1 ? 1 : 0);               \
-    } while (0)
-#define FPS_ASYNC_LAUNCH(NWK, VW)                                                                                  \
-    do {                                                                                                           \
-        const size_t lds = (size_t)m * 16 + (size_t)NWK * VW * 36 + 64 + (size_t)NWK * VW * 64 * 4;                \
-        static size_t attr_lds = 0;                                                                                \
-        if (lds > attr_lds) {                                                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_async_kernel<NWK, VW>),                   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-            attr_lds = lds;                                                                                        \
-        }                                                                                                          \
-        hipLaunchKernelGGL((fps_async_kernel<NWK, VW>), dim3(b), dim3((NWK + 1) * 64), lds, st, n, m, inp, (const int *)temp, \
-                           (const float *)(temp + (size_t)b * n), out);                                            \
+        hipLaunchKernelGGL((fps_bucket2_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)sidx.perm, \
+                           (const float *)sidx.bbox, out, g_fps_two_pick == 1 ? 1 : 0);                            \
     } while (0)
 #define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
     do {                                                                                                           \
@@ -1431,8 +1228,8 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
             attr_set = true;                                                                                       \
         }                                                                                                          \
-        hipLaunchKernelGGL((fps_bucket_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)temp, \
-                           (const float *)(temp + (size_t)b * n), out);                                            \
+        hipLaunchKernelGGL((fps_bucket_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)sidx.perm, \
+                           (const float *)sidx.bbox, (const float4 *)sidx.sorted, out);                            \
     } while (0)
 
 extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
@@ -1464,23 +1261,22 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
     } else if (n <= 4096) {
         FPS_LAUNCH(8, 8);
     } else if (n <= kFpsBucketMax) {
-        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(b), dim3(1024), 0, st, n, inp, (int *)temp, temp + (size_t)b * n);
+        const SpatialIndex sidx = spatial_index_view(temp, b, n);
+        if (build_spatial_index(b, n, inp, temp, st) != VOTENET_OK) return VOTENET_E_HIP;
         const bool single = !g_fps_two_pick; // measured: the two-pick rounds are 1.9x as long as the plain ones
         if (n <= 16 * 16 * 64) {
             if (single) FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
             else FPS_BUCKET2_LAUNCH(16, 16);
-        } else if (single && g_fps_async && n <= 11 * 32 * 64 && (size_t)m * 16 + 11 * 32 * 36 + 64 + 11 * 32 * 64 * 4 <= 160 * 1024) {
-            FPS_ASYNC_LAUNCH(11, 32); // director + 11 workers x 32 slots (n <= 22 528, m <= 3 700)
         } else {
             if (single) FPS_BUCKET_LAUNCH(12, 32); // 12 waves x 32 slots: 3 waves per SIMD, 4 x 32 data VGPRs of the 168 available
             else FPS_BUCKET2_LAUNCH(12, 32);
         }
     } else if (n <= kFpsL2Max) {
         const int nb = (n + 63) / 64;
-        float *boxes = temp + (size_t)b * n;
-        // 16-byte aligned float4 area behind the permutation and the boxes
-        float4 *sorted = reinterpret_cast<float4 *>((reinterpret_cast<uintptr_t>(boxes + (size_t)b * nb * 6) + 15) & ~(uintptr_t)15);
-        hipLaunchKernelGGL(fps_bucket_sort_kernel, dim3(b), dim3(1024), 0, st, n, inp, (int *)temp, boxes);
+        const SpatialIndex sidx = spatial_index_view(temp, b, n);
+        if (build_spatial_index(b, n, inp, temp, st) != VOTENET_OK) return VOTENET_E_HIP;
+        float *boxes = sidx.bbox;
+        float4 *sorted = sidx.sorted;
         if (nb <= 16 * 64)
             hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 1>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
         else if (nb <= 16 * 64 * 2)

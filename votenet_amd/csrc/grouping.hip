@@ -237,6 +237,154 @@ extern "C" int votenet_query_ball_point(int b, int n, int m, float radius, int n
     return check_launch("query_ball_point");
 }
 
+namespace votenet {
+// ---------------------------------------------------------------- ball query over the spatial index
+// One wave per query.  The candidates are the index's buckets of 64 Morton-sorted points (common.h: SpatialIndex, built
+// by the farthest-point sampling of the same cloud or by votenet_spatial_index): the wave tests the query against all
+// bucket boxes (lane = bucket, conservative: a bucket is skipped only if its box is farther than the threshold even
+// after shrinking the bound by 1e-5), then evaluates the reference's hit test -- the same un-fused fp32 expression on
+// the same coordinates -- only on the points of the surviving buckets (r = 0.2 in a 5 m room: ~15 of 320).  The result
+// must be the first nsample hits in ORIGINAL index order (tf_grouping_g.cu:13-35) while the buckets arrive in Morton
+// order: hits set bits in a per-wave LDS bitmap over the original indices (n bits), which is then read in index order
+// with a wave prefix sum of popcounts -- the brute-force kernel's pop phase, on one n-bit row.  Neighbour lists and
+// pts_cnt are identical to ball_query_kernel's; the pair tests drop from m * n to about m * n / 20.
+constexpr int BQI_CH = 6; // 64-bucket chunks whose boxes are loaded together (sa1: 320 buckets = one pass)
+constexpr int BQI_U = 6;  // buckets fetched together
+template <int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void ball_query_indexed_kernel(int n, int m, float thr, int nsample,
+                                                                        const float *__restrict__ xyz2, const int *__restrict__ perm,
+                                                                        const float *__restrict__ bbox,
+                                                                        const float4 *__restrict__ sorted, int *__restrict__ idx,
+                                                                        int *__restrict__ pts_cnt)
+{
+    extern __shared__ unsigned s_bits[]; // WAVES x nw32 dwords
+    const int scene = blockIdx.y;
+    const int lane = lane_id();
+    const int w = wave_id_uniform();
+    const int q = blockIdx.x * WAVES + w;
+    if (q >= m) return; // wave-uniform; no workgroup barrier below
+    const int nb = (n + 63) / 64;
+    const int nw32 = (n + 31) / 32;
+    const int wpl = (nw32 + 63) / 64; // bitmap dwords per lane in the read-out
+    unsigned *__restrict__ bits = s_bits + (size_t)w * wpl * 64;
+    const float *__restrict__ qp = xyz2 + ((size_t)scene * m + q) * 3;
+    const float qx = qp[0], qy = qp[1], qz = qp[2];
+    const int *__restrict__ pm = perm + (size_t)scene * n;
+    const float *__restrict__ bb = bbox + (size_t)scene * nb * 6;
+    const float4 *__restrict__ sp = sorted + (size_t)scene * nb * 64;
+    for (int i = 0; i < wpl; i++) bits[i * 64 + lane] = 0u;
+    for (int g00 = 0; g00 < nb; g00 += 64 * BQI_CH) {
+        // box tests of up to BQI_CH x 64 buckets: all box loads of the chunk are issued before the first test
+        float bl[BQI_CH][6];
+#pragma unroll
+        for (int h = 0; h < BQI_CH; h++) {
+            const int g = g00 + h * 64 + lane;
+            const int gg = g < nb ? g : nb - 1;
+#pragma unroll
+            for (int t = 0; t < 6; t++) bl[h][t] = bb[gg * 6 + t];
+        }
+        unsigned long long acts[BQI_CH];
+#pragma unroll
+        for (int h = 0; h < BQI_CH; h++) {
+            const int g = g00 + h * 64 + lane;
+            const float ex = fmaxf(fmaxf(bl[h][0] - qx, qx - bl[h][3]), 0.0f);
+            const float ey = fmaxf(fmaxf(bl[h][1] - qy, qy - bl[h][4]), 0.0f);
+            const float ez = fmaxf(fmaxf(bl[h][2] - qz, qz - bl[h][5]), 0.0f);
+            acts[h] = __ballot(g < nb && !((ex * ex + ey * ey + ez * ez) * 0.99999f >= thr));
+        }
+#pragma unroll
+        for (int h = 0; h < BQI_CH; h++) {
+            unsigned long long act = acts[h];
+            const int g0 = g00 + h * 64;
+            while (act) { // up to BQI_U buckets per pass: their loads are in flight together
+                int gi[BQI_U];
+                float4 c[BQI_U];
+                int k[BQI_U];
+#pragma unroll
+                for (int u = 0; u < BQI_U; u++) {
+                    gi[u] = -1;
+                    if (act) {
+                        gi[u] = g0 + __ffsll((long long)act) - 1;
+                        act &= act - 1;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < BQI_U; u++) {
+                    const int p = (gi[u] >= 0 ? gi[u] : 0) * 64 + lane;
+                    const bool ok = gi[u] >= 0 && p < n;
+                    c[u] = ok ? sp[p] : make_float4(0.f, 0.f, 0.f, 0.f);
+                    k[u] = ok ? pm[p] : -1;
+                }
+#pragma unroll
+                for (int u = 0; u < BQI_U; u++) {
+                    const float dx = qx - c[u].x, dy = qy - c[u].y, dz = qz - c[u].z;
+                    const float s = dx * dx + dy * dy + dz * dz; // tf_grouping_g.cu:24, un-fused
+                    if (k[u] >= 0 && s < thr) atomicOr(&bits[k[u] >> 5], 1u << (k[u] & 31));
+                }
+            }
+        }
+    }
+    // read-out in index order: lane l owns bitmap dwords [l * wpl, (l + 1) * wpl)
+    int pc = 0;
+    for (int i = 0; i < wpl; i++) pc += __popc(bits[lane * wpl + i]);
+    int incl = pc;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    const int total = __builtin_amdgcn_readlane(incl, 63);
+    int *__restrict__ row = idx + ((size_t)scene * m + q) * nsample;
+    int first = 0;
+    if (total > 0) {
+        int pos = incl - pc;
+        int myfirst = -1;
+        for (int i = 0; i < wpl && (pos < nsample || myfirst < 0); i++) {
+            unsigned v = bits[lane * wpl + i];
+            const int base = (lane * wpl + i) * 32;
+            if (v && myfirst < 0) myfirst = base + __ffs((int)v) - 1;
+            while (v && pos < nsample) {
+                row[pos++] = base + __ffs((int)v) - 1;
+                v &= v - 1;
+            }
+        }
+        const unsigned long long have = __ballot(pc > 0);
+        first = __builtin_amdgcn_readlane(myfirst, __ffsll((long long)have) - 1);
+    }
+    const int cnt = total < nsample ? total : nsample;
+    for (int l = cnt + lane; l < nsample; l += 64) row[l] = first; // tf_grouping_g.cu:26-29 (all-zero row without a hit)
+    if (lane == 0) pts_cnt[(size_t)scene * m + q] = cnt;
+}
+} // namespace votenet
+
+// The ball query of a cloud whose spatial index exists (votenet_spatial_index, or the temp scratch of a
+// votenet_farthest_point_sample call on the same cloud with 4096 < n <= 262144): same results as votenet_query_ball_point.
+extern "C" int votenet_query_ball_point_indexed(int b, int n, int m, float radius, int nsample, const float *xyz1,
+                                                const float *xyz2, const float *index, int *idx, int *pts_cnt, void *stream)
+{
+    VN_REQUIRE(radius > 0, "QueryBallPoint expects positive radius");   // tf_grouping.cpp:71
+    VN_REQUIRE(nsample > 0, "QueryBallPoint expects positive nsample"); // tf_grouping.cpp:74
+    VN_REQUIRE(b >= 0 && n > 0, "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape."); // :79
+    VN_REQUIRE(m >= 0, "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.");            // :84
+    if (b == 0 || m == 0) return VOTENET_OK;
+    VN_REQUIRE(xyz1 && xyz2 && idx && pts_cnt, "QueryBallPoint: null buffer");
+    if (!index || n > 131072) // no index (or a bitmap row that would not fit the LDS): the brute-force scan
+        return votenet_query_ball_point(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, stream);
+    const float thr = (radius <= 1e-20f) ? -1.0f : ball_threshold(radius);
+    const SpatialIndex v = spatial_index_view(const_cast<float *>(index), b, n);
+    const int wpl = ((n + 31) / 32 + 63) / 64;
+    const size_t lds = (size_t)4 * wpl * 64 * 4;
+    static size_t attr_lds = 0;
+    if (lds > attr_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&ball_query_indexed_kernel<4>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_lds = lds;
+    }
+    hipLaunchKernelGGL((ball_query_indexed_kernel<4>), dim3((m + 3) / 4, b), dim3(256), lds, as_stream(stream), n, m, thr, nsample,
+                       xyz2, (const int *)v.perm, (const float *)v.bbox, (const float4 *)v.sorted, idx, pts_cnt);
+    return check_launch("query_ball_point_indexed");
+}
+
 extern "C" int votenet_group_point(int b, int n, int c, int m, int nsample, const float *points, const int *idx,
                                    float *out, void *stream)
 {

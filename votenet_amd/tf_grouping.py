@@ -12,10 +12,20 @@ from . import _lib as L
 # bench.py sets this to a list to bracket every ball-query launch with HIP events recorded on the launch stream:
 # entries are (start, end, b, n, m, nsample).
 PROFILE_EVENTS = None
+USE_INDEX = True  # False: query_ball_point always scans all candidates (votenet_query_ball_point), for A/B and tests
 
 
 def query_ball_point(radius, nsample, xyz1, xyz2):
-    """tf_grouping.py:8-20.  float, int, (B,n,3), (B,m,3) -> (idx (B,m,nsample) i32, pts_cnt (B,m) i32)."""
+    """tf_grouping.py:8-20.  float, int, (B,n,3), (B,m,3) -> (idx (B,m,nsample) i32, pts_cnt (B,m) i32).
+    Large candidate clouds (4096 < n <= 131072) go through their spatial index -- the one the farthest-point sampling of the
+    same tensor left behind, or one built here -- with identical results (USE_INDEX = False: always the full scan)."""
+    from . import tf_sampling
+    index = None
+    if USE_INDEX and xyz1.dim() == 3 and tf_sampling.INDEX_MIN_N <= xyz1.shape[1] <= tf_sampling.INDEX_MAX_N and xyz1.is_cuda \
+            and xyz1.dtype == torch.float32 and xyz1.is_contiguous() and xyz1.shape[2] == 3 and float(radius) > 0 and int(nsample) > 0:
+        index = tf_sampling.cached_index(xyz1)
+        if index is None:
+            index = tf_sampling.spatial_index(xyz1)
     xyz1 = L.dev_f32(xyz1.detach(), "QueryBallPoint expects (batch_size, ndataset, 3) xyz1 shape.", 3, 3)
     xyz2 = L.dev_f32(xyz2.detach(), "QueryBallPoint expects (batch_size, npoint, 3) xyz2 shape.", 3, 3)
     b, n, _ = xyz1.shape
@@ -27,8 +37,12 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
         if PROFILE_EVENTS is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        L.check(L.lib().votenet_query_ball_point(b, n, m, float(radius), nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx),
-                                                 L.ptr(cnt), L.stream_ptr()))
+        if index is not None:
+            L.check(L.lib().votenet_query_ball_point_indexed(b, n, m, float(radius), nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(index),
+                                                             L.ptr(idx), L.ptr(cnt), L.stream_ptr()))
+        else:
+            L.check(L.lib().votenet_query_ball_point(b, n, m, float(radius), nsample, L.ptr(xyz1), L.ptr(xyz2), L.ptr(idx),
+                                                     L.ptr(cnt), L.stream_ptr()))
         if PROFILE_EVENTS is not None:
             e1.record()
             PROFILE_EVENTS.append((e0, e1, b, n, m, nsample))

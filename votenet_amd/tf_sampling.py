@@ -14,8 +14,43 @@ from . import _lib as L
 PROFILE_EVENTS = None
 
 
+# Spatial indices left behind by farthest_point_sample (its temp scratch, 4096 < n <= 262144) or built by spatial_index():
+# id(cloud tensor) -> (tensor, version, index scratch).  tf_grouping.query_ball_point looks its candidate cloud up here, so
+# the ball query that follows the sampling of the same cloud (every sample_and_group, utils.py:42-49) reuses the index.
+_INDEX_CACHE = {}
+INDEX_MIN_N, INDEX_MAX_N = 4097, 131072
+
+
+def _remember_index(x, scratch):
+    while len(_INDEX_CACHE) >= 6:
+        _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+    _INDEX_CACHE[id(x)] = (x, x._version, scratch)
+
+
+def cached_index(x):
+    e = _INDEX_CACHE.get(id(x))
+    if e is not None and e[0] is x and e[1] == x._version:
+        return e[2]
+    return None
+
+
+def spatial_index(xyz):
+    """(B,n,3) f32 -> the cloud's spatial index (votenet_spatial_index), remembered for the calls that follow."""
+    got = cached_index(xyz)
+    if got is not None:
+        return got
+    x = L.dev_f32(xyz.detach(), "spatial_index expects (batch_size,num_points,3) xyz shape", 3, 3)
+    b, n, _ = x.shape
+    scratch = torch.empty(L.lib().votenet_spatial_index_floats(b, n), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        L.check(L.lib().votenet_spatial_index(b, n, L.ptr(x), L.ptr(scratch), L.stream_ptr()))
+    _remember_index(xyz, scratch)
+    return scratch
+
+
 def farthest_point_sample(npoint, inp):
     """tf_sampling.py:48-56.  int, (B,n,3) f32 -> (B,npoint) int32.  No gradient."""
+    inp_arg = inp
     inp = L.dev_f32(inp.detach(), "FarthestPointSample expects (batch_size,num_points,3) inp shape", 3, 3)
     b, n, _ = inp.shape
     npoint = int(npoint)
@@ -30,6 +65,8 @@ def farthest_point_sample(npoint, inp):
         if PROFILE_EVENTS is not None:
             e1.record()
             PROFILE_EVENTS.append((e0, e1, b, n, npoint))
+    if temp is not None and INDEX_MIN_N <= n <= 262144 and inp_arg.is_contiguous() and inp_arg.dtype == torch.float32:
+        _remember_index(inp_arg, temp)  # the scratch now holds the cloud's spatial index
     return out
 
 
