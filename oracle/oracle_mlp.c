@@ -17,6 +17,7 @@
 #include "oracle.h"
 #include <math.h>
 #include <stddef.h>
+#include <stdlib.h>
 
 void oracle_linear(long rows, int cin, int cout, const float *x, const float *w, const float *bias, float *z)
 {
@@ -35,36 +36,61 @@ void oracle_linear(long rows, int cin, int cout, const float *x, const float *w,
     }
 }
 
+/* Sums in double over fixed blocks of 4096 rows, the block sums added in block order: the same numbers whatever the number of
+ * threads (liboracle_omp.so gives each block to one thread), row-contiguous reads. */
+#define BN_BLOCK 4096
 void oracle_bn_stats(long rows, int c, const float *z, float *mean, float *var)
 {
+    const long nblk = (rows + BN_BLOCK - 1) / BN_BLOCK;
+    double *part = (double *)malloc(sizeof(double) * (size_t)(nblk > 0 ? nblk : 1) * (size_t)c);
+    double *mu = (double *)malloc(sizeof(double) * (size_t)c);
+    for (int pass = 0; pass < 2; pass++) {
 #pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
-    for (int o = 0; o < c; o++) {
-        double s = 0;
-        for (long r = 0; r < rows; r++) s += z[(size_t)r * c + o];
-        double mu = s / (double)rows;
-        double v = 0;
-        for (long r = 0; r < rows; r++) {
-            double d = z[(size_t)r * c + o] - mu;
-            v += d * d;
+        for (long blk = 0; blk < nblk; blk++) {
+            double *p = part + (size_t)blk * c;
+            for (int o = 0; o < c; o++) p[o] = 0;
+            const long r1 = (blk + 1) * BN_BLOCK < rows ? (blk + 1) * BN_BLOCK : rows;
+            for (long r = blk * BN_BLOCK; r < r1; r++) {
+                const float *zr = z + (size_t)r * c;
+                if (pass == 0)
+                    for (int o = 0; o < c; o++) p[o] += zr[o];
+                else
+                    for (int o = 0; o < c; o++) {
+                        double d = zr[o] - mu[o];
+                        p[o] += d * d;
+                    }
+            }
         }
-        mean[o] = (float)mu;
-        var[o] = (float)(v / (double)rows);
+        for (int o = 0; o < c; o++) {
+            double s = 0;
+            for (long blk = 0; blk < nblk; blk++) s += part[(size_t)blk * c + o];
+            if (pass == 0) {
+                mu[o] = s / (double)rows;
+                mean[o] = (float)mu[o];
+            } else
+                var[o] = (float)(s / (double)rows);
+        }
     }
+    free(part);
+    free(mu);
 }
 
 void oracle_bn_relu(long rows, int c, const float *z, const float *mean, const float *var,
                     const float *gamma, const float *beta, float eps, int relu, float *y)
 {
-#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
+    float *scale = (float *)malloc(sizeof(float) * (size_t)c * 2), *shift = scale + c;
     for (int o = 0; o < c; o++) {
-        float scale = gamma[o] / sqrtf(var[o] + eps);
-        float shift = beta[o] - mean[o] * scale;
-        for (long r = 0; r < rows; r++) {
-            float v = z[(size_t)r * c + o] * scale + shift;
+        scale[o] = gamma[o] / sqrtf(var[o] + eps);
+        shift[o] = beta[o] - mean[o] * scale[o];
+    }
+#pragma omp parallel for schedule(static) /* only in liboracle_omp.so (-fopenmp) */
+    for (long r = 0; r < rows; r++)
+        for (int o = 0; o < c; o++) {
+            float v = z[(size_t)r * c + o] * scale[o] + shift[o];
             if (relu && !(v > 0.0f)) v = 0.0f;
             y[(size_t)r * c + o] = v;
         }
-    }
+    free(scale);
 }
 
 /* utils.py:132 reduce_max over the nsample axis */

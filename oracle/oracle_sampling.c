@@ -21,10 +21,14 @@
 void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int *idxs)
 {
     if (m <= 0) return;
-    float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
-    float dists[FPS_BLOCK];
-    int dists_i[FPS_BLOCK];
+    float *temp_all = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * (size_t)(b > 0 ? b : 1));
+    /* only in liboracle_omp.so: the scenes are independent (the rounds of a scene are a dependent chain; a fork/join per
+     * round costs more than the round) */
+#pragma omp parallel for schedule(static)
     for (int i = 0; i < b; i++) {
+        float *temp = temp_all + (size_t)i * n;
+        float dists[FPS_BLOCK];
+        int dists_i[FPS_BLOCK];
         const float *pts = dataset + (size_t)i * n * 3;
         int old = 0;
         idxs[(size_t)i * m + 0] = old;
@@ -33,7 +37,6 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int
             float x1 = pts[old * 3 + 0];
             float y1 = pts[old * 3 + 1];
             float z1 = pts[old * 3 + 2];
-#pragma omp parallel for schedule(static) /* only in liboracle_omp.so: the 512 "threads" of a round are independent */
             for (int t = 0; t < FPS_BLOCK; t++) {
                 int besti = 0;
                 float best = -1;
@@ -67,7 +70,7 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int
             idxs[(size_t)i * m + j] = old;
         }
     }
-    free(temp);
+    free(temp_all);
 }
 
 /*

@@ -99,31 +99,31 @@ def _median_ms(fn, runs=10, warm=2):
 
 
 def cpu_ops(points, scene_kind, threads_all, runs=10):
-    """Per-op medians (>= 10 runs after 2 warm-ups) of the oracle on ONE scene at sa1 size, at config 1's size and the fp2
-    three_nn, single thread and all cores.  ms per call."""
+    """Per-op medians (>= 10 runs after 2 warm-ups) of the oracle at sa1 size, at config 1's size and the fp2 three_nn, in ms PER
+    SCENE: single thread on one scene; all cores on a batch of 8 scenes (the workload's batch: FPS parallelises over scenes
+    only, its rounds are a dependent chain), divided by 8."""
     from oracle import oracle as O
     from votenet_amd import synth
-    xyz = synth.room_batch(1, points, 1000) if scene_kind == "room" else synth.uniform_batch(1, points, 1000)
-    c1 = np.random.default_rng(0).random((1, 2048, 3), dtype=np.float32)
+    gen = synth.room_batch if scene_kind == "room" else synth.uniform_batch
     res = {}
-    for label, th in (("1t", 1), ("all", threads_all)):
+    for label, th, nb in (("1t", 1, 1), ("all", threads_all, 8)):
+        xyz = gen(nb, points, 1000)
+        c1 = np.stack([np.random.default_rng(s).random((2048, 3), dtype=np.float32) for s in range(nb)])
         prev = O.set_threads(th)
         try:
-            fidx = O.farthest_point_sample(2048, xyz)
-            ctr = O.gather_point(xyz, fidx)
-            f1 = O.farthest_point_sample(512, c1)
-            q1 = O.gather_point(c1, f1)
+            ctr = O.gather_point(xyz, O.farthest_point_sample(2048, xyz))
+            q1 = O.gather_point(c1, O.farthest_point_sample(512, c1))
             l2 = O.gather_point(ctr, O.farthest_point_sample(1024, ctr))
             l3 = O.gather_point(l2, O.farthest_point_sample(512, l2))
             ops = {
-                "fps_sa1 (1 x %d -> 2048)" % points: lambda: O.farthest_point_sample(2048, xyz),
-                "ball_query_sa1 (1 x 2048 x %d, r 0.2, K 64)" % points: lambda: O.query_ball_point(0.2, 64, xyz, ctr),
-                "three_nn_fp2 (1 x 1024 x 512)": lambda: O.three_nn(l2, l3),
-                "config1_fps (1 x 2048 -> 512)": lambda: O.farthest_point_sample(512, c1),
+                "fps_sa1 (%d -> 2048)" % points: lambda: O.farthest_point_sample(2048, xyz),
+                "ball_query_sa1 (2048 x %d, r 0.2, K 64)" % points: lambda: O.query_ball_point(0.2, 64, xyz, ctr),
+                "three_nn_fp2 (1024 x 512)": lambda: O.three_nn(l2, l3),
+                "config1_fps (2048 -> 512)": lambda: O.farthest_point_sample(512, c1),
                 "config1_ball_query (512 x 2048, r 0.2, K 32)": lambda: O.query_ball_point(0.2, 32, c1, q1),
             }
             for name, fn in ops.items():
-                res.setdefault(name, {})["ms_" + label] = round(_median_ms(fn, runs), 4)
+                res.setdefault(name, {})["ms_per_scene_" + label] = round(_median_ms(fn, runs) / nb, 4)
         finally:
             O.set_threads(prev)
     return res
@@ -161,7 +161,7 @@ def cpu_baseline(points, scene_kind, min_seconds=8.0, max_scenes=3, batch_all=4,
                      % (points, scene_kind, k1, tot1, ka, batch_all, h["threads_all"], tota)}
     if ops:
         out["ops_ms"] = cpu_ops(points, scene_kind, h["threads_all"])
-        out["ops_note"] = ("median of 10 runs after 2 warm-ups, one scene per call; FPS is the restatement of tf_sampling_g.cu:105-170 "
+        out["ops_note"] = ("ms per scene, median of 10 runs after 2 warm-ups: one scene per call single-thread, 8 scenes per call on all cores; FPS is the restatement of tf_sampling_g.cu:105-170 "
                            "(the reference has no CPU FPS), ball query / three_nn restate test/query_ball_point.cpp:19-84 and "
                            "tf_interpolate.cpp:60-103 and are bit-identical to those compiled (tests/test_oracle_golden.py)")
     return out
