@@ -277,12 +277,16 @@ int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const floa
                                const float *below_mean, const float *below_var, float eps, int below_relu,
                                double *below_sums, void *stream);
 /* gram (c x c, pre-zeroed or accumulating) += a^T a with a = act(z * scale + shift); scale_shift = [scale | shift] (2c) */
-int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, void *stream);
+/* scratch: votenet_mlp_wgrad_scratch_floats(NULL, rows, c, c) floats or NULL, as for votenet_mlp_wgrad */
+int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
+                     void *stream);
 /* dw (cin x cout) += the gathered rows; colsum (cin, pre-zeroed) += sum_r x[r,:]; xz / in_scale / in_shift / in_relu
  * describe x as in votenet_mlp_input */
 int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
                               const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
-                              const float *coef, int relu, float *dw, float *colsum, void *stream);
+                              const float *coef, int relu, float *dw, float *colsum, float *scratch, void *stream);
+/* scratch of votenet_pool_wgrad_sparse (NULL: fp32 atomics, summation order unspecified) */
+size_t votenet_pool_wgrad_scratch_floats(long groups, int cin, int cout);
 /* dw[j,c] += C[c] (gram[j,:] . W[:,c]) + colsum[j] (B[c] + C[c] b[c]) */
 int votenet_pool_wgrad_finish(int cin, int cout, const float *gram, const float *colsum, const float *w, const float *bias,
                               const float *coef, float *dw, void *stream);
@@ -313,10 +317,13 @@ int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float 
 
 /* dw (cin x cout, the caller's row order) += input(rows x cin)^T * dz (rows x cout), the input
  * described exactly as for votenet_mlp_linear (same fused GATHER / DENSE+BNReLU loaders).
- * The contraction over rows is split across workgroups; partial tiles are added with fp32 atomics
- * (summation order unspecified, like the reference's cuDNN / atomics-based gradients). */
+ * The contraction over rows is split across workgroups.  scratch != NULL (votenet_mlp_wgrad_scratch_floats floats): every
+ * workgroup stores its partial tile there and a second launch adds the partials to dw in workgroup order -- one summation
+ * order, bit-reproducible gradients.  scratch == NULL: the partial tiles are added with fp32 atomics (summation order
+ * unspecified, like the reference's cuDNN / atomics-based gradients). */
+size_t votenet_mlp_wgrad_scratch_floats(const votenet_mlp_input *in, long rows, int cin, int cout);
 int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
-                      void *stream);
+                      float *scratch, void *stream);
 
 /* ---- BatchNorm backward folded into the two backward GEMMs (no dz tensor in memory) -----------------
  * With sums = [sum g', sum g'*zhat] (votenet_bn_backward_reduce) the
@@ -332,7 +339,7 @@ int votenet_bn_backward_coef(long rows, int c, const float *scale, const float *
  * upstream gradient) / gout (rows/pool_k x cout, gradient of the max over pool_k rows, with argmax). */
 int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int cout, const float *da,
                          const float *gout, const int *argmax, int pool_k, const float *z, const float *coef,
-                         int relu, float *dw, void *stream);
+                         int relu, float *dw, float *scratch, void *stream);
 
 /* da_prev (rows x cout) = dz (rows x c) * wT (c x cout), dz formed as above from (da | gout+argmax, zsrc,
  * coef) inside the operand loader.

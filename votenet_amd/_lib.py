@@ -83,9 +83,9 @@ _SIGS.update({
     "votenet_pool_dgrad_prepare": [ctypes.c_int] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_pool_dgrad_scatter": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_int] + [_c_f] * 7
                                   + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.c_void_p],
-    "votenet_mlp_gram": [ctypes.c_long, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_mlp_gram": [ctypes.c_long, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],
     "votenet_pool_wgrad_sparse": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
-                                 + [_c_f] * 2 + [ctypes.c_void_p],
+                                 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_pool_wgrad_finish": [ctypes.c_int] * 2 + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
@@ -104,10 +104,10 @@ _SIGS.update({
                                                                                              ctypes.c_void_p],
     "votenet_bn_backward_apply": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_bias_grad": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
-    "votenet_mlp_wgrad": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_mlp_wgrad": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_bn_backward_coef": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_float] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_mlp_wgrad_bn": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int]
-                            + [_c_f] * 2 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+                            + [_c_f] * 2 + [ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],
     "votenet_mlp_dgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int]
                             + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
@@ -129,6 +129,10 @@ def lib():
         L.votenet_version.restype = ctypes.c_char_p
         L.votenet_fps_temp_floats.restype = ctypes.c_size_t
         L.votenet_fps_temp_floats.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_mlp_wgrad_scratch_floats.restype = ctypes.c_size_t
+        L.votenet_mlp_wgrad_scratch_floats.argtypes = [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        L.votenet_pool_wgrad_scratch_floats.restype = ctypes.c_size_t
+        L.votenet_pool_wgrad_scratch_floats.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.votenet_spatial_index_floats.restype = ctypes.c_size_t
         L.votenet_spatial_index_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_loss_workspace_floats.restype = ctypes.c_size_t

@@ -524,7 +524,11 @@ __global__ __launch_bounds__(256) void mlp_wgrad_kernel(MlpIn in, long rows, int
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int i = i0 + (wi * TI + s) * 32 + (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5);
-                if (i < cin && j < cout) unsafeAtomicAdd(&dw[(size_t)w_row<MODE>(i, in.c) * cout + j], acc[s][t][e]);
+                if (i < cin && j < cout) {
+                    const size_t off = (size_t)w_row<MODE>(i, in.c) * cout + j;
+                    if (bs.part) bs.part[(size_t)blockIdx.x * bs.pstride + off] = acc[s][t][e];
+                    else unsafeAtomicAdd(&dw[off], acc[s][t][e]);
+                }
             }
         }
 }
@@ -704,7 +708,7 @@ extern "C" int votenet_bias_grad(long rows, int c, const float *dz, double *scra
 // tile would be ~97 % padding here; this is a streaming reduction over dz instead: every workgroup stages the
 // narrow rows of 256 grouped points in LDS, thread (column j, row subset) accumulates nch partial sums.
 __global__ __launch_bounds__(256) void wgrad_narrow_kernel(MlpIn in, long rows, int nch, int cout, const float *__restrict__ dz,
-                                                           float *__restrict__ dw, long rows_per_block)
+                                                           float *__restrict__ dw, long rows_per_block, float *__restrict__ part)
 {
     __shared__ __attribute__((aligned(16))) float As[256][8];
     __shared__ float red[256][8];
@@ -753,23 +757,64 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(MlpIn in, long rows, 
         for (int q = 0; q < nch; q++) {
             float t = 0.0f;
             for (int u = 0; u < nsub; u++) t += red[u * cout + tid][q];
-            unsafeAtomicAdd(&dw[(size_t)q * cout + tid], t); // narrow channel q is W row q (dxyz first, utils.py:55)
+            // narrow channel q is W row q (dxyz first, utils.py:55); part: this workgroup's slice (see BnSrc::part)
+            if (part) part[((size_t)blockIdx.x * nch + q) * cout + tid] = t;
+            else unsafeAtomicAdd(&dw[(size_t)q * cout + tid], t);
         }
     }
 }
 
-template <int MODE, int BSRC>
-static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, float *dw, hipStream_t st)
+// dw[e] += part[0][e] + part[1][e] + ... in ascending slice order, e in [e0, e1): the ordered reduction behind BnSrc::part
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nslice, long pstride, long e0, long e1, const float *__restrict__ part,
+                                                           float *__restrict__ dw)
 {
-    const int TIr = cin <= 64 ? 1 : 2, TJr = cout <= 64 ? 1 : 2;
+    const long e = e0 + (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= e1) return;
+    float s = 0.0f;
+    int t = 0;
+    for (; t + 4 <= nslice; t += 4) { // four loads in flight, added in order
+        const float a = part[(size_t)t * pstride + e], b = part[(size_t)(t + 1) * pstride + e];
+        const float c = part[(size_t)(t + 2) * pstride + e], d = part[(size_t)(t + 3) * pstride + e];
+        s = (((s + a) + b) + c) + d;
+    }
+    for (; t < nslice; t++) s += part[(size_t)t * pstride + e];
+    dw[e] += s;
+}
+namespace votenet {
+void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st)
+{
+    if (e1 > e0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, st, nslice, pstride, e0, e1, part, dw);
+}
+}
+
+// row ranges of the generic kernel: grid.x slices of rpb rows
+static void plan_wgrad(long rows, int cin, int cout, int &TIr, int &TJr, int &ti, int &tj, long &rpb, unsigned &gx)
+{
+    TIr = cin <= 64 ? 1 : 2;
+    TJr = cout <= 64 ? 1 : 2;
     const int BI = 64 * TIr, BJ = 64 * TJr;
-    const int ti = (cin + BI - 1) / BI, tj = (cout + BJ - 1) / BJ;
+    ti = (cin + BI - 1) / BI;
+    tj = (cout + BJ - 1) / BJ;
     long splits = 768 / (ti * tj);
     if (splits < 1) splits = 1;
-    long rpb = (rows + splits - 1) / splits;
+    rpb = (rows + splits - 1) / splits;
     rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
-    if (rpb < 8 * WG_BR) rpb = 8 * WG_BR; // short row ranges are dominated by the atomic flush of the dW tile (measured)
-    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
+    if (rpb < 8 * WG_BR) rpb = 8 * WG_BR; // short row ranges are dominated by the flush of the dW tile (measured)
+    gx = (unsigned)((rows + rpb - 1) / rpb);
+}
+
+// wrows: rows of the dw block the launch addresses (MODE 0: cin; MODE 1: 3 + in.c); r0: first of them it writes
+template <int MODE, int BSRC>
+static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const float *dz, BnSrc bs, float *dw, hipStream_t st, float *scratch,
+                         int wrows, int r0)
+{
+    int TIr, TJr, ti, tj;
+    long rpb;
+    unsigned gx;
+    plan_wgrad(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx);
+    bs.part = scratch;
+    bs.pstride = (long)wrows * cout;
+    const dim3 grid(gx, ti, tj);
     if (TIr == 2 && TJr == 2)
         hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else if (TIr == 2)
@@ -778,15 +823,42 @@ static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const flo
         hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else
         hipLaunchKernelGGL((mlp_wgrad_kernel<MODE, 1, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    if (scratch) votenet::wgrad_reduce((int)gx, bs.pstride, (long)r0 * cout, (long)wrows * cout, scratch, dw, st);
 }
 
 namespace votenet {
 bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
-                       hipStream_t st); // mlp_wgrad_fast.hip
+                       hipStream_t st, float *scratch); // mlp_wgrad_fast.hip
+long wgrad_fast_slices(long rows, int cin, int cout); // its grid.x
+}
+
+static long narrow_rpb(long rows)
+{
+    long rpb = (rows + 1023) / 1024;
+    return (rpb + 255) / 256 * 256;
+}
+
+// floats of scratch that make every launch of wgrad_entry deterministic (an upper bound over the kernels it may choose)
+static size_t wgrad_scratch_floats(const votenet_mlp_input *in, long rows, int cin, int cout)
+{
+    if (rows <= 0 || cin <= 0 || cout <= 0) return 0;
+    int TIr, TJr, ti, tj;
+    long rpb;
+    unsigned gx;
+    plan_wgrad(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx);
+    size_t need = (size_t)gx * cin * cout;
+    const size_t fast = (size_t)wgrad_fast_slices(rows, cin, cout) * cin * cout;
+    if (fast > need) need = fast;
+    if (in && !in->x) {
+        const long rn = narrow_rpb(rows);
+        const size_t nar = (size_t)((rows + rn - 1) / rn) * 8 * cout;
+        if (nar > need) need = nar;
+    }
+    return need;
 }
 
 static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc,
-                       float *dw, void *stream)
+                       float *dw, float *scratch, void *stream)
 {
     VN_REQUIRE(in != nullptr, "mlp_wgrad: null input descriptor");
     VN_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "mlp_wgrad expects rows >= 0, cin > 0, cout > 0");
@@ -796,10 +868,10 @@ static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout
     hipStream_t st = as_stream(stream);
     if (in->x) {
         VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_wgrad: in_scale and in_shift go together");
-        if (wgrad_fast_launch(0, d, rows, cin, cout, dz, bs, bsrc, dw, st)) return check_launch("mlp_wgrad");
-        if (bsrc == 0) launch_wgrad<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
-        else if (bsrc == 1) launch_wgrad<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
-        else launch_wgrad<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
+        if (wgrad_fast_launch(0, d, rows, cin, cout, dz, bs, bsrc, dw, st, scratch)) return check_launch("mlp_wgrad");
+        if (bsrc == 0) launch_wgrad<0, 0>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
+        else if (bsrc == 1) launch_wgrad<0, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
+        else launch_wgrad<0, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
     } else {
         VN_REQUIRE(in->xyz && in->new_xyz && in->idx, "mlp_wgrad: GATHER input needs xyz, new_xyz and idx");
         VN_REQUIRE(rows == (long)in->b * in->m * in->nsample, "mlp_wgrad: rows must equal b*m*nsample for a GATHER input");
@@ -808,33 +880,38 @@ static int wgrad_entry(const votenet_mlp_input *in, long rows, int cin, int cout
         if (narrow_ok) {
             // dxyz (and <= 5 feature) columns: streaming reduction; wide feature block: MFMA kernel on W rows 3..
             const int nch = d.c <= 5 ? 3 + d.c : 3;
-            long rpb = (rows + 1023) / 1024;
-            rpb = (rpb + 255) / 256 * 256;
-            hipLaunchKernelGGL(wgrad_narrow_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, st, d, rows, nch, cout, dz,
-                               dw, rpb);
-            if (d.c > 5 && !wgrad_fast_launch(1, d, rows, d.c, cout, dz, bs, 0, dw, st))
-                launch_wgrad<1, 0>(d, rows, d.c, cout, dz, bs, dw, st); // internal k < c are the feature channels
+            const long rpb = narrow_rpb(rows);
+            const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
+            hipLaunchKernelGGL(wgrad_narrow_kernel, dim3(gx), dim3(256), 0, st, d, rows, nch, cout, dz, dw, rpb, scratch);
+            if (scratch) votenet::wgrad_reduce((int)gx, (long)nch * cout, 0, (long)nch * cout, scratch, dw, st);
+            if (d.c > 5 && !wgrad_fast_launch(1, d, rows, d.c, cout, dz, bs, 0, dw, st, scratch))
+                launch_wgrad<1, 0>(d, rows, d.c, cout, dz, bs, dw, st, scratch, 3 + d.c, 3); // internal k < c are the feature channels
         } else {
-            if (bsrc == 0) launch_wgrad<1, 0>(d, rows, cin, cout, dz, bs, dw, st);
-            else if (bsrc == 1) launch_wgrad<1, 1>(d, rows, cin, cout, dz, bs, dw, st);
-            else launch_wgrad<1, 2>(d, rows, cin, cout, dz, bs, dw, st);
+            if (bsrc == 0) launch_wgrad<1, 0>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
+            else if (bsrc == 1) launch_wgrad<1, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
+            else launch_wgrad<1, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch, cin, 0);
         }
     }
     return check_launch("mlp_wgrad");
 }
 
+extern "C" size_t votenet_mlp_wgrad_scratch_floats(const votenet_mlp_input *in, long rows, int cin, int cout)
+{
+    return wgrad_scratch_floats(in, rows, cin, cout);
+}
+
 extern "C" int votenet_mlp_wgrad(const votenet_mlp_input *in, long rows, int cin, int cout, const float *dz, float *dw,
-                                 void *stream)
+                                 float *scratch, void *stream)
 {
     VN_REQUIRE(dz != nullptr || rows == 0, "mlp_wgrad: null dz");
     BnSrc bs = {};
-    return wgrad_entry(in, rows, cin, cout, dz, bs, 0, dw, stream);
+    return wgrad_entry(in, rows, cin, cout, dz, bs, 0, dw, scratch, stream);
 }
 
 // dw += input^T * dz with dz = BatchNorm-backward(da | pooled gout, z, coef) formed inside the dz-operand loader
 extern "C" int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int cout, const float *da, const float *gout,
                                     const int *argmax, int pool_k, const float *z, const float *coef, int relu, float *dw,
-                                    void *stream)
+                                    float *scratch, void *stream)
 {
     VN_REQUIRE((da != nullptr) != (gout != nullptr), "mlp_wgrad_bn: exactly one of da / gout");
     VN_REQUIRE(z && coef, "mlp_wgrad_bn: null buffer");
@@ -842,8 +919,8 @@ extern "C" int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int 
     VN_REQUIRE(rows < (1L << 31), "mlp_wgrad_bn: rows must be below 2^31");
     int shift = -1;
     if (pool_k > 0 && (pool_k & (pool_k - 1)) == 0) shift = __builtin_ctz((unsigned)pool_k);
-    BnSrc bs = {da, gout, argmax, pool_k, shift, z, coef, relu};
-    return wgrad_entry(in, rows, cin, cout, nullptr, bs, da ? 1 : 2, dw, stream);
+    BnSrc bs = {da, gout, argmax, pool_k, shift, z, coef, relu, nullptr, 0};
+    return wgrad_entry(in, rows, cin, cout, nullptr, bs, da ? 1 : 2, dw, scratch, stream);
 }
 
 // coefficient vector [A | B | C | scale | shift] (5*c floats) of the folded BatchNorm backward, from the reductions

@@ -32,6 +32,11 @@ struct BnSrc {
     int pool_k, pool_shift; // pool_shift = log2(pool_k) when pool_k is a power of two, else -1
     const float *z, *coef;
     int relu;
+    // deterministic weight gradients: when part != NULL a workgroup STORES its partial dW tile at
+    // part[blockIdx.x * pstride + (the element's offset inside dw)] instead of adding it to dw with atomics;
+    // wgrad_reduce_kernel then adds the blockIdx.x slices to dw in ascending order (one summation order -> bit-reproducible)
+    float *part;
+    long pstride;
 };
 
 } // namespace votenet

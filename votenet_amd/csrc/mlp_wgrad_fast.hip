@@ -238,26 +238,58 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int i = i0 + (wi * TI + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                unsafeAtomicAdd(&dw[(size_t)(wrow0 + i) * cout + j], acc[a][b][e]);
+                const size_t off = (size_t)(wrow0 + i) * cout + j;
+                if (bs.part) bs.part[(size_t)blockIdx.x * bs.pstride + off] = acc[a][b][e]; // ordered reduction follows (BnSrc::part)
+                else unsafeAtomicAdd(&dw[off], acc[a][b][e]);
             }
         }
 }
 
-template <int MODE, int BSRC>
-static bool launch(const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, float *dw, hipStream_t st)
+int g_wgrad_fast_wgs = 0; // votenet_debug_wgrad_workgroups (tuning hook): 0 = the measured defaults below
+static void plan_fast(long rows, int cin, int cout, int &TIr, int &TJr, int &ti, int &tj, long &rpb, unsigned &gx, bool partials)
 {
-    const int TIr = cin % 128 == 0 ? 2 : 1, TJr = cout % 128 == 0 ? 2 : 1;
-    const int ti = cin / (64 * TIr), tj = cout / (64 * TJr);
+    TIr = cin % 128 == 0 ? 2 : 1;
+    TJr = cout % 128 == 0 ? 2 : 1;
+    ti = cin / (64 * TIr);
+    tj = cout / (64 * TJr);
     // 384 workgroups, not the 768 that are fastest when the kernel has the GPU to itself (+12 % there): in a train step it runs
     // on its own stream beside the input-gradient chain, which is the critical one (8.00 -> 7.90 ms per step, measured)
-    long splits = 384 / (ti * tj);
+    // with partial tiles + ordered reduction (scratch given) 256: every extra workgroup is another 64 KB slice to write and read
+    // (same-box A/B of the train step: 384 -> 8.03 ms, 256 -> 7.91 ms, 192 -> 8.04 ms, 128 -> 8.65 ms; atomics, 384: 7.83 ms)
+    const int wgs = g_wgrad_fast_wgs > 0 ? g_wgrad_fast_wgs : (partials ? 256 : 384);
+    long splits = wgs / (ti * tj);
     if (splits < 1) splits = 1;
-    long rpb = (rows + splits - 1) / splits;
+    rpb = (rows + splits - 1) / splits;
     rpb = (rpb + 2 * WF_BR - 1) / (2 * WF_BR) * (2 * WF_BR);
-    if (rpb < 8 * WF_BR) rpb = 8 * WF_BR; // short row ranges are dominated by the atomic flush of the dW tile (measured)
+    if (rpb < 8 * WF_BR) rpb = 8 * WF_BR; // short row ranges are dominated by the flush of the dW tile (measured)
+    gx = (unsigned)((rows + rpb - 1) / rpb);
+}
+
+long wgrad_fast_slices(long rows, int cin, int cout)
+{
+    if (cin % 64 != 0 || cout % 64 != 0 || rows <= 0) return 0;
+    int TIr, TJr, ti, tj;
+    long rpb;
+    unsigned gx;
+    plan_fast(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx, false); // the larger of the two plans: an upper bound
+    return gx;
+}
+
+void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st); // mlp_bwd.hip
+
+template <int MODE, int BSRC>
+static bool launch(const MlpIn &d, long rows, int cin, int cout, const float *dz, BnSrc bs, float *dw, hipStream_t st, float *scratch)
+{
+    int TIr, TJr, ti, tj;
+    long rpb;
+    unsigned gx;
+    plan_fast(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx, scratch != nullptr);
     const int wide = cin > cout ? cin : cout;
     if (rpb * wide >= (1L << 31)) return false; // 32-bit element offsets inside a workgroup's row range
-    const dim3 grid((unsigned)((rows + rpb - 1) / rpb), ti, tj);
+    const int wrow0 = (MODE == 1) ? 3 : 0;
+    bs.part = scratch;
+    bs.pstride = (long)(wrow0 + cin) * cout;
+    const dim3 grid(gx, ti, tj);
     if (TIr == 2 && TJr == 2)
         hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else if (TIr == 2)
@@ -266,12 +298,13 @@ static bool launch(const MlpIn &d, long rows, int cin, int cout, const float *dz
         hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else
         hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    if (scratch) wgrad_reduce((int)gx, bs.pstride, (long)wrow0 * cout, (long)(wrow0 + cin) * cout, scratch, dw, st);
     return true;
 }
 
 // Takes the launch when the shape fits; mode 1: cin = the feature channels of the GATHER input (d.c).
 bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
-                       hipStream_t st)
+                       hipStream_t st, float *scratch)
 {
     if (cin % 64 != 0 || cout % 64 != 0 || rows <= 0 || rows >= (1L << 31)) return false;
     auto al = [](const void *p) { return ((uintptr_t)p % 16) == 0; };
@@ -280,13 +313,15 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         return false;
     if (mode == 0) {
         if (!al(d.x) || (d.in_scale && (!al(d.in_scale) || !al(d.in_shift)))) return false;
-        if (bsrc == 0) return launch<0, 0>(d, rows, cin, cout, dz, bs, dw, st);
-        if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st);
-        if (bsrc == 3) return launch<0, 3>(d, rows, cin, cout, dz, bs, dw, st);
-        return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st);
+        if (bsrc == 0) return launch<0, 0>(d, rows, cin, cout, dz, bs, dw, st, scratch);
+        if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
+        if (bsrc == 3) return launch<0, 3>(d, rows, cin, cout, dz, bs, dw, st, scratch);
+        return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (d.c != cin || !al(d.feat) || bsrc != 0) return false;
-    return launch<1, 0>(d, rows, cin, cout, dz, bs, dw, st);
+    return launch<1, 0>(d, rows, cin, cout, dz, bs, dw, st, scratch);
 }
 
 } // namespace votenet
+
+extern "C" void votenet_debug_wgrad_workgroups(int n) { votenet::g_wgrad_fast_wgs = n > 0 ? n : 0; } // tuning hook

@@ -16,7 +16,8 @@
 namespace votenet {
 
 bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, const float *dz, const BnSrc &bs, int bsrc, float *dw,
-                       hipStream_t st); // mlp_wgrad_fast.hip
+                       hipStream_t st, float *scratch); // mlp_wgrad_fast.hip
+void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st); // mlp_bwd.hip
 
 static inline int pb_grid(long total, int block, int cap)
 {
@@ -267,7 +268,7 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
                                                                 int in_relu, const float *__restrict__ gout,
                                                                 const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                 const float *__restrict__ coef, int relu, float *__restrict__ dw,
-                                                                float *__restrict__ colsum)
+                                                                float *__restrict__ colsum, float *__restrict__ part)
 {
     constexpr int LD = CIN + 4;
     __shared__ __attribute__((aligned(16))) float xs[K][LD];
@@ -335,6 +336,15 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
             for (int r = 0; r < K; r++) csum += xs[r][jc];
         }
         __syncthreads();
+    }
+    if (part) { // this workgroup's slice [(CIN + 1) x cout]: dW rows, then the column sums; added in workgroup order afterwards
+        float *__restrict__ mine = part + (size_t)blockIdx.x * (CIN + 1) * cout;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < CIN; i++) mine[(size_t)i * cout + tid] = acc[i];
+        }
+        if (tid >= 256 - CIN) mine[(size_t)CIN * cout + tid - (256 - CIN)] = csum;
+        return;
     }
     if (own) {
 #pragma unroll
@@ -452,7 +462,8 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
     return check_launch("pool_dgrad_scatter");
 }
 
-extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, void *stream)
+extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
+                                void *stream)
 {
     VN_REQUIRE(rows > 0 && c > 0 && z && scale_shift && gram, "mlp_gram: bad arguments");
     MlpIn d = {};
@@ -464,16 +475,17 @@ extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *s
     bs.z = z;
     bs.coef = scale_shift;
     bs.relu = relu;
-    VN_REQUIRE(wgrad_fast_launch(0, d, rows, c, c, nullptr, bs, 3, gram, as_stream(stream)),
+    VN_REQUIRE(wgrad_fast_launch(0, d, rows, c, c, nullptr, bs, 3, gram, as_stream(stream), scratch),
                "mlp_gram: shape not served (c %% 64 == 0, 16-byte aligned operands), got c = %d", c);
     return check_launch("mlp_gram");
 }
 
 extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
                                          const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
-                                         const float *coef, int relu, float *dw, float *colsum, void *stream)
+                                         const float *coef, int relu, float *dw, float *colsum, float *scratch, void *stream)
 {
     VN_REQUIRE(groups > 0 && xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse: bad arguments");
+    VN_REQUIRE(cin <= cout, "pool_wgrad_sparse expects cin <= cout");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, k), "pool_wgrad_sparse: unsupported shape cin=%d cout=%d k=%d", cin, cout, k);
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse: in_scale and in_shift go together");
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
@@ -482,11 +494,22 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
     hipStream_t st = as_stream(stream);
     if (cin == 128)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum);
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch);
     else
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum);
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch);
+    if (scratch) { // ordered reduction of the workgroups' slices: dW rows, then the column sums (row cin of a slice)
+        const long ps = (long)(cin + 1) * cout;
+        wgrad_reduce(grid, ps, 0, (long)cin * cout, scratch, dw, st);
+        wgrad_reduce(grid, ps, (long)cin * cout, (long)cin * cout + cin, scratch, colsum - (long)cin * cout, st);
+    }
     return check_launch("pool_wgrad_sparse");
+}
+
+extern "C" size_t votenet_pool_wgrad_scratch_floats(long groups, int cin, int cout)
+{
+    if (groups <= 0) return 0;
+    return (size_t)pb_grid(groups, 8, 384) * (size_t)(cin + 1) * cout;
 }
 
 extern "C" int votenet_pool_wgrad_finish(int cin, int cout, const float *gram, const float *colsum, const float *w, const float *bias,

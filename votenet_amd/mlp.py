@@ -63,6 +63,17 @@ def _zeros_f64(n, device):
     return torch.zeros(n, dtype=torch.float64, device=device)
 
 
+# Weight gradients through per-workgroup partial tiles + an ordered reduction (bit-reproducible) instead of fp32 atomics
+DETERMINISTIC = True
+
+
+def _wgrad_scratch(desc, rows, cin, cout, device):
+    if not DETERMINISTIC:
+        return None
+    nf = L.lib().votenet_mlp_wgrad_scratch_floats(ctypes.byref(desc) if desc is not None else None, rows, cin, cout)
+    return torch.empty(nf, dtype=torch.float32, device=device) if nf else None
+
+
 BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
 
 
@@ -275,8 +286,9 @@ def gram(xz, scale_shift, relu):
     """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c)."""
     rows, c = xz.shape
     g = torch.zeros((c + 1, c), dtype=torch.float32, device=xz.device)  # [gram ; column sums (filled by pool_wgrad)]
+    scr = _wgrad_scratch(None, rows, c, c, xz.device)
     with torch.cuda.device(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
-        L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.stream_ptr()))
+        L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.ptr(scr), L.stream_ptr()))
     return g
 
 
@@ -284,10 +296,13 @@ def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, g
     """dw += x^T dz of the pooled layer from the Gram matrix (gram()), the gathered arg-max rows and the column sums."""
     rows, cin = xz.shape
     cout = w.shape[1]
+    scr = None
+    if DETERMINISTIC:
+        scr = torch.empty(L.lib().votenet_pool_wgrad_scratch_floats(rows // k, cin, cout), dtype=torch.float32, device=xz.device)
     with torch.cuda.device(xz.device):
         L.check(L.lib().votenet_pool_wgrad_sparse(rows // k, k, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0,
                                                   L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
-                                                  L.ptr(gram_buf[cin]), L.stream_ptr()))
+                                                  L.ptr(gram_buf[cin]), L.ptr(scr), L.stream_ptr()))
         L.check(L.lib().votenet_pool_wgrad_finish(cin, cout, L.ptr(gram_buf), L.ptr(gram_buf[cin]), L.ptr(w), L.ptr(bias), L.ptr(coef),
                                                   L.ptr(dw), L.stream_ptr()))
 
@@ -413,9 +428,10 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
     rows, cin = x.shape
     cout = z.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
+    scr = _wgrad_scratch(d, rows, cin, cout, x.device)
     with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad_bn")):
         L.check(L.lib().votenet_mlp_wgrad_bn(ctypes.byref(d), rows, cin, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z),
-                                             L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.stream_ptr()))
+                                             L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
 def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0):
@@ -441,16 +457,18 @@ def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
     rows, cin = x.shape
     cout = dz.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
+    scr = _wgrad_scratch(d, rows, cin, cout, x.device)
     with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad")):
-        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.stream_ptr()))
+        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
 def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
     b, m, k = idx.shape
     c = feat.shape[2] if feat is not None else 0
     d = _desc_gather(xyz, new_xyz, feat, idx)
+    scr = _wgrad_scratch(d, b * m * k, 3 + c, dz.shape[1], xyz.device)
     with torch.cuda.device(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1], (b * m * k, 3 + c, dz.shape[1], "wgrad_gather")):
-        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.stream_ptr()))
+        L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
 def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):

@@ -302,6 +302,7 @@ class VoteNetHotPath:
         sa1, sa2, sa3, sa4, fp1, fp2, vote, prop = [recs[i] for i in range(8)]
         # proposal layer: gradients reach the vote features AND the vote xyz (grouped xyz, gathered centres)
         d_vp, d_vx = self.proposal.backward(prop, cot["proposals_output"], need_feat_grad=True, need_xyz_grad=True)
+        P.wgrad_flush()  # the module's weight gradients go to their stream together, underneath the next module's chain
         if cot.get("votes_xyz") is not None:
             d_vx = d_vx + cot["votes_xyz"]
         if cot.get("proposals_xyz") is not None:  # proposals_xyz = gather(votes_xyz, fps_idx), utils.py:42-47
@@ -310,21 +311,31 @@ class VoteNetHotPath:
         b, n = vote["b"], vote["n"]
         d_votes = torch.cat([d_vx, d_vp], dim=2).view(b * n, 259)
         d_x = d_votes + P.mlp_chain_backward(vote["recs"], d_votes, "plain", need_input_grad=True)
+        P.wgrad_flush()
         d_seeds_p = d_x[:, 3:].contiguous().view(b, n, 256)
         # feature propagation
         d_l2p, d_l3p2 = self.fp2.backward(fp2, d_seeds_p)
+        P.wgrad_flush()
         d_l3p, d_l4p = self.fp1.backward(fp1, d_l3p2)
+        P.wgrad_flush()
         # set abstraction (xyz carries no gradient in the backbone: the cloud is the input)
         g3, _ = self.sa4.backward(sa4, d_l4p)
+        P.wgrad_flush()
         d_l3p = d_l3p + g3
         g2, _ = self.sa3.backward(sa3, d_l3p)
+        P.wgrad_flush()
         d_l2p = d_l2p + g2
         # every gradient of sa3 ... proposal (the tail of the flat bucket) is enqueued: its all-reduce runs on the
         # communication stream underneath the backward pass of sa2 and sa1 (dp.GradSync; a no-op on one GPU)
         if getattr(self, "_gsync", None) is not None:
             self._gsync.start_tail([P.WGRAD_STREAM])
         g1, _ = self.sa2.backward(sa2, d_l2p)
-        self.sa1.backward(sa1, g1, need_feat_grad=False)
+        P.wgrad_flush()
+        P.wgrad_fine(True)  # the last module: nothing follows to hide its weight gradients under, so they start layer by layer
+        try:
+            self.sa1.backward(sa1, g1, need_feat_grad=False)
+        finally:
+            P.wgrad_fine(False)
 
     def init_optimizer(self, lr=1e-3):
         s = self.store

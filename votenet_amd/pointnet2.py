@@ -240,34 +240,62 @@ WGRAD_STREAM = None
 _wgrad_pending = False
 
 
-class _OnWgradStream:
-    """Context: run the enclosed launches on WGRAD_STREAM after everything issued so far on the current stream."""
+# Every hand-over to WGRAD_STREAM costs an event (a barrier packet in the main queue: a few microseconds in which the chain
+# stands still).  WGRAD_BATCH = True collects the weight-gradient launches of a module and hands them over together at
+# wgrad_flush() (one event per module: its weight gradients then run underneath the NEXT module's chain); modules named in
+# WGRAD_FINE (the last one of the backward pass, whose weight gradients have nothing after them to hide under) keep one
+# hand-over per launch.
+WGRAD_BATCH = False  # measured (tools/ab_step.py, same box): 7.81 ms per step per launch vs 7.99 ms batched per module -- where the weight gradients run matters more than the ~30 events saved
+_wgrad_deferred = []
+_wgrad_fine = False
 
-    def __init__(self, *tensors):
-        self.tensors = [t for t in tensors if isinstance(t, torch.Tensor)]
 
-    def __enter__(self):
-        global _wgrad_pending
-        self.ctx = None
-        if WGRAD_STREAM is not None:
-            main = torch.cuda.current_stream()
-            ev = torch.cuda.Event()
-            ev.record(main)
-            WGRAD_STREAM.wait_event(ev)
-            for t in self.tensors:
-                t.record_stream(WGRAD_STREAM)
-            self.ctx = torch.cuda.stream(WGRAD_STREAM)
-            self.ctx.__enter__()
-            _wgrad_pending = True
+def wgrad_fine(on):
+    global _wgrad_fine
+    _wgrad_fine = bool(on)
 
-    def __exit__(self, *a):
-        if self.ctx is not None:
-            self.ctx.__exit__(*a)
+
+def _hand_over(thunks, tensors):
+    global _wgrad_pending
+    main = torch.cuda.current_stream()
+    ev = torch.cuda.Event()
+    ev.record(main)
+    WGRAD_STREAM.wait_event(ev)
+    for t in tensors:
+        t.record_stream(WGRAD_STREAM)
+    with torch.cuda.stream(WGRAD_STREAM):
+        for f in thunks:
+            f()
+    _wgrad_pending = True
+
+
+def on_wgrad_stream(fn, *tensors):
+    """Run fn() -- launches of weight-gradient kernels reading `tensors` -- on WGRAD_STREAM after everything issued so far on the
+    current stream (now, or together with the module's other weight gradients at the next wgrad_flush()); on the current
+    stream when there is no weight-gradient stream."""
+    tensors = [t for t in tensors if isinstance(t, torch.Tensor)]
+    if WGRAD_STREAM is None:
+        fn()
+    elif WGRAD_BATCH and not _wgrad_fine:
+        _wgrad_deferred.append((fn, tensors))
+    else:
+        _hand_over([fn], tensors)
+
+
+def wgrad_flush():
+    if _wgrad_deferred:
+        if WGRAD_STREAM is None:
+            for f, _ in _wgrad_deferred:
+                f()
+        else:
+            _hand_over([f for f, _ in _wgrad_deferred], [t for _, ts in _wgrad_deferred for t in ts])
+        _wgrad_deferred.clear()
 
 
 def wgrad_join():
     """The current stream waits for every weight-gradient kernel launched on WGRAD_STREAM so far."""
     global _wgrad_pending
+    wgrad_flush()
     if WGRAD_STREAM is not None and _wgrad_pending:
         ev = torch.cuda.Event()
         ev.record(WGRAD_STREAM)
@@ -300,9 +328,10 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             sums = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu)
             coef = M.bn_backward_coef(r["rows"], *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
             mm = M.pool_dgrad_prepare(W, b, coef) if want_da else None
-            with _OnWgradStream(x, aff, coef, da, argmax, zsel):
+            def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da):
                 G = M.gram(x, aff[:2], r["in_relu"])
                 M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
+            on_wgrad_stream(_pooled_wgrad, x, aff, coef, da, argmax, zsel)
             if not want_da:
                 return None
             below = recs[i - 1]
@@ -325,9 +354,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
                 # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
                 src = dict(gout=da, argmax=argmax, k=k) if pooled else dict(da=da)
-                with _OnWgradStream(r["x"], z, coef, da, argmax if pooled else None):
-                    M.wgrad_dense_bn(r["x"], z, coef, L.relu, L.gp("W"), in_scale=r["in_scale"], in_shift=r["in_shift"],
-                                     in_relu=r["in_relu"], **src)
+                on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, src=src: M.wgrad_dense_bn(
+                    r["x"], z, coef, L.relu, L.gp("W"), in_scale=r["in_scale"], in_shift=r["in_shift"], in_relu=r["in_relu"], **src),
+                    r["x"], z, coef, da, argmax if pooled else None)
                 if not want_da:
                     return None
                 da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
@@ -341,8 +370,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             M.bias_grad(dz, L.gp("b"))
         if i == 0 and r["kind"] == "gather":
             return dict(dz=dz)  # the caller (SAModule.backward) finishes the first layer: it owns idx / pts_cnt / the tables
-        with _OnWgradStream(dz, r.get("x")):
-            M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"])
+        on_wgrad_stream(lambda r=r, dz=dz, L=L: M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"]),
+                        dz, r.get("x"))
         if want_da:
             da, _ = M.linear_dense(dz, L.wT(), want_stats=False)  # da_prev = dz W^T
         else:
@@ -443,8 +472,7 @@ class SAModule:
         if "dz" in h:
             dz = h["dz"]
             if feat is None or PRE_LINEAR:
-                with _OnWgradStream(dz):
-                    M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW)  # rows 0..2 of dW (no feature block in the descriptor)
+                on_wgrad_stream(lambda: M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW), dz)  # rows 0..2 of dW (no feature block)
             if feat is not None and PRE_LINEAR:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
         else:
@@ -454,14 +482,12 @@ class SAModule:
             c = feat.shape[2]
             if PRE_LINEAR:
                 S2, feat2 = S.view(b * n, cout), feat.reshape(b * n, c)
-                with _OnWgradStream(S2, feat2):
-                    M.wgrad_dense(feat2, S2, gW[3:])
+                on_wgrad_stream(lambda: M.wgrad_dense(feat2, S2, gW[3:]), S2, feat2)
                 if need_feat:
                     d2, _ = M.linear_dense(S2, L0.wT(3, None), want_stats=False)
                     d_feat = d2.view(b, n, c)
             else:  # the fused GATHER GEMMs over the grouped rows
-                with _OnWgradStream(dz, feat):
-                    M.wgrad_gather(xyz, new_xyz, feat, idx, dz, gW)
+                on_wgrad_stream(lambda: M.wgrad_gather(xyz, new_xyz, feat, idx, dz, gW), dz, feat)
                 if need_feat:
                     d_rows_feat, _ = M.linear_dense(dz, L0.wT(3, None), want_stats=False)
                     d_feat, _, _ = M.group_concat_grad(d_rows_feat, None, idx, pts_cnt, n, c)
