@@ -262,6 +262,30 @@ def main():
                    "what": "same workload, no geometry prefetch: FPS / ball query / three_nn of a batch inside its own step"}
         pipe_on[0] = True
 
+    # the same step in bit-reproducible mode (votenet_amd.set_deterministic: no fp32 atomics anywhere in the backward pass)
+    det_step = None
+    if workload == "train" and world == 1 and not args.headline_only:
+        import votenet_amd
+        prev = votenet_amd.set_deterministic(True)
+        try:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+        finally:
+            votenet_amd.set_deterministic(prev)
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        det_step = {"value": round(B * 10 / dt3, 2), "ms_per_step": round(dt3 / 10 * 1e3, 3), "steps": 10,
+                    "what": "same workload with votenet_amd.set_deterministic(True): weight gradients through ordered partial sums, "
+                            "scatter-adds as gather-sums over the groupings' inverse index; two identical passes give bit-identical "
+                            "gradients (tests/test_gpu_backward.py)"}
+
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None
     if rank == 0 and not args.headline_only:
@@ -379,7 +403,7 @@ def main():
                                     + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
                                        "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
-            "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "configs": cfgs,
+            "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step, "configs": cfgs,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

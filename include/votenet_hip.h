@@ -365,6 +365,25 @@ int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const flo
                               const float *d_rows_xyz, const int *idx, const int *pts_cnt, float *d_feat, float *d_xyz,
                               float *d_new_xyz, void *stream);
 
+/* ---- deterministic "scatter-add" of the backward pass: gather-sums over the inverse of a grouping (csr.hip) --------------
+ * GroupPointGrad / ThreeInterpolateGrad add every gathered row's gradient back to its source point (tf_grouping_g.cu:61-78,
+ * tf_interpolate.cpp:131-153): fp32 atomics on a GPU, summation order unspecified.  The inverse of the grouping -- for every
+ * point the slots that reference it, ascending (CSR: offsets[npts + 1], order[slots]) -- depends on coordinates only and is
+ * built ahead (stable sort); one thread per (point, channel) then sums in that fixed order.
+ * out[p, :] = sum over t in [offsets[p], offsets[p+1]) of weight[order[t]] * src[order[t] / div, :]   (weight may be NULL;
+ * div = slots per source row: 1 for a grouped tensor (b*m*k rows), 3 for three_interpolate's (b*n, 3) taps). */
+int votenet_csr_gather_sum(long npts, int c, const float *src, const int *order, const int *offsets, const float *weight,
+                           int div, float *out, void *stream);
+/* votenet_group_linear_backward over the inverse index: s_points is written (not accumulated: no zero fill), the xyz rows of
+ * the weight gradient go through per-workgroup partials in scratch (votenet_group_linear_backward_scratch_floats) + an
+ * ordered reduction.  Bit-reproducible. */
+size_t votenet_group_linear_backward_scratch_floats(int b, int n, int cout);
+int votenet_group_linear_backward_csr(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                      const int *order, const int *offsets, const int *visit /* b*n point ids: the order in which
+                                      the points are visited (any fixed permutation; NULL = 0, 1, 2, ...) */, const float *z,
+                                      const float *da, const float *coef, int relu, float *s_points, float *dw_xyz, float *dz_out,
+                                      float *scratch, void *stream);
+
 /* Optimizer of model.py:240-250 over one flat parameter bucket: per-tensor
  * tf.clip_by_average_norm(g, clip) = g*clip/max(||g||_2/numel, clip) (skipped when clip <= 0), then
  * Adam(lr, beta1, beta2, eps) with bias correction for `step` (1-based).  seg: 2*ntensors element

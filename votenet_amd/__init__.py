@@ -12,4 +12,12 @@ There is no CPU fallback: importing an op module without the built library raise
 """
 from ._lib import InvalidArgumentError, VotenetError, build, lib_path  # noqa: F401
 
-__all__ = ["InvalidArgumentError", "VotenetError", "build", "lib_path"]
+
+
+def set_deterministic(on=True):
+    """Bit-reproducible backward pass (no fp32 atomics): see votenet_amd.mlp.DETERMINISTIC."""
+    from . import mlp
+    return mlp.set_deterministic(on)
+
+
+__all__ = ["InvalidArgumentError", "VotenetError", "build", "lib_path", "set_deterministic"]

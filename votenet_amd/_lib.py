@@ -111,6 +111,8 @@ _SIGS.update({
     "votenet_mlp_dgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int]
                             + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
+    "votenet_csr_gather_sum": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_group_linear_backward_csr": [ctypes.c_int] * 5 + [_c_f] * 8 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_clip_adam": [ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                                               ctypes.c_void_p],
 })
@@ -133,6 +135,8 @@ def lib():
         L.votenet_mlp_wgrad_scratch_floats.argtypes = [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.votenet_pool_wgrad_scratch_floats.restype = ctypes.c_size_t
         L.votenet_pool_wgrad_scratch_floats.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
+        L.votenet_group_linear_backward_scratch_floats.restype = ctypes.c_size_t
+        L.votenet_group_linear_backward_scratch_floats.argtypes = [ctypes.c_int] * 3
         L.votenet_spatial_index_floats.restype = ctypes.c_size_t
         L.votenet_spatial_index_floats.argtypes = [ctypes.c_int, ctypes.c_int]
         L.votenet_loss_workspace_floats.restype = ctypes.c_size_t

@@ -1,0 +1,191 @@
+// csr.hip -- deterministic "scatter-add" of the backward pass: gather-sums over an inverse index (gfx950).
+//
+// GroupPointGrad / ThreeInterpolateGrad (tf_grouping_g.cu:61-78, tf_interpolate.cpp:131-153) add every grouped row's
+// gradient to the point it was gathered from; on a GPU that is fp32 atomics -- summation order unspecified, results not
+// reproducible run to run.  The grouping (ball query / three_nn) depends on coordinates only, so its INVERSE is known
+// before the backward pass (built with the geometry, on the geometry stream): for every point the list of the slots that
+// reference it, in ascending slot order (CSR: offsets (points + 1), order (slots); votenet_amd/pointnet2.py builds it with a
+// stable sort).  The gradients of a point are then summed by ONE thread per channel in that fixed order: no atomics, no
+// zero-fill of the target, every source row still read exactly once.
+//   csr_gather_sum_kernel        out[p, :] = sum_t w[order[t]] * src[order[t] / div, :]      (generic: xyz / feature gradients
+//                                of a grouping, three_interpolate's gradient with its weights, div = 3)
+//   group_linear_bwd_gather      votenet_group_linear_backward on the inverse index: dz formed from (z, da, coef) on the fly,
+//                                S[p, :] = sum of the dz rows of point p; the xyz rows of the weight gradient as
+//                                per-workgroup partials + ordered reduction; optional dz output
+#include "mlp_types.h"
+
+namespace votenet {
+
+void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st); // mlp_bwd.hip
+
+// thread = (point lane, channel): TPP = threads per point (>= c, a divisor of 256)
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(long npts, int c, int tpp, const float *__restrict__ src,
+                                                             const int *__restrict__ order, const int *__restrict__ offsets,
+                                                             const float *__restrict__ weight, int div, float *__restrict__ out)
+{
+    const int ppb = 256 / tpp;
+    const int ch = threadIdx.x % tpp, pl = threadIdx.x / tpp;
+    for (long p = (long)blockIdx.x * ppb + pl; p < npts; p += (long)gridDim.x * ppb) {
+        const int t0 = offsets[p], t1 = offsets[p + 1];
+        float acc = 0.0f;
+        int t = t0;
+        for (; t + 4 <= t1; t += 4) { // four source rows in flight, added in list order
+            const int s0 = order[t], s1 = order[t + 1], s2 = order[t + 2], s3 = order[t + 3];
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            if (ch < c) {
+                v0 = src[(size_t)(s0 / div) * c + ch];
+                v1 = src[(size_t)(s1 / div) * c + ch];
+                v2 = src[(size_t)(s2 / div) * c + ch];
+                v3 = src[(size_t)(s3 / div) * c + ch];
+            }
+            if (weight) {
+                v0 *= weight[s0];
+                v1 *= weight[s1];
+                v2 *= weight[s2];
+                v3 *= weight[s3];
+            }
+            acc = (((acc + v0) + v1) + v2) + v3;
+        }
+        for (; t < t1; t++) {
+            const int s = order[t];
+            float v = ch < c ? src[(size_t)(s / div) * c + ch] : 0.0f;
+            if (weight) v *= weight[s];
+            acc += v;
+        }
+        if (ch < c) out[(size_t)p * c + ch] = acc;
+    }
+}
+
+// thread = (point lane, channel QUAD): cout / 4 threads per point, 1024 / cout points per workgroup pass -- four points per
+// wavefront at cout = 64, so that a wavefront has the row loads of four independent points in flight (one point per
+// wavefront was a chain of dependent round trips: offsets -> order -> rows, 0.34 ms at sa1 against 0.20 ms for the atomics)
+__global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(long npts, int n, int groups_per_scene, int nsample, int cout,
+                                                                      const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                                      const int *__restrict__ order, const int *__restrict__ offsets,
+                                                                      const int *__restrict__ visit, const float *__restrict__ z,
+                                                                      const float *__restrict__ da, const float *__restrict__ coef, int relu,
+                                                                      float *__restrict__ spt, float *__restrict__ part,
+                                                                      float *__restrict__ dz_out)
+{
+    __shared__ float red[256][12];
+    const int tid = threadIdx.x;
+    const int tpp = cout >> 2, ppb = 256 / tpp;
+    const int cq = tid % tpp, pl = tid / tpp;
+    const float4 kA = *reinterpret_cast<const float4 *>(coef + 4 * cq), kB = *reinterpret_cast<const float4 *>(coef + cout + 4 * cq);
+    const float4 kC = *reinterpret_cast<const float4 *>(coef + 2 * cout + 4 * cq), kS = *reinterpret_cast<const float4 *>(coef + 3 * cout + 4 * cq);
+    const float4 kH = *reinterpret_cast<const float4 *>(coef + 4 * cout + 4 * cq);
+    float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0;
+    for (long pi = (long)blockIdx.x * ppb + pl; pi < npts; pi += (long)gridDim.x * ppb) {
+        const long p = visit ? visit[pi] : pi; // visiting order of the points (any fixed permutation)
+        const int t0 = offsets[p], t1 = offsets[p + 1];
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (t1 > t0) {
+            const float px = xyz[(size_t)p * 3 + 0], py = xyz[(size_t)p * 3 + 1], pz = xyz[(size_t)p * 3 + 2];
+            auto one = [&](int s, const float4 &zz, float4 g) {
+                if (relu) {
+                    if (!(zz.x * kS.x + kH.x > 0.0f)) g.x = 0.0f;
+                    if (!(zz.y * kS.y + kH.y > 0.0f)) g.y = 0.0f;
+                    if (!(zz.z * kS.z + kH.z > 0.0f)) g.z = 0.0f;
+                    if (!(zz.w * kS.w + kH.w > 0.0f)) g.w = 0.0f;
+                }
+                const float4 d = make_float4(kA.x * g.x + kB.x + kC.x * zz.x, kA.y * g.y + kB.y + kC.y * zz.y,
+                                             kA.z * g.z + kB.z + kC.z * zz.z, kA.w * g.w + kB.w + kC.w * zz.w);
+                if (dz_out) *reinterpret_cast<float4 *>(dz_out + (size_t)s * cout + 4 * cq) = d;
+                const size_t g3 = (size_t)(s / nsample) * 3;
+                const float ex = px - new_xyz[g3 + 0], ey = py - new_xyz[g3 + 1], ez = pz - new_xyz[g3 + 2]; // utils.py:55
+                a0.x += ex * d.x; a0.y += ex * d.y; a0.z += ex * d.z; a0.w += ex * d.w;
+                a1.x += ey * d.x; a1.y += ey * d.y; a1.z += ey * d.z; a1.w += ey * d.w;
+                a2.x += ez * d.x; a2.y += ez * d.y; a2.z += ez * d.z; a2.w += ez * d.w;
+                acc.x += d.x; acc.y += d.y; acc.z += d.z; acc.w += d.w;
+            };
+            int t = t0;
+            for (; t + 4 <= t1; t += 4) { // four rows in flight per point, consumed in list order
+                int sl[4];
+                float4 zz[4], gg[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) sl[u] = order[t + u];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    zz[u] = *reinterpret_cast<const float4 *>(z + (size_t)sl[u] * cout + 4 * cq);
+                    gg[u] = *reinterpret_cast<const float4 *>(da + (size_t)sl[u] * cout + 4 * cq);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) one(sl[u], zz[u], gg[u]);
+            }
+            for (; t < t1; t++) {
+                const int s = order[t];
+                one(s, *reinterpret_cast<const float4 *>(z + (size_t)s * cout + 4 * cq),
+                    *reinterpret_cast<const float4 *>(da + (size_t)s * cout + 4 * cq));
+            }
+        }
+        *reinterpret_cast<float4 *>(spt + (size_t)p * cout + 4 * cq) = acc; // every point is written: no zero fill of S
+    }
+    float *r = red[tid];
+    r[0] = a0.x; r[1] = a0.y; r[2] = a0.z; r[3] = a0.w;
+    r[4] = a1.x; r[5] = a1.y; r[6] = a1.z; r[7] = a1.w;
+    r[8] = a2.x; r[9] = a2.y; r[10] = a2.z; r[11] = a2.w;
+    __syncthreads();
+    if (tid < cout) { // channel tid: quad tid / 4, component tid % 4; point lanes added in ascending order
+        const int q = tid >> 2, e = tid & 3;
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float t = 0.0f;
+            for (int l = 0; l < ppb; l++) t += red[l * tpp + q][d * 4 + e];
+            part[((size_t)blockIdx.x * 3 + d) * cout + tid] = t;
+        }
+    }
+}
+
+} // namespace votenet
+using namespace votenet;
+
+extern "C" int votenet_csr_gather_sum(long npts, int c, const float *src, const int *order, const int *offsets, const float *weight,
+                                      int div, float *out, void *stream)
+{
+    VN_REQUIRE(npts >= 0 && c > 0 && c <= 256 && div > 0, "csr_gather_sum expects npts >= 0, 0 < c <= 256, div > 0");
+    if (npts == 0) return VOTENET_OK;
+    VN_REQUIRE(src && order && offsets && out, "csr_gather_sum: null buffer");
+    int tpp = 1;
+    while (tpp < c) tpp <<= 1;
+    const int ppb = 256 / tpp;
+    long gx = (npts + ppb - 1) / ppb;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(csr_gather_sum_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), npts, c, tpp, src, order, offsets,
+                       weight, div, out);
+    return check_launch("csr_gather_sum");
+}
+
+static long glbg_grid(long npts, int ppb)
+{
+    long gx = (npts + ppb - 1) / ppb;
+    return gx > 2048 ? 2048 : gx;
+}
+
+extern "C" size_t votenet_group_linear_backward_scratch_floats(int b, int n, int cout)
+{
+    if (cout <= 0 || 256 % cout != 0) return 0;
+    return (size_t)glbg_grid((long)b * n, 1024 / cout) * 3 * cout;
+}
+
+// votenet_group_linear_backward over the grouping's inverse index (order: b*m*nsample slots sorted by (scene, point), ascending
+// slot inside a point; offsets: b*n + 1): s_points need NOT be zeroed, dw_xyz += the ordered sum of the workgroups' partials.
+extern "C" int votenet_group_linear_backward_csr(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                                 const int *order, const int *offsets, const int *visit, const float *z,
+                                                 const float *da, const float *coef, int relu, float *s_points, float *dw_xyz,
+                                                 float *dz_out, float *scratch, void *stream)
+{
+    VN_REQUIRE(b >= 0 && n > 0 && m >= 0 && nsample > 0 && cout > 0, "group_linear_backward_csr: bad shape");
+    VN_REQUIRE(cout == 32 || cout == 64 || cout == 128 || cout == 256, "group_linear_backward_csr expects cout in {32, 64, 128, 256}");
+    const long npts = (long)b * n;
+    if (npts == 0) return VOTENET_OK;
+    VN_REQUIRE((long)b * m * nsample < (1L << 31), "group_linear_backward_csr: b*m*nsample must be below 2^31");
+    VN_REQUIRE(xyz && new_xyz && order && offsets && z && da && coef && s_points && dw_xyz && scratch, "group_linear_backward_csr: null buffer");
+    hipStream_t st = as_stream(stream);
+    VN_REQUIRE((uintptr_t)z % 16 == 0 && (uintptr_t)da % 16 == 0 && (uintptr_t)coef % 16 == 0 && (uintptr_t)s_points % 16 == 0 &&
+                   (uintptr_t)dz_out % 16 == 0, "group_linear_backward_csr: z, da, coef, s_points, dz_out must be 16-byte aligned");
+    const long gx = glbg_grid(npts, 1024 / cout);
+    hipLaunchKernelGGL(group_linear_bwd_gather_kernel, dim3((unsigned)gx), dim3(256), 0, st, npts, n, m, nsample, cout, xyz, new_xyz,
+                       order, offsets, visit, z, da, coef, relu, s_points, scratch, dz_out);
+    wgrad_reduce((int)gx, (long)3 * cout, 0, (long)3 * cout, scratch, dw_xyz, st);
+    return check_launch("group_linear_backward_csr");
+}

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
 {
     __shared__ float s_box[LOSS_MAXBOX][8];
     __shared__ float s_red[LOSS_T / 64][LOSS_NACC];
+    __shared__ float s_dual[LOSS_MAXBOX][3];
+    __shared__ int s_dualp[LOSS_MAXBOX];
     __shared__ int s_last;
     const int tid = threadIdx.x, b = blockIdx.x;
     const int B = A.b, N = A.n, P = A.p, BB = A.bb, NH = A.nh, NS = A.ns, NC = A.nc;
@@ -143,8 +145,8 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
             for (int k = 0; k < 3; k++) {
                 float gr;
                 acc[3] += huber(o[2 + k] - cg[k], gr);
-                unsafeAtomicAdd(&go[2 + k], gr * inv_np);                  // the dual term may add to the same entries
-                unsafeAtomicAdd(&A.d_pxyz[q * 3 + k], gr * inv_np);        // d(error)/d(proposal centre) = +1
+                go[2 + k] += gr * inv_np;                  // this thread owns the proposal here; the dual term adds below, behind a barrier
+                A.d_pxyz[q * 3 + k] += gr * inv_np;        // d(error)/d(proposal centre) = +1
             }
             // heading class (0.1) and residual (1)
             const int hl = A.hlab[gi];
@@ -199,9 +201,23 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
             const float cgk = (k == 0 ? gx : (k == 1 ? gy : gz)) - A.pxyz[q * 3 + k];
             float gr;
             acc[4] += huber(A.pout[(size_t)q * W + 2 + k] - cgk, gr);
-            unsafeAtomicAdd(&A.d_pout[(size_t)q * W + 2 + k], gr * inv_bbb);
-            unsafeAtomicAdd(&A.d_pxyz[q * 3 + k], gr * inv_bbb);
+            s_dual[j][k] = gr * inv_bbb; // added to the proposal's cotangents below, box by box in ascending order
+            if (k == 0) s_dualp[j] = bp;
         }
+    }
+    __syncthreads(); // the proposals' own terms (above) and every box's pull are in place
+    // several boxes may pull the same proposal: one thread per proposal adds them in box order (no atomics: one summation
+    // order, bit-reproducible cotangents)
+    for (int pq = tid; pq < P; pq += LOSS_T) {
+        const int q = b * P + pq;
+        for (int j = 0; j < BB; j++)
+            if (s_dualp[j] == pq) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    A.d_pout[(size_t)q * W + 2 + k] += s_dual[j][k];
+                    A.d_pxyz[q * 3 + k] += s_dual[j][k];
+                }
+            }
     }
     // ---- seeds: vote targets and vote regression loss (model.py:61-84)
     const float inv_bn = 1.0f / (float)(B * N);

@@ -764,38 +764,49 @@ __global__ __launch_bounds__(256) void wgrad_narrow_kernel(MlpIn in, long rows, 
     }
 }
 
-// dw[e] += part[0][e] + part[1][e] + ... in ascending slice order, e in [e0, e1): the ordered reduction behind BnSrc::part
+// dw[e] += part[0][e] + part[1][e] + ... in ONE fixed order, e in [e0, e1): the ordered reduction behind BnSrc::part.
+// Workgroup = 64 elements x 4 slice quarters: thread (element, quarter q) adds its quarter of the slices in ascending order,
+// eight loads in flight; the four quarter sums meet in LDS and are added in quarter order.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(int nslice, long pstride, long e0, long e1, const float *__restrict__ part,
                                                            float *__restrict__ dw)
 {
-    const long e = e0 + (long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= e1) return;
+    __shared__ float s_q[4][64];
+    const int el = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long e = e0 + (long)blockIdx.x * 64 + el;
+    const int per = (nslice + 3) / 4;
+    const int t0 = q * per, t1 = (t0 + per) < nslice ? (t0 + per) : nslice;
     float s = 0.0f;
-    int t = 0;
-    for (; t + 4 <= nslice; t += 4) { // four loads in flight, added in order
-        const float a = part[(size_t)t * pstride + e], b = part[(size_t)(t + 1) * pstride + e];
-        const float c = part[(size_t)(t + 2) * pstride + e], d = part[(size_t)(t + 3) * pstride + e];
-        s = (((s + a) + b) + c) + d;
+    if (e < e1) {
+        int t = t0;
+        for (; t + 8 <= t1; t += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = part[(size_t)(t + u) * pstride + e];
+#pragma unroll
+            for (int u = 0; u < 8; u++) s += v[u];
+        }
+        for (; t < t1; t++) s += part[(size_t)t * pstride + e];
     }
-    for (; t < nslice; t++) s += part[(size_t)t * pstride + e];
-    dw[e] += s;
+    s_q[q][el] = s;
+    __syncthreads();
+    if (q == 0 && e < e1) dw[e] += ((s_q[0][el] + s_q[1][el]) + s_q[2][el]) + s_q[3][el];
 }
 namespace votenet {
 void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st)
 {
-    if (e1 > e0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((e1 - e0 + 255) / 256)), dim3(256), 0, st, nslice, pstride, e0, e1, part, dw);
+    if (e1 > e0) hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((e1 - e0 + 63) / 64)), dim3(256), 0, st, nslice, pstride, e0, e1, part, dw);
 }
 }
 
 // row ranges of the generic kernel: grid.x slices of rpb rows
-static void plan_wgrad(long rows, int cin, int cout, int &TIr, int &TJr, int &ti, int &tj, long &rpb, unsigned &gx)
+static void plan_wgrad(long rows, int cin, int cout, int &TIr, int &TJr, int &ti, int &tj, long &rpb, unsigned &gx, bool partials = false)
 {
     TIr = cin <= 64 ? 1 : 2;
     TJr = cout <= 64 ? 1 : 2;
     const int BI = 64 * TIr, BJ = 64 * TJr;
     ti = (cin + BI - 1) / BI;
     tj = (cout + BJ - 1) / BJ;
-    long splits = 768 / (ti * tj);
+    long splits = (partials ? 256 : 768) / (ti * tj); // partial tiles: every slice is written and read once more
     if (splits < 1) splits = 1;
     rpb = (rows + splits - 1) / splits;
     rpb = (rpb + WG_BR - 1) / WG_BR * WG_BR;
@@ -811,7 +822,7 @@ static void launch_wgrad(const MlpIn &d, long rows, int cin, int cout, const flo
     int TIr, TJr, ti, tj;
     long rpb;
     unsigned gx;
-    plan_wgrad(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx);
+    plan_wgrad(rows, cin, cout, TIr, TJr, ti, tj, rpb, gx, scratch != nullptr);
     bs.part = scratch;
     bs.pstride = (long)wrows * cout;
     const dim3 grid(gx, ti, tj);

@@ -63,8 +63,20 @@ def _zeros_f64(n, device):
     return torch.zeros(n, dtype=torch.float64, device=device)
 
 
-# Weight gradients through per-workgroup partial tiles + an ordered reduction (bit-reproducible) instead of fp32 atomics
-DETERMINISTIC = True
+# Bit-reproducible training (set_deterministic): weight gradients through per-workgroup partial tiles + an ordered reduction,
+# the scatter-adds of the backward pass (GroupPointGrad, ThreeInterpolateGrad) as gather-sums over the groupings' inverse index
+# (csr.hip) -- no fp32 atomics on any path; two identical passes give bit-identical gradients
+# (tests/test_gpu_backward.py::test_training_gradients_are_bit_reproducible).  Off by default: it costs 17 % of the train step
+# (7.83 -> 9.14 ms, same box; the gather-sums read the gradient rows in point order, 1.8 TB/s against 2.7 TB/s for the
+# streaming pass with atomics), and the reference itself sums with atomics (tf_grouping_g.cu:74, tf_sampling_g.cu:187-189).
+DETERMINISTIC = False
+
+
+def set_deterministic(on=True):
+    """Switch the bit-reproducible backward pass on / off; returns the previous setting."""
+    global DETERMINISTIC
+    prev, DETERMINISTIC = DETERMINISTIC, bool(on)
+    return prev
 
 
 def _wgrad_scratch(desc, rows, cin, cout, device):
@@ -72,6 +84,46 @@ def _wgrad_scratch(desc, rows, cin, cout, device):
         return None
     nf = L.lib().votenet_mlp_wgrad_scratch_floats(ctypes.byref(desc) if desc is not None else None, rows, cin, cout)
     return torch.empty(nf, dtype=torch.float32, device=device) if nf else None
+
+
+def inverse_index(idx, n):
+    """The inverse of a grouping: idx (b, m, k) int32 indices into n points per scene -> (order (b*m*k) int32, offsets (b*n + 1)
+    int32): the slots (flat positions of idx) that reference point p are order[offsets[p]:offsets[p+1]], ascending (stable
+    sort: one fixed summation order for the gather-sums of csr.hip).  Coordinates only: SAModule / FPModule.geometry build it
+    with the grouping, on the geometry stream; it travels as idx._inv."""
+    b = idx.shape[0]
+    slots = idx.numel()
+    flat = (idx.reshape(b, -1).to(torch.int64) + (torch.arange(b, device=idx.device, dtype=torch.int64) * n)[:, None]).reshape(-1)
+    # unique 64-bit keys (point, slot): any sort gives the one order; no host synchronisation anywhere (bincount would need max())
+    keys, _ = torch.sort(flat * slots + torch.arange(slots, device=idx.device, dtype=torch.int64))
+    pts = torch.div(keys, slots, rounding_mode="floor")
+    order = (keys - pts * slots).to(torch.int32)
+    offsets = torch.searchsorted(pts, torch.arange(b * n + 1, device=idx.device, dtype=torch.int64)).to(torch.int32)
+    return order, offsets
+
+
+def attach_inverse(idx, n):
+    if DETERMINISTIC and getattr(idx, "_inv", None) is None:
+        idx._inv = inverse_index(idx, n)
+    return idx
+
+
+def _inverse_of(idx, n):
+    inv = getattr(idx, "_inv", None)
+    if inv is None or inv[1].numel() != idx.shape[0] * n + 1:
+        inv = inverse_index(idx, n)
+        idx._inv = inv
+    return inv
+
+
+def csr_gather_sum(src2d, inv, npts, weight=None, div=1):
+    """out (npts, c) = for every point the sum, in slot order, of weight[slot] * src2d[slot // div] (votenet_csr_gather_sum)."""
+    c = src2d.shape[1]
+    out = torch.empty((npts, c), dtype=torch.float32, device=src2d.device)
+    with torch.cuda.device(src2d.device):
+        L.check(L.lib().votenet_csr_gather_sum(npts, c, L.ptr(src2d), L.ptr(inv[0]), L.ptr(inv[1]), L.ptr(weight), div, L.ptr(out),
+                                               L.stream_ptr()))
+    return out
 
 
 BN_EPS = 1e-5  # TensorFlow / Tensorpack BatchNorm default epsilon (not in the reference tree; see oracle/oracle_mlp.c)
@@ -330,8 +382,17 @@ def group_linear_backward(xyz, new_xyz, idx, pts_cnt, z, da, coef, relu, dw_xyz,
     accumulates the xyz rows of the weight gradient into dw_xyz (3, cout) (a view of the gradient bucket)."""
     b, m, k = idx.shape
     n, cout = xyz.shape[1], z.shape[1]
-    S = torch.zeros((b, n, cout), dtype=torch.float32, device=z.device)
     dz = torch.empty_like(z) if want_dz else None
+    if DETERMINISTIC:  # gather-sum over the grouping's inverse index: no atomics, S written once (no zero fill)
+        inv = _inverse_of(idx, n)
+        S = torch.empty((b, n, cout), dtype=torch.float32, device=z.device)
+        scr = torch.empty(L.lib().votenet_group_linear_backward_scratch_floats(b, n, cout), dtype=torch.float32, device=z.device)
+        with torch.cuda.device(z.device):
+            L.check(L.lib().votenet_group_linear_backward_csr(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(inv[0]), L.ptr(inv[1]),
+                                                              L.ptr(inv[2]) if len(inv) > 2 else None, L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
+                                                              L.ptr(dz), L.ptr(scr), L.stream_ptr()))
+        return S, dz
+    S = torch.zeros((b, n, cout), dtype=torch.float32, device=z.device)
     with torch.cuda.device(z.device):
         L.check(L.lib().votenet_group_linear_backward(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                       L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
@@ -476,6 +537,14 @@ def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
     d_new_xyz (b,m,3) or None (GroupPointGrad + the gradient of the centre subtraction, utils.py:50-57)."""
     b, m, k = idx.shape
     dev = idx.device
+    if DETERMINISTIC and (d_rows_feat is None or d_rows_feat.shape[1] <= 256):
+        inv = _inverse_of(idx, n)
+        d_feat = csr_gather_sum(d_rows_feat, inv, b * n).view(b, n, c) if d_rows_feat is not None else None
+        d_xyz = d_new = None
+        if d_rows_xyz is not None:
+            d_xyz = csr_gather_sum(d_rows_xyz, inv, b * n).view(b, n, 3)
+            d_new = -d_rows_xyz.view(b, m, k, 3).sum(2)  # gradient of the centre subtraction (utils.py:55)
+        return d_feat, d_xyz, d_new
     d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if d_rows_feat is not None else None
     d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
     d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None

@@ -70,6 +70,8 @@ class VoteNetHotPath:
             for t in (v if isinstance(v, tuple) else (v,)):
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
+                    for u in getattr(t, "_inv", None) or ():  # the grouping's inverse index rides on idx (mlp.attach_inverse)
+                        u.record_stream(main)
 
     def geometry_ahead(self, x):
         """Every FPS / ball query / three_nn of the backbone depends on coordinates only, never on features.

@@ -384,8 +384,9 @@ def _group_indices(radius, nsample, xyz, new_xyz, knn):
     """utils.py:46-49: ball query, or the nsample nearest points with knn=True (every slot then holds a distinct point)."""
     if knn:
         _, idx = tf_grouping.knn_point(nsample, xyz, new_xyz)
-        return idx, torch.full(idx.shape[:2], nsample, dtype=torch.int32, device=idx.device)
-    return tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+        return M.attach_inverse(idx, xyz.shape[1]), torch.full(idx.shape[:2], nsample, dtype=torch.int32, device=idx.device)
+    idx, cnt = tf_grouping.query_ball_point(radius, nsample, xyz, new_xyz)
+    return M.attach_inverse(idx, xyz.shape[1]), cnt  # the grouping's inverse (idx._inv) for the deterministic backward pass
 
 
 def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None, knn=False):
@@ -556,7 +557,7 @@ class FPModule:
     def geometry(xyz1, xyz2):
         """three_nn + inverse-distance weights (utils.py:278-282): feature independent."""
         dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
-        return idx, tf_interpolate.three_nn_weights(dist)
+        return M.attach_inverse(idx, xyz2.shape[1]), tf_interpolate.three_nn_weights(dist)
 
     def forward(self, xyz1, xyz2, points1, points2, tape=None, geom=None):
         b, n1 = xyz1.shape[:2]

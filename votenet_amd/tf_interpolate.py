@@ -62,6 +62,9 @@ def three_interpolate_grad_raw(m, idx, weight, grad_out):
     """ThreeInterpolateGrad (tf_interpolate.cpp:226-262): zero-filled (b,m,c) buffer + scatter-add."""
     grad_out = L.dev_f32(grad_out, "ThreeInterpolateGrad expects (b,n,c) grad_out shape", 3)
     b, n, c = grad_out.shape
+    from . import mlp as M
+    if M.DETERMINISTIC and c <= 256 and getattr(idx, "_inv", None) is not None:  # gather-sum over the taps' inverse index (csr.hip)
+        return M.csr_gather_sum(grad_out.view(b * n, c), idx._inv, b * m, weight=weight.contiguous(), div=3).view(b, m, c)
     g = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)  # tf_interpolate.cpp:258
     with torch.cuda.device(grad_out.device):
         L.check(L.lib().votenet_three_interpolate_grad(b, n, c, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g),
