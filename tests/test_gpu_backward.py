@@ -97,7 +97,7 @@ def test_full_backward_vs_autograd(hiplib, dev):
     votes = (xx + ref_chain(xx, net.voting, params, vote["recs"])).view(2, -1, 259)
     vx, vp = votes[..., :3], votes[..., 3:]
     _, pout = ref_sa(net.proposal, params, vx, vp, prop)
-    assert relerr(out["proposals_output"].double(), pout.detach()) < 2e-4
+    assert relerr(out["proposals_output"].double(), pout.detach()) < 5e-5  # fp32 path against float64, 26 layers deep (measured 2.1e-5)
     loss = (pout * cot["proposals_output"].double()).sum() + (vx * cot["votes_xyz"].double()).sum()
     loss.backward()
     worst = {}
@@ -110,10 +110,12 @@ def test_full_backward_vs_autograd(hiplib, dev):
             continue
         scale = max(float(ref.abs().max()), 1e-8)
         worst[name] = float((got - ref).abs().max()) / scale
-    bad = {k: round(v, 5) for k, v in worst.items() if v > 2e-3}
+    # the reference's own bar for its op gradients is compute_gradient_error < 1e-4 (tf_grouping_op_test.py:23-25,
+    # tf_interpolate_op_test.py:19-21); measured here over the WHOLE backward pass: worst tensor 1.8e-5 of its largest entry
+    bad = {k: round(v, 6) for k, v in worst.items() if v > 1e-4}
     print("WORST", sorted(((round(v, 6), k) for k, v in worst.items()), reverse=True)[:30])
     assert not bad, bad
-    assert np.median(list(worst.values())) < 2e-4
+    assert np.median(list(worst.values())) < 2e-5
 
 
 def test_wgrad_and_input_grad_unit(hiplib, dev):
