@@ -350,9 +350,14 @@ int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const floa
                          int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
                          float *da_prev, void *stream);
 
-/* dst[dst_off + c*rows + r] = src[src_off + r*cols + c] for every entry table[e] = {src_off, dst_off, rows, cols}
- * (device array of 4*nseg longs, element offsets): all W^T blocks the input-gradient GEMMs need, in one launch. */
+/* One launch for every re-laid-out copy of a weight block the GEMMs want (element offsets, device array of 6*nseg longs):
+ * table[e] = {src_off, dst_off, rows, cols, ld, transpose}.  transpose != 0: dst[dst_off + c*ld + r] = src[src_off + r*cols + c]
+ * (W^T for the input-gradient GEMMs; ld >= rows);  transpose == 0: dst[dst_off + r*ld + c] = src[...] (a copy with a padded
+ * leading dimension ld >= cols: 16-byte aligned rows for the 259- and 79-wide layers).  Padding elements are not written. */
 int votenet_transpose_segments(int nseg, const long *table, const float *src, float *dst, void *stream);
+
+/* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
+int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);
 
 /* Gradient of the sample_and_group concat (utils.py:50-57) = GroupPointGrad (tf_grouping_g.cu:61-78) on the
  * feature columns + the gradients of grouped_xyz - tile(new_xyz) on the xyz columns.  The per-row input

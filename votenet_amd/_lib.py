@@ -113,6 +113,7 @@ _SIGS.update({
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
     "votenet_csr_gather_sum": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_group_linear_backward_csr": [ctypes.c_int] * 5 + [_c_f] * 8 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_rows_dot3": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_clip_adam": [ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_float,
                                                                               ctypes.c_void_p],
 })

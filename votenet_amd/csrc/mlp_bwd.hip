@@ -991,12 +991,22 @@ __global__ __launch_bounds__(256) void transpose_segments_kernel(const long *__r
                                                                 float *__restrict__ dst)
 {
     __shared__ float tile[32][33];
-    const long so = table[4 * blockIdx.x + 0], dof = table[4 * blockIdx.x + 1];
-    const int rows = (int)table[4 * blockIdx.x + 2], cols = (int)table[4 * blockIdx.x + 3];
+    const long so = table[6 * blockIdx.x + 0], dof = table[6 * blockIdx.x + 1];
+    const int rows = (int)table[6 * blockIdx.x + 2], cols = (int)table[6 * blockIdx.x + 3];
+    const int ld = (int)table[6 * blockIdx.x + 4];
+    const bool tr = table[6 * blockIdx.x + 5] != 0;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
-    const int tr = (rows + 31) / 32, tc = (cols + 31) / 32;
-    for (int t = 0; t < tr * tc; t++) {
+    const int tr_ = (rows + 31) / 32, tc = (cols + 31) / 32;
+    for (int t = 0; t < tr_ * tc; t++) {
         const int r0 = (t / tc) * 32, c0 = (t % tc) * 32;
+        if (!tr) { // plain copy into a buffer with leading dimension ld >= cols (the padding stays as it was: zero)
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int r = r0 + ty + 8 * k, c = c0 + tx;
+                if (r < rows && c < cols) dst[dof + (long)r * ld + c] = src[so + (long)r * cols + c];
+            }
+            continue;
+        }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int r = r0 + ty + 8 * k, c = c0 + tx;
@@ -1005,10 +1015,40 @@ __global__ __launch_bounds__(256) void transpose_segments_kernel(const long *__r
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const int c = c0 + ty + 8 * k, r = r0 + tx; // dst[c][r]
-            if (c < cols && r < rows) dst[dof + (long)c * rows + r] = tile[tx][ty + 8 * k];
+            const int c = c0 + ty + 8 * k, r = r0 + tx; // dst[c][r], leading dimension ld >= rows
+            if (c < cols && r < rows) dst[dof + (long)c * ld + r] = tile[tx][ty + 8 * k];
         }
         __syncthreads();
+    }
+}
+
+// out[r, d] = sum_k dz[r, k] * w3[d, k], d < 3: the xyz columns of an input gradient (dz W[0:3]^T) -- a 128-wide MFMA tile would be
+// 97 % padding.  32 lanes per row (float4 each, c <= 128 per pass), two rows per wavefront, shuffle reduction.
+__global__ __launch_bounds__(256) void rows_dot3_kernel(long rows, int c, const float *__restrict__ dz, const float *__restrict__ w3,
+                                                        float *__restrict__ out)
+{
+    const int l = threadIdx.x & 31;
+    for (long r = (long)blockIdx.x * 8 + (threadIdx.x >> 5); r < rows; r += (long)gridDim.x * 8) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        for (int k = l * 4; k < c; k += 128) {
+            const float4 v = *reinterpret_cast<const float4 *>(dz + (size_t)r * c + k);
+            const float4 x = *reinterpret_cast<const float4 *>(w3 + k), y = *reinterpret_cast<const float4 *>(w3 + c + k);
+            const float4 z = *reinterpret_cast<const float4 *>(w3 + 2 * c + k);
+            a0 += v.x * x.x + v.y * x.y + v.z * x.z + v.w * x.w;
+            a1 += v.x * y.x + v.y * y.y + v.z * y.z + v.w * y.w;
+            a2 += v.x * z.x + v.y * z.y + v.z * z.z + v.w * z.w;
+        }
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+            a0 += __shfl_xor(a0, o);
+            a1 += __shfl_xor(a1, o);
+            a2 += __shfl_xor(a2, o);
+        }
+        if (l == 0) {
+            out[(size_t)r * 3 + 0] = a0;
+            out[(size_t)r * 3 + 1] = a1;
+            out[(size_t)r * 3 + 2] = a2;
+        }
     }
 }
 } // namespace votenet
@@ -1020,4 +1060,16 @@ extern "C" int votenet_transpose_segments(int nseg, const long *table, const flo
     VN_REQUIRE(table && src && dst, "transpose_segments: null buffer");
     hipLaunchKernelGGL(votenet::transpose_segments_kernel, dim3(nseg), dim3(256), 0, as_stream(stream), table, src, dst);
     return check_launch("transpose_segments");
+}
+
+extern "C" int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream)
+{
+    VN_REQUIRE(rows >= 0 && c > 0 && c % 4 == 0, "rows_dot3 expects rows >= 0, c a multiple of 4");
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(dz && w3 && out, "rows_dot3: null buffer");
+    VN_REQUIRE((uintptr_t)dz % 16 == 0 && (uintptr_t)w3 % 16 == 0, "rows_dot3: dz and w3 must be 16-byte aligned");
+    long gx = (rows + 7) / 8;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(votenet::rows_dot3_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), rows, c, dz, w3, out);
+    return check_launch("rows_dot3");
 }

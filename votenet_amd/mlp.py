@@ -532,6 +532,15 @@ def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
+def rows_dot3(dz, w3):
+    """(rows, c) x (3, c)^T -> (rows, 3): the xyz columns of an input gradient, dz W[0:3]^T (votenet_rows_dot3)."""
+    rows, c = dz.shape
+    out = torch.empty((rows, 3), dtype=torch.float32, device=dz.device)
+    with torch.cuda.device(dz.device):
+        L.check(L.lib().votenet_rows_dot3(rows, c, L.ptr(dz), L.ptr(w3), L.ptr(out), L.stream_ptr()))
+    return out
+
+
 def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
     """Per-row input gradients of the first SA layer -> d_feat (b,n,c) or None, d_xyz (b,n,3) or None,
     d_new_xyz (b,m,3) or None (GroupPointGrad + the gradient of the centre subtraction, utils.py:50-57)."""

@@ -24,6 +24,9 @@ from . import mlp as M
 from . import tf_grouping, tf_interpolate, tf_sampling
 
 
+PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
+
+
 # --------------------------------------------------------------------------- parameters
 class ParamStore:
     """All trainable tensors as views into one flat fp32 buffer (and one flat gradient buffer)."""
@@ -43,34 +46,60 @@ class ParamStore:
     def want_transpose(self, name, lo=0, hi=None):
         """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
         refresh_transposes() fills with a single launch per step."""
-        self._tspecs.append((name, lo, hi))
+        self._tspecs.append((name, lo, hi, "T", 0))
+
+    def want_padded(self, name, pad_to):
+        """Register copies of the tensor `name` whose ragged width is padded to `pad_to` columns (16-byte aligned rows for the
+        fast GEMMs): padded(name) = [W | 0] (rows x pad_to) and padded(name, True) = [W | 0]^T (pad_to x rows), refreshed by
+        the same launch as the transposes.  A 1-D tensor (bias) is a 1 x n matrix."""
+        self._tspecs.append((name, 0, None, "P", pad_to))
+        self._tspecs.append((name, 0, None, "PT", pad_to))  # skipped for 1-D tensors when the table is built
 
     def refresh_transposes(self, stream=None):
-        """One launch for every registered W^T block, on `stream` (default: the current one); transposed() makes the
-        current stream wait for it.  Call again whenever the parameters changed (once per training step)."""
+        """One launch for every registered W^T block / padded copy, on `stream` (default: the current one); transposed() /
+        padded() make the current stream wait for it.  Call again whenever the parameters changed (once per training step)."""
         if not self._tspecs:
             return
         if self._tflat is None:
             base = self.flat.data_ptr()
-            table, total = [], 0
-            for name, lo, hi in self._tspecs:
+            table, total, shapes = [], 0, {}
+            for name, lo, hi, kind, pad in self._tspecs:
                 v = self.views[name]
-                hi_ = v.shape[0] if hi is None else hi
-                rows, cols = hi_ - lo, v.shape[1]
-                table += [(v.data_ptr() - base) // 4 + lo * cols, total, rows, cols]
-                self._tviews[(name, lo, hi)] = (total, cols, rows)
-                total += (rows * cols + 3) // 4 * 4
-            self._tflat = torch.empty(total, dtype=torch.float32, device=self.device)
+                v2 = v if v.dim() == 2 else v.view(1, -1)
+                if kind == "PT" and v.dim() != 2:
+                    continue
+                hi_ = v2.shape[0] if hi is None else hi
+                rows, cols = hi_ - lo, v2.shape[1]
+                src = (v.data_ptr() - base) // 4 + lo * cols
+                if kind == "T":      # (cols x rows), leading dimension rows
+                    table += [src, total, rows, cols, rows, 1]
+                    shp = (cols, rows)
+                elif kind == "P":    # (rows x pad), zero padding
+                    table += [src, total, rows, cols, pad, 0]
+                    shp = (rows, pad) if v.dim() == 2 else (pad,)
+                else:                # "PT": (pad x rows): rows >= cols of the transpose stay zero
+                    table += [src, total, rows, cols, rows, 1]
+                    shp = (pad, rows)
+                shapes[(name, lo, hi, kind)] = (total, shp)
+                n_el = 1
+                for d in shp:
+                    n_el *= d
+                total += (n_el + 3) // 4 * 4
+            self._tflat = torch.zeros(total, dtype=torch.float32, device=self.device)  # the padding is never written: stays 0
             self._ttable = torch.tensor(table, dtype=torch.int64, device=self.device)
-            for key, (off, r, c) in list(self._tviews.items()):
-                self._tviews[key] = self._tflat[off:off + r * c].view(r, c)
+            self._nseg = len(table) // 6
+            for key, (off, shp) in shapes.items():
+                n_el = 1
+                for d in shp:
+                    n_el *= d
+                self._tviews[key] = self._tflat[off:off + n_el].view(shp)
         from . import _lib as L_
         cur = torch.cuda.current_stream()
         st = stream if stream is not None else cur
         if st is not cur:
             st.wait_stream(cur)  # the optimizer's update of the parameters is on the caller's stream
         with torch.cuda.device(self.device), torch.cuda.stream(st):
-            L_.check(L_.lib().votenet_transpose_segments(len(self._tspecs), L_.ptr(self._ttable), L_.ptr(self.flat),
+            L_.check(L_.lib().votenet_transpose_segments(self._nseg, L_.ptr(self._ttable), L_.ptr(self.flat),
                                                          L_.ptr(self._tflat), L_.stream_ptr()))
             self.t_event = torch.cuda.Event()
             self.t_event.record(st)
@@ -79,15 +108,30 @@ class ParamStore:
     def invalidate_transposes(self):
         self.t_event = None
 
-    def transposed(self, name, lo=0, hi=None):
-        """W[lo:hi]^T, contiguous: from the per-step bucket when registered and fresh, else an ad-hoc copy."""
-        v = self._tviews.get((name, lo, hi)) if self.t_event is not None else None
-        if v is None or not isinstance(v, torch.Tensor):
-            return self.views[name][lo:hi].t().contiguous()
+    def _fresh(self, key):
+        if self.t_event is None and self._tspecs and self.flat is not None and self.flat.is_cuda:
+            self.refresh_transposes()  # first use since the parameters last changed (inference: once)
+        v = self._tviews.get(key) if self.t_event is not None else None
+        if v is None:
+            return None
         if not self._t_waited:
             torch.cuda.current_stream().wait_event(self.t_event)
             self._t_waited = True
         return v
+
+    def transposed(self, name, lo=0, hi=None):
+        """W[lo:hi]^T, contiguous: from the per-step bucket when registered and fresh, else an ad-hoc copy."""
+        v = self._fresh((name, lo, hi, "T"))
+        return v if v is not None else self.views[name][lo:hi].t().contiguous()
+
+    def padded(self, name, pad_to, transpose=False):
+        """[W | 0] (rows x pad_to), or its transpose: from the per-step bucket when registered and fresh, else an ad-hoc copy."""
+        v = self._fresh((name, 0, None, "PT" if transpose else "P"))
+        if v is not None:
+            return v
+        w = self.views[name]
+        p = torch.nn.functional.pad(w, (0, pad_to - w.shape[-1]))
+        return p.t().contiguous() if transpose else p
 
     def declare(self, name, shape, init):
         self._specs.append((name, tuple(shape), init))
@@ -140,6 +184,13 @@ class Layer:
         if bn:
             store.declare(name + "/gamma", (cout,), "ones")
             store.declare(name + "/beta", (cout,), "zeros")
+        # a plain (no BatchNorm) layer with a ragged width -- voting's 259, mlp2's 79 -- runs on copies padded to a multiple of 64
+        # columns: the fast GEMMs want 16-byte aligned rows (the generic kernel they replace ran at 19 TFLOP/s)
+        self.cout_pad = 0
+        if PAD_RAGGED and not bn and cout % 64 != 0 and cin % 32 == 0:
+            self.cout_pad = (cout + 63) // 64 * 64
+            store.want_padded(name + "/W", self.cout_pad)
+            store.want_padded(name + "/b", self.cout_pad)
 
     def p(self, k):
         return self.store[self.name + "/" + k]
@@ -215,6 +266,12 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, gram_form=gram_form,
                        in_affine=pend.out if pend is not None else None, cout=w.shape[1])
+        elif L.cout_pad and i > 0:
+            # ragged plain layer on zero-padded copies of W and b: the fast GEMM, output (rows, cout_pad), the layer's z = [:, :cout]
+            zp, st = M.linear_dense(z, L.store.padded(L.name + "/W", L.cout_pad), L.store.padded(L.name + "/b", L.cout_pad), None, None,
+                                    prev_relu, want_stats=False, in_bn=pend)
+            zn = zp[:, :L.cout]
+            rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, padded=True)
         else:
             zn, st = M.linear_dense(z, w, b, None, None, prev_relu, want_stats=L.bn, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
@@ -367,7 +424,21 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             dz = M.bn_backward_apply(z, coef, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
         else:
             dz = da
-            M.bias_grad(dz, L.gp("b"))
+            M.bias_grad(dz.contiguous(), L.gp("b"))
+            if r.get("padded"):
+                # the same layer on the padded copies: dz -> [dz | 0] (rows, cout_pad); dW through a padded scratch, da = dz_p [W | 0]^T
+                dzp = torch.nn.functional.pad(dz, (0, L.cout_pad - L.cout))
+
+                def _padded_wgrad(r=r, dzp=dzp, L=L):
+                    G = torch.zeros((L.cin, L.cout_pad), dtype=torch.float32, device=dzp.device)
+                    M.wgrad_dense(r["x"], dzp, G, r["in_scale"], r["in_shift"], r["in_relu"])
+                    L.gp("W").add_(G[:, :L.cout])
+                on_wgrad_stream(_padded_wgrad, dzp, r.get("x"))
+                if want_da:
+                    da, _ = M.linear_dense(dzp, L.store.padded(L.name + "/W", L.cout_pad, transpose=True), want_stats=False)
+                else:
+                    da = None
+                continue
         if i == 0 and r["kind"] == "gather":
             return dict(dz=dz)  # the caller (SAModule.backward) finishes the first layer: it owns idx / pts_cnt / the tables
         on_wgrad_stream(lambda r=r, dz=dz, L=L: M.wgrad_dense(r["x"], dz, L.gp("W"), r["in_scale"], r["in_shift"], r["in_relu"]),
@@ -440,7 +511,7 @@ class SAModule:
         if tape is not None:
             tape.append(dict(op="sa", module=self, recs=recs, recs2=recs2, argmax=argmax, zsel=zsel, fps_idx=fps_idx, idx=idx, pts_cnt=pts_cnt,
                              xyz=xyz, points=points, new_xyz=new_xyz, b=b))
-        return new_xyz, out.view(b, self.npoint, -1), idx
+        return new_xyz, out.reshape(b, self.npoint, -1), idx
 
 
     def backward(self, rec, g_out, need_feat_grad=True, need_xyz_grad=False):
@@ -493,7 +564,7 @@ class SAModule:
                     d_rows_feat, _ = M.linear_dense(dz, L0.wT(3, None), want_stats=False)
                     d_feat, _, _ = M.group_concat_grad(d_rows_feat, None, idx, pts_cnt, n, c)
         if need_xyz_grad:
-            d_rows_xyz, _ = M.linear_dense(dz, L0.wT(0, 3), want_stats=False)
+            d_rows_xyz = M.rows_dot3(dz, W[:3])  # dz W[0:3]^T, three columns: a streaming kernel, not a 128-wide GEMM tile
             _, d_xyz, d_new = M.group_concat_grad(None, d_rows_xyz, idx, pts_cnt, n, 0)
             d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
         return d_feat, d_xyz
