@@ -4,11 +4,12 @@
  *
  * PARITY PARTIAL: tf_nms3d.cpp includes TensorFlow headers that this image lacks, so the
  * reference cannot be compiled here (and no stand-ins are written).  The restatement is
- * pinned by (i) the known answer for the reference's own smoke input
- * (tf_ops/3d_nms/tf_nms3d.py:21-46; SURVEY.md section 4: thr 0.5 -> [[0,1],[0,0]],
- * thr 0.25 -> [[0,1]], BEV intersection 0.6227418) and (ii) an independent
- * Sutherland-Hodgman clipping cross-check in tests/test_oracle_properties.py
- * (test_iou_against_independent_clipping, test_nms_semantics).
+ * pinned by (i) closed-form geometry: the reference's own smoke input (tf_ops/3d_nms/tf_nms3d.py:21-46)
+ * has BEV intersection 0.64 - 4 (0.4 sqrt 2 - 0.5)^2 = 0.6227418, hence IoU 0.49143 and keep lists
+ * [[0,1],[0,0]] @ 0.5 / [[0,1]] @ 0.25; shifted unit cubes (1-t)/(1+t); the pi/4 octagon 2 (sqrt 2 - 1)
+ * (tests/test_oracle_properties.py::test_iou_and_nms_closed_form_known_answers), and (ii) an independent
+ * Sutherland-Hodgman clipping cross-check over random boxes (test_iou_against_independent_clipping,
+ * test_nms_semantics).
  *
  * C++ (not C) on purpose: the reference's vertex ordering goes through std::sort and its
  * visit order through std::priority_queue; using the same libstdc++ containers keeps the

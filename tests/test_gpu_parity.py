@@ -407,6 +407,22 @@ def test_nms_smoke_known_answer(ops, dev, golden):
     assert abs(iou[0, 0, 1] - i3 / (1.512 - i3)) < 1e-5
 
 
+def test_iou_closed_form_known_answers(ops, dev):
+    """The device IoU against answers that come from geometry alone (same cases as tests/test_oracle_properties.py): axis-aligned unit
+    cubes shifted by t along x -> (1 - t) / (1 + t); a unit cube against itself rotated by pi/4 -> regular octagon 2 (sqrt 2 - 1);
+    the reference's smoke pair -> 0.64 - 4 (0.4 sqrt 2 - 0.5)^2."""
+    ts = (0.0, 0.125, 0.5, 0.75, 1.5)
+    boxes = [cases.corner_box(1, 1, 1)] + [cases.corner_box(1, 1, 1, None, (t, 0, 0)) for t in ts] + [cases.corner_box(1, 1, 1, np.pi / 4)]
+    iou = N(ops.n.iou3d_matrix(T(np.array([boxes]).astype(np.float32), dev)))[0]
+    for i, t in enumerate(ts):
+        assert abs(iou[0, 1 + i] - ((1 - t) / (1 + t) if t < 1 else 0.0)) < 1e-5, t
+    oct_area = 2 * (np.sqrt(2.0) - 1)
+    assert abs(iou[0, len(ts) + 1] - oct_area / (2 - oct_area)) < 1e-5
+    c = cases.nms_smoke()
+    i3 = 0.8 * (0.64 - 4 * (0.4 * np.sqrt(2.0) - 0.5) ** 2)
+    assert abs(N(ops.n.iou3d_matrix(T(c["bboxes"], dev)))[0, 0, 1] - i3 / (1.512 - i3)) < 1e-5
+
+
 def test_nms_random_golden(ops, dev, golden):
     c, g = cases.nms_random(), golden("nms_random")
     bb, sc, ob = T(c["bboxes"], dev), T(c["scores"], dev), T(c["objectiveness"], dev)

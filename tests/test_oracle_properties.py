@@ -186,3 +186,31 @@ def test_mlp_oracle_against_float64(O):
     exp = np.maximum(0, g * (z - mean) / np.sqrt(var + 1e-5) + be)
     assert np.allclose(y, exp, rtol=1e-5, atol=1e-5)
     assert (O.max_over_k(y, 64) == y.reshape(10, 64, 24).max(1)).all()
+
+
+def test_iou_and_nms_closed_form_known_answers(O):
+    """Known answers that come from geometry, not from any code: they pin the restatement of tf_nms3d.cpp:43-273 independently of
+    how the reference could (not) be compiled here.
+    (a) The reference's own smoke input (tf_nms3d.py:21-46): a unit cube and a 0.8-cube rotated by 3*pi/4 about y, same
+        centre.  The rotated footprint's half-diagonal 0.4*sqrt(2) overshoots the unit square by d = 0.4*sqrt(2) - 0.5 at each
+        of its four corners, and each overshoot is a right isosceles triangle of area d^2:
+            BEV intersection = 0.64 - 4 d^2 = 0.6227417...,  I3 = 0.8 * that,  IoU = I3 / (1 + 0.512 - I3) = 0.49143
+        -> with thr 0.5 nothing is suppressed (visit order: scores 0.6 then 0.5 -> [[0,1],[0,0]]), with thr 0.25 the unit cube is.
+    (b) Two axis-aligned unit cubes shifted by t along x: IoU = (1 - t) / (1 + t).
+    (c) A unit cube and the same cube rotated by pi/4 about y (regular octagon): BEV intersection = 2 (sqrt(2) - 1)."""
+    c = cases.nms_smoke()
+    d = 0.4 * np.sqrt(2.0) - 0.5
+    bev = 0.64 - 4 * d * d
+    assert abs(O.bev_intersection(c["bboxes"][0, 0], c["bboxes"][0, 1]) - bev) < 1e-6
+    i3 = 0.8 * bev
+    assert abs(O.iou3d(c["bboxes"][0, 0], c["bboxes"][0, 1]) - i3 / (1 + 0.512 - i3)) < 1e-6
+    assert O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.5).tolist() == [[0, 1], [0, 0]]
+    assert O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.25).tolist() == [[0, 1]]
+    for t in (0.0, 0.125, 0.5, 0.75, 1.5):
+        a, b = cases.corner_box(1, 1, 1), cases.corner_box(1, 1, 1, None, (t, 0, 0))
+        exp = (1 - t) / (1 + t) if t < 1 else 0.0
+        assert abs(O.iou3d(a.astype(np.float32), b.astype(np.float32)) - exp) < 1e-6, t
+    a, b = cases.corner_box(1, 1, 1).astype(np.float32), cases.corner_box(1, 1, 1, np.pi / 4).astype(np.float32)
+    oct_area = 2 * (np.sqrt(2.0) - 1)
+    assert abs(O.bev_intersection(a, b) - oct_area) < 1e-6
+    assert abs(O.iou3d(a, b) - oct_area / (2 - oct_area)) < 1e-6
