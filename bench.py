@@ -377,8 +377,6 @@ def main():
                                        "what": "SURVEY 8d algorithmic flops of the reference's formulation (186.0 GFLOP forward at B=8, x3 for "
                                                "fwd+bwd) / the same GEMM time; frac above counts only the flops this path executes"}
         cpu = None
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(n, args.scene)
         # every BASELINE.json configuration in this line (1: single SA layer, 2: backbone forward, 3b: predict tower + NMS,
         # 5: dense 80000-pt scan; 3a = the headline value, 4 = this command with --gpus 8) + what the ball query really scans
         cfgs = bq_detail = None
@@ -391,6 +389,8 @@ def main():
             bq_detail = bench_legs.ball_query_detail(net.sa1, xs[0], torch.from_numpy(synth.uniform_batch(B, n, 1000)).to(dev))
             if bq is not None:
                 bq["alone_on_the_gpu_detail"] = bq_detail
+        if world == 1 and not args.no_cpu_baseline:  # last: its OpenMP threads keep the host busy for a while after they finish
+            cpu = cpu_baseline(n, args.scene)
         out = {
             "metric": "SUN RGB-D 20k-pt scenes/sec (%s)" % ("fwd+bwd" if workload == "train" else "fwd"),
             "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,

@@ -53,6 +53,7 @@ def set_threads(n):
     prev, _THREADS = _THREADS, max(1, int(n))
     if _THREADS > 1:
         if _OMP is None:
+            os.environ.setdefault("OMP_WAIT_POLICY", "passive")  # idle workers sleep instead of spinning beside the GPU's host threads
             _OMP = _load("liboracle_omp.so")
             _OMP.oracle_set_threads.restype = None
         _OMP.oracle_set_threads(_THREADS)
