@@ -109,15 +109,15 @@ struct PoolBelow {
     double *sums;
 };
 
-template <int CIN, int COUT, int K, bool RED>
-__global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, const float *__restrict__ gout,
+template <int CIN, int COUT, int K, bool RED, int NWV = 8 /* wavefronts: 16 when W^T leaves room for one workgroup per CU only */>
+__global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long groups, const float *__restrict__ gout,
                                                                  const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                  const float *__restrict__ coef, int relu, const float *__restrict__ wT,
                                                                  float *__restrict__ da, PoolBelow pb)
 {
     static_assert(K == 64, "one lane per row in the prefix scan");
     constexpr int PL = CIN / 64; // floats per lane of a row
-    constexpr int RW = K / 8;    // rows per wavefront
+    constexpr int RW = K / NWV;  // rows per wavefront
     extern __shared__ __attribute__((aligned(16))) float pds_smem[];
     float *Wl = pds_smem;                                    // [COUT][CIN]
     float *sv = Wl + COUT * CIN;                              // [2][COUT]   (everything below is double-buffered by group parity)
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
     int *cnt = lst + 2 * COUT;                                // [2][K]
     int *start = cnt + 2 * K;                                 // [2][K]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int e = tid; e < COUT * CIN / 4; e += 512)
+    for (int e = tid; e < COUT * CIN / 4; e += NWV * 64)
         reinterpret_cast<float4 *>(Wl)[e] = reinterpret_cast<const float4 *>(wT)[e];
     float cA = 0.f, cS = 0.f, cH = 0.f;
     const bool own = tid < COUT;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
         for (int ri = 0; ri < RW; ri++)
 #pragma unroll
             for (int q = 0; q < PL; q++) {
-                const size_t off = ((size_t)g * K + wv + 8 * ri) * CIN + lane * PL + q;
+                const size_t off = ((size_t)g * K + wv + NWV * ri) * CIN + lane * PL + q;
                 pre[ri][q] = da[off];
                 if (RED) zpre[ri][q] = pb.z[off];
             }
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
         __syncthreads();
 #pragma unroll
         for (int ri = 0; ri < RW; ri++) {
-            const int r = wv + 8 * ri;
+            const int r = wv + NWV * ri;
             const int n = cntp[r], s0 = startp[r];
             if (!RED && n == 0) continue;
             float acc[PL];
@@ -244,17 +244,17 @@ __global__ __launch_bounds__(512) void pool_dgrad_scatter_kernel(long groups, co
     }
     if (RED) { // combine the 8 wavefronts' column sums in LDS (W^T is no longer needed), one fp64 atomic per column and workgroup
         __syncthreads();
-        float *red = Wl; // [8][2][CIN]
+        float *red = Wl; // [NWV][2][CIN]
 #pragma unroll
         for (int q = 0; q < PL; q++) {
             red[(wv * 2 + 0) * CIN + lane * PL + q] = s1[q];
             red[(wv * 2 + 1) * CIN + lane * PL + q] = s2[q];
         }
         __syncthreads();
-        for (int e = tid; e < 2 * CIN; e += 512) {
+        for (int e = tid; e < 2 * CIN; e += NWV * 64) {
             float t = 0.0f;
 #pragma unroll
-            for (int w8 = 0; w8 < 8; w8++) t += red[w8 * 2 * CIN + e];
+            for (int w8 = 0; w8 < NWV; w8++) t += red[w8 * 2 * CIN + e];
             unsafeAtomicAdd(&pb.sums[e], (double)t);
         }
     }
@@ -429,7 +429,7 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
                "pool_dgrad_scatter: below_z given without the layer's BatchNorm vectors / sums");
     hipStream_t st = as_stream(stream);
     const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums};
-    auto go = [&](auto kern, int ci, int co) {
+    auto go = [&](auto kern, int ci, int co, int threads = 512) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         static std::set<const void *> raised; // the attribute is per kernel: set once
@@ -441,19 +441,19 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
         }
         if (fresh)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(512), smem, st, groups, gout, argmax, zsel, coef, relu,
+        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(threads), smem, st, groups, gout, argmax, zsel, coef, relu,
                            wT, da, pb);
     };
     if (below_z) {
         if (cin == 128 && cout == 256)
-            go(pool_dgrad_scatter_kernel<128, 256, 64, true>, 128, 256);
+            go(pool_dgrad_scatter_kernel<128, 256, 64, true, 16>, 128, 256, 1024);
         else if (cin == 128)
             go(pool_dgrad_scatter_kernel<128, 128, 64, true>, 128, 128);
         else
             go(pool_dgrad_scatter_kernel<64, 128, 64, true>, 64, 128);
     } else {
         if (cin == 128 && cout == 256)
-            go(pool_dgrad_scatter_kernel<128, 256, 64, false>, 128, 256);
+            go(pool_dgrad_scatter_kernel<128, 256, 64, false, 16>, 128, 256, 1024);
         else if (cin == 128)
             go(pool_dgrad_scatter_kernel<128, 128, 64, false>, 128, 128);
         else
