@@ -350,6 +350,17 @@ int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const floa
                          int pool_k, const float *zsrc, const float *coef, int relu, const float *wT,
                          float *da_prev, void *stream);
 
+/* votenet_mlp_dgrad_bn (dense upstream gradient da only) whose store epilogue also reduces the BatchNorm backward of the
+ * layer BELOW -- the layer whose activation da_prev is the gradient of, z_prev (rows x cout) its pre-BatchNorm output:
+ *   sums[0:cout] += sum_rows da_prev', sums[cout:2cout] += sum_rows da_prev' * (z_prev - mean_prev) / sqrt(var_prev + eps),
+ *   da_prev' = da_prev * [z_prev*scale_prev + shift_prev > 0] (relu_prev != 0) or da_prev (relu_prev == 0),
+ * i.e. votenet_bn_backward_reduce(rows, cout, 0, da_prev, NULL, z_prev, ...) without a pass of its own over da_prev: the
+ * tile is still in the accumulators.  sums: 2*cout doubles, zeroed by the caller.  Same shapes as votenet_mlp_dgrad_bn. */
+int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                const float *wT, float *da_prev, const float *z_prev, const float *scale_prev,
+                                const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
+                                int relu_prev, double *sums, void *stream);
+
 /* One launch for every re-laid-out copy of a weight block the GEMMs want (element offsets, device array of 6*nseg longs):
  * table[e] = {src_off, dst_off, rows, cols, ld, transpose}.  transpose != 0: dst[dst_off + c*ld + r] = src[src_off + r*cols + c]
  * (W^T for the input-gradient GEMMs; ld >= rows);  transpose == 0: dst[dst_off + r*ld + c] = src[...] (a copy with a padded

@@ -185,6 +185,20 @@ def test_fused_bn_backward_gemms_match_unfused(hiplib, dev, rows, cin, c, k):
         return
     da = M.dgrad_bn(z, coef, True, wT, **src)
     assert relerr(da, da_ref) < 2e-5
+    if k == 0:
+        # the same GEMM with the BatchNorm-backward reduce of the layer below in its store epilogue (votenet_mlp_dgrad_bn_reduce):
+        # identical da, and the sums of a separate votenet_bn_backward_reduce pass over (da, z_below); with and without ReLU
+        zb = rnd(rows, cin)
+        bsc, bsh, bmu, bvar = rnd(cin), rnd(cin), rnd(cin), torch.rand(cin, generator=g).to(dev) + 0.5
+        for relu_below in (True, False):
+            da2, s_fused = M.dgrad_bn(z, coef, True, wT, da=up, below=(zb, bsc, bsh, bmu, bvar, relu_below))
+            assert torch.equal(da2, da)
+            s_ref = M.bn_backward_reduce(zb, bsc, bsh, bmu, bvar, relu_below, da)
+            gm = da.double() * ((zb * bsc + bsh > 0).double() if relu_below else 1.0)
+            s_exact = torch.cat([gm.sum(0), (gm * ((zb.double() - bmu.double()) / torch.sqrt(bvar.double() + M.BN_EPS))).sum(0)])
+            scale = torch.cat([gm.abs().sum(0), (gm * ((zb.double() - bmu.double()) / torch.sqrt(bvar.double() + M.BN_EPS))).abs().sum(0)])
+            assert ((s_fused - s_exact).abs() / (scale + 1e-30)).max().item() < 1e-5
+            assert ((s_ref - s_exact).abs() / (scale + 1e-30)).max().item() < 1e-5
 
 
 @pytest.mark.parametrize("b,n,m,k,cout", [(2, 300, 20, 16, 64), (1, 500, 33, 64, 128), (2, 256, 16, 7, 32), (1, 100, 9, 128, 256)])

@@ -25,6 +25,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int FG_BM = 128;
 constexpr int FG_BK = 16;
 constexpr int FG_LDA = FG_BM + 2;
+#ifndef EPI3_WAVES
+#define EPI3_WAVES 2 // EPI 3: minimum waves per SIMD the register allocator is held to
+#endif
+#ifndef EPI3_CH
+#define EPI3_CH 2 // EPI 3: 32x32 sub-tiles of z_prev loaded at a time
+#endif
 
 // Everything the kernel needs.  SRC selects how the A operand (rows x cin) is produced:
 //   SRC 0: x, optionally through relu(x*in_scale+in_shift)                      (forward / plain dgrad)
@@ -34,6 +40,9 @@ constexpr int FG_LDA = FG_BM + 2;
 // EPI selects the statistics accumulated next to the store of the output z (rows x cout):
 //   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
 //   EPI 1: no statistics (input-gradient GEMMs)
+//   EPI 3: the output is the gradient da of the layer BELOW's activation; next to its store the epilogue reads that layer's
+//          z tile (ez) and accumulates its BatchNorm-backward sums s1 = sum da', s2 = sum da' * zhat, da' = da [act > 0]
+//          (what votenet_bn_backward_reduce would do in a pass over da and z of its own: here da never comes back from HBM)
 //   EPI 2: EPI 0 plus the max-pool of utils.py:132 over groups of 64 rows, BEFORE BatchNorm: the layer's scale/shift
 //          need the statistics of the whole launch, but max_k relu(s*z+h) = relu(s*max_k z + h) for s >= 0 and
 //          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
@@ -55,13 +64,16 @@ struct FastArgs {
     float *z;              // may be NULL with EPI 2 (inference: only the pooled result is wanted)
     float *zmax, *zmin;    // EPI 2: per 64-row group and channel, raw max / min of z ...
     int *amax, *amin;      //        ... and the row offsets (first occurrence) where they are attained
+    const float *ez, *e_scale, *e_shift, *e_mean, *e_var; // EPI 3: z (rows x cout) and BatchNorm of the layer below
+    float e_eps;
+    int e_relu;
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
 template <int WM, int WN, int MT, int NT, int SRC, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_linear_fast_kernel(FastArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? EPI3_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
@@ -70,6 +82,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     __shared__ float As[2][FG_BK][FG_LDA];
     __shared__ float Bs[2][FG_BK][LDB];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
+    __shared__ float Eco[EPI == 3 ? 4 : 1][EPI == 3 ? BN : 1];                   // EPI 3: scale, shift, mean, 1/std of this column block
 
     const long rows = A.rows;
     const int cin = A.cin, cout = A.cout;
@@ -99,6 +112,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     } else {
         for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
     }
+    if (EPI == 3)
+        for (int cidx = tid; cidx < BN; cidx += 256) {
+            Eco[0][cidx] = A.e_scale[n0 + cidx];
+            Eco[1][cidx] = A.e_shift[n0 + cidx];
+            Eco[2][cidx] = A.e_mean[n0 + cidx];
+            Eco[3][cidx] = 1.0f / sqrtf(A.e_var[n0 + cidx] + A.e_eps);
+        }
     long my_tiles = 0;
     if ((long)blockIdx.x < ntiles) my_tiles = (ntiles - 1 - blockIdx.x) / gridDim.x + 1;
     long steps_to_load = my_tiles * nk; // steps whose operands still have to be fetched
@@ -328,7 +348,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 for (int i = 0; i < MT; i++) {
                     const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
 #pragma unroll
-                    for (int e = 0; e < 16; e++) z[off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout] = acc[i][j][e] + bv;
+                    for (int e = 0; e < 16; e++)
+                        z[off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout] = (EPI == 3) ? acc[i][j][e] : acc[i][j][e] + bv;
                 }
             }
         }
@@ -355,6 +376,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                         s1[j] += v;
                         s2[j] += v * v;
                     }
+                }
+            }
+        }
+        if (EPI == 3) {
+            const float thr = A.e_relu ? 0.0f : -__builtin_inff(); // no ReLU below: every element passes
+            // buffer loads: scalar descriptor of this tile's rows + a scalar byte offset per (sub-tile, row) + ONE 32-bit lane
+            // offset, so the sixty-four loads of a tile cost no address registers (64-bit flat addresses cost two each and
+            // pushed the kernel to 256 VGPRs with spills)
+            const unsigned voff = (unsigned)(4 * kh * cout + l31) * 4u;
+            const __amdgpu_buffer_rsrc_t rs =
+                __builtin_amdgcn_make_buffer_rsrc((void *)(A.ez + (size_t)m0 * cout + n0), 0, 0x7fffffff, 0x00020000);
+            unsigned vo = voff;
+            constexpr int CH = EPI3_CH < MT ? EPI3_CH : MT;
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int cl = (wn * NT + j) * 32 + l31;
+                const float sc = Eco[0][cl], sf = Eco[1][cl], mu = Eco[2][cl], inv = Eco[3][cl];
+#pragma unroll
+                for (int i0 = 0; i0 < MT; i0 += CH) {
+                    float zz[CH][16];
+#pragma unroll
+                    for (int ii = 0; ii < CH; ii++) {
+                        const unsigned sbase =
+                            ((unsigned)((wm * MT + i0 + ii) * 32) * (unsigned)cout + (unsigned)((wn * NT + j) * 32)) * 4u;
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            zz[ii][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                                rs, vo, sbase + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)cout * 4u, 0));
+                    }
+#pragma unroll
+                    for (int ii = 0; ii < CH; ii++)
+#pragma unroll
+                        for (int e = 0; e < 16; e++) {
+                            float g = acc[i0 + ii][j][e]; // no bias in an input-gradient GEMM
+                            if (!(zz[ii][e] * sc + sf > thr)) g = 0.0f;
+                            s1[j] += g;
+                            s2[j] += g * ((zz[ii][e] - mu) * inv);
+                        }
+                    // the next chunk's loads wait for this chunk's sums (a made-up dependence through the lane offset): CH x 16
+                    // z values in flight, not all 64 -- the accumulators and both prefetch sets are live here
+                    asm volatile("" : "+v"(vo) : "v"(s2[j]));
                 }
             }
         }
@@ -525,4 +587,39 @@ extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da,
     const bool ok = da ? fast_dispatch<1, 1>(a, st) : fast_dispatch<2, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn: shape not supported by the fused kernel (use votenet_bn_backward_apply + votenet_mlp_linear)");
     return check_launch("mlp_dgrad_bn");
+}
+
+// The same GEMM whose epilogue also reduces the BatchNorm backward of the layer BELOW (the one whose activation da_prev is the
+// gradient of): sums[0:cout] += sum da_prev', sums[cout:2cout] += sum da_prev' * zhat_prev -- votenet_bn_backward_reduce(rows,
+// cout, 0, da_prev, NULL, z_prev, ...) without the pass over da_prev and z_prev of its own.  sums (2*cout doubles) is zeroed by
+// the caller.  Dense upstream gradient only (da).
+extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                           const float *wT, float *da_prev, const float *z_prev, const float *scale_prev,
+                                           const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
+                                           int relu_prev, double *sums, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "mlp_dgrad_bn_reduce expects rows > 0, c > 0, cout > 0");
+    VN_REQUIRE(da && zsrc && coef && wT && da_prev, "mlp_dgrad_bn_reduce: null buffer");
+    VN_REQUIRE(z_prev && scale_prev && shift_prev && mean_prev && var_prev && sums, "mlp_dgrad_bn_reduce: null buffer of the layer below");
+    FastArgs a = {};
+    a.da = da;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = cout;
+    a.w = wT;
+    a.z = da_prev;
+    a.ez = z_prev;
+    a.e_scale = scale_prev;
+    a.e_shift = shift_prev;
+    a.e_mean = mean_prev;
+    a.e_var = var_prev;
+    a.e_eps = eps;
+    a.e_relu = relu_prev;
+    a.stats = sums;
+    if (!fast_dispatch<1, 3>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn_reduce: shape not supported by the fused kernel (use votenet_mlp_dgrad_bn + votenet_bn_backward_reduce)");
+    return check_launch("mlp_dgrad_bn_reduce");
 }

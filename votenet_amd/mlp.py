@@ -495,11 +495,21 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
                                              L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
-def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0):
-    """da_prev = dz @ wT with dz = BatchNorm-backward(da | pooled gout, z, coef) formed in the loader."""
+def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None, eps=BN_EPS):
+    """da_prev = dz @ wT with dz = BatchNorm-backward(da | pooled gout, z, coef) formed in the loader.
+    below = (z_prev, scale, shift, mean, var, relu) of the layer whose activation da_prev is the gradient of: the store
+    epilogue then also reduces that layer's BatchNorm backward -> returns (da_prev, sums) (dense da only)."""
     rows, c = z.shape
     cout = wT.shape[1]
     out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
+    if below is not None:
+        zp, bsc, bsh, bme, bva, brelu = below
+        sums = _zeros_f64(2 * cout, z.device)
+        with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
+            L.check(L.lib().votenet_mlp_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                        L.ptr(out), L.ptr(zp), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps,
+                                                        1 if brelu else 0, L.ptr(sums), L.stream_ptr()))
+        return out, sums
     with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))

@@ -25,6 +25,7 @@ from . import tf_grouping, tf_interpolate, tf_sampling
 
 
 PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
+FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
 # --------------------------------------------------------------------------- parameters
@@ -416,7 +417,13 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                     r["x"], z, coef, da, argmax if pooled else None)
                 if not want_da:
                     return None
-                da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
+                below = recs[i - 1] if i > 0 else None
+                if FUSE_BN_REDUCE and not pooled and below is not None and below["layer"].bn and below["z"] is r["x"]:
+                    # the layer below's BatchNorm-backward sums come out of this GEMM's store epilogue
+                    da, sums_ahead = M.dgrad_bn(z, coef, L.relu, L.wT(), da=da, below=(
+                        below["z"], below["scale"], below["shift"], below["mean"], below["var"], below["layer"].relu))
+                else:
+                    da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
                 continue
             if i == 0 and r["kind"] == "gather" and PRE_LINEAR and not pooled and r["feat"] is not None and \
                     M.group_linear_backward_supported(c, r["idx"].shape[2]):
