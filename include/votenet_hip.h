@@ -361,6 +361,46 @@ int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, con
                                 const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
                                 int relu_prev, double *sums, void *stream);
 
+/* ---- NARROW first layer of a set-abstraction MLP (narrow.hip): 3 + c <= 8 grouped input channels, no input gradient ----
+ * sa1 of VoteNet groups the bare coordinates (model.py:39: l0_points = xyz, so [xyz[idx]-new_xyz | xyz[idx]] has 6 channels).
+ * The first layer's output z0 = u W0 + b0 is then a function of eight floats per grouped row and is never stored: the kernels
+ * below rebuild it where they need it (one fixed fma chain: bit-identical in every kernel), from
+ *   u8 (rows x 8 floats, 16-byte aligned) = (dx, dy, dz, feat[idx][0..c), 0...),  rows = b*m*nsample, row order of idx.
+ * votenet_narrow_rows writes u8 and ADDS the moments (72 doubles, pre-zeroed, may be NULL): m[d] = sum_r u[r,d] at [0,8),
+ * M[d,e] = sum_r u[r,d] u[r,e] at [8 + 8 d + e].  Coordinates and input features only: it can run ahead of the step. */
+int votenet_narrow_rows(int b, int n, int m, int nsample, int c, const float *xyz, const float *new_xyz,
+                        const float *feat /* (b,n,c) or NULL when c == 0 */, const int *idx, float *u8, double *moments,
+                        void *stream);
+/* z0 (rows x c0) = u8 W0 + b0 with the kernels' own fma chain, for a caller that wants the layer output after all (tests). */
+int votenet_narrow_z0(long rows, int k0, int c0, const float *u8, const float *w0, const float *b0, float *z0, void *stream);
+/* BatchNorm statistics of z0 from the moments (W0: k0 x c0 row-major, rows [xyz(3) | feat(c)], k0 = 3 + c; b0: c0 or NULL):
+ * stats[c] = sum_r z0[r,c], stats[c0 + c] = sum_r z0[r,c]^2 (2*c0 doubles, WRITTEN; the layout votenet_bn_finalize and
+ * votenet_bn_raw take).  Exact sums of the exact products, not of the fp32-rounded z0: they agree to fp32 rounding. */
+int votenet_narrow_stats(long rows, int k0, int c0, const double *moments, const float *w0, const float *b0, double *stats,
+                         void *stream);
+/* Second layer: z (rows x cout) = relu(bn0(z0)) w + bias, bn0 from in_bn (raw statistics, finalized in the prologue) or
+ * in_scale / in_shift.  stats as votenet_mlp_linear.  Served: rows % 128 == 0, c0 % 32 == 0, c0 <= 128, cout == 64 or
+ * cout % 128 == 0, 16-byte aligned buffers. */
+int votenet_narrow_linear(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                          const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                          const float *w, const float *bias, float *z, double *stats, void *stream);
+/* Backward of the second layer.  votenet_narrow_wgrad_bn: dw (c0 x cout) += act(z0)^T dz1, dz1 from (da, z, coef) as
+ * votenet_mlp_wgrad_bn (c0 % 64 == 0, cout % 64 == 0).  votenet_narrow_dgrad_bn_reduce: the input-gradient GEMM
+ * da0 = dz1 wT (c x c0) whose result is NOT stored: its epilogue reduces the first layer's BatchNorm backward
+ * (sums, 2*c0 doubles, as votenet_mlp_dgrad_bn_reduce) and ug[d*c0 + c] += sum_r u8[r,d] da0'[r,c] (8*c0 doubles); both
+ * pre-zeroed.  Served: rows % 128 == 0, c % 32 == 0, c <= 512, c0 % 64 == 0, c0 <= 128 per launch column block. */
+int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                            const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
+                            const float *coef, int relu, float *dw, float *scratch, void *stream);
+int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
+                                   int relu, const float *wT, const float *u8, const float *w0, const float *b0,
+                                   const float *scale0, const float *shift0, const float *mean0, const float *var0, float eps,
+                                   int relu0, double *sums, double *ug, void *stream);
+/* Weight gradient of the first layer from the sums alone (dz0 = A g + B + C z0, coef = [A|B|C|S|H] of votenet_bn_backward_coef):
+ * dw0[d,c] += A[c] ug[d,c] + B[c] m[d] + C[c] (sum_e M[d,e] W0[e,c] + m[d] b0[c]),  d < k0. */
+int votenet_narrow_wgrad_first(int k0, int c0, const double *moments, const double *ug, const float *coef, const float *w0,
+                               const float *b0, float *dw0, void *stream);
+
 /* One launch for every re-laid-out copy of a weight block the GEMMs want (element offsets, device array of 6*nseg longs):
  * table[e] = {src_off, dst_off, rows, cols, ld, transpose}.  transpose != 0: dst[dst_off + c*ld + r] = src[src_off + r*cols + c]
  * (W^T for the input-gradient GEMMs; ld >= rows);  transpose == 0: dst[dst_off + r*ld + c] = src[...] (a copy with a padded

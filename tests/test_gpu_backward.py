@@ -21,7 +21,11 @@ def ref_chain(x, layers, params, recs):
             var = z.var(0, unbiased=False)
             z = params[L.name + "/gamma"] * (z - mu) / torch.sqrt(var + EPS) + params[L.name + "/beta"]
         if L.relu:
-            if r["z"] is None:  # pooled layer in Gram form: the device keeps no z; ref_sa applies the active set after the max
+            if r["kind"] == "narrow":  # the device never stores this layer: its own arithmetic, materialised for the active set
+                from votenet_amd import mlp as M
+                zd = M.narrow_z0(r["u8"], L.p("W"), L.p("b"))
+                mask = (zd * r["scale"] + r["shift"] > 0).double()
+            elif r["z"] is None:  # pooled layer in Gram form: the device keeps no z; ref_sa applies the active set after the max
                 mask = 1.0
             else:
                 mask = (r["z"] * r["scale"] + r["shift"] > 0).double()

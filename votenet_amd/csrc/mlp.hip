@@ -565,7 +565,7 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
     VN_REQUIRE(rows >= 0 && cin > 0 && cout > 0, "mlp_linear expects rows >= 0, cin > 0, cout > 0");
     if (rows == 0) return VOTENET_OK;
     VN_REQUIRE(w && z, "mlp_linear: null buffer");
-    MlpIn d;
+    MlpIn d = {};
     d.x = in->x;
     d.in_scale = in->in_scale;
     d.in_shift = in->in_shift;

@@ -627,7 +627,7 @@ static inline int grid_for(long total, int block, int cap = 256 * 16)
 
 static MlpIn to_dev(const votenet_mlp_input *in)
 {
-    MlpIn d;
+    MlpIn d = {};
     d.x = in->x;
     d.in_scale = in->in_scale;
     d.in_shift = in->in_shift;
@@ -932,6 +932,28 @@ extern "C" int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int 
     if (pool_k > 0 && (pool_k & (pool_k - 1)) == 0) shift = __builtin_ctz((unsigned)pool_k);
     BnSrc bs = {da, gout, argmax, pool_k, shift, z, coef, relu, nullptr, 0};
     return wgrad_entry(in, rows, cin, cout, nullptr, bs, da ? 1 : 2, dw, scratch, stream);
+}
+
+// Weight gradient of the SECOND layer of a chain whose first layer is NARROW (narrow.hip): dw (c0 x cout) += act(z0)^T dz1 with
+// z0 rebuilt from u8 in the loader (act = relu(z0*in_scale+in_shift)) and dz1 from (da, z, coef) as votenet_mlp_wgrad_bn.
+extern "C" int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                       const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
+                                       const float *coef, int relu, float *dw, float *scratch, void *stream)
+{
+    VN_REQUIRE(rows > 0 && rows < (1L << 31) && k0 >= 3 && k0 <= 8 && c0 > 0 && cout > 0, "narrow_wgrad_bn: bad shape");
+    VN_REQUIRE(u8 && w0 && in_scale && in_shift && da && z && coef && dw, "narrow_wgrad_bn: null buffer");
+    MlpIn d = {};
+    d.in_scale = in_scale;
+    d.in_shift = in_shift;
+    d.in_relu = in_relu;
+    d.u8 = u8;
+    d.w0 = w0;
+    d.b0 = b0;
+    d.k0 = k0;
+    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0};
+    if (!wgrad_fast_launch(2, d, rows, c0, cout, nullptr, bs, 1, dw, as_stream(stream), scratch))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_wgrad_bn: shape not served (c0 %% 64 == 0, cout %% 64 == 0, 16-byte aligned buffers)");
+    return check_launch("narrow_wgrad_bn");
 }
 
 // coefficient vector [A | B | C | scale | shift] (5*c floats) of the folded BatchNorm backward, from the reductions

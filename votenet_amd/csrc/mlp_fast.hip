@@ -16,15 +16,16 @@
 //   * the pipeline runs across row tiles of a persistent workgroup (no drain at tile boundaries);
 //   * MFMA operand fragments are double-buffered in registers (ds_reads of sub-step k2+1 before the MFMAs
 //     of k2); LDS images are [k][row] / [k][col], conflict-free for both operand reads.
-#include "common.h"
+#include "mlp_types.h"
 
 namespace votenet {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int FG_BM = 128;
 constexpr int FG_BK = 16;
 constexpr int FG_LDA = FG_BM + 2;
+#ifndef FWD_WAVES
+#define FWD_WAVES 2 // EPI 0 / 2: minimum waves per SIMD
+#endif
 #ifndef EPI3_WAVES
 #define EPI3_WAVES 2 // EPI 3: minimum waves per SIMD the register allocator is held to
 #endif
@@ -37,6 +38,9 @@ constexpr int FG_LDA = FG_BM + 2;
 //   SRC 1: dz = A*g + B + C*zsrc with g = da masked by [zsrc*S+H > 0]           (BatchNorm backward folded in,
 //   SRC 2: same with g = gout[row/pool_k] where row%pool_k == argmax[row/pool_k]  dense / max-pooled upstream)
 //          coef = [A | B | C | S | H], 5*cin floats (votenet_bn_backward_coef)
+//   SRC 3: x = z0 of a NARROW first layer (narrow.hip), rebuilt per element from the row's eight floats u8[r] with narrow_z
+//          (W0: k0 x cin, b0), then relu(x*in_scale+in_shift) as SRC 0: the loader reads 32 bytes per row and slab from L2
+//          instead of 64 bytes of z0 from HBM, and z0 is never stored                                 (cin <= 128)
 // EPI selects the statistics accumulated next to the store of the output z (rows x cout):
 //   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
 //   EPI 1: no statistics (input-gradient GEMMs)
@@ -48,6 +52,9 @@ constexpr int FG_LDA = FG_BM + 2;
 //          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
 //          group (+ arg rows) and votenet_bn_pool_finalize picks by the sign of the scale.  A wave's 2 x 32 rows
 //          are exactly one group (2x2 variant, WM = 2, MT = 2).
+//   EPI 4: EPI 3 for a narrow layer below: z_prev is rebuilt from u8 (staged per tile in LDS by the loader), the epilogue also
+//          accumulates UG[d,c] = sum_r u[r,d] da'[r,c] (the data term of that layer's weight gradient) and stores NOTHING
+//          (cout <= 128: the layer below's width)
 struct FastArgs {
     const float *x, *in_scale, *in_shift;
     BnRaw in_raw; // alternative to in_scale / in_shift: derived here from the producer's raw sums
@@ -67,13 +74,16 @@ struct FastArgs {
     const float *ez, *e_scale, *e_shift, *e_mean, *e_var; // EPI 3: z (rows x cout) and BatchNorm of the layer below
     float e_eps;
     int e_relu;
+    const float *u8, *w0, *b0; // SRC 3 / EPI 4: rows x 8 floats, W0 (k0 x c0), b0 (c0, may be NULL); c0 = cin (SRC 3) or cout (EPI 4)
+    int k0;
+    double *ug;                // EPI 4: [8][cout] doubles
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
 template <int WM, int WN, int MT, int NT, int SRC, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? EPI3_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? EPI3_WAVES : (EPI == 0 || EPI == 2) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
@@ -82,7 +92,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     __shared__ float As[2][FG_BK][FG_LDA];
     __shared__ float Bs[2][FG_BK][LDB];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
-    __shared__ float Eco[EPI == 3 ? 4 : 1][EPI == 3 ? BN : 1];                   // EPI 3: scale, shift, mean, 1/std of this column block
+    __shared__ float Eco[(EPI == 3 || EPI == 4) ? 4 : 1][(EPI == 3 || EPI == 4) ? BN : 1]; // EPI 3/4: scale, shift, mean, 1/std of this column block
+    constexpr bool NARROW = (SRC == 3 || EPI == 4);
+    __shared__ __attribute__((aligned(16))) float W0s[NARROW ? 9 : 1][NARROW ? 128 : 1]; // W0 rows 0..7 (zero padded) and b0: SRC 3 by input channel, EPI 4 by column of this block
+    __shared__ __attribute__((aligned(16))) float Us[EPI == 4 ? 2 : 1][EPI == 4 ? FG_BM : 1][8]; // EPI 4: u rows of the tile, double-buffered by tile parity
 
     const long rows = A.rows;
     const int cin = A.cin, cout = A.cout;
@@ -94,8 +107,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     const int n0 = blockIdx.y * BN;
     const int nk = cin / FG_BK;
     const long ntiles = rows / FG_BM;
-    const bool affine = (SRC == 0) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
-    if (SRC == 0) {
+    const bool affine = (SRC == 0 || SRC == 3) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
+    if (NARROW) {
+        const int c0 = (SRC == 3) ? cin : cout, cb = (SRC == 3) ? 0 : n0, cw = (SRC == 3) ? cin : BN;
+        for (int t = tid; t < 9 * cw; t += 256) {
+            const int d = t / cw, c = t % cw;
+            W0s[d][c] = d < 8 ? (d < A.k0 ? A.w0[(size_t)d * c0 + cb + c] : 0.0f) : (A.b0 ? A.b0[cb + c] : 0.0f);
+        }
+    }
+    if (SRC == 0 || SRC == 3) {
         if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
             for (int k = tid; k < cin; k += 256) {
@@ -112,7 +132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     } else {
         for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
     }
-    if (EPI == 3)
+    if (EPI == 3 || EPI == 4)
         for (int cidx = tid; cidx < BN; cidx += 256) {
             Eco[0][cidx] = A.e_scale[n0 + cidx];
             Eco[1][cidx] = A.e_shift[n0 + cidx];
@@ -125,11 +145,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
 
     // A staging: thread t -> tile rows (t>>2) and (t>>2)+64, k-quad (t&3); W staging: float4 #t (+256)
     const int a_row = tid >> 2, a_kq = tid & 3;
-    const float *abase = (SRC == 0) ? A.x : A.zsrc; // the array the row pointers walk
-    const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * cin + a_kq * 4;
-    const float *pa1 = pa0 + (size_t)64 * cin;
+    const float *abase = (SRC == 0) ? A.x : (SRC == 3) ? A.u8 : A.zsrc; // the array the row pointers walk
+    // SRC 3: the pointers stay on the row's eight floats for all slabs of a tile (re-read per slab from L2: no branch in the loop)
+    const int arow_len = (SRC == 3) ? 8 : cin;
+    const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
+    const float *pa1 = pa0 + (size_t)64 * arow_len;
     const ptrdiff_t da_off = (SRC == 1) ? (A.da - A.zsrc) : 0; // SRC 1: da has the layout of zsrc
-    const size_t a_tile_jump = (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
+    const size_t a_tile_jump = (SRC == 3) ? (size_t)gridDim.x * FG_BM * 8 : (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
+    const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
+    // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
+    const float *pu = (EPI == 4) ? A.u8 + ((size_t)blockIdx.x * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4 : nullptr;
+    int ltp = 0; // parity of the tile being LOADED
     // SRC 2: pooled upstream gradient and arg-max of this thread's two rows (group = row / pool_k)
     const int pk = (SRC == 2) ? A.pool_k : 1;
     long g0 = 0, g1 = 0;    // groups of the two staged rows of the step being LOADED
@@ -154,9 +180,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     // is less than the loaded HBM latency, which serialised memory time and matrix time.
     struct Regs {
         float4 a0, a1, b[NB4];
-        float4 g0, g1; // SRC 1: da quads; SRC 2: gout quads
+        float4 g0, g1; // SRC 1: da quads; SRC 2: gout quads; SRC 3: the second half of the rows' u
         int4 m0, m1;   // SRC 2: arg-max quads
         int k, ro0, ro1; // k / row offsets of the quads
+        float4 uq;     // EPI 4: this thread's quad of the tile's u rows
+        int tp;        //        and the tile's parity
     };
     Regs R[2];
     auto issue_loads = [&](Regs &r) {
@@ -166,6 +194,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         if (SRC == 1) {
             r.g0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
             r.g1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
+        } else if (SRC == 3) {
+            r.g0 = *reinterpret_cast<const float4 *>(pa0 + 4);
+            r.g1 = *reinterpret_cast<const float4 *>(pa1 + 4);
         } else if (SRC == 2) {
             r.g0 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g0 * cin + kq);
             r.g1 = *reinterpret_cast<const float4 *>(A.gout + (size_t)g1 * cin + kq);
@@ -176,19 +207,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         }
 #pragma unroll
         for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
+        if (EPI == 4) {
+            r.uq = *reinterpret_cast<const float4 *>(pu);
+            r.tp = ltp;
+        }
         r.k = kq;
         // Advance to the next slab only if there is one: past the end the same (valid) slab is simply loaded again, so
         // the loop body has no memory operation under a branch and the compiler's s_waitcnt bookkeeping stays exact
         // (a conditional load makes it wait for vmcnt(0), which collapses the two-deep pipeline to one).
         if (steps_to_load > 1) {
-            pa0 += FG_BK;
-            pa1 += FG_BK;
+            pa0 += a_slab_step;
+            pa1 += a_slab_step;
 #pragma unroll
             for (int u = 0; u < NB4; u++) pb[u] += b_step;
             if (++lkt == nk) {
                 lkt = 0;
                 pa0 += a_tile_jump;
                 pa1 += a_tile_jump;
+                if (EPI == 4) {
+                    pu += (size_t)gridDim.x * FG_BM * 8;
+                    ltp ^= 1;
+                }
 #pragma unroll
                 for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
                 if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
@@ -201,7 +240,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         --steps_to_load;
     };
     auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk) {
-        if (SRC == 0) {
+        if (SRC == 3) { // v, g = the row's u[0..4), u[4..8): z0 of the four channels rk..rk+3, then the folded BatchNorm + ReLU below
+            const float uu[8] = {v.x, v.y, v.z, v.w, g.x, g.y, g.z, g.w};
+            float wq[4][8];
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                const float4 w4 = *reinterpret_cast<const float4 *>(&W0s[d][rk]);
+                wq[0][d] = w4.x;
+                wq[1][d] = w4.y;
+                wq[2][d] = w4.z;
+                wq[3][d] = w4.w;
+            }
+            const float4 b4 = *reinterpret_cast<const float4 *>(&W0s[8][rk]);
+            v.x = narrow_z(uu, wq[0], b4.x);
+            v.y = narrow_z(uu, wq[1], b4.y);
+            v.z = narrow_z(uu, wq[2], b4.z);
+            v.w = narrow_z(uu, wq[3], b4.w);
+        }
+        if (SRC == 0 || SRC == 3) {
             if (affine) {
                 const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
                 const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
@@ -259,11 +315,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             const int f = tid + u * 256;
             *reinterpret_cast<float4 *>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = r.b[u];
         }
+        if (EPI == 4) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
     };
 
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
+    float ugs[EPI == 4 ? 8 : 1][NT]; // EPI 4: sum_r u[r,d] da'[r,col] over this lane's rows
+#pragma unroll
+    for (int d = 0; d < (EPI == 4 ? 8 : 1); d++)
+#pragma unroll
+        for (int j = 0; j < NT; j++) ugs[d][j] = 0.0f;
     if (my_tiles == 0) return;
     __syncthreads(); // Sco
     // bias of this lane's columns, loaded ONCE and consumed (the empty asm) before any prefetch is in flight: a load inside
@@ -331,6 +393,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         }
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
         const long m0 = ((long)blockIdx.x + t * gridDim.x) * FG_BM;
+        // row pitch in bytes as an opaque scalar: the per-row scalar offsets of the buffer accesses below are then formed here,
+        // per tile (a few s_mul), instead of being hoisted out of the tile loop as 64 loop-invariant SGPRs that spill
+        unsigned pitch = (unsigned)cout * 4u;
+        asm volatile("" : "+s"(pitch));
         float pmaxv[NT], pminv[NT];
         int pmaxi[NT], pmini[NT];
 #pragma unroll
@@ -338,18 +404,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             pmaxv[j] = pminv[j] = 0.0f;
             pmaxi[j] = pmini[j] = 0;
         }
-        const bool store_z = (EPI != 2) || z != nullptr; // wave-uniform: the stores sit in their own loop nest so that the
+        const bool store_z = (EPI != 4) && ((EPI != 2) || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
         if (store_z) {                                   // pooling arithmetic below is not scheduled around 64 addresses
+            // buffer stores: a scalar descriptor of this tile's rows, a scalar byte offset per (sub-tile, row) and ONE 32-bit lane
+            // offset.  With flat 64-bit addresses the loop-invariant parts of the 64 addresses were hoisted out of the tile loop
+            // and stayed live across the matrix loop (about 60 VGPRs: 216 in all, two waves per SIMD instead of three)
+            const unsigned svoff = (unsigned)(4 * kh) * pitch + (unsigned)l31 * 4u;
+            const __amdgpu_buffer_rsrc_t zr = __builtin_amdgcn_make_buffer_rsrc((void *)(z + (size_t)m0 * cout + n0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
             for (int j = 0; j < NT; j++) {
-                const int col = n0 + (wn * NT + j) * 32 + l31;
-                const float bv = bvs[j];
+                const float bv = (EPI == 3) ? 0.0f : bvs[j];
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    const size_t off0 = (size_t)(m0 + (wm * MT + i) * 32 + 4 * kh) * cout + col;
+                    const unsigned sbase = (unsigned)((wm * MT + i) * 32) * pitch + (unsigned)((wn * NT + j) * 32) * 4u;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        z[off0 + (size_t)((e & 3) + 8 * (e >> 2)) * cout] = (EPI == 3) ? acc[i][j][e] : acc[i][j][e] + bv;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), zr, svoff,
+                                                              sbase + (unsigned)((e & 3) + 8 * (e >> 2)) * pitch, 0);
                 }
             }
         }
@@ -384,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             // buffer loads: scalar descriptor of this tile's rows + a scalar byte offset per (sub-tile, row) + ONE 32-bit lane
             // offset, so the sixty-four loads of a tile cost no address registers (64-bit flat addresses cost two each and
             // pushed the kernel to 256 VGPRs with spills)
-            const unsigned voff = (unsigned)(4 * kh * cout + l31) * 4u;
+            const unsigned voff = (unsigned)(4 * kh) * pitch + (unsigned)l31 * 4u;
             const __amdgpu_buffer_rsrc_t rs =
                 __builtin_amdgcn_make_buffer_rsrc((void *)(A.ez + (size_t)m0 * cout + n0), 0, 0x7fffffff, 0x00020000);
             unsigned vo = voff;
@@ -398,12 +469,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
                     float zz[CH][16];
 #pragma unroll
                     for (int ii = 0; ii < CH; ii++) {
-                        const unsigned sbase =
-                            ((unsigned)((wm * MT + i0 + ii) * 32) * (unsigned)cout + (unsigned)((wn * NT + j) * 32)) * 4u;
+                        const unsigned sbase = (unsigned)((wm * MT + i0 + ii) * 32) * pitch + (unsigned)((wn * NT + j) * 32) * 4u;
 #pragma unroll
                         for (int e = 0; e < 16; e++)
                             zz[ii][e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(
-                                rs, vo, sbase + (unsigned)((e & 3) + 8 * (e >> 2)) * (unsigned)cout * 4u, 0));
+                                rs, vo, sbase + (unsigned)((e & 3) + 8 * (e >> 2)) * pitch, 0));
                     }
 #pragma unroll
                     for (int ii = 0; ii < CH; ii++)
@@ -419,6 +489,52 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
                     asm volatile("" : "+v"(vo) : "v"(s2[j]));
                 }
             }
+        }
+        if (EPI == 4) {
+            const float thr = A.e_relu ? 0.0f : -__builtin_inff();
+            const int tp = (int)(t & 1);
+            float wc[NT][8], bc[NT], sc[NT], sf[NT], mu[NT], inv[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int cl = (wn * NT + j) * 32 + l31;
+#pragma unroll
+                for (int d = 0; d < 8; d++) wc[j][d] = W0s[d][cl];
+                bc[j] = W0s[8][cl];
+                sc[j] = Eco[0][cl];
+                sf[j] = Eco[1][cl];
+                mu[j] = Eco[2][cl];
+                inv[j] = Eco[3][cl];
+            }
+            int urow = (wm * MT) * 32 + 4 * kh; // this lane's first row of the tile; four rows (e & 3) are read at a time
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++) {
+                    float4 ua[4], ub[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        ua[q] = *reinterpret_cast<const float4 *>(&Us[tp][urow + i * 32 + 8 * e4 + q][0]);
+                        ub[q] = *reinterpret_cast<const float4 *>(&Us[tp][urow + i * 32 + 8 * e4 + q][4]);
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int e = e4 * 4 + q;
+                        const float uu[8] = {ua[q].x, ua[q].y, ua[q].z, ua[q].w, ub[q].x, ub[q].y, ub[q].z, ub[q].w};
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            const float zz = narrow_z(uu, wc[j], bc[j]);
+                            float g = acc[i][j][e];
+                            if (!(zz * sc[j] + sf[j] > thr)) g = 0.0f;
+                            s1[j] += g;
+                            s2[j] += g * ((zz - mu[j]) * inv[j]);
+#pragma unroll
+                            for (int d = 0; d < 8; d++) ugs[d][j] = __builtin_fmaf(uu[d], g, ugs[d][j]);
+                        }
+                    }
+                    // the next four rows' LDS reads wait for these sums (a made-up dependence through the row index): 32 registers of
+                    // u in flight instead of 8 x 16 x MT
+                    asm volatile("" : "+v"(urow) : "v"(s2[0]));
+                }
         }
         if (EPI == 2) {
             // the other half-wave holds the interleaved rows of the same group: combine, smaller row wins ties
@@ -449,24 +565,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         // combine the WM waves that share a column block in LDS (the operand buffers are free now: every wave is past
         // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
         // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
-        float *red = &As[0][0][0]; // [2][WM][BN]
+        constexpr int NS = (EPI == 4) ? 10 : 2; // statistics per column: s1, s2 (+ the eight rows of UG)
+        float *red = &As[0][0][0];              // [NS][WM][BN]
+        static_assert(NS * WM * BN <= 2 * FG_BK * FG_LDA, "reduction scratch exceeds the A buffers");
 #pragma unroll
         for (int j = 0; j < NT; j++) {
-            const float t1 = s1[j] + __shfl_xor(s1[j], 32);
-            const float t2 = s2[j] + __shfl_xor(s2[j], 32);
             const int c = (wn * NT + j) * 32 + l31;
-            if (lane < 32) {
-                red[(0 * WM + wm) * BN + c] = t1;
-                red[(1 * WM + wm) * BN + c] = t2;
+#pragma unroll
+            for (int q = 0; q < NS; q++) {
+                const float v = q == 0 ? s1[j] : q == 1 ? s2[j] : ugs[EPI == 4 ? q - 2 : 0][j];
+                const float t = v + __shfl_xor(v, 32);
+                if (lane < 32) red[(q * WM + wm) * BN + c] = t;
             }
         }
         __syncthreads();
-        if (tid < 2 * BN) {
-            const int which = tid / BN, c = tid % BN;
+        for (int e = tid; e < NS * BN; e += 256) {
+            const int which = e / BN, c = e % BN;
             float t = 0.0f;
 #pragma unroll
             for (int i = 0; i < WM; i++) t += red[(which * WM + i) * BN + c];
-            unsafeAtomicAdd(&A.stats[which * cout + n0 + c], (double)t);
+            if (which < 2) unsafeAtomicAdd(&A.stats[which * cout + n0 + c], (double)t);
+            else unsafeAtomicAdd(&A.ug[(size_t)(which - 2) * cout + n0 + c], (double)t);
         }
     }
 }
@@ -474,13 +593,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
 template <int SRC, int EPI>
 static bool fast_dispatch(const FastArgs &a, hipStream_t st)
 {
-    const float *abase = (SRC == 0) ? a.x : a.zsrc;
+    const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : a.zsrc;
+    if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
     const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
                          (SRC != 1 || (uintptr_t)a.da % 16 == 0) &&
                          (SRC != 2 || ((uintptr_t)a.gout % 16 == 0 && (uintptr_t)a.argmax % 16 == 0));
     if (!aligned || a.cin % (2 * FG_BK) != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
     const long ntiles = a.rows / FG_BM;
     long gx;
+    if constexpr (EPI == 4) { // 128 x 64 tiles only: the epilogue's per-column constants and the u rows fit the registers of that shape
+        if (a.cout % 64 != 0) return false;
+        const int ny = a.cout / 64;
+        gx = ntiles < 2048 / ny ? ntiles : 2048 / ny;
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        return true;
+    } else {
     // few row tiles (FP layers, voting, mlp2): 128 x 64 tiles double the number of workgroups
     if (EPI != 2 && a.cout % 128 == 0 && ntiles * (a.cout / 128) < 200) {
         const int ny = a.cout / 64;
@@ -501,6 +628,7 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
         hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, 1), dim3(256), 0, st, a);
         return true;
+    }
     }
     return false;
 }
@@ -622,4 +750,73 @@ extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const flo
     if (!fast_dispatch<1, 3>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn_reduce: shape not supported by the fused kernel (use votenet_mlp_dgrad_bn + votenet_bn_backward_reduce)");
     return check_launch("mlp_dgrad_bn_reduce");
+}
+
+// Second layer of an SA chain whose first layer is NARROW (narrow.hip): z (rows x cout) = relu(bn0(z0)) w + bias with
+// z0[r,:] = narrow_z(u8[r], W0, b0) rebuilt in the operand loader (z0 is never stored), bn0 from raw statistics (in_bn) or from
+// in_scale / in_shift.  stats as for votenet_mlp_linear.
+extern "C" int votenet_narrow_linear(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                     const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                     const float *w, const float *bias, float *z, double *stats, void *stream)
+{
+    VN_REQUIRE(rows > 0 && k0 >= 3 && k0 <= 8 && c0 > 0 && cout > 0, "narrow_linear expects rows > 0, 3 <= k0 <= 8, c0 > 0, cout > 0");
+    VN_REQUIRE(u8 && w0 && w && z, "narrow_linear: null buffer");
+    VN_REQUIRE(in_bn != nullptr || (in_scale != nullptr && in_shift != nullptr), "narrow_linear: the first layer's BatchNorm is missing");
+    FastArgs a = {};
+    a.u8 = u8;
+    a.w0 = w0;
+    a.b0 = b0;
+    a.k0 = k0;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_raw = to_raw(in_bn);
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = c0;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.stats = stats;
+    hipStream_t st = as_stream(stream);
+    const bool ok = stats ? fast_dispatch<3, 0>(a, st) : fast_dispatch<3, 1>(a, st);
+    if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_linear: shape not served (rows %% 128 == 0, c0 %% 32 == 0, c0 <= 128, cout == 64 or cout %% 128 == 0, 16-byte aligned buffers)");
+    return check_launch("narrow_linear");
+}
+
+// Input-gradient GEMM of that second layer: da0 = dz1 wT (dz1 from (da, zsrc, coef) as votenet_mlp_dgrad_bn) is NOT stored; its
+// epilogue reduces the first layer's BatchNorm backward (sums: 2*c0 doubles, as votenet_mlp_dgrad_bn_reduce, z0 rebuilt from u8)
+// and ug[d*c0 + c] += sum_r u8[r,d] da0'[r,c] (8*c0 doubles), the data term of votenet_narrow_wgrad_first.  Both pre-zeroed.
+extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
+                                              int relu, const float *wT, const float *u8, const float *w0, const float *b0,
+                                              const float *scale0, const float *shift0, const float *mean0, const float *var0,
+                                              float eps, int relu0, double *sums, double *ug, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && c0 > 0 && k0 >= 3 && k0 <= 8, "narrow_dgrad_bn_reduce expects rows > 0, c > 0, c0 > 0, 3 <= k0 <= 8");
+    VN_REQUIRE(da && zsrc && coef && wT && u8 && w0, "narrow_dgrad_bn_reduce: null buffer");
+    VN_REQUIRE(scale0 && shift0 && mean0 && var0 && sums && ug, "narrow_dgrad_bn_reduce: null buffer of the first layer");
+    FastArgs a = {};
+    a.da = da;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = c0;
+    a.w = wT;
+    a.u8 = u8;
+    a.w0 = w0;
+    a.b0 = b0;
+    a.k0 = k0;
+    a.e_scale = scale0;
+    a.e_shift = shift0;
+    a.e_mean = mean0;
+    a.e_var = var0;
+    a.e_eps = eps;
+    a.e_relu = relu0;
+    a.stats = sums;
+    a.ug = ug;
+    if (!fast_dispatch<1, 4>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
+    return check_launch("narrow_dgrad_bn_reduce");
 }

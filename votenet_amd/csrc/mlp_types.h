@@ -19,7 +19,20 @@ struct MlpIn {
     const float *feat;
     const int *idx;
     int n, m, nsample, c;
+    // NARROW first layer (narrow.hip): x[r,:] = z0[r,:] = narrow_z(u8[r], W0, b0), rows of 8 floats; then in_scale / in_shift / in_relu
+    const float *u8, *w0, *b0;
+    int k0; // 3..8 rows of W0 (k0 x cin), the rest of u is zero
 };
+
+// z0[r,c] of a narrow first layer: ONE fma chain in a fixed order.  Every kernel that needs z0 rebuilds it with this function, so the
+// forward and the backward pass see bit-identical values (identical ReLU masks); zero-padded u / W0 entries add exactly nothing.
+__device__ __forceinline__ float narrow_z(const float (&u)[8], const float (&w)[8], float b)
+{
+    float z = b;
+#pragma unroll
+    for (int d = 0; d < 8; d++) z = __builtin_fmaf(u[d], w[d], z);
+    return z;
+}
 
 // How a backward GEMM obtains its dz operand (rows x cout):
 //   da == gout == NULL: dz read from memory;

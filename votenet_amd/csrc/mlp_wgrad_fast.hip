@@ -10,6 +10,8 @@
 //     (da | pooled gout, z, coef) on dZ -- struct BnSrc; BSRC 3: dZ is itself a folded activation, for the Gram matrix of
 //     votenet_mlp_gram) and refilled with the slab three steps ahead.  Loads lead by
 //     two slabs of matrix work; one slab is shorter than the loaded HBM latency;
+//   * NARROW (MODE 2): X = z0 of a narrow first layer, rebuilt from the row's eight floats u8[r] with narrow_z (narrow.hip): the
+//     thread's four channels of W0 / b0 sit in registers, a slab row costs 32 bytes instead of 4*cin;
 //   * GATHER: the idx of a slab is loaded one refill BEFORE the feature rows that need it, and ahead of that refill's
 //     other loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.
 // LDS images are the natural [row][channel] slabs; lane l reads As[k2*2 + (l>>5)][i0 + (l&31)]: conflict-free.
@@ -44,7 +46,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int xc = (MODE == 0) ? cin : in.c;
 
     // per-thread channel constants in registers
-    const bool affine = (MODE == 0) && in.in_scale != nullptr;
+    const bool affine = (MODE == 0 || MODE == 2) && in.in_scale != nullptr;
+    float w0r[4][8], b0r[4]; // MODE 2: W0[:, ka..ka+3] (zero padded to 8 rows) and b0[ka..ka+3]
+    if (MODE == 2) {
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+            const float4 w4 = d < in.k0 ? *reinterpret_cast<const float4 *>(in.w0 + (size_t)d * cin + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+            w0r[0][d] = w4.x;
+            w0r[1][d] = w4.y;
+            w0r[2][d] = w4.z;
+            w0r[3][d] = w4.w;
+        }
+        const float4 b4 = in.b0 ? *reinterpret_cast<const float4 *>(in.b0 + ka) : make_float4(0.f, 0.f, 0.f, 0.f);
+        b0r[0] = b4.x;
+        b0r[1] = b4.y;
+        b0r[2] = b4.z;
+        b0r[3] = b4.w;
+    }
     float4 csc = make_float4(1.f, 1.f, 1.f, 1.f), csh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (affine) {
         csc = *reinterpret_cast<const float4 *>(in.in_scale + ka);
@@ -66,7 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     const float b_floor = (BSRC == 3 && bs.relu) ? 0.0f : -__builtin_inff();
     // wave-uniform bases at the workgroup's first row; threads carry 32-bit element offsets (checked by the launcher)
-    const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : in.feat + ka;
+    const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : (MODE == 2) ? in.u8 + (size_t)r_begin * 8 : in.feat + ka;
     const float *zb = (BSRC == 0 ? dz : bs.z) + (size_t)r_begin * cout + nb;
     const float *gb = (BSRC == 1) ? bs.da + (size_t)r_begin * cout + nb : nullptr;
     const int *idxb = (MODE == 1) ? in.idx + r_begin : nullptr;
@@ -74,6 +92,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     struct Regs {
         float4 a[NA], b[NB], g[NB];
+        float4 a2[MODE == 2 ? NA : 1]; // MODE 2: the second half of the rows' u
         int4 m[NB];
         int s; // slab index (local)
     };
@@ -96,6 +115,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             const int lr = clampr(s * WF_BR + a_row + h * RA);
             if (MODE == 0) {
                 r.a[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * (unsigned)cin));
+            } else if (MODE == 2) {
+                r.a[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * 8u));
+                r.a2[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * 8u) + 4);
             } else {
                 const unsigned scene = (unsigned)(r_begin + lr) / grows;
                 r.a[h] = *reinterpret_cast<const float4 *>(xb + ((size_t)scene * in.n + pi[h]) * xc);
@@ -119,6 +141,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
         for (int h = 0; h < NA; h++) {
             float4 v = r.a[h];
+            if (MODE == 2) {
+                const float4 v2 = r.a2[h];
+                const float uu[8] = {v.x, v.y, v.z, v.w, v2.x, v2.y, v2.z, v2.w};
+                v.x = narrow_z(uu, w0r[0], b0r[0]);
+                v.y = narrow_z(uu, w0r[1], b0r[1]);
+                v.z = narrow_z(uu, w0r[2], b0r[2]);
+                v.w = narrow_z(uu, w0r[3], b0r[3]);
+            }
             v.x = fmaxf(v.x * csc.x + csh.x, x_floor);
             v.y = fmaxf(v.y * csc.y + csh.y, x_floor);
             v.z = fmaxf(v.z * csc.z + csh.z, x_floor);
@@ -317,6 +347,11 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         if (bsrc == 3) return launch<0, 3>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch);
+    }
+    if (mode == 2) { // NARROW first layer below: x rebuilt from u8 (votenet_narrow_wgrad_bn)
+        if (!al(d.u8) || !al(d.w0) || (d.b0 && !al(d.b0)) || d.k0 < 1 || d.k0 > 8 || bsrc != 1) return false;
+        if (d.in_scale && (!al(d.in_scale) || !al(d.in_shift))) return false;
+        return launch<2, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (d.c != cin || !al(d.feat) || bsrc != 0) return false;
     return launch<1, 0>(d, rows, cin, cout, dz, bs, dw, st, scratch);

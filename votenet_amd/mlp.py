@@ -249,6 +249,99 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     return z, stats
 
 
+# ---- NARROW first layer (csrc/narrow.hip): 3 + c <= 8 grouped channels, z0 never stored ----
+def narrow_supported(rows, k0, c0, c1):
+    """Shapes the narrow-first-layer kernels serve (include/votenet_hip.h): k0 = 3 + c grouped input channels, c0 / c1 = widths
+    of the first / second layer."""
+    return 3 <= k0 <= 8 and rows > 0 and rows % 128 == 0 and rows < 2 ** 31 and c0 % 64 == 0 and c0 <= 128 and (c1 == 64 or c1 % 128 == 0)
+
+
+def narrow_rows(xyz, new_xyz, feat, idx, want_moments=True):
+    """-> u8 (rows, 8) f32 = (xyz[idx]-new_xyz | feat[idx] | 0...), moments (72,) f64 or None (votenet_narrow_rows)."""
+    b, m, k = idx.shape
+    n = xyz.shape[1]
+    c = feat.shape[2] if feat is not None else 0
+    u8 = torch.empty((b * m * k, 8), dtype=torch.float32, device=xyz.device)
+    # not from the per-step statistics arena: the geometry of a batch is computed one or two steps ahead of its use
+    mom = torch.zeros(72, dtype=torch.float64, device=xyz.device) if want_moments else None
+    with torch.cuda.device(xyz.device):
+        L.check(L.lib().votenet_narrow_rows(b, n, m, k, c, L.ptr(xyz), L.ptr(new_xyz), L.ptr(feat), L.ptr(idx), L.ptr(u8), L.ptr(mom),
+                                            L.stream_ptr()))
+    return u8, mom
+
+
+def narrow_z0(u8, w0, b0):
+    """The first-layer output the product path never stores, with the kernels' own arithmetic (tests: the device's active set)."""
+    k0, c0 = w0.shape
+    z0 = torch.empty((u8.shape[0], c0), dtype=torch.float32, device=u8.device)
+    with torch.cuda.device(u8.device):
+        L.check(L.lib().votenet_narrow_z0(u8.shape[0], k0, c0, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(z0), L.stream_ptr()))
+    return z0
+
+
+def narrow_stats(rows, mom, w0, b0):
+    """BatchNorm statistics (2*c0 f64: sum z0, sum z0^2) of the never-stored first-layer output, from the moments."""
+    k0, c0 = w0.shape
+    stats = torch.empty(2 * c0, dtype=torch.float64, device=w0.device)
+    with torch.cuda.device(w0.device):
+        L.check(L.lib().votenet_narrow_stats(rows, k0, c0, L.ptr(mom), L.ptr(w0), L.ptr(b0), L.ptr(stats), L.stream_ptr()))
+    return stats
+
+
+def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True):
+    """Second layer over the rebuilt first-layer output: z = relu(bn0(u8 w0 + b0)) w + bias -> z (rows, cout), stats."""
+    rows = u8.shape[0]
+    k0, c0 = w0.shape
+    cout = w.shape[1]
+    z = torch.empty((rows, cout), dtype=torch.float32, device=u8.device)
+    stats = _zeros_f64(2 * cout, u8.device) if want_stats else None
+    scale = shift = raw = None
+    if in_bn.done:
+        scale, shift = in_bn.scale, in_bn.shift
+    else:
+        raw = in_bn.raw()
+    with torch.cuda.device(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow")):
+        L.check(L.lib().votenet_narrow_linear(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
+                                              ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
+                                              L.ptr(bias), L.ptr(z), L.ptr(stats), L.stream_ptr()))
+    return z, stats
+
+
+def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, dw):
+    """dw (c0, cout) += relu(bn0(u8 w0 + b0))^T dz1, dz1 = BatchNorm-backward(da, z, coef) formed in the loader."""
+    rows = u8.shape[0]
+    k0, c0 = w0.shape
+    cout = z.shape[1]
+    scr = _wgrad_scratch(None, rows, c0, cout, u8.device)
+    with torch.cuda.device(u8.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn narrow")):
+        L.check(L.lib().votenet_narrow_wgrad_bn(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(in_scale), L.ptr(in_shift),
+                                                1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
+                                                L.ptr(scr), L.stream_ptr()))
+
+
+def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS):
+    """The input-gradient GEMM of the second layer with nothing stored: -> sums (2*c0 f64: BatchNorm-backward sums of the first
+    layer), ug (8, c0) f64 = sum_r u8[r,:]^T da0'[r,:].  below = (scale, shift, mean, var, relu) of the first layer."""
+    rows, c = z.shape
+    k0, c0 = w0.shape
+    bsc, bsh, bme, bva, brelu = below
+    out = _zeros_f64(10 * c0, z.device)
+    sums, ug = out[:2 * c0], out[2 * c0:]
+    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow")):
+        L.check(L.lib().votenet_narrow_dgrad_bn_reduce(rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                       L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva),
+                                                       eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), L.stream_ptr()))
+    return sums, ug.view(8, c0)
+
+
+def narrow_wgrad_first(mom, ug, coef, w0, b0, dw0):
+    """dw0 (k0, c0) += the first layer's weight gradient from the sums alone (votenet_narrow_wgrad_first)."""
+    k0, c0 = w0.shape
+    with torch.cuda.device(w0.device):
+        L.check(L.lib().votenet_narrow_wgrad_first(k0, c0, L.ptr(mom), L.ptr(ug), L.ptr(coef), L.ptr(w0), L.ptr(b0), L.ptr(dw0),
+                                                   L.stream_ptr()))
+
+
 def linear_pool_supported(rows, cin, cout, k):
     """Shapes votenet_mlp_linear_pool serves (see include/votenet_hip.h)."""
     return k == 64 and rows > 0 and rows % 128 == 0 and cin % 32 == 0 and cin <= 512 and cout % 128 == 0

@@ -31,7 +31,7 @@ class VoteNetHotPath:
         s = P.ParamStore(device)
         self.store = s
         n1, n2, n3, n4 = npoints
-        self.sa1 = P.SAModule(s, "sa1", n1, 0.2, 64, 3, [64, 64, 128])      # model.py:39 (l0_points = xyz, C=3)
+        self.sa1 = P.SAModule(s, "sa1", n1, 0.2, 64, 3, [64, 64, 128], leaf=True)      # model.py:39 (l0_points = xyz, C=3)
         self.sa2 = P.SAModule(s, "sa2", n2, 0.4, 64, 128, [128, 128, 256])  # model.py:41
         self.sa3 = P.SAModule(s, "sa3", n3, 0.8, 64, 256, [128, 128, 256])  # model.py:43
         self.sa4 = P.SAModule(s, "sa4", n4, 1.2, 64, 256, [128, 128, 256])  # model.py:45
@@ -53,7 +53,7 @@ class VoteNetHotPath:
         the current stream; an event per level so that a consumer waits only for what it needs."""
         xyz = x if "sa1" in levels else g["sa1"][1]
         for name in levels:
-            g[name] = getattr(self, name).geometry(xyz)
+            g[name] = getattr(self, name).geometry(xyz, points=x if name == "sa1" else None)  # sa1's input features are the coordinates (model.py:39)
             xyz = g[name][1]
             if name == "sa2":  # seeds = l2_xyz: the proposal layer's FPS can start as soon as they exist
                 g["prop_fps"] = P.tf_sampling.farthest_point_sample(self.proposal.npoint, xyz)
@@ -81,7 +81,7 @@ class VoteNetHotPath:
         main = torch.cuda.current_stream()
         side = self._side_stream()
         g, ev = {}, {}
-        g["sa1"] = self.sa1.geometry(x)
+        g["sa1"] = self.sa1.geometry(x, points=x)
         start = torch.cuda.Event()
         start.record(main)
         with torch.cuda.stream(side):

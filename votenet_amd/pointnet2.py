@@ -25,6 +25,7 @@ from . import tf_grouping, tf_interpolate, tf_sampling
 
 
 PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
+NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the first layer's output is rebuilt from 8 floats per row, never stored (csrc/narrow.hip)
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -244,7 +245,17 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
         pool = None
         sc = pend.scale if pend is not None else None  # views: filled when the consumer below has run
         sh = pend.shift if pend is not None else None
-        if i == 0 and first[0] == "gather":
+        if i == 0 and first[0] == "narrow":
+            # narrow first layer (csrc/narrow.hip): no kernel writes z0 = u8 W0 + b0; its BatchNorm statistics follow from the moments
+            # of u8 and the next layer's GEMM rebuilds it in its operand loader
+            _, u8, mom = first
+            zn = None
+            st = M.narrow_stats(rows, mom, w, b) if (L.bn and FROZEN_BN is None) else None
+            rec = dict(layer=L, kind="narrow", u8=u8, mom=mom)
+        elif i == 1 and first[0] == "narrow":
+            zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn)
+            rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
+        elif i == 0 and first[0] == "gather":
             # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
             # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
             # and the layer output is assembled per grouped row: z = P[idx] + dxyz W[0:3] + bias (votenet_group_linear).
@@ -409,6 +420,20 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
             coef = M.bn_backward_coef(rows, *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
+            if r.get("narrow"):
+                # second layer above a NARROW first layer (i == 1): both GEMMs rebuild z0 from u8; the input-gradient GEMM stores
+                # nothing -- its epilogue leaves the first layer's BatchNorm-backward sums and the data term of its weight gradient
+                r0 = recs[0]
+                L0, u8, mom = r0["layer"], r0["u8"], r0["mom"]
+                w0, b0 = L0.p("W"), L0.p("b")
+                on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.narrow_wgrad_bn(
+                    u8, w0, b0, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W")), u8, z, coef, da)
+                sums0, ug = M.narrow_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, u8, w0, b0,
+                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu))
+                coef0 = M.bn_backward_coef(r0["rows"], r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.p("gamma"), sums0,
+                                           L0.gp("gamma"), L0.gp("beta"))
+                M.narrow_wgrad_first(mom, ug, coef0, w0, b0, L0.gp("W"))
+                return None  # a leaf: nothing upstream takes a gradient
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
                 # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
                 src = dict(gout=da, argmax=argmax, k=k) if pooled else dict(da=da)
@@ -478,30 +503,49 @@ def sample_and_group(npoint, radius, nsample, xyz, sample_xyz=None, knn=False):
 class SAModule:
     """pointnet_sa_module (utils.py:93-158) with group_all=False, pooling='max', use_xyz=True."""
 
-    def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None, knn=False, prefix="conv"):
+    def __init__(self, store, scope, npoint, radius, nsample, cin, mlp, mlp2=None, knn=False, prefix="conv", leaf=False):
+        """leaf: the input points carry no gradient (the first module of a network): backward() then returns (None, None), which
+        lets a narrow first layer (3 + cin <= 8) run without ever storing its output (NARROW_FIRST, csrc/narrow.hip)."""
         self.npoint, self.radius, self.nsample, self.knn = npoint, radius, nsample, knn
+        self.leaf, self.cin = leaf, cin
         self.mlp = make_mlp(store, scope, 3 + cin, mlp, prefix)
         store.want_transpose(self.mlp[0].name + "/W", 3, None)  # W[3:]^T: the per-point feature gradient
         store.want_transpose(self.mlp[0].name + "/W", 0, 3)     # W[:3]^T: the xyz gradient (proposal layer)
         self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
 
-    def geometry(self, xyz, sample_xyz=None, fps_idx=None):
-        """The feature-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream."""
+    def narrow(self, rows):
+        """True when this module runs its first layer in the narrow form for `rows` grouped rows."""
+        m = self.mlp
+        return bool(NARROW_FIRST and self.leaf and len(m) >= 3 and m[0].bn and m[1].bn and m[0].relu and
+                    M.narrow_supported(rows, 3 + self.cin, m[0].cout, m[1].cout))
+
+    def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None):
+        """The weight-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream.
+        points: the module's input features; given for a narrow leaf module, the grouped rows u8 and their moments (which depend
+        on coordinates and input features only) are appended to the result."""
         if fps_idx is None:
-            return sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz, self.knn)
-        new_xyz = tf_sampling.gather_point(xyz, fps_idx)
-        idx, pts_cnt = _group_indices(self.radius, self.nsample, xyz, new_xyz, self.knn)
-        return fps_idx, new_xyz, idx, pts_cnt
+            geom = sample_and_group(self.npoint, self.radius, self.nsample, xyz, sample_xyz, self.knn)
+        else:
+            new_xyz = tf_sampling.gather_point(xyz, fps_idx)
+            idx, pts_cnt = _group_indices(self.radius, self.nsample, xyz, new_xyz, self.knn)
+            geom = (fps_idx, new_xyz, idx, pts_cnt)
+        if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
+            geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
+        return geom
 
     def forward(self, xyz, points, sample_xyz=None, tape=None, geom=None):
         """xyz (B,n,3), points (B,n,C) or None -> new_xyz (B,m,3), new_points (B,m,C'), idx (B,m,K).
         geom: the tuple returned by geometry() when it was computed ahead of time."""
         b = xyz.shape[0]
-        fps_idx, new_xyz, idx, pts_cnt = geom if geom is not None else self.geometry(xyz, sample_xyz)
+        geom = geom if geom is not None else self.geometry(xyz, sample_xyz, points=points)
+        fps_idx, new_xyz, idx, pts_cnt = geom[:4]
         recs = []
         rows = b * self.npoint * self.nsample
-        z, pend = mlp_chain_forward(self.mlp, rows, ("gather", xyz, new_xyz, points, idx), recs, pool_k=self.nsample,
-                                    keep_z=tape is not None)
+        first = ("gather", xyz, new_xyz, points, idx)
+        if self.narrow(rows):
+            u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
+            first = ("narrow", u8, mom)
+        z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
             res = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend,
                                      want_zsel=tape is not None and bool(recs[-1].get("gram_form")))
@@ -530,6 +574,10 @@ class SAModule:
         need_feat = need_feat_grad and rec["points"] is not None
         h = mlp_chain_backward(rec["recs"], g, "pool", argmax=rec["argmax"], k=self.nsample, need_input_grad=need_feat,
                                zsel=rec.get("zsel"))
+        if rec["recs"][0]["kind"] == "narrow":
+            if need_feat or need_xyz_grad:
+                raise ValueError("SAModule(leaf=True): the narrow first layer keeps no per-row gradient; build the module with leaf=False")
+            return None, None
         return self._first_layer_backward(rec, h, need_feat, need_xyz_grad)
 
     def _first_layer_backward(self, rec, h, need_feat, need_xyz_grad):
