@@ -252,10 +252,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
                 wq[3][d] = w4.w;
             }
             const float4 b4 = *reinterpret_cast<const float4 *>(&W0s[8][rk]);
+#ifdef NARROW_ABLATE
+            v.x = uu[0] + b4.x + wq[0][0];
+            v.y = uu[1] + b4.y + wq[1][1];
+            v.z = uu[2] + b4.z + wq[2][2];
+            v.w = uu[3] + uu[7] + b4.w + wq[3][3];
+#else
             v.x = narrow_z(uu, wq[0], b4.x);
             v.y = narrow_z(uu, wq[1], b4.y);
             v.z = narrow_z(uu, wq[2], b4.z);
             v.w = narrow_z(uu, wq[3], b4.w);
+#endif
         }
         if (SRC == 0 || SRC == 3) {
             if (affine) {

@@ -19,6 +19,8 @@ from . import mlp as M
 from . import pointnet2 as P
 
 NH, NS, NC = 12, 10, 10  # config.py:2-3
+SIDE_PRIORITY = 0   # HIP stream priorities of the geometry (prefetch) streams and of the weight-gradient stream (0 = normal)
+WGRAD_PRIORITY = 0
 PROPOSAL_NUM = 256       # config.py:6
 PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
 
@@ -45,7 +47,7 @@ class VoteNetHotPath:
     # ---- forward pieces -------------------------------------------------------------
     def _side_stream(self):
         if getattr(self, "_side", None) is None:
-            self._side = torch.cuda.Stream(device=self.device)
+            self._side = torch.cuda.Stream(device=self.device, priority=SIDE_PRIORITY)
         return self._side
 
     def _geometry_chain(self, x, g, ev, levels):
@@ -103,7 +105,7 @@ class VoteNetHotPath:
             return
         main = torch.cuda.current_stream()
         if getattr(self, "_pf_streams", None) is None:
-            self._pf_streams = [self._side_stream(), torch.cuda.Stream(device=self.device)]
+            self._pf_streams = [self._side_stream(), torch.cuda.Stream(device=self.device, priority=SIDE_PRIORITY)]
             self._pf_turn = 0
         side = self._pf_streams[self._pf_turn]
         self._pf_turn ^= 1
@@ -290,7 +292,7 @@ class VoteNetHotPath:
         M.arena_begin(self.device)  # one fill for all BatchNorm-backward reductions of the pass
         if self.overlap_wgrad:
             if self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=self.device)
+                self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
             P.WGRAD_STREAM = self._wgrad_stream
         try:
             self._backward(tape, cot)
