@@ -177,8 +177,38 @@ def check(rc):
     raise VotenetError("libvotenet_hip error %d: %s" % (rc, msg))
 
 
+# The host side of a train step is ~250 launches: the Python objects behind torch.cuda.current_stream() / torch.cuda.device(...)
+# were a quarter of its enqueue time (cProfile, tools/probe/host_profile.py).  The raw-handle calls below are what those wrappers
+# end up calling.
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a void* for the C ABI."""
+    if _raw_stream is not None and _cur_device is not None:
+        return ctypes.c_void_p(_raw_stream(_cur_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _NoGuard:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+_NOGUARD = _NoGuard()
+
+
+def device_guard(device):
+    """`with device_guard(t.device):` the launches inside run on t's device.  One process per GPU is the rule here, so the device
+    almost always IS the current one: then this is a shared no-op object instead of a torch.cuda.device context."""
+    idx = device.index
+    if _cur_device is not None and (idx is None or idx == _cur_device()):
+        return _NOGUARD
+    return torch.cuda.device(device)
 
 
 def ptr(t):

@@ -91,7 +91,7 @@ def subsample_augment(raw, raw_offset, n_out=POINT_NUM, aug=None, choice=None, s
     flip = ang = c = s = sc = None
     if aug is not None:
         flip, ang, c, s, sc = aug.host_arrays()
-    with torch.cuda.device(raw.device):
+    with L.device_guard(raw.device):
         L.check(L.lib().votenet_subsample_augment(b, n_out, L.ptr(raw), 1 if raw.dtype == torch.float64 else 0, raw.shape[1], _hp(off),
                                                   L.ptr(ch), int(seed) & (2 ** 64 - 1), int(scene0), 1 if depth_to_camera else 0,
                                                   _hp(flip), _hp(c), _hp(s), _hp(sc), L.ptr(out), L.stream_ptr()))
@@ -125,7 +125,7 @@ def augment_boxes(center, size, heading, cls, box_offset, aug=None, mean_size=ME
     flip = ang = c = s = sc = None
     if aug is not None:
         flip, ang, c, s, sc = aug.host_arrays()
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(L.lib().votenet_augment_boxes(b, bb, _hp(off), L.ptr(center), L.ptr(size), L.ptr(heading), L.ptr(cls), _hp(flip),
                                               _hp(ang), _hp(c), _hp(s), _hp(sc), _hp(ms), ms.shape[0], nh,
                                               *[L.ptr(out[k]) for k, _, _ in GT_FIELDS], L.stream_ptr()))

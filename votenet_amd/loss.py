@@ -36,7 +36,7 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
     flat = torch.zeros(nv + npx + npo + nws, dtype=torch.float32, device=dev)
     d_votes, d_pxyz = flat[:nv].view_as(votes), flat[nv:nv + npx].view_as(pxyz)
     d_pout, ws = flat[nv + npx:nv + npx + npo].view_as(pout), flat[nv + npx + npo:]
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(L.lib().votenet_loss(b, n, p, bb, nh, ns, nc, L.ptr(seeds), L.ptr(votes), L.ptr(pxyz), L.ptr(pout),
                                      L.ptr(gt["bboxes_xyz"]), L.ptr(gt["bboxes_lwh"]), L.ptr(gt["bboxes_roty"]),
                                      L.ptr(gt["semantic_labels"]), L.ptr(gt["heading_labels"]), L.ptr(gt["heading_residuals"]),
@@ -56,7 +56,7 @@ def decode_boxes(proposals_xyz, proposals_output, nh=NH, ns=NS, nc=NC):
     mean = torch.tensor(MEAN_SIZES, dtype=torch.float32, device=pxyz.device).contiguous()
     boxes = torch.empty((b, p, 8, 3), dtype=torch.float32, device=pxyz.device)
     scores = torch.empty((b, p), dtype=torch.float32, device=pxyz.device)
-    with torch.cuda.device(pxyz.device):
+    with L.device_guard(pxyz.device):
         L.check(L.lib().votenet_decode_boxes(b, p, nh, ns, nc, L.ptr(pxyz), L.ptr(pout), L.ptr(mean), L.ptr(boxes), L.ptr(scores),
                                              L.stream_ptr()))
     return boxes, scores

@@ -120,7 +120,7 @@ def csr_gather_sum(src2d, inv, npts, weight=None, div=1):
     """out (npts, c) = for every point the sum, in slot order, of weight[slot] * src2d[slot // div] (votenet_csr_gather_sum)."""
     c = src2d.shape[1]
     out = torch.empty((npts, c), dtype=torch.float32, device=src2d.device)
-    with torch.cuda.device(src2d.device):
+    with L.device_guard(src2d.device):
         L.check(L.lib().votenet_csr_gather_sum(npts, c, L.ptr(src2d), L.ptr(inv[0]), L.ptr(inv[1]), L.ptr(weight), div, L.ptr(out),
                                                L.stream_ptr()))
     return out
@@ -156,7 +156,7 @@ class PendingBN:
     def finalize(self):
         if not self.done:
             c = self.gamma.shape[0]
-            with torch.cuda.device(self.gamma.device):
+            with L.device_guard(self.gamma.device):
                 L.check(L.lib().votenet_bn_finalize(self.rows, c, L.ptr(self.stats), L.ptr(self.gamma), L.ptr(self.beta), float(self.eps),
                                                     L.ptr(self.out[0]), L.ptr(self.out[1]), L.ptr(self.out[2]), L.ptr(self.out[3]),
                                                     L.stream_ptr()))
@@ -220,7 +220,7 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     stats = _zeros_f64(2 * cout, x.device) if want_stats else None
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
-    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd" + ("+bn" if (in_scale is not None or in_bn is not None) else ""))):
+    with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd" + ("+bn" if (in_scale is not None or in_bn is not None) else ""))):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -243,7 +243,7 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
     stats = _zeros_f64(2 * cout, xyz.device) if want_stats else None
     d = _desc_gather(xyz, new_xyz, feat, idx)
-    with torch.cuda.device(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout, (rows, cin, cout, "gather")):
+    with L.device_guard(xyz.device), _Timed("linear_gather", 2.0 * rows * cin * cout, (rows, cin, cout, "gather")):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -264,7 +264,7 @@ def narrow_rows(xyz, new_xyz, feat, idx, want_moments=True):
     u8 = torch.empty((b * m * k, 8), dtype=torch.float32, device=xyz.device)
     # not from the per-step statistics arena: the geometry of a batch is computed one or two steps ahead of its use
     mom = torch.zeros(72, dtype=torch.float64, device=xyz.device) if want_moments else None
-    with torch.cuda.device(xyz.device):
+    with L.device_guard(xyz.device):
         L.check(L.lib().votenet_narrow_rows(b, n, m, k, c, L.ptr(xyz), L.ptr(new_xyz), L.ptr(feat), L.ptr(idx), L.ptr(u8), L.ptr(mom),
                                             L.stream_ptr()))
     return u8, mom
@@ -274,7 +274,7 @@ def narrow_z0(u8, w0, b0):
     """The first-layer output the product path never stores, with the kernels' own arithmetic (tests: the device's active set)."""
     k0, c0 = w0.shape
     z0 = torch.empty((u8.shape[0], c0), dtype=torch.float32, device=u8.device)
-    with torch.cuda.device(u8.device):
+    with L.device_guard(u8.device):
         L.check(L.lib().votenet_narrow_z0(u8.shape[0], k0, c0, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(z0), L.stream_ptr()))
     return z0
 
@@ -283,7 +283,7 @@ def narrow_stats(rows, mom, w0, b0):
     """BatchNorm statistics (2*c0 f64: sum z0, sum z0^2) of the never-stored first-layer output, from the moments."""
     k0, c0 = w0.shape
     stats = torch.empty(2 * c0, dtype=torch.float64, device=w0.device)
-    with torch.cuda.device(w0.device):
+    with L.device_guard(w0.device):
         L.check(L.lib().votenet_narrow_stats(rows, k0, c0, L.ptr(mom), L.ptr(w0), L.ptr(b0), L.ptr(stats), L.stream_ptr()))
     return stats
 
@@ -300,7 +300,7 @@ def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True):
         scale, shift = in_bn.scale, in_bn.shift
     else:
         raw = in_bn.raw()
-    with torch.cuda.device(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow")):
+    with L.device_guard(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow")):
         L.check(L.lib().votenet_narrow_linear(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
                                               ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
                                               L.ptr(bias), L.ptr(z), L.ptr(stats), L.stream_ptr()))
@@ -313,7 +313,7 @@ def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, 
     k0, c0 = w0.shape
     cout = z.shape[1]
     scr = _wgrad_scratch(None, rows, c0, cout, u8.device)
-    with torch.cuda.device(u8.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn narrow")):
+    with L.device_guard(u8.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn narrow")):
         L.check(L.lib().votenet_narrow_wgrad_bn(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(in_scale), L.ptr(in_shift),
                                                 1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
                                                 L.ptr(scr), L.stream_ptr()))
@@ -327,7 +327,7 @@ def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS)
     bsc, bsh, bme, bva, brelu = below
     out = _zeros_f64(10 * c0, z.device)
     sums, ug = out[:2 * c0], out[2 * c0:]
-    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow")):
+    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow")):
         L.check(L.lib().votenet_narrow_dgrad_bn_reduce(rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                        L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva),
                                                        eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), L.stream_ptr()))
@@ -337,7 +337,7 @@ def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS)
 def narrow_wgrad_first(mom, ug, coef, w0, b0, dw0):
     """dw0 (k0, c0) += the first layer's weight gradient from the sums alone (votenet_narrow_wgrad_first)."""
     k0, c0 = w0.shape
-    with torch.cuda.device(w0.device):
+    with L.device_guard(w0.device):
         L.check(L.lib().votenet_narrow_wgrad_first(k0, c0, L.ptr(mom), L.ptr(ug), L.ptr(coef), L.ptr(w0), L.ptr(b0), L.ptr(dw0),
                                                    L.stream_ptr()))
 
@@ -358,7 +358,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
     args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
-    with torch.cuda.device(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool")):
+    with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool")):
         L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
                                                 L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
     return z, stats, (vals[0], vals[1], args[0], args[1])
@@ -377,7 +377,7 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, 
     out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
     arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
     zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None
-    with torch.cuda.device(zmax.device):
+    with L.device_guard(zmax.device):
         L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
                                                  ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),
                                                  L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
@@ -392,7 +392,7 @@ def pool_backward_supported(cin, cout, k):
 def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EPS):
     g, c = gout.shape
     sums = _zeros_f64(2 * c, gout.device)
-    with torch.cuda.device(gout.device):
+    with L.device_guard(gout.device):
         L.check(L.lib().votenet_bn_backward_reduce_pool(g, c, L.ptr(gout), L.ptr(zsel), L.ptr(scale), L.ptr(shift), L.ptr(mean),
                                                         L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums), L.stream_ptr()))
     return sums
@@ -402,7 +402,7 @@ def pool_dgrad_prepare(w, bias, coef):
     """-> (cin + 1, cin): [W diag(C) W^T ; (B + C.b) W^T], the weights / bias of the dense part of pool_dgrad."""
     cin, cout = w.shape
     mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with L.device_guard(w.device):
         L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
     return mm
 
@@ -419,7 +419,7 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
     sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
     bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)
-    with torch.cuda.device(xz.device):
+    with L.device_guard(xz.device):
         L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
                                                    1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(xz if below is not None else None),
                                                    L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), float(eps), 1 if brelu else 0,
@@ -432,7 +432,7 @@ def gram(xz, scale_shift, relu):
     rows, c = xz.shape
     g = torch.zeros((c + 1, c), dtype=torch.float32, device=xz.device)  # [gram ; column sums (filled by pool_wgrad)]
     scr = _wgrad_scratch(None, rows, c, c, xz.device)
-    with torch.cuda.device(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
+    with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
         L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.ptr(scr), L.stream_ptr()))
     return g
 
@@ -444,7 +444,7 @@ def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, g
     scr = None
     if DETERMINISTIC:
         scr = torch.empty(L.lib().votenet_pool_wgrad_scratch_floats(rows // k, cin, cout), dtype=torch.float32, device=xz.device)
-    with torch.cuda.device(xz.device):
+    with L.device_guard(xz.device):
         L.check(L.lib().votenet_pool_wgrad_sparse(rows // k, k, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0,
                                                   L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
                                                   L.ptr(gram_buf[cin]), L.ptr(scr), L.stream_ptr()))
@@ -460,7 +460,7 @@ def group_linear(xyz, new_xyz, idx, P, w_xyz, bias=None, want_stats=True):
     rows = b * m * k
     z = torch.empty((rows, cout), dtype=torch.float32, device=xyz.device)
     stats = _zeros_f64(2 * cout, xyz.device) if want_stats else None
-    with torch.cuda.device(xyz.device):
+    with L.device_guard(xyz.device):
         L.check(L.lib().votenet_group_linear(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(P), L.ptr(w_xyz),
                                              L.ptr(bias), L.ptr(z), L.ptr(stats), L.stream_ptr()))
     return z, stats
@@ -480,13 +480,13 @@ def group_linear_backward(xyz, new_xyz, idx, pts_cnt, z, da, coef, relu, dw_xyz,
         inv = _inverse_of(idx, n)
         S = torch.empty((b, n, cout), dtype=torch.float32, device=z.device)
         scr = torch.empty(L.lib().votenet_group_linear_backward_scratch_floats(b, n, cout), dtype=torch.float32, device=z.device)
-        with torch.cuda.device(z.device):
+        with L.device_guard(z.device):
             L.check(L.lib().votenet_group_linear_backward_csr(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(inv[0]), L.ptr(inv[1]),
                                                               L.ptr(inv[2]) if len(inv) > 2 else None, L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
                                                               L.ptr(dz), L.ptr(scr), L.stream_ptr()))
         return S, dz
     S = torch.zeros((b, n, cout), dtype=torch.float32, device=z.device)
-    with torch.cuda.device(z.device):
+    with L.device_guard(z.device):
         L.check(L.lib().votenet_group_linear_backward(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                       L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
                                                       L.ptr(dz), L.stream_ptr()))
@@ -497,7 +497,7 @@ def bn_finalize(rows, stats, gamma, beta, eps=BN_EPS):
     """-> scale, shift, mean, var (each (c,) f32): scale=gamma*rsqrt(var+eps), shift=beta-mean*scale."""
     c = gamma.shape[0]
     out = torch.empty((4, c), dtype=torch.float32, device=gamma.device)
-    with torch.cuda.device(gamma.device):
+    with L.device_guard(gamma.device):
         L.check(L.lib().votenet_bn_finalize(rows, c, L.ptr(stats), L.ptr(gamma), L.ptr(beta), float(eps), L.ptr(out[0]),
                                             L.ptr(out[1]), L.ptr(out[2]), L.ptr(out[3]), L.stream_ptr()))
     return out[0], out[1], out[2], out[3]
@@ -509,7 +509,7 @@ def bn_relu_max(z, k, scale, shift, relu=True, want_argmax=False):
     groups = rows // k
     out = torch.empty((groups, c), dtype=torch.float32, device=z.device)
     arg = torch.empty((groups, c), dtype=torch.int32, device=z.device) if want_argmax else None
-    with torch.cuda.device(z.device):
+    with L.device_guard(z.device):
         L.check(L.lib().votenet_bn_relu_max(groups, k, c, L.ptr(z), L.ptr(scale), L.ptr(shift), 1 if relu else 0, L.ptr(out),
                                             L.ptr(arg), L.stream_ptr()))
     return out, arg
@@ -525,7 +525,7 @@ def bn_relu(z, scale, shift, relu=True, bn=None):
             scale, shift = bn.scale, bn.shift
         else:
             raw = bn.raw()
-    with torch.cuda.device(z.device):
+    with L.device_guard(z.device):
         L.check(L.lib().votenet_bn_relu(rows, c, L.ptr(z), L.ptr(scale), L.ptr(shift), ctypes.byref(raw) if raw is not None else None,
                                         1 if relu else 0, L.ptr(y), L.stream_ptr()))
     return y
@@ -544,7 +544,7 @@ def bn_backward_apply(z, coef, relu, da, argmax=None, k=0):
     """dz (rows,c) = A*g' + B + C*z written out (the unfused path)."""
     rows, c = z.shape
     dz = torch.empty_like(z)
-    with torch.cuda.device(z.device):
+    with L.device_guard(z.device):
         L.check(L.lib().votenet_bn_backward_apply(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(coef), 1 if relu else 0,
                                                   L.ptr(dz), L.stream_ptr()))
     return dz
@@ -554,7 +554,7 @@ def bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax=None, k=0, e
     """sums (2*c f64) = [sum g', sum g'*zhat] of a BatchNorm'ed layer (g' = ReLU / arg-max masked gradient)."""
     rows, c = z.shape
     sums = _zeros_f64(2 * c, z.device)
-    with torch.cuda.device(z.device):
+    with L.device_guard(z.device):
         L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
                                                    L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
                                                    L.stream_ptr()))
@@ -565,7 +565,7 @@ def bn_backward_coef(rows, scale, shift, mean, var, gamma, sums, dgamma, dbeta, 
     """coef (5*c) = [A|B|C|scale|shift] with dz = A*g' + B + C*z; accumulates dgamma / dbeta."""
     c = gamma.shape[0]
     coef = torch.empty(5 * c, dtype=torch.float32, device=gamma.device)
-    with torch.cuda.device(gamma.device):
+    with L.device_guard(gamma.device):
         L.check(L.lib().votenet_bn_backward_coef(rows, c, L.ptr(scale), L.ptr(shift), L.ptr(mean), L.ptr(var), float(eps),
                                                  L.ptr(gamma), L.ptr(sums), L.ptr(coef), L.ptr(dgamma), L.ptr(dbeta),
                                                  L.stream_ptr()))
@@ -583,7 +583,7 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
     cout = z.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
     scr = _wgrad_scratch(d, rows, cin, cout, x.device)
-    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad_bn")):
+    with L.device_guard(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad_bn")):
         L.check(L.lib().votenet_mlp_wgrad_bn(ctypes.byref(d), rows, cin, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z),
                                              L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
@@ -598,12 +598,12 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
     if below is not None:
         zp, bsc, bsh, bme, bva, brelu = below
         sums = _zeros_f64(2 * cout, z.device)
-        with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
+        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
             L.check(L.lib().votenet_mlp_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                         L.ptr(out), L.ptr(zp), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps,
                                                         1 if brelu else 0, L.ptr(sums), L.stream_ptr()))
         return out, sums
-    with torch.cuda.device(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
+    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))
     return out
@@ -612,7 +612,7 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
 def bias_grad(dz, dbias):
     rows, c = dz.shape
     scratch = torch.empty(c, dtype=torch.float64, device=dz.device)
-    with torch.cuda.device(dz.device):
+    with L.device_guard(dz.device):
         L.check(L.lib().votenet_bias_grad(rows, c, L.ptr(dz), L.ptr(scratch), L.ptr(dbias), L.stream_ptr()))
 
 
@@ -622,7 +622,7 @@ def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
     cout = dz.shape[1]
     d = _desc_dense(x, in_scale, in_shift, in_relu)
     scr = _wgrad_scratch(d, rows, cin, cout, x.device)
-    with torch.cuda.device(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad")):
+    with L.device_guard(x.device), _Timed("wgrad_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "wgrad")):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), rows, cin, cout, L.ptr(dz), L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
@@ -631,7 +631,7 @@ def wgrad_gather(xyz, new_xyz, feat, idx, dz, dw):
     c = feat.shape[2] if feat is not None else 0
     d = _desc_gather(xyz, new_xyz, feat, idx)
     scr = _wgrad_scratch(d, b * m * k, 3 + c, dz.shape[1], xyz.device)
-    with torch.cuda.device(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1], (b * m * k, 3 + c, dz.shape[1], "wgrad_gather")):
+    with L.device_guard(xyz.device), _Timed("wgrad_gather", 2.0 * b * m * k * (3 + c) * dz.shape[1], (b * m * k, 3 + c, dz.shape[1], "wgrad_gather")):
         L.check(L.lib().votenet_mlp_wgrad(ctypes.byref(d), b * m * k, 3 + c, dz.shape[1], L.ptr(dz), L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
@@ -639,7 +639,7 @@ def rows_dot3(dz, w3):
     """(rows, c) x (3, c)^T -> (rows, 3): the xyz columns of an input gradient, dz W[0:3]^T (votenet_rows_dot3)."""
     rows, c = dz.shape
     out = torch.empty((rows, 3), dtype=torch.float32, device=dz.device)
-    with torch.cuda.device(dz.device):
+    with L.device_guard(dz.device):
         L.check(L.lib().votenet_rows_dot3(rows, c, L.ptr(dz), L.ptr(w3), L.ptr(out), L.stream_ptr()))
     return out
 
@@ -660,7 +660,7 @@ def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
     d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if d_rows_feat is not None else None
     d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
     d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
-    with torch.cuda.device(dev):
+    with L.device_guard(dev):
         L.check(L.lib().votenet_group_concat_grad(b, n, c, m, k, L.ptr(d_rows_feat), L.ptr(d_rows_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                   L.ptr(d_feat), L.ptr(d_xyz), L.ptr(d_new), L.stream_ptr()))
     return d_feat, d_xyz, d_new
@@ -668,7 +668,7 @@ def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
 
 def clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5, beta1=0.9, beta2=0.999, eps=1e-8):
     """model.py:240-250: per-tensor clip_by_average_norm(g, 0.5) then Adam(lr) on the flat bucket."""
-    with torch.cuda.device(p.device):
+    with L.device_guard(p.device):
         L.check(L.lib().votenet_clip_adam(seg.numel() // 2, L.ptr(seg), L.ptr(sumsq), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v),
                                           float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),
                                           float(clip), L.stream_ptr()))

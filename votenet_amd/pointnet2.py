@@ -100,7 +100,7 @@ class ParamStore:
         st = stream if stream is not None else cur
         if st is not cur:
             st.wait_stream(cur)  # the optimizer's update of the parameters is on the caller's stream
-        with torch.cuda.device(self.device), torch.cuda.stream(st):
+        with M.L.device_guard(self.device), torch.cuda.stream(st):
             L_.check(L_.lib().votenet_transpose_segments(self._nseg, L_.ptr(self._ttable), L_.ptr(self.flat),
                                                          L_.ptr(self._tflat), L_.stream_ptr()))
             self.t_event = torch.cuda.Event()

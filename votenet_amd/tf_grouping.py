@@ -33,7 +33,7 @@ def query_ball_point(radius, nsample, xyz1, xyz2):
     nsample = int(nsample)
     idx = torch.empty((b, m, max(nsample, 0)), dtype=torch.int32, device=xyz1.device)
     cnt = torch.empty((b, m), dtype=torch.int32, device=xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with L.device_guard(xyz1.device):
         if PROFILE_EVENTS is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -59,7 +59,7 @@ class _GroupPoint(torch.autograd.Function):
         b, n, c = points.shape
         _, m, k = idx.shape
         out = torch.empty((b, m, k, c), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
+        with L.device_guard(points.device):
             L.check(L.lib().votenet_group_point(b, n, c, m, k, L.ptr(points), L.ptr(idx), L.ptr(out), L.stream_ptr()))
         ctx.save_for_backward(idx)
         ctx.n = n
@@ -76,7 +76,7 @@ def group_point_grad_raw(n, idx, grad_out):
     grad_out = L.dev_f32(grad_out, "GroupPointGrad expects (batch_size, npoints, nsample, channel) grad_out shape", 4)
     b, m, k, c = grad_out.shape
     g = torch.zeros((b, n, c), dtype=torch.float32, device=grad_out.device)  # tf_grouping.cpp:204
-    with torch.cuda.device(grad_out.device):
+    with L.device_guard(grad_out.device):
         L.check(L.lib().votenet_group_point_grad(b, n, c, m, k, L.ptr(grad_out), L.ptr(idx), L.ptr(g), L.stream_ptr()))
     return g
 
@@ -93,7 +93,7 @@ def select_top_k(k, dist):
     b, m, n = dist.shape
     outi = torch.empty((b, m, n), dtype=torch.int32, device=dist.device)
     out = torch.empty((b, m, n), dtype=torch.float32, device=dist.device)
-    with torch.cuda.device(dist.device):
+    with L.device_guard(dist.device):
         L.check(L.lib().votenet_selection_sort(b, n, m, int(k), L.ptr(dist), L.ptr(outi), L.ptr(out), L.stream_ptr()))
     return outi, out
 
@@ -111,6 +111,6 @@ def knn_point(k, xyz1, xyz2):
     idx = torch.empty((b, m, max(k, 0)), dtype=torch.int32, device=xyz1.device)
     nws = int(L.lib().votenet_knn_workspace_bytes(b, n, m))
     ws = torch.empty(nws, dtype=torch.uint8, device=xyz1.device) if nws else None
-    with torch.cuda.device(xyz1.device):
+    with L.device_guard(xyz1.device):
         L.check(L.lib().votenet_knn_point(b, n, m, c, k, L.ptr(xyz1), L.ptr(xyz2), L.ptr(val), L.ptr(idx), L.ptr(ws), L.stream_ptr()))
     return val, idx

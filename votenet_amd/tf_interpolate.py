@@ -17,7 +17,7 @@ def three_nn(xyz1, xyz2):
     m = xyz2.shape[1]
     dist = torch.empty((b, n, 3), dtype=torch.float32, device=xyz1.device)
     idx = torch.empty((b, n, 3), dtype=torch.int32, device=xyz1.device)
-    with torch.cuda.device(xyz1.device):
+    with L.device_guard(xyz1.device):
         L.check(L.lib().votenet_three_nn(b, n, m, L.ptr(xyz1), L.ptr(xyz2), L.ptr(dist), L.ptr(idx), L.stream_ptr()))
     return dist, idx
 
@@ -27,7 +27,7 @@ def three_nn_weights(dist):
     dist = L.dev_f32(dist.detach(), "three_nn_weights expects (b,n,3) dist shape", 3, 3)
     b, n, _ = dist.shape
     w = torch.empty_like(dist)
-    with torch.cuda.device(dist.device):
+    with L.device_guard(dist.device):
         L.check(L.lib().votenet_three_nn_weights(b, n, L.ptr(dist), L.ptr(w), L.stream_ptr()))
     return w
 
@@ -45,7 +45,7 @@ class _ThreeInterpolate(torch.autograd.Function):
         if weight.shape[0] != b or weight.shape[1] != n:
             raise L.InvalidArgumentError("ThreeInterpolate expects (b,n,3) weight shape")
         out = torch.empty((b, n, c), dtype=torch.float32, device=points.device)
-        with torch.cuda.device(points.device):
+        with L.device_guard(points.device):
             L.check(L.lib().votenet_three_interpolate(b, m, c, n, L.ptr(points), L.ptr(idx), L.ptr(weight), L.ptr(out),
                                                       L.stream_ptr()))
         ctx.save_for_backward(idx, weight)
@@ -66,7 +66,7 @@ def three_interpolate_grad_raw(m, idx, weight, grad_out):
     if M.DETERMINISTIC and c <= 256 and getattr(idx, "_inv", None) is not None:  # gather-sum over the taps' inverse index (csr.hip)
         return M.csr_gather_sum(grad_out.view(b * n, c), idx._inv, b * m, weight=weight.contiguous(), div=3).view(b, m, c)
     g = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)  # tf_interpolate.cpp:258
-    with torch.cuda.device(grad_out.device):
+    with L.device_guard(grad_out.device):
         L.check(L.lib().votenet_three_interpolate_grad(b, n, c, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g),
                                                        L.stream_ptr()))
     return g

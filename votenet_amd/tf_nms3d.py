@@ -11,7 +11,7 @@ def iou3d_matrix(bboxes):
         raise L.InvalidArgumentError("3D NMS expects (batch_size, nbbox, 8, 3) bbox shape.")
     b, n = bboxes.shape[:2]
     iou = torch.empty((b, n, n), dtype=torch.float32, device=bboxes.device)
-    with torch.cuda.device(bboxes.device):
+    with L.device_guard(bboxes.device):
         L.check(L.lib().votenet_iou3d_matrix(b, n, L.ptr(bboxes), L.ptr(iou), L.stream_ptr()))
     return iou
 
@@ -24,7 +24,7 @@ def iou3d_cross(boxes_a, boxes_b):
         raise L.InvalidArgumentError("iou3d_cross expects (batch, n, 8, 3) and (batch, m, 8, 3) boxes")
     b, n, m = a.shape[0], a.shape[1], bset.shape[1]
     iou = torch.empty((b, n, m), dtype=torch.float32, device=a.device)
-    with torch.cuda.device(a.device):
+    with L.device_guard(a.device):
         L.check(L.lib().votenet_iou3d_cross(b, n, m, L.ptr(a), L.ptr(bset), L.ptr(iou), L.stream_ptr()))
     return iou
 
@@ -52,7 +52,7 @@ def NMS3D(bboxes, scores, objectiveness, iou_threshold, padded=False):
     count = torch.zeros(1, dtype=torch.int32, device=bboxes.device)
     wbytes = L.lib().votenet_nms3d_workspace_bytes(b, n)
     ws = torch.empty(wbytes, dtype=torch.uint8, device=bboxes.device)
-    with torch.cuda.device(bboxes.device):
+    with L.device_guard(bboxes.device):
         L.check(L.lib().votenet_nms3d(b, n, L.ptr(bboxes), L.ptr(scores), L.ptr(objectiveness), float(iou_threshold),
                                       L.ptr(out), L.ptr(count), L.ptr(ws), wbytes, L.stream_ptr()))
     if padded:

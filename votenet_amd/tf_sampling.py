@@ -42,7 +42,7 @@ def spatial_index(xyz):
     x = L.dev_f32(xyz.detach(), "spatial_index expects (batch_size,num_points,3) xyz shape", 3, 3)
     b, n, _ = x.shape
     scratch = torch.empty(L.lib().votenet_spatial_index_floats(b, n), dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with L.device_guard(x.device):
         L.check(L.lib().votenet_spatial_index(b, n, L.ptr(x), L.ptr(scratch), L.stream_ptr()))
     _remember_index(xyz, scratch)
     return scratch
@@ -57,7 +57,7 @@ def farthest_point_sample(npoint, inp):
     out = torch.empty((b, max(npoint, 0)), dtype=torch.int32, device=inp.device)
     nt = L.lib().votenet_fps_temp_floats(b, n)
     temp = torch.empty(nt, dtype=torch.float32, device=inp.device) if nt else None
-    with torch.cuda.device(inp.device):
+    with L.device_guard(inp.device):
         if PROFILE_EVENTS is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -80,7 +80,7 @@ class _GatherPoint(torch.autograd.Function):
         b, n, _ = inp.shape
         m = idx.shape[1]
         out = torch.empty((b, m, 3), dtype=torch.float32, device=inp.device)
-        with torch.cuda.device(inp.device):
+        with L.device_guard(inp.device):
             L.check(L.lib().votenet_gather_point(b, n, m, L.ptr(inp), L.ptr(idx), L.ptr(out), L.stream_ptr()))
         ctx.save_for_backward(idx)
         ctx.n = n
@@ -97,7 +97,7 @@ def gather_point_grad_raw(n, idx, out_g):
     out_g = L.dev_f32(out_g, "GatherPointGradGpuOp expects (batch_size,num_result,3) out_g shape", 3, 3)
     b, m = idx.shape
     inp_g = torch.zeros((b, n, 3), dtype=torch.float32, device=out_g.device)  # tf_sampling.cpp:174
-    with torch.cuda.device(out_g.device):
+    with L.device_guard(out_g.device):
         L.check(L.lib().votenet_gather_point_grad(b, n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream_ptr()))
     return inp_g
 
@@ -118,6 +118,6 @@ def prob_sample(inp, inpr):
     m = inpr.shape[1]
     temp = torch.empty((b, n), dtype=torch.float32, device=inp.device)  # tf_sampling.cpp:83 allocate_temp
     out = torch.empty((b, m), dtype=torch.int32, device=inp.device)
-    with torch.cuda.device(inp.device):
+    with L.device_guard(inp.device):
         L.check(L.lib().votenet_prob_sample(b, n, m, L.ptr(inp), L.ptr(inpr), L.ptr(temp), L.ptr(out), L.stream_ptr()))
     return out
