@@ -343,7 +343,7 @@ int votenet_mlp_wgrad_bn(const votenet_mlp_input *in, long rows, int cin, int co
 
 /* da_prev (rows x cout) = dz (rows x c) * wT (c x cout), dz formed as above from (da | gout+argmax, zsrc,
  * coef) inside the operand loader.
- * Shapes served: rows % 128 == 0, c % 32 == 0, c <= 512, cout == 64 or cout % 128 == 0, 16-byte aligned
+ * Shapes served: rows % 128 == 0, c % 32 == 0, c <= 512, cout % 64 == 0, 16-byte aligned
  * buffers; anything else returns VOTENET_E_INVALID_ARGUMENT (use votenet_bn_backward_apply +
  * votenet_mlp_linear instead). */
 int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const float *gout, const int *argmax,

@@ -181,7 +181,7 @@ def test_fused_bn_backward_gemms_match_unfused(hiplib, dev, rows, cin, c, k):
     assert relerr(dw_ref.double(), x.double().t() @ dz.double()) < 2e-5
     wT = w.t().contiguous()
     da_ref, _ = M.linear_dense(dz, wT, want_stats=False)
-    assert M.dgrad_bn_supported(rows, c, cin) == (c % 32 == 0 and rows % 128 == 0 and (cin == 64 or cin % 128 == 0))
+    assert M.dgrad_bn_supported(rows, c, cin) == (c % 32 == 0 and rows % 128 == 0 and cin % 64 == 0)
     if not M.dgrad_bn_supported(rows, c, cin):
         from votenet_amd import _lib
         with pytest.raises(_lib.InvalidArgumentError):

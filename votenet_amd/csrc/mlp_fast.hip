@@ -1,7 +1,7 @@
 // mlp_fast.hip -- lean fp32 MFMA GEMM for the dense layers of the grouped-point MLP (gfx950).
 //
 // Same contract as mlp_linear_kernel (mlp.hip) for the case every dense VoteNet layer is in:
-//   DENSE input, cin % 32 == 0, cout % BN == 0, rows % 128 == 0, 16-byte aligned operands, cin <= 512.
+//   DENSE input, cin % 32 == 0, cout % 64 == 0, rows % 128 == 0, 16-byte aligned operands, cin <= 512.
 // Written separately so that the hot loop carries no bounds checks, no mode branches and few live
 // registers (the generic kernel needs > 220 VGPRs and spills its prefetch registers, which turns the
 // "asynchronous" global loads into synchronous ones):
@@ -630,10 +630,11 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
         hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
         return true;
     }
-    if (a.cout == 64) {
-        gx = ntiles < 2048 ? ntiles : 2048;
+    if (EPI != 2 && a.cout % 64 == 0) { // 64, and the odd multiples of 64 (320 = voting's 259 padded): 128 x 64 tiles, cout / 64 column blocks
+        const int ny = a.cout / 64;
+        gx = ntiles < 2048 / ny ? ntiles : 2048 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, 1), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
         return true;
     }
     }

@@ -253,7 +253,7 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
 def narrow_supported(rows, k0, c0, c1):
     """Shapes the narrow-first-layer kernels serve (include/votenet_hip.h): k0 = 3 + c grouped input channels, c0 / c1 = widths
     of the first / second layer."""
-    return 3 <= k0 <= 8 and rows > 0 and rows % 128 == 0 and rows < 2 ** 31 and c0 % 64 == 0 and c0 <= 128 and (c1 == 64 or c1 % 128 == 0)
+    return 3 <= k0 <= 8 and rows > 0 and rows % 128 == 0 and rows < 2 ** 31 and c0 % 64 == 0 and c0 <= 128 and (c1 % 64 == 0)
 
 
 def narrow_rows(xyz, new_xyz, feat, idx, want_moments=True):
@@ -574,7 +574,7 @@ def bn_backward_coef(rows, scale, shift, mean, var, gamma, sums, dgamma, dbeta, 
 
 def dgrad_bn_supported(rows, c, cout):
     """Shapes the fused BatchNorm-backward dgrad kernel serves (see include/votenet_hip.h)."""
-    return rows > 0 and rows % 128 == 0 and c % 32 == 0 and c <= 512 and (cout == 64 or cout % 128 == 0)
+    return rows > 0 and rows % 128 == 0 and c % 32 == 0 and c <= 512 and cout % 64 == 0
 
 
 def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, in_scale=None, in_shift=None, in_relu=True):
