@@ -175,6 +175,22 @@ typedef struct votenet_bn_raw {
     float *out;                /* 4*c floats: scale | shift | mean | var (may be NULL) */
 } votenet_bn_raw;
 
+/* Optional tail of a kernel that reduces the BatchNorm-backward sums of a layer (votenet_bn_backward_reduce(_pool),
+ * votenet_pool_dgrad_scatter, votenet_mlp_dgrad_bn_reduce, votenet_narrow_dgrad_bn_reduce): the LAST workgroup to finish
+ * (an atomic ticket) turns the completed sums into the coefficient vector, i.e. does votenet_bn_backward_coef's work --
+ * coef = [A|B|C|scale|shift] (5*c floats), dgamma += sums[c:], dbeta += sums[:c] -- so that no separate launch sits between
+ * the reduction and its consumers on the step's dependent chain.  ticket: one zero-initialised unsigned the kernel resets
+ * to zero when it is done; kernels that may run concurrently need distinct tickets.  scale / shift / mean / var / eps are
+ * the ones the reducing call already takes.  NULL: no tail (the caller launches votenet_bn_backward_coef). */
+typedef struct votenet_coef_tail {
+    unsigned *ticket;
+    long rows;          /* rows the sums run over (N of the BatchNorm) */
+    const float *gamma; /* c */
+    float *coef;        /* 5*c, written */
+    float *dgamma;      /* c, accumulated; may be NULL */
+    float *dbeta;       /* c, accumulated; may be NULL */
+} votenet_coef_tail;
+
 typedef struct votenet_mlp_input {
     /* DENSE source (rows x cin); NULL for GATHER */
     const float *x;
@@ -264,7 +280,7 @@ int votenet_pool_backward_supported(int cin, int cout, int k);
 /* sums (2c doubles, pre-zeroed) += [sum g', sum g' zhat] over the arg-max entries: g' = gout masked by the ReLU */
 int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const float *zsel, const float *scale,
                                     const float *shift, const float *mean, const float *var, float eps, int relu,
-                                    double *sums, void *stream);
+                                    double *sums, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 /* mmat (cin x cin) = W diag(C) W^T, cvec (cin) = (B + C.b) W^T; w (cin x cout), bias may be NULL */
 int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                float *cvec, void *stream);
@@ -275,7 +291,7 @@ int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const floa
                                const float *zsel, const float *coef, int relu, const float *wT, float *da,
                                const float *below_z, const float *below_scale, const float *below_shift,
                                const float *below_mean, const float *below_var, float eps, int below_relu,
-                               double *below_sums, void *stream);
+                               double *below_sums, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 /* gram (c x c, pre-zeroed or accumulating) += a^T a with a = act(z * scale + shift); scale_shift = [scale | shift] (2c) */
 /* scratch: votenet_mlp_wgrad_scratch_floats(NULL, rows, c, c) floats or NULL, as for votenet_mlp_wgrad */
 int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
@@ -307,7 +323,7 @@ int votenet_bn_relu(long rows, int c, const float *z, const float *scale, const 
  * through argmax (rows/k x c): da[g*k+argmax[g,ch], ch] = gout[g,ch], zero elsewhere (utils.py:132). */
 int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                                const float *scale, const float *shift, const float *mean, const float *var, float eps,
-                               int relu, double *sums /* 2*c, pre-zeroed */, void *stream);
+                               int relu, double *sums /* 2*c, pre-zeroed */, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                               const float *coef /* 5*c, from votenet_bn_backward_coef */, int relu,
                               float *dz /* rows x c */, void *stream);
@@ -359,7 +375,7 @@ int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da, const floa
 int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
                                 const float *wT, float *da_prev, const float *z_prev, const float *scale_prev,
                                 const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
-                                int relu_prev, double *sums, void *stream);
+                                int relu_prev, double *sums, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 
 /* ---- NARROW first layer of a set-abstraction MLP (narrow.hip): 3 + c <= 8 grouped input channels, no input gradient ----
  * sa1 of VoteNet groups the bare coordinates (model.py:39: l0_points = xyz, so [xyz[idx]-new_xyz | xyz[idx]] has 6 channels).
@@ -395,7 +411,7 @@ int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, const float *u8
 int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
                                    int relu, const float *wT, const float *u8, const float *w0, const float *b0,
                                    const float *scale0, const float *shift0, const float *mean0, const float *var0, float eps,
-                                   int relu0, double *sums, double *ug, void *stream);
+                                   int relu0, double *sums, double *ug, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 /* Weight gradient of the first layer from the sums alone (dz0 = A g + B + C z0, coef = [A|B|C|S|H] of votenet_bn_backward_coef):
  * dw0[d,c] += A[c] ug[d,c] + B[c] m[d] + C[c] (sum_e M[d,e] W0[e,c] + m[d] b0[c]),  d < k0. */
 int votenet_narrow_wgrad_first(int k0, int c0, const double *moments, const double *ug, const float *coef, const float *w0,

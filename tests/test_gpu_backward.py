@@ -392,3 +392,63 @@ def test_training_gradients_are_bit_reproducible(hiplib, dev, full):
         a2 = once()[0]
         assert not torch.equal(a1, a2)                                   # atomics: summation order varies run to run ...
         assert float((a1 - g1).abs().max()) <= 1e-3 * float(g1.abs().max())          # ... around the same gradient
+
+
+def test_coefficient_tails_equal_the_separate_launch(hiplib, dev):
+    """struct votenet_coef_tail: the last workgroup of a reducing kernel computes the BatchNorm-backward coefficient vector and
+    accumulates dgamma / dbeta.  Every producer, with the tail against votenet_bn_backward_coef launched after it
+    (mlp.COEF_TAIL = False, the default); repeated, so that a ticket left non-zero by one launch would show in the next."""
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    pos = lambda n: torch.rand(n, generator=g).to(dev) + 0.5
+
+    def both(fn, c):
+        """fn(tail) -> coef (or a tuple whose LAST tensor of 5*c floats is coef): run with and without the in-kernel tail"""
+        out = []
+        for flag in (True, False, True):
+            M.COEF_TAIL = flag
+            dg, db = torch.full((c,), 0.25, device=dev), torch.full((c,), -0.5, device=dev)
+            try:
+                coef = fn((4096, gamma[:c].contiguous(), dg, db))
+            finally:
+                M.COEF_TAIL = False
+            torch.cuda.synchronize()
+            out.append((coef, dg, db))
+        for coef, dg, db in (out[0], out[2]):
+            assert coef.shape == (5 * c,)
+            for a, b in zip((coef, dg, db), out[1]):
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-12
+
+    gamma = rnd(256) * 0.2 + 1.0
+    rows = 4096
+    for c in (128, 48, 256):  # vectorised, generic and wide column blocks of votenet_bn_backward_reduce
+        z, da = rnd(rows, c), rnd(rows, c)
+        sc, sh, mu, var = pos(c), rnd(c), rnd(c), pos(c)
+        both(lambda t: M.bn_backward_reduce(z, sc, sh, mu, var, True, da, tail=t), c)
+    c, k = 128, 64
+    z, gout = rnd(rows, c), rnd(rows // k, c)
+    sc, sh, mu, var = pos(c), rnd(c), rnd(c), pos(c)
+    argmax = torch.randint(0, k, (rows // k, c), generator=g, dtype=torch.int32).to(dev)
+    both(lambda t: M.bn_backward_reduce(z, sc, sh, mu, var, True, gout, argmax, k, tail=t), c)
+    zsel = rnd(rows // k, c)
+    both(lambda t: M.bn_backward_reduce_pool(gout, zsel, sc, sh, mu, var, True, tail=t), c)
+    # the GEMM epilogue (votenet_mlp_dgrad_bn_reduce) and the scatter pass of the Gram-form backward (votenet_pool_dgrad_scatter)
+    cin = 128
+    zb, coef1, wT = rnd(rows, cin), rnd(5 * c), rnd(c, cin) * 0.1
+    bsc, bsh, bmu, bvar = pos(cin), rnd(cin), rnd(cin), pos(cin)
+    da1 = rnd(rows, c)
+    both(lambda t: M.dgrad_bn(z, coef1, True, wT, da=da1, below=(zb, bsc, bsh, bmu, bvar, True), below_tail=t)[1], cin)
+    w = rnd(cin, 256) * 0.1
+    gout2, zsel2, coef2 = rnd(rows // k, 256), rnd(rows // k, 256), rnd(5 * 256)
+    argmax2 = torch.randint(0, k, (rows // k, 256), generator=g, dtype=torch.int32).to(dev)
+    both(lambda t: M.pool_dgrad(zb, bsc, bsh, True, w, None, w.t().contiguous(), coef2, True, gout2, argmax2, zsel2, k,
+                                below=(bsc, bsh, bmu, bvar, True), below_tail=t)[1], cin)
+    # the narrow first layer's epilogue
+    u8 = rnd(rows, 8)
+    u8[:, 6:] = 0
+    w0, b0 = rnd(6, 64) * 0.5, rnd(64) * 0.1
+    z1, coefn, wTn = rnd(rows, 64), rnd(5 * 64), rnd(64, 64) * 0.1
+    s0, h0, m0, v0 = pos(64), rnd(64), rnd(64), pos(64)
+    dan = rnd(rows, 64)
+    both(lambda t: M.narrow_dgrad_bn_reduce(z1, coefn, True, wTn, dan, u8, w0, b0, (s0, h0, m0, v0, True), tail=t)[0], 64)

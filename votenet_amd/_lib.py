@@ -62,6 +62,12 @@ class BnRaw(ctypes.Structure):
                 ("eps", ctypes.c_float), ("out", ctypes.c_void_p)]
 
 
+class CoefTail(ctypes.Structure):
+    """struct votenet_coef_tail (include/votenet_hip.h)."""
+    _fields_ = [("ticket", ctypes.c_void_p), ("rows", ctypes.c_long), ("gamma", ctypes.c_void_p), ("coef", ctypes.c_void_p),
+                ("dgamma", ctypes.c_void_p), ("dbeta", ctypes.c_void_p)]
+
+
 class MlpInput(ctypes.Structure):
     """struct votenet_mlp_input (include/votenet_hip.h)."""
     _fields_ = [("x", ctypes.c_void_p), ("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p),
@@ -79,10 +85,11 @@ _SIGS.update({
     "votenet_bn_pool_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.POINTER(BnRaw), ctypes.c_int] + [_c_f] * 3
                                 + [ctypes.c_void_p],
     "votenet_pool_backward_supported": [ctypes.c_int] * 3,
-    "votenet_bn_backward_reduce_pool": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_bn_backward_reduce_pool": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float, ctypes.c_int, _c_f,
+                                        ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_pool_dgrad_prepare": [ctypes.c_int] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_pool_dgrad_scatter": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_int] + [_c_f] * 7
-                                  + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.c_void_p],
+                                  + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_mlp_gram": [ctypes.c_long, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],
     "votenet_pool_wgrad_sparse": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int]
                                  + [_c_f] * 3 + [ctypes.c_void_p],
@@ -101,7 +108,7 @@ _SIGS.update({
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_bn_relu": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.POINTER(BnRaw), ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_bn_backward_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 7 + [ctypes.c_float, ctypes.c_int, _c_f,
-                                                                                             ctypes.c_void_p],
+                                                                                             ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_bn_backward_apply": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_bias_grad": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_mlp_wgrad": [ctypes.POINTER(MlpInput), ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
@@ -111,7 +118,7 @@ _SIGS.update({
     "votenet_mlp_dgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int]
                             + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_mlp_dgrad_bn_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 7
-                                   + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p],
+                                   + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_narrow_rows": [ctypes.c_int] * 5 + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_narrow_z0": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_narrow_stats": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
@@ -120,7 +127,7 @@ _SIGS.update({
     "votenet_narrow_wgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_int] + [_c_f] * 3
                                + [ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],
     "votenet_narrow_dgrad_bn_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 8
-                                      + [ctypes.c_float, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],
+                                      + [ctypes.c_float, ctypes.c_int, _c_f, _c_f, ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_narrow_wgrad_first": [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
     "votenet_csr_gather_sum": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],

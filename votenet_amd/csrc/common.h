@@ -48,6 +48,56 @@ __device__ __forceinline__ void bn_raw_channel(const BnRaw &r, int c, int o, boo
     }
 }
 
+// ---- BatchNorm-backward coefficients in the tail of the kernel that reduced their sums (struct votenet_coef_tail) ----
+struct CoefTail {
+    unsigned *ticket;
+    long rows;
+    const float *gamma;
+    float *coef, *dgamma, *dbeta;
+};
+inline CoefTail to_tail(const votenet_coef_tail *t)
+{
+    CoefTail r = {};
+    if (t) r = CoefTail{t->ticket, t->rows, t->gamma, t->coef, t->dgamma, t->dbeta};
+    return r;
+}
+#ifdef __HIPCC__
+// Call at the very end of a kernel, by ALL threads of every workgroup, after the workgroup's atomics on sums.  The last
+// workgroup to take a ticket computes bn_bwd_coef_kernel's result (mlp_bwd.hip) from device-scope loads of the sums.
+// Ordering without a fence: the sums are updated by device-scope atomics only, which execute at the memory side; a thread waits
+// for the acknowledgement of its own atomics (vmcnt) before the workgroup takes its ticket, so whoever draws the last ticket
+// finds every update in place.  __threadfence() would be correct too and costs 2 ms per train step: a device-scope release
+// writes the XCD's L2 back, i.e. the whole output tile the kernel has just stored.
+__device__ __forceinline__ void coef_tail(const CoefTail &t, unsigned nwg, int c, const double *sums, const float *scale,
+                                          const float *shift, const float *mean, const float *var, float eps)
+{
+    if (!t.ticket) return;
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(t.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    const double invn = 1.0 / (double)t.rows;
+    for (int col = threadIdx.x; col < c; col += blockDim.x) {
+        const double q1 = __hip_atomic_load(&sums[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double q2 = __hip_atomic_load(&sums[c + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float inv = 1.0f / sqrtf(var[col] + eps);
+        const float m1 = (float)(q1 * invn), m2 = (float)(q2 * invn);
+        const float A = t.gamma[col] * inv;
+        const float C = -A * inv * m2;
+        t.coef[col] = A;
+        t.coef[c + col] = -A * m1 - C * mean[col];
+        t.coef[2 * c + col] = C;
+        t.coef[3 * c + col] = scale[col];
+        t.coef[4 * c + col] = shift[col];
+        if (t.dgamma) t.dgamma[col] += (float)q2;
+        if (t.dbeta) t.dbeta[col] += (float)q1;
+    }
+    if (threadIdx.x == 0) *t.ticket = 0u;
+}
+#endif
+
 // ---- spatial index of a batch of clouds (fps.hip builds it, grouping.hip reads it; include/votenet_hip.h) ----
 // Points sorted by Morton cell into buckets of 64 consecutive sorted points.  One float scratch, four regions:
 //   perm    b * n ints          original index of the p-th sorted point

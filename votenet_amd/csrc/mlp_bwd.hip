@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_kernel(long rows, int
                                                                   const float *__restrict__ z, const float *__restrict__ scale,
                                                                   const float *__restrict__ shift, const float *__restrict__ mean,
                                                                   const float *__restrict__ var, float eps, int relu,
-                                                                  double *__restrict__ sums)
+                                                                  double *__restrict__ sums, CoefTail tail)
 {
     __shared__ float sh1[4][64], sh2[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -48,6 +48,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_kernel(long rows, int
         unsafeAtomicAdd(&sums[col], (double)t1);
         unsafeAtomicAdd(&sums[c + col], (double)t2);
     }
+    coef_tail(tail, gridDim.x * gridDim.y, c, sums, scale, shift, mean, var, eps);
 }
 
 // The same reduction for c % 4 == 0 (c <= 1024), 16-byte accesses: thread = one channel quad, QC = c/4 threads per row,
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_vec_kernel(long rows,
                                                                       const float *__restrict__ z, const float *__restrict__ scale,
                                                                       const float *__restrict__ shift, const float *__restrict__ mean,
                                                                       const float *__restrict__ var, float eps, int relu,
-                                                                      double *__restrict__ sums)
+                                                                      double *__restrict__ sums, CoefTail tail)
 {
     __shared__ float red[2][256][4];
     const int qc = c >> 2;             // quads per row (a divisor of 256, checked by the launcher)
@@ -106,6 +107,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_vec_kernel(long rows,
         for (int i = 0; i < rpp; i++) v += red[which][i * qc + (ch >> 2)][ch & 3];
         unsafeAtomicAdd(&sums[which * c + ch], (double)v);
     }
+    coef_tail(tail, gridDim.x, c, sums, scale, shift, mean, var, eps);
 }
 
 // max-pool mode: da'[g*k+argmax[g,col], col] = gout[g,col] * [act > 0], zero elsewhere
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(long groups, in
                                                                  const int *__restrict__ argmax, const float *__restrict__ z,
                                                                  const float *__restrict__ scale, const float *__restrict__ shift,
                                                                  const float *__restrict__ mean, const float *__restrict__ var,
-                                                                 float eps, int relu, double *__restrict__ sums)
+                                                                 float eps, int relu, double *__restrict__ sums, CoefTail tail)
 {
     __shared__ float sh1[4][64], sh2[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -139,6 +141,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(long groups, in
         unsafeAtomicAdd(&sums[col], (double)t1);
         unsafeAtomicAdd(&sums[c + col], (double)t2);
     }
+    coef_tail(tail, gridDim.x * gridDim.y, c, sums, scale, shift, mean, var, eps);
 }
 
 // plain column sums (bias gradient of a layer without BatchNorm)
@@ -649,8 +652,10 @@ using namespace votenet;
 
 extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                                           const float *scale, const float *shift, const float *mean, const float *var,
-                                          float eps, int relu, double *sums, void *stream)
+                                          float eps, int relu, double *sums, const votenet_coef_tail *tail_, void *stream)
 {
+    VN_REQUIRE(!tail_ || (tail_->ticket && tail_->gamma && tail_->coef && tail_->rows > 0), "bn_backward_reduce: incomplete coefficient tail");
+    const CoefTail tail = to_tail(tail_);
     VN_REQUIRE(rows > 0 && c > 0 && k >= 0, "bn_backward_reduce expects rows > 0, c > 0, k >= 0");
     VN_REQUIRE(da && z && scale && shift && mean && var && sums, "bn_backward_reduce: null buffer");
     hipStream_t st = as_stream(stream);
@@ -659,17 +664,17 @@ extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *
         VN_REQUIRE(argmax != nullptr && rows % k == 0, "bn_backward_reduce: pooled mode needs argmax and rows % k == 0");
         const long groups = rows / k;
         hipLaunchKernelGGL(bn_bwd_reduce_pool_kernel, dim3(grid_for(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, st, groups, k, c,
-                           da, argmax, z, scale, shift, mean, var, eps, relu, sums);
+                           da, argmax, z, scale, shift, mean, var, eps, relu, sums, tail);
     } else if (c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0 && (uintptr_t)da % 16 == 0 && (uintptr_t)z % 16 == 0 &&
                (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0 && (uintptr_t)mean % 16 == 0 && (uintptr_t)var % 16 == 0) {
         const long rpp = 256 / (c / 4);
         long gx = (rows + 32 * rpp - 1) / (32 * rpp); // >= 8 loop trips per workgroup: its 2*c atomics must amortise
         if (gx > 2048) gx = 2048;
         hipLaunchKernelGGL(bn_bwd_reduce_dense_vec_kernel, dim3((unsigned)gx), dim3(256), 0, st, rows, c, da, z, scale, shift, mean,
-                           var, eps, relu, sums);
+                           var, eps, relu, sums, tail);
     } else {
         hipLaunchKernelGGL(bn_bwd_reduce_dense_kernel, dim3(grid_for(rows, 4, 2048 / ny + 1), ny), dim3(256), 0, st, rows, c, da,
-                           z, scale, shift, mean, var, eps, relu, sums);
+                           z, scale, shift, mean, var, eps, relu, sums, tail);
     }
     return check_launch("bn_backward_reduce");
 }

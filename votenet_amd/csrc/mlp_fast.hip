@@ -77,6 +77,7 @@ struct FastArgs {
     const float *u8, *w0, *b0; // SRC 3 / EPI 4: rows x 8 floats, W0 (k0 x c0), b0 (c0, may be NULL); c0 = cin (SRC 3) or cout (EPI 4)
     int k0;
     double *ug;                // EPI 4: [8][cout] doubles
+    CoefTail tail;             // EPI 3 / 4: the layer below's coefficient vector from the completed sums (last workgroup, common.h)
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
@@ -333,7 +334,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     for (int d = 0; d < (EPI == 4 ? 8 : 1); d++)
 #pragma unroll
         for (int j = 0; j < NT; j++) ugs[d][j] = 0.0f;
-    if (my_tiles == 0) return;
+    if (my_tiles == 0) { // never with the launchers below (gridDim.x <= row tiles); a workgroup without work still takes its ticket
+        if (EPI == 3 || EPI == 4) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
+        return;
+    }
     __syncthreads(); // Sco
     // bias of this lane's columns, loaded ONCE and consumed (the empty asm) before any prefetch is in flight: a load inside
     // the per-tile epilogue -- or one still pending in the compiler's bookkeeping -- costs an s_waitcnt vmcnt(0) there,
@@ -595,6 +599,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             else unsafeAtomicAdd(&A.ug[(size_t)(which - 2) * cout + n0 + c], (double)t);
         }
     }
+    if (EPI == 3 || EPI == 4) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
 
 template <int SRC, int EPI>
@@ -732,8 +737,9 @@ extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da,
 extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
                                            const float *wT, float *da_prev, const float *z_prev, const float *scale_prev,
                                            const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
-                                           int relu_prev, double *sums, void *stream)
+                                           int relu_prev, double *sums, const votenet_coef_tail *tail, void *stream)
 {
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "mlp_dgrad_bn_reduce: incomplete coefficient tail");
     VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "mlp_dgrad_bn_reduce expects rows > 0, c > 0, cout > 0");
     VN_REQUIRE(da && zsrc && coef && wT && da_prev, "mlp_dgrad_bn_reduce: null buffer");
     VN_REQUIRE(z_prev && scale_prev && shift_prev && mean_prev && var_prev && sums, "mlp_dgrad_bn_reduce: null buffer of the layer below");
@@ -755,6 +761,7 @@ extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const flo
     a.e_eps = eps;
     a.e_relu = relu_prev;
     a.stats = sums;
+    a.tail = to_tail(tail);
     if (!fast_dispatch<1, 3>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn_reduce: shape not supported by the fused kernel (use votenet_mlp_dgrad_bn + votenet_bn_backward_reduce)");
     return check_launch("mlp_dgrad_bn_reduce");
@@ -798,8 +805,9 @@ extern "C" int votenet_narrow_linear(long rows, int k0, int c0, int cout, const 
 extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
                                               int relu, const float *wT, const float *u8, const float *w0, const float *b0,
                                               const float *scale0, const float *shift0, const float *mean0, const float *var0,
-                                              float eps, int relu0, double *sums, double *ug, void *stream)
+                                              float eps, int relu0, double *sums, double *ug, const votenet_coef_tail *tail, void *stream)
 {
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "narrow_dgrad_bn_reduce: incomplete coefficient tail");
     VN_REQUIRE(rows > 0 && c > 0 && c0 > 0 && k0 >= 3 && k0 <= 8, "narrow_dgrad_bn_reduce expects rows > 0, c > 0, c0 > 0, 3 <= k0 <= 8");
     VN_REQUIRE(da && zsrc && coef && wT && u8 && w0, "narrow_dgrad_bn_reduce: null buffer");
     VN_REQUIRE(scale0 && shift0 && mean0 && var0 && sums && ug, "narrow_dgrad_bn_reduce: null buffer of the first layer");
@@ -824,6 +832,7 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     a.e_relu = relu0;
     a.stats = sums;
     a.ug = ug;
+    a.tail = to_tail(tail);
     if (!fast_dispatch<1, 4>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_dgrad_bn_reduce");

@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
                                                                  const float *__restrict__ zsel, const float *__restrict__ scale,
                                                                  const float *__restrict__ shift, const float *__restrict__ mean,
                                                                  const float *__restrict__ var, float eps, int relu,
-                                                                 double *__restrict__ sums)
+                                                                 double *__restrict__ sums, CoefTail tail)
 {
     __shared__ float sh1[4][64], sh2[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
         unsafeAtomicAdd(&sums[col], (double)t1);
         unsafeAtomicAdd(&sums[c + col], (double)t2);
     }
+    coef_tail(tail, gridDim.x * gridDim.y, c, sums, scale, shift, mean, var, eps);
 }
 
 // mmat (cin x cin) = W diag(C) W^T ; cvec (cin) = (B + C.b) W^T.  W is cin x cout row-major; coef = [A|B|C|S|H].
@@ -107,6 +108,7 @@ struct PoolBelow {
     float eps;
     int relu;
     double *sums;
+    CoefTail tail; // that layer's coefficient vector from the completed sums, by the last workgroup (common.h)
 };
 
 template <int CIN, int COUT, int K, bool RED, int NWV = 8 /* wavefronts: 16 when W^T leaves room for one workgroup per CU only */>
@@ -257,6 +259,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
             for (int w8 = 0; w8 < NWV; w8++) t += red[w8 * 2 * CIN + e];
             unsafeAtomicAdd(&pb.sums[e], (double)t);
         }
+        coef_tail(pb.tail, gridDim.x, CIN, pb.sums, pb.scale, pb.shift, pb.mean, pb.var, pb.eps);
     }
 }
 
@@ -393,13 +396,14 @@ extern "C" int votenet_pool_backward_supported(int cin, int cout, int k)
 
 extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const float *zsel, const float *scale,
                                                const float *shift, const float *mean, const float *var, float eps, int relu,
-                                               double *sums, void *stream)
+                                               double *sums, const votenet_coef_tail *tail, void *stream)
 {
     VN_REQUIRE(groups > 0 && c > 0, "bn_backward_reduce_pool expects groups > 0, c > 0");
     VN_REQUIRE(gout && zsel && scale && shift && mean && var && sums, "bn_backward_reduce_pool: null buffer");
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "bn_backward_reduce_pool: incomplete coefficient tail");
     const int ny = (c + 63) / 64;
     hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, as_stream(stream), groups,
-                       c, gout, zsel, scale, shift, mean, var, eps, relu, sums);
+                       c, gout, zsel, scale, shift, mean, var, eps, relu, sums, to_tail(tail));
     return check_launch("bn_backward_reduce_pool");
 }
 
@@ -420,15 +424,17 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
                                           const float *zsel, const float *coef, int relu, const float *wT, float *da,
                                           const float *below_z, const float *below_scale, const float *below_shift,
                                           const float *below_mean, const float *below_var, float eps, int below_relu,
-                                          double *below_sums, void *stream)
+                                          double *below_sums, const votenet_coef_tail *below_tail, void *stream)
 {
+    VN_REQUIRE(!below_tail || (below_z && below_tail->ticket && below_tail->gamma && below_tail->coef && below_tail->rows > 0),
+               "pool_dgrad_scatter: incomplete coefficient tail");
     VN_REQUIRE(groups > 0 && gout && argmax && zsel && coef && wT && da, "pool_dgrad_scatter: bad arguments");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, k), "pool_dgrad_scatter: unsupported shape cin=%d cout=%d k=%d", cin, cout, k);
     VN_REQUIRE((uintptr_t)wT % 16 == 0, "pool_dgrad_scatter: wT must be 16-byte aligned");
     VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
                "pool_dgrad_scatter: below_z given without the layer's BatchNorm vectors / sums");
     hipStream_t st = as_stream(stream);
-    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums};
+    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail)};
     auto go = [&](auto kern, int ci, int co, int threads = 512) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);

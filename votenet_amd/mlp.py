@@ -79,6 +79,41 @@ def set_deterministic(on=True):
     return prev
 
 
+# BatchNorm-backward coefficients in the tail of the kernel that reduced their sums (struct votenet_coef_tail): the last workgroup
+# to finish does votenet_bn_backward_coef's work, so no launch sits between a reduction and its consumers on the step's
+# dependent chain (23 launches of ~5 us per train step).  Measured (tools/ab_step.py mlp.COEF_TAIL False True, same box, six
+# pairs): 6.997 -> 6.964 ms per step, 0.4 % -- the small launches overlap the dispatch of their neighbours, their summed
+# duration (0.12 ms) is not what they cost.  Off by default: the tail relies on a device-scope atomic being in place once its
+# issuing wave's vmcnt has drained, which holds in every test here but is a weaker guarantee than a kernel boundary.
+COEF_TAIL = False
+_tickets = {}
+
+
+def _coef_tail(tail, c, device):
+    """tail = (rows, gamma, dgamma, dbeta) or None -> (ctypes struct or None, coef tensor or None)."""
+    if tail is None or not COEF_TAIL:
+        return None, None
+    rows, gamma, dgamma, dbeta = tail
+    tk = _tickets.get(device)
+    if tk is None:
+        tk = _tickets[device] = [torch.zeros(64, dtype=torch.int32, device=device), 0]
+    tk[1] = (tk[1] + 1) % 64  # kernels that may overlap must not share a ticket: 64 in rotation, each reset by its kernel
+    coef = torch.empty(5 * c, dtype=torch.float32, device=device)
+    t = L.CoefTail()
+    t.ticket = tk[0].data_ptr() + 4 * tk[1]
+    t.rows = rows
+    t.gamma, t.coef = gamma.data_ptr(), coef.data_ptr()
+    t.dgamma = dgamma.data_ptr() if dgamma is not None else None
+    t.dbeta = dbeta.data_ptr() if dbeta is not None else None
+    return t, coef
+
+
+def _coef_after(tail, bn, sums, eps):
+    """The separate launch, for a reduction that ran without a tail."""
+    rows, gamma, dgamma, dbeta = tail
+    return bn_backward_coef(rows, bn[0], bn[1], bn[2], bn[3], gamma, sums, dgamma, dbeta, eps)
+
+
 def _wgrad_scratch(desc, rows, cin, cout, device):
     if not DETERMINISTIC:
         return None
@@ -319,7 +354,7 @@ def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, 
                                                 L.ptr(scr), L.stream_ptr()))
 
 
-def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS):
+def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS, tail=None):
     """The input-gradient GEMM of the second layer with nothing stored: -> sums (2*c0 f64: BatchNorm-backward sums of the first
     layer), ug (8, c0) f64 = sum_r u8[r,:]^T da0'[r,:].  below = (scale, shift, mean, var, relu) of the first layer."""
     rows, c = z.shape
@@ -327,11 +362,15 @@ def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS)
     bsc, bsh, bme, bva, brelu = below
     out = _zeros_f64(10 * c0, z.device)
     sums, ug = out[:2 * c0], out[2 * c0:]
+    t, coef0 = _coef_tail(tail, c0, z.device)
     with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow")):
         L.check(L.lib().votenet_narrow_dgrad_bn_reduce(rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                        L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva),
-                                                       eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), L.stream_ptr()))
-    return sums, ug.view(8, c0)
+                                                       eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug),
+                                                       ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if tail is None:
+        return sums, ug.view(8, c0)
+    return (coef0 if coef0 is not None else _coef_after(tail, (bsc, bsh, bme, bva), sums, eps)), ug.view(8, c0)  # tail: (coef of the first layer, ug)
 
 
 def narrow_wgrad_first(mom, ug, coef, w0, b0, dw0):
@@ -389,13 +428,19 @@ def pool_backward_supported(cin, cout, k):
     return bool(L.lib().votenet_pool_backward_supported(cin, cout, k))
 
 
-def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EPS):
+def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EPS, tail=None):
+    """sums (2*c f64) of the pooled gradient at the arg-max entries; with tail = (rows, gamma, dgamma, dbeta) the coefficient
+    vector of votenet_bn_backward_coef instead (computed in the kernel's tail)."""
     g, c = gout.shape
     sums = _zeros_f64(2 * c, gout.device)
+    t, coef = _coef_tail(tail, c, gout.device)
     with L.device_guard(gout.device):
         L.check(L.lib().votenet_bn_backward_reduce_pool(g, c, L.ptr(gout), L.ptr(zsel), L.ptr(scale), L.ptr(shift), L.ptr(mean),
-                                                        L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums), L.stream_ptr()))
-    return sums
+                                                        L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
+                                                        ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if tail is None:
+        return sums
+    return coef if coef is not None else _coef_after(tail, (scale, shift, mean, var), sums, eps)
 
 
 def pool_dgrad_prepare(w, bias, coef):
@@ -407,7 +452,8 @@ def pool_dgrad_prepare(w, bias, coef):
     return mm
 
 
-def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS, mm=None):
+def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS, mm=None,
+               below_tail=None):
     """da (rows, cin) of the pooled layer: x (W diag(C) W^T) + (B + C.b) W^T as ONE forward-type GEMM on the layer's input,
     then the cout scattered rows per group.  below = (scale, shift, mean, var, relu) of the layer that produced xz: the
     scatter pass then also reduces that layer's BatchNorm backward -> returns (da, sums).  mm: pool_dgrad_prepare's result
@@ -419,12 +465,17 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
     sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
     bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)
+    t, coef_b = _coef_tail(below_tail if below is not None else None, cin, xz.device)
     with L.device_guard(xz.device):
         L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
                                                    1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(xz if below is not None else None),
                                                    L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), float(eps), 1 if brelu else 0,
-                                                   L.ptr(sums), L.stream_ptr()))
-    return (da, sums) if below is not None else da
+                                                   L.ptr(sums), ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if below is None:
+        return da
+    if below_tail is None:
+        return da, sums
+    return da, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))  # below_tail: (da, coef of the layer below)
 
 
 def gram(xz, scale_shift, relu):
@@ -550,15 +601,19 @@ def bn_backward_apply(z, coef, relu, da, argmax=None, k=0):
     return dz
 
 
-def bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax=None, k=0, eps=BN_EPS):
-    """sums (2*c f64) = [sum g', sum g'*zhat] of a BatchNorm'ed layer (g' = ReLU / arg-max masked gradient)."""
+def bn_backward_reduce(z, scale, shift, mean, var, relu, da, argmax=None, k=0, eps=BN_EPS, tail=None):
+    """sums (2*c f64) = [sum g', sum g'*zhat] of a BatchNorm'ed layer (g' = ReLU / arg-max masked gradient); with
+    tail = (rows, gamma, dgamma, dbeta) the coefficient vector of votenet_bn_backward_coef instead (kernel tail)."""
     rows, c = z.shape
     sums = _zeros_f64(2 * c, z.device)
+    t, coef = _coef_tail(tail, c, z.device)
     with L.device_guard(z.device):
         L.check(L.lib().votenet_bn_backward_reduce(rows, c, k, L.ptr(da), L.ptr(argmax), L.ptr(z), L.ptr(scale), L.ptr(shift),
                                                    L.ptr(mean), L.ptr(var), float(eps), 1 if relu else 0, L.ptr(sums),
-                                                   L.stream_ptr()))
-    return sums
+                                                   ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if tail is None:
+        return sums
+    return coef if coef is not None else _coef_after(tail, (scale, shift, mean, var), sums, eps)
 
 
 def bn_backward_coef(rows, scale, shift, mean, var, gamma, sums, dgamma, dbeta, eps=BN_EPS):
@@ -588,7 +643,7 @@ def wgrad_dense_bn(x, z, coef, relu, dw, da=None, gout=None, argmax=None, k=0, i
                                              L.ptr(coef), 1 if relu else 0, L.ptr(dw), L.ptr(scr), L.stream_ptr()))
 
 
-def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None, eps=BN_EPS):
+def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None, eps=BN_EPS, below_tail=None):
     """da_prev = dz @ wT with dz = BatchNorm-backward(da | pooled gout, z, coef) formed in the loader.
     below = (z_prev, scale, shift, mean, var, relu) of the layer whose activation da_prev is the gradient of: the store
     epilogue then also reduces that layer's BatchNorm backward -> returns (da_prev, sums) (dense da only)."""
@@ -598,11 +653,15 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
     if below is not None:
         zp, bsc, bsh, bme, bva, brelu = below
         sums = _zeros_f64(2 * cout, z.device)
+        t, coef_b = _coef_tail(below_tail, cout, z.device)
         with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
             L.check(L.lib().votenet_mlp_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                         L.ptr(out), L.ptr(zp), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps,
-                                                        1 if brelu else 0, L.ptr(sums), L.stream_ptr()))
-        return out, sums
+                                                        1 if brelu else 0, L.ptr(sums), ctypes.byref(t) if t is not None else None,
+                                                        L.stream_ptr()))
+        if below_tail is None:
+            return out, sums
+        return out, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))  # (da_prev, coef of the layer below)
     with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))

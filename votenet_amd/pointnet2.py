@@ -382,7 +382,12 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
     dict(dz=...) (rows, cout) or dict(da=, coef=, relu=) when the fused first-layer backward kernel will form dz itself:
     SAModule.backward finishes the layer (weight gradient, point gradients)."""
     da = g
-    sums_ahead = None  # BatchNorm-backward sums of layer i already reduced by the layer above (pool_dgrad's scatter pass)
+    coef_ahead = None  # BatchNorm-backward coefficients of layer i already produced by the layer above (the reduce rides in its
+    #                    scatter pass / GEMM epilogue, the coefficient vector in that kernel's tail)
+
+    def tail_of(rec):
+        Lr = rec["layer"]
+        return (rec["rows"], Lr.p("gamma"), Lr.gp("gamma"), Lr.gp("beta"))
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
         L = r["layer"]
@@ -394,8 +399,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             # weight-gradient stream (x^T x, arg-max rows, finish) starts beside the dense GEMM that follows it
             x, aff, W, b = r["x"], r["in_affine"], L.p("W"), L.p("b")
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
-            sums = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu)
-            coef = M.bn_backward_coef(r["rows"], *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
+            coef = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu, tail=tail_of(r))
             mm = M.pool_dgrad_prepare(W, b, coef) if want_da else None
             def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da):
                 G = M.gram(x, aff[:2], r["in_relu"])
@@ -405,20 +409,20 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 return None
             below = recs[i - 1]
             if below["layer"].bn and below["z"] is x:
-                da, sums_ahead = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax,
+                da, coef_ahead = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax,
                                               zsel, k, below=(below["scale"], below["shift"], below["mean"], below["var"],
-                                                              below["layer"].relu), mm=mm)
+                                                              below["layer"].relu), mm=mm, below_tail=tail_of(below))
             else:
                 da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k, mm=mm)
             continue
         rows, c = z.shape
         if L.bn:
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
-            if sums_ahead is not None:
-                sums, sums_ahead = sums_ahead, None
+            if coef_ahead is not None:
+                coef, coef_ahead = coef_ahead, None
             else:
-                sums = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
-            coef = M.bn_backward_coef(rows, *bn, L.p("gamma"), sums, L.gp("gamma"), L.gp("beta"))
+                coef = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0,
+                                            tail=tail_of(r))
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
             if r.get("narrow"):
                 # second layer above a NARROW first layer (i == 1): both GEMMs rebuild z0 from u8; the input-gradient GEMM stores
@@ -428,10 +432,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 w0, b0 = L0.p("W"), L0.p("b")
                 on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.narrow_wgrad_bn(
                     u8, w0, b0, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W")), u8, z, coef, da)
-                sums0, ug = M.narrow_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, u8, w0, b0,
-                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu))
-                coef0 = M.bn_backward_coef(r0["rows"], r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.p("gamma"), sums0,
-                                           L0.gp("gamma"), L0.gp("beta"))
+                coef0, ug = M.narrow_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, u8, w0, b0,
+                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0))
                 M.narrow_wgrad_first(mom, ug, coef0, w0, b0, L0.gp("W"))
                 return None  # a leaf: nothing upstream takes a gradient
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
@@ -445,8 +447,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 below = recs[i - 1] if i > 0 else None
                 if FUSE_BN_REDUCE and not pooled and below is not None and below["layer"].bn and below["z"] is r["x"]:
                     # the layer below's BatchNorm-backward sums come out of this GEMM's store epilogue
-                    da, sums_ahead = M.dgrad_bn(z, coef, L.relu, L.wT(), da=da, below=(
-                        below["z"], below["scale"], below["shift"], below["mean"], below["var"], below["layer"].relu))
+                    da, coef_ahead = M.dgrad_bn(z, coef, L.relu, L.wT(), da=da, below=(
+                        below["z"], below["scale"], below["shift"], below["mean"], below["var"], below["layer"].relu),
+                        below_tail=tail_of(below))
                 else:
                     da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
                 continue
