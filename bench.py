@@ -202,6 +202,7 @@ def main():
     tf_sampling.PROFILE_EVENTS = []
     tf_grouping.PROFILE_EVENTS = []
     vmlp.PROFILE_EVENTS = []
+    vmlp.PROFILE_SHAPES = True  # entries carry (rows, cin, cout, note): the per-family table of roofline_mlp
     events, bq_events, gemm_events = [], [], []
     gc.collect()
     gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
@@ -348,7 +349,7 @@ def main():
             # in use is the UNION of the launch intervals, not their sum.  All events are placed on one time axis by
             # their distance from the first one.
             base = gemm_events[0][0]
-            iv = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for (e0, e1, _, _) in gemm_events)
+            iv = sorted((base.elapsed_time(e0), base.elapsed_time(e1)) for (e0, e1, *_r) in gemm_events)
             tot_ms, cur_s, cur_e = 0.0, iv[0][0], iv[0][1]
             for a, b in iv[1:]:
                 if a > cur_e:
@@ -358,7 +359,7 @@ def main():
                     cur_e = max(cur_e, b)
             tot_ms += cur_e - cur_s
             sum_ms = sum(b - a for a, b in iv)
-            tot_fl = sum(f for (_, _, _, f) in gemm_events)
+            tot_fl = sum(ev[3] for ev in gemm_events)
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             mfma = {"bound": "mfma", "kernel": "mlp_linear_fast_kernel / mlp_linear_kernel / mlp_wgrad_fast_kernel (all %d GEMM launches of "
                                                "the first two timed steps, fp32 in / fp32 accumulate; executed flops / union of the "
@@ -366,6 +367,20 @@ def main():
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                     "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gemm_ms_per_step_summed": round(sum_ms / gemm_steps, 3),
                     "gflop_per_step": round(tot_fl / gemm_steps / 1e9, 1)}
+            # the same launches by family (the note of mlp._Timed: forward with the pooling epilogue, forward with statistics, fused
+            # BatchNorm-backward input-gradient GEMM with the reduce of the layer below, weight gradients, ...): executed flops / the
+            # SUM of the family's launch durations inside the step (other streams run beside them)
+            fam = {}
+            for ev in gemm_events:
+                note = ev[4][3] if len(ev) > 4 and ev[4] else ev[2]
+                f = fam.setdefault(note, [0.0, 0.0, 0])
+                f[0] += ev[3]
+                f[1] += ev[0].elapsed_time(ev[1])
+                f[2] += 1
+            mfma["by_family"] = {k: {"launches_per_step": round(v[2] / gemm_steps, 1), "gflop_per_step": round(v[0] / gemm_steps / 1e9, 1),
+                                     "ms_per_step": round(v[1] / gemm_steps, 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1),
+                                     "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 3)}
+                                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:6]}
             if workload == "train" and B == 8 and n == 20480:
                 # SURVEY.md 8(d)'s ALGORITHMIC figure for the grouped MLP: flops = 2 rows sum(C_in C_out) of the reference's
                 # formulation (conv over the materialised grouped tensor): 186.0 GFLOP forward at B = 8, backward = 2 x forward.
