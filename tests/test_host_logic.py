@@ -1,0 +1,62 @@
+"""CPU: host-side decisions of the layer stack that need no device -- which SA module takes the narrow-first-layer form
+(csrc/narrow.hip), which layers run on padded copies, what the fused kernels accept."""
+import numpy as np
+import torch
+
+
+def test_narrow_first_layer_eligibility():
+    from votenet_amd import mlp as M
+    from votenet_amd import pointnet2 as P
+    dev = torch.device("cpu")
+    s = P.ParamStore(dev)
+    sa1 = P.SAModule(s, "sa1", 2048, 0.2, 64, 3, [64, 64, 128], leaf=True)      # VoteNet's sa1: 6 grouped channels, no input gradient
+    sa2 = P.SAModule(s, "sa2", 1024, 0.4, 64, 128, [128, 128, 256])            # 131 grouped channels
+    two = P.SAModule(s, "two", 2048, 0.2, 64, 3, [64, 128], leaf=True)           # second layer is the pooled one: no room for the form
+    inner = P.SAModule(s, "in", 2048, 0.2, 64, 3, [64, 64, 128])                 # same shapes, but its input takes a gradient
+    rows = 8 * 2048 * 64
+    assert sa1.narrow(rows) and not sa2.narrow(rows) and not two.narrow(rows) and not inner.narrow(rows)
+    assert not sa1.narrow(rows + 1)  # whole 128-row tiles only
+    old = P.NARROW_FIRST
+    P.NARROW_FIRST = False
+    try:
+        assert not sa1.narrow(rows)
+    finally:
+        P.NARROW_FIRST = old
+    assert M.narrow_supported(1024, 3, 64, 64) and M.narrow_supported(1024, 8, 128, 320)
+    assert not M.narrow_supported(1024, 2, 64, 64) and not M.narrow_supported(1024, 6, 256, 64) and not M.narrow_supported(1024, 6, 64, 96)
+
+
+def test_ragged_plain_layers_get_padded_copies():
+    from votenet_amd import pointnet2 as P
+    s = P.ParamStore(torch.device("cpu"))
+    voting = P.make_mlp(s, "voting", 259, [256, 256, 259], "fc", last_plain=True)
+    post = P.make_mlp(s, "post", 128, [128, 128, 79], "conv_post_", last_plain=True)
+    assert [L.cout_pad for L in voting] == [0, 0, 320] and [L.cout_pad for L in post] == [0, 0, 128]
+    assert [(L.bn, L.relu) for L in voting] == [(True, True), (True, True), (False, False)]
+
+
+def test_fused_kernel_shape_predicates():
+    from votenet_amd import mlp as M
+    assert M.dgrad_bn_supported(1024, 128, 320) and M.dgrad_bn_supported(128, 512, 64)
+    assert not M.dgrad_bn_supported(1000, 128, 128) and not M.dgrad_bn_supported(1024, 48, 128) and not M.dgrad_bn_supported(1024, 128, 96)
+    assert M.linear_pool_supported(8192, 128, 256, 64) and not M.linear_pool_supported(8192, 128, 256, 32)
+    assert M.group_linear_backward_supported(128, 64) and not M.group_linear_backward_supported(96, 64)
+
+
+def test_narrow_statistics_algebra():
+    """What votenet_narrow_stats / votenet_narrow_wgrad_first compute, in numpy: BatchNorm sums of z0 = u W0 + b0 and the first
+    layer's weight gradient follow from the moments of u alone (the identity the never-stored layer rests on)."""
+    rng = np.random.default_rng(3)
+    n, k0, c0 = 5000, 6, 16
+    u = rng.normal(size=(n, k0)) + np.array([0, 0, 0, 2.0, -1.0, 0.5])
+    w0, b0 = rng.normal(size=(k0, c0)), rng.normal(size=c0)
+    z0 = u @ w0 + b0
+    m, M2 = u.sum(0), u.T @ u
+    s1 = m @ w0 + n * b0
+    s2 = np.einsum("dc,de,ec->c", w0, M2, w0) + 2 * b0 * (m @ w0) + n * b0 * b0
+    assert np.allclose(s1, z0.sum(0), rtol=1e-12) and np.allclose(s2, (z0 * z0).sum(0), rtol=1e-12)
+    A, B, C = rng.normal(size=c0), rng.normal(size=c0), rng.normal(size=c0)
+    g = rng.normal(size=(n, c0)) * (rng.random(size=(n, c0)) > 0.4)
+    dz0 = A * g + B + C * z0
+    dw0 = A * (u.T @ g) + np.outer(m, B) + C * (M2 @ w0 + np.outer(m, b0))
+    assert np.allclose(dw0, u.T @ dz0, rtol=1e-10, atol=1e-9)

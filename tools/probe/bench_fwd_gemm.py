@@ -10,7 +10,10 @@ if v:
 from votenet_amd import mlp as M
 from bench_legs import gpu_ms
 dev = torch.device("cuda:0")
-print("variant", v or "in-tree")
+cap22, cap41 = int(os.environ.get("CAP22", "0")), int(os.environ.get("CAP41", "0"))
+if cap22 or cap41:
+    L.lib().votenet_debug_fast_workgroups(cap22, cap41)
+print("variant", v or "in-tree", "caps", cap22, cap41)
 tot = 0.0
 for rows, c, cout, pool in ((1048576, 64, 64, 0), (1048576, 64, 128, 64), (524288, 128, 128, 0), (524288, 128, 256, 64), (262144, 128, 128, 0),
                             (262144, 128, 256, 64), (131072, 128, 128, 0), (131072, 128, 256, 64), (8192, 256, 256, 0), (8192, 512, 256, 0)):

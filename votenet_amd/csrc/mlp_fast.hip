@@ -602,6 +602,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     if (EPI == 3 || EPI == 4) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
 
+int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
+
 template <int SRC, int EPI>
 static bool fast_dispatch(const FastArgs &a, hipStream_t st)
 {
@@ -616,7 +618,7 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
     if constexpr (EPI == 4) { // 128 x 64 tiles only: the epilogue's per-column constants and the u rows fit the registers of that shape
         if (a.cout % 64 != 0) return false;
         const int ny = a.cout / 64;
-        gx = ntiles < 2048 / ny ? ntiles : 2048 / ny;
+        gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
         hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
         return true;
     } else {
@@ -630,14 +632,14 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
     }
     if (a.cout % 128 == 0) {
         const int ny = a.cout / 128;
-        gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
+        gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false; // a tile jump must be a whole number of groups
         hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
         return true;
     }
     if (EPI != 2 && a.cout % 64 == 0) { // 64, and the odd multiples of 64 (320 = voting's 259 padded): 128 x 64 tiles, cout / 64 column blocks
         const int ny = a.cout / 64;
-        gx = ntiles < 2048 / ny ? ntiles : 2048 / ny;
+        gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
         hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
         return true;
@@ -692,7 +694,7 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
     if (!aligned || cin % (2 * FG_BK) != 0 || cin > 512 || rows % FG_BM != 0 || rows == 0 || cout % 128 != 0) return false;
     const long ntiles = rows / FG_BM;
     const int ny = cout / 128;
-    const long gx = ntiles < 1024 / ny ? ntiles : 1024 / ny;
+    const long gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
     hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
     return true;
 }
@@ -836,4 +838,10 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     if (!fast_dispatch<1, 4>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_dgrad_bn_reduce");
+}
+
+extern "C" void votenet_debug_fast_workgroups(int cap22, int cap41) // tuning hook: 0 keeps a value
+{
+    if (cap22 > 0) votenet::g_fast_cap22 = cap22;
+    if (cap41 > 0) votenet::g_fast_cap41 = cap41;
 }
