@@ -377,6 +377,45 @@ int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const float *da, con
                                 const float *shift_prev, const float *mean_prev, const float *var_prev, float eps,
                                 int relu_prev, double *sums, const votenet_coef_tail *tail /* may be NULL */, void *stream);
 
+/* ---- first SA layer ASSEMBLED inside its consumers (assemble.hip): z0 = P[idx] + dxyz . W[0:3] is never stored ----
+ * With the linear map before the grouping (votenet_group_linear) z0[r,:] = P[prow(r),:] + dxyz(r) . wx is a gather of a per-point
+ * row (P = feat . W[3:] + b, points x c0, L2 resident) plus three multiply-adds per channel; instead of writing it (rows x c0) and
+ * reading it back, the consumers rebuild its elements from geo[r] = (dx, dy, dz, bits(prow)), 16 bytes per grouped row.
+ * votenet_assemble_rows writes geo (rows x 4 floats; prow = scene*n + idx) and ADDS, when given, cntv (b*n x 4 64-bit integers,
+ * pre-zeroed: per point the number of rows that gather it and the sum of their dxyz in fixed point 2^-32 -- integer atomics, so the
+ * sums do not depend on the order of the additions) and moments (9 doubles, pre-zeroed:
+ * sum dx, dy, dz, then xx, xy, xz, yy, yz, zz).  Coordinates only.
+ * votenet_assemble_stats ADDS the BatchNorm statistics of z0 (2*c0 doubles, pre-zeroed: sum z0, sum z0^2) from one pass over
+ * the points (see assemble.hip); exact sums of exact products -- they agree with sums over the fp32 z0 to fp32 rounding.
+ * votenet_assemble_z0 writes z0 after all (tests: the device's own arithmetic). */
+int votenet_assemble_rows(int b, int n, int m, int nsample, const float *xyz, const float *new_xyz, const int *idx,
+                          const int *pts_cnt /* (b,m) or NULL: the padding slots k >= pts_cnt repeat slot 0 and are added by it */,
+                          float *geo, long long *cntv /* may be NULL */, double *moments /* may be NULL */, void *stream);
+int votenet_assemble_stats(long npts, int c0, const float *P, const long long *cntv, const float *wx, const double *moments,
+                           double *stats, void *stream);
+int votenet_assemble_z0(long rows, int c0, const float *geo, const float *P, const float *wx, float *z0, void *stream);
+/* Second layer: z (rows x cout) = relu(bn0(z0)) w + bias with z0 rebuilt in the GEMM's operand loader, bn0 from in_bn (raw
+ * statistics) or in_scale / in_shift; stats as votenet_mlp_linear.  Served: rows % 128 == 0, c0 % 32 == 0, c0 <= 512,
+ * cout % 64 == 0, 16-byte aligned buffers. */
+int votenet_assembled_linear(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
+                             const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias,
+                             float *z, double *stats, void *stream);
+
+/* Backward of the second layer over an ASSEMBLED first layer, and of the first layer itself (z0 rebuilt, never read):
+ * votenet_assembled_wgrad_bn = votenet_mlp_wgrad_bn with x = relu(z0*in_scale+in_shift); votenet_assembled_dgrad_bn_reduce =
+ * votenet_mlp_dgrad_bn_reduce with z_prev = z0 (P: points x cout with points*cout*4 < 2^32); votenet_group_linear_backward_assembled
+ * = votenet_group_linear_backward with z = z0. */
+int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
+                               const float *in_shift, int in_relu, const float *da, const float *z, const float *coef, int relu,
+                               float *dw, float *scratch, void *stream);
+int votenet_assembled_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                      const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
+                                      const float *scale_prev, const float *shift_prev, const float *mean_prev, const float *var_prev,
+                                      float eps, int relu_prev, double *sums, const votenet_coef_tail *tail /* may be NULL */, void *stream);
+int votenet_group_linear_backward_assembled(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                            const int *idx, const int *pts_cnt, const float *P, const float *wx, const float *da,
+                                            const float *coef, int relu, float *s_points, float *dw_xyz, float *dz_out, void *stream);
+
 /* ---- NARROW first layer of a set-abstraction MLP (narrow.hip): 3 + c <= 8 grouped input channels, no input gradient ----
  * sa1 of VoteNet groups the bare coordinates (model.py:39: l0_points = xyz, so [xyz[idx]-new_xyz | xyz[idx]] has 6 channels).
  * The first layer's output z0 = u W0 + b0 is then a function of eight floats per grouped row and is never stored: the kernels

@@ -119,6 +119,16 @@ _SIGS.update({
                             + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_mlp_dgrad_bn_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 7
                                    + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(CoefTail), ctypes.c_void_p],
+    "votenet_assemble_rows": [ctypes.c_int] * 4 + [_c_f] * 7 + [ctypes.c_void_p],
+    "votenet_assemble_stats": [ctypes.c_long, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_assemble_z0": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_assembled_linear": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), ctypes.c_int]
+                                + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_assembled_wgrad_bn": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int, _c_f, _c_f,
+                                   ctypes.c_void_p],
+    "votenet_assembled_dgrad_bn_reduce": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 9
+                                         + [ctypes.c_float, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(CoefTail), ctypes.c_void_p],
+    "votenet_group_linear_backward_assembled": [ctypes.c_int] * 5 + [_c_f] * 8 + [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_narrow_rows": [ctypes.c_int] * 5 + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_narrow_z0": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_narrow_stats": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],

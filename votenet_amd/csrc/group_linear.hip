@@ -8,7 +8,7 @@
 // This kernel is the HBM-bound part: one 16-byte-vectorised gather of P rows (the P table of a scene is L2 resident),
 // three FMAs per output, one streaming write of z, and the per-channel BatchNorm statistics (sum z, sum z^2) of the layer.
 // Rounding differs from the k-ordered chain of the fused GEMM by the summation order only (xyz terms added last).
-#include "common.h"
+#include "mlp_types.h"
 
 namespace votenet {
 
@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(long groups, int 
                                                                const int *__restrict__ idx, const int *__restrict__ pts_cnt,
                                                                const float *__restrict__ z, const float *__restrict__ da,
                                                                const float *__restrict__ coef, int relu, float *__restrict__ spt,
-                                                               float *__restrict__ dw_xyz, float *__restrict__ dz_out)
+                                                               float *__restrict__ dw_xyz, float *__restrict__ dz_out,
+                                                               const float *__restrict__ ptab, const float *__restrict__ wx)
 {
     constexpr int KMAX = 128; // nsample <= 128 (launcher)
     __shared__ int s_idx[GPB][KMAX];
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(long groups, int 
     const int ch = tid % cout, gl = tid / cout; // channel, group lane inside the pass
     const float kA = coef[ch], kB = coef[cout + ch], kC = coef[2 * cout + ch], kS = coef[3 * cout + ch], kH = coef[4 * cout + ch];
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    // z == NULL: the layer output was never stored (assemble.hip): rebuilt per element from the per-point table and the dxyz staged below
+    const float wx0 = ptab ? wx[ch] : 0.f, wx1 = ptab ? wx[cout + ch] : 0.f, wx2 = ptab ? wx[2 * cout + ch] : 0.f;
     for (long g0 = (long)blockIdx.x * GPB; g0 < groups; g0 += (long)gridDim.x * GPB) {
         __syncthreads(); // previous pass's LDS fully consumed
         // stage idx and dxyz of the pass's groups: GPB * nsample rows over 256 threads
@@ -163,13 +166,17 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(long groups, int 
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int k = k0 + u < nsample ? k0 + u : nsample - 1;
-                    zz[u] = z[(row0 + k) * cout + ch];
+                    if (ptab)
+                        zz[u] = ptab[((size_t)(g / groups_per_scene) * n + s_idx[gl][k]) * cout + ch];
+                    else
+                        zz[u] = z[(row0 + k) * cout + ch];
                     gg[u] = da[(row0 + k) * cout + ch];
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const int k = k0 + u;
                     if (k < nsample) {
+                        if (ptab) zz[u] = assembled_z(zz[u], make_float4(s_dx[gl][k][0], s_dx[gl][k][1], s_dx[gl][k][2], 0.f), wx0, wx1, wx2);
                         float gq = gg[u];
                         if (relu && !(zz[u] * kS + kH > 0.0f)) gq = 0.0f;
                         const float d = kA * gq + kB + kC * zz[u];
@@ -203,27 +210,47 @@ __global__ __launch_bounds__(256) void group_linear_bwd_kernel(long groups, int 
 
 } // namespace votenet
 
-extern "C" int votenet_group_linear_backward(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
-                                             const int *idx, const int *pts_cnt, const float *z, const float *da, const float *coef,
-                                             int relu, float *s_points, float *dw_xyz, float *dz_out, void *stream)
+static int group_linear_backward_impl(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                      const int *idx, const int *pts_cnt, const float *z, const float *da, const float *coef,
+                                      int relu, float *s_points, float *dw_xyz, float *dz_out, const float *ptab, const float *wx,
+                                      void *stream)
 {
     VN_REQUIRE(b >= 0 && n > 0 && m >= 0 && nsample > 0 && cout > 0, "group_linear_backward: bad shape");
     VN_REQUIRE(nsample <= 128, "group_linear_backward expects nsample <= 128");
     VN_REQUIRE(cout == 32 || cout == 64 || cout == 128 || cout == 256, "group_linear_backward expects cout in {32, 64, 128, 256}");
     const long groups = (long)b * m;
     if (groups == 0) return VOTENET_OK;
-    VN_REQUIRE(xyz && new_xyz && idx && z && da && coef && s_points && dw_xyz, "group_linear_backward: null buffer");
+    VN_REQUIRE(xyz && new_xyz && idx && (z || (ptab && wx)) && da && coef && s_points && dw_xyz, "group_linear_backward: null buffer");
     hipStream_t st = as_stream(stream);
     const int gpb = 256 / cout;
     long gx = (groups + gpb - 1) / gpb;
     if (gx > 2048) gx = 2048;
 #define GLB_LAUNCH(G)                                                                                                             \
     hipLaunchKernelGGL(group_linear_bwd_kernel<G>, dim3((unsigned)gx), dim3(256), 0, st, groups, n, m, nsample, cout, xyz, new_xyz, \
-                       idx, pts_cnt, z, da, coef, relu, s_points, dw_xyz, dz_out)
+                       idx, pts_cnt, z, da, coef, relu, s_points, dw_xyz, dz_out, ptab, wx)
     if (gpb == 8) GLB_LAUNCH(8);
     else if (gpb == 4) GLB_LAUNCH(4);
     else if (gpb == 2) GLB_LAUNCH(2);
     else GLB_LAUNCH(1);
 #undef GLB_LAUNCH
     return check_launch("group_linear_backward");
+}
+
+extern "C" int votenet_group_linear_backward(int b, int n, int m, int nsample, int cout, const float *xyz, const float *new_xyz,
+                                             const int *idx, const int *pts_cnt, const float *z, const float *da, const float *coef,
+                                             int relu, float *s_points, float *dw_xyz, float *dz_out, void *stream)
+{
+    return group_linear_backward_impl(b, n, m, nsample, cout, xyz, new_xyz, idx, pts_cnt, z, da, coef, relu, s_points, dw_xyz, dz_out,
+                                      nullptr, nullptr, stream);
+}
+
+// The same pass for a layer whose output was never stored (assemble.hip): z is rebuilt from P (b*n x cout, bias included) and wx.
+extern "C" int votenet_group_linear_backward_assembled(int b, int n, int m, int nsample, int cout, const float *xyz,
+                                                       const float *new_xyz, const int *idx, const int *pts_cnt, const float *P,
+                                                       const float *wx, const float *da, const float *coef, int relu,
+                                                       float *s_points, float *dw_xyz, float *dz_out, void *stream)
+{
+    VN_REQUIRE(P && wx, "group_linear_backward_assembled: null buffer");
+    return group_linear_backward_impl(b, n, m, nsample, cout, xyz, new_xyz, idx, pts_cnt, nullptr, da, coef, relu, s_points, dw_xyz,
+                                      dz_out, P, wx, stream);
 }

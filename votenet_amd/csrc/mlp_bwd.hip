@@ -961,6 +961,27 @@ extern "C" int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, cons
     return check_launch("narrow_wgrad_bn");
 }
 
+// Weight gradient of the SECOND layer of a chain whose first layer is ASSEMBLED (assemble.hip): dw (c0 x cout) += act(z0)^T dz1 with
+// z0[r,:] = P[prow(r),:] + dxyz(r) . wx rebuilt in the loader (act = relu(z0*in_scale+in_shift)), dz1 from (da, z, coef).
+extern "C" int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
+                                          const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
+                                          const float *coef, int relu, float *dw, float *scratch, void *stream)
+{
+    VN_REQUIRE(rows > 0 && rows < (1L << 31) && c0 > 0 && cout > 0, "assembled_wgrad_bn: bad shape");
+    VN_REQUIRE(geo && P && wx && in_scale && in_shift && da && z && coef && dw, "assembled_wgrad_bn: null buffer");
+    MlpIn d = {};
+    d.in_scale = in_scale;
+    d.in_shift = in_shift;
+    d.in_relu = in_relu;
+    d.geo = geo;
+    d.ptab = P;
+    d.wx = wx;
+    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0};
+    if (!wgrad_fast_launch(3, d, rows, c0, cout, nullptr, bs, 1, dw, as_stream(stream), scratch))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_wgrad_bn: shape not served (c0 %% 64 == 0, cout %% 64 == 0, 16-byte aligned buffers)");
+    return check_launch("assembled_wgrad_bn");
+}
+
 // coefficient vector [A | B | C | scale | shift] (5*c floats) of the folded BatchNorm backward, from the reductions
 // sums = [sum g', sum g'*zhat]; also dgamma += sums[c:], dbeta += sums[:c] (each may be NULL)
 extern "C" int votenet_bn_backward_coef(long rows, int c, const float *scale, const float *shift, const float *mean,

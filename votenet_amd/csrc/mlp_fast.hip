@@ -41,6 +41,10 @@ constexpr int FG_LDA = FG_BM + 2;
 //   SRC 3: x = z0 of a NARROW first layer (narrow.hip), rebuilt per element from the row's eight floats u8[r] with narrow_z
 //          (W0: k0 x cin, b0), then relu(x*in_scale+in_shift) as SRC 0: the loader reads 32 bytes per row and slab from L2
 //          instead of 64 bytes of z0 from HBM, and z0 is never stored                                 (cin <= 128)
+//   SRC 4: x = z0 of a first SA layer ASSEMBLED here (assemble.hip): P[prow(r), k] + dxyz(r) . Wx[:, k] from the row's geo record
+//          (16 bytes: dx, dy, dz, bits(prow)) and a gather of the L2-resident per-point table P; then the folded BatchNorm +
+//          ReLU as SRC 0.  The geo of a slab is loaded one refill BEFORE the P rows that need it and ahead of that refill's other
+//          loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.          (cin <= 512)
 // EPI selects the statistics accumulated next to the store of the output z (rows x cout):
 //   EPI 0: sum z, sum z^2                      (BatchNorm statistics of a forward layer)
 //   EPI 1: no statistics (input-gradient GEMMs)
@@ -52,6 +56,9 @@ constexpr int FG_LDA = FG_BM + 2;
 //          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
 //          group (+ arg rows) and votenet_bn_pool_finalize picks by the sign of the scale.  A wave's 2 x 32 rows
 //          are exactly one group (2x2 variant, WM = 2, MT = 2).
+//   EPI 6: EPI 3 for an ASSEMBLED layer below (assemble.hip): z_prev[r,c] = P[prow(r),c] + dxyz(r) . wx[:,c] is rebuilt per element
+//          from the tile's geo records (staged in LDS by the loader) and a gather of the per-point table P through a buffer
+//          descriptor (lane offset prow * pitch + column); da is stored as in EPI 3
 //   EPI 4: EPI 3 for a narrow layer below: z_prev is rebuilt from u8 (staged per tile in LDS by the loader), the epilogue also
 //          accumulates UG[d,c] = sum_r u[r,d] da'[r,c] (the data term of that layer's weight gradient) and stores NOTHING
 //          (cout <= 128: the layer below's width)
@@ -74,6 +81,7 @@ struct FastArgs {
     const float *ez, *e_scale, *e_shift, *e_mean, *e_var; // EPI 3: z (rows x cout) and BatchNorm of the layer below
     float e_eps;
     int e_relu;
+    const float *geo, *ptab, *wx; // SRC 4: geo (rows x 4 floats), P (points x cin), Wx (3 x cin)
     const float *u8, *w0, *b0; // SRC 3 / EPI 4: rows x 8 floats, W0 (k0 x c0), b0 (c0, may be NULL); c0 = cin (SRC 3) or cout (EPI 4)
     int k0;
     double *ug;                // EPI 4: [8][cout] doubles
@@ -84,7 +92,7 @@ struct FastArgs {
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
 template <int WM, int WN, int MT, int NT, int SRC, int EPI>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? EPI3_WAVES : (EPI == 0 || EPI == 2) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 || EPI == 6) ? EPI3_WAVES : (EPI == 0 || EPI == 2) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
@@ -93,10 +101,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     __shared__ float As[2][FG_BK][FG_LDA];
     __shared__ float Bs[2][FG_BK][LDB];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
-    __shared__ float Eco[(EPI == 3 || EPI == 4) ? 4 : 1][(EPI == 3 || EPI == 4) ? BN : 1]; // EPI 3/4: scale, shift, mean, 1/std of this column block
+    constexpr bool REDUCE_BELOW = (EPI == 3 || EPI == 4 || EPI == 6);
+    __shared__ float Eco[REDUCE_BELOW ? 4 : 1][REDUCE_BELOW ? BN : 1]; // EPI 3/4/6: scale, shift, mean, 1/std of this column block
     constexpr bool NARROW = (SRC == 3 || EPI == 4);
     __shared__ __attribute__((aligned(16))) float W0s[NARROW ? 9 : 1][NARROW ? 128 : 1]; // W0 rows 0..7 (zero padded) and b0: SRC 3 by input channel, EPI 4 by column of this block
-    __shared__ __attribute__((aligned(16))) float Us[EPI == 4 ? 2 : 1][EPI == 4 ? FG_BM : 1][8]; // EPI 4: u rows of the tile, double-buffered by tile parity
+    __shared__ __attribute__((aligned(16))) float Wxs[SRC == 4 ? 3 : 1][SRC == 4 ? 512 : 1];             // SRC 4: W[0:3] by input channel
+    __shared__ __attribute__((aligned(16))) float Us[EPI == 4 ? 2 : 1][EPI == 4 ? FG_BM : 1][8];
+    __shared__ __attribute__((aligned(16))) float4 Gs[EPI == 6 ? 2 : 1][EPI == 6 ? FG_BM : 1]; // EPI 6: geo rows of the tile, by tile parity // EPI 4: u rows of the tile, double-buffered by tile parity
 
     const long rows = A.rows;
     const int cin = A.cin, cout = A.cout;
@@ -108,7 +119,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     const int n0 = blockIdx.y * BN;
     const int nk = cin / FG_BK;
     const long ntiles = rows / FG_BM;
-    const bool affine = (SRC == 0 || SRC == 3) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
+    const bool affine = (SRC == 0 || SRC == 3 || SRC == 4) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
+    if (SRC == 4)
+        for (int t = tid; t < 3 * cin; t += 256) Wxs[t / cin][t % cin] = A.wx[t];
     if (NARROW) {
         const int c0 = (SRC == 3) ? cin : cout, cb = (SRC == 3) ? 0 : n0, cw = (SRC == 3) ? cin : BN;
         for (int t = tid; t < 9 * cw; t += 256) {
@@ -116,7 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             W0s[d][c] = d < 8 ? (d < A.k0 ? A.w0[(size_t)d * c0 + cb + c] : 0.0f) : (A.b0 ? A.b0[cb + c] : 0.0f);
         }
     }
-    if (SRC == 0 || SRC == 3) {
+    if (SRC == 0 || SRC == 3 || SRC == 4) {
         if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
             const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
             for (int k = tid; k < cin; k += 256) {
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     } else {
         for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
     }
-    if (EPI == 3 || EPI == 4)
+    if (REDUCE_BELOW)
         for (int cidx = tid; cidx < BN; cidx += 256) {
             Eco[0][cidx] = A.e_scale[n0 + cidx];
             Eco[1][cidx] = A.e_shift[n0 + cidx];
@@ -146,7 +159,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
 
     // A staging: thread t -> tile rows (t>>2) and (t>>2)+64, k-quad (t&3); W staging: float4 #t (+256)
     const int a_row = tid >> 2, a_kq = tid & 3;
-    const float *abase = (SRC == 0) ? A.x : (SRC == 3) ? A.u8 : A.zsrc; // the array the row pointers walk
+    const float *abase = (SRC == 0) ? A.x : (SRC == 3) ? A.u8 : (SRC == 4) ? A.ptab : A.zsrc; // the array the row pointers walk
     // SRC 3: the pointers stay on the row's eight floats for all slabs of a tile (re-read per slab from L2: no branch in the loop)
     const int arow_len = (SRC == 3) ? 8 : cin;
     const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
@@ -155,8 +168,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
     const size_t a_tile_jump = (SRC == 3) ? (size_t)gridDim.x * FG_BM * 8 : (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
-    const float *pu = (EPI == 4) ? A.u8 + ((size_t)blockIdx.x * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4 : nullptr;
+    const float *pu = (EPI == 4) ? A.u8 + ((size_t)blockIdx.x * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4
+                      : (EPI == 6) ? A.geo + ((size_t)blockIdx.x * FG_BM + (tid & 127)) * 4 : nullptr; // EPI 6: both halves of the workgroup fetch the row's record (no load under a branch)
     int ltp = 0; // parity of the tile being LOADED
+    // SRC 4: the geo cursor runs ONE SLAB AHEAD of the operand cursor (qn = the geo of this thread's two rows of the slab the next
+    // issue_loads call fetches); dq0 / dq1 in a register set are the dxyz of the rows of ITS slab
+    const float4 *pg = (SRC == 4) ? reinterpret_cast<const float4 *>(A.geo) + (size_t)blockIdx.x * FG_BM + a_row : nullptr;
+    float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
+    int glkt = 0;
+    long gsteps = steps_to_load;
+    auto geo_next = [&]() { // load the cursor's geo, then move the cursor one slab on (same no-branch-around-a-load rule as below)
+        qn0 = pg[0];
+        qn1 = pg[64];
+        if (gsteps > 1 && ++glkt == nk) {
+            glkt = 0;
+            pg += (size_t)gridDim.x * FG_BM;
+        }
+        --gsteps;
+    };
     // SRC 2: pooled upstream gradient and arg-max of this thread's two rows (group = row / pool_k)
     const int pk = (SRC == 2) ? A.pool_k : 1;
     long g0 = 0, g1 = 0;    // groups of the two staged rows of the step being LOADED
@@ -186,12 +215,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         int k, ro0, ro1; // k / row offsets of the quads
         float4 uq;     // EPI 4: this thread's quad of the tile's u rows
         int tp;        //        and the tile's parity
+        float4 dq0, dq1; // SRC 4: geo of the two rows (dxyz used when the slab goes to LDS)
     };
     Regs R[2];
     auto issue_loads = [&](Regs &r) {
-        r.a0 = *reinterpret_cast<const float4 *>(pa0);
-        r.a1 = *reinterpret_cast<const float4 *>(pa1);
         const int kq = lkt * FG_BK + a_kq * 4;
+        if (SRC == 4) {
+            r.dq0 = qn0; // the geo of THIS slab's rows: loaded by the previous call, as the oldest of its loads
+            r.dq1 = qn1;
+            geo_next();  // first load of this call: the geo of the slab the next call fetches
+            r.a0 = *reinterpret_cast<const float4 *>(A.ptab + (size_t)__float_as_uint(r.dq0.w) * cin + kq);
+            r.a1 = *reinterpret_cast<const float4 *>(A.ptab + (size_t)__float_as_uint(r.dq1.w) * cin + kq);
+        } else {
+            r.a0 = *reinterpret_cast<const float4 *>(pa0);
+            r.a1 = *reinterpret_cast<const float4 *>(pa1);
+        }
         if (SRC == 1) {
             r.g0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
             r.g1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
@@ -208,7 +246,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         }
 #pragma unroll
         for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
-        if (EPI == 4) {
+        if (EPI == 4 || EPI == 6) {
             r.uq = *reinterpret_cast<const float4 *>(pu);
             r.tp = ltp;
         }
@@ -225,8 +263,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
                 lkt = 0;
                 pa0 += a_tile_jump;
                 pa1 += a_tile_jump;
-                if (EPI == 4) {
-                    pu += (size_t)gridDim.x * FG_BM * 8;
+                if (EPI == 4 || EPI == 6) {
+                    pu += (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4);
                     ltp ^= 1;
                 }
 #pragma unroll
@@ -241,6 +279,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         --steps_to_load;
     };
     auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk) {
+        if (SRC == 4) { // v = the P quad of the row, g = its geo: z0 of the four channels rk..rk+3
+            const float4 w0 = *reinterpret_cast<const float4 *>(&Wxs[0][rk]), w1 = *reinterpret_cast<const float4 *>(&Wxs[1][rk]);
+            const float4 w2 = *reinterpret_cast<const float4 *>(&Wxs[2][rk]);
+            v.x = assembled_z(v.x, g, w0.x, w1.x, w2.x);
+            v.y = assembled_z(v.y, g, w0.y, w1.y, w2.y);
+            v.z = assembled_z(v.z, g, w0.z, w1.z, w2.z);
+            v.w = assembled_z(v.w, g, w0.w, w1.w, w2.w);
+        }
         if (SRC == 3) { // v, g = the row's u[0..4), u[4..8): z0 of the four channels rk..rk+3, then the folded BatchNorm + ReLU below
             const float uu[8] = {v.x, v.y, v.z, v.w, g.x, g.y, g.z, g.w};
             float wq[4][8];
@@ -265,7 +311,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             v.w = narrow_z(uu, wq[3], b4.w);
 #endif
         }
-        if (SRC == 0 || SRC == 3) {
+        if (SRC == 0 || SRC == 3 || SRC == 4) {
             if (affine) {
                 const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
                 const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
@@ -309,7 +355,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         return make_float4(o[0], o[1], o[2], o[3]);
     };
     auto store_regs = [&](int buf, const Regs &r) {
-        const float4 v0 = act4(r.a0, r.g0, r.m0, r.ro0, r.k), v1 = act4(r.a1, r.g1, r.m1, r.ro1, r.k);
+        const float4 v0 = act4(r.a0, SRC == 4 ? r.dq0 : r.g0, r.m0, r.ro0, r.k), v1 = act4(r.a1, SRC == 4 ? r.dq1 : r.g1, r.m1, r.ro1, r.k);
         As[buf][a_kq * 4 + 0][a_row] = v0.x;
         As[buf][a_kq * 4 + 1][a_row] = v0.y;
         As[buf][a_kq * 4 + 2][a_row] = v0.z;
@@ -324,6 +370,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             *reinterpret_cast<float4 *>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = r.b[u];
         }
         if (EPI == 4) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+        if (EPI == 6) Gs[r.tp][tid & 127] = r.uq;
     };
 
     float s1[NT], s2[NT];
@@ -335,7 +382,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
 #pragma unroll
         for (int j = 0; j < NT; j++) ugs[d][j] = 0.0f;
     if (my_tiles == 0) { // never with the launchers below (gridDim.x <= row tiles); a workgroup without work still takes its ticket
-        if (EPI == 3 || EPI == 4) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
+        if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
         return;
     }
     __syncthreads(); // Sco
@@ -349,6 +396,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
         asm volatile("" : "+v"(bvs[j]));
     }
     // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
+    if (SRC == 4) geo_next(); // qn = slab 0's geo (the cursor then stands on slab 1)
     issue_loads(R[0]);
     store_regs(0, R[0]);
     issue_loads(R[1]);
@@ -501,6 +549,56 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
                 }
             }
         }
+        if (EPI == 6) {
+            const float thr = A.e_relu ? 0.0f : -__builtin_inff();
+            const int tp = (int)(t & 1);
+            const __amdgpu_buffer_rsrc_t pr = __builtin_amdgcn_make_buffer_rsrc((void *)(A.ptab + n0), 0, 0xffffffff, 0x00020000);
+            float sc[NT], sf[NT], mu[NT], inv[NT], x0[NT], x1[NT], x2[NT];
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const int cl = (wn * NT + j) * 32 + l31;
+                sc[j] = Eco[0][cl];
+                sf[j] = Eco[1][cl];
+                mu[j] = Eco[2][cl];
+                inv[j] = Eco[3][cl];
+                x0[j] = A.wx[n0 + cl];
+                x1[j] = A.wx[cout + n0 + cl];
+                x2[j] = A.wx[2 * cout + n0 + cl];
+            }
+            int urow = (wm * MT) * 32 + 4 * kh; // this lane's first row of the tile
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int h = 0; h < 2; h++) { // eight rows at a time: e = 8h .. 8h+7
+                    // phase 1: the rows' table offsets, then 8 x NT gathers in flight; phase 2 reads the dxyz again from LDS
+                    unsigned vo[8];
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int e = 8 * h + q;
+                        vo[q] = __float_as_uint(Gs[tp][urow + i * 32 + (e & 3) + 8 * (e >> 2)].w) * pitch + (unsigned)l31 * 4u;
+                    }
+                    float pv[NT][8];
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+#pragma unroll
+                        for (int q = 0; q < 8; q++)
+                            pv[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pr, vo[q], (unsigned)((wn * NT + j) * 32) * 4u, 0));
+#pragma unroll
+                    for (int q = 0; q < 8; q++) {
+                        const int e = 8 * h + q;
+                        const float4 g4 = Gs[tp][urow + i * 32 + (e & 3) + 8 * (e >> 2)];
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            const float zz = assembled_z(pv[j][q], g4, x0[j], x1[j], x2[j]);
+                            float g = acc[i][j][e];
+                            if (!(zz * sc[j] + sf[j] > thr)) g = 0.0f;
+                            s1[j] += g;
+                            s2[j] += g * ((zz - mu[j]) * inv[j]);
+                        }
+                    }
+                    asm volatile("" : "+v"(urow) : "v"(s2[0])); // the next rows' gathers wait for these sums: 8 x NT in flight
+                }
+        }
         if (EPI == 4) {
             const float thr = A.e_relu ? 0.0f : -__builtin_inff();
             const int tp = (int)(t & 1);
@@ -599,7 +697,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EPI == 3 ? 
             else unsafeAtomicAdd(&A.ug[(size_t)(which - 2) * cout + n0 + c], (double)t);
         }
     }
-    if (EPI == 3 || EPI == 4) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
+    if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
 
 int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
@@ -607,7 +705,8 @@ int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launc
 template <int SRC, int EPI>
 static bool fast_dispatch(const FastArgs &a, hipStream_t st)
 {
-    const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : a.zsrc;
+    const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : (SRC == 4) ? a.ptab : a.zsrc;
+    if (SRC == 4 && ((uintptr_t)a.geo % 16 != 0 || (uintptr_t)a.wx % 16 != 0)) return false;
     if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
     const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
                          (SRC != 1 || (uintptr_t)a.da % 16 == 0) &&
@@ -844,4 +943,74 @@ extern "C" void votenet_debug_fast_workgroups(int cap22, int cap41) // tuning ho
 {
     if (cap22 > 0) votenet::g_fast_cap22 = cap22;
     if (cap41 > 0) votenet::g_fast_cap41 = cap41;
+}
+
+// Second layer of an SA chain whose first layer is ASSEMBLED in the operand loader (assemble.hip): z (rows x cout) =
+// relu(bn0(z0)) w + bias with z0[r,:] = P[prow(r),:] + dxyz(r) . wx rebuilt from geo and the per-point table P (points x c0,
+// bias included); bn0 from raw statistics (in_bn: votenet_assemble_stats) or in_scale / in_shift.  stats as votenet_mlp_linear.
+extern "C" int votenet_assembled_linear(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
+                                        const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                        const float *w, const float *bias, float *z, double *stats, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c0 > 0 && cout > 0, "assembled_linear expects rows > 0, c0 > 0, cout > 0");
+    VN_REQUIRE(geo && P && wx && w && z, "assembled_linear: null buffer");
+    VN_REQUIRE(in_bn != nullptr || (in_scale != nullptr && in_shift != nullptr), "assembled_linear: the first layer's BatchNorm is missing");
+    FastArgs a = {};
+    a.geo = geo;
+    a.ptab = P;
+    a.wx = wx;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_raw = to_raw(in_bn);
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = c0;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.stats = stats;
+    hipStream_t st = as_stream(stream);
+    const bool ok = stats ? fast_dispatch<4, 0>(a, st) : fast_dispatch<4, 1>(a, st);
+    if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_linear: shape not served (rows %% 128 == 0, c0 %% 32 == 0, c0 <= 512, cout %% 64 == 0, 16-byte aligned buffers)");
+    return check_launch("assembled_linear");
+}
+
+// votenet_mlp_dgrad_bn_reduce for an ASSEMBLED layer below (assemble.hip): z_prev is not read but rebuilt from geo, the per-point
+// table P (points x cout, bias included; points * cout * 4 < 2^32) and wx (3 x cout).  da_prev is stored.
+extern "C" int votenet_assembled_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                                 const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
+                                                 const float *scale_prev, const float *shift_prev, const float *mean_prev,
+                                                 const float *var_prev, float eps, int relu_prev, double *sums,
+                                                 const votenet_coef_tail *tail, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "assembled_dgrad_bn_reduce expects rows > 0, c > 0, cout > 0");
+    VN_REQUIRE(da && zsrc && coef && wT && da_prev && geo && P && wx, "assembled_dgrad_bn_reduce: null buffer");
+    VN_REQUIRE(scale_prev && shift_prev && mean_prev && var_prev && sums, "assembled_dgrad_bn_reduce: null buffer of the layer below");
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "assembled_dgrad_bn_reduce: incomplete coefficient tail");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "assembled_dgrad_bn_reduce: geo must be 16-byte aligned");
+    FastArgs a = {};
+    a.da = da;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = cout;
+    a.w = wT;
+    a.z = da_prev;
+    a.geo = geo;
+    a.ptab = P;
+    a.wx = wx;
+    a.e_scale = scale_prev;
+    a.e_shift = shift_prev;
+    a.e_mean = mean_prev;
+    a.e_var = var_prev;
+    a.e_eps = eps;
+    a.e_relu = relu_prev;
+    a.stats = sums;
+    a.tail = to_tail(tail);
+    if (!fast_dispatch<1, 6>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_dgrad_bn_reduce: shape not served (as votenet_mlp_dgrad_bn_reduce)");
+    return check_launch("assembled_dgrad_bn_reduce");
 }

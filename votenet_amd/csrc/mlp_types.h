@@ -22,6 +22,8 @@ struct MlpIn {
     // NARROW first layer (narrow.hip): x[r,:] = z0[r,:] = narrow_z(u8[r], W0, b0), rows of 8 floats; then in_scale / in_shift / in_relu
     const float *u8, *w0, *b0;
     int k0; // 3..8 rows of W0 (k0 x cin), the rest of u is zero
+    // ASSEMBLED first layer (assemble.hip): x[r,:] = z0[r,:] = assembled_z(P[prow(r),:], geo[r], wx); then in_scale / in_shift / in_relu
+    const float *geo, *ptab, *wx;
 };
 
 // z0[r,c] of a narrow first layer: ONE fma chain in a fixed order.  Every kernel that needs z0 rebuilds it with this function, so the
@@ -51,5 +53,12 @@ struct BnSrc {
     float *part;
     long pstride;
 };
+
+// z0[r,c] of a first SA layer assembled where it is consumed (assemble.hip): p = P[prow(r), c], g = geo[r] = (dx, dy, dz, bits(prow)),
+// w0..w2 = W[0:3][c].  ONE fma chain, the same in every kernel, so all consumers see bit-identical values (identical ReLU masks).
+__device__ __forceinline__ float assembled_z(float p, const float4 &g, float w0, float w1, float w2)
+{
+    return __builtin_fmaf(g.z, w2, __builtin_fmaf(g.y, w1, __builtin_fmaf(g.x, w0, p)));
+}
 
 } // namespace votenet

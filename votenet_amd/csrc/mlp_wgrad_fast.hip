@@ -12,6 +12,8 @@
 //     two slabs of matrix work; one slab is shorter than the loaded HBM latency;
 //   * NARROW (MODE 2): X = z0 of a narrow first layer, rebuilt from the row's eight floats u8[r] with narrow_z (narrow.hip): the
 //     thread's four channels of W0 / b0 sit in registers, a slab row costs 32 bytes instead of 4*cin;
+//   * ASSEMBLED (MODE 3): X = z0 of a first SA layer rebuilt from geo[r] and a gather of the per-point table P (assemble.hip); the geo
+//     of a slab travels like the idx of a GATHER slab, one refill ahead;
 //   * GATHER: the idx of a slab is loaded one refill BEFORE the feature rows that need it, and ahead of that refill's
 //     other loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.
 // LDS images are the natural [row][channel] slabs; lane l reads As[k2*2 + (l>>5)][i0 + (l&31)]: conflict-free.
@@ -46,7 +48,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const int xc = (MODE == 0) ? cin : in.c;
 
     // per-thread channel constants in registers
-    const bool affine = (MODE == 0 || MODE == 2) && in.in_scale != nullptr;
+    const bool affine = (MODE == 0 || MODE == 2 || MODE == 3) && in.in_scale != nullptr;
+    float4 wx0 = make_float4(0.f, 0.f, 0.f, 0.f), wx1 = wx0, wx2 = wx0; // MODE 3: W[0:3][ka..ka+3]
+    if (MODE == 3) {
+        wx0 = *reinterpret_cast<const float4 *>(in.wx + ka);
+        wx1 = *reinterpret_cast<const float4 *>(in.wx + cin + ka);
+        wx2 = *reinterpret_cast<const float4 *>(in.wx + 2 * cin + ka);
+    }
     float w0r[4][8], b0r[4]; // MODE 2: W0[:, ka..ka+3] (zero padded to 8 rows) and b0[ka..ka+3]
     if (MODE == 2) {
 #pragma unroll
@@ -84,7 +92,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     }
     const float b_floor = (BSRC == 3 && bs.relu) ? 0.0f : -__builtin_inff();
     // wave-uniform bases at the workgroup's first row; threads carry 32-bit element offsets (checked by the launcher)
-    const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : (MODE == 2) ? in.u8 + (size_t)r_begin * 8 : in.feat + ka;
+    const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : (MODE == 2) ? in.u8 + (size_t)r_begin * 8 : (MODE == 3) ? in.ptab + ka : in.feat + ka;
+    const float4 *geob = (MODE == 3) ? reinterpret_cast<const float4 *>(in.geo) + r_begin : nullptr;
     const float *zb = (BSRC == 0 ? dz : bs.z) + (size_t)r_begin * cout + nb;
     const float *gb = (BSRC == 1) ? bs.da + (size_t)r_begin * cout + nb : nullptr;
     const int *idxb = (MODE == 1) ? in.idx + r_begin : nullptr;
@@ -92,23 +101,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     struct Regs {
         float4 a[NA], b[NB], g[NB];
-        float4 a2[MODE == 2 ? NA : 1]; // MODE 2: the second half of the rows' u
+        float4 a2[(MODE == 2 || MODE == 3) ? NA : 1]; // MODE 2: the second half of the rows' u; MODE 3: the rows' geo
         int4 m[NB];
         int s; // slab index (local)
     };
     Regs R[2];
-    int pidx[NA]; // GATHER: feat row (scene*n + idx) of this thread's rows of the slab loaded by the NEXT refill
+    struct Pix { // what a GATHER / ASSEMBLED row needs one refill ahead: its idx, or its geo record
+        int i;
+        float4 g;
+    };
+    Pix pidx[NA]; // of this thread's rows of the slab loaded by the NEXT refill
     auto clampr = [&](int lr) { return lr < nrow ? lr : nrow - 1; };
     auto load_idx = [&](int s) {
-        if (MODE == 1) {
+        if (MODE == 1 || MODE == 3) {
 #pragma unroll
             for (int h = 0; h < NA; h++) {
                 const int lr = clampr(s * WF_BR + a_row + h * RA);
-                pidx[h] = idxb[lr];
+                if (MODE == 1) pidx[h].i = idxb[lr];
+                else pidx[h].g = geob[lr];
             }
         }
     };
-    auto load_slab = [&](Regs &r, int s, const int (&pi)[NA]) {
+    auto load_slab = [&](Regs &r, int s, const Pix (&pi)[NA]) {
         r.s = s;
 #pragma unroll
         for (int h = 0; h < NA; h++) {
@@ -118,9 +132,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             } else if (MODE == 2) {
                 r.a[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * 8u));
                 r.a2[h] = *reinterpret_cast<const float4 *>(xb + (size_t)((unsigned)lr * 8u) + 4);
+            } else if (MODE == 3) {
+                r.a[h] = *reinterpret_cast<const float4 *>(xb + (size_t)__float_as_uint(pi[h].g.w) * cin);
+                r.a2[h] = pi[h].g;
             } else {
                 const unsigned scene = (unsigned)(r_begin + lr) / grows;
-                r.a[h] = *reinterpret_cast<const float4 *>(xb + ((size_t)scene * in.n + pi[h]) * xc);
+                r.a[h] = *reinterpret_cast<const float4 *>(xb + ((size_t)scene * in.n + pi[h].i) * xc);
             }
         }
 #pragma unroll
@@ -148,6 +165,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 v.y = narrow_z(uu, w0r[1], b0r[1]);
                 v.z = narrow_z(uu, w0r[2], b0r[2]);
                 v.w = narrow_z(uu, w0r[3], b0r[3]);
+            }
+            if (MODE == 3) {
+                const float4 g = r.a2[h];
+                v.x = assembled_z(v.x, g, wx0.x, wx1.x, wx2.x);
+                v.y = assembled_z(v.y, g, wx0.y, wx1.y, wx2.y);
+                v.z = assembled_z(v.z, g, wx0.z, wx1.z, wx2.z);
+                v.w = assembled_z(v.w, g, wx0.w, wx1.w, wx2.w);
             }
             v.x = fmaxf(v.x * csc.x + csh.x, x_floor);
             v.y = fmaxf(v.y * csc.y + csh.y, x_floor);
@@ -201,7 +225,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 
     // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in sets 1 and 0; idx of slab 3 in pidx.
     // Slab numbers past the end are clamped row by row (they re-read the last row and are stored as zeros).
-    int pcur[NA];
+    Pix pcur[NA];
     load_idx(0);
 #pragma unroll
     for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
@@ -347,6 +371,11 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         if (bsrc == 1) return launch<0, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         if (bsrc == 3) return launch<0, 3>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch);
+    }
+    if (mode == 3) { // ASSEMBLED first layer below: x rebuilt from geo + P (votenet_assembled_wgrad_bn)
+        if (!al(d.geo) || !al(d.ptab) || !al(d.wx) || bsrc != 1) return false;
+        if (d.in_scale && (!al(d.in_scale) || !al(d.in_shift))) return false;
+        return launch<3, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (mode == 2) { // NARROW first layer below: x rebuilt from u8 (votenet_narrow_wgrad_bn)
         if (!al(d.u8) || !al(d.w0) || (d.b0 && !al(d.b0)) || d.k0 < 1 || d.k0 > 8 || bsrc != 1) return false;

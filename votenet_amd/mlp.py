@@ -284,6 +284,100 @@ def linear_gather(xyz, new_xyz, feat, idx, w, bias=None, want_stats=True):
     return z, stats
 
 
+# ---- first SA layer assembled inside its consumers (csrc/assemble.hip): z0 = P[idx] + dxyz W[0:3] never stored ----
+def assembled_supported(rows, c0, c1):
+    return rows > 0 and rows % 128 == 0 and rows < 2 ** 31 and c0 % 64 == 0 and c0 <= 512 and c1 % 64 == 0
+
+
+def assemble_rows(xyz, new_xyz, idx, want_sums=True, pts_cnt=None):
+    """-> geo (rows, 4) f32 = (dx, dy, dz, bits(scene*n + idx)), cntv (b*n, 4) i64 and moments (9,) f64 or None, None."""
+    b, m, k = idx.shape
+    n = xyz.shape[1]
+    geo = torch.empty((b * m * k, 4), dtype=torch.float32, device=xyz.device)
+    # not from the per-step arenas: geometry is computed one or two steps ahead of its use
+    cntv = torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device) if want_sums else None  # count, sum dxyz in fixed point 2^-32
+    mom = torch.zeros(9, dtype=torch.float64, device=xyz.device) if want_sums else None
+    with L.device_guard(xyz.device):
+        L.check(L.lib().votenet_assemble_rows(b, n, m, k, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt), L.ptr(geo), L.ptr(cntv), L.ptr(mom),
+                                              L.stream_ptr()))
+    return geo, cntv, mom
+
+
+def assemble_stats(P, cntv, wx, mom):
+    """BatchNorm statistics (2*c0 f64) of the never-stored z0 from one pass over the points."""
+    npts, c0 = P.shape
+    stats = _zeros_f64(2 * c0, P.device)
+    with L.device_guard(P.device):
+        L.check(L.lib().votenet_assemble_stats(npts, c0, L.ptr(P), L.ptr(cntv), L.ptr(wx), L.ptr(mom), L.ptr(stats), L.stream_ptr()))
+    return stats
+
+
+def assemble_z0(geo, P, wx):
+    """The first-layer output the product path never stores, with the kernels' own arithmetic (tests)."""
+    z0 = torch.empty((geo.shape[0], P.shape[1]), dtype=torch.float32, device=P.device)
+    with L.device_guard(P.device):
+        L.check(L.lib().votenet_assemble_z0(geo.shape[0], P.shape[1], L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(z0), L.stream_ptr()))
+    return z0
+
+
+def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True):
+    """Second layer over the assembled first-layer output: z = relu(bn0(P[prow] + dxyz wx)) w + bias -> z (rows, cout), stats."""
+    rows, c0, cout = geo.shape[0], P.shape[1], w.shape[1]
+    z = torch.empty((rows, cout), dtype=torch.float32, device=P.device)
+    stats = _zeros_f64(2 * cout, P.device) if want_stats else None
+    scale = shift = raw = None
+    if in_bn.done:
+        scale, shift = in_bn.scale, in_bn.shift
+    else:
+        raw = in_bn.raw()
+    with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled")):
+        L.check(L.lib().votenet_assembled_linear(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
+                                                 ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
+                                                 L.ptr(bias), L.ptr(z), L.ptr(stats), L.stream_ptr()))
+    return z, stats
+
+
+def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, da, dw):
+    """dw (c0, cout) += relu(bn0(z0))^T dz1 with z0 rebuilt in the loader, dz1 = BatchNorm-backward(da, z, coef)."""
+    rows, c0, cout = geo.shape[0], P.shape[1], z.shape[1]
+    scr = _wgrad_scratch(None, rows, c0, cout, P.device)
+    with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled")):
+        L.check(L.lib().votenet_assembled_wgrad_bn(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(in_scale), L.ptr(in_shift),
+                                                   1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(dw),
+                                                   L.ptr(scr), L.stream_ptr()))
+
+
+def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_EPS, below_tail=None):
+    """dgrad_bn(..., below=...) for an assembled layer below: -> (da_prev, sums) or, with below_tail, (da_prev, coef of that layer)."""
+    rows, c = z.shape
+    cout = wT.shape[1]
+    bsc, bsh, bme, bva, brelu = below
+    out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
+    sums = _zeros_f64(2 * cout, z.device)
+    t, coef_b = _coef_tail(below_tail, cout, z.device)
+    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled")):
+        L.check(L.lib().votenet_assembled_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                          L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh), L.ptr(bme),
+                                                          L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
+                                                          ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if below_tail is None:
+        return out, sums
+    return out, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))
+
+
+def group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, P, wx, da, coef, relu, dw_xyz, want_dz=False):
+    """group_linear_backward for a first layer whose output was never stored: z rebuilt from P (b*n, cout) and wx."""
+    b, m, k = idx.shape
+    n, cout = xyz.shape[1], P.shape[1]
+    dz = torch.empty((b * m * k, cout), dtype=torch.float32, device=P.device) if want_dz else None
+    S = torch.zeros((b, n, cout), dtype=torch.float32, device=P.device)
+    with L.device_guard(P.device):
+        L.check(L.lib().votenet_group_linear_backward_assembled(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
+                                                                L.ptr(P), L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S),
+                                                                L.ptr(dw_xyz), L.ptr(dz), L.stream_ptr()))
+    return S, dz
+
+
 # ---- NARROW first layer (csrc/narrow.hip): 3 + c <= 8 grouped channels, z0 never stored ----
 def narrow_supported(rows, k0, c0, c1):
     """Shapes the narrow-first-layer kernels serve (include/votenet_hip.h): k0 = 3 + c grouped input channels, c0 / c1 = widths

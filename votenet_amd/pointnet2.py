@@ -26,6 +26,7 @@ from . import tf_grouping, tf_interpolate, tf_sampling
 
 PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
 NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the first layer's output is rebuilt from 8 floats per row, never stored (csrc/narrow.hip)
+ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -252,6 +253,19 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             zn = None
             st = M.narrow_stats(rows, mom, w, b) if (L.bn and FROZEN_BN is None) else None
             rec = dict(layer=L, kind="narrow", u8=u8, mom=mom)
+        elif i == 0 and first[0] == "assembled":
+            # first layer assembled inside its consumers (csrc/assemble.hip): the per-point GEMM P = feat W[3:] + b is all that runs here;
+            # the BatchNorm statistics of z0 = P[idx] + dxyz W[0:3] come from one pass over the points
+            _, xyz, new_xyz, feat, idx, geo, cntv, mom = first
+            bb, nn, cc = feat.shape
+            P, _ = M.linear_dense(feat.reshape(bb * nn, cc), w[3:], b, want_stats=False)
+            zn = None
+            st = M.assemble_stats(P, cntv, w[:3], mom) if (L.bn and FROZEN_BN is None) else None
+            rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3])
+        elif i == 1 and first[0] == "assembled":
+            r0 = tape[-1]
+            zn, st = M.assembled_linear(r0["geo"], r0["P"], r0["wx"], w, b, pend, prev_relu, want_stats=L.bn)
+            rec = dict(layer=L, kind="dense", x=None, assembled=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
         elif i == 1 and first[0] == "narrow":
             zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
@@ -415,7 +429,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             else:
                 da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k, mm=mm)
             continue
-        rows, c = z.shape
+        rows, c = r["rows"], L.cout  # z is None for a first layer that is never stored (narrow / assembled)
         if L.bn:
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
             if coef_ahead is not None:
@@ -424,6 +438,17 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 coef = M.bn_backward_reduce(z, *bn, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0,
                                             tail=tail_of(r))
             # d bias of a BatchNorm'ed layer is identically zero (BN removes the mean): left at 0
+            if r.get("assembled"):
+                # second layer above an ASSEMBLED first layer (i == 1): both GEMMs rebuild z0 from geo + P; the input-gradient GEMM's
+                # epilogue reduces the first layer's BatchNorm backward on the rebuilt z0
+                r0 = recs[0]
+                geo, Pt, wx = r0["geo"], r0["P"], r0["wx"]
+                on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.assembled_wgrad_bn(
+                    geo, Pt, wx, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W")), geo, Pt, z, coef, da)
+                da, coef_ahead = M.assembled_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, geo, Pt, wx,
+                                                              (r0["scale"], r0["shift"], r0["mean"], r0["var"], r0["layer"].relu),
+                                                              below_tail=tail_of(r0))
+                continue
             if r.get("narrow"):
                 # second layer above a NARROW first layer (i == 1): both GEMMs rebuild z0 from u8; the input-gradient GEMM stores
                 # nothing -- its epilogue leaves the first layer's BatchNorm-backward sums and the data term of its weight gradient
@@ -453,6 +478,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 else:
                     da = M.dgrad_bn(z, coef, L.relu, L.wT(), **src)
                 continue
+            if i == 0 and r["kind"] == "assembled":
+                return dict(da=da, coef=coef, relu=L.relu)  # dz is formed inside votenet_group_linear_backward_assembled
             if i == 0 and r["kind"] == "gather" and PRE_LINEAR and not pooled and r["feat"] is not None and \
                     M.group_linear_backward_supported(c, r["idx"].shape[2]):
                 return dict(da=da, coef=coef, relu=L.relu)  # dz is formed inside votenet_group_linear_backward
@@ -522,6 +549,14 @@ class SAModule:
         return bool(NARROW_FIRST and self.leaf and len(m) >= 3 and m[0].bn and m[1].bn and m[0].relu and
                     M.narrow_supported(rows, 3 + self.cin, m[0].cout, m[1].cout))
 
+    def assembled(self, b, n):
+        """True when this module's first layer is assembled inside its consumers (csrc/assemble.hip) for b scenes of n points."""
+        m = self.mlp
+        rows = b * self.npoint * self.nsample
+        return bool(ASSEMBLE_FIRST and PRE_LINEAR and not M.DETERMINISTIC and self.cin > 0 and not self.narrow(rows) and len(m) >= 3
+                    and m[0].bn and m[1].bn and m[0].relu and M.assembled_supported(rows, m[0].cout, m[1].cout)
+                    and M.group_linear_backward_supported(m[0].cout, self.nsample) and b * n * m[0].cout * 4 < 2 ** 32)
+
     def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None):
         """The weight-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream.
         points: the module's input features; given for a narrow leaf module, the grouped rows u8 and their moments (which depend
@@ -534,6 +569,8 @@ class SAModule:
             geom = (fps_idx, new_xyz, idx, pts_cnt)
         if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
             geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
+        elif self.assembled(xyz.shape[0], xyz.shape[1]):
+            geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3])  # geo records + per-point sums: coordinates only
         return geom
 
     def forward(self, xyz, points, sample_xyz=None, tape=None, geom=None):
@@ -548,6 +585,9 @@ class SAModule:
         if self.narrow(rows):
             u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
             first = ("narrow", u8, mom)
+        elif points is not None and self.assembled(b, xyz.shape[1]):
+            geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt)
+            first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
         z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
             res = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend,
@@ -605,6 +645,9 @@ class SAModule:
                 on_wgrad_stream(lambda: M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW), dz)  # rows 0..2 of dW (no feature block)
             if feat is not None and PRE_LINEAR:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
+        elif r0["kind"] == "assembled":
+            S, dz = M.group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"],
+                                                      gW[:3], want_dz=need_xyz_grad)
         else:
             S, dz = M.group_linear_backward(xyz, new_xyz, idx, pts_cnt, r0["z"], h["da"], h["coef"], h["relu"], gW[:3],
                                             want_dz=need_xyz_grad)
