@@ -172,7 +172,7 @@ class VoteNetHotPath:
         """model.py:89-93: SA on votes with FPS on the seeds -> proposals_xyz (B,256,3), output (B,256,79)."""
         geom = None
         if getattr(self, "_prop_fps", None) is not None:  # FPS on the seeds was computed ahead (side stream)
-            geom = self.proposal.geometry(votes_xyz, fps_idx=self._prop_fps)
+            geom = self.proposal.geometry(votes_xyz, fps_idx=self._prop_fps, ahead=False)  # the votes exist only now
         p_xyz, p_out, _ = self.proposal.forward(votes_xyz, votes_points, sample_xyz=seeds_xyz, tape=tape, geom=geom)
         return p_xyz, p_out
 

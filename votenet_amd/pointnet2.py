@@ -27,6 +27,7 @@ from . import tf_grouping, tf_interpolate, tf_sampling
 PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
 NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the first layer's output is rebuilt from 8 floats per row, never stored (csrc/narrow.hip)
 ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
+ASSEMBLE_INLINE = True  # also where the geo records were not computed ahead with the geometry (they are built in place)
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -557,7 +558,7 @@ class SAModule:
                     and m[0].bn and m[1].bn and m[0].relu and M.assembled_supported(rows, m[0].cout, m[1].cout)
                     and M.group_linear_backward_supported(m[0].cout, self.nsample) and b * n * m[0].cout * 4 < 2 ** 32)
 
-    def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None):
+    def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None, ahead=True):
         """The weight-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream.
         points: the module's input features; given for a narrow leaf module, the grouped rows u8 and their moments (which depend
         on coordinates and input features only) are appended to the result."""
@@ -569,7 +570,7 @@ class SAModule:
             geom = (fps_idx, new_xyz, idx, pts_cnt)
         if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
             geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
-        elif self.assembled(xyz.shape[0], xyz.shape[1]):
+        elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
             geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3])  # geo records + per-point sums: coordinates only
         return geom
 
@@ -585,7 +586,7 @@ class SAModule:
         if self.narrow(rows):
             u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
             first = ("narrow", u8, mom)
-        elif points is not None and self.assembled(b, xyz.shape[1]):
+        elif points is not None and self.assembled(b, xyz.shape[1]) and (len(geom) >= 7 or ASSEMBLE_INLINE):
             geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt)
             first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
         z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
