@@ -1,0 +1,55 @@
+"""Forward pass with its geometry already on the device and NOTHING running beside it, against the pipelined pass the bench times
+(one geometry chain per call on a side stream): how much of the 2.55 ms is the kernels' sum, how much the company (scratch)."""
+import os, sys, time, gc
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
+import torch
+from votenet_amd import model as VM, synth
+dev = torch.device("cuda:0")
+xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in (1000, 500000, 900000)]
+net = VM.VoteNetHotPath(dev, seed=0)
+def piped(k):
+    for i in range(k):
+        net.forward(xs[i % 3], next_x=[xs[(i + 1) % 3], xs[(i + 2) % 3]])
+piped(9); torch.cuda.synchronize(); gc.disable()
+t0 = time.perf_counter(); piped(60); torch.cuda.synchronize(); print("pipelined: %.3f ms per forward" % ((time.perf_counter() - t0) / 60 * 1e3))
+# geometry of the three batches computed once, re-inserted before every call (NOT what a benchmark may do: a floor measurement)
+net._prefetched.clear()
+for x in xs:
+    net.prefetch_geometry(x)
+torch.cuda.synchronize()
+saved = dict(net._prefetched)
+def floor(k):
+    for i in range(k):
+        x = xs[i % 3]
+        net._prefetched[id(x)] = saved[id(x)]
+        net.forward(x)
+floor(9); torch.cuda.synchronize()
+t0 = time.perf_counter(); floor(60); torch.cuda.synchronize(); print("geometry given, nothing beside it: %.3f ms per forward" % ((time.perf_counter() - t0) / 60 * 1e3))
+# what beside the pass costs it how much: the floor loop with ONE kind of geometry kernel looping on a side stream
+from votenet_amd import tf_sampling, tf_grouping
+side = torch.cuda.Stream(device=dev)
+x0 = xs[0]
+fi = tf_sampling.farthest_point_sample(2048, x0); c0 = tf_sampling.gather_point(x0, fi)
+def beside(name, fn, per_call):
+    floor(3); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(per_call):
+                fn()
+        x = xs[i % 3]
+        net._prefetched[id(x)] = saved[id(x)]
+        net.forward(x)
+    torch.cuda.synchronize(main := None)
+    print("beside %-44s %.3f ms per forward" % (name, (time.perf_counter() - t0) / 40 * 1e3), flush=True)
+from votenet_amd import _lib as L
+fl = int(os.environ.get("FPS_LDS", "0"))
+if fl:
+    L.lib().votenet_debug_fps_lds_floor(fl)
+    print("FPS LDS floor", fl)
+    piped(9); torch.cuda.synchronize()
+    t0 = time.perf_counter(); piped(60); torch.cuda.synchronize(); print("pipelined with the floor: %.3f ms per forward" % ((time.perf_counter() - t0) / 60 * 1e3))
+beside("nothing", lambda: None, 0)
+beside("one sa1 FPS per forward (1.67 ms, 8 workgroups)", lambda: tf_sampling.farthest_point_sample(2048, x0), 1)
+beside("two sa1 FPS per forward", lambda: tf_sampling.farthest_point_sample(2048, x0), 2)
+beside("ten sa1 ball queries per forward", lambda: tf_grouping.query_ball_point(0.2, 64, x0, c0), 10)

@@ -1221,16 +1221,22 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
     } while (0)
 #define FPS_BUCKET_LAUNCH(NW, VW)                                                                                  \
     do {                                                                                                           \
-        constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;                                          \
-        static bool attr_set = false;                                                                              \
-        if (!attr_set) {                                                                                           \
+        constexpr size_t lds_need = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;                                     \
+        /* g_fps_lds_floor: ask for more LDS than the kernel uses, so that no other workgroup fits on its CU (see  \
+           votenet_debug_fps_lds_floor) */                                                                        \
+        const size_t lds = lds_need > (size_t)g_fps_lds_floor ? lds_need : (size_t)g_fps_lds_floor;                \
+        static size_t attr_set = 0;                                                                                \
+        if (attr_set != lds) {                                                                                     \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_kernel<NW, VW>),                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-            attr_set = true;                                                                                       \
+            attr_set = lds;                                                                                        \
         }                                                                                                          \
         hipLaunchKernelGGL((fps_bucket_kernel<NW, VW>), dim3(b), dim3(NW * 64), lds, st, n, m, inp, (const int *)sidx.perm, \
                            (const float *)sidx.bbox, (const float4 *)sidx.sorted, out);                            \
     } while (0)
+
+static int g_fps_lds_floor = 0;
+extern "C" void votenet_debug_fps_lds_floor(int bytes) { g_fps_lds_floor = bytes > 0 ? bytes : 0; } // tuning hook
 
 extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
 {

@@ -19,6 +19,7 @@ from . import mlp as M
 from . import pointnet2 as P
 
 NH, NS, NC = 12, 10, 10  # config.py:2-3
+PREFETCH_AFTER = 2  # when the geometry chain of the next batch is enqueued: -1 at the start of the pass, k after the forward of sa<k>, 5 at the start of the backward pass.  Its FPS holds 8 CUs for 1.7 ms and every GEMM beside it runs ~18 % longer (tools/probe/gemm_beside_fps.py): after sa2 it falls on the small-kernel stretch of the pass (7.03 -> 6.88 ms per step, same box)
 SIDE_PRIORITY = 0   # HIP stream priorities of the geometry (prefetch) streams and of the weight-gradient stream (0 = normal)
 WGRAD_PRIORITY = 0
 PROPOSAL_NUM = 256       # config.py:6
@@ -137,20 +138,30 @@ class VoteNetHotPath:
             g, ev = self.geometry_ahead(x)
         else:
             g, ev = {}, {}
-        for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
-            self.prefetch_geometry(nx)
+        nexts = next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])
+        if PREFETCH_AFTER < 0:
+            for nx in nexts:
+                self.prefetch_geometry(nx)
         overlap = overlap or pf is not None
         self._prop_fps = g.get("prop_fps")
+        def launch_prefetch(after):
+            if PREFETCH_AFTER == after:
+                for nx in nexts:
+                    self.prefetch_geometry(nx)
         l1_xyz, l1_p, _ = self.sa1.forward(x, x, tape=tape, geom=g.get("sa1"))
+        launch_prefetch(1)
         if overlap:
             main.wait_event(ev["sa2"])
         l2_xyz, l2_p, _ = self.sa2.forward(l1_xyz, l1_p, tape=tape, geom=g.get("sa2"))
+        launch_prefetch(2)
         if overlap:
             main.wait_event(ev["sa3"])
         l3_xyz, l3_p, _ = self.sa3.forward(l2_xyz, l2_p, tape=tape, geom=g.get("sa3"))
+        launch_prefetch(3)
         if overlap:
             main.wait_event(ev["sa4"])
         l4_xyz, l4_p, _ = self.sa4.forward(l3_xyz, l3_p, tape=tape, geom=g.get("sa4"))
+        launch_prefetch(4)
         if overlap:
             main.wait_event(ev["fp"])
         l3_p2 = self.fp1.forward(l3_xyz, l4_xyz, l3_p, l4_p, tape=tape, geom=g.get("fp1"))
@@ -375,6 +386,9 @@ class VoteNetHotPath:
         if getattr(self, "_gsync", None) is None:
             self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))
         self._gsync.begin()
+        if PREFETCH_AFTER >= 5:  # the next batch's geometry chain under the BACKWARD pass
+            for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
+                self.prefetch_geometry(nx)
         self.backward(tape, cot)                # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
         self.store.invalidate_transposes()      # the optimizer changes W
         gscale = self._gsync.finish()           # head all-reduce + wait for both; 1/world goes to the optimizer
