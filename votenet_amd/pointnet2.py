@@ -26,6 +26,7 @@ from . import tf_grouping, tf_interpolate, tf_sampling
 
 PAD_RAGGED = True  # False: ragged plain layers go through the generic bounds-checked GEMM (A/B, tests)
 NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the first layer's output is rebuilt from 8 floats per row, never stored (csrc/narrow.hip)
+PAD_RAGGED_IN = True  # ragged INPUT widths (voting's 259) padded as well (Layer.cin_pad); False: the bounds-checked GEMMs (A/B)
 ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
 ASSEMBLE_INLINE = True  # also where the geo records were not computed ahead with the geometry (they are built in place)
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
@@ -59,6 +60,13 @@ class ParamStore:
         self._tspecs.append((name, 0, None, "P", pad_to))
         self._tspecs.append((name, 0, None, "PT", pad_to))  # skipped for 1-D tensors when the table is built
 
+    def want_padded_rows(self, name, pad_to):
+        """Register copies of the 2-D tensor `name` with its ragged ROW count padded to `pad_to`: padded_rows(name) = [W ; 0]
+        (pad_to x cols) for a GEMM whose input carries zero columns up to pad_to, padded_rows(name, True) = [W ; 0]^T
+        (cols x pad_to) for the input-gradient GEMM.  Same launch as the transposes."""
+        self._tspecs.append((name, 0, None, "R", pad_to))
+        self._tspecs.append((name, 0, None, "RT", pad_to))
+
     def refresh_transposes(self, stream=None):
         """One launch for every registered W^T block / padded copy, on `stream` (default: the current one); transposed() /
         padded() make the current stream wait for it.  Call again whenever the parameters changed (once per training step)."""
@@ -78,6 +86,12 @@ class ParamStore:
                 if kind == "T":      # (cols x rows), leading dimension rows
                     table += [src, total, rows, cols, rows, 1]
                     shp = (cols, rows)
+                elif kind == "R":    # (pad x cols): rows >= the tensor's stay zero
+                    table += [src, total, rows, cols, cols, 0]
+                    shp = (pad, cols)
+                elif kind == "RT":   # (cols x pad): the transpose with leading dimension pad
+                    table += [src, total, rows, cols, pad, 1]
+                    shp = (cols, pad)
                 elif kind == "P":    # (rows x pad), zero padding
                     table += [src, total, rows, cols, pad, 0]
                     shp = (rows, pad) if v.dim() == 2 else (pad,)
@@ -135,6 +149,15 @@ class ParamStore:
             return v
         w = self.views[name]
         p = torch.nn.functional.pad(w, (0, pad_to - w.shape[-1]))
+        return p.t().contiguous() if transpose else p
+
+    def padded_rows(self, name, pad_to, transpose=False):
+        """[W ; 0] (pad_to x cols), or its transpose (cols x pad_to): from the per-step bucket when registered and fresh, else ad hoc."""
+        v = self._fresh((name, 0, None, "RT" if transpose else "R"))
+        if v is not None:
+            return v
+        w = self.views[name]
+        p = torch.nn.functional.pad(w, (0, 0, 0, pad_to - w.shape[0]))
         return p.t().contiguous() if transpose else p
 
     def declare(self, name, shape, init):
@@ -195,6 +218,12 @@ class Layer:
             self.cout_pad = (cout + 63) // 64 * 64
             store.want_padded(name + "/W", self.cout_pad)
             store.want_padded(name + "/b", self.cout_pad)
+        # a BatchNorm'ed layer with a ragged INPUT width -- voting's 259 -- takes its dense input zero-padded to a multiple of 64
+        # columns against [W ; 0]: forward, weight-gradient and input-gradient GEMMs all leave the bounds-checked kernels
+        self.cin_pad = 0
+        if PAD_RAGGED and bn and cin % 32 != 0 and cin > 64 and cout % 64 == 0:
+            self.cin_pad = (cin + 63) // 64 * 64
+            store.want_padded_rows(name + "/W", self.cin_pad)
 
     def p(self, k):
         return self.store[self.name + "/" + k]
@@ -283,6 +312,10 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             else:
                 zn, st = M.linear_gather(xyz, new_xyz, feat, idx, w, b, want_stats=L.bn)
             rec = dict(layer=L, kind="gather", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx)
+        elif i == 0 and L.cin_pad and PAD_RAGGED_IN and first[1].is_cuda:
+            xp = torch.nn.functional.pad(first[1], (0, L.cin_pad - L.cin))  # [x | 0] against [W ; 0]
+            zn, st = M.linear_dense(xp, L.store.padded_rows(L.name + "/W", L.cin_pad), b, want_stats=L.bn)
+            rec = dict(layer=L, kind="dense", x=xp, in_scale=None, in_shift=None, in_relu=False, cin_padded=True)
         elif i == 0:
             zn, st = M.linear_dense(first[1], w, b, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=first[1], in_scale=None, in_shift=None, in_relu=False)
@@ -462,6 +495,17 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                                                      (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0))
                 M.narrow_wgrad_first(mom, ug, coef0, w0, b0, L0.gp("W"))
                 return None  # a leaf: nothing upstream takes a gradient
+            if r.get("cin_padded") and not pooled and M.dgrad_bn_supported(rows, c, L.cin_pad):
+                # the same layer on [x | 0] and [W ; 0]: dW through a padded scratch (its rows >= cin multiply zeros), da = dz [W ; 0]^T
+                def _padded_in_wgrad(r=r, z=z, coef=coef, L=L, da=da):
+                    G = torch.zeros((L.cin_pad, L.cout), dtype=torch.float32, device=z.device)
+                    M.wgrad_dense_bn(r["x"], z, coef, L.relu, G, da=da)
+                    L.gp("W").add_(G[:L.cin])
+                on_wgrad_stream(_padded_in_wgrad, r["x"], z, coef, da)
+                if not want_da:
+                    return None
+                da = M.dgrad_bn(z, coef, L.relu, L.store.padded_rows(L.name + "/W", L.cin_pad, transpose=True), da=da)[:, :L.cin]
+                continue
             if r["kind"] == "dense" and (not want_da or M.dgrad_bn_supported(rows, c, r["x"].shape[1])):
                 # dz never materialised: both GEMMs rebuild it from (da | gout, z, coef) in their loaders
                 src = dict(gout=da, argmax=argmax, k=k) if pooled else dict(da=da)
