@@ -1,5 +1,7 @@
 """One forward GEMM (524288 x 128 -> 128) beside a kernel that only OCCUPIES CUs (tools/probe/src/hold.hip): 8 workgroups of 768
-threads with 97 KB of LDS (the FPS kernel's footprint), asleep or spinning, against the real FPS kernel."""
+threads with 97 KB of LDS (the FPS kernel's footprint), asleep or spinning, against the real FPS kernel.
+Build the holder first (hipcc cross-compiles without a GPU):
+    hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/probe/src/hold.hip -o tools/probe/lib/libhold.so"""
 import ctypes, os, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
 import torch
