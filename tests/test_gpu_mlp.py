@@ -231,3 +231,48 @@ def test_consumer_side_bn_finalize(hiplib, dev, rows, cin, cout):
     pend = mlp.PendingBN(st, gamma, beta, rows)
     s2, h2 = pend.finalize()
     assert torch.equal(s2, sc) and torch.equal(h2, sh)
+
+
+@pytest.mark.parametrize("form", ["narrow", "assembled", "stored"])
+def test_sa_module_cfg1_every_first_layer_form_vs_oracle(hiplib, dev, O, form):
+    """BASELINE config 1 through pointnet2.SAModule, against the CPU oracle's materialised grouped convolution: the first layer never
+    stored and rebuilt from eight floats per row (leaf module, csrc/narrow.hip), assembled inside its consumers from the per-point
+    table (csrc/assemble.hip), and stored (votenet_group_linear)."""
+    import cases
+    from votenet_amd import pointnet2 as P
+    xyz = cases.cfg1_cloud()
+    rng = np.random.default_rng(1)
+    dims = [6, 64, 64, 128]
+    ws = [(rng.normal(size=(dims[i], dims[i + 1])) * np.sqrt(2.0 / dims[i])).astype(np.float32) for i in range(3)]
+    bs = [rng.normal(size=dims[i + 1]).astype(np.float32) * 0.1 for i in range(3)]
+    gs = [1 + 0.1 * rng.normal(size=dims[i + 1]).astype(np.float32) for i in range(3)]
+    be = [0.1 * rng.normal(size=dims[i + 1]).astype(np.float32) for i in range(3)]
+    fidx = O.farthest_point_sample(512, xyz)
+    new_xyz = O.gather_point(xyz, fidx)
+    idx, _ = O.query_ball_point(0.2, 32, xyz, new_xyz)
+    a = O.group_concat(xyz, new_xyz, xyz, idx).reshape(-1, 6)
+    for i in range(3):
+        zz = O.linear(a, ws[i], bs[i])
+        mean, var = O.bn_stats(zz)
+        a = O.bn_relu(zz, mean, var, gs[i], be[i])
+    exp = O.max_over_k(a, 32)
+    store = P.ParamStore(dev)
+    mod = P.SAModule(store, "sa", 512, 0.2, 32, 3, [64, 64, 128], leaf=(form == "narrow"))
+    store.materialize(0)
+    for i in range(3):
+        store["sa/conv%d/W" % i].copy_(T(ws[i], dev))
+        store["sa/conv%d/b" % i].copy_(T(bs[i], dev))
+        store["sa/conv%d/gamma" % i].copy_(T(gs[i], dev))
+        store["sa/conv%d/beta" % i].copy_(T(be[i], dev))
+    old = P.ASSEMBLE_FIRST
+    P.ASSEMBLE_FIRST = form != "stored"
+    try:
+        x = T(xyz, dev)
+        tape = []
+        nx, out, didx = mod.forward(x, x, tape=tape)
+    finally:
+        P.ASSEMBLE_FIRST = old
+    assert tape[0]["recs"][0]["kind"] == {"narrow": "narrow", "assembled": "assembled", "stored": "gather"}[form]
+    assert np.array_equal(N(didx), idx) and np.array_equal(N(nx), new_xyz)
+    got = N(out)[0]
+    assert np.abs(got - exp).max() <= 2e-5 * max(1.0, np.abs(exp).max())
