@@ -462,6 +462,20 @@ int votenet_narrow_wgrad_first(int k0, int c0, const double *moments, const doub
  * leading dimension ld >= cols: 16-byte aligned rows for the 259- and 79-wide layers).  Padding elements are not written. */
 int votenet_transpose_segments(int nseg, const long *table, const float *src, float *dst, void *stream);
 
+/* BF3 GEMMs (mlp_fast.hip): the fused forward / input-gradient GEMMs multiply fp32 operands as three bf16 pieces each
+ * (x = hi + mid + lo exactly; six v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate: the error of a product is below the fp32
+ * rounding of the product itself) when the weight matrix they are given has a registered IMAGE: the matrix pre-split into the
+ * kernel's LDS order, cin * cout * 6 bytes.  No reference counterpart (Tensorpack Conv2D / FullyConnected, utils.py:125-155).
+ *   votenet_split_weights: one launch that (re)builds the images of nseg matrices; table (device, 4 longs per segment) = source
+ *     address (cin x cout floats, row-major), image address (16-byte aligned), cin (% 16 == 0), cout.  Call after every change of
+ *     the weights.
+ *   votenet_register_split_weights: from now on a GEMM entry point that receives `w` (with these cin, cout) reads `w3` instead
+ *     (w3 == NULL: forget the registration).  Matrices without a registration run on the fp32 MFMA kernels. */
+int votenet_split_weights(int nseg, const long *table, void *stream);
+int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3);
+/* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used */
+void votenet_debug_fast_bf3(int on);
+
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
 int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);
 

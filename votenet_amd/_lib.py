@@ -104,6 +104,8 @@ _SIGS.update({
                                   ctypes.c_long, ctypes.c_int] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_augment_boxes": [ctypes.c_int, ctypes.c_int] + [_c_f] * 11 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_split_weights": [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_register_split_weights": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_bn_relu": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.POINTER(BnRaw), ctypes.c_int, _c_f, ctypes.c_void_p],

@@ -17,6 +17,8 @@
 //   * MFMA operand fragments are double-buffered in registers (ds_reads of sub-step k2+1 before the MFMAs
 //     of k2); LDS images are [k][row] / [k][col], conflict-free for both operand reads.
 #include "mlp_types.h"
+#include <mutex>
+#include <unordered_map>
 
 namespace votenet {
 
@@ -28,6 +30,15 @@ constexpr int FG_LDA = FG_BM + 2;
 #endif
 #ifndef EPI3_WAVES
 #define EPI3_WAVES 2 // EPI 3: minimum waves per SIMD the register allocator is held to
+#endif
+#ifndef BF3_VPM
+#define BF3_VPM 6 // BF3: vector instructions scheduled after each MFMA of a slab
+#endif
+#ifndef BF3_SETS
+#define BF3_SETS 2 // BF3: register sets of raw operands in flight (slabs of lead); cin % (16 * BF3_SETS) == 0
+#endif
+#ifndef BF3_ABL
+#define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging
 #endif
 #ifndef EPI3_CH
 #define EPI3_CH 2 // EPI 3: 32x32 sub-tiles of z_prev loaded at a time
@@ -62,6 +73,23 @@ constexpr int FG_LDA = FG_BM + 2;
 //   EPI 4: EPI 3 for a narrow layer below: z_prev is rebuilt from u8 (staged per tile in LDS by the loader), the epilogue also
 //          accumulates UG[d,c] = sum_r u[r,d] da'[r,c] (the data term of that layer's weight gradient) and stores NOTHING
 //          (cout <= 128: the layer below's width)
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> three bf16 pieces by truncation: x = hi + mid + lo EXACTLY (8 + 8 + 8 significant bits; both subtractions are exact), the
+// pieces of x in the low halves of h / m / l and those of y in the high halves (v_perm_b32 picks the upper 16 bits of both).
+// A product x*w is then the six bf16 MFMA terms hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi accumulated in fp32: what is left
+// out (mid*lo, lo*mid, lo*lo) is below 2^-23 of |x*w| -- the size of the fp32 rounding of the product itself.
+__device__ __forceinline__ void split3(float x, float y, unsigned &h, unsigned &m, unsigned &l)
+{
+    const unsigned ux = __float_as_uint(x), uy = __float_as_uint(y);
+    h = __builtin_amdgcn_perm(uy, ux, 0x07060302u);
+    const float rx = x - __uint_as_float(ux & 0xffff0000u), ry = y - __uint_as_float(uy & 0xffff0000u);
+    const unsigned vx = __float_as_uint(rx), vy = __float_as_uint(ry);
+    m = __builtin_amdgcn_perm(vy, vx, 0x07060302u);
+    const float sx = rx - __uint_as_float(vx & 0xffff0000u), sy = ry - __uint_as_float(vy & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__float_as_uint(sy), __float_as_uint(sx), 0x07060302u);
+}
+
 struct FastArgs {
     const float *x, *in_scale, *in_shift;
     BnRaw in_raw; // alternative to in_scale / in_shift: derived here from the producer's raw sums
@@ -75,6 +103,7 @@ struct FastArgs {
     long rows;
     int cin, cout;
     const float *w, *bias;
+    const unsigned *w3;    // BF3: w as three bf16 pieces in the kernel's LDS order (votenet_split_weights), or NULL
     float *z;              // may be NULL with EPI 2 (inference: only the pooled result is wanted)
     float *zmax, *zmin;    // EPI 2: per 64-row group and channel, raw max / min of z ...
     int *amax, *amin;      //        ... and the row offsets (first occurrence) where they are attained
@@ -91,15 +120,21 @@ struct FastArgs {
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
-template <int WM, int WN, int MT, int NT, int SRC, int EPI>
+template <int WM, int WN, int MT, int NT, int SRC, int EPI, bool BF3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 || EPI == 6) ? EPI3_WAVES : (EPI == 0 || EPI == 2) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
     constexpr int LDB = BN + 4;
     constexpr int NB4 = FG_BK * BN / 4 / 256; // W float4 per thread per slab (1 or 2)
-    __shared__ float As[2][FG_BK][FG_LDA];
-    __shared__ float Bs[2][FG_BK][LDB];
+    __shared__ float As[BF3 ? 1 : 2][BF3 ? 1 : FG_BK][FG_LDA];
+    __shared__ float Bs[BF3 ? 1 : 2][BF3 ? 1 : FG_BK][LDB];
+    // BF3: both operands as three bf16 pieces (split3 below), one image per (piece, k-half): [row or column][8 bf16 = 4 dwords] --
+    // a lane's MFMA fragment is ONE 16-byte read and consecutive lanes read consecutive 16 bytes (conflict-free ds_read_b128);
+    // 16 dwords between the planes put the two k-halves one staging wave writes on different banks
+    constexpr int PLA = FG_BM * 4 + 16, PLB = BN * 4 + 16;
+    __shared__ __attribute__((aligned(16))) unsigned As3[BF3 ? 2 : 1][3][2][BF3 ? PLA : 4];
+    __shared__ __attribute__((aligned(16))) unsigned Bs3[BF3 ? 2 : 1][3][2][BF3 ? PLB : 4];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
     constexpr bool REDUCE_BELOW = (EPI == 3 || EPI == 4 || EPI == 6);
     __shared__ float Eco[REDUCE_BELOW ? 4 : 1][REDUCE_BELOW ? BN : 1]; // EPI 3/4/6: scale, shift, mean, 1/std of this column block
@@ -142,6 +177,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             for (int k = tid; k < cin; k += 256) {
                 Sco[0][k] = A.in_scale[k];
                 Sco[1][k] = A.in_shift[k];
+            }
+        else if (BF3) // the BF3 loader has no branch on `affine`: x * 1 + 0
+            for (int k = tid; k < cin; k += 256) {
+                Sco[0][k] = 1.0f;
+                Sco[1][k] = 0.0f;
             }
     } else {
         for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
@@ -204,12 +244,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         pb[u] = w + (size_t)(f / (BN / 4)) * cout + n0 + (f % (BN / 4)) * 4;
     }
     const size_t b_step = (size_t)FG_BK * cout, b_wrap = (size_t)cin * cout;
+    // BF3: W comes pre-split (votenet_split_weights): per slab [piece][k-half][column][8 bf16], i.e. the LDS image itself.  A slab
+    // of this column block is 6 planes of BN x 16 bytes; thread t copies chunk t of planes (2u + t/128), u = 0..2 (16-byte chunks
+    // at BN = 128, 8-byte chunks at BN = 64): one 32-bit lane offset that walks the slabs, the plane pair u as a scalar offset
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void *)A.w3, 0, 0x7fffffff, 0x00020000);
+    const int b3_pl = tid >> 7, b3_c = (BN == 128) ? (tid & 127) : ((tid & 127) >> 1), b3_h = (BN == 128) ? 0 : (tid & 1);
+    unsigned wvo = (((unsigned)b3_pl * (unsigned)cout + (unsigned)(n0 + b3_c)) * 4u + (unsigned)b3_h * 2u) * 4u;
+    unsigned wpitch = (unsigned)cout * 32u; // bytes between plane pairs (= pieces)
+    const unsigned w3_slab = (unsigned)cout * 96u; // bytes per slab of the split image
     int lkt = 0; // k-slab index of the step being loaded
     // One k-slab step of raw operands in registers.  Two sets alternate: a set is filled two steps before its slab
     // is needed in LDS, so the global loads have two steps of matrix work (2 x 2048 MFMA cycles) to arrive -- one step
     // is less than the loaded HBM latency, which serialised memory time and matrix time.
     struct Regs {
-        float4 a0, a1, b[NB4];
+        float4 a0, a1, b[BF3 ? 1 : NB4];
+        uint4 bq[BF3 ? 3 : 1];   // BF3: this thread's chunk of the three pieces of the W slab (x, y only at BN = 64)
         float4 g0, g1; // SRC 1: da quads; SRC 2: gout quads; SRC 3: the second half of the rows' u
         int4 m0, m1;   // SRC 2: arg-max quads
         int k, ro0, ro1; // k / row offsets of the quads
@@ -217,8 +266,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         int tp;        //        and the tile's parity
         float4 dq0, dq1; // SRC 4: geo of the two rows (dxyz used when the slab goes to LDS)
     };
-    Regs R[2];
+    constexpr int NSETS = BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
+    Regs R[NSETS];
+    bool abl_prologue = true;
     auto issue_loads = [&](Regs &r) {
+        if (BF3 && (BF3_ABL & 4) && !abl_prologue) return;
         const int kq = lkt * FG_BK + a_kq * 4;
         if (SRC == 4) {
             r.dq0 = qn0; // the geo of THIS slab's rows: loaded by the previous call, as the oldest of its loads
@@ -244,13 +296,48 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             r.ro0 = ro0;
             r.ro1 = ro1;
         }
+        if constexpr (BF3) {
 #pragma unroll
-        for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
+            for (int u = 0; u < 3; u++) {
+                if constexpr (BN == 128) {
+                    r.bq[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, (unsigned)u * wpitch, 0));
+                } else {
+                    const uint2 t2 = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(wrs, wvo, (unsigned)u * wpitch, 0));
+                    r.bq[u].x = t2.x;
+                    r.bq[u].y = t2.y;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
+        }
         if (EPI == 4 || EPI == 6) {
             r.uq = *reinterpret_cast<const float4 *>(pu);
             r.tp = ltp;
         }
         r.k = kq;
+        if constexpr (BF3) {
+            // the same cursor movement as below without a branch (scalar selects): the slab body stays ONE basic block, which is
+            // what lets its MFMAs and the staging arithmetic be interleaved (sched_group_barrier in the loop)
+            const bool adv = steps_to_load > 1;
+            const bool wrap = adv && (lkt + 1 == nk);
+            const ptrdiff_t astep = adv ? (ptrdiff_t)a_slab_step + (wrap ? (ptrdiff_t)a_tile_jump : 0) : 0;
+            pa0 += astep;
+            pa1 += astep;
+            wvo += adv ? (wrap ? w3_slab - w3_slab * (unsigned)nk : w3_slab) : 0u;
+            lkt = wrap ? 0 : (adv ? lkt + 1 : lkt);
+            if (EPI == 4 || EPI == 6) {
+                pu += wrap ? (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4) : 0;
+                ltp ^= wrap ? 1 : 0;
+            }
+            if (SRC == 2) {
+                const long dg = wrap ? (long)gridDim.x * FG_BM / pk : 0;
+                g0 += dg;
+                g1 += dg;
+            }
+            --steps_to_load;
+            return;
+        }
         // Advance to the next slab only if there is one: past the end the same (valid) slab is simply loaded again, so
         // the loop body has no memory operation under a branch and the compiler's s_waitcnt bookkeeping stays exact
         // (a conditional load makes it wait for vmcnt(0), which collapses the two-deep pipeline to one).
@@ -278,6 +365,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         }
         --steps_to_load;
     };
+    const float relu_floor = (affine && A.in_relu) ? 0.0f : -__builtin_inff(); // BF3: the folded ReLU as a select against a uniform floor
     auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk) {
         if (SRC == 4) { // v = the P quad of the row, g = its geo: z0 of the four channels rk..rk+3
             const float4 w0 = *reinterpret_cast<const float4 *>(&Wxs[0][rk]), w1 = *reinterpret_cast<const float4 *>(&Wxs[1][rk]);
@@ -310,6 +398,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             v.z = narrow_z(uu, wq[2], b4.z);
             v.w = narrow_z(uu, wq[3], b4.w);
 #endif
+        }
+        if constexpr (BF3 && (SRC == 0 || SRC == 3 || SRC == 4)) {
+            const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
+            const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
+            v.x = v.x * sc.x + sh.x;
+            v.y = v.y * sc.y + sh.y;
+            v.z = v.z * sc.z + sh.z;
+            v.w = v.w * sc.w + sh.w;
+            v.x = v.x > relu_floor ? v.x : relu_floor;
+            v.y = v.y > relu_floor ? v.y : relu_floor;
+            v.z = v.z > relu_floor ? v.z : relu_floor;
+            v.w = v.w > relu_floor ? v.w : relu_floor;
+            return v;
         }
         if (SRC == 0 || SRC == 3 || SRC == 4) {
             if (affine) {
@@ -355,7 +456,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         return make_float4(o[0], o[1], o[2], o[3]);
     };
     auto store_regs = [&](int buf, const Regs &r) {
+        if (BF3 && (BF3_ABL & 8) && !abl_prologue) return;
         const float4 v0 = act4(r.a0, SRC == 4 ? r.dq0 : r.g0, r.m0, r.ro0, r.k), v1 = act4(r.a1, SRC == 4 ? r.dq1 : r.g1, r.m1, r.ro1, r.k);
+        if constexpr (BF3) {
+            unsigned h[4], m[4], l[4];
+            split3(v0.x, v0.y, h[0], m[0], l[0]);
+            split3(v0.z, v0.w, h[1], m[1], l[1]);
+            split3(v1.x, v1.y, h[2], m[2], l[2]);
+            split3(v1.z, v1.w, h[3], m[3], l[3]);
+            const int ao = a_row * 4 + (a_kq & 1) * 2, ap = a_kq >> 1;
+            *reinterpret_cast<uint2 *>(&As3[buf][0][ap][ao]) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2 *>(&As3[buf][1][ap][ao]) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2 *>(&As3[buf][2][ap][ao]) = make_uint2(l[0], l[1]);
+            *reinterpret_cast<uint2 *>(&As3[buf][0][ap][ao + 256]) = make_uint2(h[2], h[3]);
+            *reinterpret_cast<uint2 *>(&As3[buf][1][ap][ao + 256]) = make_uint2(m[2], m[3]);
+            *reinterpret_cast<uint2 *>(&As3[buf][2][ap][ao + 256]) = make_uint2(l[2], l[3]);
+#pragma unroll
+            for (int u = 0; u < 3; u++) {
+                if constexpr (BN == 128) *reinterpret_cast<uint4 *>(&Bs3[buf][u][b3_pl][b3_c * 4]) = r.bq[u];
+                else *reinterpret_cast<uint2 *>(&Bs3[buf][u][b3_pl][b3_c * 4 + b3_h * 2]) = make_uint2(r.bq[u].x, r.bq[u].y);
+            }
+            if (EPI == 4) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+            if (EPI == 6) Gs[r.tp][tid & 127] = r.uq;
+            return;
+        }
         As[buf][a_kq * 4 + 0][a_row] = v0.x;
         As[buf][a_kq * 4 + 1][a_row] = v0.y;
         As[buf][a_kq * 4 + 2][a_row] = v0.z;
@@ -399,13 +523,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     if (SRC == 4) geo_next(); // qn = slab 0's geo (the cursor then stands on slab 1)
     issue_loads(R[0]);
     store_regs(0, R[0]);
-    issue_loads(R[1]);
-    __builtin_amdgcn_sched_barrier(0); // same issue order as in the loop: set 1, then set 0
-    issue_loads(R[0]);
+#pragma unroll
+    for (int q = 1; q <= NSETS; q++) { // same issue order as in the loop: sets 1 .. NSETS-1, then set 0
+        issue_loads(R[q % NSETS]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     __syncthreads();
 
     const int kh = lane >> 5, l31 = lane & 31;
     int buf = 0;
+    abl_prologue = false;
     for (long t = 0; t < my_tiles; t++) {
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -417,10 +544,54 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         // nk is even (launcher): step parity == kt parity, so the register set of a step is a compile-time constant.
         // During step g the set (g+1)&1 holds slab g+1: half way through it goes to the other LDS buffer and the set is
         // refilled with slab g+3.
-        for (int kt = 0; kt < nk; kt += 2) {
+        for (int kt = 0; kt < nk; kt += NSETS) {
 #pragma unroll
-            for (int par = 0; par < 2; par++) {
-                Regs &rs = R[par ^ 1];
+            for (int par = 0; par < NSETS; par++) {
+                Regs &rs = R[(par + 1) % NSETS];
+                if constexpr (BF3) {
+                    // one slab = ONE k-step of v_mfma_f32_32x32x16_bf16 per piece pair: six per 32x32 sub-tile, small terms first
+                    uint4 fa[3][MT], fb[3][NT];
+                    constexpr int orda[3] = {2, 0, 1}, ordw[3] = {0, 2, 1}; // in the order the MFMAs below need them
+#pragma unroll
+                    for (int q = 0; q < 3; q++) {
+#pragma unroll
+                        for (int i = 0; i < MT; i++)
+                            fa[orda[q]][i] = *reinterpret_cast<const uint4 *>(&As3[buf][orda[q]][kh][((wm * MT + i) * 32 + l31) * 4]);
+#pragma unroll
+                        for (int j = 0; j < NT; j++)
+                            fb[ordw[q]][j] = *reinterpret_cast<const uint4 *>(&Bs3[buf][ordw[q]][kh][((wn * NT + j) * 32 + l31) * 4]);
+                    }
+                    auto mm = [&](int pa, int pw) {
+                        if (BF3_ABL & 1) {
+                            acc[0][0][0] += __uint_as_float(fa[pa][0].x ^ fb[pw][0].y);
+                            return;
+                        }
+#pragma unroll
+                        for (int i = 0; i < MT; i++)
+#pragma unroll
+                            for (int j = 0; j < NT; j++)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][i]),
+                                                                                    __builtin_bit_cast(bf16x8, fb[pw][j]), acc[i][j], 0, 0, 0);
+                    };
+                    mm(2, 0);
+                    mm(0, 2);
+                    mm(1, 1);
+                    store_regs(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
+                    issue_loads(rs);
+                    mm(1, 0);
+                    mm(0, 1);
+                    mm(0, 0);
+                    // one MFMA (32 cycles on the SIMD's matrix pipe), then BF3_VPM vector instructions of the staging arithmetic
+                    // beside it: without this the 6 MT NT MFMAs come in two clumps around ~150 VALU instructions
+#pragma unroll
+                    for (int g = 0; g < 6 * MT * NT; g++) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x002, BF3_VPM, 0);
+                    }
+                    lds_barrier();
+                    buf ^= 1;
+                    continue;
+                }
                 float fa[2][MT], fb[2][NT];
 #pragma unroll
                 for (int i = 0; i < MT; i++) fa[0][i] = As[buf][kh][(wm * MT + i) * 32 + l31];
@@ -462,6 +633,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         for (int j = 0; j < NT; j++) {
             pmaxv[j] = pminv[j] = 0.0f;
             pmaxi[j] = pmini[j] = 0;
+        }
+        if (BF3 && (BF3_ABL & 2)) {
+            float t_ = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++) t_ += acc[i][j][e];
+            if (t_ == 12345.678f) z[0] = t_;
+            continue;
         }
         const bool store_z = (EPI != 4) && ((EPI != 2) || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
         if (store_z) {                                   // pooling arithmetic below is not scheduled around 64 addresses
@@ -675,8 +857,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
         // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
         constexpr int NS = (EPI == 4) ? 10 : 2; // statistics per column: s1, s2 (+ the eight rows of UG)
-        float *red = &As[0][0][0];              // [NS][WM][BN]
+        float *red = BF3 ? reinterpret_cast<float *>(&As3[0][0][0][0]) : &As[0][0][0]; // [NS][WM][BN]
         static_assert(NS * WM * BN <= 2 * FG_BK * FG_LDA, "reduction scratch exceeds the A buffers");
+        static_assert(!BF3 || NS * WM * BN <= 2 * 3 * 2 * PLA, "reduction scratch exceeds the split A buffers");
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const int c = (wn * NT + j) * 32 + l31;
@@ -700,11 +883,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
 
+// ---- BF3: weights pre-split into the kernel's LDS order -----------------------------------------------------------------------
+// image of a (cin x cout) matrix, cin % 16 == 0: [slab = k/16][piece hi, mid, lo][k-half][column][8 bf16 = 4 dwords], 6 bytes per
+// weight.  One workgroup column per segment of `table` (4 longs each: source address, image address, cin, cout).
+__global__ __launch_bounds__(256) void split_weights_kernel(const long *__restrict__ table)
+{
+    const long *e = table + (size_t)blockIdx.x * 4;
+    const float *w = reinterpret_cast<const float *>(e[0]);
+    unsigned *out = reinterpret_cast<unsigned *>(e[1]);
+    const int cin = (int)e[2], cout = (int)e[3];
+    const int items = (cin / 8) * cout; // one k-octet of one column each
+    for (int it = blockIdx.y * 256 + threadIdx.x; it < items; it += gridDim.y * 256) {
+        const int o = it / cout, c = it - o * cout;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = w[(size_t)(o * 8 + i) * cout + c];
+        unsigned h[4], m[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+        const int sl = o >> 1, kh = o & 1;
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((size_t)(sl * 3) * 2 + kh) * cout + c;
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[(size_t)2 * cout] = make_uint4(m[0], m[1], m[2], m[3]);
+        dst[(size_t)4 * cout] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+
+// which matrices have an image: keyed by the address the GEMM entry points receive as `w` (the caller keeps the image current:
+// votenet_split_weights after every change of the weights -- pointnet2.ParamStore does, once per step)
+struct W3Entry {
+    int cin, cout;
+    const unsigned *w3;
+};
+static std::mutex g_w3_mu;
+static std::unordered_map<const void *, W3Entry> g_w3;
+static const unsigned *w3_lookup(const float *w, int cin, int cout)
+{
+    std::lock_guard<std::mutex> lk(g_w3_mu);
+    auto it = g_w3.find(w);
+    return (it != g_w3.end() && it->second.cin == cin && it->second.cout == cout) ? it->second.w3 : nullptr;
+}
+
+int g_fast_bf3 = 1; // 1: the (SRC, EPI) pairs bf3_built() lists run on bf16 x 3 split operands (votenet_debug_fast_bf3)
+template <int SRC, int EPI> constexpr bool bf3_built() { return SRC == 0 && (EPI == 0 || EPI == 1 || EPI == 2); }
+#define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
+    do {                                                                                                                             \
+        if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
+            if (g_fast_bf3 && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
+                hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), 0, ST_, A_);    \
+                break;                                                                                                               \
+            }                                                                                                                        \
+        }                                                                                                                            \
+        hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, false>), GRID_, dim3(256), 0, ST_, A_);           \
+    } while (0)
 int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
 
 template <int SRC, int EPI>
-static bool fast_dispatch(const FastArgs &a, hipStream_t st)
+static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
 {
+    FastArgs a = a_in;
+    if (bf3_built<SRC, EPI>() && g_fast_bf3) a.w3 = w3_lookup(a.w, a.cin, a.cout);
     const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : (SRC == 4) ? a.ptab : a.zsrc;
     if (SRC == 4 && ((uintptr_t)a.geo % 16 != 0 || (uintptr_t)a.wx % 16 != 0)) return false;
     if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
@@ -718,7 +956,7 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
         if (a.cout % 64 != 0) return false;
         const int ny = a.cout / 64;
         gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
         return true;
     } else {
     // few row tiles (FP layers, voting, mlp2): 128 x 64 tiles double the number of workgroups
@@ -726,21 +964,21 @@ static bool fast_dispatch(const FastArgs &a, hipStream_t st)
         const int ny = a.cout / 64;
         gx = ntiles;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
         return true;
     }
     if (a.cout % 128 == 0) {
         const int ny = a.cout / 128;
         gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false; // a tile jump must be a whole number of groups
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        FAST_LAUNCH(2, 2, 2, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
         return true;
     }
     if (EPI != 2 && a.cout % 64 == 0) { // 64, and the odd multiples of 64 (320 = voting's 259 padded): 128 x 64 tiles, cout / 64 column blocks
         const int ny = a.cout / 64;
         gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
-        hipLaunchKernelGGL((mlp_linear_fast_kernel<4, 1, 1, 2, SRC, EPI>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
         return true;
     }
     }
@@ -789,12 +1027,13 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
     a.zmin = zmin;
     a.amax = amax;
     a.amin = amin;
+    if (g_fast_bf3) a.w3 = w3_lookup(w, cin, cout);
     const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
     if (!aligned || cin % (2 * FG_BK) != 0 || cin > 512 || rows % FG_BM != 0 || rows == 0 || cout % 128 != 0) return false;
     const long ntiles = rows / FG_BM;
     const int ny = cout / 128;
     const long gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
-    hipLaunchKernelGGL((mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2>), dim3((unsigned)gx, ny), dim3(256), 0, st, a);
+    FAST_LAUNCH(2, 2, 2, 2, 0, 2, dim3((unsigned)gx, ny), st, a);
     return true;
 }
 
@@ -939,6 +1178,31 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     return check_launch("narrow_dgrad_bn_reduce");
 }
 
+extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = on; }
+
+// BF3 weight images.  table (device, 4 longs per segment): source address (cin x cout floats, row-major), image address
+// (cin * cout * 6 bytes, 16-byte aligned), cin (% 16 == 0), cout.  One launch for all segments.
+extern "C" int votenet_split_weights(int nseg, const long *table, void *stream)
+{
+    VN_REQUIRE(nseg >= 0, "split_weights expects nseg >= 0");
+    if (nseg == 0) return VOTENET_OK;
+    VN_REQUIRE(table != nullptr, "split_weights: null table");
+    hipLaunchKernelGGL(votenet::split_weights_kernel, dim3(nseg, 8), dim3(256), 0, as_stream(stream), table);
+    return check_launch("split_weights");
+}
+
+// Tell the GEMM entry points that the matrix they receive at address `w` (cin x cout) has a current image at `w3`
+// (w3 == NULL: forget it).  While registered, the fused forward / input-gradient GEMMs read the image instead of w.
+extern "C" int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3)
+{
+    VN_REQUIRE(w != nullptr, "register_split_weights: null w");
+    VN_REQUIRE(w3 == nullptr || (cin > 0 && cin % 16 == 0 && cout > 0 && (uintptr_t)w3 % 16 == 0),
+               "register_split_weights expects cin % 16 == 0, cout > 0 and a 16-byte aligned image");
+    std::lock_guard<std::mutex> lk(votenet::g_w3_mu);
+    if (w3) votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3)};
+    else votenet::g_w3.erase(w);
+    return VOTENET_OK;
+}
 extern "C" void votenet_debug_fast_workgroups(int cap22, int cap41) // tuning hook: 0 keeps a value
 {
     if (cap22 > 0) votenet::g_fast_cap22 = cap22;

@@ -243,6 +243,55 @@ def _desc_gather(xyz, new_xyz, feat, idx):
     return d
 
 
+def split_eligible(cin, cout):
+    """Shapes whose GEMMs can read a bf16 x 3 image of the weights (mlp_fast.hip, BF3): whole 16-row slabs, 64-column blocks."""
+    return cin % 32 == 0 and cin <= 512 and cout % 64 == 0
+
+
+class SplitImages:
+    """bf16 x 3 images of a set of weight matrices (votenet_split_weights): one device buffer, one launch to (re)build all of them,
+    registered with the library so that the GEMM entry points which receive one of the matrices read its image.  The owner calls
+    refresh() after every change of the weights; close() (or deletion) withdraws the registrations."""
+
+    def __init__(self, mats):
+        mats = [w for w in mats if w.dim() == 2 and w.is_contiguous() and split_eligible(*w.shape)]
+        self.mats = mats
+        self.nseg = len(mats)
+        if not mats:
+            return
+        dev = mats[0].device
+        total, offs = 0, []
+        for w in mats:
+            offs.append(total)
+            total += w.shape[0] * w.shape[1] * 6
+            total = (total + 15) // 16 * 16
+        self.buf = torch.empty(total, dtype=torch.uint8, device=dev)
+        base = self.buf.data_ptr()
+        table = []
+        for w, o in zip(mats, offs):
+            table += [w.data_ptr(), base + o, w.shape[0], w.shape[1]]
+        self.table = torch.tensor(table, dtype=torch.int64, device=dev)
+        self._reg = [(w.data_ptr(), w.shape[0], w.shape[1], base + o) for w, o in zip(mats, offs)]
+        for wp, cin, cout, ip in self._reg:
+            L.check(L.lib().votenet_register_split_weights(ctypes.c_void_p(wp), cin, cout, ctypes.c_void_p(ip)))
+
+    def refresh(self):
+        if self.nseg:
+            with L.device_guard(self.buf.device):
+                L.check(L.lib().votenet_split_weights(self.nseg, L.ptr(self.table), L.stream_ptr()))
+
+    def close(self):
+        for wp, cin, cout, _ in getattr(self, "_reg", []):
+            L.lib().votenet_register_split_weights(ctypes.c_void_p(wp), cin, cout, None)
+        self._reg = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, want_stats=True, in_bn=None):
     """z = act(x) @ w + bias with act = relu(x*in_scale+in_shift) folded into the load (or identity).
     x (rows, cin) f32 -> z (rows, cout), stats (2*cout) f64 [column sums of z, of z*z] or None."""

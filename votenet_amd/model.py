@@ -26,6 +26,9 @@ PROPOSAL_NUM = 256       # config.py:6
 PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
 
 
+SPLIT_BF16 = True  # fused GEMMs on bf16 x 3 split operands (fp32-accurate products, six bf16 MFMAs per k-step; mlp.SplitImages)
+
+
 class VoteNetHotPath:
     def __init__(self, device, seed=0, npoints=(2048, 1024, 512, 256)):
         self.device = device
@@ -44,6 +47,7 @@ class VoteNetHotPath:
         self.proposal = P.SAModule(s, "proposal", PROPOSAL_NUM, 0.3, 64, 256, [128, 128, 128],
                                    mlp2=[128, 128, PROPOSAL_OUT])           # model.py:89-93
         s.materialize(seed)
+        s.enable_split(SPLIT_BF16)  # forward() refreshes the images at its start, refresh_transposes() those of the copies
 
     # ---- forward pieces -------------------------------------------------------------
     def _side_stream(self):
@@ -190,6 +194,7 @@ class VoteNetHotPath:
     def forward(self, x, tape=None, next_x=None):
         """next_x: the batch of the NEXT call (or a list of the next few), if known: their geometry is computed underneath this
         pass (prefetch_geometry)."""
+        self.store.refresh_split()  # bf16 x 3 images of the weights as they are NOW (one launch; no-op unless enable_split())
         M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
         try:
             seeds_xyz, seeds_p = self.backbone(x, tape, next_x=next_x)

@@ -47,6 +47,8 @@ class ParamStore:
         self._tviews = {}
         self._tflat = self._ttable = None
         self.t_event = None  # recorded after the transposes of the current step; None = stale
+        self.split = False      # enable_split(): bf16 x 3 images of the weight matrices for the fused GEMMs (mlp.SplitImages)
+        self._split_flat = self._split_t = None
 
     def want_transpose(self, name, lo=0, hi=None):
         """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
@@ -66,6 +68,24 @@ class ParamStore:
         (cols x pad_to) for the input-gradient GEMM.  Same launch as the transposes."""
         self._tspecs.append((name, 0, None, "R", pad_to))
         self._tspecs.append((name, 0, None, "RT", pad_to))
+
+    def enable_split(self, on=True):
+        """The owner promises to call refresh_split() whenever the parameters changed before the next GEMM reads them
+        (VoteNetHotPath.forward does, at its start; refresh_transposes() covers the transposed / padded copies)."""
+        self.split = bool(on)
+        if not on:
+            for im in (self._split_flat, self._split_t):
+                if im is not None:
+                    im.close()
+            self._split_flat = self._split_t = None
+
+    def refresh_split(self):
+        """One launch on the current stream: the images of every eligible 2-D tensor of the bucket."""
+        if not self.split or self.flat is None or not self.flat.is_cuda:
+            return
+        if self._split_flat is None:
+            self._split_flat = M.SplitImages([v for v in self.views.values() if v.dim() == 2])
+        self._split_flat.refresh()
 
     def refresh_transposes(self, stream=None):
         """One launch for every registered W^T block / padded copy, on `stream` (default: the current one); transposed() /
@@ -119,6 +139,10 @@ class ParamStore:
         with M.L.device_guard(self.device), torch.cuda.stream(st):
             L_.check(L_.lib().votenet_transpose_segments(self._nseg, L_.ptr(self._ttable), L_.ptr(self.flat),
                                                          L_.ptr(self._tflat), L_.stream_ptr()))
+            if self.split:  # the images of the copies, behind the copies on the same stream
+                if self._split_t is None:
+                    self._split_t = M.SplitImages([v for v in self._tviews.values() if v.dim() == 2])
+                self._split_t.refresh()
             self.t_event = torch.cuda.Event()
             self.t_event.record(st)
         self._t_waited = False
