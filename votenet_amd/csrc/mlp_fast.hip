@@ -925,7 +925,7 @@ static const unsigned *w3_lookup(const float *w, int cin, int cout)
 }
 
 int g_fast_bf3 = 1; // 1: the (SRC, EPI) pairs bf3_built() lists run on bf16 x 3 split operands (votenet_debug_fast_bf3)
-template <int SRC, int EPI> constexpr bool bf3_built() { return SRC == 0 && (EPI == 0 || EPI == 1 || EPI == 2); }
+template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
         if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
