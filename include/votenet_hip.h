@@ -472,6 +472,7 @@ int votenet_transpose_segments(int nseg, const long *table, const float *src, fl
  *   votenet_register_split_weights: from now on a GEMM entry point that receives `w` (with these cin, cout) reads `w3` instead
  *     (w3 == NULL: forget the registration).  Matrices without a registration run on the fp32 MFMA kernels. */
 int votenet_split_weights(int nseg, const long *table, void *stream);
+int votenet_split_weights_one(const float *w, int cin, int cout, void *image, void *stream); /* one matrix, arguments by value */
 int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3);
 /* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used */
 void votenet_debug_fast_bf3(int on);

@@ -105,6 +105,7 @@ _SIGS.update({
     "votenet_augment_boxes": [ctypes.c_int, ctypes.c_int] + [_c_f] * 11 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_split_weights": [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_split_weights_one": [_c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_register_split_weights": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],

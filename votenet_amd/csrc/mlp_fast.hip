@@ -886,14 +886,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 // ---- BF3: weights pre-split into the kernel's LDS order -----------------------------------------------------------------------
 // image of a (cin x cout) matrix, cin % 16 == 0: [slab = k/16][piece hi, mid, lo][k-half][column][8 bf16 = 4 dwords], 6 bytes per
 // weight.  One workgroup column per segment of `table` (4 longs each: source address, image address, cin, cout).
-__global__ __launch_bounds__(256) void split_weights_kernel(const long *__restrict__ table)
+__device__ __forceinline__ void split_weights_body(const float *__restrict__ w, unsigned *__restrict__ out, int cin, int cout, int first,
+                                                   int stride)
 {
-    const long *e = table + (size_t)blockIdx.x * 4;
-    const float *w = reinterpret_cast<const float *>(e[0]);
-    unsigned *out = reinterpret_cast<unsigned *>(e[1]);
-    const int cin = (int)e[2], cout = (int)e[3];
     const int items = (cin / 8) * cout; // one k-octet of one column each
-    for (int it = blockIdx.y * 256 + threadIdx.x; it < items; it += gridDim.y * 256) {
+    for (int it = first; it < items; it += stride) {
         const int o = it / cout, c = it - o * cout;
         float v[8];
 #pragma unroll
@@ -907,6 +904,16 @@ __global__ __launch_bounds__(256) void split_weights_kernel(const long *__restri
         dst[(size_t)2 * cout] = make_uint4(m[0], m[1], m[2], m[3]);
         dst[(size_t)4 * cout] = make_uint4(l[0], l[1], l[2], l[3]);
     }
+}
+__global__ __launch_bounds__(256) void split_weights_kernel(const long *__restrict__ table)
+{
+    const long *e = table + (size_t)blockIdx.x * 4;
+    split_weights_body(reinterpret_cast<const float *>(e[0]), reinterpret_cast<unsigned *>(e[1]), (int)e[2], (int)e[3],
+                       blockIdx.y * 256 + threadIdx.x, gridDim.y * 256);
+}
+__global__ __launch_bounds__(256) void split_weights_one_kernel(const float *__restrict__ w, unsigned *__restrict__ out, int cin, int cout)
+{
+    split_weights_body(w, out, cin, cout, blockIdx.x * 256 + threadIdx.x, gridDim.x * 256);
 }
 
 // which matrices have an image: keyed by the address the GEMM entry points receive as `w` (the caller keeps the image current:
@@ -1189,6 +1196,17 @@ extern "C" int votenet_split_weights(int nseg, const long *table, void *stream)
     VN_REQUIRE(table != nullptr, "split_weights: null table");
     hipLaunchKernelGGL(votenet::split_weights_kernel, dim3(nseg, 8), dim3(256), 0, as_stream(stream), table);
     return check_launch("split_weights");
+}
+
+// The image of ONE matrix, arguments by value (a matrix made on the fly, e.g. votenet_pool_dgrad_prepare's).
+extern "C" int votenet_split_weights_one(const float *w, int cin, int cout, void *image, void *stream)
+{
+    VN_REQUIRE(w && image && cin > 0 && cin % 16 == 0 && cout > 0 && (uintptr_t)image % 16 == 0,
+               "split_weights_one expects cin % 16 == 0, cout > 0 and a 16-byte aligned image");
+    const int items = (cin / 8) * cout;
+    hipLaunchKernelGGL(votenet::split_weights_one_kernel, dim3((items + 255) / 256), dim3(256), 0, as_stream(stream), w,
+                       static_cast<unsigned *>(image), cin, cout);
+    return check_launch("split_weights_one");
 }
 
 // Tell the GEMM entry points that the matrix they receive at address `w` (cin x cout) has a current image at `w3`

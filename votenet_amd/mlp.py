@@ -243,6 +243,14 @@ def _desc_gather(xyz, new_xyz, feat, idx):
     return d
 
 
+# Matrices made on the fly (pool_dgrad's W diag(C) W^T) can get an image too (votenet_split_weights_one + a registration around the
+# one launch).  Measured, same box (tools/ab_step.py mlp.SPLIT_ADHOC False True): 6.25 -> 6.35 ms per step -- those GEMMs run beside
+# the weight-gradient stream and are bound by the traffic they share with it, not by the matrix pipe; the extra launch sits on the
+# backward pass's dependent chain.  Off.
+SPLIT_ADHOC = False
+SPLIT_ADHOC_ROWS = 65536
+
+
 def split_eligible(cin, cout):
     """Shapes whose GEMMs can read a bf16 x 3 image of the weights (mlp_fast.hip, BF3): whole 16-row slabs, 64-column blocks."""
     return cin % 32 == 0 and cin <= 512 and cout % 64 == 0
@@ -605,7 +613,18 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     cout = w.shape[1]
     if mm is None:
         mm = pool_dgrad_prepare(w, bias, coef)
-    da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
+    if SPLIT_ADHOC and split_eligible(cin, cin) and rows >= SPLIT_ADHOC_ROWS:
+        # the matrix exists only for this launch: its bf16 x 3 image (one small launch), registered around the GEMM's launch only
+        img = torch.empty(cin * cin * 6, dtype=torch.uint8, device=xz.device)
+        with L.device_guard(xz.device):
+            L.check(L.lib().votenet_split_weights_one(L.ptr(mm), cin, cin, L.ptr(img), L.stream_ptr()))
+        L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(img)))
+        try:
+            da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
+        finally:
+            L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, None)
+    else:
+        da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
     sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
     bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)
     t, coef_b = _coef_tail(below_tail if below is not None else None, cin, xz.device)
