@@ -474,7 +474,8 @@ int votenet_transpose_segments(int nseg, const long *table, const float *src, fl
 int votenet_split_weights(int nseg, const long *table, void *stream);
 int votenet_split_weights_one(const float *w, int cin, int cout, void *image, void *stream); /* one matrix, arguments by value */
 int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3);
-/* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used */
+/* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used; another
+ * value: a mask over GEMM families (mlp_fast.hip, bf3_family) */
 void votenet_debug_fast_bf3(int on);
 
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */

@@ -1,0 +1,174 @@
+"""GPU: the fused GEMMs on bf16 x 3 split operands (mlp_fast.hip, BF3) -- fp32 operands split EXACTLY into three bf16 pieces,
+six v_mfma_f32_32x32x16_bf16 per k-step, fp32 accumulate -- against the CPU oracle (oracle/oracle_mlp.c), float64, and the
+fp32 MFMA kernels they replace.  Tolerance: the one tests/test_gpu_mlp.py holds the fp32 kernels to (1e-5 of the magnitude of
+the accumulated products); the split's own error (the three dropped cross terms) is < 2^-23 of a product."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def N(t):
+    return t.detach().cpu().numpy()
+
+
+def split3_numpy(w):
+    """The kernel's split restated: truncate to the upper 16 bits, subtract (exact), twice."""
+    u = w.view(np.uint32)
+    hi = (u & 0xFFFF0000).view(np.float32)
+    r1 = w - hi
+    mid = (r1.view(np.uint32) & 0xFFFF0000).view(np.float32)
+    lo = r1 - mid
+    return hi, mid, lo
+
+
+@pytest.fixture()
+def bf3(hiplib):
+    """Restore the default (images are used) whatever the test switched."""
+    yield hiplib
+    hiplib.votenet_debug_fast_bf3(1)
+
+
+def test_the_split_is_exact_and_the_image_has_the_kernels_lds_order(bf3, dev):
+    from votenet_amd import mlp
+    rng = np.random.default_rng(0)
+    cin, cout = 64, 128
+    w = (rng.normal(size=(cin, cout)) * np.exp(rng.uniform(-20, 20, size=(cin, cout)))).astype(np.float32)  # every exponent range
+    w[0, 0], w[1, 1], w[2, 2] = 0.0, -0.0, np.float32(2.0 ** -120)
+    hi, mid, lo = split3_numpy(w)
+    assert ((hi.astype(np.float64) + mid.astype(np.float64) + lo.astype(np.float64)) == w.astype(np.float64)).all()
+    assert ((lo.view(np.uint32) & 0xFFFF) == 0).all()  # the third piece is a bf16 already: nothing is left over
+    wt = T(w, dev)
+    img = mlp.SplitImages([wt])
+    img.refresh()
+    torch.cuda.synchronize()
+    got = N(img.buf).view(np.uint16)[:cin * cout * 3].reshape(cin // 16, 3, 2, cout, 8)  # [slab][piece][k-half][column][8 bf16]
+    for p, piece in enumerate((hi, mid, lo)):
+        exp = (piece.view(np.uint32) >> 16).astype(np.uint16).reshape(cin // 16, 2, 8, cout).transpose(0, 1, 3, 2)
+        assert (got[:, p] == exp).all(), "piece %d of the image differs" % p
+    img.close()
+
+
+@pytest.mark.parametrize("rows,cin,cout,pool", [(4096, 64, 64, 0), (8192, 64, 128, 64), (4096, 128, 128, 0), (8192, 128, 256, 64),
+                                                (2048, 256, 256, 0), (1024, 512, 256, 0), (640, 256, 320, 0), (256, 128, 128, 0)])
+def test_bf3_gemm_vs_oracle_float64_and_the_fp32_mfma_kernel(bf3, dev, O, rows, cin, cout, pool):
+    from votenet_amd import mlp
+    rng = np.random.default_rng(rows + cin + cout)
+    x = (rng.normal(size=(rows, cin)) * 2 + 0.3).astype(np.float32)
+    w = (rng.normal(size=(cin, cout)) * np.sqrt(2.0 / cin)).astype(np.float32)
+    b = rng.normal(size=cout).astype(np.float32)
+    sc = (rng.random(cin) + 0.5).astype(np.float32)
+    sh = (rng.normal(size=cin) * 0.2).astype(np.float32)
+    xt, wt, bt, sct, sht = (T(a, dev) for a in (x, w, b, sc, sh))
+    img = mlp.SplitImages([wt])
+    img.refresh()
+
+    def run():
+        if pool:
+            z, st, pl = mlp.linear_dense_pool(xt, wt, pool, bt, sct, sht, True, keep_z=True)
+            return N(z), N(st), [N(p) for p in pl]
+        z, st = mlp.linear_dense(xt, wt, bt, sct, sht, True)
+        return N(z), N(st), None
+    bf3.votenet_debug_fast_bf3(1)
+    z3, st3, pl3 = run()
+    bf3.votenet_debug_fast_bf3(0)
+    z0, st0, pl0 = run()
+    a = np.maximum(x * sc + sh, 0.0).astype(np.float32)   # the folded BatchNorm + ReLU of the loader, in fp32 as the kernel does
+    oz = O.linear(a, w, b)
+    ref = a.astype(np.float64) @ w.astype(np.float64) + b
+    bound = max(1.0, float((np.abs(a) @ np.abs(w)).max()))
+    assert np.abs(z3 - oz).max() <= 1e-5 * bound          # the oracle, at the fp32 kernels' tolerance
+    e3, e0 = np.abs(z3 - ref).max() / bound, np.abs(z0 - ref).max() / bound
+    assert e3 <= 2e-6 and e3 <= 2.0 * e0 + 2e-7, "bf16 x 3: %.3g of the product magnitude, fp32 MFMA: %.3g" % (e3, e0)
+    assert not np.array_equal(z3, z0)                     # the two modes did run different kernels
+    sref = np.concatenate([ref.sum(0), (ref * ref).sum(0)])
+    assert np.allclose(st3, sref, rtol=1e-5, atol=1e-3 * bound)
+    if pool:
+        g = z3.reshape(rows // pool, pool, cout)
+        assert (pl3[0] == g.max(1)).all() and (pl3[1] == g.min(1)).all()
+        assert (pl3[2] == g.argmax(1)).all() and (pl3[3] == g.argmin(1)).all()
+    img.close()
+
+
+def test_a_matrix_without_an_image_runs_the_fp32_kernel_whatever_the_switch(bf3, dev):
+    from votenet_amd import mlp
+    rng = np.random.default_rng(5)
+    x, w = T(rng.normal(size=(4096, 128)).astype(np.float32), dev), T((rng.normal(size=(128, 128)) * 0.1).astype(np.float32), dev)
+    bf3.votenet_debug_fast_bf3(1)
+    za, _ = mlp.linear_dense(x, w)
+    bf3.votenet_debug_fast_bf3(0)
+    zb, _ = mlp.linear_dense(x, w)
+    assert torch.equal(za, zb)
+    img = mlp.SplitImages([w])
+    img.refresh()
+    bf3.votenet_debug_fast_bf3(1)
+    zc, _ = mlp.linear_dense(x, w)
+    assert not torch.equal(zc, za) and float((zc - za).abs().max()) < 1e-4
+    img.close()  # the registration is withdrawn: the fp32 kernel again
+    zd, _ = mlp.linear_dense(x, w)
+    assert torch.equal(zd, za)
+
+
+def test_dgrad_with_the_batchnorm_backward_folded_in_on_split_operands(bf3, dev):
+    """votenet_mlp_dgrad_bn (loader SRC 1: dz = A g + B + C z with the ReLU mask) on an image of W^T against float64."""
+    from votenet_amd import mlp
+    rng = np.random.default_rng(9)
+    rows, c, cprev = 4096, 128, 128
+    z = T(rng.normal(size=(rows, c)).astype(np.float32), dev)
+    da = T(rng.normal(size=(rows, c)).astype(np.float32), dev)
+    coef = T(np.concatenate([rng.random(c) + 0.5, rng.normal(size=c) * 0.1, rng.normal(size=c) * 0.1, rng.random(c) + 0.5,
+                             rng.normal(size=c) * 0.2]).astype(np.float32), dev)
+    wT = T((rng.normal(size=(c, cprev)) * 0.1).astype(np.float32), dev)
+    img = mlp.SplitImages([wT])
+    img.refresh()
+    outs = []
+    for mode in (1, 0):
+        bf3.votenet_debug_fast_bf3(mode)
+        outs.append(mlp.dgrad_bn(z, coef, True, wT, da=da))
+    A, Bc, C, S, H = (coef[i * c:(i + 1) * c].double() for i in range(5))
+    g = torch.where(z.double() * S + H > 0, da.double(), torch.zeros_like(da, dtype=torch.float64))
+    ref = (A * g + Bc + C * z.double()) @ wT.double()
+    bound = float(((A * g + Bc + C * z.double()).abs() @ wT.double().abs()).max())
+    e3, e0 = float((outs[0].double() - ref).abs().max()) / bound, float((outs[1].double() - ref).abs().max()) / bound
+    assert e3 <= 2e-6 and e3 <= 2.0 * e0 + 2e-7
+    img.close()
+
+
+def test_forward_rebuilds_the_images_after_the_weights_changed_by_hand(bf3, dev):
+    from votenet_amd import model as VM, synth
+    x = torch.from_numpy(synth.room_batch(2, 4096, 3)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=1, npoints=(512, 256, 128, 64))
+    bf3.votenet_debug_fast_bf3(1)
+    key = "proposals_output"
+    a = net.forward(x)[key]
+    name = [n for n, v in net.store.views.items() if n.startswith("sa2") and v.dim() == 2 and v.shape == (128, 128)][0]
+    net.store[name].add_(torch.randn_like(net.store[name]) * 0.1)  # by hand, behind the store's back (a scaling would vanish in the BatchNorm)
+    b3 = net.forward(x)[key]
+    bf3.votenet_debug_fast_bf3(0)
+    b0 = net.forward(x)[key]
+    assert not torch.allclose(a, b0, rtol=1e-3, atol=1e-3)          # the change is visible ...
+    scale = float(b0.abs().max())
+    assert float((b3 - b0).abs().max()) <= 2e-4 * max(1.0, scale)  # ... and the BF3 pass saw the same weights (a stale image would not)
+
+
+def test_train_step_on_split_operands_agrees_with_the_fp32_mfma_step(bf3, dev):
+    from votenet_amd import loss as VL, model as VM, synth
+    x = torch.from_numpy(synth.room_batch(2, 4096, 7)).to(dev)
+    gt = VL.gt_to_device(synth.room_gt(2, 4096, 7), dev)
+    grads = []
+    for mode in (1, 0):
+        bf3.votenet_debug_fast_bf3(mode)
+        net = VM.VoteNetHotPath(dev, seed=2, npoints=(512, 256, 128, 64))
+        net.train_step(x, gt=gt)
+        torch.cuda.synchronize()
+        grads.append(net.store.grad.clone())
+        del net
+    g3, g0 = grads
+    assert torch.isfinite(g3).all()
+    num, den = float((g3 - g0).norm()), float(g0.norm())
+    assert num <= 2e-3 * den, "gradient of the whole step: |bf3 - fp32| / |fp32| = %.3g" % (num / den)

@@ -1,0 +1,20 @@
+"""Same-box A/B of the train step over masks of BF3 GEMM families (votenet_debug_fast_bf3): python ab_bf3_mask.py 63 1 3 ..."""
+import os, sys, time, gc
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
+import torch
+from votenet_amd import loss as VL, model as VM, synth, _lib as L
+dev = torch.device("cuda:0")
+B, n = 8, 20480
+xs = [torch.from_numpy(synth.room_batch(B, n, s)).to(dev) for s in (1000, 500000, 900000)]
+gts = [VL.gt_to_device(synth.room_gt(B, n, s), dev) for s in (1000, 500000, 900000)]
+net = VM.VoteNetHotPath(dev, seed=0)
+def run(k):
+    for i in range(k):
+        net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
+masks = [int(v) for v in sys.argv[1:]]
+for rep in range(3):
+    for v in masks:
+        L.lib().votenet_debug_fast_bf3(v if v != 1 else 1)
+        run(6); torch.cuda.synchronize(); gc.collect(); gc.disable()
+        t0 = time.perf_counter(); run(40); torch.cuda.synchronize(); dt = time.perf_counter() - t0; gc.enable()
+        print("mask %2d: train %.3f ms per step" % (v, dt / 40 * 1e3), flush=True)

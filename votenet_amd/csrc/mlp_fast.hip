@@ -533,6 +533,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const int kh = lane >> 5, l31 = lane & 31;
     int buf = 0;
     abl_prologue = false;
+    constexpr int MX = MT > NT ? MT : NT;
+    uint4 fAlo[MX], fWhi[MX], fAhi[MX], fWmid[MX], fX[2][MX]; // BF3: fragments that live across slabs (see the slab body)
+    if constexpr (BF3) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) {
+            fAlo[i] = *reinterpret_cast<const uint4 *>(&As3[0][2][kh][((wm * MT + i) * 32 + l31) * 4]);
+            fX[0][i] = *reinterpret_cast<const uint4 *>(&As3[0][1][kh][((wm * MT + i) * 32 + l31) * 4]);
+        }
+#pragma unroll
+        for (int j = 0; j < NT; j++) fWhi[j] = *reinterpret_cast<const uint4 *>(&Bs3[0][0][kh][((wn * NT + j) * 32 + l31) * 4]);
+    }
     for (long t = 0; t < my_tiles; t++) {
         f32x16 acc[MT][NT];
 #pragma unroll
@@ -549,46 +560,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             for (int par = 0; par < NSETS; par++) {
                 Regs &rs = R[(par + 1) % NSETS];
                 if constexpr (BF3) {
-                    // one slab = ONE k-step of v_mfma_f32_32x32x16_bf16 per piece pair: six per 32x32 sub-tile, small terms first
-                    uint4 fa[3][MT], fb[3][NT];
-                    constexpr int orda[3] = {2, 0, 1}, ordw[3] = {0, 2, 1}; // in the order the MFMAs below need them
+                    // One slab = ONE k-step of v_mfma_f32_32x32x16_bf16 per piece pair, six per 32x32 sub-tile.  The slab's barrier
+                    // sits in the MIDDLE: the products before it run while the next slab is staged into the other buffer, the
+                    // products behind it while the first fragments of the next slab (A.lo, W.hi, A.mid) are read from that buffer
+                    // into registers whose pieces are dead by then -- the matrix pipe never waits for an LDS read behind a
+                    // barrier.  (With the barrier at the end of the slab the two waves of a SIMD fall into step: both read
+                    // fragments, then both want the matrix pipe; the bare loop ran at 68 % of it.)
+                    // Pieces: A.lo, W.hi, A.hi, W.mid in fixed registers; A.mid and W.lo swap two blocks by slab parity.
+                    auto rdA = [&](uint4(&f)[MX], int piece, int b) {
 #pragma unroll
-                    for (int q = 0; q < 3; q++) {
+                        for (int i = 0; i < MT; i++) f[i] = *reinterpret_cast<const uint4 *>(&As3[b][piece][kh][((wm * MT + i) * 32 + l31) * 4]);
+                    };
+                    auto rdW = [&](uint4(&f)[MX], int piece, int b) {
 #pragma unroll
-                        for (int i = 0; i < MT; i++)
-                            fa[orda[q]][i] = *reinterpret_cast<const uint4 *>(&As3[buf][orda[q]][kh][((wm * MT + i) * 32 + l31) * 4]);
-#pragma unroll
-                        for (int j = 0; j < NT; j++)
-                            fb[ordw[q]][j] = *reinterpret_cast<const uint4 *>(&Bs3[buf][ordw[q]][kh][((wn * NT + j) * 32 + l31) * 4]);
-                    }
-                    auto mm = [&](int pa, int pw) {
+                        for (int j = 0; j < NT; j++) f[j] = *reinterpret_cast<const uint4 *>(&Bs3[b][piece][kh][((wn * NT + j) * 32 + l31) * 4]);
+                    };
+                    auto mm = [&](const uint4(&fa_)[MX], const uint4(&fw_)[MX]) {
                         if (BF3_ABL & 1) {
-                            acc[0][0][0] += __uint_as_float(fa[pa][0].x ^ fb[pw][0].y);
+                            acc[0][0][0] += __uint_as_float(fa_[0].x ^ fw_[0].y);
                             return;
                         }
 #pragma unroll
                         for (int i = 0; i < MT; i++)
 #pragma unroll
                             for (int j = 0; j < NT; j++)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][i]),
-                                                                                    __builtin_bit_cast(bf16x8, fb[pw][j]), acc[i][j], 0, 0, 0);
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]),
+                                                                                    __builtin_bit_cast(bf16x8, fw_[j]), acc[i][j], 0, 0, 0);
                     };
-                    mm(2, 0);
-                    mm(0, 2);
-                    mm(1, 1);
-                    store_regs(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
-                    issue_loads(rs);
-                    mm(1, 0);
-                    mm(0, 1);
-                    mm(0, 0);
-                    // one MFMA (32 cycles on the SIMD's matrix pipe), then BF3_VPM vector instructions of the staging arithmetic
-                    // beside it: without this the 6 MT NT MFMAs come in two clumps around ~150 VALU instructions
-#pragma unroll
-                    for (int g = 0; g < 6 * MT * NT; g++) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                        __builtin_amdgcn_sched_group_barrier(0x002, BF3_VPM, 0);
-                    }
+                    rdA(fAhi, 0, buf);
+                    rdW(fWmid, 1, buf);
+                    rdW(fX[par ^ 1], 2, buf); // W.lo
+                    mm(fAlo, fWhi);
+                    mm(fX[par], fWhi); // A.mid
+                    store_regs(buf ^ 1, rs); // the other buffer was last read before the previous slab's barrier
+                    mm(fAhi, fWhi);
                     lds_barrier();
+                    rdA(fAlo, 2, buf ^ 1);
+                    rdW(fWhi, 0, buf ^ 1);
+                    mm(fAhi, fX[par ^ 1]); // W.lo: its block is free from here on
+                    __builtin_amdgcn_sched_barrier(0);
+                    rdA(fX[par ^ 1], 1, buf ^ 1); // the next slab's A.mid
+                    issue_loads(rs);
+                    mm(fAhi, fWmid);
+                    mm(fX[par], fWmid);
                     buf ^= 1;
                     continue;
                 }
@@ -931,12 +945,19 @@ static const unsigned *w3_lookup(const float *w, int cin, int cout)
     return (it != g_w3.end() && it->second.cin == cin && it->second.cout == cout) ? it->second.w3 : nullptr;
 }
 
-int g_fast_bf3 = 1; // 1: the (SRC, EPI) pairs bf3_built() lists run on bf16 x 3 split operands (votenet_debug_fast_bf3)
+int g_fast_bf3 = 63; // 1: the (SRC, EPI) pairs bf3_built() lists run on bf16 x 3 split operands (votenet_debug_fast_bf3)
 template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
+// g_fast_bf3 is a mask over GEMM families (votenet_debug_fast_bf3): bit 0 forward with statistics / pooling (EPI 0, 2), 1 plain
+// forward-type (EPI 1 from x / narrow / assembled), 2 BatchNorm-backward dgrad (SRC 1, 2 with EPI 1), 3 dgrad reducing the layer
+// below (EPI 3), 4 the same over an assembled layer (EPI 6), 5 over a narrow layer (EPI 4)
+template <int SRC, int EPI> constexpr int bf3_family()
+{
+    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : EPI == 4 ? 5 : (SRC == 1 || SRC == 2) ? 2 : 1;
+}
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
         if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
-            if (g_fast_bf3 && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
+            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
                 hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), 0, ST_, A_);    \
                 break;                                                                                                               \
             }                                                                                                                        \
@@ -1185,7 +1206,7 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     return check_launch("narrow_dgrad_bn_reduce");
 }
 
-extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = on; }
+extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = (on == 1) ? 63 : on; } // 0 off, 1 every family, else a mask
 
 // BF3 weight images.  table (device, 4 longs per segment): source address (cin x cout floats, row-major), image address
 // (cin * cout * 6 bytes, 16-byte aligned), cin (% 16 == 0), cout.  One launch for all segments.
