@@ -37,6 +37,9 @@ constexpr int FG_LDA = FG_BM + 2;
 #ifndef BF3_SETS
 #define BF3_SETS 2 // BF3: register sets of raw operands in flight (slabs of lead); cin % (16 * BF3_SETS) == 0
 #endif
+#ifndef BF3_PRIO
+#define BF3_PRIO 0 // BF3: 1 = matrix loop at s_setprio 1, epilogue at 0; 2 = the reverse; 3 = prio 1 only around the MFMAs of a slab
+#endif
 #ifndef BF3_ABL
 #define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging
 #endif
@@ -402,14 +405,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if constexpr (BF3 && (SRC == 0 || SRC == 3 || SRC == 4)) {
             const float4 sc = *reinterpret_cast<const float4 *>(&Sco[0][rk]);
             const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
-            v.x = v.x * sc.x + sh.x;
-            v.y = v.y * sc.y + sh.y;
-            v.z = v.z * sc.z + sh.z;
-            v.w = v.w * sc.w + sh.w;
-            v.x = v.x > relu_floor ? v.x : relu_floor;
-            v.y = v.y > relu_floor ? v.y : relu_floor;
-            v.z = v.z > relu_floor ? v.z : relu_floor;
-            v.w = v.w > relu_floor ? v.w : relu_floor;
+            // the same two roundings as the fp32 loader (mul, add: every consumer of this BatchNorm sees one ReLU mask); the ReLU as
+            // one v_max against the uniform floor (the staging arithmetic is issue-bound: T ~ 4 N_valu + 32 N_mfma per SIMD)
+            v.x = __builtin_fmaxf(v.x * sc.x + sh.x, relu_floor);
+            v.y = __builtin_fmaxf(v.y * sc.y + sh.y, relu_floor);
+            v.z = __builtin_fmaxf(v.z * sc.z + sh.z, relu_floor);
+            v.w = __builtin_fmaxf(v.w * sc.w + sh.w, relu_floor);
             return v;
         }
         if (SRC == 0 || SRC == 3 || SRC == 4) {
@@ -545,6 +546,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         for (int j = 0; j < NT; j++) fWhi[j] = *reinterpret_cast<const uint4 *>(&Bs3[0][0][kh][((wn * NT + j) * 32 + l31) * 4]);
     }
     for (long t = 0; t < my_tiles; t++) {
+        if (BF3 && BF3_PRIO == 1) __builtin_amdgcn_s_setprio(1);
+        if (BF3 && BF3_PRIO == 2) __builtin_amdgcn_s_setprio(0);
         f32x16 acc[MT][NT];
 #pragma unroll
         for (int i = 0; i < MT; i++)
@@ -580,12 +583,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                             acc[0][0][0] += __uint_as_float(fa_[0].x ^ fw_[0].y);
                             return;
                         }
+                        if (BF3_PRIO == 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
                         for (int i = 0; i < MT; i++)
 #pragma unroll
                             for (int j = 0; j < NT; j++)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]),
                                                                                     __builtin_bit_cast(bf16x8, fw_[j]), acc[i][j], 0, 0, 0);
+                        if (BF3_PRIO == 3) __builtin_amdgcn_s_setprio(0);
                     };
                     rdA(fAhi, 0, buf);
                     rdW(fWmid, 1, buf);
@@ -635,6 +640,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 buf ^= 1;
             }
         }
+        if (BF3 && BF3_PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        if (BF3 && BF3_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
         const long m0 = ((long)blockIdx.x + t * gridDim.x) * FG_BM;
         // row pitch in bytes as an opaque scalar: the per-row scalar offsets of the buffer accesses below are then formed here,
