@@ -58,7 +58,11 @@ lines = ["# rocprofv3 --pmc on tools/pmc_mlp.py (separate passes: SQ_VALU_MFMA_B
          "# two layers, 17.18 GFLOP each: sa1 L2 = 1048576 x 64 -> 128 (HBM-bound), sa2 L2 = 262144 x 128 -> 256 (MFMA-bound)",
          "# SQ/GRBM counters per XCD (means).  SQ_VALU_MFMA_BUSY_CYCLES in quad-cycles: MfmaUtil = 4 * MFMA_BUSY / (128 SIMDs per XCD * GRBM_GUI_ACTIVE);",
          "# clock = GRBM_GUI_ACTIVE / duration.  FETCH_SIZE doubled (gfx950), KB -> MB.",
-         "%-44s %8s %9s %9s %8s %9s %10s %10s" % ("kernel", "avg_us", "MfmaUtil", "GHz", "TFLOP/s", "of_157.3", "HBM_rd_MB", "HBM_wr_MB")]
+         "# Last template argument true = BF3: the products on six v_mfma_f32_32x32x16_bf16 of exactly split operands (32 busy cycles each)",
+         "# instead of eight v_mfma_f32_32x32x2_f32 (64 each) per 16-deep slab -- MfmaUtil is the matrix pipe's busy share either way,",
+         "# TFLOP/s the fp32 multiply-adds of the GEMM per second, of_157.3 that against the fp32 MFMA peak (what an fp32-MFMA kernel",
+         "# could reach at most is 1.0).  The first pass of tools/pmc_mlp.py runs the same launches on the fp32 kernels (false).",
+         "%-52s %8s %9s %9s %8s %9s %10s %10s" % ("kernel", "avg_us", "MfmaUtil", "GHz", "TFLOP/s", "of_157.3", "HBM_rd_MB", "HBM_wr_MB")]
 for k, (c, us, v) in sq.items():
     if "mlp_" not in k:
         continue
@@ -66,7 +70,7 @@ for k, (c, us, v) in sq.items():
     tf = 17.18e9 / (us * 1e-6) / 1e12
     rd = 2 * mf.get(k, (0, 0, [0.0]))[2][0] / 1024
     w = mw.get(k, (0, 0, [0.0]))[2][0] / 1024
-    lines.append("%-44s %8.1f %9.3f %9.2f %8.1f %9.3f %10.1f %10.1f" % (k[:44], us, 4 * mfma / (128 * gui), gui / us / 1e3, tf, tf / 157.3, rd, w))
+    lines.append("%-52s %8.1f %9.3f %9.2f %8.1f %9.3f %10.1f %10.1f" % (k[:52], us, 4 * mfma / (128 * gui), gui / us / 1e3, tf, tf / 157.3, rd, w))
 open(os.path.join(P, "%s_pmc_mlp.txt" % tag), "w").write("\n".join(lines) + "\n")
 print(open(os.path.join(P, "%s_pmc_fps.txt" % tag)).read())
 print(open(os.path.join(P, "%s_pmc_mlp.txt" % tag)).read())
