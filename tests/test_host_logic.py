@@ -60,3 +60,25 @@ def test_narrow_statistics_algebra():
     dz0 = A * g + B + C * z0
     dw0 = A * (u.T @ g) + np.outer(m, B) + C * (M2 @ w0 + np.outer(m, b0))
     assert np.allclose(dw0, u.T @ dz0, rtol=1e-10, atol=1e-9)
+
+
+def test_split_image_eligibility_and_cpu_store_is_inert():
+    """Which weight matrices get a bf16 x 3 image (mlp.SplitImages), and that a store on the CPU (the gloo tests) never touches
+    the device library for it."""
+    from votenet_amd import mlp as M
+    from votenet_amd import pointnet2 as P
+    assert M.split_eligible(64, 64) and M.split_eligible(128, 256) and M.split_eligible(512, 256) and M.split_eligible(256, 320)
+    assert not M.split_eligible(3, 64)       # first layers: the bounds-checked kernels
+    assert not M.split_eligible(259, 256)    # ragged input width: its padded copy (320) is eligible instead
+    assert not M.split_eligible(128, 79)     # ragged output width
+    assert not M.split_eligible(1024, 256)   # beyond the fused kernel's cin
+    imgs = M.SplitImages([torch.zeros(3, 64), torch.zeros(7)])  # nothing eligible: no buffer, no registration, refresh is a no-op
+    assert imgs.nseg == 0
+    imgs.refresh()
+    imgs.close()
+    s = P.ParamStore(torch.device("cpu"))
+    P.SAModule(s, "sa", 64, 0.4, 16, 128, [128, 128, 256])
+    s.materialize(0)
+    s.enable_split(True)
+    s.refresh_split()  # parameters not on a GPU: returns before any library call
+    assert s._split_flat is None
