@@ -958,6 +958,7 @@ static const unsigned *w3_lookup(const float *w, int cin, int cout)
     return (it != g_w3.end() && it->second.cin == cin && it->second.cout == cout) ? it->second.w3 : nullptr;
 }
 
+int g_fast_dyn_lds = 0; // probe (votenet_debug_fast_dyn_lds): unused dynamic LDS per BF3 workgroup, to lower the occupancy
 int g_fast_bf3 = 63; // 1: the (SRC, EPI) pairs bf3_built() lists run on bf16 x 3 split operands (votenet_debug_fast_bf3)
 template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
 // g_fast_bf3 is a mask over GEMM families (votenet_debug_fast_bf3): bit 0 forward with statistics / pooling (EPI 0, 2), 1 plain
@@ -971,7 +972,7 @@ template <int SRC, int EPI> constexpr int bf3_family()
     do {                                                                                                                             \
         if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
             if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
-                hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), 0, ST_, A_);    \
+                hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_);    \
                 break;                                                                                                               \
             }                                                                                                                        \
         }                                                                                                                            \
@@ -1219,6 +1220,7 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     return check_launch("narrow_dgrad_bn_reduce");
 }
 
+extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }
 extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = (on == 1) ? 63 : on; } // 0 off, 1 every family, else a mask
 
 // BF3 weight images.  table (device, 4 longs per segment): source address (cin x cout floats, row-major), image address
