@@ -45,3 +45,12 @@ def dev():
     import torch
     assert torch.cuda.is_available(), "gpu-marked test run without a GPU"
     return torch.device("cuda:0")
+
+
+@pytest.fixture(params=[1, 0], ids=["bf16x3_images", "fp32_mfma"])
+def gemm_form(request, hiplib):
+    """The fused GEMMs on bf16 x 3 images of the weights (the model's default; a test that wants them registers its matrices with
+    mlp.SplitImages) or on the fp32 MFMA kernels (votenet_debug_fast_bf3(0): registered images are ignored)."""
+    hiplib.votenet_debug_fast_bf3(request.param)
+    yield request.param
+    hiplib.votenet_debug_fast_bf3(1)

@@ -13,7 +13,7 @@ def relerr(a, b):
 
 @pytest.mark.parametrize("b,n,m,k,cf,c0,c1,radius", [(2, 600, 64, 64, 128, 128, 128, 0.5), (1, 400, 32, 64, 16, 64, 64, 0.3),
                                                      (2, 300, 16, 32, 32, 128, 256, 0.25), (1, 500, 8, 16, 8, 64, 320, 2.0)])
-def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, b, n, m, k, cf, c0, c1, radius):
+def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_form, b, n, m, k, cf, c0, c1, radius):
     from votenet_amd import mlp as M
     from votenet_amd import tf_grouping, tf_sampling
     g = torch.Generator().manual_seed(3 * n + cf)
@@ -27,6 +27,9 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, b, n,
     assert M.assembled_supported(rows, c0, c1)
     w0, b0, w1 = rnd(3 + cf, c0) * 0.3, rnd(c0) * 0.1, rnd(c0, c1) * 0.2
     wx = w0[:3].contiguous()
+    wT = w1.t().contiguous()
+    img = M.SplitImages([w1, wT])  # the second layer's forward (SRC 4 / SRC 0) and input-gradient (EPI 6 / EPI 3) GEMMs when gemm_form == 1
+    img.refresh()
     P, _ = M.linear_dense(feat.reshape(b * n, cf), w0[3:].contiguous(), b0, want_stats=False)
     # geometry records and the per-point sums (padding slots repeat slot 0: with and without pts_cnt the sums agree)
     geo, cntv, mom = M.assemble_rows(xyz, new_xyz, idx, pts_cnt=cnt)
@@ -63,7 +66,6 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, b, n,
     M.assembled_wgrad_bn(geo, P, wx, bn0.scale, bn0.shift, True, z1, coef1, True, da1, dw)
     M.wgrad_dense_bn(z0, z1, coef1, True, dwm, da=da1, in_scale=bn0.scale, in_shift=bn0.shift, in_relu=True)
     assert relerr(dw, dwm) < 1e-5
-    wT = w1.t().contiguous()
     below = (bn0.scale, bn0.shift, bn0.mean, bn0.var, True)
     da0, sums = M.assembled_dgrad_bn_reduce(z1, coef1, True, wT, da1, geo, P, wx, below)
     da0m, sumsm = M.dgrad_bn(z1, coef1, True, wT, da=da1, below=(z0,) + below)
@@ -76,6 +78,7 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, b, n,
     S, _ = M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, P, wx, da0, coef0, True, dwx)
     Sm, _ = M.group_linear_backward(xyz, new_xyz, idx, cnt, z0, da0, coef0, True, dwxm)
     assert relerr(S, Sm) < 1e-5 and relerr(dwx, dwxm) < 1e-4
+    img.close()
 
 
 def test_model_with_and_without_the_assembled_first_layers(hiplib, dev):

@@ -74,14 +74,6 @@ def perturb(net, dev):
             v.copy_((0.1 * torch.randn(v.shape, generator=g)).to(dev))
 
 
-@pytest.fixture(params=[1, 0], ids=["bf16x3_images", "fp32_mfma"])
-def gemm_form(request, hiplib):
-    """The fused GEMMs on bf16 x 3 images of the weights (default) or on the fp32 MFMA kernels."""
-    hiplib.votenet_debug_fast_bf3(request.param)
-    yield request.param
-    hiplib.votenet_debug_fast_bf3(1)
-
-
 def test_full_backward_vs_autograd(hiplib, dev, gemm_form):
     from votenet_amd import model as VM
     from votenet_amd import synth

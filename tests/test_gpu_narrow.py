@@ -31,9 +31,12 @@ def setup(dev, b, n, m, k, c, c0, c1, seed):
 
 @pytest.mark.parametrize("b,n,m,k,c,c0,c1", [(2, 500, 64, 64, 3, 64, 64), (1, 300, 32, 64, 1, 128, 128), (2, 256, 16, 64, 0, 64, 128),
                                              (1, 400, 8, 16, 5, 64, 64)])
-def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, b, n, m, k, c, c0, c1):
+def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_form, b, n, m, k, c, c0, c1):
     from votenet_amd import mlp as M
     xyz, new_xyz, feat, idx, w0, b0, w1, rows_in, rnd = setup(dev, b, n, m, k, c, c0, c1, 7 * n + c)
+    wT = w1.t().contiguous()
+    img = M.SplitImages([w1, wT])  # used by the second layer's forward (SRC 3) and input-gradient (EPI 4) GEMMs when gemm_form == 1
+    img.refresh()
     rows, k0 = rows_in.shape
     assert M.narrow_supported(rows, k0, c0, c1)
     # u8 and its moments
@@ -66,7 +69,6 @@ def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, b, n, m,
     M.narrow_wgrad_bn(u8, w0, b0, bn0.scale, bn0.shift, True, z1, coef1, True, da1, dw1)
     a0f = torch.relu((u8[:, :k0].double() @ w0.double() + b0.double()) * bn0.scale.double() + bn0.shift.double())
     assert relerr(dw1, a0f.t() @ dz1) < 2e-5
-    wT = w1.t().contiguous()
     sums, ug = M.narrow_dgrad_bn_reduce(z1, coef1, True, wT, da1, u8, w0, b0, (bn0.scale, bn0.shift, bn0.mean, bn0.var, True))
     da0 = dz1 @ w1.double().t()
     act = (z0 * bn0.scale.double() + bn0.shift.double()) > 0
@@ -84,6 +86,7 @@ def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, b, n, m,
     dw0 = torch.zeros(k0, c0, device=dev)
     M.narrow_wgrad_first(mom, ug, coef0, w0, b0, dw0)
     assert relerr(dw0, ud[:, :k0].t() @ dz0) < 2e-5
+    img.close()
 
 
 def test_narrow_kernels_reject_unserved_shapes(hiplib, dev):
