@@ -173,27 +173,103 @@ __global__ __launch_bounds__(64) void iou3d_cross_kernel(int n, int m, const flo
     iou[((size_t)scene * n + i) * m + j] = iou3d_pair(bi, bj);
 }
 
-// visit order: rank[e] = number of candidates visited before flat element e; -1 if not a candidate
-__global__ void nms_rank_kernel(int total, const float *__restrict__ scores, const float *__restrict__ obj,
-                                int *__restrict__ order /* rank -> flat index */, int *__restrict__ ncand)
+// visit order: rank[e] = number of candidates visited before flat element e; -1 if not a candidate.
+// The scores and candidate flags of ALL boxes of the batch are walked by every candidate: they are staged through LDS in chunks
+// (one coalesced pass per workgroup) and read back as broadcasts -- the loop over global memory took 213 us for 8 x 256 boxes.
+constexpr int NMS_RANK_CHUNK = 2048;
+__global__ __launch_bounds__(256) void nms_rank_kernel(int total, const float *__restrict__ scores, const float *__restrict__ obj,
+                                                       int *__restrict__ order /* rank -> flat index */, int *__restrict__ ncand)
 {
+    __shared__ float2 s_sc[NMS_RANK_CHUNK]; // (score with NaN -> -inf, 1.0 if candidate else 0.0)
     const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= total) return;
-    const bool cand = obj[e * 2 + 1] > obj[e * 2]; // tf_nms3d.cpp:230
-    if (!cand) return;
+    const bool live = e < total;
+    const bool cand = live && obj[e * 2 + 1] > obj[e * 2]; // tf_nms3d.cpp:230
     // a TOTAL order even for the scores of a diverged model: NaN ranks with -inf (visited last), ties by flat index --
     // every candidate gets its own rank, so order[0 .. ncand) is a permutation of the candidates
-    const float s0 = scores[e];
+    const float s0 = live ? scores[e] : 0.0f;
     const float s = (s0 != s0) ? -__builtin_inff() : s0;
     int rank = 0;
-    for (int f = 0; f < total; f++) {
-        const bool fc = obj[f * 2 + 1] > obj[f * 2];
-        const float t0 = scores[f];
-        const float t = (t0 != t0) ? -__builtin_inff() : t0;
-        if (fc && (t > s || (t == s && f < e))) rank++;
+    for (int base = 0; base < total; base += NMS_RANK_CHUNK) {
+        const int cnt = total - base < NMS_RANK_CHUNK ? total - base : NMS_RANK_CHUNK;
+        __syncthreads();
+        for (int f = threadIdx.x; f < cnt; f += blockDim.x) {
+            const float t0 = scores[base + f];
+            s_sc[f] = make_float2((t0 != t0) ? -__builtin_inff() : t0, obj[(base + f) * 2 + 1] > obj[(base + f) * 2] ? 1.0f : 0.0f);
+        }
+        __syncthreads();
+        if (cand)
+            for (int f = 0; f < cnt; f++) {
+                const float2 tc = s_sc[f];
+                if (tc.y != 0.0f && (tc.x > s || (tc.x == s && base + f < e))) rank++;
+            }
     }
+    if (!cand) return;
     order[rank] = e;
     atomicAdd(ncand, 1);
+}
+
+// Greedy suppression of one scene by bit masks (n <= NMS_MASK_MAX boxes per scene): the scene's candidates in visit order go to
+// LDS (an ordered compaction of `order`), every candidate i gets the bit row {j later in the order : IoU(i, j) > thr} -- all rows at
+// once, the IoU reads independent of each other -- and ONE pass over the rows keeps a candidate iff no kept candidate has
+// removed it: the same decisions as the loop of tf_nms3d.cpp:237-262 (a box is dropped iff its IoU with an earlier KEPT box
+// exceeds thr, strictly), without a memory round trip per candidate (the wave-per-scene loop took 159 us for 8 x 256 boxes).
+constexpr int NMS_MASK_MAX = 512;
+__global__ __launch_bounds__(256) void nms_greedy_mask_kernel(int n, float thr, const float *__restrict__ iou, const int *__restrict__ order,
+                                                              const int *__restrict__ ncand, int *__restrict__ keep_flag)
+{
+    extern __shared__ unsigned long long s_mask[]; // n rows x W words, then the list of boxes (n ints), then per-wave counts
+    const int W = (n + 63) / 64;
+    int *s_list = reinterpret_cast<int *>(s_mask + (size_t)n * W);
+    int *s_wcnt = s_list + n;
+    __shared__ int s_len;
+    const int scene = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nc = *ncand;
+    const float *__restrict__ miou = iou + (size_t)scene * n * n;
+    if (tid == 0) s_len = 0;
+    __syncthreads();
+    // (a) this scene's candidates, in visit order
+    for (int start = 0; start < nc; start += 256) {
+        const int p = start + tid;
+        const int e = p < nc ? order[p] : -1;
+        const bool mine = e >= 0 && e / n == scene;
+        const unsigned long long bal = __ballot(mine);
+        if (lane == 0) s_wcnt[w] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < 4; i++) {
+            if (i < w) woff += s_wcnt[i];
+            tot += s_wcnt[i];
+        }
+        const int base = s_len;
+        if (mine) s_list[base + woff + __popcll(bal & ((1ull << lane) - 1ull))] = e - scene * n;
+        __syncthreads();
+        if (tid == 0) s_len = base + tot;
+        __syncthreads();
+    }
+    const int L = s_len;
+    // (b) suppression rows: bit j of row i = candidate j comes later and overlaps candidate i by more than thr.  A wave per row,
+    //     a lane per candidate j of the word: the word is the ballot of the 64 comparisons
+    for (int i = w; i < L; i += 4) {
+        const float *__restrict__ row = miou + (size_t)s_list[i] * n;
+        for (int wd = 0; wd < W; wd++) {
+            const int j = wd * 64 + lane;
+            const bool hit = j > i && j < L && row[s_list[j < L ? j : 0]] > thr; // tf_nms3d.cpp:250 (strict >)
+            const unsigned long long m = __ballot(hit);
+            if (lane == 0) s_mask[(size_t)i * W + wd] = m;
+        }
+    }
+    __syncthreads();
+    // (c) one pass: lane wd of wave 0 owns word wd of the removed set
+    if (w == 0) {
+        unsigned long long removed = 0ull;
+        for (int i = 0; i < L; i++) {
+            const unsigned long long cur = __shfl(removed, i >> 6);
+            if (!((cur >> (i & 63)) & 1ull)) { // uniform
+                if (lane < W) removed |= s_mask[(size_t)i * W + lane];
+                if (lane == 0) keep_flag[scene * n + s_list[i]] = 1;
+            }
+        }
+    }
 }
 
 // one wave per scene; the scene's kept boxes (visit order) live in LDS
@@ -343,8 +419,13 @@ extern "C" int votenet_nms3d(int b, int n, const float *bboxes, const float *sco
     (void)hipMemsetAsync(w.ncand, 0, sizeof(int), st);
     hipLaunchKernelGGL(nms_rank_kernel, dim3((total + 255) / 256), dim3(256), 0, st, total, scores, objectiveness, w.order,
                        w.ncand);
-    hipLaunchKernelGGL(nms_greedy_kernel, dim3(b), dim3(64), (size_t)n * sizeof(int), st, n, iou_threshold, w.iou, w.order,
-                       w.ncand, w.keep_flag);
+    if (n <= NMS_MASK_MAX) {
+        const size_t smem = (size_t)n * ((n + 63) / 64) * 8 + (size_t)n * 4 + 16;
+        hipLaunchKernelGGL(nms_greedy_mask_kernel, dim3(b), dim3(256), smem, st, n, iou_threshold, w.iou, w.order, w.ncand, w.keep_flag);
+    } else {
+        hipLaunchKernelGGL(nms_greedy_kernel, dim3(b), dim3(64), (size_t)n * sizeof(int), st, n, iou_threshold, w.iou, w.order,
+                           w.ncand, w.keep_flag);
+    }
     hipLaunchKernelGGL(nms_emit_kernel, dim3(1), dim3(1024), 0, st, n, w.order, w.ncand, w.keep_flag, out, out_count);
     return check_launch("nms3d");
 }
