@@ -1,4 +1,5 @@
-// mlp_fast.hip -- lean fp32 MFMA GEMM for the dense layers of the grouped-point MLP (gfx950).
+// mlp_fast.hip -- lean MFMA GEMM (fp32 operands; products on fp32 MFMAs or on bf16 x 3 split operands) for the dense layers of the
+// grouped-point MLP (gfx950).
 //
 // Same contract as mlp_linear_kernel (mlp.hip) for the case every dense VoteNet layer is in:
 //   DENSE input, cin % 32 == 0, cout % 64 == 0, rows % 128 == 0, 16-byte aligned operands, cin <= 512.
@@ -16,6 +17,13 @@
 //   * the pipeline runs across row tiles of a persistent workgroup (no drain at tile boundaries);
 //   * MFMA operand fragments are double-buffered in registers (ds_reads of sub-step k2+1 before the MFMAs
 //     of k2); LDS images are [k][row] / [k][col], conflict-free for both operand reads.
+//
+// BF3 = true instantiations (the default path once the weight matrix has a registered image, votenet_split_weights): the same
+// kernel with the products on bf16 MFMAs.  Every fp32 operand is split exactly into three bf16 pieces (split3), a product is the
+// six terms hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation (what is dropped
+// is <= 2^-23 of the product); the weights arrive pre-split in LDS order, the activations are split where they are staged; one
+// 16-deep slab is ONE k-step per piece pair, its barrier sits in the middle of the slab (see the slab body).  Loaders (SRC) and
+// epilogues (EPI) are shared with the fp32 form: the 32 x 32 accumulator layout is the same.
 #include "mlp_types.h"
 #include <mutex>
 #include <unordered_map>
