@@ -477,6 +477,9 @@ int votenet_register_split_weights(const float *w, int cin, int cout, const void
 /* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used; another
  * value: a mask over GEMM families (mlp_fast.hip, bf3_family) */
 void votenet_debug_fast_bf3(int on);
+/* votenet_mlp_gram on split operands as well (pool_bwd.hip: 8 consecutive rows of a channel per MFMA fragment; c = 64 or 128,
+ * no scratch = atomics mode); 0: the fp32 MFMA kernel always.  Default 1. */
+void votenet_debug_gram_bf3(int on);
 
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
 int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);

@@ -169,3 +169,25 @@ def test_forward_rebuilds_the_images_after_the_weights_changed_by_hand(bf3, dev)
 # comparable element by element: the proposal module samples and groups the *predicted* votes, so a last-bit difference upstream
 # moves a neighbour set and with it a few per cent of the gradient -- measured 2.5e-2 between the two GEMM forms, the same
 # size as between two runs of one form with atomics.)
+
+
+@pytest.mark.parametrize("rows,c,relu", [(4096, 128, True), (40000, 128, True), (4111, 64, True), (131072, 64, False), (130, 128, True)])
+def test_gram_matrix_on_split_operands_vs_float64_and_the_fp32_kernel(bf3, dev, rows, c, relu):
+    """votenet_mlp_gram (pool_bwd.hip): a^T a of the activated input of a pooled layer, the contraction over the rows -- the BF3 kernel
+    stages 8 consecutive rows of a channel per fragment.  Ragged row counts (padding rows must add nothing), both widths."""
+    from votenet_amd import mlp
+    rng = np.random.default_rng(rows + c)
+    z = T((rng.normal(size=(rows, c)) * 1.5 + 0.2).astype(np.float32), dev)
+    ss = T(np.stack([rng.random(c) + 0.5, rng.normal(size=c) * 0.3]).astype(np.float32), dev)
+    a = z.double() * ss[0].double() + ss[1].double()
+    if relu:
+        a = torch.relu(a)
+    ref = a.t() @ a
+    bound = float((a.abs().t() @ a.abs()).max())
+    errs = []
+    for mode in (1, 0):
+        bf3.votenet_debug_gram_bf3(mode)
+        g = mlp.gram(z, ss, relu)[:c]
+        errs.append(float((g.double() - ref).abs().max()) / bound)
+    bf3.votenet_debug_gram_bf3(1)
+    assert errs[0] <= 3e-6 and errs[0] <= 2.0 * errs[1] + 5e-7, "bf16 x 3: %.3g of the accumulated magnitude, fp32 MFMA: %.3g" % tuple(errs)

@@ -61,4 +61,28 @@ __device__ __forceinline__ float assembled_z(float p, const float4 &g, float w0,
     return __builtin_fmaf(g.z, w2, __builtin_fmaf(g.y, w1, __builtin_fmaf(g.x, w0, p)));
 }
 
+// ---- bf16 x 3 split operands (BF3: mlp_fast.hip, the Gram kernel of pool_bwd.hip) ---------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// fp32 -> three bf16 pieces, each rounded to nearest even: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid).  Both subtractions
+// are exact (a float minus its own rounding), and the second remainder has at most 8 significant bits, so lo is exact as well:
+// x = hi + mid + lo EXACTLY, with |mid| <= 2^-8 |x| and |lo| <= 2^-16 |x|, signs as the roundings fall.  The pieces of x go to the
+// low halves of h / m / l and those of y to the high halves (v_cvt_pk_bf16_f32 converts and packs two values in one instruction).
+// A product x*w is then the six bf16 MFMA terms hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi accumulated in fp32: what is left
+// out (mid*lo, lo*mid, lo*lo) is at most 2^-23 of |x*w| -- the size of the fp32 rounding of the product itself -- and unbiased.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16_rne(float x, float y)
+{
+    const bf16x2 v = {(__bf16)x, (__bf16)y};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ void split3(float x, float y, unsigned &h, unsigned &m, unsigned &l)
+{
+    h = pack_bf16_rne(x, y);
+    const float rx = x - __uint_as_float(h << 16), ry = y - __uint_as_float(h & 0xffff0000u);
+    m = pack_bf16_rne(rx, ry);
+    const float sx = rx - __uint_as_float(m << 16), sy = ry - __uint_as_float(m & 0xffff0000u);
+    l = pack_bf16_rne(sx, sy);
+}
+
 } // namespace votenet

@@ -468,9 +468,149 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
     return check_launch("pool_dgrad_scatter");
 }
 
+// ---- Gram matrix on bf16 x 3 split operands ---------------------------------------------------------------------------------------
+// G (C x C) += a^T a, a = act(z * scale + shift), over the rows of a workgroup's range.  The contraction runs over the ROWS, so an
+// MFMA fragment is 8 consecutive rows of one channel: thread (channel c, row group) loads its KPT = C / 16 rows of the slab as
+// scalars (coalesced over c), applies the activation with ITS channel's scale / shift, splits the values exactly into three bf16
+// pieces (split3, mlp_types.h) and writes them as one 16-byte (8-byte at C = 64) row of the LDS image [piece][row-half][channel][8
+// rows] -- which is the A^T AND the B operand image: both operands of a^T a are the same matrix.  Six v_mfma_f32_32x32x16_bf16
+// per 32 x 32 sub-tile and 16-row slab instead of eight v_mfma_f32_32x32x2_f32 of twice the length; two register sets of raw
+// rows in flight, LDS double-buffered, one barrier per slab.  Partial tiles are added with atomics (the deterministic mode keeps
+// the fp32 kernel with its ordered reduction).
+template <int C>
+__global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
+                                                       int relu, float *__restrict__ gram, long rows_per_block)
+{
+    constexpr int KPT = C / 16;          // rows of a slab per thread (8 or 4)
+    constexpr int T = C / 64;            // 32 x 32 sub-tiles per wave and direction (waves 2 x 2)
+    constexpr int PL = C * 4 + 16;       // dwords per (piece, row-half) plane; the pad keeps a wave's two halves on different banks
+    __shared__ __attribute__((aligned(16))) unsigned Ts[2][3][2][PL];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const long r_begin = (long)blockIdx.x * rows_per_block;
+    if (r_begin >= rows) return;
+    const int nrow = (int)((r_begin + rows_per_block < rows ? r_begin + rows_per_block : rows) - r_begin);
+    const int nslab = (nrow + 15) / 16;
+    const int c = tid % C, rg = tid / C; // C = 128: rg = row-half; C = 64: rg = quarter (row-half rg >> 1, dword pair rg & 1)
+    const int kh_w = (C == 128) ? rg : (rg >> 1), d_w = (C == 128) ? 0 : (rg & 1) * 2;
+    const float sc = scale_shift[c], sh = scale_shift[C + c];
+    const float floor_ = relu ? 0.0f : -__builtin_inff();
+    const float *xb = x + (size_t)r_begin * C + c;
+    float R[2][KPT];
+    auto load = [&](float (&r)[KPT], int s) {
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            int lr = s * 16 + rg * KPT + i;
+            lr = lr < nrow ? lr : nrow - 1; // past the end: a valid row, stored as zero below
+            r[i] = xb[(size_t)lr * C];
+        }
+    };
+    auto store = [&](int buf, const float (&r)[KPT], int s) {
+        float v[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; i++) {
+            v[i] = fmaxf(r[i] * sc + sh, floor_);
+            if (s * 16 + rg * KPT + i >= nrow) v[i] = 0.0f; // padding rows contribute nothing
+        }
+        unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
+#pragma unroll
+        for (int i = 0; i < KPT / 2; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
+        if constexpr (C == 128) {
+            *reinterpret_cast<uint4 *>(&Ts[buf][0][kh_w][c * 4]) = make_uint4(h[0], h[1], h[2], h[3]);
+            *reinterpret_cast<uint4 *>(&Ts[buf][1][kh_w][c * 4]) = make_uint4(m[0], m[1], m[2], m[3]);
+            *reinterpret_cast<uint4 *>(&Ts[buf][2][kh_w][c * 4]) = make_uint4(l[0], l[1], l[2], l[3]);
+        } else {
+            *reinterpret_cast<uint2 *>(&Ts[buf][0][kh_w][c * 4 + d_w]) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2 *>(&Ts[buf][1][kh_w][c * 4 + d_w]) = make_uint2(m[0], m[1]);
+            *reinterpret_cast<uint2 *>(&Ts[buf][2][kh_w][c * 4 + d_w]) = make_uint2(l[0], l[1]);
+        }
+    };
+    f32x16 acc[T][T];
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++)
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
+    // prologue: slab 0 -> buffer 0; slabs 1 and 2 in flight
+    load(R[0], 0);
+    store(0, R[0], 0);
+    load(R[1], 1);
+    __builtin_amdgcn_sched_barrier(0);
+    load(R[0], 2);
+    __syncthreads();
+    const int kh = lane >> 5, l31 = lane & 31;
+    int buf = 0;
+    const int nslab2 = (nslab + 1) & ~1; // the loop runs slab pairs; a padding slab multiplies zeros
+    for (int s = 0; s < nslab2; s += 2) {
+#pragma unroll
+        for (int par = 0; par < 2; par++) {
+            uint4 fa[3][T], fb[3][T];
+#pragma unroll
+            for (int p = 0; p < 3; p++) {
+#pragma unroll
+                for (int t = 0; t < T; t++) {
+                    fa[p][t] = *reinterpret_cast<const uint4 *>(&Ts[buf][p][kh][((wi * T + t) * 32 + l31) * 4]);
+                    fb[p][t] = *reinterpret_cast<const uint4 *>(&Ts[buf][p][kh][((wj * T + t) * 32 + l31) * 4]);
+                }
+            }
+            auto mm = [&](int pa, int pb) {
+#pragma unroll
+                for (int a = 0; a < T; a++)
+#pragma unroll
+                    for (int b = 0; b < T; b++)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][a]),
+                                                                            __builtin_bit_cast(bf16x8, fb[pb][b]), acc[a][b], 0, 0, 0);
+            };
+            mm(2, 0);
+            mm(0, 2);
+            mm(1, 1);
+            store(buf ^ 1, R[par ^ 1], s + par + 1); // the other buffer was last read one slab ago, behind a barrier
+            load(R[par ^ 1], s + par + 3);
+            mm(1, 0);
+            mm(0, 1);
+            mm(0, 0);
+            lds_barrier();
+            buf ^= 1;
+        }
+    }
+    // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int a = 0; a < T; a++)
+#pragma unroll
+        for (int b = 0; b < T; b++) {
+            const int j = (wj * T + b) * 32 + l31;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const int i = (wi * T + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                unsafeAtomicAdd(&gram[(size_t)i * C + j], acc[a][b][e]);
+            }
+        }
+}
+
+int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always
+template <int C>
+static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st)
+{
+    // 384 workgroups as the fp32 weight-gradient kernels (mlp_wgrad_fast.hip, plan_fast): the launch runs beside the input-gradient chain
+    long rpb = (rows + 383) / 384;
+    rpb = (rpb + 31) / 32 * 32;
+    if (rpb < 128) rpb = 128;
+    const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
+    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb);
+}
+extern "C" void votenet_debug_gram_bf3(int on) { g_gram_bf3 = on; }
+
 extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
                                 void *stream)
 {
+    if (g_gram_bf3 && scratch == nullptr && (c == 64 || c == 128) && rows > 0 && rows < (1L << 31) / c && z && scale_shift && gram &&
+        (uintptr_t)z % 16 == 0) {
+        if (c == 128) gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream));
+        else gram_bf3_launch<64>(rows, z, scale_shift, relu, gram, as_stream(stream));
+        return check_launch("mlp_gram");
+    }
     VN_REQUIRE(rows > 0 && c > 0 && z && scale_shift && gram, "mlp_gram: bad arguments");
     MlpIn d = {};
     d.x = z;
