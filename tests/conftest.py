@@ -52,5 +52,7 @@ def gemm_form(request, hiplib):
     """The fused GEMMs on bf16 x 3 images of the weights (the model's default; a test that wants them registers its matrices with
     mlp.SplitImages) or on the fp32 MFMA kernels (votenet_debug_fast_bf3(0): registered images are ignored)."""
     hiplib.votenet_debug_fast_bf3(request.param)
+    hiplib.votenet_debug_gram_bf3(request.param)
     yield request.param
     hiplib.votenet_debug_fast_bf3(1)
+    hiplib.votenet_debug_gram_bf3(1)
