@@ -292,6 +292,7 @@ def main():
     if world == 1 and not args.headline_only:
         from votenet_amd import _lib as vlib
         vlib.lib().votenet_debug_fast_bf3(0)
+        vlib.lib().votenet_debug_gram_bf3(0)
         try:
             for _ in range(4):
                 step()
@@ -303,12 +304,13 @@ def main():
             dt4 = time.perf_counter() - t1
         finally:
             vlib.lib().votenet_debug_fast_bf3(1)
+            vlib.lib().votenet_debug_gram_bf3(1)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
         fp32_step = {"value": round(B * 10 / dt4, 2), "ms_per_step": round(dt4 / 10 * 1e3, 3), "steps": 10,
-                     "what": "same workload, votenet_debug_fast_bf3(0): every GEMM product on v_mfma_f32_32x32x2_f32 (the round-1 "
-                             "kernels) instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
+                     "what": "same workload, votenet_debug_fast_bf3(0) + votenet_debug_gram_bf3(0): every GEMM product on "
+                             "v_mfma_f32_32x32x2_f32 instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
 
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None
@@ -388,8 +390,8 @@ def main():
                                                "the first two timed steps, fp32 in / fp32 accumulate; executed flops / union of the "
                                                "launch intervals over both streams).  The fused forward / input-gradient GEMMs multiply each fp32 "
                                                "operand as three bf16 pieces (x = hi + mid + lo exactly): six v_mfma_f32_32x32x16_bf16 per "
-                                               "k-step, fp32 accumulate, error vs float64 equal to the fp32 MFMA kernel's; weight-gradient "
-                                               "GEMMs run on v_mfma_f32_32x32x2_f32.  flops = fp32 multiply-adds of the GEMM (2 rows cin "
+                                               "k-step, fp32 accumulate, error vs float64 equal to the fp32 MFMA kernel's; so do the Gram matrices "
+                                               "of the pooled layers' backward; the other weight-gradient GEMMs run on v_mfma_f32_32x32x2_f32.  flops = fp32 multiply-adds of the GEMM (2 rows cin "
                                                "cout), priced against the fp32 MFMA peak" % len(gemm_events),
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                     "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gemm_ms_per_step_summed": round(sum_ms / gemm_steps, 3),
@@ -447,7 +449,8 @@ def main():
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate; products of the fused forward and input-gradient GEMMs as bf16 x 3 "
                                "split operands (exact split, 6 of the 9 cross terms: what is dropped is < 2^-23 of a product), "
-                               "weight gradients on fp32 MFMA; tests hold both forms to the same tolerances",
+                               "likewise the Gram matrices of the pooled layers' backward; the other weight gradients on fp32 MFMA; tests hold both "
+                               "forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
             "fp32_mfma_gemms": fp32_step, "configs": cfgs,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
