@@ -40,6 +40,11 @@ def parse():
     ap.add_argument("--dry-run", action="store_true", help="launcher self-test on CPU (gloo rendezvous, no kernels, nothing measured)")
     ap.add_argument("--headline-only", action="store_true", help="skip the extra unpipelined / alone-on-the-GPU measurements (profiling)")
     ap.add_argument("--no-gram", action="store_true", help="pooled layers: direct backward GEMMs on the stored z instead of the Gram form")
+    ap.add_argument("--check-dp", action="store_true",
+                    help="data-parallel self-check instead of a measurement: in deterministic mode, train steps with the overlapped "
+                         "gradient exchange (dp.GradSync: tail under sa2/sa1's backward, head at the end) against the same steps with ONE "
+                         "blocking all-reduce after a device synchronise; parameters must be bit-equal on every rank, else exit code 4.  "
+                         "Works at --gpus 1 too (a one-rank RCCL communicator still runs both collectives)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not compute the coordinate-only geometry of the next batch underneath the current step")
     return ap.parse_args()
@@ -53,52 +58,91 @@ def cpu_baseline(points, scene_kind, min_seconds=8.0, max_scenes=3, ops=True):
     return bench_legs.cpu_baseline(points, scene_kind, min_seconds=min_seconds, max_scenes=max_scenes, ops=ops)
 
 
+def visible_gpu_count(root="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs this process could use, counted WITHOUT any HIP / HSA call: the KFD topology in sysfs (a node with simd_count > 0 is a
+    GPU; CPU nodes have 0), narrowed by HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when one is set.
+    torch.cuda.device_count() is not used: on a ROCm build without amdsmi it is hipGetDeviceCount, which initialises the runtime
+    in the launcher -- and a process that has initialised the GPU must not start the ranks (fork + exec) on this pool.
+    -> the count, or None when sysfs has no KFD topology (then the ranks find out themselves: rank r fails fast if r >= its own
+    device_count())."""
+    try:
+        nodes = sorted(os.listdir(root), key=lambda v: int(v) if v.isdigit() else 0)
+    except OSError:
+        return None
+    gpus = 0
+    for nd in nodes:
+        try:
+            props = dict(ln.split(None, 1) for ln in open(os.path.join(root, nd, "properties")).read().splitlines() if " " in ln)
+        except OSError:
+            continue
+        if int(props.get("simd_count", "0").strip() or 0) > 0:
+            gpus += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = [t for t in v.split(",") if t.strip() != ""]
+            gpus = min(gpus, len(listed))
+    return gpus
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks of this script as CHILD processes (one per GPU,
     RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set as torch.distributed.run would) and forward rank 0's JSON line.  The parent
-    never touches the GPU (no HIP call, no torch.cuda.is_available(): only device_count(), which does not initialise it
-    on this image) and never re-execs itself.  A failed child ends the others and makes the whole run fail."""
+    never touches the GPU -- it imports neither torch nor the HIP library; GPUs are counted in sysfs (visible_gpu_count) -- and never
+    re-execs itself.  A failed child ends the others and makes the whole run fail; a rendezvous port that was taken between
+    choosing it and rank 0 binding it (EADDRINUSE) is retried on a new port."""
     import socket
     import subprocess
     import tempfile
     if not args.dry_run:
-        import torch
-        have = torch.cuda.device_count()
-        if have < args.gpus:
-            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible\n" % (args.gpus, have))
+        have = visible_gpu_count()
+        if have is not None and have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible (KFD topology)\n" % (args.gpus, have))
             return 2
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    port = s.getsockname()[1]
-    s.close()
-    procs = []
-    out0 = tempfile.TemporaryFile(mode="w+")
-    for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=out0 if r == 0 else subprocess.DEVNULL))
-    codes = [None] * len(procs)
-    while any(c is None for c in codes):
-        for r, p in enumerate(procs):
-            if codes[r] is None:
-                codes[r] = p.poll()
-        if any(c not in (None, 0) for c in codes):  # one rank died: the others would wait in the collective forever
+    for attempt in range(3):
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        procs = []
+        out0 = tempfile.TemporaryFile(mode="w+")
+        err0 = tempfile.TemporaryFile(mode="w+")
+        for r in range(args.gpus):
+            # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's (and torch's)
+            # cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; it is
+            # repeated here so that a launcher started from a scrubbed environment still hands it to every rank.
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err0 if r == 0 else None))
+        codes = [None] * len(procs)
+        while any(c is None for c in codes):
             for r, p in enumerate(procs):
                 if codes[r] is None:
-                    p.kill()  # exactly the PIDs started above
-                    codes[r] = p.wait()
-            break
-        time.sleep(0.05)
-    out0.seek(0)
-    sys.stdout.write(out0.read())
-    sys.stdout.flush()
-    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
-    if bad:
-        sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
-        return 1
-    return 0
+                    codes[r] = p.poll()
+            if any(c not in (None, 0) for c in codes):  # one rank died: the others would wait in the collective forever
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        p.kill()  # exactly the PIDs started above
+                        codes[r] = p.wait()
+                break
+            time.sleep(0.05)
+        err0.seek(0)
+        err_text = err0.read()
+        bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+        if bad and attempt < 2 and ("EADDRINUSE" in err_text or "address already in use" in err_text.lower()):
+            sys.stderr.write("bench.py: rendezvous port %d was taken, retrying on another\n" % port)
+            continue
+        sys.stderr.write(err_text)
+        out0.seek(0)
+        sys.stdout.write(out0.read())
+        sys.stdout.flush()
+        if bad:
+            sys.stderr.write("bench.py: rank(s) failed (rank, exit code): %s\n" % bad)
+            return 1
+        return 0
+    return 1
 
 
 def dry_run(args):
@@ -121,6 +165,38 @@ def dry_run(args):
         dist.destroy_process_group()
 
 
+def check_dp(args, dev, world, rank):
+    """--check-dp (see parse()): two replicas from the same seed, deterministic mode, the same scenes; one exchanges gradients the
+    overlapped way, the other with one blocking all-reduce.  Prints one JSON line on rank 0; exit code 4 when they differ."""
+    import torch
+    import torch.distributed as dist
+    import votenet_amd
+    from votenet_amd import dp, synth
+    from votenet_amd import loss as vloss
+    from votenet_amd import model as VM
+    B, n = args.batch, args.points
+    info = dp.comm_info(dev)
+    votenet_amd.set_deterministic(True)
+    seeds = [dp.scene_seeds(rank, B, base=bs)[0] for bs in (1000, 500000)]
+    xs = [torch.from_numpy(synth.room_batch(B, n, sd)).to(dev) for sd in seeds]
+    gts = [vloss.gt_to_device(synth.room_gt(B, n, sd), dev) for sd in seeds]
+    nets = [VM.VoteNetHotPath(dev, seed=0) for _ in range(2)]
+    for net in nets:
+        dp.broadcast_params(net.store)
+        net.init_optimizer()
+
+    def run(net, i):
+        net.train_step(xs[i % 2], None, world, gt=gts[i % 2])
+    res = dp.check_overlap_against_blocking(nets[0], nets[1], run, steps=max(2, min(args.steps, 4)))
+    if rank == 0:
+        print(json.dumps({"metric": "data-parallel self-check (--check-dp; nothing measured)", "value": None,
+                          "n_gpus": info["world_size"], "communicator": info, "check_dp": res,
+                          "what": "deterministic mode; parameters after %d train steps with dp.GradSync's overlapped exchange vs one "
+                                  "blocking all-reduce between device synchronisations: torch.equal on every rank, every rank equal to "
+                                  "rank 0" % res["steps"]}), flush=True)
+    return 0 if res["equal_everywhere"] else 4
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -134,11 +210,23 @@ def main():
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.device_count() <= local:  # the launcher counted in sysfs (or could not count at all): fail fast here
+        sys.exit("bench.py: rank %d has no GPU %d (device_count %d)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or args.check_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:  # --gpus 1 --check-dp without a launcher: a one-rank communicator
+            import socket
+            s_ = socket.socket()
+            s_.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+            s_.close()
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.check_dp:
+        code = check_dp(args, dev, world, rank)
+        dist.destroy_process_group()
+        sys.exit(code)
 
     from votenet_amd import model as VM
     from votenet_amd import mlp as vmlp
@@ -323,6 +411,44 @@ def main():
         iso_bq = sum(e0.elapsed_time(e1) for (e0, e1, *_r) in tf_grouping.PROFILE_EVENTS) / 5
         tf_sampling.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS = None
 
+    # what the COMMUNICATOR says about this run (world size, backend, every rank's PCI address / uuid gathered over the group) and
+    # the latency of the two gradient collectives in three extra, untimed steps with HIP events on the communication stream.  At
+    # --gpus 1 there is no group in the timed region; afterwards a ONE-rank RCCL communicator is created so that the same two
+    # collectives run through RCCL and the three-stream ordering on this GPU (labelled: it measures the path, not xGMI)
+    comm = dp.comm_info(dev)
+    dp_coll = None
+    if workload == "train" and not args.headline_only:
+        try:
+            one_rank = False
+            if world == 1:
+                import socket
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                s_ = socket.socket()
+                s_.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
+                s_.close()
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                one_rank = True
+            keep = net._gsync
+            net._gsync = dp.GradSync(net.store, net.store.offset_of("sa3/"), overlap=True, force=True, profile=True)
+            tms = []
+            for _ in range(4):
+                step()
+                torch.cuda.synchronize()
+                tms.append(net._gsync.timings())
+            net._gsync = keep
+            tms = tms[1:]
+            dp_coll = {k: round(sum(t[k] for t in tms) / len(tms), 4) for k in tms[0]}
+            dp_coll["collectives_per_step"] = [["tail", net.store.grad.numel() - net.store.offset_of("sa3/")], ["head", net.store.offset_of("sa3/")]]
+            dp_coll["communicator"] = dp.comm_info(dev)
+            dp_coll["what"] = ("mean of 3 steps, HIP events on the communication stream around each all-reduce (fp32 elements); tail_exposed = "
+                               "how long the tail was still running when the main stream reached the end of the backward pass"
+                               + ("; ONE-rank RCCL communicator created after the timed region: the path and its stream ordering, not xGMI"
+                                  if one_rank else ""))
+            if one_rank:
+                dist.destroy_process_group()
+        except Exception as e:  # never lose the headline to this leg
+            dp_coll = {"error": repr(e)[:300]}
     if rank == 0:
         # dominant kernel: the sa1 farthest-point-sampling launch (n=20480 -> 2048)
         m1 = net.sa1.npoint
@@ -437,7 +563,7 @@ def main():
             cpu = cpu_baseline(n, args.scene)
         out = {
             "metric": "SUN RGB-D 20k-pt scenes/sec (%s)" % ("fwd+bwd" if workload == "train" else "fwd"),
-            "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+            "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": comm["world_size"], "steps": args.steps,
             "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("VoteNet hot path %s: sa1-4 + fp1-2 + voting + proposal, %d scenes x %d pts per GPU, "
@@ -453,6 +579,7 @@ def main():
                                "forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
             "fp32_mfma_gemms": fp32_step, "configs": cfgs,
+            "communicator": comm, "dp_collectives": dp_coll,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         print(json.dumps(out), flush=True)

@@ -284,6 +284,10 @@ int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const
 /* mmat (cin x cin) = W diag(C) W^T, cvec (cin) = (B + C.b) W^T; w (cin x cout), bias may be NULL */
 int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                float *cvec, void *stream);
+/* the same launch also writes the bf16 x 3 image of mmat (cin * cin * 6 bytes, 16-byte aligned, cin % 16 == 0; the layout of
+ * votenet_split_weights) for the one forward-type GEMM that multiplies by it (register it around that launch) */
+int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                                     float *cvec, void *image, void *stream);
 /* da (groups*k x cin) += the scattered rows; wT = W^T (cout x cin).  With below_z != NULL (the raw output, rows x cin, of
  * the layer BELOW, whose output gradient da is) the same pass also performs that layer's votenet_bn_backward_reduce:
  * below_sums (2*cin doubles, pre-zeroed) += [sum g', sum g' zhat] with g' = the final da masked by the layer's ReLU. */

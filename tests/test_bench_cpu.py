@@ -64,3 +64,33 @@ def test_a_failed_rank_fails_the_run():
 def test_gpus_must_match_the_launcher_world_size():
     r = _run_bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0"})
     assert r.returncode != 0 and "does not match WORLD_SIZE" in r.stderr
+
+
+def test_gpus_are_counted_in_sysfs_without_touching_the_runtime(tmp_path, monkeypatch):
+    """The launcher parent must not initialise HIP (it fork+execs the ranks): GPUs = KFD topology nodes with simd_count > 0,
+    narrowed by *_VISIBLE_DEVICES; no topology -> None (the ranks then check for themselves)."""
+    for i, simd in enumerate([0, 0, 1024, 1024, 1024]):  # two CPU nodes, three GPUs
+        d = tmp_path / str(i)
+        d.mkdir()
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nmem_banks_count 1\n" % (64 if simd == 0 else 0, simd))
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    assert bench.visible_gpu_count(str(tmp_path)) == 3
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0,2")
+    assert bench.visible_gpu_count(str(tmp_path)) == 2
+    monkeypatch.delenv("HIP_VISIBLE_DEVICES")
+    assert bench.visible_gpu_count(str(tmp_path / "missing")) is None
+
+
+def test_the_launcher_parent_never_imports_torch():
+    """launch_ranks runs before anything GPU-related is imported: the parent process of `--gpus N` holds no HIP runtime."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.argv = ['bench.py', '--gpus', '2', '--dry-run']; sys.path.insert(0, %r); import bench\n"
+            "a = bench.parse(); rc = bench.launch_ranks(a)\n"
+            "assert rc == 0, rc\n"
+            "assert 'torch' not in sys.modules, 'the launcher imported torch'\n" % root)
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], env=e, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr

@@ -104,25 +104,19 @@ def _stub_grad(name, shape, rank, step):
     return torch.randn(shape, generator=g) * (3.0 if "sa1" in name else 0.01)
 
 
-def _train_worker(rank, world, port, q):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from votenet_amd import dp
+def _stub_net(rank, seed, events, step_no, B=2):
+    """A VoteNetHotPath on the CPU whose kernels are stand-ins (see above); the chain-backward stub finds its net through the
+    voting record, so several stubbed nets can live in one process."""
     from votenet_amd import mlp as M
     from votenet_amd import model as VM
     from votenet_amd import pointnet2 as P
     cpu = torch.device("cpu")
-    net = VM.VoteNetHotPath(cpu, seed=rank)     # replicas start different ...
-    dp.broadcast_params(net.store)              # ... one broadcast makes them identical
-    p_start = net.store.flat.clone()
+    net = VM.VoteNetHotPath(cpu, seed=seed)
     net.overlap_wgrad = False
     net._side_stream = lambda: None
     net.store.refresh_transposes = lambda stream=None: None
     net.update_moving_averages = lambda tape: None
-    events, step_no = [], [0]
-    B, NS = 2, net.sa2.npoint
+    NS = net.sa2.npoint
 
     def fill(layers):
         for L in layers:
@@ -132,7 +126,7 @@ def _train_worker(rank, world, port, q):
     def stub_forward(x, tape=None, next_x=None):
         for op in ("sa", "sa", "sa", "sa", "fp", "fp"):
             tape.append(dict(op=op))
-        tape.append(dict(op="vote", recs=[], b=B, n=NS))
+        tape.append(dict(op="vote", recs=[net], b=B, n=NS))
         tape.append(dict(op="sa", fps_idx=None))
         return dict(proposals_output=torch.zeros(B, 256, 79))
 
@@ -158,13 +152,27 @@ def _train_worker(rank, world, port, q):
     net.sa1.backward = sa_backward(net.sa1, "sa1", 64, 3)
     net.fp2.backward = fp_backward(net.fp2, "fp2", net.sa2.npoint, 256, net.sa3.npoint, 256)
     net.fp1.backward = fp_backward(net.fp1, "fp1", net.sa3.npoint, 256, net.sa4.npoint, 256)
+    net._stub_fill_voting = lambda: (events.append("voting.backward"), fill(net.voting))
 
     def chain_backward(recs, g, mode, **kw):
-        events.append("voting.backward")
-        fill(net.voting)
+        recs[0]._stub_fill_voting()
         return torch.zeros_like(g)
     P.mlp_chain_backward = chain_backward
     M.clip_adam = _torch_clip_adam
+    return net
+
+
+def _train_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from votenet_amd import dp
+    events, step_no = [], [0]
+    B = 2
+    net = _stub_net(rank, rank, events, step_no, B)  # replicas start different ...
+    dp.broadcast_params(net.store)                   # ... one broadcast makes them identical
+    p_start = net.store.flat.clone()
     net._gsync = dp.GradSync(net.store, net.store.offset_of("sa3/"))
     real_tail = net._gsync.start_tail
     net._gsync.start_tail = lambda streams=None: (events.append("tail all-reduce issued"), real_tail(streams))[1]
@@ -187,6 +195,40 @@ def _train_worker(rank, world, port, q):
                 g_sum[off:off + v.numel()] += _stub_grad(name, v.shape, r, step).reshape(-1)
         _torch_clip_adam(net._seg, None, p_exp, g_sum, m_exp, v_exp, 1e-3, step, grad_scale=1.0 / world)
     q.put((rank, net.store.flat.clone(), p_exp, p_start, logs, net.store.grad.numel(), net.store.offset_of("sa3/")))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _check_worker(rank, world, port, q, sabotage):
+    """dp.check_overlap_against_blocking (what bench.py --check-dp runs) on two stubbed replicas per rank; sabotage: the overlapped
+    replica's tail collective is issued BEFORE sa3's gradients exist -- the check has to see it."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from votenet_amd import dp
+    events, step_no = [], [0]
+    B = 2
+    nets = [_stub_net(rank, 0, events, step_no, B) for _ in range(2)]
+    for net in nets:
+        dp.broadcast_params(net.store)
+        net.init_optimizer(lr=1e-3)
+    cot = dict(proposals_output=torch.zeros(B, 256, 79), votes_xyz=None)
+
+    def run(net, i):
+        step_no[0] = i + 1
+        if sabotage and net is nets[0]:
+            real = net.sa3.backward
+
+            def early(rec, g_out, **kw):
+                net._gsync.start_tail(None)          # too early: sa3's own gradients are not in the bucket yet
+                net._gsync.start_tail = lambda streams=None: None
+                return real(rec, g_out, **kw)
+            net.sa3.backward = early
+        net.train_step(torch.zeros(B, 64, 3), cot, world)
+    res = dp.check_overlap_against_blocking(nets[0], nets[1], run, steps=2)
+    info = dp.comm_info(torch.device("cpu"))
+    q.put((rank, res, info))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -214,3 +256,34 @@ def test_train_step_world2():
         assert order == ["proposal.backward", "voting.backward", "fp2.backward", "fp1.backward", "sa4.backward", "sa3.backward",
                          "tail all-reduce issued", "sa2.backward", "sa1.backward"]
     assert 0 < split < 0.1 * numel                   # the part that cannot be overlapped is small (sa1 + sa2: 8 % of the bucket)
+
+
+def _run2(target, *extra):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + extra) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return res
+
+
+def test_check_dp_overlapped_exchange_equals_blocking_world2():
+    """bench.py --check-dp's comparison on the real train_step host path (stubbed kernels): overlapped == blocking on every rank,
+    every rank == rank 0, and the communicator's own report (world size, backend, one entry per rank) is what goes into the line."""
+    for rank, res, info in _run2(_check_worker, False):
+        assert res["equal_on_this_rank"] and res["ranks_identical"] and res["equal_everywhere"]
+        assert [c[0] for c in res["collectives_per_step"]] == ["tail", "head"]
+        assert info["world_size"] == 2 and info["backend"] == "gloo" and info["distinct_devices"] == 2
+        assert sorted(d["rank"] for d in info["devices"]) == [0, 1]
+
+
+def test_check_dp_detects_a_collective_issued_too_early():
+    """The check is not vacuous: a tail all-reduce issued before sa3's gradients are written gives different parameters, and
+    every rank learns it (the verdict is an all-reduce MIN)."""
+    for rank, res, info in _run2(_check_worker, True):
+        assert not res["equal_on_this_rank"] and not res["equal_everywhere"]

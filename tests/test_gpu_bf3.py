@@ -191,3 +191,50 @@ def test_gram_matrix_on_split_operands_vs_float64_and_the_fp32_kernel(bf3, dev, 
         errs.append(float((g.double() - ref).abs().max()) / bound)
     bf3.votenet_debug_gram_bf3(1)
     assert errs[0] <= 3e-6 and errs[0] <= 2.0 * errs[1] + 5e-7, "bf16 x 3: %.3g of the accumulated magnitude, fp32 MFMA: %.3g" % tuple(errs)
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 256), (128, 128), (64, 128)])
+def test_the_gram_form_dgrad_matrix_gets_its_image_from_the_launch_that_forms_it(bf3, dev, cin, cout):
+    """votenet_pool_dgrad_prepare_split: the image written beside W diag(C) W^T is bit for bit the image votenet_split_weights makes
+    of that matrix, and pool_dgrad on it equals pool_dgrad on the fp32 kernel to the split's accuracy (and differs: it really ran)."""
+    from votenet_amd import mlp
+    g = torch.Generator().manual_seed(cin + cout)
+    groups, k = 1024, 64
+    rows = groups * k
+    w = (torch.randn(cin, cout, generator=g) * 0.15).to(dev)
+    b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    coef = torch.randn(5 * cout, generator=g).to(dev)
+    assert mlp.SPLIT_ADHOC and rows >= mlp.SPLIT_ADHOC_ROWS
+    mm = mlp.pool_dgrad_prepare(w, b, coef, rows)
+    assert getattr(mm, "_img", None) is not None
+    ref = mlp.SplitImages([mm[:cin]])
+    ref.refresh()
+    torch.cuda.synchronize()
+    assert torch.equal(mm._img.view(torch.int32), ref.buf.view(torch.int32)[:mm._img.numel() // 4])
+    ref.close()
+    mm0 = mlp.pool_dgrad_prepare(w, b, coef, 1)  # below SPLIT_ADHOC_ROWS: no image
+    assert getattr(mm0, "_img", None) is None and torch.equal(mm0, mm)
+    xz = torch.randn(rows, cin, generator=g).to(dev)
+    aff = torch.stack([torch.randn(cin, generator=g) * 0.3 + 1, torch.randn(cin, generator=g) * 0.2]).to(dev).contiguous()
+    gout = torch.randn(groups, cout, generator=g).to(dev)
+    arg = torch.randint(0, k, (groups, cout), generator=g, dtype=torch.int32).to(dev)
+    zsel = torch.randn(groups, cout, generator=g).to(dev)
+    wT = w.t().contiguous()
+    da3 = mlp.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k, mm=mm)
+    da1 = mlp.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k, mm=mm0)
+    d = float((da3 - da1).abs().max() / da1.abs().max())
+    assert 0.0 < d < 2e-6, d
+    a = torch.relu(xz.double() * aff[0].double() + aff[1].double())
+    exact = a @ mm[:cin].double() + mm[cin].double()
+    dense3, _ = _dense_only(mlp, xz, mm, cin, aff)
+    e3 = float((dense3.double() - exact).abs().max() / exact.abs().max())
+    assert e3 < 1e-5, e3
+
+
+def _dense_only(mlp, xz, mm, cin, aff):
+    from votenet_amd import _lib as L
+    L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(mm._img)))
+    try:
+        return mlp.linear_dense(xz, mm[:cin], mm[cin], aff[0], aff[1], True, want_stats=False)
+    finally:
+        L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, None)

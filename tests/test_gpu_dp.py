@@ -99,3 +99,22 @@ def test_train_step_two_ranks_real_kernels(hiplib):
         assert ok_equal == [True] * 3                 # bit-identical replicas after every step
         assert ok_update == [True] * 3                # = optimizer(mean of the local gradients), bit for bit
         assert colls == [[("tail", numel - split), ("head", split)]] * 3
+
+
+def test_check_dp_one_rank_rccl_communicator(hiplib):
+    """bench.py --gpus 1 --check-dp: a ONE-rank RCCL communicator (backend nccl) carries both collectives of dp.GradSync from the
+    communication stream -- the three-stream event ordering in front of RCCL itself, on the GPU this box has -- and the result must
+    be bit-equal to the blocking exchange.  The line reports what the communicator says, and the device's PCI address / uuid."""
+    import json
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--check-dp", "--steps", "2"], env=e,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["check_dp"]["equal_everywhere"] and line["check_dp"]["equal_on_this_rank"]
+    assert [c[0] for c in line["check_dp"]["collectives_per_step"]] == ["tail", "head"]
+    assert line["communicator"]["backend"] == "nccl" and line["communicator"]["world_size"] == 1 and line["n_gpus"] == 1
+    assert "tail_ms" in line["check_dp"]["timings_last_step"] and "head_ms" in line["check_dp"]["timings_last_step"]
+    d0 = line["communicator"]["devices"][0]
+    assert "pci_bus_id" in d0 or "uuid" in d0

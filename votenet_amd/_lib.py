@@ -88,6 +88,7 @@ _SIGS.update({
     "votenet_bn_backward_reduce_pool": [ctypes.c_long, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float, ctypes.c_int, _c_f,
                                         ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_pool_dgrad_prepare": [ctypes.c_int] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_pool_dgrad_prepare_split": [ctypes.c_int] * 2 + [_c_f] * 5 + [ctypes.c_void_p, ctypes.c_void_p],
     "votenet_pool_dgrad_scatter": [ctypes.c_long] + [ctypes.c_int] * 3 + [_c_f] * 4 + [ctypes.c_int] + [_c_f] * 7
                                   + [ctypes.c_float, ctypes.c_int, _c_f, ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_mlp_gram": [ctypes.c_long, ctypes.c_int] + [_c_f] * 2 + [ctypes.c_int, _c_f, _c_f, ctypes.c_void_p],

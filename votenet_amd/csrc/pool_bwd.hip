@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
 template <int COUT>
 __global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, const float *__restrict__ w, const float *__restrict__ bias,
                                                                  const float *__restrict__ coef, float *__restrict__ mmat,
-                                                                 float *__restrict__ cvec)
+                                                                 float *__restrict__ cvec, unsigned *__restrict__ image)
 {
     constexpr int LD = COUT + 4;
     __shared__ __attribute__((aligned(16))) float Wj[16][LD], Wk[16][LD];
@@ -94,6 +94,24 @@ __global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, const 
     }
     if (j0 + ty < cin && k0 + tx < cin) mmat[(size_t)(j0 + ty) * cin + k0 + tx] = acc;
     if (blockIdx.y == 0 && ty == 0 && k0 + tx < cin) cvec[k0 + tx] = accv;
+    if (image != nullptr) {
+        // the matrix is the weight operand of ONE forward-type GEMM (mlp_fast.hip): its bf16 x 3 image goes out with it, in that
+        // kernel's LDS order [slab = row / 16][piece][k-half][column][8 bf16] (cin % 16 == 0: this tile is one slab of 16 columns)
+        __syncthreads();
+        float(*T)[LD] = Wj; // the panels are dead: the tile goes through them
+        T[ty][tx] = acc;
+        __syncthreads();
+        if (tid < 32) {
+            const int kh = tid >> 4, c = tid & 15;
+            unsigned h[4], m[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) split3(T[kh * 8 + 2 * i][c], T[kh * 8 + 2 * i + 1][c], h[i], m[i], l[i]);
+            uint4 *dst = reinterpret_cast<uint4 *>(image) + ((size_t)(blockIdx.y * 3) * 2 + kh) * cin + k0 + c;
+            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            dst[(size_t)2 * cin] = make_uint4(m[0], m[1], m[2], m[3]);
+            dst[(size_t)4 * cin] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    }
 }
 
 // da[g*k + argmax[g,c], :] += A[c] g'[g,c] W[:,c]^T.  One persistent workgroup per CU keeps W^T (cout x CIN) in LDS and walks
@@ -407,17 +425,32 @@ extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *
     return check_launch("bn_backward_reduce_pool");
 }
 
-extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
-                                          float *cvec, void *stream)
+static int pool_dgrad_prepare_launch(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat, float *cvec,
+                                     void *image, void *stream)
 {
     VN_REQUIRE(cin > 0 && w && coef && mmat && cvec, "pool_dgrad_prepare: bad arguments");
     VN_REQUIRE((cout == 128 || cout == 256) && (uintptr_t)w % 16 == 0, "pool_dgrad_prepare: cout must be 128 or 256 (got %d), w 16-byte aligned", cout);
+    VN_REQUIRE(image == nullptr || (cin % 16 == 0 && (uintptr_t)image % 16 == 0), "pool_dgrad_prepare_split: cin %% 16 == 0 and a 16-byte aligned image");
     const dim3 grid((cin + 15) / 16, (cin + 15) / 16);
+    unsigned *img = static_cast<unsigned *>(image);
     if (cout == 256)
-        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<256>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec);
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<256>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img);
     else
-        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<128>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec);
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<128>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img);
     return check_launch("pool_dgrad_prepare");
+}
+extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                                          float *cvec, void *stream)
+{
+    return pool_dgrad_prepare_launch(cin, cout, w, bias, coef, mmat, cvec, nullptr, stream);
+}
+// The same, and the bf16 x 3 image of mmat (cin * cin * 6 bytes, votenet_split_weights' layout) written by the same launch: the
+// caller registers it (votenet_register_split_weights) around the one GEMM that multiplies by mmat.
+extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                                                float *cvec, void *image, void *stream)
+{
+    VN_REQUIRE(image != nullptr, "pool_dgrad_prepare_split: null image");
+    return pool_dgrad_prepare_launch(cin, cout, w, bias, coef, mmat, cvec, image, stream);
 }
 
 extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,

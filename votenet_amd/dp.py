@@ -48,6 +48,32 @@ def sync_gradients(store):
     return 1.0 / w
 
 
+def _device_identity(dev):
+    """What tells two GPUs of one node apart: PCI address and uuid from the device properties (each guarded: older torch builds lack them)."""
+    pr = torch.cuda.get_device_properties(dev)
+    ident = {"index": dev.index if dev.index is not None else torch.cuda.current_device(), "name": pr.name}
+    for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+        if hasattr(pr, k):
+            ident[k] = int(getattr(pr, k))
+    if hasattr(pr, "uuid"):
+        ident["uuid"] = str(pr.uuid)
+    return ident
+
+
+def comm_info(dev=None):
+    """What the COMMUNICATOR reports (not the environment): world size, backend, and every rank's device identity gathered over the
+    process group itself -- so that a bench line can show N ranks on N distinct devices.  Single process: world 1, backend None."""
+    if not (dist.is_available() and dist.is_initialized()):
+        me = _device_identity(dev) if (dev is not None and dev.type == "cuda") else {"index": None, "name": "cpu"}
+        return {"world_size": 1, "backend": None, "devices": [dict(me, rank=0)], "distinct_devices": 1}
+    me = _device_identity(dev) if (dev is not None and dev.type == "cuda") else {"index": None, "name": "cpu", "pid": __import__("os").getpid()}
+    me["rank"] = dist.get_rank()
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, me)
+    key = lambda d: (d.get("uuid"), d.get("pci_domain_id"), d.get("pci_bus_id"), d.get("pci_device_id"), d.get("index"), d.get("pid"))
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "devices": got, "distinct_devices": len({key(d) for d in got})}
+
+
 class GradSync:
     """The gradient exchange of one training step, overlapped with the backward pass (see the module docstring).
 
@@ -57,14 +83,29 @@ class GradSync:
         scale = gs.finish(streams)         after the last weight gradient: head all-reduce, then the current stream waits
                                            for both; returns 1/world for the optimizer
 
-    With world == 1 every call is a no-op.  On CUDA tensors the collectives are issued from a dedicated HIP stream so that
-    neither the main stream nor the weight-gradient stream ever waits for the network before finish()."""
+    With world == 1 every call is a no-op (unless force=True and a process group exists: a one-rank communicator then still runs
+    both collectives -- how the 1-GPU box puts the stream ordering in front of RCCL itself).  On CUDA tensors the collectives are
+    issued from a dedicated HIP stream so that neither the main stream nor the weight-gradient stream ever waits for the network
+    before finish().
 
-    def __init__(self, store, split):
+    overlap=False is the control the overlapped form is checked against (bench.py --check-dp, tests): no tail, and finish()
+    drains the device, runs ONE blocking all-reduce of the whole bucket on the current stream and drains again -- nothing can
+    race with it by construction.
+    profile=True records HIP events around both collectives: after finish(), timings() gives their latency on the communication
+    stream and how much of the tail had finished before the main stream arrived at finish() (= hidden under sa2 / sa1)."""
+
+    def __init__(self, store, split, overlap=True, force=False, profile=False):
         self.store, self.split = store, int(split)
+        self.overlap, self.force, self.profile = bool(overlap), bool(force), bool(profile)
         self._work = []
         self._comm = None
+        self._marks = {}
         self.log = []  # (what, numel) per collective of the last step: tests read it
+
+    def _active(self):
+        if self.force and dist.is_available() and dist.is_initialized():
+            return True
+        return world_size() > 1
 
     def _issue(self, t, what, streams):
         if t.is_cuda:
@@ -76,7 +117,15 @@ class GradSync:
                 ev.record(s)
                 self._comm.wait_event(ev)
             with torch.cuda.stream(self._comm):
+                if self.profile:
+                    e0 = torch.cuda.Event(enable_timing=True)
+                    e0.record(self._comm)
                 w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+                if self.profile:
+                    w.wait()  # the COMMUNICATION stream waits for the collective (device side), so that an event on it marks its end
+                    e1 = torch.cuda.Event(enable_timing=True)
+                    e1.record(self._comm)
+                    self._marks[what] = (e0, e1)
         else:
             w = dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
         self._work.append(w)
@@ -84,17 +133,31 @@ class GradSync:
 
     def begin(self):
         self._work, self.log = [], []
+        self._marks = {}
         self._tail_started = False
 
     def start_tail(self, streams=None):
-        if world_size() > 1 and 0 < self.split < self.store.grad.numel():
+        if self.overlap and self._active() and 0 < self.split < self.store.grad.numel():
             self._issue(self.store.grad[self.split:], "tail", streams)
             self._tail_started = True
 
     def finish(self, streams=None):
         w = world_size()
-        if w > 1:
+        if self._active():
             g = self.store.grad
+            if not self.overlap:
+                if g.is_cuda:
+                    torch.cuda.synchronize(g.device)
+                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                if g.is_cuda:
+                    torch.cuda.synchronize(g.device)
+                self.log.append(("blocking", g.numel()))
+                self._tail_started = False
+                return 1.0 / w
+            if g.is_cuda and self.profile:
+                arrive = torch.cuda.Event(enable_timing=True)
+                arrive.record(torch.cuda.current_stream())
+                self._marks["main_arrives"] = arrive
             if getattr(self, "_tail_started", False):
                 self._issue(g[:self.split], "head", streams)
             else:
@@ -104,3 +167,50 @@ class GradSync:
             self._work = []
         self._tail_started = False
         return 1.0 / w
+
+    def timings(self):
+        """After a profiled step (and a device synchronise): {'tail_ms', 'head_ms' | 'all_ms', 'tail_exposed_ms', 'tail_hidden_frac'}.
+        tail_exposed = how long after the main stream reached finish() the tail collective was still running."""
+        out = {}
+        for what in ("tail", "head", "all"):
+            if what in self._marks:
+                e0, e1 = self._marks[what]
+                out[what + "_ms"] = round(e0.elapsed_time(e1), 4)
+        if "tail" in self._marks and "main_arrives" in self._marks:
+            exposed = max(0.0, self._marks["main_arrives"].elapsed_time(self._marks["tail"][1]))
+            out["tail_exposed_ms"] = round(exposed, 4)
+            out["tail_hidden_frac"] = round(1.0 - min(1.0, exposed / max(out["tail_ms"], 1e-9)), 4)
+        return out
+
+
+def check_overlap_against_blocking(net_a, net_b, run_step, steps=2):
+    """The overlapped exchange cannot be told from a blocking one: net_a and net_b are two replicas in the SAME state (same
+    parameters, optimizer state, deterministic mode on); run_step(net, i) runs training step i on a net.  net_a exchanges its
+    gradients with GradSync's overlap (tail issued after sa3's backward from the communication stream, head after the last weight
+    gradient), net_b with ONE blocking all-reduce between two device synchronisations.  Any missing stream dependency in the
+    overlapped form (a collective that starts before a gradient is final, an optimizer that starts before a collective is done)
+    shows as different parameters.  -> dict(equal_on_this_rank, ranks_identical, equal_everywhere, collectives, timings):
+    equal_everywhere is the AND over all ranks (one MIN all-reduce)."""
+    split = net_a.store.offset_of("sa3/")
+    on_gpu = net_a.store.flat.is_cuda
+    net_a._gsync = GradSync(net_a.store, split, overlap=True, force=True, profile=on_gpu)
+    net_b._gsync = GradSync(net_b.store, split, overlap=False, force=True)
+    logs = []
+    for i in range(steps):
+        run_step(net_a, i)
+        logs.append(list(net_a._gsync.log))
+        run_step(net_b, i)
+    if on_gpu:
+        torch.cuda.synchronize(net_a.store.flat.device)
+    same = bool(torch.equal(net_a.store.flat, net_b.store.flat))
+    identical = True
+    everywhere = same
+    if dist.is_available() and dist.is_initialized():
+        ref = net_a.store.flat.clone()
+        dist.broadcast(ref, 0)
+        identical = bool(torch.equal(ref, net_a.store.flat))
+        flag = torch.tensor([1.0 if (same and identical) else 0.0], device=net_a.store.flat.device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        everywhere = bool(flag.item() == 1.0)
+    return {"equal_on_this_rank": same, "ranks_identical": identical, "equal_everywhere": everywhere, "steps": steps,
+            "collectives_per_step": logs[-1] if logs else [], "timings_last_step": net_a._gsync.timings() if on_gpu else {}}

@@ -243,11 +243,12 @@ def _desc_gather(xyz, new_xyz, feat, idx):
     return d
 
 
-# Matrices made on the fly (pool_dgrad's W diag(C) W^T) can get an image too (votenet_split_weights_one + a registration around the
-# one launch).  Measured, same box (tools/ab_step.py mlp.SPLIT_ADHOC False True): 6.25 -> 6.35 ms per step -- those GEMMs run beside
-# the weight-gradient stream and are bound by the traffic they share with it, not by the matrix pipe; the extra launch sits on the
-# backward pass's dependent chain.  Off.
-SPLIT_ADHOC = False
+# Matrices made on the fly (pool_dgrad's W diag(C) W^T) get an image too: votenet_pool_dgrad_prepare_split writes it in the launch
+# that forms the matrix, and the image is registered around the one GEMM that multiplies by it.  (Round 2 built the image with a
+# separate launch and measured a loss inside the three-stream step; the step is the SUM of its kernels' alone-times -- round 3,
+# tools/serial_step.py -- and this GEMM alone is 0.253 -> 0.124 ms at sa2 on split operands.)  SPLIT_ADHOC_ROWS: below that the
+# launch is latency-bound either way.
+SPLIT_ADHOC = True
 SPLIT_ADHOC_ROWS = 65536
 
 
@@ -594,12 +595,20 @@ def bn_backward_reduce_pool(gout, zsel, scale, shift, mean, var, relu, eps=BN_EP
     return coef if coef is not None else _coef_after(tail, (scale, shift, mean, var), sums, eps)
 
 
-def pool_dgrad_prepare(w, bias, coef):
-    """-> (cin + 1, cin): [W diag(C) W^T ; (B + C.b) W^T], the weights / bias of the dense part of pool_dgrad."""
+def pool_dgrad_prepare(w, bias, coef, rows=None):
+    """-> (cin + 1, cin): [W diag(C) W^T ; (B + C.b) W^T], the weights / bias of the dense part of pool_dgrad.  With SPLIT_ADHOC
+    (and a shape the split-operand GEMM serves; rows = the rows of that GEMM) the result carries the matrix's bf16 x 3 image (._img)."""
     cin, cout = w.shape
     mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=w.device)
+    want_img = SPLIT_ADHOC and split_eligible(cin, cin) and (rows is None or rows >= SPLIT_ADHOC_ROWS)
     with L.device_guard(w.device):
-        L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
+        if want_img:
+            img = torch.empty(cin * cin * 6, dtype=torch.uint8, device=w.device)
+            L.check(L.lib().votenet_pool_dgrad_prepare_split(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]),
+                                                             L.ptr(img), L.stream_ptr()))
+            mm._img = img
+        else:
+            L.check(L.lib().votenet_pool_dgrad_prepare(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]), L.stream_ptr()))
     return mm
 
 
@@ -612,12 +621,10 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     rows, cin = xz.shape
     cout = w.shape[1]
     if mm is None:
-        mm = pool_dgrad_prepare(w, bias, coef)
-    if SPLIT_ADHOC and split_eligible(cin, cin) and rows >= SPLIT_ADHOC_ROWS:
-        # the matrix exists only for this launch: its bf16 x 3 image (one small launch), registered around the GEMM's launch only
-        img = torch.empty(cin * cin * 6, dtype=torch.uint8, device=xz.device)
-        with L.device_guard(xz.device):
-            L.check(L.lib().votenet_split_weights_one(L.ptr(mm), cin, cin, L.ptr(img), L.stream_ptr()))
+        mm = pool_dgrad_prepare(w, bias, coef, rows)
+    img = getattr(mm, "_img", None)
+    if img is not None:
+        # the matrix exists only for this launch: its image is registered around the GEMM's launch only
         L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(img)))
         try:
             da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)

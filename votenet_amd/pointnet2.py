@@ -472,7 +472,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             x, aff, W, b = r["x"], r["in_affine"], L.p("W"), L.p("b")
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
             coef = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu, tail=tail_of(r))
-            mm = M.pool_dgrad_prepare(W, b, coef) if want_da else None
+            mm = M.pool_dgrad_prepare(W, b, coef, x.shape[0]) if want_da else None
             def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da):
                 G = M.gram(x, aff[:2], r["in_relu"])
                 M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
