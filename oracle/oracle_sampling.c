@@ -18,9 +18,48 @@
  *   - d = (x2-x1)^2+(y2-y1)^2+(z2-z1)^2 in fp32, no FMA (:142); d2 = min(d,td) (:143)
  *   - m <= 0: nothing written (:106-107)
  */
+
+/*
+ * Non-finite coordinates.  NOT a restatement: with a NaN point the CUDA kernel's fminf / '>' leave it at its initial distance
+ * 1e38, pick it at once and, with a NaN centre, freeze every running distance -- an artefact, not a behaviour anyone relies on.
+ * The build DEFINES the case (csrc/fps.hip fps_get): a point with a non-finite coordinate is read as a copy of
+ * point 0 (so it is never sampled), point 0's own non-finite components are read as 0.  Finite clouds are untouched.
+ * -> a sanitized copy of the batch, or NULL when every coordinate is finite.
+ */
+static int nonfinite_bits(float v)
+{
+    unsigned u;
+    memcpy(&u, &v, 4);
+    return (u & 0x7f800000u) == 0x7f800000u;
+}
+static float *fps_defined_cloud(int b, int n, const float *dataset)
+{
+    const size_t tot = (size_t)(b > 0 ? b : 0) * (size_t)(n > 0 ? n : 0) * 3;
+    size_t i;
+    for (i = 0; i < tot; i++)
+        if (nonfinite_bits(dataset[i])) break;
+    if (i == tot) return NULL;
+    float *c = (float *)malloc(sizeof(float) * (tot ? tot : 1));
+    memcpy(c, dataset, sizeof(float) * tot);
+    for (int s = 0; s < b; s++) {
+        float *p = c + (size_t)s * n * 3;
+        for (int a = 0; a < 3 && n > 0; a++)
+            if (nonfinite_bits(p[a])) p[a] = 0.0f;
+        for (int k = 1; k < n; k++)
+            if (nonfinite_bits(p[k * 3]) || nonfinite_bits(p[k * 3 + 1]) || nonfinite_bits(p[k * 3 + 2])) {
+                p[k * 3] = p[0];
+                p[k * 3 + 1] = p[1];
+                p[k * 3 + 2] = p[2];
+            }
+    }
+    return c;
+}
+
 void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int *idxs)
 {
     if (m <= 0) return;
+    float *defined = fps_defined_cloud(b, n, dataset);
+    if (defined) dataset = defined;
     float *temp_all = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1) * (size_t)(b > 0 ? b : 1));
     /* only in liboracle_omp.so: the scenes are independent (the rounds of a scene are a dependent chain; a fork/join per
      * round costs more than the round) */
@@ -71,6 +110,7 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int
         }
     }
     free(temp_all);
+    free(defined);
 }
 
 /*
@@ -81,6 +121,8 @@ void oracle_farthest_point_sample(int b, int n, int m, const float *dataset, int
 void oracle_farthest_point_sample_closed(int b, int n, int m, const float *dataset, int *idxs)
 {
     if (m <= 0) return;
+    float *defined = fps_defined_cloud(b, n, dataset);
+    if (defined) dataset = defined;
     float *temp = (float *)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
     for (int i = 0; i < b; i++) {
         const float *pts = dataset + (size_t)i * n * 3;
@@ -110,6 +152,7 @@ void oracle_farthest_point_sample_closed(int b, int n, int m, const float *datas
         }
     }
     free(temp);
+    free(defined);
 }
 
 /* gatherpointKernel, tf_sampling_g.cu:172-181 */

@@ -215,16 +215,25 @@ def _check_worker(rank, world, port, q, sabotage):
         net.init_optimizer(lr=1e-3)
     cot = dict(proposals_output=torch.zeros(B, 256, 79), votes_xyz=None)
 
+    orig_sa3 = nets[0].sa3.backward
+
     def run(net, i):
         step_no[0] = i + 1
         if sabotage and net is nets[0]:
-            real = net.sa3.backward
+            gs = net._gsync
 
             def early(rec, g_out, **kw):
-                net._gsync.start_tail(None)          # too early: sa3's own gradients are not in the bucket yet
-                net._gsync.start_tail = lambda streams=None: None
-                return real(rec, g_out, **kw)
+                gs.start_tail(None)                  # too early: sa3's own gradients are not in the bucket yet
+                gs._work[-1].wait()                  # (make the race lose every time: the collective completes before sa3 writes)
+                gs.start_tail = lambda streams=None: None  # the real call site, after sa3: nothing left to start
+                return orig_sa3(rec, g_out, **kw)
             net.sa3.backward = early
+            try:
+                net.train_step(torch.zeros(B, 64, 3), cot, world)
+            finally:
+                gs.__dict__.pop("start_tail", None)
+                net.sa3.backward = orig_sa3
+            return
         net.train_step(torch.zeros(B, 64, 3), cot, world)
     res = dp.check_overlap_against_blocking(nets[0], nets[1], run, steps=2)
     info = dp.comm_info(torch.device("cpu"))

@@ -79,6 +79,112 @@ def test_forward_small_vs_oracle(hiplib, dev, O):
     assert out["proposals_output"].shape == (2, 256, 79)
 
 
+_FULL = {}
+
+
+def _perturbed_net(dev, seed):
+    from votenet_amd import model as VM
+    net = VM.VoteNetHotPath(dev, seed=seed)
+    g = torch.Generator().manual_seed(1)
+    for name, v in net.store.views.items():
+        if name.endswith("gamma"):
+            v.copy_((1 + 0.2 * torch.randn(v.shape, generator=g)).to(dev))
+        if name.endswith("beta") or name.endswith("/b"):
+            v.copy_((0.1 * torch.randn(v.shape, generator=g)).to(dev))
+    return net
+
+
+def _device_layers(net, x, dev):
+    """The stack module by module (what VoteNetHotPath.forward runs, with every intermediate kept)."""
+    from votenet_amd import mlp as M
+    net.store.refresh_split()
+    M.arena_begin(dev)
+    try:
+        l1x, l1p, _ = net.sa1.forward(x, x)
+        l2x, l2p, _ = net.sa2.forward(l1x, l1p)
+        l3x, l3p, _ = net.sa3.forward(l2x, l2p)
+        l4x, l4p, _ = net.sa4.forward(l3x, l3p)
+        l3p2 = net.fp1.forward(l3x, l4x, l3p, l4p)
+        seeds = net.fp2.forward(l2x, l3x, l2p, l3p2)
+        vx, vp = net.vote(l2x, seeds)
+        px, pout = net.propose(vx, vp, l2x)
+    finally:
+        M.arena_end()
+    torch.cuda.synchronize()
+    return dict(l1x=l1x, l1p=l1p, l2x=l2x, l2p=l2p, l3x=l3x, l3p=l3p, l4x=l4x, l4p=l4p, l3p2=l3p2, seeds=seeds, vx=vx, vp=vp, px=px, pout=pout)
+
+
+def test_forward_full_size_vs_oracle_layer_by_layer(hiplib, dev, O, gemm_form):
+    """The layer stack at the REAL sizes of model.py:39-57,89-93 (2 x 20480 points -> 2048 -> 1024 -> 512 -> 256, K = 64, fp1, fp2,
+    voting, proposal) against the CPU oracle, layer by layer, on both GEMM forms: sampled indices / centres bit-exact, features to
+    2e-5 of the tensor maximum.  The oracle runs on all host cores (liboracle_omp.so: bit-identical to the single-thread build,
+    tests/test_oracle_omp.py); its result is computed once for both forms."""
+    import os
+    from votenet_amd import synth
+    x = synth.room_batch(2, 20480, 4242)
+    net = _perturbed_net(dev, 3)
+    got = {k: N(v) for k, v in _device_layers(net, torch.from_numpy(x).to(dev), dev).items()}
+    if "ref" not in _FULL:
+        prev = O.set_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
+        try:
+            r = {}
+            r["l1x"], r["l1p"] = oracle_sa(O, net.sa1, x, x)
+            r["l2x"], r["l2p"] = oracle_sa(O, net.sa2, r["l1x"], r["l1p"])
+            r["l3x"], r["l3p"] = oracle_sa(O, net.sa3, r["l2x"], r["l2p"])
+            r["l4x"], r["l4p"] = oracle_sa(O, net.sa4, r["l3x"], r["l3p"])
+            r["l3p2"] = oracle_fp(O, net.fp1, r["l3x"], r["l4x"], r["l3p"], r["l4p"])
+            r["seeds"] = oracle_fp(O, net.fp2, r["l2x"], r["l3x"], r["l2p"], r["l3p2"])
+            xx = np.concatenate([r["l2x"], r["seeds"]], 2).reshape(-1, 259)
+            votes = (xx + oracle_chain(O, xx, net.voting)).reshape(2, -1, 259)
+            r["vx"], r["vp"] = votes[..., :3], votes[..., 3:]
+        finally:
+            O.set_threads(prev)
+        _FULL["ref"] = r
+    r = _FULL["ref"]
+
+    def relerr(a, b):
+        return float(np.abs(a - b).max() / max(1.0, np.abs(b).max()))
+    for k in ("l1x", "l2x", "l3x", "l4x"):
+        assert (got[k] == r[k]).all(), k  # FPS picks (incl. the prefix shortcut of the lower levels) and gathered centres: exact
+    errs = {k: relerr(got[k], r[k]) for k in ("l1p", "l2p", "l3p", "l4p", "l3p2", "seeds", "vx", "vp")}
+    assert max(errs.values()) < 2e-5, errs
+    # proposal layer on the DEVICE votes (its neighbour lists depend on the vote coordinates to the last bit)
+    prev = O.set_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
+    try:
+        px, pout = oracle_sa(O, net.proposal, got["vx"], got["vp"], sample_xyz=r["l2x"])
+    finally:
+        O.set_threads(prev)
+    assert (got["px"] == px).all()
+    assert relerr(got["pout"], pout) < 2e-5 and got["pout"].shape == (2, 256, 79)
+
+
+def test_config5_scene_through_sa1_vs_oracle(hiplib, dev, O, gemm_form):
+    """One 80 000-point config-5 scene through sa1 -- the L2-resident bucket FPS, the indexed ball query and the narrow
+    first layer + two GEMMs + max over K at 131 072 grouped rows -- against the oracle: centres exact, features to 2e-5."""
+    import os
+    from votenet_amd import synth
+    x = synth.room_batch(1, 80000, 77, size=(8.0, 3.0, 8.0), nbox=(15, 25))
+    net = _perturbed_net(dev, 3)
+    from votenet_amd import mlp as M
+    net.store.refresh_split()
+    M.arena_begin(dev)
+    try:
+        xt = torch.from_numpy(x).to(dev)
+        l1x, l1p, _ = net.sa1.forward(xt, xt)
+    finally:
+        M.arena_end()
+    if "cfg5" not in _FULL:
+        prev = O.set_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
+        try:
+            _FULL["cfg5"] = oracle_sa(O, net.sa1, x, x)
+        finally:
+            O.set_threads(prev)
+    rx, rp = _FULL["cfg5"]
+    assert (N(l1x) == rx).all()
+    err = float(np.abs(N(l1p) - rp).max() / max(1.0, np.abs(rp).max()))
+    assert err < 2e-5, err
+
+
 def test_predict_tail_nms_vs_oracle(hiplib, dev, O):
     """Predict tower (model.py:98-139): decoded boxes -> device NMS equals the oracle NMS on the same boxes."""
     from votenet_amd import model as VM
@@ -106,8 +212,9 @@ def _brute_ball(xyz, centre, r, k):
 
 
 def test_config5_dense_scan_forward_properties(hiplib, dev):
-    """BASELINE config 5 (4 x 80 000-point scenes, 2048 -> 1024 seeds -> 512 -> 256, 256 proposals) at full size: the CPU
-    oracle would take minutes, so the checks are size-independent properties of the path's pieces."""
+    """BASELINE config 5 (4 x 80 000-point scenes, 2048 -> 1024 seeds -> 512 -> 256, 256 proposals) at full size through
+    size-independent properties of the path's pieces (one scene of it goes through sa1 against the oracle in
+    test_config5_scene_through_sa1_vs_oracle)."""
     from votenet_amd import model as VM
     from votenet_amd import synth, tf_sampling as S
     x = torch.from_numpy(synth.room_batch(4, 80000, 77, size=(8.0, 3.0, 8.0), nbox=(15, 25))).to(dev)  # SURVEY 8d, config 5

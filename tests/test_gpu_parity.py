@@ -103,6 +103,75 @@ def test_fps_of_an_fps_ordered_subset_short_cut_is_exact(ops, dev, O, hiplib):
     assert 8 <= identity < 20  # both outcomes were exercised: confirmed prefixes and ties that break them
 
 
+def _with_holes(xyz, rng, frac=0.01, first=False):
+    """NaN / +-Inf in single components, in whole points, optionally in point 0 (the first centre)."""
+    x = xyz.copy()
+    b, n = x.shape[:2]
+    k = max(2, int(n * frac))
+    for s in range(b):
+        pts = rng.choice(np.arange(1, n), size=min(k, n - 1), replace=False)
+        vals = rng.choice(np.array([np.nan, np.inf, -np.inf], np.float32), size=len(pts))
+        comp = rng.integers(0, 3, size=len(pts))
+        x[s, pts, comp] = vals
+        x[s, pts[: len(pts) // 3]] = np.nan  # whole points
+        if first:
+            x[s, 0, s % 3] = np.nan
+    return x
+
+
+@pytest.mark.parametrize("n,m", [(300, 100), (2048, 512), (4096, 700), (8192, 300), (20480, 400), (24577, 60), (80000, 150), (262145, 8)])
+def test_fps_of_a_cloud_with_nan_and_inf_points_is_defined_in_range_and_equals_the_oracle(ops, dev, O, n, m):
+    """Depth clouds have holes.  Every sampling kernel (register, bucket-pruned, L2-resident, streaming, the prefix shortcut) reads a
+    point with a non-finite coordinate as a copy of point 0 (fps.hip: fps_get; oracle_sampling.c defines the same): never a hang,
+    never an index outside [0, n), a hole is never sampled, and the picks are the oracle's."""
+    rng = np.random.default_rng(n + m)
+    base = rng.random((2, n, 3), dtype=np.float32) * 5
+    for first in (False, True):
+        xyz = _with_holes(base, rng, first=first)
+        got = N(ops.s.farthest_point_sample(m, T(xyz, dev)))
+        assert got.min() >= 0 and got.max() < n
+        exp = O.farthest_point_sample(m, xyz)
+        assert (got == exp).all()
+        holes = ~np.isfinite(xyz).all(-1)
+        for s in range(2):
+            assert not holes[s, got[s, 1:]].any()
+        assert (got[:, 0] == 0).all()
+
+
+def test_geometry_chain_and_ball_query_with_holes(ops, dev, O):
+    """The whole coordinate-only chain of sa1 / sa2 on a cloud with holes: FPS -> centres -> ball query over the spatial index the
+    sampling left behind -> the next level (prefix shortcut on centres whose first entry may be a hole).  Indices in range; the
+    ball query equals the full scan and the oracle (a non-finite distance never passes the radius test: holes are no neighbours)."""
+    from votenet_amd import synth, tf_sampling as S
+    rng = np.random.default_rng(9)
+    for first in (False, True):
+        xyz = _with_holes(synth.room_batch(2, 20480, 31), rng, frac=0.02, first=first)
+        x = T(xyz, dev)
+        S._INDEX_CACHE.clear()
+        fidx = ops.s.farthest_point_sample(2048, x)
+        assert S.cached_index(x) is not None
+        assert (N(fidx) == O.farthest_point_sample(2048, xyz)).all()
+        new_xyz = ops.s.gather_point(x, fidx)
+        idx, cnt = ops.g.query_ball_point(0.2, 64, x, new_xyz)               # over the index
+        oi, oc = O.query_ball_point(0.2, 64, xyz, N(new_xyz))
+        assert (N(idx) == oi).all() and (N(cnt) == oc).all()
+        ops.g.USE_INDEX = False
+        try:
+            bi, bc = ops.g.query_ball_point(0.2, 64, x, new_xyz)             # full scan
+        finally:
+            ops.g.USE_INDEX = True
+        assert torch.equal(bi, idx) and torch.equal(bc, cnt)
+        holes = ~np.isfinite(xyz).all(-1)
+        ii, cc = N(idx), N(cnt)
+        for s in range(2):
+            used = np.concatenate([ii[s, j, :max(1, cc[s, j])] for j in range(2048) if cc[s, j] > 0])
+            assert not holes[s, used].any()
+        # next level: the centres (a hole at index 0 when `first`) through the prefix shortcut and the rounds
+        f2 = ops.s.farthest_point_sample(1024, new_xyz)
+        assert (N(f2) == O.farthest_point_sample(1024, N(new_xyz))).all()
+        assert int(f2.min()) >= 0 and int(f2.max()) < 2048
+
+
 def test_fps_full_size_properties(ops, dev):
     """BASELINE config 2 size (8 x 20480 -> 2048): size-independent properties, checked on the device."""
     xyz = T(np.random.default_rng(0).random((8, 20480, 3), dtype=np.float32) * 5, dev)
@@ -444,8 +513,8 @@ def test_nms_full_size_vs_oracle(ops, dev, O):
     keep = N(ops.n.NMS3D(bb, sc, ob, 0.25))
     exp = O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.25)
     iou = np.stack([O.iou3d_matrix(c["bboxes"][s]) for s in range(8)])
-    if not (np.abs(iou - 0.25) < 1e-5).any():
-        assert (keep == exp).all()
+    assert not (np.abs(iou - 0.25) < 1e-5).any()  # the seed was chosen so: no pair within rounding of the threshold, the lists are exact
+    assert (keep == exp).all()
     assert np.allclose(N(ops.n.iou3d_matrix(bb)), iou, rtol=0, atol=1e-5, equal_nan=True)
 
 
@@ -461,9 +530,50 @@ def test_nms_greedy_by_bit_masks_and_by_the_wave_loop_vs_oracle(ops, dev, O, b, 
     exp = O.nms3d(c["bboxes"], c["scores"], ob, thr)
     iou = np.stack([O.iou3d_matrix(c["bboxes"][s]) for s in range(b)])
     assert len(keep) < int((ob[..., 1] > ob[..., 0]).sum())  # something was suppressed
-    if (np.abs(iou - thr) < 1e-5).any():  # an IoU within rounding of the threshold may fall either side
-        pytest.skip("a pair of this case lies within 1e-5 of the threshold")
+    assert not (np.abs(iou - thr) < 1e-5).any()  # seeds chosen so (an IoU within rounding of the threshold could fall either side)
     assert keep.shape == exp.shape and (keep == exp).all()
+
+
+def _greedy_on_matrix(M, order, thr):
+    """tf_nms3d.cpp:237-262 on a given IoU matrix of one scene: M is read as M[candidate][kept] (suppress_check(candidate, selected))."""
+    kept = []
+    for c in order:
+        if not any(M[c, k] > thr for k in kept):
+            kept.append(int(c))
+    return kept
+
+
+@pytest.mark.parametrize("n_pad", [0, 460])
+def test_nms_reads_the_pair_matrix_the_way_the_reference_does(ops, dev, n_pad):
+    """iou3d_pair(a, b) and (b, a) may differ in the last bit (the first box's footprint is clipped by the second's).  With the
+    threshold set between the two orientations of a pair, the decision depends on which one is read: both greedy kernels (bit masks
+    up to 512 boxes, wave loop beyond: n_pad pushes the scene over 512) must read [later candidate][earlier box] like the reference."""
+    c = cases.nms_random(b=1, n=64, seed=11, room=2.5)  # dense: many overlapping pairs
+    boxes = c["bboxes"]
+    if n_pad:  # far-away boxes that overlap nothing and score below everything else
+        far = np.stack([cases.corner_box(0.3, 0.3, 0.3, None, (100.0 + 2 * i, 0, 0)) for i in range(n_pad)]).astype(np.float32)
+        boxes = np.concatenate([boxes, far[None]], 1)
+    n = boxes.shape[1]
+    M = N(ops.n.iou3d_matrix(T(boxes, dev)))[0]
+    asym = [(a, b) for a in range(64) for b in range(64) if a != b and M[a, b] > 0.05 and M[a, b] > M[b, a]]
+    assert asym, "no asymmetric pair in this case: pick another seed"
+    hits = 0
+    for a, b in asym[:6]:
+        thr = float(M[b, a])  # M[a, b] > thr is true, M[b, a] > thr is false
+        for first, second in ((a, b), (b, a)):
+            sc = np.full((1, n), -5.0, np.float32) - np.arange(n, dtype=np.float32)[None] * 1e-3
+            sc[0, first], sc[0, second] = 10.0, 9.0
+            obj = np.tile(np.array([1.0, 0.0], np.float32), (1, n, 1))
+            obj[0, [first, second]] = np.array([0.0, 1.0], np.float32)
+            if n_pad:
+                obj[0, 64:] = np.array([0.0, 1.0], np.float32)
+                sc[0, 64:] = -50.0 - np.arange(n_pad, dtype=np.float32)
+            order = [i for i in np.argsort(-sc[0], kind="stable") if obj[0, i, 1] > obj[0, i, 0]]
+            exp = _greedy_on_matrix(M, order, thr)
+            got = N(ops.n.NMS3D(T(boxes, dev), T(sc, dev), T(obj, dev), thr))
+            assert got[:, 1].tolist() == exp, (a, b, first)
+            hits += (second in exp) == bool(M[first, second] > thr)  # reading [earlier][later] instead would have decided differently
+    assert hits > 0
 
 
 def test_nms_nan_scores_are_ordered_last_not_out_of_bounds(ops, dev, O):

@@ -45,6 +45,28 @@ __device__ __forceinline__ unsigned fps_tiekey(unsigned k) { return ((k & 511u) 
 __device__ __forceinline__ unsigned fps_key_to_index(unsigned key) { return ((key & 0x7FFFFFu) << 9) | (key >> 23); }
 __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); }
 
+// Non-finite coordinates (NaN / Inf: holes of a depth camera).  The reference leaves them to fminf / compare artefacts (a NaN point
+// keeps its initial distance 1e38, is picked at once and freezes every running distance); here the result is DEFINED on every path:
+// a point with a non-finite coordinate is read as a copy of point 0 -- it is at distance 0 from the first centre and is never sampled
+// (index 0 wins every all-zero tie) -- and point 0's own non-finite components are read as 0.  Integer tests: this file is built
+// with -fno-honor-nans.  The spatial index marks such points in `perm` (sign bit): the ball query over the index never reports them,
+// like the full scan, where a NaN / Inf distance fails the radius test (oracle/oracle_sampling.c defines the same).
+__device__ __forceinline__ bool fps_nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool fps_get(const float *__restrict__ pts, size_t k, float &x, float &y, float &z)
+{
+    x = pts[k * 3 + 0];
+    y = pts[k * 3 + 1];
+    z = pts[k * 3 + 2];
+    const bool bad = fps_nonfinite(x) || fps_nonfinite(y) || fps_nonfinite(z);
+    if (bad || k == 0) { // rare
+        const float a = pts[0], b = pts[1], c = pts[2];
+        x = fps_nonfinite(a) ? 0.0f : a;
+        y = fps_nonfinite(b) ? 0.0f : b;
+        z = fps_nonfinite(c) ? 0.0f : c;
+    }
+    return bad;
+}
+
 // ---- wave64 reductions on unsigned keys: six dependent VOP2-DPP steps, result uniform
 #define FPS_DPP_REDUCE(OP)                                                                                   \
     asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t" \
@@ -224,12 +246,16 @@ constexpr int kFpsPrefixMax = 2048;
 // leaves at once when it fails: an unordered cloud pays two near-empty launches, not the full check.
 __device__ __forceinline__ bool fps_step1_fails(const float *__restrict__ pts, int n, int tid, int nthreads)
 {
-    const float x0 = pts[0], y0 = pts[1], z0 = pts[2];
-    const float ex = pts[3] - x0, ey = pts[4] - y0, ez = pts[5] - z0;
+    float x0, y0, z0, x1, y1, z1;
+    fps_get(pts, 0, x0, y0, z0);
+    fps_get(pts, 1, x1, y1, z1);
+    const float ex = x1 - x0, ey = y1 - y0, ez = z1 - z0;
     const unsigned t1 = fbits(ex * ex + ey * ey + ez * ez), k1 = fps_tiekey(1u);
     int bad = 0;
     for (int q = tid; q < n; q += nthreads) {
-        const float dx = pts[(size_t)q * 3] - x0, dy = pts[(size_t)q * 3 + 1] - y0, dz = pts[(size_t)q * 3 + 2] - z0;
+        float qx, qy, qz;
+        fps_get(pts, (size_t)q, qx, qy, qz);
+        const float dx = qx - x0, dy = qy - y0, dz = qz - z0;
         const unsigned d = fbits(dx * dx + dy * dy + dz * dz);
         if (q != 1 && !(d < t1 || (d == t1 && fps_tiekey((unsigned)q) > k1))) bad = 1;
     }
@@ -252,11 +278,13 @@ __global__ __launch_bounds__(256) void fps_prefix_t_kernel(int n, int m, const f
     const int k0 = blockIdx.x * 32 + (tid >> 3);
     const bool live = 2 * k0 < m;
     const int ka = live ? k0 : 0, kb = live ? m - 1 - k0 : 0;
-    const float ax0 = pts[(size_t)ka * 3], ay0 = pts[(size_t)ka * 3 + 1], az0 = pts[(size_t)ka * 3 + 2];
-    const float bx0 = pts[(size_t)kb * 3], by0 = pts[(size_t)kb * 3 + 1], bz0 = pts[(size_t)kb * 3 + 2];
+    float ax0, ay0, az0, bx0, by0, bz0;
+    fps_get(pts, (size_t)ka, ax0, ay0, az0);
+    fps_get(pts, (size_t)kb, bx0, by0, bz0);
     unsigned ta = fbits(1e38f), tb = ta;
     for (int i = sub; i < kb; i += 8) {
-        const float cx = pts[(size_t)i * 3], cy = pts[(size_t)i * 3 + 1], cz = pts[(size_t)i * 3 + 2];
+        float cx, cy, cz;
+        fps_get(pts, (size_t)i, cx, cy, cz);
         const float bx = bx0 - cx, by = by0 - cy, bz = bz0 - cz; // point minus centre, tf_sampling_g.cu:142
         tb = min(tb, fbits(bx * bx + by * by + bz * bz));
         if (i < ka) {
@@ -283,13 +311,17 @@ __global__ __launch_bounds__(128) void fps_prefix_check_kernel(int n, int m, con
     int *__restrict__ o = out + (size_t)blockIdx.y * m;
     const int tid = threadIdx.x, sub = tid & 7;
     if (fps_step1_fails(pts, n, tid, 128)) return; // fps_prefix_t_kernel has set the verdict
-    for (int k = tid; k < m; k += 128)
-        P4[k] = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k ? o[k] : 0));
+    for (int k = tid; k < m; k += 128) {
+        float px, py, pz;
+        fps_get(pts, (size_t)k, px, py, pz);
+        P4[k] = make_float4(px, py, pz, __int_as_float(k ? o[k] : 0));
+    }
     __syncthreads();
     const int q = blockIdx.x * 16 + (tid >> 3);
     const bool live = q < n;
     const int qq = live ? q : 0;
-    const float x = pts[(size_t)qq * 3], y = pts[(size_t)qq * 3 + 1], z = pts[(size_t)qq * 3 + 2];
+    float x, y, z;
+    fps_get(pts, (size_t)qq, x, y, z);
     const unsigned qkey = fps_tiekey((unsigned)qq);
     // lane `sub` owns the steps k in [k_lo, k_hi): step k uses centre k-1
     const int L = (m - 1 + 7) / 8;
@@ -340,16 +372,16 @@ __global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const fl
     for (int i = 0; i < P; i++) {
         const int k = fps_slot_to_k<NW, P>(tid, i);
         const bool valid = k < n;
-        x[i] = valid ? pts[(size_t)k * 3 + 0] : 0.0f;
-        y[i] = valid ? pts[(size_t)k * 3 + 1] : 0.0f;
-        z[i] = valid ? pts[(size_t)k * 3 + 2] : 0.0f;
+        x[i] = y[i] = z[i] = 0.0f;
+        if (valid) fps_get(pts, (size_t)k, x[i], y[i], z[i]);
         td[i] = valid ? fbits(1e38f) : 0u; // tf_sampling_g.cu:118
     }
     if (tid == 0) fps_cross_init(s_ex);
     __syncthreads();
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
-    float cx = pts[0], cy = pts[1], cz = pts[2];
+    float cx, cy, cz;
+    fps_get(pts, 0, cx, cy, cz);
     for (int j = 1; j < m; j++) {
         unsigned best = 0u;
         int bi = 0;
@@ -403,9 +435,11 @@ __device__ __forceinline__ unsigned part1by2_4(unsigned v) // spread 4 bits: abc
 __device__ __forceinline__ unsigned sidx_cell(const float *__restrict__ pts, int k, const float *lo, const float *inv)
 {
     unsigned c = 0;
+    float p3[3];
+    fps_get(pts, (size_t)k, p3[0], p3[1], p3[2]);
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-        int q = (int)((pts[(size_t)k * 3 + a] - lo[a]) * inv[a]);
+        int q = (int)((p3[a] - lo[a]) * inv[a]);
         q = q < 0 ? 0 : (q > 15 ? 15 : q);
         c |= part1by2_4((unsigned)q) << a;
     }
@@ -421,8 +455,10 @@ __global__ __launch_bounds__(256) void sidx_bounds_kernel(int n, const float *__
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int i = blockIdx.x * 256 + tid; i < n * 3; i += 256 * kSidxParts) { // coalesced: component a = i % 3
-        const float v = pts[i];
+        float v = pts[i];
         const int a = i % 3;
+        if (fps_nonfinite(v)) v = pts[a]; // a hole reads as point 0 (fps_get): leaves the bounds alone
+        if (fps_nonfinite(v)) v = 0.0f;
         mn[0] = a == 0 ? fminf(mn[0], v) : mn[0];
         mx[0] = a == 0 ? fmaxf(mx[0], v) : mx[0];
         mn[1] = a == 1 ? fminf(mn[1], v) : mn[1];
@@ -538,9 +574,10 @@ __global__ __launch_bounds__(256) void sidx_scatter_kernel(int n, const float *_
     const int k1 = min(n, (int)(blockIdx.x + 1) * chunk);
     for (int k = blockIdx.x * chunk + threadIdx.x; k < k1; k += 256) {
         const int pos = atomicAdd(&s_off[sidx_cell(pts, k, lo, inv)], 1);
-        perm[(size_t)blockIdx.y * n + pos] = k;
-        sorted[(size_t)blockIdx.y * nb * 64 + pos] =
-            make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], __int_as_float(k));
+        float px, py, pz;
+        const bool hole = fps_get(pts, (size_t)k, px, py, pz);
+        perm[(size_t)blockIdx.y * n + pos] = hole ? (int)((unsigned)k | 0x80000000u) : k; // sign bit: never a ball-query neighbour
+        sorted[(size_t)blockIdx.y * nb * 64 + pos] = make_float4(px, py, pz, __int_as_float(k));
     }
 }
 
@@ -631,7 +668,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     __syncthreads();
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
-    float cx = pts[0], cy = pts[1], cz = pts[2];
+    float cx, cy, cz;
+    fps_get(pts, 0, cx, cy, cz);
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
     int cw_slot = -1;                           // ... and the slot (bucket) it lives in
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
@@ -765,10 +803,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
         unsigned key = 0xFFFFFFFFu;
         float px = 0.f, py = 0.f, pz = 0.f;
         if (valid) {
-            const int k = pm[p];
-            px = pts[(size_t)k * 3 + 0];
-            py = pts[(size_t)k * 3 + 1];
-            pz = pts[(size_t)k * 3 + 2];
+            const int k = pm[p] & 0x7fffffff;
+            fps_get(pts, (size_t)k, px, py, pz);
             key = fps_tiekey((unsigned)k);
         }
         X[i] = px;
@@ -789,7 +825,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
     __syncthreads();
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid);
-    float cx = pts[0], cy = pts[1], cz = pts[2]; // first centre of the round
+    float cx, cy, cz; // first centre of the round
+    fps_get(pts, 0, cx, cy, cz);
     float ex2 = cx, ey2 = cy, ez2 = cz;          // second centre (valid when two)
     bool two = false;
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's best point (uniform) ...
@@ -957,8 +994,10 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
     for (int p = tid; p < nb * 64; p += NW * 64) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < n) {
-            const int k = pm[p];
-            v = make_float4(pts[(size_t)k * 3 + 0], pts[(size_t)k * 3 + 1], pts[(size_t)k * 3 + 2], 1e38f); // tf_sampling_g.cu:118
+            const int k = pm[p] & 0x7fffffff;
+            float px, py, pz;
+            fps_get(pts, (size_t)k, px, py, pz);
+            v = make_float4(px, py, pz, 1e38f); // tf_sampling_g.cu:118
         }
         sp[p] = v;
     }
@@ -987,7 +1026,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
     __syncthreads(); // the sorted copy (written by other waves) is read below: block-scope release / acquire
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
-    float cx = pts[0], cy = pts[1], cz = pts[2];
+    float cx, cy, cz;
+    fps_get(pts, 0, cx, cy, cz);
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
     int cw_slot = -1;                           // ... and its bucket (slot * 64 + lane)
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
@@ -1015,7 +1055,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
                         act &= act - 1;
                         const size_t base = (size_t)((s * 64 + li[f]) * NW + w) * 64 + lane;
                         pv[f] = sp[base];
-                        pk[f] = (base < (size_t)n) ? pm[base] : -1;
+                        pk[f] = (base < (size_t)n) ? (pm[base] & 0x7fffffff) : -1;
                         cnt = f + 1;
                     }
                 }
@@ -1107,13 +1147,15 @@ __global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m
         for (int k = tid; k < n; k += T) td[k] = fbits(1e38f);
         FpsOut fo = {o, m, 0};
         fo.put(0, 0, tid);
-        float cx = pts[0], cy = pts[1], cz = pts[2];
+        float cx, cy, cz;
+        fps_get(pts, 0, cx, cy, cz);
         for (int j = 1; j < m; j++) {
             unsigned best = 0u, bk = (unsigned)tid;
             float bx = 0.f, by = 0.f, bz = 0.f;
             bool any = false;
             for (int k = tid; k < n; k += T) { // ascending k, k mod 512 constant per lane
-                const float px = pts[(size_t)k * 3 + 0], py = pts[(size_t)k * 3 + 1], pz = pts[(size_t)k * 3 + 2];
+                float px, py, pz;
+                fps_get(pts, (size_t)k, px, py, pz);
                 const float dx = px - cx, dy = py - cy, dz = pz - cz;
                 const float d = dx * dx + dy * dy + dz * dz;
                 const unsigned t0 = td[k];

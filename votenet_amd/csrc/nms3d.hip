@@ -249,11 +249,14 @@ __global__ __launch_bounds__(256) void nms_greedy_mask_kernel(int n, float thr, 
     const int L = s_len;
     // (b) suppression rows: bit j of row i = candidate j comes later and overlaps candidate i by more than thr.  A wave per row,
     //     a lane per candidate j of the word: the word is the ballot of the 64 comparisons
+    //     The matrix is read as iou[later candidate][earlier box] -- suppress_check(candidate, selected) of tf_nms3d.cpp:250, the
+    //     orientation nms_greedy_kernel below uses too: iou3d_pair clips the first box by the second, so the two orientations
+    //     of a pair can differ in the last bit, and a pair within an ulp of the threshold must fall the reference's way
     for (int i = w; i < L; i += 4) {
-        const float *__restrict__ row = miou + (size_t)s_list[i] * n;
+        const int col = s_list[i];
         for (int wd = 0; wd < W; wd++) {
             const int j = wd * 64 + lane;
-            const bool hit = j > i && j < L && row[s_list[j < L ? j : 0]] > thr; // tf_nms3d.cpp:250 (strict >)
+            const bool hit = j > i && j < L && miou[(size_t)s_list[j < L ? j : 0] * n + col] > thr; // strict >
             const unsigned long long m = __ballot(hit);
             if (lane == 0) s_mask[(size_t)i * W + wd] = m;
         }
