@@ -133,6 +133,14 @@ int votenet_three_interpolate(int b, int m, int c, int n, const float *points, c
  * grad_points (b,m,c) += ; pre-zeroed by the caller. */
 int votenet_three_interpolate_grad(int b, int n, int c, int m, const float *grad_out, const int *idx,
                                    const float *weight, float *grad_points, void *stream);
+/* The FP layer's concat written by the interpolation (utils.py:283-286): out (b,n,c+c1) = [three_interpolate(points) | skip],
+ * skip (b,n,c1) = the unknown points' own features. */
+int votenet_three_interpolate_concat(int b, int m, int c, int n, const float *points, const int *idx, const float *weight,
+                                     const float *skip, int c1, float *out, void *stream);
+/* votenet_three_interpolate_grad with grad_out read in place from a wider tensor: rows of go_pitch floats, the c channels at go_off
+ * (the gradient of the concat above is [d interpolated | d skip]). */
+int votenet_three_interpolate_grad_strided(int b, int n, int c, int m, const float *grad_out, int go_pitch, int go_off,
+                                           const int *idx, const float *weight, float *grad_points, void *stream);
 
 /* ---------------------------------------------------------------- tf_ops/3d_nms */
 
@@ -334,6 +342,9 @@ int votenet_bn_backward_apply(long rows, int c, int k, const float *da, const in
 
 /* dbias[c] += column sums of dz (rows x c); scratch: c doubles. */
 int votenet_bias_grad(long rows, int c, const float *dz, double *scratch, float *dbias, void *stream);
+/* the same over the first c columns of rows of `pitch` floats (the zero-padded gradient of a ragged layer); zeroed_scratch:
+ * c doubles the CALLER has cleared */
+int votenet_bias_grad_strided(long rows, int c, const float *dz, int pitch, double *zeroed_scratch, float *dbias, void *stream);
 
 /* dw (cin x cout, the caller's row order) += input(rows x cin)^T * dz (rows x cout), the input
  * described exactly as for votenet_mlp_linear (same fused GATHER / DENSE+BNReLU loaders).
@@ -621,6 +632,21 @@ int votenet_augment_boxes(int b, int n_box_out, const long *box_offset, const do
 /* 3D IoU (the arithmetic of tf_nms3d.cpp:178-192) of every box of set A (b,n,8,3) against every box of set B
  * (b,m,8,3) of the same scene -> iou (b,n,m): the detections-vs-ground-truth overlaps of evaluator.py:26-39,122-132. */
 int votenet_iou3d_cross(int b, int n, int m, const float *boxes_a, const float *boxes_b, float *iou, void *stream);
+
+/* Plumbing between the path's kernels in one launch: concat (utils.py:286, model.py:53), slices of an input gradient, zero
+ * padding of a ragged layer, residual sums (votes = x + offset, model.py:57-61; gradients from two consumers) of row-major
+ * (rows x width) tensors.  For every segment s < nseg <= 8:
+ *     dst[r*dst_pitch + dst_off + c] = a[r*a_pitch + a_off + c] (+ b[r*b_pitch + b_off + c]),  c < width
+ * a == NULL writes zeros; b may be NULL.  Pitches in elements; the segments of one call must not overlap in memory. */
+typedef struct votenet_row_segment {
+    float *dst;
+    int dst_pitch, dst_off, width;
+    const float *a;
+    int a_pitch, a_off;
+    const float *b;
+    int b_pitch, b_off;
+} votenet_row_segment;
+int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, void *stream);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,15 @@ def _torch_clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5,
         p[a:b] -= lr_t * m[a:b] / (v[a:b].sqrt() + eps)
 
 
+def _torch_row_segments(rows, segs):
+    """votenet_row_segments (csrc/glue.hip) as torch ops: dst = a (+ b), zeros without a -- the stand-in for the glue kernel."""
+    for dst, a, b in segs:
+        if a is None:
+            dst.zero_()
+        else:
+            dst.copy_(a if b is None else a + b)
+
+
 def _stub_grad(name, shape, rank, step):
     import zlib
     g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 100000 + 1000 * rank + step)
@@ -159,6 +168,7 @@ def _stub_net(rank, seed, events, step_no, B=2):
         return torch.zeros_like(g)
     P.mlp_chain_backward = chain_backward
     M.clip_adam = _torch_clip_adam
+    M.row_segments = _torch_row_segments
     return net
 
 

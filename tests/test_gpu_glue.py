@@ -1,0 +1,129 @@
+"""GPU: the plumbing kernels that took the tensor-library launches off the train step (csrc/glue.hip, the concat / strided forms
+of three_interpolate, the strided bias gradient) and the one-fill arena -- each against the torch expression it replaces,
+bit for bit (they only move and add fp32 values)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_row_segments_concat_slice_pad_add(hiplib, dev):
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(0)
+    rows = 1031
+    xyz, feat = torch.randn(rows, 3, generator=g).to(dev), torch.randn(rows, 256, generator=g).to(dev)
+    xp = torch.full((rows, 320), 7.0, device=dev)
+    M.row_segments(rows, [(xp[:, :3], xyz, None), (xp[:, 3:259], feat, None), (xp[:, 259:], None, None)])
+    assert torch.equal(xp, torch.nn.functional.pad(torch.cat([xyz, feat], 1), (0, 61)))
+    off = torch.randn(rows, 320, generator=g).to(dev)
+    vx, vp = torch.empty(rows, 3, device=dev), torch.empty(rows, 256, device=dev)
+    M.row_segments(rows, [(vx, xp[:, :3], off[:, :3]), (vp, xp[:, 3:259], off[:, 3:259])])  # two destinations, strided sources
+    votes = xp[:, :259] + off[:, :259]
+    assert torch.equal(vx, votes[:, :3]) and torch.equal(vp, votes[:, 3:])
+    from votenet_amd import InvalidArgumentError
+    with pytest.raises(InvalidArgumentError):
+        M.row_segments(rows, [(vx, xp[:, :4], None)])            # widths differ
+    with pytest.raises(InvalidArgumentError):
+        M.row_segments(rows, [(vx.t(), xyz.t(), None)])          # not row-major
+
+
+def test_add_rows_takes_a_column_slice(hiplib, dev):
+    from votenet_amd import pointnet2 as P
+    g = torch.Generator().manual_seed(1)
+    d_x = torch.randn(4, 100, 512, generator=g).to(dev)
+    other = torch.randn(4, 100, 256, generator=g).to(dev)
+    view = d_x[:, :, 256:]
+    out = P.add_rows(view, other)
+    assert out.is_contiguous() and torch.equal(out, view + other)
+    assert torch.equal(P.add_rows(other, other), other + other)
+
+
+def test_three_interpolate_concat_and_strided_grad(hiplib, dev):
+    from votenet_amd import tf_interpolate as TI
+    g = torch.Generator().manual_seed(2)
+    b, n, m = 3, 257, 64
+    for c, c1 in ((256, 256), (8, 4), (5, 3)):
+        p2 = torch.randn(b, m, c, generator=g).to(dev)
+        p1 = torch.randn(b, n, c1, generator=g).to(dev)
+        idx = torch.randint(0, m, (b, n, 3), generator=g, dtype=torch.int32).to(dev)
+        w = torch.rand(b, n, 3, generator=g).to(dev)
+        x = TI.three_interpolate_concat(p2, idx, w, p1)
+        assert torch.equal(x, torch.cat([TI.three_interpolate(p2, idx, w), p1], 2))
+        d_x = torch.randn(b, n, c + c1, generator=g).to(dev)
+        a = TI.three_interpolate_grad_raw(m, idx, w, d_x[:, :, :c])              # read in place (row pitch c + c1)
+        ref = TI.three_interpolate_grad_raw(m, idx, w, d_x[:, :, :c].contiguous())
+        assert torch.allclose(a, ref, rtol=1e-5, atol=1e-5)                      # atomics: order differs run to run
+
+
+def test_bias_grad_reads_a_padded_gradient_in_place(hiplib, dev):
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(3)
+    dzp = torch.randn(2048, 128, generator=g).to(dev)
+    db = torch.zeros(79, device=dev)
+    M.bias_grad(dzp[:, :79], db)
+    assert torch.allclose(db, dzp[:, :79].double().sum(0).float(), rtol=1e-5, atol=1e-4)
+    db2 = torch.zeros(79, device=dev)
+    M.bias_grad(dzp[:, :79].contiguous(), db2)
+    assert torch.equal(db, db2)
+
+
+def test_arena_hands_out_zeroed_scratch_after_one_fill_and_falls_back_outside_a_pass(hiplib, dev):
+    from votenet_amd import mlp as M
+    a = M._StatsArena
+    assert not a.active
+    t0 = M._zeros_f32((10, 3), dev)                # outside a pass: torch.zeros
+    assert t0.abs().sum() == 0
+    M.arena_begin(dev)
+    try:
+        first = M._zeros_f32((1000, 128), dev)     # first pass of this demand may be beyond the zeroed region: still zeros
+        first.fill_(3.0)
+        M.arena_begin(dev)                         # a pass inside the pass joins it: no second fill, nothing wiped
+        assert first.min() == 3.0
+        M.arena_end()
+        assert a.active
+    finally:
+        M.arena_end()
+    assert not a.active
+    M.arena_begin(dev)                             # the next pass holds the previous demand and is cleared by its one fill
+    try:
+        again = M._zeros_f32((1000, 128), dev)
+        cnt = M._zeros_i64((64, 4), dev)
+        acc = M._zeros_f64(300, dev)
+        assert again.abs().sum() == 0 and cnt.abs().sum() == 0 and acc.abs().sum() == 0
+        assert again.data_ptr() >= a.buf.data_ptr() and again.data_ptr() < a.buf.data_ptr() + a.buf.numel() * 8
+        assert again.data_ptr() % 16 == 0 and cnt.dtype == torch.int64
+    finally:
+        M.arena_end()
+
+
+def test_a_train_step_issues_no_tensor_library_kernels_on_its_chain(hiplib, dev):
+    """What the step still asks of torch between its first GEMM and the optimizer: counted with the dispatch-mode hook -- the
+    gradient-bucket fill, the pass's one arena fill and the two multi-tensor launches of the moving averages are all that is left."""
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from votenet_amd import loss as VL, model as VM, synth
+
+    class Count(TorchDispatchMode):
+        def __init__(self):
+            super().__init__()
+            self.ops = {}
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            name = str(func)
+            launches = not any(k in name for k in ("empty", "view", "as_strided", "reshape", "slice", "select", "detach", "alias", "expand",
+                                                   "record_stream", "transpose", "t.default", "unsqueeze", "_unsafe_view", "stride",
+                                                   "size", "numel", "is_", "dim", "storage_offset", "split", "unbind", "permute", "squeeze",
+                                                   "_local_scalar", "lift_fresh", "item"))
+            if launches:
+                self.ops[name] = self.ops.get(name, 0) + 1
+            return func(*args, **(kwargs or {}))
+    net = VM.VoteNetHotPath(dev, seed=0, npoints=(512, 256, 128, 64))
+    x = torch.from_numpy(synth.room_batch(2, 4096, 5)).to(dev)
+    gt = VL.gt_to_device(synth.room_gt(2, 4096, 5), dev)
+    for _ in range(3):
+        net.train_step(x, gt=gt)
+    torch.cuda.synchronize()
+    with Count() as c:
+        net.train_step(x, gt=gt)
+    torch.cuda.synchronize()
+    launches = sum(c.ops.values())
+    assert launches <= 8, c.ops

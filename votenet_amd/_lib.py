@@ -152,6 +152,19 @@ _SIGS.update({
 })
 
 
+class RowSegment(ctypes.Structure):
+    """struct votenet_row_segment (include/votenet_hip.h)."""
+    _fields_ = [("dst", ctypes.c_void_p), ("dst_pitch", ctypes.c_int), ("dst_off", ctypes.c_int), ("width", ctypes.c_int),
+                ("a", ctypes.c_void_p), ("a_pitch", ctypes.c_int), ("a_off", ctypes.c_int),
+                ("b", ctypes.c_void_p), ("b_pitch", ctypes.c_int), ("b_off", ctypes.c_int)]
+
+
+_SIGS["votenet_three_interpolate_concat"] = [ctypes.c_int] * 4 + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p]
+_SIGS["votenet_three_interpolate_grad_strided"] = [ctypes.c_int] * 4 + [_c_f, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p]
+_SIGS["votenet_bias_grad_strided"] = [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p]
+_SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(RowSegment), ctypes.c_void_p]
+
+
 def lib():
     """Load the library once; raise loudly if it has not been built."""
     global _lib

@@ -51,7 +51,12 @@ __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); 
 // (index 0 wins every all-zero tie) -- and point 0's own non-finite components are read as 0.  Integer tests: this file is built
 // with -fno-honor-nans.  The spatial index marks such points in `perm` (sign bit): the ball query over the index never reports them,
 // like the full scan, where a NaN / Inf distance fails the radius test (oracle/oracle_sampling.c defines the same).
-__device__ __forceinline__ bool fps_nonfinite(float v) { return (__float_as_uint(v) & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ bool fps_nonfinite(float v)
+{
+    unsigned u = __float_as_uint(v);
+    asm volatile("" : "+v"(u)); // opaque: under no-nans-fp-math the optimiser recognises the exponent test as a class test and drops its NaN half
+    return (u & 0x7f800000u) == 0x7f800000u;
+}
 __device__ __forceinline__ bool fps_get(const float *__restrict__ pts, size_t k, float &x, float &y, float &z)
 {
     x = pts[k * 3 + 0];

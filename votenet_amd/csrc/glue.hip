@@ -1,0 +1,79 @@
+// glue.hip -- the plumbing between the path's kernels as ONE small kernel instead of framework element-wise launches (gfx950).
+//
+// Between two GEMMs the reference's graph concatenates, slices, pads and adds small per-point tensors: the FP layers' concat
+// (utils.py:286), the voting input [seeds_xyz | seeds_points] and votes = x + offset (model.py:53-61), the split of a layer's
+// input gradient back into its sources, residual sums of gradients arriving from two consumers.  Done with tensor-library ops
+// each is its own launch (torch.cat, .contiguous(), F.pad = fill + copy, +): ~30 launches of 3-8 us per train step, all on the
+// dependent chain.  votenet_row_segments does any such regrouping of row-major (rows x width) tensors in one launch:
+//
+//     for every segment s (up to 8):   dst_s[r, dst_off_s + c] = a_s[r, a_off_s + c] (+ b_s[r, b_off_s + c])   c < width_s
+//                                      width_s columns of zeros when a_s == NULL (padding of a ragged layer)
+//
+// Every tensor has its own row pitch (elements), so a slice of a wider tensor is read or written in place.  The tensors are small
+// (<= 8192 x 320 floats): one thread per element of the widest segment layout, no vectorisation games -- the launch latency is the cost.
+#include "common.h"
+
+namespace votenet {
+
+constexpr int kMaxSeg = 8;
+struct RowSegs {
+    int nseg;
+    float *dst[kMaxSeg];
+    const float *a[kMaxSeg], *b[kMaxSeg];
+    int dst_pitch[kMaxSeg], dst_off[kMaxSeg], width[kMaxSeg], a_pitch[kMaxSeg], a_off[kMaxSeg], b_pitch[kMaxSeg], b_off[kMaxSeg];
+    int cum[kMaxSeg + 1]; // prefix sums of the widths: a thread's column -> its segment
+};
+
+__global__ __launch_bounds__(256) void row_segments_kernel(long rows, RowSegs S)
+{
+    const int total = S.cum[S.nseg];
+    const long n = rows * total;
+    for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long)gridDim.x * 256) {
+        const long r = e / total;
+        const int col = (int)(e - r * total);
+        int s = 0;
+#pragma unroll
+        for (int t = 1; t < kMaxSeg; t++) s += (t < S.nseg && col >= S.cum[t]) ? 1 : 0;
+        const int c = col - S.cum[s];
+        float v = 0.0f;
+        if (S.a[s]) {
+            v = S.a[s][(size_t)r * S.a_pitch[s] + S.a_off[s] + c];
+            if (S.b[s]) v += S.b[s][(size_t)r * S.b_pitch[s] + S.b_off[s] + c];
+        }
+        S.dst[s][(size_t)r * S.dst_pitch[s] + S.dst_off[s] + c] = v;
+    }
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, void *stream)
+{
+    VN_REQUIRE(rows >= 0 && nseg > 0 && nseg <= kMaxSeg && seg, "row_segments expects rows >= 0 and 1..8 segments");
+    if (rows == 0) return VOTENET_OK;
+    RowSegs S = {};
+    S.nseg = nseg;
+    for (int i = 0; i < nseg; i++) {
+        const votenet_row_segment &g = seg[i];
+        VN_REQUIRE(g.dst && g.width > 0 && g.dst_off >= 0 && g.dst_off + g.width <= g.dst_pitch, "row_segments: segment %d does not fit its destination row", i);
+        VN_REQUIRE(!g.a || (g.a_off >= 0 && g.a_off + g.width <= g.a_pitch), "row_segments: segment %d reads past its source row", i);
+        VN_REQUIRE(!g.b || (g.a && g.b_off >= 0 && g.b_off + g.width <= g.b_pitch), "row_segments: segment %d: second source without a first / past its row", i);
+        S.dst[i] = g.dst;
+        S.a[i] = g.a;
+        S.b[i] = g.b;
+        S.dst_pitch[i] = g.dst_pitch;
+        S.dst_off[i] = g.dst_off;
+        S.width[i] = g.width;
+        S.a_pitch[i] = g.a_pitch;
+        S.a_off[i] = g.a_off;
+        S.b_pitch[i] = g.b_pitch;
+        S.b_off[i] = g.b_off;
+        S.cum[i + 1] = S.cum[i] + g.width;
+    }
+    const long n = rows * S.cum[nseg];
+    long grid = (n + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(row_segments_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), rows, S);
+    return check_launch("row_segments");
+}

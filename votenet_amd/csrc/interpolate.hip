@@ -152,8 +152,33 @@ __global__ void three_interpolate_kernel(long rows, int n, int m, int cv, const 
     }
 }
 
-__global__ void three_interpolate_grad_kernel(long rows, int n, int m, int c, const float *__restrict__ grad_out,
-                                              const int *__restrict__ idx, const float *__restrict__ weight,
+// [three_interpolate(points2) | skip]: the FP layer's concat (utils.py:283-286) written by the interpolation itself, rows of
+// cv + sv vectors; the skip features (the unknown points' own, sv vectors per row) are copied next to the interpolated ones
+template <typename V>
+__global__ void three_interpolate_concat_kernel(long rows, int n, int m, int cv, int sv, const V *__restrict__ points,
+                                                const int *__restrict__ idx, const float *__restrict__ weight,
+                                                const V *__restrict__ skip, V *__restrict__ out)
+{
+    const int pv = cv + sv;
+    const long total = rows * pv;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long row = e / pv;
+        const int l = (int)(e - row * pv);
+        if (l >= cv) {
+            out[e] = skip[(size_t)row * sv + (l - cv)];
+            continue;
+        }
+        const long s = row / n;
+        const int i1 = idx[row * 3], i2 = idx[row * 3 + 1], i3 = idx[row * 3 + 2];
+        const float w1 = weight[row * 3], w2 = weight[row * 3 + 1], w3 = weight[row * 3 + 2];
+        const V *__restrict__ p = points + (size_t)s * m * cv;
+        out[e] = lerp3<V>(p[(size_t)i1 * cv + l], p[(size_t)i2 * cv + l], p[(size_t)i3 * cv + l], w1, w2, w3);
+    }
+}
+
+// grad_out: rows of go_pitch floats, the c channels of interest at go_off (a slice of the concat's gradient, read in place)
+__global__ void three_interpolate_grad_kernel(long rows, int n, int m, int c, const float *__restrict__ grad_out, int go_pitch,
+                                              int go_off, const int *__restrict__ idx, const float *__restrict__ weight,
                                               float *__restrict__ grad_points)
 {
     const long total = rows * c;
@@ -161,7 +186,7 @@ __global__ void three_interpolate_grad_kernel(long rows, int n, int m, int c, co
         const long row = e / c;
         const int l = (int)(e - row * c);
         const long s = row / n;
-        const float g = grad_out[e];
+        const float g = grad_out[(size_t)row * go_pitch + go_off + l];
         float *__restrict__ gp = grad_points + (size_t)s * m * c;
         unsafeAtomicAdd(&gp[(size_t)idx[row * 3 + 0] * c + l], g * weight[row * 3 + 0]); // tf_interpolate.cpp:144-146
         unsafeAtomicAdd(&gp[(size_t)idx[row * 3 + 1] * c + l], g * weight[row * 3 + 1]);
@@ -232,6 +257,42 @@ extern "C" int votenet_three_interpolate_grad(int b, int n, int c, int m, const 
     if (rows == 0) return VOTENET_OK;
     VN_REQUIRE(grad_out && idx && weight && grad_points, "ThreeInterpolateGrad: null buffer");
     hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, n,
-                       m, c, grad_out, idx, weight, grad_points);
+                       m, c, grad_out, c, 0, idx, weight, grad_points);
     return check_launch("three_interpolate_grad");
+}
+
+// ThreeInterpolateGrad reading its upstream gradient in place from a wider row-major tensor (rows of go_pitch floats, this
+// op's c channels at go_off): the FP layer's input gradient is [d interpolated | d skip], utils.py:286
+extern "C" int votenet_three_interpolate_grad_strided(int b, int n, int c, int m, const float *grad_out, int go_pitch, int go_off,
+                                                      const int *idx, const float *weight, float *grad_points, void *stream)
+{
+    VN_REQUIRE(b >= 0 && m > 0 && c > 0, "ThreeInterpolateGrad expects (b,m,c) points shape");
+    VN_REQUIRE(n >= 0, "ThreeInterpolateGrad expects (b,n,3) idx shape");
+    VN_REQUIRE(go_off >= 0 && go_off + c <= go_pitch, "ThreeInterpolateGrad: the slice [go_off, go_off + c) exceeds the row pitch");
+    const long rows = (long)b * n;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(grad_out && idx && weight && grad_points, "ThreeInterpolateGrad: null buffer");
+    hipLaunchKernelGGL(three_interpolate_grad_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows, n,
+                       m, c, grad_out, go_pitch, go_off, idx, weight, grad_points);
+    return check_launch("three_interpolate_grad_strided");
+}
+
+// ThreeInterpolate + the concat with the unknown points' own features (utils.py:283-286): out (b,n,c + c1) = [interpolated | skip]
+extern "C" int votenet_three_interpolate_concat(int b, int m, int c, int n, const float *points, const int *idx,
+                                                const float *weight, const float *skip, int c1, float *out, void *stream)
+{
+    VN_REQUIRE(b >= 0 && m > 0 && c > 0 && c1 > 0, "ThreeInterpolate expects (b,m,c) points shape (and c1 > 0 skip channels)");
+    VN_REQUIRE(n >= 0, "ThreeInterpolate expects (b,n,3) idx shape");
+    const long rows = (long)b * n;
+    if (rows == 0) return VOTENET_OK;
+    VN_REQUIRE(points && idx && weight && skip && out, "ThreeInterpolate: null buffer");
+    hipStream_t st = as_stream(stream);
+    if (c % 4 == 0 && c1 % 4 == 0 && (((uintptr_t)points | (uintptr_t)out | (uintptr_t)skip) % 16 == 0)) {
+        hipLaunchKernelGGL((three_interpolate_concat_kernel<float4>), dim3(grid_for(rows * ((c + c1) / 4), 256)), dim3(256), 0, st, rows,
+                           n, m, c / 4, c1 / 4, (const float4 *)points, idx, weight, (const float4 *)skip, (float4 *)out);
+    } else {
+        hipLaunchKernelGGL((three_interpolate_concat_kernel<float>), dim3(grid_for(rows * (c + c1), 256)), dim3(256), 0, st, rows, n, m,
+                           c, c1, points, idx, weight, skip, out);
+    }
+    return check_launch("three_interpolate_concat");
 }

@@ -145,14 +145,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_pool_kernel(long groups, in
 }
 
 // plain column sums (bias gradient of a layer without BatchNorm)
-__global__ __launch_bounds__(256) void colsum_kernel(long rows, int c, const float *__restrict__ x, double *__restrict__ sums)
+__global__ __launch_bounds__(256) void colsum_kernel(long rows, int c, const float *__restrict__ x, int pitch, double *__restrict__ sums)
 {
     __shared__ float sh1[4][64];
     const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
     const int col = blockIdx.y * 64 + cx;
     float s1 = 0;
     if (col < c)
-        for (long r = (long)blockIdx.x * 4 + ry; r < rows; r += (long)gridDim.x * 4) s1 += x[(size_t)r * c + col];
+        for (long r = (long)blockIdx.x * 4 + ry; r < rows; r += (long)gridDim.x * 4) s1 += x[(size_t)r * pitch + col];
     sh1[ry][cx] = s1;
     __syncthreads();
     if (ry == 0 && col < c) unsafeAtomicAdd(&sums[col], (double)((sh1[0][cx] + sh1[1][cx]) + (sh1[2][cx] + sh1[3][cx])));
@@ -703,9 +703,22 @@ extern "C" int votenet_bias_grad(long rows, int c, const float *dz, double *scra
     hipStream_t st = as_stream(stream);
     (void)hipMemsetAsync(scratch, 0, sizeof(double) * c, st);
     const int ny = (c + 63) / 64;
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid_for(rows, 4, 1024 / ny + 1), ny), dim3(256), 0, st, rows, c, dz, scratch);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid_for(rows, 4, 1024 / ny + 1), ny), dim3(256), 0, st, rows, c, dz, c, scratch);
     hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3((c + 255) / 256), dim3(256), 0, st, c, scratch, dbias);
     return check_launch("bias_grad");
+}
+
+// The same for the first c columns of a wider row-major tensor (rows of `pitch` floats: the zero-padded gradient of a ragged
+// layer) and a scratch the CALLER has zeroed (a carve-out of the pass's one fill: no memset here).
+extern "C" int votenet_bias_grad_strided(long rows, int c, const float *dz, int pitch, double *zeroed_scratch, float *dbias, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && pitch >= c, "bias_grad expects rows > 0, 0 < c <= pitch");
+    VN_REQUIRE(dz && zeroed_scratch && dbias, "bias_grad: null buffer");
+    hipStream_t st = as_stream(stream);
+    const int ny = (c + 63) / 64;
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid_for(rows, 4, 1024 / ny + 1), ny), dim3(256), 0, st, rows, c, dz, pitch, zeroed_scratch);
+    hipLaunchKernelGGL(add_f64_to_f32_kernel, dim3((c + 255) / 256), dim3(256), 0, st, c, zeroed_scratch, dbias);
+    return check_launch("bias_grad_strided");
 }
 
 // Weight gradient of the few "narrow" input channels of a GATHER layer: the three dxyz columns (W rows 0..2)

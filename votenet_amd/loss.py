@@ -33,7 +33,8 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
     losses = torch.empty(12, dtype=torch.float32, device=dev)
     # the three cotangents and the kernel's workspace are ONE buffer cleared by ONE fill
     nv, npx, npo, nws = votes.numel(), pxyz.numel(), pout.numel(), int(L.lib().votenet_loss_workspace_floats(b))
-    flat = torch.zeros(nv + npx + npo + nws, dtype=torch.float32, device=dev)
+    from . import mlp as M
+    flat = M._zeros_f32((nv + npx + npo + nws,), dev)  # inside a train step: a carve-out of the pass's one zero fill
     d_votes, d_pxyz = flat[:nv].view_as(votes), flat[nv:nv + npx].view_as(pxyz)
     d_pout, ws = flat[nv + npx:nv + npx + npo].view_as(pout), flat[nv + npx + npo:]
     with L.device_guard(dev):

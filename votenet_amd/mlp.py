@@ -32,35 +32,86 @@ class _Timed:
 
 
 class _StatsArena:
-    """Zero-initialised fp64 accumulators (BatchNorm statistics, backward reductions) come out of one device buffer that
-    is cleared by ONE fill per pass instead of one torch.zeros launch per layer (about 45 tiny launches per train step).
-    The owner (VoteNetHotPath.forward / backward) calls arena_begin() on the stream the layers run on; without it every
-    request falls back to torch.zeros."""
-    buf = None
-    off = 0
+    """Zero-initialised scratch of one pass comes out of ONE device buffer cleared by ONE fill: the fp64 accumulators (BatchNorm
+    statistics, backward reductions; int64 counters share the region) and the fp32 buffers that kernels accumulate into with
+    atomics (per-point scatter targets of the grouping's backward, Gram matrices, padded weight-gradient scratch, the gradients of
+    three_interpolate / gather_point) -- about 60 tiny fills per train step otherwise.  The owner (VoteNetHotPath.train_step, or
+    forward / backward on their own) calls arena_begin() on the stream the layers run on; a nested begin (forward inside
+    train_step) joins the enclosing pass.  Without an arena every request falls back to torch.zeros.
+    Only for buffers that are produced AND consumed inside the pass, on the pass's stream or on streams that wait for it (the
+    weight-gradient stream): the geometry prefetched for the NEXT step allocates its own.
+    The fp32 region is sized by the previous pass's demand (the first pass of a shape falls back to torch.zeros)."""
+    buf = None        # float64 storage: [ndoubles fp64 | cap32 / 2 doubles viewed as fp32]
+    nd = 0            # doubles of the fp64 region
+    off = 0           # next free double
+    cap32 = 0         # floats of the fp32 region
+    off32 = 0         # next free float
+    want32 = 0        # floats requested in this pass (what the next pass's region must hold)
+    depth = 0
     active = False
 
 
-def arena_begin(device, ndoubles=1 << 16):
+def arena_begin(device, ndoubles=1 << 17):
     a = _StatsArena
-    if a.buf is None or a.buf.device != device or a.buf.numel() < ndoubles:
-        a.buf = torch.empty(ndoubles, dtype=torch.float64, device=device)
-    a.buf.zero_()
-    a.off = 0
+    if a.active and a.buf is not None and a.buf.device == device:
+        a.depth += 1  # a pass inside a pass (forward / backward inside train_step): one fill for both
+        return
+    need32 = (a.want32 + 1023) // 1024 * 1024
+    if a.buf is None or a.buf.device != device or a.nd < ndoubles or a.cap32 < need32:
+        a.nd, a.cap32 = ndoubles, max(need32, a.cap32)
+        a.buf = torch.empty(a.nd + a.cap32 // 2, dtype=torch.float64, device=device)
+    used32 = min(a.cap32, need32)
+    a.buf[:a.nd + used32 // 2].zero_()
+    a.zeroed32 = used32
+    a.off = a.off32 = a.want32 = 0
+    a.depth = 1
     a.active = True
 
 
 def arena_end():
-    _StatsArena.active = False
+    a = _StatsArena
+    a.depth -= 1
+    if a.depth <= 0:
+        a.active = False
+        a.depth = 0
 
 
 def _zeros_f64(n, device):
     a = _StatsArena
-    if a.active and a.buf.device == device and a.off + n <= a.buf.numel():
+    if a.active and a.buf.device == device and a.off + n <= a.nd:
         v = a.buf[a.off:a.off + n]
         a.off += (n + 1) & ~1  # keep 16-byte alignment
         return v
     return torch.zeros(n, dtype=torch.float64, device=device)
+
+
+def _zeros_i64(shape, device):
+    """Zero-initialised int64 counters from the fp64 region (same width)."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    a = _StatsArena
+    if a.active and a.buf.device == device and a.off + n <= a.nd:
+        v = a.buf[a.off:a.off + n].view(torch.int64).view(shape)
+        a.off += (n + 1) & ~1
+        return v
+    return torch.zeros(shape, dtype=torch.int64, device=device)
+
+
+def _zeros_f32(shape, device):
+    """Zero-initialised fp32 scratch of the pass (see _StatsArena); torch.zeros outside a pass or beyond the region."""
+    n = 1
+    for d in shape:
+        n *= int(d)
+    a = _StatsArena
+    if a.active and a.buf.device == device:
+        n4 = (n + 3) & ~3  # 16-byte aligned carve-outs
+        a.want32 += n4
+        if a.off32 + n4 <= a.zeroed32:
+            v = a.buf[a.nd:].view(torch.float32)[a.off32:a.off32 + n].view(shape)
+            a.off32 += n4
+            return v
+    return torch.zeros(shape, dtype=torch.float32, device=device)
 
 
 # Bit-reproducible training (set_deterministic): weight gradients through per-workgroup partial tiles + an ordered reduction,
@@ -347,14 +398,16 @@ def assembled_supported(rows, c0, c1):
     return rows > 0 and rows % 128 == 0 and rows < 2 ** 31 and c0 % 64 == 0 and c0 <= 512 and c1 % 64 == 0
 
 
-def assemble_rows(xyz, new_xyz, idx, want_sums=True, pts_cnt=None):
+def assemble_rows(xyz, new_xyz, idx, want_sums=True, pts_cnt=None, in_pass=False):
     """-> geo (rows, 4) f32 = (dx, dy, dz, bits(scene*n + idx)), cntv (b*n, 4) i64 and moments (9,) f64 or None, None."""
     b, m, k = idx.shape
     n = xyz.shape[1]
     geo = torch.empty((b * m * k, 4), dtype=torch.float32, device=xyz.device)
     # not from the per-step arenas: geometry is computed one or two steps ahead of its use
-    cntv = torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device) if want_sums else None  # count, sum dxyz in fixed point 2^-32
-    mom = torch.zeros(9, dtype=torch.float64, device=xyz.device) if want_sums else None
+    # count, sum dxyz in fixed point 2^-32.  in_pass: called inside the pass that consumes the result (the proposal layer, whose votes
+    # exist only then): the counters come out of the pass's arena; geometry computed ahead for a later step allocates its own
+    cntv = (_zeros_i64((b * n, 4), xyz.device) if in_pass else torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device)) if want_sums else None
+    mom = (_zeros_f64(10, xyz.device)[:9] if in_pass else torch.zeros(9, dtype=torch.float64, device=xyz.device)) if want_sums else None
     with L.device_guard(xyz.device):
         L.check(L.lib().votenet_assemble_rows(b, n, m, k, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt), L.ptr(geo), L.ptr(cntv), L.ptr(mom),
                                               L.stream_ptr()))
@@ -428,7 +481,7 @@ def group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, P, wx, da, coef,
     b, m, k = idx.shape
     n, cout = xyz.shape[1], P.shape[1]
     dz = torch.empty((b * m * k, cout), dtype=torch.float32, device=P.device) if want_dz else None
-    S = torch.zeros((b, n, cout), dtype=torch.float32, device=P.device)
+    S = _zeros_f32((b, n, cout), P.device)
     with L.device_guard(P.device):
         L.check(L.lib().votenet_group_linear_backward_assembled(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                                 L.ptr(P), L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S),
@@ -650,7 +703,7 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
 def gram(xz, scale_shift, relu):
     """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c)."""
     rows, c = xz.shape
-    g = torch.zeros((c + 1, c), dtype=torch.float32, device=xz.device)  # [gram ; column sums (filled by pool_wgrad)]
+    g = _zeros_f32((c + 1, c), xz.device)  # [gram ; column sums (filled by pool_wgrad)]
     scr = _wgrad_scratch(None, rows, c, c, xz.device)
     with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
         L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.ptr(scr), L.stream_ptr()))
@@ -705,7 +758,7 @@ def group_linear_backward(xyz, new_xyz, idx, pts_cnt, z, da, coef, relu, dw_xyz,
                                                               L.ptr(inv[2]) if len(inv) > 2 else None, L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
                                                               L.ptr(dz), L.ptr(scr), L.stream_ptr()))
         return S, dz
-    S = torch.zeros((b, n, cout), dtype=torch.float32, device=z.device)
+    S = _zeros_f32((b, n, cout), z.device)
     with L.device_guard(z.device):
         L.check(L.lib().votenet_group_linear_backward(b, n, m, k, cout, L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                       L.ptr(z), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
@@ -838,10 +891,13 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
 
 
 def bias_grad(dz, dbias):
+    """dbias += column sums of dz (rows, c); dz may be a column slice [:, :c] of a wider row-major tensor (read in place)."""
     rows, c = dz.shape
-    scratch = torch.empty(c, dtype=torch.float64, device=dz.device)
+    pitch = dz.stride(0) if rows > 1 else c
+    if dz.stride(1) != 1:
+        dz, pitch = dz.contiguous(), c
     with L.device_guard(dz.device):
-        L.check(L.lib().votenet_bias_grad(rows, c, L.ptr(dz), L.ptr(scratch), L.ptr(dbias), L.stream_ptr()))
+        L.check(L.lib().votenet_bias_grad_strided(rows, c, L.ptr(dz), pitch, L.ptr(_zeros_f64(c, dz.device)), L.ptr(dbias), L.stream_ptr()))
 
 
 def wgrad_dense(x, dz, dw, in_scale=None, in_shift=None, in_relu=True):
@@ -885,13 +941,47 @@ def group_concat_grad(d_rows_feat, d_rows_xyz, idx, pts_cnt, n, c):
             d_xyz = csr_gather_sum(d_rows_xyz, inv, b * n).view(b, n, 3)
             d_new = -d_rows_xyz.view(b, m, k, 3).sum(2)  # gradient of the centre subtraction (utils.py:55)
         return d_feat, d_xyz, d_new
-    d_feat = torch.zeros((b, n, c), dtype=torch.float32, device=dev) if d_rows_feat is not None else None
-    d_xyz = torch.zeros((b, n, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
-    d_new = torch.zeros((b, m, 3), dtype=torch.float32, device=dev) if d_rows_xyz is not None else None
+    d_feat = _zeros_f32((b, n, c), dev) if d_rows_feat is not None else None
+    d_xyz = _zeros_f32((b, n, 3), dev) if d_rows_xyz is not None else None
+    d_new = _zeros_f32((b, m, 3), dev) if d_rows_xyz is not None else None
     with L.device_guard(dev):
         L.check(L.lib().votenet_group_concat_grad(b, n, c, m, k, L.ptr(d_rows_feat), L.ptr(d_rows_xyz), L.ptr(idx), L.ptr(pts_cnt),
                                                   L.ptr(d_feat), L.ptr(d_xyz), L.ptr(d_new), L.stream_ptr()))
     return d_feat, d_xyz, d_new
+
+
+def _rows2d(t):
+    """(base tensor, pitch) of a 2-D row-major view with unit column stride (a column slice of a wider tensor is fine)."""
+    if t.dim() != 2 or (t.shape[1] > 1 and t.stride(1) != 1):
+        raise L.InvalidArgumentError("row_segments: operands are 2-D row-major views with unit column stride")
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0)))
+
+
+def row_segments(rows, segs):
+    """votenet_row_segments (csrc/glue.hip): concat / slice / zero-pad / add of row-major tensors in one launch.
+    segs: up to 8 tuples (dst, a, b): 2-D views of `rows` rows and equal width -- dst = a (+ b); a None writes zeros, b may be None.
+    Views may be column slices of wider tensors (their row pitch is used)."""
+    arr = (L.RowSegment * len(segs))()
+    dev = None
+    for i, (dst, a, b) in enumerate(segs):
+        d, dp = _rows2d(dst)
+        dev = d.device
+        w = d.shape[1]
+        arr[i].dst, arr[i].dst_pitch, arr[i].dst_off, arr[i].width = d.data_ptr(), dp, 0, w
+        for name, t in (("a", a), ("b", b)):
+            if t is None:
+                setattr(arr[i], name, None)
+                setattr(arr[i], name + "_pitch", w)
+                setattr(arr[i], name + "_off", 0)
+                continue
+            tt, tp = _rows2d(t)
+            if tt.shape[0] != rows or tt.shape[1] != w or d.shape[0] != rows:
+                raise L.InvalidArgumentError("row_segments: segment %d: shapes %s / %s do not match (%d rows)" % (i, tuple(d.shape), tuple(tt.shape), rows))
+            setattr(arr[i], name, tt.data_ptr())
+            setattr(arr[i], name + "_pitch", tp)
+            setattr(arr[i], name + "_off", 0)
+    with L.device_guard(dev):
+        L.check(L.lib().votenet_row_segments(rows, len(segs), arr, L.stream_ptr()))
 
 
 def clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5, beta1=0.9, beta2=0.999, eps=1e-8):

@@ -175,13 +175,24 @@ class VoteNetHotPath:
     def vote(self, seeds_xyz, seeds_points, tape=None):
         """model.py:53-61: votes = [seeds_xyz, seeds_points] + FC(...)."""
         b, n = seeds_xyz.shape[:2]
-        x = torch.cat([seeds_xyz, seeds_points], dim=2).view(b * n, 259)
+        rows = b * n
+        # [seeds_xyz | seeds_points | 0]: the concat of model.py:53 and the zero padding of the ragged 259-wide input in ONE launch
+        # (csrc/glue.hip) instead of cat + fill + copy; votes = x + offset and its split into xyz / features in another one
+        pad = (self.voting[0].cin_pad if (self.voting[0].cin_pad and P.PAD_RAGGED_IN) else 259)
+        xp = torch.empty((rows, pad), dtype=torch.float32, device=seeds_xyz.device)
+        segs = [(xp[:, :3], seeds_xyz.reshape(rows, 3), None), (xp[:, 3:259], seeds_points.reshape(rows, 256), None)]
+        if pad > 259:
+            segs.append((xp[:, 259:], None, None))
+        M.row_segments(rows, segs)
+        x = xp[:, :259]
         recs = []
-        off, _ = P.mlp_chain_forward(self.voting, b * n, ("dense", x), recs)
-        votes = (x + off).view(b, n, 259)
+        off, _ = P.mlp_chain_forward(self.voting, rows, ("dense", x, xp) if pad > 259 else ("dense", x), recs)
+        v_xyz = torch.empty((b, n, 3), dtype=torch.float32, device=x.device)
+        v_p = torch.empty((b, n, 256), dtype=torch.float32, device=x.device)
+        M.row_segments(rows, [(v_xyz.view(rows, 3), x[:, :3], off[:, :3]), (v_p.view(rows, 256), x[:, 3:], off[:, 3:])])
         if tape is not None:
             tape.append(dict(op="vote", recs=recs, b=b, n=n))
-        return votes[..., :3].contiguous(), votes[..., 3:].contiguous()
+        return v_xyz, v_p
 
     def propose(self, votes_xyz, votes_points, seeds_xyz, tape=None):
         """model.py:89-93: SA on votes with FPS on the seeds -> proposals_xyz (B,256,3), output (B,256,79)."""
@@ -323,16 +334,27 @@ class VoteNetHotPath:
         # proposal layer: gradients reach the vote features AND the vote xyz (grouped xyz, gathered centres)
         d_vp, d_vx = self.proposal.backward(prop, cot["proposals_output"], need_feat_grad=True, need_xyz_grad=True)
         P.wgrad_flush()  # the module's weight gradients go to their stream together, underneath the next module's chain
-        if cot.get("votes_xyz") is not None:
-            d_vx = d_vx + cot["votes_xyz"]
-        if cot.get("proposals_xyz") is not None:  # proposals_xyz = gather(votes_xyz, fps_idx), utils.py:42-47
-            d_vx = d_vx + P.tf_sampling.gather_point_grad_raw(d_vx.shape[1], prop["fps_idx"], cot["proposals_xyz"])
-        # voting: votes = x + FC(x), x = [seeds_xyz, seeds_points]
+        if cot.get("proposals_xyz") is not None:  # proposals_xyz = gather(votes_xyz, fps_idx), utils.py:42-47: accumulated in place
+            d_vx = P.tf_sampling.gather_point_grad_raw(d_vx.shape[1], prop["fps_idx"], cot["proposals_xyz"], into=d_vx.contiguous())
+        # voting: votes = x + FC(x), x = [seeds_xyz, seeds_points].  d_votes = [d_vx (+ the loss's pull on the votes) | d_vp | 0]: the
+        # concat, the sum and the zero padding of the ragged 259-wide layer in ONE launch (csrc/glue.hip)
         b, n = vote["b"], vote["n"]
-        d_votes = torch.cat([d_vx, d_vp], dim=2).view(b * n, 259)
-        d_x = d_votes + P.mlp_chain_backward(vote["recs"], d_votes, "plain", need_input_grad=True)
+        rows = b * n
+        last = self.voting[-1]
+        padw = last.cout_pad if last.cout_pad else 259
+        d_votes_p = torch.empty((rows, padw), dtype=torch.float32, device=d_vp.device)
+        cv = cot.get("votes_xyz")
+        segs = [(d_votes_p[:, :3], d_vx.reshape(rows, 3), cv.reshape(rows, 3) if cv is not None else None),
+                (d_votes_p[:, 3:259], d_vp.reshape(rows, 256), None)]
+        if padw > 259:
+            segs.append((d_votes_p[:, 259:], None, None))
+        M.row_segments(rows, segs)
+        d_votes = d_votes_p[:, :259]
+        d_in = P.mlp_chain_backward(vote["recs"], d_votes, "plain", need_input_grad=True, g_padded=d_votes_p if padw > 259 else None)
         P.wgrad_flush()
-        d_seeds_p = d_x[:, 3:].contiguous().view(b, n, 256)
+        # d x = d_votes + d_in; only its feature columns go on (the seeds' coordinates carry no gradient in the backbone)
+        d_seeds_p = torch.empty((b, n, 256), dtype=torch.float32, device=d_vp.device)
+        M.row_segments(rows, [(d_seeds_p.view(rows, 256), d_votes[:, 3:], d_in[:, 3:259])])
         # feature propagation
         d_l2p, d_l3p2 = self.fp2.backward(fp2, d_seeds_p)
         P.wgrad_flush()
@@ -341,10 +363,10 @@ class VoteNetHotPath:
         # set abstraction (xyz carries no gradient in the backbone: the cloud is the input)
         g3, _ = self.sa4.backward(sa4, d_l4p)
         P.wgrad_flush()
-        d_l3p = d_l3p + g3
+        d_l3p = P.add_rows(d_l3p, g3)
         g2, _ = self.sa3.backward(sa3, d_l3p)
         P.wgrad_flush()
-        d_l2p = d_l2p + g2
+        d_l2p = P.add_rows(d_l2p, g2)
         # every gradient of sa3 ... proposal (the tail of the flat bucket) is enqueued: its all-reduce runs on the
         # communication stream underneath the backward pass of sa2 and sa1 (dp.GradSync; a no-op on one GPU)
         if getattr(self, "_gsync", None) is not None:
@@ -383,18 +405,23 @@ class VoteNetHotPath:
         # every W^T of the backward pass's input-gradient GEMMs: one launch on the geometry stream, under the sa1 FPS
         self.store.refresh_transposes(self._side_stream())
         tape = []
-        out = self.forward(x, tape, next_x=next_x)
-        self.update_moving_averages(tape)
-        if gt is not None:
-            from . import loss as VL
-            self.last_losses, cot = VL.votenet_loss(out, gt)
-        if getattr(self, "_gsync", None) is None:
-            self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))
-        self._gsync.begin()
-        if PREFETCH_AFTER >= 5:  # the next batch's geometry chain under the BACKWARD pass
-            for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
-                self.prefetch_geometry(nx)
-        self.backward(tape, cot)                # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
+        # ONE zero fill for every accumulator and scatter target of the step (mlp._StatsArena): forward() and backward() join it
+        M.arena_begin(self.device)
+        try:
+            out = self.forward(x, tape, next_x=next_x)
+            self.update_moving_averages(tape)
+            if gt is not None:
+                from . import loss as VL
+                self.last_losses, cot = VL.votenet_loss(out, gt)
+            if getattr(self, "_gsync", None) is None:
+                self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))
+            self._gsync.begin()
+            if PREFETCH_AFTER >= 5:  # the next batch's geometry chain under the BACKWARD pass
+                for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
+                    self.prefetch_geometry(nx)
+            self.backward(tape, cot)            # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
+        finally:
+            M.arena_end()
         self.store.invalidate_transposes()      # the optimizer changes W
         gscale = self._gsync.finish()           # head all-reduce + wait for both; 1/world goes to the optimizer
         self._step += 1

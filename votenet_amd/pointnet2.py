@@ -337,7 +337,8 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
                 zn, st = M.linear_gather(xyz, new_xyz, feat, idx, w, b, want_stats=L.bn)
             rec = dict(layer=L, kind="gather", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx)
         elif i == 0 and L.cin_pad and PAD_RAGGED_IN and first[1].is_cuda:
-            xp = torch.nn.functional.pad(first[1], (0, L.cin_pad - L.cin))  # [x | 0] against [W ; 0]
+            # [x | 0] against [W ; 0]; first = ("dense", x, xp): the caller built the padded rows itself (x = xp[:, :cin])
+            xp = first[2] if len(first) > 2 else torch.nn.functional.pad(first[1], (0, L.cin_pad - L.cin))
             zn, st = M.linear_dense(xp, L.store.padded_rows(L.name + "/W", L.cin_pad), b, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=xp, in_scale=None, in_shift=None, in_relu=False, cin_padded=True)
         elif i == 0:
@@ -444,7 +445,7 @@ def wgrad_join():
         _wgrad_pending = False
 
 
-def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zsel=None):
+def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zsel=None, g_padded=None):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
          'act'   : g = dy (rows, c) of y = relu(bn(z))                         (FP layers)
@@ -522,7 +523,7 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             if r.get("cin_padded") and not pooled and M.dgrad_bn_supported(rows, c, L.cin_pad):
                 # the same layer on [x | 0] and [W ; 0]: dW through a padded scratch (its rows >= cin multiply zeros), da = dz [W ; 0]^T
                 def _padded_in_wgrad(r=r, z=z, coef=coef, L=L, da=da):
-                    G = torch.zeros((L.cin_pad, L.cout), dtype=torch.float32, device=z.device)
+                    G = M._zeros_f32((L.cin_pad, L.cout), z.device)
                     M.wgrad_dense_bn(r["x"], z, coef, L.relu, G, da=da)
                     L.gp("W").add_(G[:L.cin])
                 on_wgrad_stream(_padded_in_wgrad, r["x"], z, coef, da)
@@ -555,13 +556,18 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             dz = M.bn_backward_apply(z, coef, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
         else:
             dz = da
-            M.bias_grad(dz.contiguous(), L.gp("b"))
+            M.bias_grad(dz, L.gp("b"))
             if r.get("padded"):
                 # the same layer on the padded copies: dz -> [dz | 0] (rows, cout_pad); dW through a padded scratch, da = dz_p [W | 0]^T
-                dzp = torch.nn.functional.pad(dz, (0, L.cout_pad - L.cout))
+                # (g_padded: the caller already holds the last layer's gradient as [g | 0], g = g_padded[:, :cout])
+                if g_padded is not None and i == len(recs) - 1 and g_padded.shape[1] == L.cout_pad:
+                    dzp = g_padded
+                else:
+                    dzp = torch.empty((dz.shape[0], L.cout_pad), dtype=torch.float32, device=dz.device)
+                    M.row_segments(dz.shape[0], [(dzp[:, :L.cout], dz, None), (dzp[:, L.cout:], None, None)])
 
                 def _padded_wgrad(r=r, dzp=dzp, L=L):
-                    G = torch.zeros((L.cin, L.cout_pad), dtype=torch.float32, device=dzp.device)
+                    G = M._zeros_f32((L.cin, L.cout_pad), dzp.device)
                     M.wgrad_dense(r["x"], dzp, G, r["in_scale"], r["in_shift"], r["in_relu"])
                     L.gp("W").add_(G[:, :L.cout])
                 on_wgrad_stream(_padded_wgrad, dzp, r.get("x"))
@@ -579,6 +585,23 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
         else:
             da = None
     return da
+
+
+def add_rows(a, b):
+    """a + b for two (..., c) tensors of equal shape as ONE launch of the glue kernel; either may be a column slice of a wider
+    row-major tensor (FPModule.backward returns d_points1 that way).  -> a new contiguous tensor."""
+    c = a.shape[-1]
+    rows = a.numel() // c
+    out = torch.empty(a.shape, dtype=torch.float32, device=a.device)
+
+    def two_d(t):
+        if t.is_contiguous():
+            return t.view(rows, c)
+        if t.dim() == 3 and t.stride(2) == 1 and t.stride(0) == t.shape[1] * t.stride(1):
+            return t.as_strided((rows, c), (t.stride(1), 1), t.storage_offset())
+        return t.contiguous().view(rows, c)
+    M.row_segments(rows, [(out.view(rows, c), two_d(a), two_d(b))])
+    return out
 
 
 # --------------------------------------------------------------------------- SA / FP modules
@@ -639,7 +662,7 @@ class SAModule:
         if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
             geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
-            geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3])  # geo records + per-point sums: coordinates only
+            geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3], in_pass=not ahead)  # geo records + per-point sums: coordinates only
         return geom
 
     def forward(self, xyz, points, sample_xyz=None, tape=None, geom=None):
@@ -655,7 +678,7 @@ class SAModule:
             u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
             first = ("narrow", u8, mom)
         elif points is not None and self.assembled(b, xyz.shape[1]) and (len(geom) >= 7 or ASSEMBLE_INLINE):
-            geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt)
+            geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt, in_pass=True)
             first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
         z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
@@ -736,7 +759,7 @@ class SAModule:
         if need_xyz_grad:
             d_rows_xyz = M.rows_dot3(dz, W[:3])  # dz W[0:3]^T, three columns: a streaming kernel, not a 128-wide GEMM tile
             _, d_xyz, d_new = M.group_concat_grad(None, d_rows_xyz, idx, pts_cnt, n, 0)
-            d_xyz = d_xyz + tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new)  # new_xyz = gather(xyz, fps_idx)
+            d_xyz = tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new, into=d_xyz)  # new_xyz = gather(xyz, fps_idx): accumulated in place
         return d_feat, d_xyz
 
 
@@ -803,8 +826,10 @@ class FPModule:
     def forward(self, xyz1, xyz2, points1, points2, tape=None, geom=None):
         b, n1 = xyz1.shape[:2]
         idx, weight = geom if geom is not None else self.geometry(xyz1, xyz2)  # utils.py:278-282
-        interp = tf_interpolate.three_interpolate(points2, idx, weight)  # utils.py:283
-        x = torch.cat([interp, points1], dim=2) if points1 is not None else interp  # utils.py:286
+        if points1 is not None:  # utils.py:283-286: the interpolation writes the concat [interpolated | points1] itself
+            x = tf_interpolate.three_interpolate_concat(points2, idx, weight, points1)
+        else:
+            x = tf_interpolate.three_interpolate(points2, idx, weight)
         rows = b * n1
         recs = []
         z, pend = mlp_chain_forward(self.mlp, rows, ("dense", x.view(rows, -1)), recs)
@@ -818,7 +843,9 @@ class FPModule:
         """dy (B,n1,C) -> d_points1 (B,n1,c1) or None, d_points2 (B,m,c2)."""
         b, n1, c1, c2 = rec["b"], rec["n1"], rec["c1"], rec["c2"]
         d_x = mlp_chain_backward(rec["recs"], dy.reshape(b * n1, -1).contiguous(), "act", need_input_grad=True)
-        d_interp = d_x[:, :c2].contiguous().view(b, n1, c2)
-        d_p1 = d_x[:, c2:].contiguous().view(b, n1, c1) if c1 else None
-        d_p2 = tf_interpolate.three_interpolate_grad_raw(rec["m"], rec["idx"], rec["weight"], d_interp)
+        # [d interpolated | d points1] are column slices of d_x, read in place: ThreeInterpolateGrad takes a row pitch, and
+        # d_points1 is returned as a VIEW (its consumer adds it to another gradient: add_rows)
+        d_x3 = d_x.view(b, n1, c2 + c1)
+        d_p1 = d_x3[:, :, c2:] if c1 else None
+        d_p2 = tf_interpolate.three_interpolate_grad_raw(rec["m"], rec["idx"], rec["weight"], d_x3[:, :, :c2])
         return d_p1, d_p2

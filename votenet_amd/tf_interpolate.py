@@ -59,17 +59,45 @@ class _ThreeInterpolate(torch.autograd.Function):
 
 
 def three_interpolate_grad_raw(m, idx, weight, grad_out):
-    """ThreeInterpolateGrad (tf_interpolate.cpp:226-262): zero-filled (b,m,c) buffer + scatter-add."""
-    grad_out = L.dev_f32(grad_out, "ThreeInterpolateGrad expects (b,n,c) grad_out shape", 3)
+    """ThreeInterpolateGrad (tf_interpolate.cpp:226-262): zero-filled (b,m,c) buffer + scatter-add.
+    grad_out: (b,n,c), or a column slice of a wider row-major tensor (a view with unit channel stride: the gradient of the FP
+    layer's concat is [d interpolated | d skip], utils.py:286) -- read in place, no copy."""
+    if not (isinstance(grad_out, torch.Tensor) and grad_out.is_cuda and grad_out.dtype == torch.float32 and grad_out.dim() == 3):
+        grad_out = L.dev_f32(grad_out, "ThreeInterpolateGrad expects (b,n,c) grad_out shape", 3)
     b, n, c = grad_out.shape
+    strided = not grad_out.is_contiguous()
+    if strided and not (grad_out.stride(2) == 1 and grad_out.stride(0) == n * grad_out.stride(1) and grad_out.stride(1) >= c):
+        grad_out, strided = grad_out.contiguous(), False
     from . import mlp as M
     if M.DETERMINISTIC and c <= 256 and getattr(idx, "_inv", None) is not None:  # gather-sum over the taps' inverse index (csr.hip)
-        return M.csr_gather_sum(grad_out.view(b * n, c), idx._inv, b * m, weight=weight.contiguous(), div=3).view(b, m, c)
-    g = torch.zeros((b, m, c), dtype=torch.float32, device=grad_out.device)  # tf_interpolate.cpp:258
+        return M.csr_gather_sum(grad_out.contiguous().view(b * n, c), idx._inv, b * m, weight=weight.contiguous(), div=3).view(b, m, c)
+    g = M._zeros_f32((b, m, c), grad_out.device)  # tf_interpolate.cpp:258 (inside a pass: a carve-out of its one zero fill)
     with L.device_guard(grad_out.device):
-        L.check(L.lib().votenet_three_interpolate_grad(b, n, c, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g),
-                                                       L.stream_ptr()))
+        if strided:
+            L.check(L.lib().votenet_three_interpolate_grad_strided(b, n, c, m, L.ptr(grad_out), grad_out.stride(1), 0, L.ptr(idx),
+                                                                   L.ptr(weight), L.ptr(g), L.stream_ptr()))
+        else:
+            L.check(L.lib().votenet_three_interpolate_grad(b, n, c, m, L.ptr(grad_out), L.ptr(idx), L.ptr(weight), L.ptr(g),
+                                                           L.stream_ptr()))
     return g
+
+
+def three_interpolate_concat(points, idx, weight, skip):
+    """[three_interpolate(points, idx, weight) | skip] (b,n,c + c1) in ONE launch: the FP layer's concat of utils.py:283-286 written
+    by the interpolation kernel itself (no gradient wiring: the hot path's backward is explicit)."""
+    points = L.dev_f32(points, "ThreeInterpolate expects (b,m,c) points shape", 3)
+    skip = L.dev_f32(skip, "ThreeInterpolate expects (b,n,c1) skip shape", 3)
+    idx = L.dev_i32(idx, "ThreeInterpolate expects (b,n,3) idx shape", 3)
+    weight = L.dev_f32(weight, "ThreeInterpolate expects (b,n,3) weight shape", 3, 3)
+    b, m, c = points.shape
+    n, c1 = idx.shape[1], skip.shape[2]
+    if idx.shape[0] != b or weight.shape[:2] != idx.shape[:2] or skip.shape[:2] != idx.shape[:2]:
+        raise L.InvalidArgumentError("ThreeInterpolate expects (b,n,3) idx / weight and (b,n,c1) skip shapes")
+    out = torch.empty((b, n, c + c1), dtype=torch.float32, device=points.device)
+    with L.device_guard(points.device):
+        L.check(L.lib().votenet_three_interpolate_concat(b, m, c, n, L.ptr(points), L.ptr(idx), L.ptr(weight), L.ptr(skip), c1,
+                                                         L.ptr(out), L.stream_ptr()))
+    return out
 
 
 def three_interpolate(points, idx, weight):

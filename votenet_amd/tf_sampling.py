@@ -92,11 +92,18 @@ class _GatherPoint(torch.autograd.Function):
         return gather_point_grad_raw(ctx.n, idx, out_g), None
 
 
-def gather_point_grad_raw(n, idx, out_g):
-    """GatherPointGrad (tf_sampling.cpp:150-178): zero-filled (B,n,3) buffer + scatter-add."""
+def gather_point_grad_raw(n, idx, out_g, into=None):
+    """GatherPointGrad (tf_sampling.cpp:150-178): zero-filled (B,n,3) buffer + scatter-add.  into: an existing contiguous (B,n,3)
+    gradient to accumulate on instead (d_xyz + GatherPointGrad(...) without the zero fill and the add)."""
     out_g = L.dev_f32(out_g, "GatherPointGradGpuOp expects (batch_size,num_result,3) out_g shape", 3, 3)
     b, m = idx.shape
-    inp_g = torch.zeros((b, n, 3), dtype=torch.float32, device=out_g.device)  # tf_sampling.cpp:174
+    if into is not None:
+        if tuple(into.shape) != (b, n, 3) or not into.is_contiguous():
+            raise L.InvalidArgumentError("GatherPointGrad: `into` must be a contiguous (batch_size,n,3) tensor")
+        inp_g = into
+    else:
+        from . import mlp as M
+        inp_g = M._zeros_f32((b, n, 3), out_g.device)  # tf_sampling.cpp:174
     with L.device_guard(out_g.device):
         L.check(L.lib().votenet_gather_point_grad(b, n, m, L.ptr(out_g), L.ptr(idx), L.ptr(inp_g), L.stream_ptr()))
     return inp_g
