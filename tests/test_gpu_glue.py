@@ -125,5 +125,13 @@ def test_a_train_step_issues_no_tensor_library_kernels_on_its_chain(hiplib, dev)
     with Count() as c:
         net.train_step(x, gt=gt)
     torch.cuda.synchronize()
-    launches = sum(c.ops.values())
-    assert launches <= 8, c.ops
+    ops = dict(c.ops)
+    # what is left: the gradient-bucket fill and the pass's ONE arena fill (zero_), the two multi-tensor launches of the moving
+    # averages, the zero-initialised counters of the coordinate-only geometry kernels (they run on the geometry streams, and
+    # with a prefetched next batch outlive the step: not arena material), one defensive copy
+    allowed = {"aten.zero_.default": 2, "aten._foreach_mul_.Scalar": 1, "aten._foreach_addcmul_.Scalar": 1, "aten.zeros.default": 7,
+               "aten.clone.default": 1}
+    assert set(ops) <= set(allowed), sorted(ops.items())
+    assert all(ops[k] <= allowed[k] for k in ops), sorted(ops.items())
+    for gone in ("aten.cat.default", "aten.add.Tensor", "aten.add_.Tensor", "aten.constant_pad_nd.default", "aten.fill_.Scalar"):
+        assert gone not in ops

@@ -525,7 +525,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 def _padded_in_wgrad(r=r, z=z, coef=coef, L=L, da=da):
                     G = M._zeros_f32((L.cin_pad, L.cout), z.device)
                     M.wgrad_dense_bn(r["x"], z, coef, L.relu, G, da=da)
-                    L.gp("W").add_(G[:L.cin])
+                    gw = L.gp("W")
+                    M.row_segments(L.cin, [(gw, gw, G[:L.cin])])  # dW += the scratch's first cin rows (in place, one launch)
                 on_wgrad_stream(_padded_in_wgrad, r["x"], z, coef, da)
                 if not want_da:
                     return None
@@ -569,7 +570,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 def _padded_wgrad(r=r, dzp=dzp, L=L):
                     G = M._zeros_f32((L.cin, L.cout_pad), dzp.device)
                     M.wgrad_dense(r["x"], dzp, G, r["in_scale"], r["in_shift"], r["in_relu"])
-                    L.gp("W").add_(G[:, :L.cout])
+                    gw = L.gp("W")
+                    M.row_segments(L.cin, [(gw, gw, G[:, :L.cout])])  # dW += the scratch's first cout columns (in place, one launch)
                 on_wgrad_stream(_padded_wgrad, dzp, r.get("x"))
                 if want_da:
                     da, _ = M.linear_dense(dzp, L.store.padded(L.name + "/W", L.cout_pad, transpose=True), want_stats=False)
