@@ -381,6 +381,7 @@ def main():
         from votenet_amd import _lib as vlib
         vlib.lib().votenet_debug_fast_bf3(0)
         vlib.lib().votenet_debug_gram_bf3(0)
+        vlib.lib().votenet_debug_wgrad_bf3(0)
         try:
             for _ in range(4):
                 step()
@@ -393,6 +394,7 @@ def main():
         finally:
             vlib.lib().votenet_debug_fast_bf3(1)
             vlib.lib().votenet_debug_gram_bf3(1)
+            vlib.lib().votenet_debug_wgrad_bf3(1)
         for _ in range(2):
             step()
         torch.cuda.synchronize()

@@ -53,6 +53,8 @@ def gemm_form(request, hiplib):
     mlp.SplitImages) or on the fp32 MFMA kernels (votenet_debug_fast_bf3(0): registered images are ignored)."""
     hiplib.votenet_debug_fast_bf3(request.param)
     hiplib.votenet_debug_gram_bf3(request.param)
+    hiplib.votenet_debug_wgrad_bf3(request.param)
     yield request.param
     hiplib.votenet_debug_fast_bf3(1)
     hiplib.votenet_debug_gram_bf3(1)
+    hiplib.votenet_debug_wgrad_bf3(1)

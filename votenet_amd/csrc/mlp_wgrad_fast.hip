@@ -17,13 +17,35 @@
 //   * GATHER: the idx of a slab is loaded one refill BEFORE the feature rows that need it, and ahead of that refill's
 //     other loads in program order, so neither the dependency nor vmcnt's in-order retirement exposes it.
 // LDS images are the natural [row][channel] slabs; lane l reads As[k2*2 + (l>>5)][i0 + (l&31)]: conflict-free.
+//
+// BF3 = true (the default for every shape once votenet_debug_wgrad_bf3 is on): the products on bf16 x 3 split operands as in
+// mlp_fast.hip -- six v_mfma_f32_32x32x16_bf16 per 32 x 32 sub-tile and 16-row slab instead of eight v_mfma_f32_32x32x2_f32 at a
+// sixteenth of the rate.  The contraction runs over the ROWS here, so an MFMA fragment is 8 consecutive rows of ONE channel, while the
+// loaders hold 4 consecutive channels of one row: the slabs stay row-major in LDS -- three bf16 images [piece][row][channel], split
+// where they are staged (3 x ds_write_b64 per float4) -- and the fragments come out through the transposing LDS read
+// ds_read_b64_tr_b16: a 16-lane group reads a 4-row x 16-channel block (lane s: row s / 4, channels 4 (s % 4) ..) and lane t receives
+// channel t of the four rows (tools/probe/src/tr_b16_probe.hip: semantics, and the row pitch that keeps it conflict-free -- the read
+// banks like ds_read_b64 at the same addresses: a pitch of 64 bytes mod 256 puts the four rows of a half-wave on disjoint banks).
+// Both operands use the same row -> k assignment (lanes 0-31: rows 0-3 | 4-7, lanes 32-63: rows 8-11 | 12-15), which is all a
+// contraction needs.  Loaders, channel constants, the two-set prefetch and the epilogue are shared with the fp32 form.
 #include "mlp_types.h"
 
 namespace votenet {
 
 constexpr int WF_BR = 16; // rows per slab (the MFMA contraction index)
 
-template <int MODE, int TI, int TJ, int BSRC>
+typedef short tr_v4s __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) tr_v4s *tr_lds_ptr;
+// 8 consecutive rows of one channel (two transposing reads 4 rows apart) as one bf16 x 8 MFMA operand; lds_off: byte offset in LDS
+__device__ __forceinline__ uint4 tr_fragment(unsigned lds_off, unsigned four_rows)
+{
+    const tr_v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_ptr)(uintptr_t)lds_off);
+    const tr_v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr_lds_ptr)(uintptr_t)(lds_off + four_rows));
+    const uint2 a = __builtin_bit_cast(uint2, lo), b = __builtin_bit_cast(uint2, hi);
+    return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+template <int MODE, int TI, int TJ, int BSRC, bool BF3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_wgrad_fast_kernel(
     MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz, BnSrc bs, float *__restrict__ dw, long rows_per_block)
 {
@@ -31,8 +53,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     constexpr int QA = BI / 4, QB = BJ / 4;                       // float4 per slab row
     constexpr int NA = WF_BR * QA / 256, NB = WF_BR * QB / 256;   // float4 per thread per slab (1 or 2)
     constexpr int RA = 256 / QA, RB = 256 / QB;                   // slab rows covered by one pass of the 256 threads
-    __shared__ float As[2][WF_BR][BI + 4];
-    __shared__ float Bs[2][WF_BR][BJ + 4];
+    __shared__ float As[BF3 ? 1 : 2][BF3 ? 1 : WF_BR][BI + 4];
+    __shared__ float Bs[BF3 ? 1 : 2][BF3 ? 1 : WF_BR][BJ + 4];
+    // BF3: [buffer][piece hi, mid, lo][row][channel] bf16, row pitch = the channels' bytes + 64 (see the file header)
+    constexpr int PA = BI * 2 + 64, PB = BJ * 2 + 64;
+    __shared__ __attribute__((aligned(16))) unsigned char A3[BF3 ? 2 * 3 * WF_BR * PA : 16];
+    __shared__ __attribute__((aligned(16))) unsigned char B3[BF3 ? 2 * 3 * WF_BR * PB : 16];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wv >> 1, wj = wv & 1;
@@ -177,7 +203,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             v.y = fmaxf(v.y * csc.y + csh.y, x_floor);
             v.z = fmaxf(v.z * csc.z + csh.z, x_floor);
             v.w = fmaxf(v.w * csc.w + csh.w, x_floor);
-            *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = v;
+            if constexpr (BF3) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(v.x, v.y, h0, m0, l0);
+                split3(v.z, v.w, h1, m1, l1);
+                unsigned char *d = A3 + ((size_t)(buf * 3) * WF_BR + a_row + h * RA) * PA + a_q * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(d + WF_BR * PA) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(d + 2 * WF_BR * PA) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4 *>(&As[buf][a_row + h * RA][a_q * 4]) = v;
+            }
         }
 #pragma unroll
         for (int h = 0; h < NB; h++) {
@@ -211,7 +247,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 v.w = kA.w * g.w + kB.w + kC.w * v.w;
             }
             if (lr >= nrow) v = make_float4(0.f, 0.f, 0.f, 0.f); // padding rows contribute nothing
-            *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = v;
+            if constexpr (BF3) {
+                unsigned h0, m0, l0, h1, m1, l1;
+                split3(v.x, v.y, h0, m0, l0);
+                split3(v.z, v.w, h1, m1, l1);
+                unsigned char *d = B3 + ((size_t)(buf * 3) * WF_BR + b_row + h * RB) * PB + b_q * 8;
+                *reinterpret_cast<uint2 *>(d) = make_uint2(h0, h1);
+                *reinterpret_cast<uint2 *>(d + WF_BR * PB) = make_uint2(m0, m1);
+                *reinterpret_cast<uint2 *>(d + 2 * WF_BR * PB) = make_uint2(l0, l1);
+            } else {
+                *reinterpret_cast<float4 *>(&Bs[buf][b_row + h * RB][b_q * 4]) = v;
+            }
         }
     };
 
@@ -250,6 +296,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 #pragma unroll
         for (int par = 0; par < 2; par++) {
             Regs &rs = R[par ^ 1]; // holds slab s+par+1
+            if constexpr (BF3) {
+                // one slab = ONE k-step of v_mfma_f32_32x32x16_bf16 per piece pair.  Lane l of a 16-lane group g = l / 16 addresses
+                // row 8 (g / 2) + (l % 16) / 4 (and + 4), channels 16 (g % 2) + 4 (l % 4) .. of the 32-channel block: it receives
+                // channel l % 32, rows 8 (l / 32) .. + 7
+                const unsigned g = (unsigned)lane >> 4, sl = (unsigned)lane & 15u;
+                const unsigned la = ((g >> 1) * 8u + (sl >> 2)) * PA + ((g & 1u) * 16u + (sl & 3u) * 4u) * 2u + (unsigned)(wi * TI) * 64u;
+                const unsigned lb = ((g >> 1) * 8u + (sl >> 2)) * PB + ((g & 1u) * 16u + (sl & 3u) * 4u) * 2u + (unsigned)(wj * TJ) * 64u;
+                const unsigned a0 = (unsigned)(uintptr_t)A3 + (unsigned)buf * (3u * WF_BR * PA) + la;
+                const unsigned b0 = (unsigned)(uintptr_t)B3 + (unsigned)buf * (3u * WF_BR * PB) + lb;
+                uint4 fa3[3][TI], fb3[3][TJ];
+#pragma unroll
+                for (int pc = 0; pc < 3; pc++) {
+#pragma unroll
+                    for (int t = 0; t < TI; t++) fa3[pc][t] = tr_fragment(a0 + (unsigned)pc * (WF_BR * PA) + (unsigned)t * 64u, 4u * PA);
+#pragma unroll
+                    for (int t = 0; t < TJ; t++) fb3[pc][t] = tr_fragment(b0 + (unsigned)pc * (WF_BR * PB) + (unsigned)t * 64u, 4u * PB);
+                }
+                auto mm = [&](int pa, int pb) {
+#pragma unroll
+                    for (int a = 0; a < TI; a++)
+#pragma unroll
+                        for (int b = 0; b < TJ; b++)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa3[pa][a]),
+                                                                                __builtin_bit_cast(bf16x8, fb3[pb][b]), acc[a][b], 0, 0, 0);
+                };
+                mm(2, 0); // lo * hi
+                mm(0, 2); // hi * lo: the smallest terms first
+                mm(1, 1);
+                store_slab(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
+#pragma unroll
+                for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
+                load_idx(s + par + 4);
+                load_slab(rs, s + par + 3, pcur);
+                mm(1, 0);
+                mm(0, 1);
+                mm(0, 0);
+                lds_barrier();
+                buf ^= 1;
+                continue;
+            }
             float fa[2][TI], fb[2][TJ]; // register double-buffered fragments: reads of k2+1 issued before MFMAs of k2
 #pragma unroll
             for (int t = 0; t < TI; t++) fa[0][t] = As[buf][kh][(wi * TI + t) * 32 + l31];
@@ -300,6 +386,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
 }
 
 int g_wgrad_fast_wgs = 0; // votenet_debug_wgrad_workgroups (tuning hook): 0 = the measured defaults below
+int g_wgrad_bf3 = 1;      // votenet_debug_wgrad_bf3: 1 = products on bf16 x 3 split operands (transposing LDS reads), 0 = fp32 MFMA
 static void plan_fast(long rows, int cin, int cout, int &TIr, int &TJr, int &ti, int &tj, long &rpb, unsigned &gx, bool partials)
 {
     TIr = cin % 128 == 0 ? 2 : 1;
@@ -344,7 +431,16 @@ static bool launch(const MlpIn &d, long rows, int cin, int cout, const float *dz
     bs.part = scratch;
     bs.pstride = (long)(wrow0 + cin) * cout;
     const dim3 grid(gx, ti, tj);
-    if (TIr == 2 && TJr == 2)
+    if (g_wgrad_bf3 && BSRC != 3) { // (BSRC 3, the Gram matrix, has its own split-operand kernel: pool_bwd.hip)
+        if (TIr == 2 && TJr == 2)
+            hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 2, BSRC, true>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+        else if (TIr == 2)
+            hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 1, BSRC, true>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+        else if (TJr == 2)
+            hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 2, BSRC, true>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+        else
+            hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 1, 1, BSRC, true>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
+    } else if (TIr == 2 && TJr == 2)
         hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 2, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
     else if (TIr == 2)
         hipLaunchKernelGGL((mlp_wgrad_fast_kernel<MODE, 2, 1, BSRC>), grid, dim3(256), 0, st, d, rows, cin, cout, dz, bs, dw, rpb);
@@ -389,3 +485,4 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
 } // namespace votenet
 
 extern "C" void votenet_debug_wgrad_workgroups(int n) { votenet::g_wgrad_fast_wgs = n > 0 ? n : 0; } // tuning hook
+extern "C" void votenet_debug_wgrad_bf3(int on) { votenet::g_wgrad_bf3 = on ? 1 : 0; } // 0: the fp32 MFMA form of every weight gradient

@@ -294,12 +294,14 @@ def _desc_gather(xyz, new_xyz, feat, idx):
     return d
 
 
-# Matrices made on the fly (pool_dgrad's W diag(C) W^T) get an image too: votenet_pool_dgrad_prepare_split writes it in the launch
-# that forms the matrix, and the image is registered around the one GEMM that multiplies by it.  (Round 2 built the image with a
-# separate launch and measured a loss inside the three-stream step; the step is the SUM of its kernels' alone-times -- round 3,
-# tools/serial_step.py -- and this GEMM alone is 0.253 -> 0.124 ms at sa2 on split operands.)  SPLIT_ADHOC_ROWS: below that the
-# launch is latency-bound either way.
-SPLIT_ADHOC = True
+# Matrices made on the fly (pool_dgrad's W diag(C) W^T) can get an image too: votenet_pool_dgrad_prepare_split writes it in the
+# launch that forms the matrix (no extra launch), and the image is registered around the one GEMM that multiplies by it.  That GEMM
+# alone is 0.253 -> 0.124 ms at sa2 on split operands -- and the train step is SLOWER with it, measured twice on the same box
+# (tools/ab_step.py mlp.SPLIT_ADHOC False True, round 3: 6.07 / 6.12 / 6.13 -> 6.24 / 6.23 / 6.24 ms; round 2 with a separate image
+# launch: 6.25 -> 6.35): in the step this GEMM runs beside the Gram matrix and the arg-max gather of the weight-gradient stream, all
+# three streaming the same activation -- the phase is bound by HBM traffic, and the leaner fp32 kernel (37 KB LDS, 72 VGPRs against
+# 54 KB, 112) shares the CUs better (tools/trace_ab.sh adhoc: main queue +38 us, the other queue -95 us, the step +0.1 ms).  Off.
+SPLIT_ADHOC = False
 SPLIT_ADHOC_ROWS = 65536
 
 
