@@ -25,6 +25,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate, dense
+MFMA_BF3_EQUIV_TF = round(16 * 157.3 / 6, 1)  # dense bf16 MFMA peak (16 x the fp32 rate, 2.5 PFLOP/s) / six bf16 MFMAs per fp32 product = 419.5
 
 
 def parse():
@@ -399,7 +400,7 @@ def main():
             step()
         torch.cuda.synchronize()
         fp32_step = {"value": round(B * 10 / dt4, 2), "ms_per_step": round(dt4 / 10 * 1e3, 3), "steps": 10,
-                     "what": "same workload, votenet_debug_fast_bf3(0) + votenet_debug_gram_bf3(0): every GEMM product on "
+                     "what": "same workload, votenet_debug_fast_bf3(0) + votenet_debug_gram_bf3(0) + votenet_debug_wgrad_bf3(0): every GEMM product on "
                              "v_mfma_f32_32x32x2_f32 instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
 
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
@@ -519,7 +520,7 @@ def main():
                                                "launch intervals over both streams).  The fused forward / input-gradient GEMMs multiply each fp32 "
                                                "operand as three bf16 pieces (x = hi + mid + lo exactly): six v_mfma_f32_32x32x16_bf16 per "
                                                "k-step, fp32 accumulate, error vs float64 equal to the fp32 MFMA kernel's; so do the Gram matrices "
-                                               "of the pooled layers' backward; the other weight-gradient GEMMs run on v_mfma_f32_32x32x2_f32.  flops = fp32 multiply-adds of the GEMM (2 rows cin "
+                                               "of the pooled layers' backward and (round 3) every other weight-gradient GEMM (row-major bf16 images, fragments through ds_read_b64_tr_b16).  flops = fp32 multiply-adds of the GEMM (2 rows cin "
                                                "cout), priced against the fp32 MFMA peak" % len(gemm_events),
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                     "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gemm_ms_per_step_summed": round(sum_ms / gemm_steps, 3),
@@ -534,10 +535,36 @@ def main():
                 f[0] += ev[3]
                 f[1] += ev[0].elapsed_time(ev[1])
                 f[2] += 1
-            mfma["by_family"] = {k: {"launches_per_step": round(v[2] / gemm_steps, 1), "gflop_per_step": round(v[0] / gemm_steps / 1e9, 1),
-                                     "ms_per_step": round(v[1] / gemm_steps, 3), "tflops": round(v[0] / (v[1] * 1e-3) / 1e12, 1),
-                                     "frac": round(v[0] / (v[1] * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 3)}
-                                 for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:6]}
+            # rocprof's MFMA utilisation of each family's kernel (matrix-pipe busy share, kernel alone on the GPU) cannot be read inside
+            # this process: quoted from the committed counter summary, labelled with its source like `traffic` above
+            util, util_src = {}, None
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc_latest.json"))).get("mlp_families", {})
+                util, util_src = pj.get("families", {}), pj.get("source")
+            except Exception:
+                pass
+
+            def fam_entry(k, v):
+                tf = v[0] / (v[1] * 1e-3) / 1e12
+                e = {"launches_per_step": round(v[2] / gemm_steps, 1), "gflop_per_step": round(v[0] / gemm_steps / 1e9, 1),
+                     "ms_per_step": round(v[1] / gemm_steps, 3), "tflops": round(tf, 1), "frac": round(tf / MFMA_F32_PEAK_TF, 3),
+                     "frac_bf3_equiv": round(tf / MFMA_BF3_EQUIV_TF, 3)}
+                u = util.get(k)
+                if u:
+                    e["mfma_util_alone"] = u.get("mfma_util")
+                    e["tflops_alone"] = u.get("alone_tflops")
+                return e
+            mfma["by_family"] = {k: fam_entry(k, v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:8]}
+            mfma["by_family_note"] = ("tflops / frac: the family's executed flops / the SUM of its launch durations INSIDE the step (two GEMM streams and "
+                                      "the next batch's geometry run beside them); mfma_util_alone / tflops_alone: rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES "
+                                      "share and rate of the same kernel alone on the GPU at sa2's / sa1's shape, from %s (separate --pmc passes, "
+                                      "not measured in this run)" % util_src) if util_src else None
+            mfma["peak_bf3_equiv"] = MFMA_BF3_EQUIV_TF
+            mfma["frac_bf3_equiv"] = round(ach / MFMA_BF3_EQUIV_TF, 4)
+            mfma["pricing"] = ("frac prices the fp32 multiply-adds against the fp32 MFMA peak (157.3 TFLOP/s: what a kernel on v_mfma_f32_32x32x2_f32 "
+                               "could reach at most); the kernels issue six v_mfma_f32_32x32x16_bf16 per product on exactly split operands, whose "
+                               "ceiling is the dense bf16 peak / 6 = %.1f TFLOP/s of fp32 multiply-adds: frac_bf3_equiv is the utilisation of the "
+                               "pipe that is actually used" % MFMA_BF3_EQUIV_TF)
             if workload == "train" and B == 8 and n == 20480:
                 # SURVEY.md 8(d)'s ALGORITHMIC figure for the grouped MLP: flops = 2 rows sum(C_in C_out) of the reference's
                 # formulation (conv over the materialised grouped tensor): 186.0 GFLOP forward at B = 8, backward = 2 x forward.
@@ -577,8 +604,8 @@ def main():
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate; products of the fused forward and input-gradient GEMMs as bf16 x 3 "
                                "split operands (exact split, 6 of the 9 cross terms: what is dropped is < 2^-23 of a product), "
-                               "likewise the Gram matrices of the pooled layers' backward; the other weight gradients on fp32 MFMA; tests hold both "
-                               "forms to the same tolerances",
+                               "likewise the Gram matrices of the pooled layers' backward and the weight-gradient GEMMs; a few GEMMs on matrices made on the "
+                               "fly (W diag(C) W^T of the Gram-form input gradient) stay on fp32 MFMA; tests hold both forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
             "fp32_mfma_gemms": fp32_step, "configs": cfgs,
             "communicator": comm, "dp_collectives": dp_coll,

@@ -13,6 +13,9 @@ import sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [R, R + "/tools"]
 import torch
+from votenet_amd import _lib as L_
+if os.environ.get("VARIANT"):  # tools/probe/build_variant.sh NAME ...: the library with one source rebuilt under other flags
+    L_._LIB_PATH = os.path.join(R, "tools", "probe", "lib", "libvotenet_%s.so" % os.environ["VARIANT"])
 from votenet_amd import mlp as M, model as VM, synth
 
 mode = sys.argv[1] if len(sys.argv) > 1 else "alone"
@@ -51,6 +54,13 @@ jobs["sa2 wgrad_bn assembled"] = lambda: M.assembled_wgrad_bn(geo, P, wx, bn0[0]
 jobs["sa2 gram"] = lambda: M.gram(z1, aff, True)
 jobs["sa2 fwd-type dense (Gram-form dgrad)"] = lambda: M.linear_dense(z1, w1, None, bn0[0], bn0[1], True, want_stats=False)
 jobs["sa2 dgrad_bn plain (EPI 1)"] = lambda: M.dgrad_bn(z1, coef1, True, wT, da=da1)
+# the forward families at the same shapes, for the same counters side by side
+w2 = rnd(c, 2 * c) * 0.1
+img3 = M.SplitImages([w2])
+img3.refresh()
+bnp = M.FrozenBN(torch.stack([bn0[0], bn0[1]]).contiguous())
+jobs["sa2 fwd+pool (128 -> 256)"] = lambda: M.linear_dense_pool(z1, w2, 64, None, bn0[0], bn0[1], True, keep_z=False)
+jobs["sa2 fwd+bn assembled"] = lambda: M.assembled_linear(geo, P, wx, w1, None, bnp)
 # sa1: 1048576 x 64 -> 64
 rows1, c1 = u8.shape[0], 64
 w0, b0 = rnd(6, c1) * 0.5, rnd(c1) * 0.1
@@ -89,7 +99,8 @@ elif mode == "time":
     for name, fn in jobs.items():
         t = gpu_ms(fn, it=10)
         rr, cc = (rows1, c1) if name.startswith("sa1") else (rows, c)
-        print("%-40s %.4f ms  %6.1f TF/s" % (name, t, 2.0 * rr * cc * cc / t / 1e9))
+        co = 2 * cc if "256" in name else cc
+        print("%-40s %.4f ms  %6.1f TF/s" % (name, t, 2.0 * rr * cc * co / t / 1e9))
     side = torch.cuda.Stream()
     for main_k, side_k in [("sa2 dgrad_bn_reduce assembled", "sa2 wgrad_bn assembled"), ("sa2 fwd-type dense (Gram-form dgrad)", "sa2 gram"),
                            ("sa1 dgrad_bn_reduce narrow", "sa1 wgrad_bn narrow")]:

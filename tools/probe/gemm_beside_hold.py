@@ -37,3 +37,8 @@ beside("beside 8 spinning workgroups x 768 threads, 97 KB LDS", holder(8, 768, 9
 beside("beside 8 sleeping workgroups x 768 threads, 160000 B LDS", holder(8, 768, 160000, 0))
 beside("beside 8 sleeping workgroups x 64 threads, 1 KB LDS", holder(8, 64, 1024, 0))
 beside("beside 64 sleeping workgroups x 768 threads, 97 KB LDS", holder(64, 768, 98944, 0))
+# round 3: what if the FPS kernel's footprint were smaller (tie keys as 16-bit, 49 KB; or all in registers)?
+beside("beside 8 sleeping workgroups x 768 threads, 49 KB LDS", holder(8, 768, 50176, 0))
+beside("beside 8 spinning workgroups x 768 threads, 49 KB LDS", holder(8, 768, 50176, 1))
+beside("beside 8 sleeping workgroups x 768 threads, 1 KB LDS", holder(8, 768, 1024, 0))
+beside("beside 8 sleeping workgroups x 256 threads, 49 KB LDS", holder(8, 256, 50176, 0))

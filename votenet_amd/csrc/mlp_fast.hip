@@ -51,6 +51,9 @@ constexpr int FG_LDA = FG_BM + 2;
 #ifndef BF3_ABL
 #define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging
 #endif
+#ifndef EPI6_ROWS
+#define EPI6_ROWS 8 // EPI 6: rows of a 32 x 32 sub-tile column whose P gathers are in flight together (8 or 16)
+#endif
 #ifndef EPI3_CH
 #define EPI3_CH 2 // EPI 3: 32x32 sub-tiles of z_prev loaded at a time
 #endif
@@ -760,26 +763,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 x2[j] = A.wx[2 * cout + n0 + cl];
             }
             int urow = (wm * MT) * 32 + 4 * kh; // this lane's first row of the tile
+            constexpr int ER = EPI6_ROWS; // rows of a sub-tile column gathered together (8 or 16): ER x NT loads in flight
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
-                for (int h = 0; h < 2; h++) { // eight rows at a time: e = 8h .. 8h+7
-                    // phase 1: the rows' table offsets, then 8 x NT gathers in flight; phase 2 reads the dxyz again from LDS
-                    unsigned vo[8];
+                for (int h = 0; h < 16 / ER; h++) { // ER rows at a time: e = ER h .. ER h + ER - 1
+                    // phase 1: the rows' table offsets, then ER x NT gathers in flight; phase 2 reads the dxyz again from LDS
+                    unsigned vo[ER];
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int e = 8 * h + q;
+                    for (int q = 0; q < ER; q++) {
+                        const int e = ER * h + q;
                         vo[q] = __float_as_uint(Gs[tp][urow + i * 32 + (e & 3) + 8 * (e >> 2)].w) * pitch + (unsigned)l31 * 4u;
                     }
-                    float pv[NT][8];
+                    float pv[NT][ER];
 #pragma unroll
                     for (int j = 0; j < NT; j++)
 #pragma unroll
-                        for (int q = 0; q < 8; q++)
+                        for (int q = 0; q < ER; q++)
                             pv[j][q] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(pr, vo[q], (unsigned)((wn * NT + j) * 32) * 4u, 0));
 #pragma unroll
-                    for (int q = 0; q < 8; q++) {
-                        const int e = 8 * h + q;
+                    for (int q = 0; q < ER; q++) {
+                        const int e = ER * h + q;
                         const float4 g4 = Gs[tp][urow + i * 32 + (e & 3) + 8 * (e >> 2)];
 #pragma unroll
                         for (int j = 0; j < NT; j++) {
