@@ -160,8 +160,8 @@ def dry_run(args):
     if world > 1:
         dist.all_reduce(t)
     if rank == 0:
-        print(json.dumps({"metric": "dry run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                          "rank_sum": float(t.item())}), flush=True)
+        emit(json.dumps({"metric": "dry run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
+                         "rank_sum": float(t.item())}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -190,18 +190,37 @@ def check_dp(args, dev, world, rank):
         net.train_step(xs[i % 2], None, world, gt=gts[i % 2])
     res = dp.check_overlap_against_blocking(nets[0], nets[1], run, steps=max(2, min(args.steps, 4)))
     if rank == 0:
-        print(json.dumps({"metric": "data-parallel self-check (--check-dp; nothing measured)", "value": None,
-                          "n_gpus": info["world_size"], "communicator": info, "check_dp": res,
-                          "what": "deterministic mode; parameters after %d train steps with dp.GradSync's overlapped exchange vs one "
-                                  "blocking all-reduce between device synchronisations: torch.equal on every rank, every rank equal to "
-                                  "rank 0" % res["steps"]}), flush=True)
+        emit(json.dumps({"metric": "data-parallel self-check (--check-dp; nothing measured)", "value": None,
+                         "n_gpus": info["world_size"], "communicator": info, "check_dp": res,
+                         "what": "deterministic mode; parameters after %d train steps with dp.GradSync's overlapped exchange vs one "
+                                 "blocking all-reduce between device synchronisations: torch.equal on every rank, every rank equal to "
+                                 "rank 0" % res["steps"]}))
     return 0 if res["equal_everywhere"] else 4
+
+
+_REAL_STDOUT = None
+
+
+def quiet_stdout():
+    """From here on everything any library writes to file descriptor 1 (RCCL prints its version banner there when a communicator
+    is created) goes to stderr; emit() writes the ONE JSON line of the contract to the real stdout."""
+    global _REAL_STDOUT
+    if _REAL_STDOUT is None:
+        sys.stdout.flush()
+        _REAL_STDOUT = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush()
+    os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
 
 
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(launch_ranks(args))
+    quiet_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
@@ -611,7 +630,7 @@ def main():
             "communicator": comm, "dp_collectives": dp_coll,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
