@@ -242,3 +242,31 @@ def _dense_only(mlp, xz, mm, cin, aff):
         return mlp.linear_dense(xz, mm[:cin], mm[cin], aff[0], aff[1], True, want_stats=False)
     finally:
         L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, None)
+
+
+def test_a_module_driven_directly_after_an_optimizer_step_multiplies_by_the_current_weights(bf3, dev):
+    """The optimizer updates the flat bucket through a raw pointer.  forward() refreshes the bf16 x 3 images at its start; a module
+    called on its own afterwards (SAModule.forward, backbone) must not multiply by the images of the previous generation: the
+    parameter accessor rebuilds them on first use (ParamStore.generation)."""
+    from votenet_amd import loss as VL, mlp as M, model as VM, synth
+    net = VM.VoteNetHotPath(dev, seed=1, npoints=(512, 256, 128, 64))
+    x = torch.from_numpy(synth.room_batch(2, 4096, 9)).to(dev)
+    gt = VL.gt_to_device(synth.room_gt(2, 4096, 9), dev)
+    net.init_optimizer(lr=0.05)  # a large step: stale images would be far off
+    net.train_step(x, gt=gt)
+    gen = net.store.generation
+    assert net.store._split_gen != gen  # the images are those of the previous generation now
+    M.arena_begin(dev)
+    try:
+        _, direct, _ = net.sa1.forward(x, x)  # no refresh_split() by the caller
+    finally:
+        M.arena_end()
+    assert net.store._split_gen == gen
+    bf3.votenet_debug_fast_bf3(0)  # the same call on the fp32 kernels reads the weights themselves
+    M.arena_begin(dev)
+    try:
+        _, ref, _ = net.sa1.forward(x, x)
+    finally:
+        M.arena_end()
+    bf3.votenet_debug_fast_bf3(1)
+    assert float((direct - ref).abs().max() / ref.abs().max()) < 2e-5

@@ -620,3 +620,23 @@ def test_argument_errors(ops, dev):
         ops.g.query_ball_point(0.1, 0, x, x)  # tf_grouping.cpp:74
     with pytest.raises(InvalidArgumentError):
         ops.s.farthest_point_sample(4, torch.zeros(1, 16, 4, device=dev))  # tf_sampling.cpp:105
+
+
+def test_a_cloud_rewritten_through_its_raw_pointer_needs_forget_index(ops, dev, O):
+    """The remembered spatial index is trusted while the tensor's version counter is unchanged; a kernel that writes the cloud through
+    its raw pointer bumps none.  forget_index() is the documented way out (the library's own writers allocate fresh outputs)."""
+    from votenet_amd import mlp as M, tf_sampling as S
+    rng = np.random.default_rng(4)
+    a = rng.random((1, 6000, 3), dtype=np.float32) * 4
+    b = rng.random((1, 6000, 3), dtype=np.float32) * 4
+    x, other = T(a, dev), T(b, dev)
+    q = T(rng.random((1, 50, 3), dtype=np.float32) * 4, dev)
+    S.clear_index_cache()
+    S.farthest_point_sample(64, x)                    # leaves the index of cloud `a` behind
+    M.row_segments(6000, [(x.view(6000, 3), other.view(6000, 3), None)])  # x := b, through the raw pointer: no version bump
+    assert S.cached_index(x) is not None              # ... so the stale index would still be used
+    S.forget_index(x)
+    assert S.cached_index(x) is None
+    idx, cnt = ops.g.query_ball_point(0.3, 16, x, q)  # builds a fresh index of what x holds now
+    oi, oc = O.query_ball_point(0.3, 16, b, N(q))
+    assert (N(idx) == oi).all() and (N(cnt) == oc).all()

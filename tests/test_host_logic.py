@@ -82,3 +82,43 @@ def test_split_image_eligibility_and_cpu_store_is_inert():
     s.enable_split(True)
     s.refresh_split()  # parameters not on a GPU: returns before any library call
     assert s._split_flat is None
+
+
+def test_frozen_bn_table_is_thread_local_and_nests():
+    """pointnet2.frozen_bn: the inference-mode BatchNorm table is set per thread and restored on exit (a predict() inside another
+    model's pass, two models on two threads)."""
+    import threading
+    from votenet_amd import pointnet2 as P
+    assert P._FROZEN.table is None
+    seen = {}
+    with P.frozen_bn({"a": 1}) as t:
+        assert P._FROZEN.table is t
+        with P.frozen_bn(None):
+            assert P._FROZEN.table is None
+        assert P._FROZEN.table == {"a": 1}
+
+        def other():
+            seen["other"] = P._FROZEN.table
+            with P.frozen_bn({"b": 2}):
+                seen["inner"] = P._FROZEN.table
+        th = threading.Thread(target=other)
+        th.start()
+        th.join()
+        assert P._FROZEN.table == {"a": 1}
+    assert P._FROZEN.table is None and seen == {"other": None, "inner": {"b": 2}}
+
+
+def test_param_store_generations():
+    """Derived copies of the parameters belong to a generation of the bucket: params_changed() (the optimizer, a manual edit) opens a
+    new one; invalidate_transposes() is the same call."""
+    import torch
+    from votenet_amd import pointnet2 as P
+    st = P.ParamStore(torch.device("cpu"))
+    P.make_mlp(st, "m", 32, [64], "fc")
+    st.materialize(0)
+    g0 = st.generation
+    st.params_changed()
+    st.invalidate_transposes()
+    assert st.generation == g0 + 2 and st.t_event is None
+    st.ensure_split()  # no images enabled on the CPU: a no-op, no library call
+    assert st._split_gen != st.generation

@@ -276,7 +276,7 @@ class VoteNetHotPath:
         """name -> mlp.FrozenBN (scale = gamma rsqrt(moving_var + eps), shift = beta - moving_mean scale); rebuilt only when
         the parameters or the moving averages changed since the last call."""
         ema = self._ema_state()
-        key = (self._ema_version, getattr(self, "_step", 0), self.store.flat._version)
+        key = (self._ema_version, self.store.generation, self.store.flat._version)  # generation: bumped by the optimizer's raw-pointer update
         if getattr(self, "_frozen_key", None) != key:
             self._frozen = {}
             for L in self._bn_layers():
@@ -294,11 +294,13 @@ class VoteNetHotPath:
         next_x: the batch(es) of the next call(s), as in forward().  sync=False: nms_idx stays padded on the device with its
         length in nms_count (no host synchronisation: calls pipeline)."""
         from . import tf_nms3d
-        P.FROZEN_BN = None if batch_statistics else self.inference_bn()
-        try:
+        if not batch_statistics and self._ema_state() is not None and self._ema_version == 0 and not getattr(self, "_warned_ema", False):
+            import warnings
+            warnings.warn("VoteNetHotPath.predict: no training step has updated the BatchNorm moving averages yet (mean 0, variance 1): "
+                          "pass batch_statistics=True for a freshly initialised model", stacklevel=2)
+            self._warned_ema = True
+        with P.frozen_bn(None if batch_statistics else self.inference_bn()):
             out = self.forward(x, next_x=next_x)
-        finally:
-            P.FROZEN_BN = None
         boxes, score = self.decode_boxes(out["proposals_xyz"], out["proposals_output"])
         keep = tf_nms3d.NMS3D(boxes, score, out["proposals_output"][..., :2].contiguous(), iou_threshold, padded=not sync)
         extra = {} if sync else dict(nms_count=keep[1])
@@ -371,13 +373,21 @@ class VoteNetHotPath:
         # communication stream underneath the backward pass of sa2 and sa1 (dp.GradSync; a no-op on one GPU)
         if getattr(self, "_gsync", None) is not None:
             self._gsync.start_tail([P.WGRAD_STREAM])
-        g1, _ = self.sa2.backward(sa2, d_l2p)
-        P.wgrad_flush()
-        P.wgrad_fine(True)  # the last module: nothing follows to hide its weight gradients under, so they start layer by layer
+        # inline_wgrad_tail (experiment, default off): the weight gradients of the two largest modules on the MAIN stream -- by the time
+        # their backward runs the next batch's sampling kernel has finished, and pairs of GPU-filling kernels gain nothing from two streams
+        keep_stream = P.WGRAD_STREAM
+        if getattr(self, "inline_wgrad_tail", False):
+            P.WGRAD_STREAM = None
         try:
-            self.sa1.backward(sa1, g1, need_feat_grad=False)
+            g1, _ = self.sa2.backward(sa2, d_l2p)
+            P.wgrad_flush()
+            P.wgrad_fine(True)  # the last module: nothing follows to hide its weight gradients under, so they start layer by layer
+            try:
+                self.sa1.backward(sa1, g1, need_feat_grad=False)
+            finally:
+                P.wgrad_fine(False)
         finally:
-            P.wgrad_fine(False)
+            P.WGRAD_STREAM = keep_stream
 
     def init_optimizer(self, lr=1e-3):
         s = self.store

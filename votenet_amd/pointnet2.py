@@ -16,7 +16,7 @@ Parameters live in one flat fp32 bucket (ParamStore) so that data-parallel train
 single RCCL all-reduce over one contiguous gradient buffer per step.
 """
 import math
-
+import threading
 
 import torch
 
@@ -49,6 +49,11 @@ class ParamStore:
         self.t_event = None  # recorded after the transposes of the current step; None = stale
         self.split = False      # enable_split(): bf16 x 3 images of the weight matrices for the fused GEMMs (mlp.SplitImages)
         self._split_flat = self._split_t = None
+        # every derived copy of the parameters (bf16 x 3 images, transposes, padded copies, inference BatchNorm tables) belongs to a
+        # GENERATION of the bucket: params_changed() opens a new one (the optimizer does; so must anyone who writes the parameters in
+        # place), and a copy of an older generation is rebuilt before its next use instead of being multiplied by silently
+        self.generation = 0
+        self._split_gen = -1
 
     def want_transpose(self, name, lo=0, hi=None):
         """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
@@ -86,6 +91,13 @@ class ParamStore:
         if self._split_flat is None:
             self._split_flat = M.SplitImages([v for v in self.views.values() if v.dim() == 2])
         self._split_flat.refresh()
+        self._split_gen = self.generation
+
+    def ensure_split(self):
+        """Images of the current generation before a GEMM reads them: a no-op inside a pass (forward() refreshed them at its start),
+        one launch when a module is driven directly after the parameters changed (SAModule.forward after an optimizer step)."""
+        if self.split and self._split_gen != self.generation:
+            self.refresh_split()
 
     def refresh_transposes(self, stream=None):
         """One launch for every registered W^T block / padded copy, on `stream` (default: the current one); transposed() /
@@ -147,8 +159,13 @@ class ParamStore:
             self.t_event.record(st)
         self._t_waited = False
 
-    def invalidate_transposes(self):
+    def params_changed(self):
+        """The parameters were written (optimizer step, manual edit): every derived copy is stale from here on."""
+        self.generation += 1
         self.t_event = None
+
+    def invalidate_transposes(self):
+        self.params_changed()
 
     def _fresh(self, key):
         if self.t_event is None and self._tspecs and self.flat is not None and self.flat.is_cuda:
@@ -250,7 +267,10 @@ class Layer:
             store.want_padded_rows(name + "/W", self.cin_pad)
 
     def p(self, k):
-        return self.store[self.name + "/" + k]
+        st = self.store
+        if st.split and st._split_gen != st.generation:
+            st.refresh_split()  # a weight is about to be handed to a GEMM: its image must be of this generation
+        return st[self.name + "/" + k]
 
     def wT(self, lo=0, hi=None):
         return self.store.transposed(self.name + "/W", lo, hi)
@@ -279,8 +299,28 @@ POOL_IN_EPILOGUE = True
 # of the layer is neither stored nor read.  False = votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn on the stored z.
 POOL_GRAM_BACKWARD = True
 # Inference mode of every BatchNorm (model.py:98-139 runs with is_training=False): dict layer name -> mlp.FrozenBN built from the
-# moving averages (VoteNetHotPath.inference_bn); None = training mode (batch statistics).  Set by VoteNetHotPath.predict.
-FROZEN_BN = None
+# moving averages (VoteNetHotPath.inference_bn); None = training mode (batch statistics).
+class _FrozenBN(threading.local):
+    """Inference-mode BatchNorm table (layer name -> mlp.FrozenBN) of the forward pass running on THIS thread, or None (batch
+    statistics).  Set with frozen_bn(table) as a context manager (VoteNetHotPath.predict does): thread-local and nesting-safe, so two
+    models used from two threads, or a predict() inside another model's pass, do not see each other's tables."""
+    table = None
+
+
+_FROZEN = _FrozenBN()
+
+
+class frozen_bn:
+    def __init__(self, table):
+        self.table = table
+
+    def __enter__(self):
+        self.prev, _FROZEN.table = _FROZEN.table, self.table
+        return self.table
+
+    def __exit__(self, *a):
+        _FROZEN.table = self.prev
+        return False
 
 
 def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
@@ -305,7 +345,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             # of u8 and the next layer's GEMM rebuilds it in its operand loader
             _, u8, mom = first
             zn = None
-            st = M.narrow_stats(rows, mom, w, b) if (L.bn and FROZEN_BN is None) else None
+            st = M.narrow_stats(rows, mom, w, b) if (L.bn and _FROZEN.table is None) else None
             rec = dict(layer=L, kind="narrow", u8=u8, mom=mom)
         elif i == 0 and first[0] == "assembled":
             # first layer assembled inside its consumers (csrc/assemble.hip): the per-point GEMM P = feat W[3:] + b is all that runs here;
@@ -314,7 +354,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             bb, nn, cc = feat.shape
             P, _ = M.linear_dense(feat.reshape(bb * nn, cc), w[3:], b, want_stats=False)
             zn = None
-            st = M.assemble_stats(P, cntv, w[:3], mom) if (L.bn and FROZEN_BN is None) else None
+            st = M.assemble_stats(P, cntv, w[:3], mom) if (L.bn and _FROZEN.table is None) else None
             rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3])
         elif i == 1 and first[0] == "assembled":
             r0 = tape[-1]
@@ -360,8 +400,8 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
         else:
             zn, st = M.linear_dense(z, w, b, None, None, prev_relu, want_stats=L.bn, in_bn=pend)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu)
-        if L.bn and FROZEN_BN is not None:
-            pend = FROZEN_BN[L.name]  # moving averages: the batch sums of this launch are ignored
+        if L.bn and _FROZEN.table is not None:
+            pend = _FROZEN.table[L.name]  # moving averages: the batch sums of this launch are ignored
             rec.update(scale=pend.scale, shift=pend.shift)
         elif L.bn:
             pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows)

@@ -15,8 +15,12 @@ PROFILE_EVENTS = None
 
 
 # Spatial indices left behind by farthest_point_sample (its temp scratch, 4096 < n <= 262144) or built by spatial_index():
-# id(cloud tensor) -> (tensor, version, index scratch).  tf_grouping.query_ball_point looks its candidate cloud up here, so
-# the ball query that follows the sampling of the same cloud (every sample_and_group, utils.py:42-49) reuses the index.
+# id(cloud tensor) -> (tensor, version, data pointer, index scratch).  tf_grouping.query_ball_point looks its candidate cloud up
+# here, so the ball query that follows the sampling of the same cloud (every sample_and_group, utils.py:42-49) reuses the index.
+# An entry is trusted while the tensor object, its version counter and its storage are unchanged.  A kernel that rewrites a cloud
+# THROUGH ITS RAW POINTER (any votenet_* op writing into a buffer the caller reuses) bumps no version counter: such a caller must
+# forget_index(cloud) -- the library's own writers allocate fresh outputs, so the hot path never needs to.  The cache holds at most six
+# clouds (strong references: an id cannot be recycled while its entry lives); clear_index_cache() drops them.
 _INDEX_CACHE = {}
 INDEX_MIN_N, INDEX_MAX_N = 4097, 131072
 
@@ -24,14 +28,25 @@ INDEX_MIN_N, INDEX_MAX_N = 4097, 131072
 def _remember_index(x, scratch):
     while len(_INDEX_CACHE) >= 6:
         _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
-    _INDEX_CACHE[id(x)] = (x, x._version, scratch)
+    _INDEX_CACHE[id(x)] = (x, x._version, x.data_ptr(), scratch)
 
 
 def cached_index(x):
     e = _INDEX_CACHE.get(id(x))
-    if e is not None and e[0] is x and e[1] == x._version:
-        return e[2]
+    if e is not None and e[0] is x and e[1] == x._version and e[2] == x.data_ptr():
+        if x.is_cuda:
+            e[3].record_stream(torch.cuda.current_stream(x.device))  # built on one stream, maybe consumed on another: keep its memory
+        return e[3]
     return None
+
+
+def forget_index(x):
+    """Drop the remembered spatial index of `x` (after rewriting the cloud in place through a raw pointer)."""
+    _INDEX_CACHE.pop(id(x), None)
+
+
+def clear_index_cache():
+    _INDEX_CACHE.clear()
 
 
 def spatial_index(xyz):
