@@ -439,7 +439,7 @@ def main():
     # collectives run through RCCL and the three-stream ordering on this GPU (labelled: it measures the path, not xGMI)
     comm = dp.comm_info(dev)
     dp_coll = None
-    if workload == "train" and not args.headline_only:
+    if workload == "train" and not args.headline_only and not os.environ.get("VOTENET_BENCH_NO_DP_LEG"):
         try:
             one_rank = False
             if world == 1:
@@ -449,7 +449,8 @@ def main():
                 s_.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
                 s_.close()
-                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+                import datetime
+                dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, timeout=datetime.timedelta(seconds=60))
                 one_rank = True
             keep = net._gsync
             net._gsync = dp.GradSync(net.store, net.store.offset_of("sa3/"), overlap=True, force=True, profile=True)

@@ -127,6 +127,7 @@ struct PoolBelow {
     int relu;
     double *sums;
     CoefTail tail; // that layer's coefficient vector from the completed sums, by the last workgroup (common.h)
+    int reverse;   // walk the groups back to front (votenet_debug_scatter_reverse)
 };
 
 template <int CIN, int COUT, int K, bool RED, int NWV = 8 /* wavefronts: 16 when W^T leaves room for one workgroup per CU only */>
@@ -176,10 +177,14 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
             n_a = argmax[(size_t)g * COUT + tid];
         }
     };
-    if ((long)blockIdx.x < groups) fetch(blockIdx.x);
+    // pb.reverse: walk the groups from the last to the first.  The kernel before this one streamed da (and z) front to back, so the
+    // Infinity Cache holds their TAILS when this pass starts: a pass that starts at the tail finds them there
+    auto grp = [&](long i) { return pb.reverse ? groups - 1 - i : i; };
+    if ((long)blockIdx.x < groups) fetch(grp(blockIdx.x));
     __syncthreads();
     int par = 0;
-    for (long g = blockIdx.x; g < groups; g += gridDim.x, par ^= 1) {
+    for (long gi = blockIdx.x; gi < groups; gi += gridDim.x, par ^= 1) {
+        const long g = grp(gi);
         float *svp = sv + par * COUT;
         int *lstp = lst + par * COUT, *cntp = cnt + par * K, *startp = start + par * K;
         const float zz = n_z;
@@ -195,8 +200,8 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
                 pre[ri][q] = da[off];
                 if (RED) zpre[ri][q] = pb.z[off];
             }
-        const long gn = g + gridDim.x;
-        if (gn < groups) fetch(gn);
+        const long gn = gi + gridDim.x;
+        if (gn < groups) fetch(grp(gn));
         int mypos = 0;
         if (own) {
             if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
@@ -453,6 +458,8 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
     return pool_dgrad_prepare_launch(cin, cout, w, bias, coef, mmat, cvec, image, stream);
 }
 
+static int g_scatter_reverse = 0;
+extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
 extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
                                           const float *zsel, const float *coef, int relu, const float *wT, float *da,
                                           const float *below_z, const float *below_scale, const float *below_shift,
@@ -467,7 +474,7 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
     VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
                "pool_dgrad_scatter: below_z given without the layer's BatchNorm vectors / sums");
     hipStream_t st = as_stream(stream);
-    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail)};
+    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse};
     auto go = [&](auto kern, int ci, int co, int threads = 512) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
