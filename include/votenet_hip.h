@@ -647,6 +647,9 @@ typedef struct votenet_row_segment {
     int b_pitch, b_off;
 } votenet_row_segment;
 int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, void *stream);
+/* Moving averages of every BatchNorm layer in one launch (Tensorpack BatchNorm, momentum 0.9): ema[i] = momentum * ema[i] +
+ * factor[i] * batch[i] over flat buffers holding all layers' (scale | shift | mean | var) blocks. */
+int votenet_ema_update(long n, float momentum, float *ema, const float *batch, const float *factor, void *stream);
 
 #ifdef __cplusplus
 }

@@ -404,7 +404,8 @@ def test_training_gradients_are_bit_reproducible(hiplib, dev, full):
 def test_coefficient_tails_equal_the_separate_launch(hiplib, dev):
     """struct votenet_coef_tail: the last workgroup of a reducing kernel computes the BatchNorm-backward coefficient vector and
     accumulates dgamma / dbeta.  Every producer, with the tail against votenet_bn_backward_coef launched after it
-    (mlp.COEF_TAIL = False, the default); repeated, so that a ticket left non-zero by one launch would show in the next."""
+    (mlp.COEF_TAIL = False; the tails are the default since round 3); repeated, so that a ticket left non-zero by one launch would show
+    in the next."""
     from votenet_amd import mlp as M
     g = torch.Generator().manual_seed(5)
     rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
@@ -414,12 +415,13 @@ def test_coefficient_tails_equal_the_separate_launch(hiplib, dev):
         """fn(tail) -> coef (or a tuple whose LAST tensor of 5*c floats is coef): run with and without the in-kernel tail"""
         out = []
         for flag in (True, False, True):
-            M.COEF_TAIL = flag
             dg, db = torch.full((c,), 0.25, device=dev), torch.full((c,), -0.5, device=dev)
+            prev = M.COEF_TAIL
             try:
+                M.COEF_TAIL = flag
                 coef = fn((4096, gamma[:c].contiguous(), dg, db))
             finally:
-                M.COEF_TAIL = False
+                M.COEF_TAIL = prev
             torch.cuda.synchronize()
             out.append((coef, dg, db))
         for coef, dg, db in (out[0], out[2]):

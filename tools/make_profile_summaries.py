@@ -46,10 +46,13 @@ lines += ["# sa1 FPS launch = spatial index (5 kernels) + sampling kernel: %.1f 
           "# sa1 ball query over the index: %.1f us, HBM read %d B, written %d B; algorithmic (all pairs) %d -> %.4f"
           % (grp["bq"][0], grp["bq"][1], grp["bq"][2], alg_b, (grp["bq"][1] + grp["bq"][2]) / alg_b)]
 open(os.path.join(P, "%s_pmc_fps.txt" % tag), "w").write("\n".join(lines) + "\n")
-json.dump({"fps_sa1": {"hbm_bytes_per_launch": int(fb[1] + fb[2]), "fetch_bytes_corrected": int(fb[1]), "write_bytes": int(fb[2]),
-                       "source": "profiles/%s_pmc_fps.txt" % tag},
-           "ball_query_sa1": {"hbm_bytes_per_launch": int(grp["bq"][1] + grp["bq"][2]), "source": "profiles/%s_pmc_fps.txt" % tag},
-           "source": "profiles/%s_pmc_fps.txt" % tag}, open(os.path.join(P, "pmc_latest.json"), "w"), indent=1)
+_pj_path = os.path.join(P, "pmc_latest.json")
+_pj = json.load(open(_pj_path)) if os.path.exists(_pj_path) else {}  # other blocks (mlp_families: tools/pmc_mlp_bwd_summary.py) stay
+_pj.update({"fps_sa1": {"hbm_bytes_per_launch": int(fb[1] + fb[2]), "fetch_bytes_corrected": int(fb[1]), "write_bytes": int(fb[2]),
+                        "source": "profiles/%s_pmc_fps.txt" % tag},
+            "ball_query_sa1": {"hbm_bytes_per_launch": int(grp["bq"][1] + grp["bq"][2]), "source": "profiles/%s_pmc_fps.txt" % tag},
+            "source": "profiles/%s_pmc_fps.txt" % tag})
+json.dump(_pj, open(_pj_path, "w"), indent=1)
 # ---- MLP
 sq, mf, mw = table("mlp_sq.txt"), table("mlp_fetch.txt"), table("mlp_write.txt")
 hdr = open(os.path.join(src, "mlp_sq.txt")).read().splitlines()[1].split()

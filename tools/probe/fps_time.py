@@ -2,6 +2,9 @@
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
+from votenet_amd import _lib as L_
+if os.environ.get("VARIANT"):
+    L_._LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libvotenet_%s.so" % os.environ["VARIANT"])
 from votenet_amd import synth, tf_sampling
 dev = torch.device("cuda:0")
 def timeit(fn, it=10, warm=2):

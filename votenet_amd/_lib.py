@@ -162,6 +162,7 @@ class RowSegment(ctypes.Structure):
 _SIGS["votenet_three_interpolate_concat"] = [ctypes.c_int] * 4 + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p]
 _SIGS["votenet_three_interpolate_grad_strided"] = [ctypes.c_int] * 4 + [_c_f, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p]
 _SIGS["votenet_bias_grad_strided"] = [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p]
+_SIGS["votenet_ema_update"] = [ctypes.c_long, ctypes.c_float, _c_f, _c_f, _c_f, ctypes.c_void_p]
 _SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(RowSegment), ctypes.c_void_p]
 
 

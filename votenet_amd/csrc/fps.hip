@@ -51,11 +51,40 @@ __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); 
 // (index 0 wins every all-zero tie) -- and point 0's own non-finite components are read as 0.  Integer tests: this file is built
 // with -fno-honor-nans.  The spatial index marks such points in `perm` (sign bit): the ball query over the index never reports them,
 // like the full scan, where a NaN / Inf distance fails the radius test (oracle/oracle_sampling.c defines the same).
+// The round loop of the bucket-pruned kernels is a dependent chain on one CU: its time moves by ~2 % with the 4-byte phase of the
+// loop's code (measured: an edit of the PROLOGUE alone took sa1 from 1.659 to 1.692 ms on one box).  FPS_PAD_A / FPS_PAD_B shift the
+// loops of fps_bucket_kernel / fps_bucket_l2_kernel by that many s_nop (4 bytes each); the values are the measured best.
+#ifndef FPS_PAD_A
+#define FPS_PAD_A 0
+#endif
+#ifndef FPS_PAD_B
+#define FPS_PAD_B 0
+#endif
+#define FPS_NOPS_0
+#define FPS_NOPS_1 asm volatile("s_nop 0");
+#define FPS_NOPS_2 FPS_NOPS_1 FPS_NOPS_1
+#define FPS_NOPS_3 FPS_NOPS_2 FPS_NOPS_1
+#define FPS_NOPS_4 FPS_NOPS_2 FPS_NOPS_2
+#define FPS_NOPS_5 FPS_NOPS_4 FPS_NOPS_1
+#define FPS_NOPS_6 FPS_NOPS_4 FPS_NOPS_2
+#define FPS_NOPS_7 FPS_NOPS_4 FPS_NOPS_3
+#define FPS_CAT_(a, b) a##b
+#define FPS_CAT(a, b) FPS_CAT_(a, b)
+#define FPS_LOOP_PAD_A FPS_CAT(FPS_NOPS_, FPS_PAD_A)
+#define FPS_LOOP_PAD_B FPS_CAT(FPS_NOPS_, FPS_PAD_B)
 __device__ __forceinline__ bool fps_nonfinite(float v)
 {
     unsigned u = __float_as_uint(v);
     asm volatile("" : "+v"(u)); // opaque: under no-nans-fp-math the optimiser recognises the exponent test as a class test and drops its NaN half
     return (u & 0x7f800000u) == 0x7f800000u;
+}
+// point 0 (the first centre): three loads and three selects, no branch
+__device__ __forceinline__ void fps_get0(const float *__restrict__ pts, float &x, float &y, float &z)
+{
+    const float a = pts[0], b = pts[1], c = pts[2];
+    x = fps_nonfinite(a) ? 0.0f : a;
+    y = fps_nonfinite(b) ? 0.0f : b;
+    z = fps_nonfinite(c) ? 0.0f : c;
 }
 __device__ __forceinline__ bool fps_get(const float *__restrict__ pts, size_t k, float &x, float &y, float &z)
 {
@@ -386,7 +415,7 @@ __global__ __launch_bounds__(NW * 64) void fps_reg_kernel(int n, int m, const fl
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx, cy, cz;
-    fps_get(pts, 0, cx, cy, cz);
+    fps_get0(pts, cx, cy, cz);
     for (int j = 1; j < m; j++) {
         unsigned best = 0u;
         int bi = 0;
@@ -674,7 +703,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx, cy, cz;
-    fps_get(pts, 0, cx, cy, cz);
+    fps_get0(pts, cx, cy, cz);
+    FPS_LOOP_PAD_A
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
     int cw_slot = -1;                           // ... and the slot (bucket) it lives in
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
@@ -831,7 +861,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket2_kernel(int n, int m, cons
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid);
     float cx, cy, cz; // first centre of the round
-    fps_get(pts, 0, cx, cy, cz);
+    fps_get0(pts, cx, cy, cz);
     float ex2 = cx, ey2 = cy, ez2 = cz;          // second centre (valid when two)
     bool two = false;
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's best point (uniform) ...
@@ -999,10 +1029,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
     for (int p = tid; p < nb * 64; p += NW * 64) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (p < n) {
-            const int k = pm[p] & 0x7fffffff;
-            float px, py, pz;
-            fps_get(pts, (size_t)k, px, py, pz);
-            v = make_float4(px, py, pz, 1e38f); // tf_sampling_g.cu:118
+            v = sp[p];    // the index's sorted copy already holds the point (holes read as point 0: sidx_scatter_kernel) ...
+            v.w = 1e38f;  // ... its w, the original index (readers take indices from perm), becomes the running distance, tf_sampling_g.cu:118
         }
         sp[p] = v;
     }
@@ -1032,7 +1060,8 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
     FpsOut fo = {o, m, 0};
     fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
     float cx, cy, cz;
-    fps_get(pts, 0, cx, cy, cz);
+    fps_get0(pts, cx, cy, cz);
+    FPS_LOOP_PAD_B
     unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu; // this wave's cached winner (uniform)
     int cw_slot = -1;                           // ... and its bucket (slot * 64 + lane)
     float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
@@ -1153,7 +1182,7 @@ __global__ __launch_bounds__(NW * 64) void fps_stream_kernel(int b, int n, int m
         FpsOut fo = {o, m, 0};
         fo.put(0, 0, tid);
         float cx, cy, cz;
-        fps_get(pts, 0, cx, cy, cz);
+        fps_get0(pts, cx, cy, cz);
         for (int j = 1; j < m; j++) {
             unsigned best = 0u, bk = (unsigned)tid;
             float bx = 0.f, by = 0.f, bz = 0.f;

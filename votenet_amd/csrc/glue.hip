@@ -77,3 +77,24 @@ extern "C" int votenet_row_segments(long rows, int nseg, const votenet_row_segme
     hipLaunchKernelGGL(row_segments_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), rows, S);
     return check_launch("row_segments");
 }
+
+// BatchNorm moving averages of every layer in one launch: ema = momentum * ema + factor .* batch over the flat buffers that hold all
+// layers' (scale | shift | mean | var) blocks (factor = 1 - momentum, times rows / (rows - 1) on the variance rows: the unbiased batch
+// variance tf.nn.fused_batch_norm hands to the update).
+namespace votenet {
+__global__ __launch_bounds__(256) void ema_update_kernel(long n, float momentum, float *__restrict__ ema, const float *__restrict__ batch,
+                                                         const float *__restrict__ factor)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) ema[i] = momentum * ema[i] + factor[i] * batch[i];
+}
+} // namespace votenet
+
+extern "C" int votenet_ema_update(long n, float momentum, float *ema, const float *batch, const float *factor, void *stream)
+{
+    VN_REQUIRE(n >= 0 && (n == 0 || (ema && batch && factor)), "ema_update: bad arguments");
+    if (n == 0) return VOTENET_OK;
+    long grid = (n + 255) / 256;
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(votenet::ema_update_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), n, momentum, ema, batch, factor);
+    return check_launch("ema_update");
+}

@@ -132,11 +132,15 @@ def set_deterministic(on=True):
 
 # BatchNorm-backward coefficients in the tail of the kernel that reduced their sums (struct votenet_coef_tail): the last workgroup
 # to finish does votenet_bn_backward_coef's work, so no launch sits between a reduction and its consumers on the step's
-# dependent chain (23 launches of ~5 us per train step).  Measured (tools/ab_step.py mlp.COEF_TAIL False True, same box, six
-# pairs): 6.997 -> 6.964 ms per step, 0.4 % -- the small launches overlap the dispatch of their neighbours, their summed
-# duration (0.12 ms) is not what they cost.  Off by default: the tail relies on a device-scope atomic being in place once its
-# issuing wave's vmcnt has drained, which holds in every test here but is a weaker guarantee than a kernel boundary.
-COEF_TAIL = False
+# dependent chain (23 launches of ~5 us per train step: 219 -> 196 launches).  Time: neutral (tools/ab_step.py mlp.COEF_TAIL False True,
+# round 3, three alternations: 6.038 / 6.049 / 6.059 -> 6.044 / 6.052 / 6.050 ms; round 2: 6.997 -> 6.964) -- the small launches overlap
+# the dispatch of their neighbours; what it saves is host enqueue time and queue slots.
+# On since round 3.  The hand-off is the form MI355X_MICROARCH.md lists as valid for cross-workgroup data ("8-byte agent-scope atomics
+# on both sides"): every contribution to the sums is a device-scope fp64 atomic (executed at the memory side, coherent across XCDs);
+# each thread drains its own atomics (asm volatile s_waitcnt vmcnt(0): invisible to the pass that may drop a compiler-generated wait)
+# before the workgroup's barrier and its ticket (a returning device-scope atomic); whoever draws the last ticket reads the sums with
+# device-scope atomic loads, which bypass the CU's L1.  No plain store or load takes part, so no cache needs a release or an acquire.
+COEF_TAIL = True
 _tickets = {}
 
 
@@ -220,10 +224,12 @@ class PendingBN:
     consumes the layer output derives scale / shift in its prologue (struct votenet_bn_raw) and fills `out`
     (scale | shift | mean | var, kept for the backward pass); finalize() launches the stand-alone kernel instead."""
 
-    def __init__(self, stats, gamma, beta, rows, eps=None):
+    def __init__(self, stats, gamma, beta, rows, eps=None, out=None):
+        """out: the layer's persistent (4, c) block (ParamStore.bn_flat) -- the backward pass of the SAME step reads it, the next
+        forward pass of the layer overwrites it; None: a fresh buffer."""
         self.stats, self.gamma, self.beta, self.rows = stats, gamma, beta, rows
         self.eps = BN_EPS if eps is None else eps
-        self.out = torch.empty((4, gamma.shape[0]), dtype=torch.float32, device=gamma.device)
+        self.out = out if out is not None else torch.empty((4, gamma.shape[0]), dtype=torch.float32, device=gamma.device)
         self.done = False
 
     scale = property(lambda self: self.out[0])

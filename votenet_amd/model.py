@@ -236,11 +236,21 @@ class VoteNetHotPath:
         gradient bucket: the moving averages are not trained and never all-reduced (statistics stay per replica)."""
         if getattr(self, "_ema", None) is None:
             self._ema = {}
+            st = self.store
+            # one flat buffer in the layout of ParamStore.bn_flat (the blocks the consumers' prologues fill): one launch updates all
+            self._ema_flat = torch.zeros_like(st.bn_flat) if st.bn_flat is not None else None
+            base = st.bn_flat.data_ptr() if st.bn_flat is not None else 0
             for L in self._bn_layers():
-                t = torch.zeros((4, L.cout), dtype=torch.float32, device=self.device)
+                blk = st._bn_views.get(L.name)
+                if blk is not None and self._ema_flat is not None:
+                    o = (blk.data_ptr() - base) // 4
+                    t = self._ema_flat[o:o + 4 * L.cout].view(4, L.cout)
+                else:
+                    t = torch.zeros((4, L.cout), dtype=torch.float32, device=self.device)
                 t[3].fill_(1.0)
                 self._ema[L.name] = t
             self._ema_fac = {}
+            self._ema_fac_flat = None
             self._ema_version = 0
         return self._ema
 
@@ -256,8 +266,29 @@ class VoteNetHotPath:
         tf.nn.fused_batch_norm hands to the moving-average update) of every BatchNorm layer of this forward pass: two
         multi-tensor launches per step on the (scale | shift | mean | var) blocks the consumers' prologues left behind."""
         ema = self._ema_state()
+        recs = list(self._bn_records(tape))
+        st = self.store
+        blocks = st._bn_views
+        if self._ema_flat is not None and self._ema_flat.is_cuda and len(recs) == len(blocks) and \
+                all(r["bn_out"] is blocks.get(r["layer"].name) for r in recs):
+            # every BatchNorm layer of the model ran once and left its block in the persistent buffer: ONE launch (csrc/glue.hip)
+            key = tuple(r["rows"] for r in recs)
+            if self._ema_fac_flat is None or self._ema_fac_flat[0] != key:
+                f = torch.full_like(st.bn_flat, 1.0 - self.BN_MOMENTUM)
+                base = st.bn_flat.data_ptr()
+                for r in recs:
+                    c, rows = r["layer"].cout, r["rows"]
+                    o = (blocks[r["layer"].name].data_ptr() - base) // 4
+                    f[o + 3 * c:o + 4 * c] *= rows / max(rows - 1.0, 1.0)
+                self._ema_fac_flat = (key, f)
+            from . import _lib as L_
+            with L_.device_guard(self.device):
+                L_.check(L_.lib().votenet_ema_update(st.bn_flat.numel(), self.BN_MOMENTUM, L_.ptr(self._ema_flat), L_.ptr(st.bn_flat),
+                                                     L_.ptr(self._ema_fac_flat[1]), L_.stream_ptr()))
+            self._ema_version += 1
+            return
         dst, src, fac = [], [], []
-        for r in self._bn_records(tape):
+        for r in recs:
             name, rows = r["layer"].name, r["rows"]
             key = (name, rows)
             if key not in self._ema_fac:

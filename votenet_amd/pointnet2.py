@@ -54,6 +54,11 @@ class ParamStore:
         # place), and a copy of an older generation is rebuilt before its next use instead of being multiplied by silently
         self.generation = 0
         self._split_gen = -1
+        # the (scale | shift | mean | var) blocks the BatchNorm consumers leave behind, one per BatchNorm'ed layer, in ONE persistent
+        # buffer (bn_block): the moving-average update of a train step is then one launch over it (votenet_ema_update)
+        self._bn_specs = []   # (layer name, cout)
+        self.bn_flat = None
+        self._bn_views = {}
 
     def want_transpose(self, name, lo=0, hi=None):
         """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
@@ -212,6 +217,12 @@ class ParamStore:
             total += (math.prod(shape) + 3) // 4 * 4
         self.flat = torch.zeros(total, dtype=torch.float32, device=self.device)
         self.grad = torch.zeros(total, dtype=torch.float32, device=self.device)
+        nbn = sum(4 * c for _, c in self._bn_specs)
+        self.bn_flat = torch.zeros(max(nbn, 1), dtype=torch.float32, device=self.device)
+        o = 0
+        for name, c in self._bn_specs:
+            self._bn_views[name] = self.bn_flat[o:o + 4 * c].view(4, c)
+            o += 4 * c
         gen = torch.Generator(device="cpu").manual_seed(seed)
         for (name, shape, init), off in zip(self._specs, offs):
             n = math.prod(shape)
@@ -252,6 +263,7 @@ class Layer:
         if bn:
             store.declare(name + "/gamma", (cout,), "ones")
             store.declare(name + "/beta", (cout,), "zeros")
+            store._bn_specs.append((name, cout))
         # a plain (no BatchNorm) layer with a ragged width -- voting's 259, mlp2's 79 -- runs on copies padded to a multiple of 64
         # columns: the fast GEMMs want 16-byte aligned rows (the generic kernel they replace ran at 19 TFLOP/s)
         self.cout_pad = 0
@@ -404,7 +416,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             pend = _FROZEN.table[L.name]  # moving averages: the batch sums of this launch are ignored
             rec.update(scale=pend.scale, shift=pend.shift)
         elif L.bn:
-            pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows)
+            pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows, out=L.store._bn_views.get(L.name))
             rec.update(scale=pend.scale, shift=pend.shift, mean=pend.mean, var=pend.var, bn_out=pend.out)
         else:
             pend = None
