@@ -55,10 +55,10 @@ __device__ __forceinline__ unsigned fbits(float f) { return __float_as_uint(f); 
 // loop's code (measured: an edit of the PROLOGUE alone took sa1 from 1.659 to 1.692 ms on one box).  FPS_PAD_A / FPS_PAD_B shift the
 // loops of fps_bucket_kernel / fps_bucket_l2_kernel by that many s_nop (4 bytes each); the values are the measured best.
 #ifndef FPS_PAD_A
-#define FPS_PAD_A 0
+#define FPS_PAD_A 1 // same box, sa1: 0 -> 1.688 ms, 1 -> 1.660, 2 -> 1.681, 3 -> 1.684 (round 2's build: 1.658)
 #endif
 #ifndef FPS_PAD_B
-#define FPS_PAD_B 0
+#define FPS_PAD_B 3 // same box, 4 x 80000 -> 2048: 0 -> 2.92 ms, 1 -> 2.93, 2 -> 2.87, 3 -> 2.855 (round 2's build: 2.94).  Re-measure after any edit of this file
 #endif
 #define FPS_NOPS_0
 #define FPS_NOPS_1 asm volatile("s_nop 0");
@@ -1089,7 +1089,7 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_l2_kernel(int n, int m, co
                         act &= act - 1;
                         const size_t base = (size_t)((s * 64 + li[f]) * NW + w) * 64 + lane;
                         pv[f] = sp[base];
-                        pk[f] = (base < (size_t)n) ? (pm[base] & 0x7fffffff) : -1;
+                        pk[f] = (base < (size_t)n) ? pm[base] : -1; // a hole's entry is negative (sidx_scatter_kernel): like padding, it never wins a tie
                         cnt = f + 1;
                     }
                 }
