@@ -47,6 +47,7 @@ class _StatsArena:
     cap32 = 0         # floats of the fp32 region
     off32 = 0         # next free float
     want32 = 0        # floats requested in this pass (what the next pass's region must hold)
+    zeroed32 = 0      # floats of the fp32 region this pass's fill cleared
     depth = 0
     active = False
 

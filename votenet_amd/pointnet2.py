@@ -457,9 +457,14 @@ def _hand_over(thunks, tensors):
     WGRAD_STREAM.wait_event(ev)
     for t in tensors:
         t.record_stream(WGRAD_STREAM)
-    with torch.cuda.stream(WGRAD_STREAM):
+    # set_stream both ways instead of the `with torch.cuda.stream(...)` context: the context manager looks the current stream up
+    # twice on entry and exit (~40 us per hand-over on the host, ~24 hand-overs per step)
+    torch.cuda.set_stream(WGRAD_STREAM)
+    try:
         for f in thunks:
             f()
+    finally:
+        torch.cuda.set_stream(main)
     _wgrad_pending = True
 
 
