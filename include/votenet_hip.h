@@ -495,6 +495,11 @@ void votenet_debug_fast_bf3(int on);
 /* votenet_mlp_gram on split operands as well (pool_bwd.hip: 8 consecutive rows of a channel per MFMA fragment; c = 64 or 128,
  * no scratch = atomics mode); 0: the fp32 MFMA kernel always.  Default 1. */
 void votenet_debug_gram_bf3(int on);
+/* every other weight-gradient GEMM (votenet_mlp_wgrad / _wgrad_bn, assembled, narrow) on split operands: row-major bf16 images in LDS,
+ * fragments through ds_read_b64_tr_b16 (mlp_wgrad_fast.hip); 0: the fp32 MFMA kernel.  Default 1. */
+void votenet_debug_wgrad_bf3(int on);
+/* measurement hook: votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
+void votenet_debug_scatter_reverse(int on);
 
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
 int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);

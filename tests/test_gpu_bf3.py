@@ -270,3 +270,42 @@ def test_a_module_driven_directly_after_an_optimizer_step_multiplies_by_the_curr
         M.arena_end()
     bf3.votenet_debug_fast_bf3(1)
     assert float((direct - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4096, 128, 128), (40000, 128, 128), (4111, 64, 64), (65536, 64, 128), (8192, 256, 128), (130, 128, 64),
+                                           (100000, 128, 256)])
+def test_weight_gradient_on_split_operands_vs_float64_and_the_fp32_kernel(bf3, dev, rows, cin, cout):
+    """mlp_wgrad_fast.hip, BF3: dW = act(x)^T dz with the contraction over the rows -- row-major bf16 images in LDS, fragments through
+    ds_read_b64_tr_b16.  Plain and BatchNorm-backward right operands, ragged row counts (padding rows must add nothing), every tile
+    shape (64- and 128-wide blocks on either side); error against float64 as for the other split-operand GEMMs, and it really ran."""
+    from votenet_amd import mlp
+    rng = np.random.default_rng(rows + cin + cout)
+    x = T((rng.normal(size=(rows, cin)) * 1.2).astype(np.float32), dev)
+    sc, sh = T((rng.random(cin) + 0.5).astype(np.float32), dev), T((rng.normal(size=cin) * 0.3).astype(np.float32), dev)
+    dz = T(rng.normal(size=(rows, cout)).astype(np.float32), dev)
+    a = torch.relu(x.double() * sc.double() + sh.double())
+    ref = a.t() @ dz.double()
+    bound = float((a.abs().t() @ dz.double().abs()).max())
+    errs, outs = [], []
+    for mode in (1, 0):
+        bf3.votenet_debug_wgrad_bf3(mode)
+        dw = torch.zeros(cin, cout, device=dev)
+        mlp.wgrad_dense(x, dz, dw, sc, sh, True)
+        errs.append(float((dw.double() - ref).abs().max()) / bound)
+        outs.append(dw)
+    bf3.votenet_debug_wgrad_bf3(1)
+    assert errs[0] <= 3e-6 and errs[0] <= 2.0 * errs[1] + 5e-7, "bf16 x 3: %.3g of the accumulated magnitude, fp32 MFMA: %.3g" % tuple(errs)
+    assert not torch.equal(outs[0], outs[1])
+    # the BatchNorm-backward right operand rebuilt in the loader: dz = A g + B + C z with g = da masked by the ReLU of z
+    z = T(rng.normal(size=(rows, cout)).astype(np.float32), dev)
+    da = T(rng.normal(size=(rows, cout)).astype(np.float32), dev)
+    coef = T(np.concatenate([rng.normal(size=cout), rng.normal(size=cout) * 0.1, rng.normal(size=cout) * 0.2, rng.random(cout) + 0.5,
+                             rng.normal(size=cout) * 0.3]).astype(np.float32), dev)
+    A, B, C, S, H = [coef[i * cout:(i + 1) * cout].double() for i in range(5)]
+    g = torch.where(z.double() * S + H > 0, da.double(), torch.zeros_like(da, dtype=torch.float64))
+    dzb = A * g + B + C * z.double()
+    ref2 = a.t() @ dzb
+    bound2 = float((a.abs().t() @ dzb.abs()).max())
+    dw2 = torch.zeros(cin, cout, device=dev)
+    mlp.wgrad_dense_bn(x, z, coef, True, dw2, da=da, in_scale=sc, in_shift=sh, in_relu=True)
+    assert float((dw2.double() - ref2).abs().max()) / bound2 <= 4e-6

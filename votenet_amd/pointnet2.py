@@ -56,6 +56,7 @@ class ParamStore:
         self._split_gen = -1
         # the (scale | shift | mean | var) blocks the BatchNorm consumers leave behind, one per BatchNorm'ed layer, in ONE persistent
         # buffer (bn_block): the moving-average update of a train step is then one launch over it (votenet_ema_update)
+        self._split_rows = []  # (tensor name, row_lo, row_hi): row blocks of a matrix that are GEMM operands of their own (W[3:] of an SA first layer)
         self._bn_specs = []   # (layer name, cout)
         self.bn_flat = None
         self._bn_views = {}
@@ -94,7 +95,9 @@ class ParamStore:
         if not self.split or self.flat is None or not self.flat.is_cuda:
             return
         if self._split_flat is None:
-            self._split_flat = M.SplitImages([v for v in self.views.values() if v.dim() == 2])
+            mats = [v for v in self.views.values() if v.dim() == 2]
+            mats += [self.views[name][lo:hi] for name, lo, hi in self._split_rows]  # e.g. W[3:]: the per-point GEMM P = feat W[3:]
+            self._split_flat = M.SplitImages(mats)
         self._split_flat.refresh()
         self._split_gen = self.generation
 
@@ -691,6 +694,7 @@ class SAModule:
         self.leaf, self.cin = leaf, cin
         self.mlp = make_mlp(store, scope, 3 + cin, mlp, prefix)
         store.want_transpose(self.mlp[0].name + "/W", 3, None)  # W[3:]^T: the per-point feature gradient
+        store._split_rows.append((self.mlp[0].name + "/W", 3, None))  # W[3:]: the per-point GEMM of the forward pass gets its image too
         store.want_transpose(self.mlp[0].name + "/W", 0, 3)     # W[:3]^T: the xyz gradient (proposal layer)
         self.mlp2 = make_mlp(store, scope, mlp[-1], mlp2, "conv_post_", last_plain=True) if mlp2 else None
 
