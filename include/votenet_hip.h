@@ -656,6 +656,56 @@ int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, vo
  * factor[i] * batch[i] over flat buffers holding all layers' (scale | shift | mean | var) blocks. */
 int votenet_ema_update(long n, float momentum, float *ema, const float *batch, const float *factor, void *stream);
 
+/* ---- HALF-GROUP layout of a set-abstraction level (half.hip): the grouped MLP without the rows that are copies ----
+ * A ball with fewer than nsample = 64 neighbours repeats its first hit in the remaining slots (tf_grouping_g.cu:26-29); a repeated
+ * slot is an identical row through every layer of the grouped MLP (utils.py:125-132).  The rows of a level are laid out as half-groups
+ * of 32: half-group h < G (G = b*m centres) = slots 0..31 of centre h; half-group h >= G = slots 32..63 of centre hc[h], present only
+ * for centres with pts_cnt > 31 (plus up to three all-copy ones so that nh % 4 == 0).  Row 31 of a first half whose second half is
+ * dropped stands for 33 identical true rows: wh[h] = 33 (else 1) is its weight in every sum over the true rows -- the BatchNorm
+ * statistics and the affine part B + C z of every BatchNorm backward.  Gradients per compact row are TOTALS over the rows it stands
+ * for.  Same results as the full layout up to the association of those sums.
+ * votenet_half_groups: pos2 (G) = index of centre c's second half among the kept ones or -1, hc (2G) = centre of half-group h,
+ * wh (2G), nh (1 int, device) = number of half-groups.  One workgroup, a prefix scan: the layout is the same in every run. */
+int votenet_half_groups(int G, const int *pts_cnt, int *pos2, int *hc, float *wh, int *nh, void *stream);
+/* votenet_assemble_rows on the half-group layout: geo (up to 2G*32 x 4 floats; rows past 32*nh[0] are not written), cntv and moments
+ * exactly as votenet_assemble_rows (they run over the true rows).  nh is read on the device: no host synchronisation. */
+int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
+                               const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream);
+/* Forward GEMMs on rows = 32*nh compact rows: votenet_assembled_linear / votenet_mlp_linear_pool with the statistics weighted by wh;
+ * the pool variant leaves the raw max / min / arg of every 32-row half-group (nh x cout), joined per centre by
+ * votenet_bn_pool_finalize_half (ties -> the first half, the first occurrence as in the 64-row epilogue; argmax = slot 0..63). */
+int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
+                                  const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias,
+                                  float *z, double *stats, const float *wh, void *stream);
+int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
+                                 double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin, void *stream);
+int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin, const int *pos2,
+                                  const float *scale, const float *shift, const votenet_bn_raw *bn, int relu, float *out, int *argmax,
+                                  float *zsel, void *stream);
+/* Backward on the compact rows (gout / argmax / zsel stay per centre): the scatter of the pooled layer's input gradient (also scales
+ * the dense part of row 31 by wh), its Gram matrix a^T diag(w) a, its sparse weight-gradient part with weighted column sums, the
+ * second layer's weight / input gradient over the assembled first layer, and the first layer's scatter to the points. */
+int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
+                                    const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
+                                    const float *below_z, const float *below_scale, const float *below_shift, const float *below_mean,
+                                    const float *below_var, float eps, int below_relu, double *below_sums,
+                                    const votenet_coef_tail *below_tail, void *stream);
+int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram, void *stream);
+int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
+                                   int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
+                                   float *dw, float *colsum, const int *hc, const float *wh, void *stream);
+int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
+                                    const float *in_shift, int in_relu, const float *da, const float *z, const float *coef, int relu,
+                                    const float *wh, float *dw, void *stream);
+int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                           const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
+                                           const float *scale_prev, const float *shift_prev, const float *mean_prev,
+                                           const float *var_prev, float eps, int relu_prev, double *sums,
+                                           const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
+int votenet_group_linear_backward_half(long nh, int G, int cout, const float *geo, const int *pts_cnt, const int *hc, const float *wh,
+                                       const float *P, const float *wx, const float *da, const float *coef, int relu, float *s_points,
+                                       float *dw_xyz, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,213 @@
+"""GPU: the HALF-GROUP layout of a set-abstraction level (csrc/half.hip and the *_half entries of include/votenet_hip.h) against the
+full layout of the same level: the rows a ball repeats (tf_grouping_g.cu:26-29 pads with the first hit) dropped by halves of 32, one row
+standing for the dropped copies with a weight.  Same values per row, same sums up to their association."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    return float((a.double() - b.double()).abs().max() / max(1e-12, float(b.double().abs().max())))
+
+
+def layout_reference(cnt):
+    """numpy restatement of votenet_half_groups: centres in ascending order, then all-copy halves until nh % 4 == 0."""
+    G = cnt.size
+    pos2 = np.full(G, -1, np.int64)
+    hc = list(range(G))
+    for c in range(G):
+        if cnt[c] > 31:
+            pos2[c] = len(hc) - G
+            hc.append(c)
+    c = 0
+    while len(hc) % 4:
+        if pos2[c] < 0:
+            pos2[c] = len(hc) - G
+            hc.append(c)
+        c += 1
+    hc = np.array(hc)
+    wh = np.where((np.arange(len(hc)) < G) & (pos2[hc] < 0), 33.0, 1.0).astype(np.float32)
+    return pos2, hc, wh
+
+
+@pytest.mark.parametrize("G,kind", [(8, "mixed"), (4096, "mixed"), (64, "full"), (64, "empty"), (20, "one"), (16384, "mixed")])
+def test_half_group_layout_of_a_level(hiplib, dev, G, kind):
+    from votenet_amd import mlp as M
+    rng = np.random.RandomState(G)
+    cnt = {"mixed": rng.randint(0, 65, G), "full": np.full(G, 64), "empty": np.zeros(G, np.int64),
+           "one": np.where(np.arange(G) == 7, 40, 3)}[kind].astype(np.int32)
+    half = M.half_groups(torch.from_numpy(cnt).to(dev).view(1, G)).resolve()
+    pos2, hc, wh = layout_reference(cnt)
+    assert half.nh == len(hc) and half.nh % 4 == 0
+    assert np.array_equal(half.pos2.cpu().numpy(), pos2) and np.array_equal(half.hc.cpu().numpy(), hc)
+    assert np.array_equal(half.wh.cpu().numpy(), wh)
+    # twice the same layout (a scan, not atomics)
+    again = M.half_groups(torch.from_numpy(cnt).to(dev).view(1, G)).resolve()
+    assert torch.equal(again.hc, half.hc) and torch.equal(again.pos2, half.pos2)
+
+
+def _rows_of(half, dev):
+    """compact row -> (its full row, the number of full rows it stands for): row 31 of a first half without a second one stands for
+    slots 31..63 of its centre."""
+    G, nh = half.G, half.nh
+    h = torch.arange(nh, device=dev)[:, None]
+    s = torch.arange(32, device=dev)[None, :]
+    full = half.hc.long()[:, None] * 64 + torch.where(h >= G, 32, 0) + s
+    mult = torch.ones(nh, 32, device=dev)
+    mult[:, 31] = half.wh
+    return full.reshape(-1), mult.reshape(-1)
+
+
+def _totals(t_full, half, dev):
+    """Sum of the full-layout rows every compact row stands for."""
+    full, mult = _rows_of(half, dev)
+    out = t_full[full].double()
+    heavy = torch.nonzero(mult > 1).flatten()
+    for j in range(1, 33):  # slots 32..63 of the centres whose second half is dropped
+        out[heavy] += t_full[full[heavy] + j].double()
+    return out
+
+
+@pytest.mark.parametrize("b,n,m,cf,c2,radius", [(2, 600, 64, 128, 256, 0.5), (1, 500, 48, 32, 128, 0.42), (2, 400, 32, 64, 256, 0.62)])
+def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_form, b, n, m, cf, c2, radius):
+    from votenet_amd import mlp as M
+    from votenet_amd import tf_grouping, tf_sampling
+    k, c0, c1 = 64, 128, 128
+    g = torch.Generator().manual_seed(7 * n + cf)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    xyz = (torch.rand(b, n, 3, generator=g) * 2.0).to(dev)
+    feat = rnd(b, n, cf)
+    new_xyz = tf_sampling.gather_point(xyz, tf_sampling.farthest_point_sample(m, xyz))
+    idx, cnt = tf_grouping.query_ball_point(radius, k, xyz, new_xyz)
+    assert bool((cnt <= 31).any()), cnt.flatten().tolist()
+    G, rows = b * m, b * m * k
+    w0, b0, w1, w2, b2 = rnd(3 + cf, c0) * 0.3, rnd(c0) * 0.1, rnd(c0, c1) * 0.2, rnd(c1, c2) * 0.2, rnd(c2) * 0.1
+    wx = w0[:3].contiguous()
+    w1T, w2T = w1.t().contiguous(), w2.t().contiguous()
+    img = M.SplitImages([w1, w1T, w2])
+    img.refresh()
+    P, _ = M.linear_dense(feat.reshape(b * n, cf), w0[3:].contiguous(), b0, want_stats=False)
+    # ---- geometry
+    geo, cntv, mom = M.assemble_rows(xyz, new_xyz, idx, pts_cnt=cnt)
+    half = M.half_groups(cnt)
+    _, cntv_h, mom_h = M.assemble_rows_half(xyz, new_xyz, idx, cnt, half)
+    half.resolve()
+    full, mult = _rows_of(half, dev)
+    saved = 1.0 - half.rows / rows
+    assert 0.0 < saved <= 0.5 and half.rows % 128 == 0, cnt.flatten().tolist()
+    assert torch.equal(half.geo, geo[full]) and torch.equal(cntv_h, cntv) and relerr(mom_h, mom) < 1e-12
+    # every full row is represented exactly once
+    cover = torch.zeros(rows, device=dev)
+    cover.index_add_(0, full, torch.ones_like(mult))
+    heavy = torch.nonzero(mult > 1).flatten()
+    for j in range(1, 33):
+        cover.index_add_(0, full[heavy] + j, torch.ones(heavy.numel(), device=dev))
+    kept_twice = (half.pos2 >= 0) & (cnt.flatten() <= 31)  # all-copy second halves kept for the tile count: represented by themselves
+    assert torch.equal(cover, torch.ones(rows, device=dev)), (int(kept_twice.sum()), cover.unique())
+    # ---- forward: layer 1 (assembled loader), layer 2 (pool in the epilogue) with ONE BatchNorm per layer for both layouts
+    st0 = M.assemble_stats(P, cntv, wx, mom)
+    bn0 = M.PendingBN(st0, rnd(c0) * 0.2 + 1.0, rnd(c0) * 0.1, rows)
+    z1, st1 = M.assembled_linear(geo, P, wx, w1, None, bn0)
+    z1h, st1h = M.assembled_linear(half.geo, P, wx, w1, None, bn0, half=half)
+    assert torch.equal(z1h, z1[full])
+    assert relerr(st1h[:c1], st1[:c1]) < 1e-6 and relerr(st1h[c1:], st1[c1:]) < 1e-6
+    bn1 = M.PendingBN(st1, rnd(c1) * 0.2 + 1.0, rnd(c1) * 0.1, rows)
+    bn1.finalize()
+    _, st2, pool = M.linear_dense_pool(z1, w2, k, b2, bn1.scale, bn1.shift, True, keep_z=False)
+    _, st2h, poolh = M.linear_dense_pool(z1h, w2, k, b2, bn1.scale, bn1.shift, True, keep_z=False, half=half)
+    assert relerr(st2h[:c2], st2[:c2]) < 1e-6 and relerr(st2h[c2:], st2[c2:]) < 1e-6
+    bn2 = M.PendingBN(st2, rnd(c2) * 0.3 + 0.2, rnd(c2) * 0.1, rows)  # some negative gammas: the min side of the pool
+    bn2.finalize()
+    out, arg, zsel = M.bn_pool_finalize(pool, bn2.scale, bn2.shift, True, want_argmax=True, want_zsel=True)
+    outh, argh, zselh = M.bn_pool_finalize(poolh, bn2.scale, bn2.shift, True, want_argmax=True, want_zsel=True, half=half)
+    assert torch.equal(outh, out) and torch.equal(zselh, zsel) and torch.equal(argh, arg)
+    assert int((bn2.scale < 0).sum()) > 0
+    # ---- backward of the pooled layer in Gram form
+    gout, coef2 = rnd(G, c2), rnd(5 * c2) * 0.3
+    coef2[3 * c2:4 * c2], coef2[4 * c2:] = bn2.scale, bn2.shift
+    aff1 = torch.stack([bn1.scale, bn1.shift]).contiguous()
+    Gm, Gh = M.gram(z1, aff1, True), M.gram(z1h, aff1, True, half=half)
+    dw2, dw2h = torch.zeros(c1, c2, device=dev), torch.zeros(c1, c2, device=dev)
+    M.pool_wgrad(z1, bn1.scale, bn1.shift, True, Gm, w2, b2, coef2, True, gout, arg, zsel, k, dw2)
+    M.pool_wgrad(z1h, bn1.scale, bn1.shift, True, Gh, w2, b2, coef2, True, gout, arg, zsel, k, dw2h, half=half)
+    assert relerr(Gh[:c1], Gm[:c1]) < 2e-6 and relerr(Gh[c1], Gm[c1]) < 2e-6 and relerr(dw2h, dw2) < 1e-5
+    below = (bn1.scale, bn1.shift, bn1.mean, bn1.var, True)
+    da1, sums1 = M.pool_dgrad(z1, bn1.scale, bn1.shift, True, w2, b2, w2T, coef2, True, gout, arg, zsel, k, below=below)
+    da1h, sums1h = M.pool_dgrad(z1h, bn1.scale, bn1.shift, True, w2, b2, w2T, coef2, True, gout, arg, zsel, k, below=below, half=half)
+    assert relerr(da1h, _totals(da1, half, dev)) < 2e-6
+    zh1 = (z1.double() - bn1.mean.double()) / torch.sqrt(bn1.var.double() + M.BN_EPS)
+    scale1 = torch.cat([da1.double().abs().sum(0), (da1.double() * zh1).abs().sum(0)])
+    assert float(((sums1h - sums1).abs() / (scale1 + 1e-30)).max()) < 1e-5
+    # ---- backward of layer 1 over the assembled layer 0 (da: random per full row; the compact rows carry the totals)
+    da1 = rnd(rows, c1)
+    da1h = _totals(da1, half, dev).float()
+    coef1 = rnd(5 * c1) * 0.3
+    coef1[3 * c1:4 * c1], coef1[4 * c1:] = bn1.scale, bn1.shift
+    dw1, dw1h = torch.zeros(c0, c1, device=dev), torch.zeros(c0, c1, device=dev)
+    M.assembled_wgrad_bn(geo, P, wx, bn0.scale, bn0.shift, True, z1, coef1, True, da1, dw1)
+    M.assembled_wgrad_bn(half.geo, P, wx, bn0.scale, bn0.shift, True, z1h, coef1, True, da1h, dw1h, half=half)
+    assert relerr(dw1h, dw1) < 1e-5
+    bn0.finalize()
+    below0 = (bn0.scale, bn0.shift, bn0.mean, bn0.var, True)
+    da0, sums0 = M.assembled_dgrad_bn_reduce(z1, coef1, True, w1T, da1, geo, P, wx, below0)
+    da0h, sums0h = M.assembled_dgrad_bn_reduce(z1h, coef1, True, w1T, da1h, half.geo, P, wx, below0, half=half)
+    assert relerr(da0h, _totals(da0, half, dev)) < 1e-5
+    z0 = M.assemble_z0(geo, P, wx)
+    scale0 = torch.cat([da0.double().abs().sum(0), (da0.double() * ((z0.double() - bn0.mean.double()) / torch.sqrt(bn0.var.double() + M.BN_EPS))).abs().sum(0)])
+    assert float(((sums0h - sums0).abs() / (scale0 + 1e-30)).max()) < 1e-5
+    # ---- backward of layer 0: scatter to the points and the xyz rows of dW
+    coef0 = rnd(5 * c0) * 0.3
+    coef0[3 * c0:4 * c0], coef0[4 * c0:] = bn0.scale, bn0.shift
+    dwx, dwxh = torch.zeros(3, c0, device=dev), torch.zeros(3, c0, device=dev)
+    da0t = _totals(da0, half, dev).float()
+    S, _ = M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, P, wx, da0, coef0, True, dwx)
+    Sh = M.group_linear_backward_half(half, cnt, b, n, P, wx, da0t, coef0, True, dwxh)
+    assert relerr(Sh, S) < 1e-5 and relerr(dwxh, dwx) < 1e-4
+    img.close()
+
+
+def test_model_with_and_without_the_half_group_layout(hiplib, dev):
+    """The whole hot path with sa2 / sa3 / sa4 on the half-group layout against the full layout: same outputs and losses to fp32
+    rounding (the BatchNorm sums are associated differently), the same gradient in the L2 sense (tests/test_gpu_narrow.py: two fp32
+    evaluations of a forward pass move ReLU / arg-max decisions), fewer grouped rows."""
+    from votenet_amd import loss as VL
+    from votenet_amd import model as VM
+    from votenet_amd import pointnet2 as P
+    from votenet_amd import synth
+    b, n = 2, 8192
+    x = torch.from_numpy(synth.room_batch(b, n, 9)).to(dev)
+    gt = VL.gt_to_device(synth.room_gt(b, n, 9), dev)
+    net = VM.VoteNetHotPath(dev, seed=6, npoints=(1024, 512, 256, 128))
+    fixed = {}
+
+    def once():
+        net.store.grad.zero_()
+        net.store.refresh_transposes()
+        tape = []
+        out = net.forward(x, tape)
+        losses, cot = VL.votenet_loss(out, gt)
+        cot = fixed.setdefault("cot", cot)
+        net.backward(tape, cot)
+        torch.cuda.synchronize()
+        return tape, out["proposals_output"].clone(), losses.clone(), net.store.grad.clone()
+    assert not P.HALF_GROUPS
+    tape, o0, l0, g0 = once()
+    assert all(t["recs"][0].get("half") is None for t in tape if t.get("op") == "sa")
+    P.HALF_GROUPS = True
+    try:
+        tape, o1, l1, g1 = once()
+        sas = [t for t in tape if t.get("op") == "sa"]
+        halves = [t["recs"][0].get("half") for t in sas]
+        assert [h is not None for h in halves] == [False, True, True, True, False]
+        for t, h in zip(sas[1:4], halves[1:4]):
+            assert t["recs"][1]["z"].shape[0] == h.rows < t["recs"][0]["rows"]
+        # inference through the same layout
+        r1 = net.predict(x, 0.25, batch_statistics=True)
+    finally:
+        P.HALF_GROUPS = False
+    r0 = net.predict(x, 0.25, batch_statistics=True)
+    assert relerr(o1, o0) < 5e-5 and relerr(l1, l0) < 5e-5
+    assert float((g1.double() - g0.double()).norm() / g0.double().norm()) < 1e-2
+    assert len(r1) == len(r0)

@@ -164,6 +164,23 @@ _SIGS["votenet_three_interpolate_grad_strided"] = [ctypes.c_int] * 4 + [_c_f, ct
 _SIGS["votenet_bias_grad_strided"] = [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p]
 _SIGS["votenet_ema_update"] = [ctypes.c_long, ctypes.c_float, _c_f, _c_f, _c_f, ctypes.c_void_p]
 _SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(RowSegment), ctypes.c_void_p]
+# half-group layout (csrc/half.hip)
+_I, _L, _F = ctypes.c_int, ctypes.c_long, ctypes.c_float
+_SIGS.update({
+    "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 9 + [ctypes.c_void_p],
+    "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 9 + [ctypes.c_void_p],
+    "votenet_bn_pool_finalize_half": [_L, _I] + [_c_f] * 7 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_pool_dgrad_scatter_half": [_L, _I, _I, _I] + [_c_f] * 4 + [_I] + [_c_f] * 9 + [_F, _I, _c_f, ctypes.POINTER(CoefTail),
+                                                                                       ctypes.c_void_p],
+    "votenet_mlp_gram_half": [_L, _I, _c_f, _c_f, _I, _c_f, _c_f, ctypes.c_void_p],
+    "votenet_pool_wgrad_sparse_half": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [_I] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_assembled_wgrad_bn_half": [_L, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, ctypes.c_void_p],
+    "votenet_assembled_dgrad_bn_reduce_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 9 + [_F, _I, ctypes.c_void_p,
+                                                                                             ctypes.POINTER(CoefTail), _c_f, ctypes.c_void_p],
+    "votenet_group_linear_backward_half": [_L, _I, _I] + [_c_f] * 8 + [_I] + [_c_f] * 2 + [ctypes.c_void_p],
+})
 
 
 def lib():

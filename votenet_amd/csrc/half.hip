@@ -1,0 +1,317 @@
+// half.hip -- the HALF-GROUP layout of a set-abstraction level: the grouped MLP on the rows that are not copies (gfx950).
+//
+// A ball with fewer than K = 64 neighbours repeats its first hit in the remaining slots (tf_grouping_g.cu:26-29), and a repeated slot is
+// an identical row through every layer of the grouped MLP: same point, same centre, same input row, same z at every layer; the max-pool
+// takes the first occurrence, so a repeated row is never the arg-max, and its gradient is the same B + C z at every layer.  On room
+// scenes 39-76 % of the grouped rows are such copies (tools/probe/pts_cnt_stats.py).  Here a level's rows are laid out as HALF-GROUPS of
+// 32 rows:
+//     half-group h <  G (G = b * m centres):  slots  0..31 of centre h                       -- always present
+//     half-group h >= G:                      slots 32..63 of centre hc[h]                   -- only for centres with pts_cnt > 31
+// A centre whose second half is dropped has pts_cnt <= 31, so its slot 31 is itself a copy of slot 0 -- and stands for the 32 dropped copies
+// as well: row 31 of its first half carries WEIGHT 33 (wh[h]) wherever a sum runs over the true rows -- the BatchNorm statistics of the
+// forward pass and the affine part B + C z of every BatchNorm backward.  With TOTAL gradients per row (the sum over the true rows a row
+// stands for) the backward reductions, the weight gradients and the scatter to the points need no weight.  The number of half-groups is
+// kept a multiple of 4 (a 128-row GEMM tile = 4 half-groups) by keeping up to three all-copy second halves, which is exact.
+// The result differs from the full layout only in the association of those sums.
+#include "mlp_types.h"
+
+namespace votenet {
+
+// One workgroup: pos2[c] = index among the kept second halves of centre c (or -1), hc[h] = centre of half-group h, wh[h] = weight of
+// half-group h's row 31, nh[0] = number of half-groups.  Centres in ascending order (a prefix scan, no atomics): the layout -- and with
+// it the order of every sum over the rows -- is the same in every run.
+__global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__restrict__ pts_cnt, int *__restrict__ pos2, int *__restrict__ hc,
+                                                           float *__restrict__ wh, int *__restrict__ nh_out)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_n2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int per = (G + 1023) / 1024;
+    const int c0 = tid * per, c1 = min(G, c0 + per);
+    int mine = 0;
+    for (int c = c0; c < c1; c++) mine += pts_cnt[c] > 31 ? 1 : 0;
+    int x = mine; // inclusive scan over the wavefront, then over the 16 wavefronts
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(x, off);
+        if (lane >= off) x += t;
+    }
+    if (lane == 63) s_wave[wv] = x;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; w++) base += s_wave[w];
+    int p = base + x - mine;
+    for (int c = c0; c < c1; c++) {
+        hc[c] = c;
+        if (pts_cnt[c] > 31) {
+            hc[G + p] = c;
+            pos2[c] = p++;
+        } else {
+            pos2[c] = -1;
+        }
+    }
+    if (tid == 1023) s_n2 = p; // the last thread's running index = the total (its chunk may be empty)
+    __syncthreads();
+    if (tid == 0) {
+        // a GEMM tile is 128 rows = 4 half-groups: round up with all-copy second halves, which is exact (G % 4 == 0: there are enough)
+        int n2 = s_n2;
+        for (int c = 0; c < G && ((G + n2) & 3) != 0; c++)
+            if (pos2[c] < 0) {
+                pos2[c] = n2;
+                hc[G + n2] = c;
+                n2++;
+            }
+        s_n2 = n2;
+        nh_out[0] = G + n2;
+    }
+    __syncthreads();
+    const int nh = G + s_n2;
+    for (int h = tid; h < nh; h += 1024) wh[h] = (h < G && pos2[h] < 0) ? 33.0f : 1.0f;
+}
+
+__device__ __forceinline__ double half_shfl_xor_f64(double v, int m)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __shfl_xor(lo, m);
+    hi = __shfl_xor(hi, m);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ long long half_fixed(float v) { return (long long)((double)v * 4294967296.0); }
+
+// votenet_assemble_rows on the half-group layout: thread = compact row r = h * 32 + s <-> (centre hc[h], slot 32 [h >= G] + s).
+// The per-point counters and the moments run over the TRUE rows exactly as in assemble_rows_kernel: slot k < pts_cnt adds itself, slot 0
+// also the 64 - pts_cnt copies.
+__global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__restrict__ nh_dev, int G, int n, int groups_per_scene, const float *__restrict__ xyz,
+                                                                 const float *__restrict__ new_xyz, const int *__restrict__ idx,
+                                                                 const int *__restrict__ pts_cnt, const int *__restrict__ hc,
+                                                                 float4 *__restrict__ geo, long long *__restrict__ cntv,
+                                                                 double *__restrict__ moments)
+{
+    __shared__ double red[4][9];
+    double acc[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) acc[i] = 0.0;
+    const long rows = (long)nh_dev[0] * 32; // the number of half-groups is known on the device only when this is enqueued
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const int h = (int)(r >> 5), s = (int)(r & 31);
+        const int c = hc[h];
+        const int k = (h >= G ? 32 : 0) + s;
+        const int id = idx[(size_t)c * 64 + k];
+        const unsigned prow = ((unsigned)c / (unsigned)groups_per_scene) * (unsigned)n + (unsigned)id;
+        const float dx = xyz[(size_t)prow * 3 + 0] - new_xyz[(size_t)c * 3 + 0]; // utils.py:55
+        const float dy = xyz[(size_t)prow * 3 + 1] - new_xyz[(size_t)c * 3 + 1];
+        const float dz = xyz[(size_t)prow * 3 + 2] - new_xyz[(size_t)c * 3 + 2];
+        geo[r] = make_float4(dx, dy, dz, __uint_as_float(prow));
+        int cnt = pts_cnt[c];
+        if (cnt < 1) cnt = 1;
+        if (k < cnt) {
+            const long long mult = (k == 0) ? (long long)(64 - cnt + 1) : 1LL;
+            if (cntv) {
+                unsigned long long *cv = reinterpret_cast<unsigned long long *>(cntv + (size_t)prow * 4);
+                atomicAdd(cv + 0, (unsigned long long)mult);
+                atomicAdd(cv + 1, (unsigned long long)(mult * half_fixed(dx)));
+                atomicAdd(cv + 2, (unsigned long long)(mult * half_fixed(dy)));
+                atomicAdd(cv + 3, (unsigned long long)(mult * half_fixed(dz)));
+            }
+            const double m = (double)mult, x = dx, y = dy, z = dz;
+            acc[0] += m * x; acc[1] += m * y; acc[2] += m * z;
+            acc[3] += m * x * x; acc[4] += m * x * y; acc[5] += m * x * z; acc[6] += m * y * y; acc[7] += m * y * z; acc[8] += m * z * z;
+        }
+    }
+    if (!moments) return;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        double v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += half_shfl_xor_f64(v, m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 9)
+        unsafeAtomicAdd(&moments[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+// votenet_bn_pool_finalize over half-groups: a centre's pooled value = the better of its one or two halves (ties -> the first half: the
+// first occurrence, as the 64-row epilogue decides); arg-max = the row offset inside the 64-slot ball.
+__global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
+                                             const int *__restrict__ amax, const int *__restrict__ amin, const int *__restrict__ pos2,
+                                             const float *__restrict__ scale, const float *__restrict__ shift, BnRaw raw, int relu,
+                                             float *__restrict__ out, int *__restrict__ argmax, float *__restrict__ zsel)
+{
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ch = (int)(e % c);
+        const long g = e / c;
+        float s, h;
+        if (raw.stats) bn_raw_channel(raw, c, ch, e < c, s, h);
+        else {
+            s = scale[ch];
+            h = shift[ch];
+        }
+        const int p2 = pos2[g];
+        float vmax = zmax[e], vmin = zmin[e];
+        int imax = amax[e], imin = amin[e];
+        if (p2 >= 0) {
+            const size_t e2 = (size_t)(G + p2) * c + ch;
+            const float bmax = zmax[e2], bmin = zmin[e2];
+            if (bmax > vmax) {
+                vmax = bmax;
+                imax = 32 + amax[e2];
+            }
+            if (bmin < vmin) {
+                vmin = bmin;
+                imin = 32 + amin[e2];
+            }
+        }
+        const float zr = s >= 0.0f ? vmax : vmin;
+        float v = zr * s + h;
+        if (relu && !(v > 0.0f)) v = 0.0f;
+        out[e] = v;
+        if (argmax) argmax[e] = s >= 0.0f ? imax : imin;
+        if (zsel) zsel[e] = zr;
+    }
+}
+
+// votenet_group_linear_backward_assembled on the half-group layout: da holds TOTAL gradients per compact row, so
+//   dz_total = A g' + w (B + C z),  w = wh[h] on row 31 (the rows it stands for share z, hence the mask of g')
+// and the scatter to the points / the xyz rows of dW run over the compact rows unweighted.  Thread = (half-group, channel); the
+// half-group's geo records (dxyz and the point row) are staged in LDS.  Padding rows (slot >= pts_cnt) and slot 0 share one point:
+// summed in a register, one atomic.
+template <int GPB /* half-groups per workgroup pass = 256 / cout */>
+__global__ __launch_bounds__(256) void group_linear_bwd_half_kernel(int nh, int G, int cout, const float4 *__restrict__ geo,
+                                                                    const int *__restrict__ pts_cnt, const int *__restrict__ hc,
+                                                                    const float *__restrict__ wh, const float *__restrict__ ptab,
+                                                                    const float *__restrict__ wx, const float *__restrict__ da,
+                                                                    const float *__restrict__ coef, int relu, float *__restrict__ spt,
+                                                                    float *__restrict__ dw_xyz)
+{
+    __shared__ float4 s_geo[GPB][32];
+    __shared__ float red[256][3];
+    const int tid = threadIdx.x;
+    const int ch = tid % cout, gl = tid / cout;
+    const float kA = coef[ch], kB = coef[cout + ch], kC = coef[2 * cout + ch], kS = coef[3 * cout + ch], kH = coef[4 * cout + ch];
+    const float wx0 = wx[ch], wx1 = wx[cout + ch], wx2 = wx[2 * cout + ch];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    for (int h0 = blockIdx.x * GPB; h0 < nh; h0 += gridDim.x * GPB) {
+        __syncthreads();
+        if (tid < GPB * 32 && h0 + (tid >> 5) < nh) s_geo[tid >> 5][tid & 31] = geo[(size_t)h0 * 32 + tid];
+        __syncthreads();
+        const int h = h0 + gl;
+        if (h < nh) {
+            const int kbase = h >= G ? 32 : 0;
+            int cnt = pts_cnt[hc[h]];
+            if (cnt < 1) cnt = 1;
+            const float w31 = wh[h];
+            const float *__restrict__ darow = da + (size_t)h * 32 * cout + ch;
+            float pad = 0.0f;
+#pragma unroll 1
+            for (int s0 = 0; s0 < 32; s0 += 8) {
+                float zz[8], gg[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    zz[u] = ptab[(size_t)__float_as_uint(s_geo[gl][s0 + u].w) * cout + ch];
+                    gg[u] = darow[(size_t)(s0 + u) * cout];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int s = s0 + u, k = kbase + s;
+                    const float4 g4 = s_geo[gl][s];
+                    const float z = assembled_z(zz[u], g4, wx0, wx1, wx2);
+                    float gq = gg[u];
+                    if (relu && !(z * kS + kH > 0.0f)) gq = 0.0f;
+                    const float aff = kB + kC * z;
+                    const float d = kA * gq + (s == 31 ? w31 * aff : aff);
+                    a0 += g4.x * d;
+                    a1 += g4.y * d;
+                    a2 += g4.z * d;
+                    if (k > 0 && k < cnt)
+                        unsafeAtomicAdd(&spt[(size_t)__float_as_uint(g4.w) * cout + ch], d);
+                    else
+                        pad += d; // slot 0 and the copies of it
+                }
+            }
+            // the point slot 0 names: row 0 of a first half; of a second half, any padding row (row 31 is one if there is any)
+            if (kbase == 0) unsafeAtomicAdd(&spt[(size_t)__float_as_uint(s_geo[gl][0].w) * cout + ch], pad);
+            else if (63 >= cnt) unsafeAtomicAdd(&spt[(size_t)__float_as_uint(s_geo[gl][31].w) * cout + ch], pad);
+        }
+    }
+    red[tid][0] = a0;
+    red[tid][1] = a1;
+    red[tid][2] = a2;
+    __syncthreads();
+    if (tid < cout) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float t = 0.0f;
+            for (int q = 0; q < GPB; q++) t += red[q * cout + tid][d];
+            unsafeAtomicAdd(&dw_xyz[(size_t)d * cout + tid], t);
+        }
+    }
+}
+
+} // namespace votenet
+
+using namespace votenet;
+
+extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos2, int *hc, float *wh, int *nh_out, void *stream)
+{
+    VN_REQUIRE(G > 0 && G % 4 == 0, "half_groups expects a positive number of centres, a multiple of 4");
+    VN_REQUIRE(pts_cnt && pos2 && hc && wh && nh_out, "half_groups: null buffer");
+    hipLaunchKernelGGL(half_groups_kernel, dim3(1), dim3(1024), 0, as_stream(stream), G, pts_cnt, pos2, hc, wh, nh_out);
+    return check_launch("half_groups");
+}
+
+extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
+                                          const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream)
+{
+    VN_REQUIRE(b > 0 && n > 0 && m > 0, "assemble_rows_half: bad shape");
+    const long max_rows = 2L * b * m * 32;
+    VN_REQUIRE(max_rows < (1L << 31) && (long)b * n < (1L << 31), "assemble_rows_half: row and point counts must be below 2^31");
+    VN_REQUIRE(nh && xyz && new_xyz && idx && pts_cnt && hc && geo, "assemble_rows_half: null buffer");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0 && (!cntv || (uintptr_t)cntv % 16 == 0), "assemble_rows_half: geo / cntv must be 16-byte aligned");
+    long gx = (max_rows * 3 / 4 + 256 * 8 - 1) / (256 * 8); // sized for a typical fill; grid-stride covers the rest
+    if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, b * m, n, m, xyz, new_xyz, idx,
+                       pts_cnt, hc, reinterpret_cast<float4 *>(geo), cntv, moments);
+    return check_launch("assemble_rows_half");
+}
+
+extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
+                                             const int *pos2, const float *scale, const float *shift, const votenet_bn_raw *bn, int relu,
+                                             float *out, int *argmax, float *zsel, void *stream)
+{
+    VN_REQUIRE(G >= 0 && c > 0, "bn_pool_finalize_half expects G >= 0, c > 0");
+    if (G == 0) return VOTENET_OK;
+    const BnRaw raw = to_raw(bn);
+    VN_REQUIRE(zmax && zmin && amax && amin && pos2 && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
+               "bn_pool_finalize_half: null buffer");
+    long grid = (G * c + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(bn_pool_finalize_half_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), G * c, (int)G, c, zmax, zmin, amax,
+                       amin, pos2, scale, shift, raw, relu, out, argmax, zsel);
+    return check_launch("bn_pool_finalize_half");
+}
+
+extern "C" int votenet_group_linear_backward_half(long nh, int G, int cout, const float *geo, const int *pts_cnt, const int *hc,
+                                                  const float *wh, const float *P, const float *wx, const float *da, const float *coef,
+                                                  int relu, float *s_points, float *dw_xyz, void *stream)
+{
+    VN_REQUIRE(nh >= G && nh <= 2L * G && G > 0, "group_linear_backward_half: bad shape");
+    VN_REQUIRE(cout == 64 || cout == 128 || cout == 256, "group_linear_backward_half expects cout in {64, 128, 256}");
+    VN_REQUIRE(geo && pts_cnt && hc && wh && P && wx && da && coef && s_points && dw_xyz, "group_linear_backward_half: null buffer");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_half: geo must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const int gpb = 256 / cout;
+    long gx = (nh + gpb - 1) / gpb;
+    if (gx > 2048) gx = 2048;
+    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
+    if (gpb == 4)
+        hipLaunchKernelGGL(group_linear_bwd_half_kernel<4>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
+                           da, coef, relu, s_points, dw_xyz);
+    else if (gpb == 2)
+        hipLaunchKernelGGL(group_linear_bwd_half_kernel<2>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
+                           da, coef, relu, s_points, dw_xyz);
+    else
+        hipLaunchKernelGGL(group_linear_bwd_half_kernel<1>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
+                           da, coef, relu, s_points, dw_xyz);
+    return check_launch("group_linear_backward_half");
+}

@@ -596,7 +596,7 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
 namespace votenet {
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
-                            float *zmin, int *amax, int *amin, hipStream_t st); // mlp_fast.hip
+                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh = nullptr); // mlp_fast.hip
 }
 
 extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
@@ -616,6 +616,26 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
                                   "mlp_linear_pool: shape not served (pool_k == 64, rows % 128 == 0, cin % 32 == 0, cin <= 512, "
                                   "cout % 128 == 0, 16-byte aligned): use votenet_mlp_linear + votenet_bn_relu_max");
     return check_launch("mlp_linear_pool");
+}
+
+// votenet_mlp_linear_pool on the half-group layout (half.hip): rows = 32 x half-groups; zmax / zmin / amax / amin (half-groups x cout) are
+// the raw max / min of every 32-row half-group (votenet_bn_pool_finalize_half joins a centre's halves); the statistics count row 31 of a
+// half-group wh times.
+extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
+                                            float *z, double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin,
+                                            void *stream)
+{
+    VN_REQUIRE(in != nullptr && in->x != nullptr, "mlp_linear_pool_half: DENSE input descriptor required");
+    VN_REQUIRE(rows > 0 && cin > 0 && cout > 0, "mlp_linear_pool_half expects rows > 0, cin > 0, cout > 0");
+    VN_REQUIRE(w && wh && zmax && zmin && amax && amin, "mlp_linear_pool_half: null buffer");
+    VN_REQUIRE((in->in_scale == nullptr) == (in->in_shift == nullptr), "mlp_linear_pool_half: in_scale and in_shift go together");
+    const BnRaw raw = to_raw(in->in_bn);
+    VN_REQUIRE(in->in_bn == nullptr || (raw.stats && raw.gamma && raw.beta && raw.rows > 0 && in->in_scale == nullptr),
+               "mlp_linear_pool_half: in_bn needs stats, gamma, beta, rows > 0 and no in_scale");
+    if (!votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, raw, in->in_relu, rows, cin, cout, w, bias, z, stats, zmax, zmin,
+                                         amax, amin, as_stream(stream), wh))
+        return votenet::set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_linear_pool_half: shape not served (as votenet_mlp_linear_pool)");
+    return check_launch("mlp_linear_pool_half");
 }
 
 extern "C" int votenet_bn_pool_finalize(long groups, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,

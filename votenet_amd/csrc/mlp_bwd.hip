@@ -995,6 +995,27 @@ extern "C" int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const flo
     return check_launch("assembled_wgrad_bn");
 }
 
+// The same on the half-group layout (half.hip): da holds TOTAL gradients per compact row, the affine part of the rebuilt dz1 counts wh[h]
+// times on row 32 h + 31.
+extern "C" int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
+                                               const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
+                                               const float *coef, int relu, const float *wh, float *dw, void *stream)
+{
+    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) && c0 > 0 && cout > 0, "assembled_wgrad_bn_half: bad shape");
+    VN_REQUIRE(geo && P && wx && in_scale && in_shift && da && z && coef && wh && dw, "assembled_wgrad_bn_half: null buffer");
+    MlpIn d = {};
+    d.in_scale = in_scale;
+    d.in_shift = in_shift;
+    d.in_relu = in_relu;
+    d.geo = geo;
+    d.ptab = P;
+    d.wx = wx;
+    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0, wh};
+    if (!wgrad_fast_launch(3, d, rows, c0, cout, nullptr, bs, 4, dw, as_stream(stream), nullptr))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_wgrad_bn_half: shape not served (as votenet_assembled_wgrad_bn)");
+    return check_launch("assembled_wgrad_bn_half");
+}
+
 // coefficient vector [A | B | C | scale | shift] (5*c floats) of the folded BatchNorm backward, from the reductions
 // sums = [sum g', sum g'*zhat]; also dgamma += sums[c:], dbeta += sums[:c] (each may be NULL)
 extern "C" int votenet_bn_backward_coef(long rows, int c, const float *scale, const float *shift, const float *mean,

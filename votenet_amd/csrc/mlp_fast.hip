@@ -112,6 +112,11 @@ struct FastArgs {
     int k0;
     double *ug;                // EPI 4: [8][cout] doubles
     CoefTail tail;             // EPI 3 / 4: the layer below's coefficient vector from the completed sums (last workgroup, common.h)
+    // half-group layout (half.hip): rows are 32-row half-groups, wh[row / 32] = the weight of the half-group's row 31 (33 when it also
+    // stands for a dropped all-copy second half, else 1).  EPI 0 / 2: the statistics count that row wh times; SRC 5: the affine part
+    // B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per 32-row half-group instead of per 64 rows
+    const float *wh;
+    int pool32;
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
@@ -201,7 +206,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const int arow_len = (SRC == 3) ? 8 : cin;
     const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
     const float *pa1 = pa0 + (size_t)64 * arow_len;
-    const ptrdiff_t da_off = (SRC == 1) ? (A.da - A.zsrc) : 0; // SRC 1: da has the layout of zsrc
+    const ptrdiff_t da_off = (SRC == 1 || SRC == 5) ? (A.da - A.zsrc) : 0; // SRC 1 / 5: da has the layout of zsrc
+    // SRC 5 (half-group layout): this thread's rows a_row / a_row + 64 of a tile are row 31 of their half-group iff a_row % 32 == 31; the
+    // weights of those two half-groups travel with the slab (no load under a branch: every thread loads, most ignore)
+    const bool sel31 = (a_row & 31) == 31;
+    const float *pw = (SRC == 5) ? A.wh + (size_t)blockIdx.x * (FG_BM / 32) + (a_row >> 5) : nullptr;
     const size_t a_tile_jump = (SRC == 3) ? (size_t)gridDim.x * FG_BM * 8 : (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
@@ -262,6 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         float4 uq;     // EPI 4: this thread's quad of the tile's u rows
         int tp;        //        and the tile's parity
         float4 dq0, dq1; // SRC 4: geo of the two rows (dxyz used when the slab goes to LDS)
+        float mu0, mu1;  // SRC 5: weights of the two rows' half-groups
     };
     constexpr int NSETS = BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
     Regs R[NSETS];
@@ -279,9 +289,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             r.a0 = *reinterpret_cast<const float4 *>(pa0);
             r.a1 = *reinterpret_cast<const float4 *>(pa1);
         }
-        if (SRC == 1) {
+        if (SRC == 1 || SRC == 5) {
             r.g0 = *reinterpret_cast<const float4 *>(pa0 + da_off);
             r.g1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
+            if (SRC == 5) {
+                r.mu0 = pw[0];
+                r.mu1 = pw[2];
+            }
         } else if (SRC == 3) {
             r.g0 = *reinterpret_cast<const float4 *>(pa0 + 4);
             r.g1 = *reinterpret_cast<const float4 *>(pa1 + 4);
@@ -327,6 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 pu += wrap ? (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4) : 0;
                 ltp ^= wrap ? 1 : 0;
             }
+            if (SRC == 5) pw += wrap ? (size_t)gridDim.x * (FG_BM / 32) : 0;
             if (SRC == 2) {
                 const long dg = wrap ? (long)gridDim.x * FG_BM / pk : 0;
                 g0 += dg;
@@ -351,6 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     pu += (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4);
                     ltp ^= 1;
                 }
+                if (SRC == 5) pw += (size_t)gridDim.x * (FG_BM / 32);
 #pragma unroll
                 for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
                 if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
@@ -363,7 +379,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         --steps_to_load;
     };
     const float relu_floor = (affine && A.in_relu) ? 0.0f : -__builtin_inff(); // BF3: the folded ReLU as a select against a uniform floor
-    auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk) {
+    auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk, float mu = 1.0f) {
         if (SRC == 4) { // v = the P quad of the row, g = its geo: z0 of the four channels rk..rk+3
             const float4 w0 = *reinterpret_cast<const float4 *>(&Wxs[0][rk]), w1 = *reinterpret_cast<const float4 *>(&Wxs[1][rk]);
             const float4 w2 = *reinterpret_cast<const float4 *>(&Wxs[2][rk]);
@@ -446,13 +462,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             for (int q = 0; q < 4; q++)
                 if (!(zz[q] * cSa[q] + cHa[q] > 0.0f)) gg[q] = 0.0f;
         }
+        if (SRC == 5) { // total gradient of a row that stands for mu true rows: the upstream part is a total already, the affine part is per row
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[q] = cAa[q] * gg[q] + mu * (cBa[q] + cCa[q] * zz[q]);
+            return make_float4(o[0], o[1], o[2], o[3]);
+        }
 #pragma unroll
         for (int q = 0; q < 4; q++) o[q] = cAa[q] * gg[q] + cBa[q] + cCa[q] * zz[q];
         return make_float4(o[0], o[1], o[2], o[3]);
     };
     auto store_regs = [&](int buf, const Regs &r) {
         if (BF3 && (BF3_ABL & 8) && !abl_prologue) return;
-        const float4 v0 = act4(r.a0, SRC == 4 ? r.dq0 : r.g0, r.m0, r.ro0, r.k), v1 = act4(r.a1, SRC == 4 ? r.dq1 : r.g1, r.m1, r.ro1, r.k);
+        const float4 v0 = act4(r.a0, SRC == 4 ? r.dq0 : r.g0, r.m0, r.ro0, r.k, (SRC == 5 && sel31) ? r.mu0 : 1.0f),
+                     v1 = act4(r.a1, SRC == 4 ? r.dq1 : r.g1, r.m1, r.ro1, r.k, (SRC == 5 && sel31) ? r.mu1 : 1.0f);
         if constexpr (BF3) {
             unsigned h[4], m[4], l[4];
             split3(v0.x, v0.y, h[0], m[0], l[0]);
@@ -642,13 +664,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         // per tile (a few s_mul), instead of being hoisted out of the tile loop as 64 loop-invariant SGPRs that spill
         unsigned pitch = (unsigned)cout * 4u;
         asm volatile("" : "+s"(pitch));
-        float pmaxv[NT], pminv[NT];
-        int pmaxi[NT], pmini[NT];
+        float pmaxv[MT][NT], pminv[MT][NT];
+        int pmaxi[MT][NT], pmini[MT][NT];
 #pragma unroll
-        for (int j = 0; j < NT; j++) {
-            pmaxv[j] = pminv[j] = 0.0f;
-            pmaxi[j] = pmini[j] = 0;
-        }
+        for (int i = 0; i < MT; i++)
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                pmaxv[i][j] = pminv[i][j] = 0.0f;
+                pmaxi[i][j] = pmini[i][j] = 0;
+            }
         if (BF3 && (BF3_ABL & 2)) {
             float t_ = 0.0f;
 #pragma unroll
@@ -690,18 +714,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     for (int e = 0; e < 16; e++) {
                         const float v = acc[i][j][e] + bv;
                         if (EPI == 2) {
-                            const int rloc = i * 32 + 4 * kh + (e & 3) + 8 * (e >> 2); // ascending in (i, e): strict compares
-                            if ((i == 0 && e == 0) || v > pmaxv[j]) {                  // keep the first occurrence
-                                pmaxv[j] = v;
-                                pmaxi[j] = rloc;
+                            const int rloc = 4 * kh + (e & 3) + 8 * (e >> 2); // inside the 32-row block; ascending in e: strict compares
+                            if (e == 0 || v > pmaxv[i][j]) {                  // keep the first occurrence
+                                pmaxv[i][j] = v;
+                                pmaxi[i][j] = rloc;
                             }
-                            if ((i == 0 && e == 0) || v < pminv[j]) {
-                                pminv[j] = v;
-                                pmini[j] = rloc;
+                            if (e == 0 || v < pminv[i][j]) {
+                                pminv[i][j] = v;
+                                pmini[i][j] = rloc;
                             }
                         }
                         s1[j] += v;
                         s2[j] += v * v;
+                    }
+                }
+            }
+            if (A.wh != nullptr) {
+                // half-group layout: row 31 of every 32-row block (accumulator element 15 of the upper half-wave) stands for wh rows
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const int hg = __builtin_amdgcn_readfirstlane((int)(m0 >> 5) + (wm * MT + i));
+                    const float wm1 = (kh == 1) ? A.wh[hg] - 1.0f : 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        const float v = acc[i][j][15] + bvs[j];
+                        s1[j] += wm1 * v;
+                        s2[j] += wm1 * (v * v);
                     }
                 }
             }
@@ -844,26 +882,62 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 }
         }
         if (EPI == 2) {
-            // the other half-wave holds the interleaved rows of the same group: combine, smaller row wins ties
-            const long grp = m0 / 64 + wm;
+            // the other half-wave holds the interleaved rows of the same 32-row block: combine, smaller row wins ties
 #pragma unroll
-            for (int j = 0; j < NT; j++) {
-                const float ov = __shfl_xor(pmaxv[j], 32), uv = __shfl_xor(pminv[j], 32);
-                const int oi = __shfl_xor(pmaxi[j], 32), ui = __shfl_xor(pmini[j], 32);
-                if (ov > pmaxv[j] || (ov == pmaxv[j] && oi < pmaxi[j])) {
-                    pmaxv[j] = ov;
-                    pmaxi[j] = oi;
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    const float ov = __shfl_xor(pmaxv[i][j], 32), uv = __shfl_xor(pminv[i][j], 32);
+                    const int oi = __shfl_xor(pmaxi[i][j], 32), ui = __shfl_xor(pmini[i][j], 32);
+                    if (ov > pmaxv[i][j] || (ov == pmaxv[i][j] && oi < pmaxi[i][j])) {
+                        pmaxv[i][j] = ov;
+                        pmaxi[i][j] = oi;
+                    }
+                    if (uv < pminv[i][j] || (uv == pminv[i][j] && ui < pmini[i][j])) {
+                        pminv[i][j] = uv;
+                        pmini[i][j] = ui;
+                    }
                 }
-                if (uv < pminv[j] || (uv == pminv[j] && ui < pmini[j])) {
-                    pminv[j] = uv;
-                    pmini[j] = ui;
+            if (A.pool32) {
+                // half-group layout: every 32-row block is a group of its own (votenet_bn_pool_finalize_half joins a centre's halves)
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+                    const long hg = (m0 >> 5) + (wm * MT + i);
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                        if (lane < 32) {
+                            const size_t o = (size_t)hg * cout + n0 + (wn * NT + j) * 32 + l31;
+                            A.zmax[o] = pmaxv[i][j];
+                            A.zmin[o] = pminv[i][j];
+                            A.amax[o] = pmaxi[i][j];
+                            A.amin[o] = pmini[i][j];
+                        }
                 }
-                if (lane < 32) {
-                    const size_t o = (size_t)grp * cout + n0 + (wn * NT + j) * 32 + l31;
-                    A.zmax[o] = pmaxv[j];
-                    A.zmin[o] = pminv[j];
-                    A.amax[o] = pmaxi[j];
-                    A.amin[o] = pmini[j];
+            } else {
+                // a wave's MT = 2 blocks are one 64-row group: the later block replaces the earlier one only when strictly better
+                const long grp = m0 / 64 + wm;
+#pragma unroll
+                for (int j = 0; j < NT; j++) {
+                    float vmax = pmaxv[0][j], vmin = pminv[0][j];
+                    int imax = pmaxi[0][j], imin = pmini[0][j];
+#pragma unroll
+                    for (int i = 1; i < MT; i++) {
+                        if (pmaxv[i][j] > vmax) {
+                            vmax = pmaxv[i][j];
+                            imax = i * 32 + pmaxi[i][j];
+                        }
+                        if (pminv[i][j] < vmin) {
+                            vmin = pminv[i][j];
+                            imin = i * 32 + pmini[i][j];
+                        }
+                    }
+                    if (lane < 32) {
+                        const size_t o = (size_t)grp * cout + n0 + (wn * NT + j) * 32 + l31;
+                        A.zmax[o] = vmax;
+                        A.zmin[o] = vmin;
+                        A.amax[o] = imax;
+                        A.amin[o] = imin;
+                    }
                 }
             }
         }
@@ -955,7 +1029,7 @@ template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
 // below (EPI 3), 4 the same over an assembled layer (EPI 6), 5 over a narrow layer (EPI 4)
 template <int SRC, int EPI> constexpr int bf3_family()
 {
-    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : EPI == 4 ? 5 : (SRC == 1 || SRC == 2) ? 2 : 1;
+    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : EPI == 4 ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
 }
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
@@ -978,7 +1052,7 @@ static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
     if (SRC == 4 && ((uintptr_t)a.geo % 16 != 0 || (uintptr_t)a.wx % 16 != 0)) return false;
     if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
     const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
-                         (SRC != 1 || (uintptr_t)a.da % 16 == 0) &&
+                         ((SRC != 1 && SRC != 5) || (uintptr_t)a.da % 16 == 0) && (SRC != 5 || a.wh != nullptr) &&
                          (SRC != 2 || ((uintptr_t)a.gout % 16 == 0 && (uintptr_t)a.argmax % 16 == 0));
     if (!aligned || a.cin % (2 * FG_BK) != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
     const long ntiles = a.rows / FG_BM;
@@ -1039,9 +1113,11 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
 // forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
-                            float *zmin, int *amax, int *amin, hipStream_t st)
+                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh)
 {
     FastArgs a = {};
+    a.wh = wh;                       // half-group layout (half.hip): weighted statistics ...
+    a.pool32 = wh != nullptr ? 1 : 0; // ... and raw max / min per 32-row half-group
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
@@ -1283,6 +1359,37 @@ extern "C" int votenet_assembled_linear(long rows, int c0, int cout, const float
     return check_launch("assembled_linear");
 }
 
+// votenet_assembled_linear on the half-group layout (half.hip): rows = 32 x half-groups, wh = the weight of every half-group's row 31 in
+// the BatchNorm statistics (the row also stands for a dropped all-copy second half when wh = 33).
+extern "C" int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
+                                             const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                             const float *w, const float *bias, float *z, double *stats, const float *wh, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c0 > 0 && cout > 0, "assembled_linear_half expects rows > 0, c0 > 0, cout > 0");
+    VN_REQUIRE(geo && P && wx && w && z && wh, "assembled_linear_half: null buffer");
+    VN_REQUIRE(in_bn != nullptr || (in_scale != nullptr && in_shift != nullptr), "assembled_linear_half: the first layer's BatchNorm is missing");
+    FastArgs a = {};
+    a.geo = geo;
+    a.ptab = P;
+    a.wx = wx;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_raw = to_raw(in_bn);
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = c0;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.stats = stats;
+    a.wh = wh;
+    hipStream_t st = as_stream(stream);
+    const bool ok = stats ? fast_dispatch<4, 0>(a, st) : fast_dispatch<4, 1>(a, st);
+    if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_linear_half: shape not served (as votenet_assembled_linear)");
+    return check_launch("assembled_linear_half");
+}
+
 // votenet_mlp_dgrad_bn_reduce for an ASSEMBLED layer below (assemble.hip): z_prev is not read but rebuilt from geo, the per-point
 // table P (points x cout, bias included; points * cout * 4 < 2^32) and wx (3 x cout).  da_prev is stored.
 extern "C" int votenet_assembled_dgrad_bn_reduce(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
@@ -1320,4 +1427,44 @@ extern "C" int votenet_assembled_dgrad_bn_reduce(long rows, int c, int cout, con
     if (!fast_dispatch<1, 6>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_dgrad_bn_reduce: shape not served (as votenet_mlp_dgrad_bn_reduce)");
     return check_launch("assembled_dgrad_bn_reduce");
+}
+
+// The same on the half-group layout (half.hip): da / da_prev are TOTAL gradients per compact row; the affine part B + C z of the rebuilt
+// dz is scaled by wh on the rows that stand for a dropped second half (SRC 5); the epilogue's sums over totals need no weight.
+extern "C" int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                                      const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
+                                                      const float *scale_prev, const float *shift_prev, const float *mean_prev,
+                                                      const float *var_prev, float eps, int relu_prev, double *sums,
+                                                      const votenet_coef_tail *tail, const float *wh, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "assembled_dgrad_bn_reduce_half expects rows > 0, c > 0, cout > 0");
+    VN_REQUIRE(da && zsrc && coef && wT && da_prev && geo && P && wx && wh, "assembled_dgrad_bn_reduce_half: null buffer");
+    VN_REQUIRE(scale_prev && shift_prev && mean_prev && var_prev && sums, "assembled_dgrad_bn_reduce_half: null buffer of the layer below");
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "assembled_dgrad_bn_reduce_half: incomplete coefficient tail");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "assembled_dgrad_bn_reduce_half: geo must be 16-byte aligned");
+    FastArgs a = {};
+    a.da = da;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = cout;
+    a.w = wT;
+    a.z = da_prev;
+    a.geo = geo;
+    a.ptab = P;
+    a.wx = wx;
+    a.e_scale = scale_prev;
+    a.e_shift = shift_prev;
+    a.e_mean = mean_prev;
+    a.e_var = var_prev;
+    a.e_eps = eps;
+    a.e_relu = relu_prev;
+    a.stats = sums;
+    a.tail = to_tail(tail);
+    a.wh = wh;
+    if (!fast_dispatch<5, 6>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_dgrad_bn_reduce_half: shape not served (as votenet_mlp_dgrad_bn_reduce)");
+    return check_launch("assembled_dgrad_bn_reduce_half");
 }

@@ -52,6 +52,7 @@ struct BnSrc {
     // wgrad_reduce_kernel then adds the blockIdx.x slices to dw in ascending order (one summation order -> bit-reproducible)
     float *part;
     long pstride;
+    const float *wh; // BSRC 4 (half-group layout, half.hip): da holds totals; the affine part B + C z of row 32 h + 31 counts wh[h] times
 };
 
 // z0[r,c] of a first SA layer assembled where it is consumed (assemble.hip): p = P[prow(r), c], g = geo[r] = (dx, dy, dz, bits(prow)),

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float x_floor = (affine && in.in_relu) ? 0.0f : -__builtin_inff(); // ReLU as a floor: branch-free
     float4 kA, kB, kC, kS, kH;
     kA = kB = kC = kS = kH = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (BSRC == 1 || BSRC == 2) {
+    if (BSRC == 1 || BSRC == 2 || BSRC == 4) {
         kA = *reinterpret_cast<const float4 *>(bs.coef + nb);
         kB = *reinterpret_cast<const float4 *>(bs.coef + cout + nb);
         kC = *reinterpret_cast<const float4 *>(bs.coef + 2 * cout + nb);
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
     const float *xb = (MODE == 0) ? in.x + (size_t)r_begin * cin + ka : (MODE == 2) ? in.u8 + (size_t)r_begin * 8 : (MODE == 3) ? in.ptab + ka : in.feat + ka;
     const float4 *geob = (MODE == 3) ? reinterpret_cast<const float4 *>(in.geo) + r_begin : nullptr;
     const float *zb = (BSRC == 0 ? dz : bs.z) + (size_t)r_begin * cout + nb;
-    const float *gb = (BSRC == 1) ? bs.da + (size_t)r_begin * cout + nb : nullptr;
+    const float *gb = (BSRC == 1 || BSRC == 4) ? bs.da + (size_t)r_begin * cout + nb : nullptr;
     const int *idxb = (MODE == 1) ? in.idx + r_begin : nullptr;
     const unsigned grows = (MODE == 1) ? (unsigned)in.m * (unsigned)in.nsample : 1u; // rows per scene
 
@@ -129,6 +129,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
         float4 a[NA], b[NB], g[NB];
         float4 a2[(MODE == 2 || MODE == 3) ? NA : 1]; // MODE 2: the second half of the rows' u; MODE 3: the rows' geo
         int4 m[NB];
+        float mu[NB]; // BSRC 4: the row's weight
         int s; // slab index (local)
     };
     Regs R[2];
@@ -171,7 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             const int lr = clampr(s * WF_BR + b_row + h * RB);
             const unsigned off = (unsigned)lr * (unsigned)cout;
             r.b[h] = *reinterpret_cast<const float4 *>(zb + (size_t)off);
-            if (BSRC == 1) r.g[h] = *reinterpret_cast<const float4 *>(gb + (size_t)off);
+            if (BSRC == 1 || BSRC == 4) r.g[h] = *reinterpret_cast<const float4 *>(gb + (size_t)off);
+            if (BSRC == 4) {
+                const unsigned gr = (unsigned)(r_begin + lr);
+                r.mu[h] = (gr & 31u) == 31u ? bs.wh[gr >> 5] : 1.0f;
+            }
             if (BSRC == 2) {
                 const unsigned gr = (unsigned)(r_begin + lr);
                 const unsigned grp = bs.pool_shift >= 0 ? gr >> bs.pool_shift : gr / (unsigned)bs.pool_k;
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                 v.z = fmaxf(v.z * kS.z + kH.z, b_floor);
                 v.w = fmaxf(v.w * kS.w + kH.w, b_floor);
             }
-            if (BSRC == 1 || BSRC == 2) {
+            if (BSRC == 1 || BSRC == 2 || BSRC == 4) {
                 float4 g = r.g[h];
                 if (BSRC == 2) {
                     const unsigned gr = (unsigned)(r_begin + lr);
@@ -241,10 +246,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                     if (!(v.z * kS.z + kH.z > 0.0f)) g.z = 0.0f;
                     if (!(v.w * kS.w + kH.w > 0.0f)) g.w = 0.0f;
                 }
-                v.x = kA.x * g.x + kB.x + kC.x * v.x;
-                v.y = kA.y * g.y + kB.y + kC.y * v.y;
-                v.z = kA.z * g.z + kB.z + kC.z * v.z;
-                v.w = kA.w * g.w + kB.w + kC.w * v.w;
+                if (BSRC == 4) {
+                    const float mu = r.mu[h];
+                    v.x = kA.x * g.x + mu * (kB.x + kC.x * v.x);
+                    v.y = kA.y * g.y + mu * (kB.y + kC.y * v.y);
+                    v.z = kA.z * g.z + mu * (kB.z + kC.z * v.z);
+                    v.w = kA.w * g.w + mu * (kB.w + kC.w * v.w);
+                } else {
+                    v.x = kA.x * g.x + kB.x + kC.x * v.x;
+                    v.y = kA.y * g.y + kB.y + kC.y * v.y;
+                    v.z = kA.z * g.z + kB.z + kC.z * v.z;
+                    v.w = kA.w * g.w + kB.w + kC.w * v.w;
+                }
             }
             if (lr >= nrow) v = make_float4(0.f, 0.f, 0.f, 0.f); // padding rows contribute nothing
             if constexpr (BF3) {
@@ -458,7 +471,7 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
 {
     if (cin % 64 != 0 || cout % 64 != 0 || rows <= 0 || rows >= (1L << 31)) return false;
     auto al = [](const void *p) { return ((uintptr_t)p % 16) == 0; };
-    if (!al(dw) || (bsrc == 0 && !al(dz)) || (bsrc != 0 && (!al(bs.z) || !al(bs.coef))) || (bsrc == 1 && !al(bs.da)) ||
+    if (!al(dw) || (bsrc == 0 && !al(dz)) || (bsrc != 0 && (!al(bs.z) || !al(bs.coef))) || ((bsrc == 1 || bsrc == 4) && !al(bs.da)) ||
         (bsrc == 2 && (!al(bs.gout) || !al(bs.argmax))))
         return false;
     if (mode == 0) {
@@ -469,8 +482,9 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         return launch<0, 2>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (mode == 3) { // ASSEMBLED first layer below: x rebuilt from geo + P (votenet_assembled_wgrad_bn)
-        if (!al(d.geo) || !al(d.ptab) || !al(d.wx) || bsrc != 1) return false;
+        if (!al(d.geo) || !al(d.ptab) || !al(d.wx) || (bsrc != 1 && bsrc != 4)) return false;
         if (d.in_scale && (!al(d.in_scale) || !al(d.in_shift))) return false;
+        if (bsrc == 4) return bs.wh != nullptr && rows % 32 == 0 && launch<3, 4>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         return launch<3, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (mode == 2) { // NARROW first layer below: x rebuilt from u8 (votenet_narrow_wgrad_bn)

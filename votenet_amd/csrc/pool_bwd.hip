@@ -128,6 +128,11 @@ struct PoolBelow {
     double *sums;
     CoefTail tail; // that layer's coefficient vector from the completed sums, by the last workgroup (common.h)
     int reverse;   // walk the groups back to front (votenet_debug_scatter_reverse)
+    // half-group layout (half.hip; K = 32): a "group" is a half-group h of 32 compact rows; gout / argmax / zsel are per CENTRE hc[h],
+    // a channel belongs to this half when its arg-max slot lies in [32 [h >= G], + 32); the dense part of row 31 is scaled by wh[h]
+    const int *hc;
+    const float *wh;
+    int G;
 };
 
 template <int CIN, int COUT, int K, bool RED, int NWV = 8 /* wavefronts: 16 when W^T leaves room for one workgroup per CU only */>
@@ -136,7 +141,8 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
                                                                  const float *__restrict__ coef, int relu, const float *__restrict__ wT,
                                                                  float *__restrict__ da, PoolBelow pb)
 {
-    static_assert(K == 64, "one lane per row in the prefix scan");
+    static_assert(K == 64 || K == 32, "one lane per row in the prefix scan");
+    constexpr bool HALF = K == 32;
     constexpr int PL = CIN / 64; // floats per lane of a row
     constexpr int RW = K / NWV;  // rows per wavefront
     extern __shared__ __attribute__((aligned(16))) float pds_smem[];
@@ -168,13 +174,19 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
             bI[q] = 1.0f / sqrtf(pb.var[j] + pb.eps);
         }
     }
-    float n_z = 0.f, n_g = 0.f;
+    float n_z = 0.f, n_g = 0.f, n_w = 1.0f;
     int n_a = 0;
     auto fetch = [&](long g) {
+        const long ctr = HALF ? (long)pb.hc[g] : g;
+        if (HALF) n_w = pb.wh[g];
         if (own) {
-            n_z = zsel[(size_t)g * COUT + tid];
-            n_g = gout[(size_t)g * COUT + tid];
-            n_a = argmax[(size_t)g * COUT + tid];
+            n_z = zsel[(size_t)ctr * COUT + tid];
+            n_g = gout[(size_t)ctr * COUT + tid];
+            n_a = argmax[(size_t)ctr * COUT + tid];
+            if (HALF) {
+                n_a -= g >= pb.G ? 32 : 0;
+                if (n_a < 0 || n_a >= 32) n_a = -1; // the centre's other half holds this channel's arg-max
+            }
         }
     };
     // pb.reverse: walk the groups from the last to the first.  The kernel before this one streamed da (and z) front to back, so the
@@ -187,9 +199,10 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
         const long g = grp(gi);
         float *svp = sv + par * COUT;
         int *lstp = lst + par * COUT, *cntp = cnt + par * K, *startp = start + par * K;
-        const float zz = n_z;
+        const float zz = n_z, w31 = n_w;
         float gg = n_g;
         const int myrow = n_a;
+        const bool mine = own && (!HALF || myrow >= 0);
         // this wavefront's da rows travel while the channels are bucketed
         float pre[RW][PL], zpre[RW][PL];
 #pragma unroll
@@ -211,32 +224,33 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
         // ascending order and the floating-point sum below has ONE order: da is reproducible bit for bit
 #pragma unroll
         for (int w2 = 0; w2 < COUT / 64; w2++) {
-            if (wv == w2) mypos = atomicAdd(&cntp[myrow], 1);
+            if (wv == w2 && (!HALF || myrow >= 0)) mypos = atomicAdd(&cntp[myrow], 1);
             __syncthreads();
         }
         if (wv == 0) { // exclusive prefix of the K counters: one lane per row
-            const int c0 = cntp[lane];
+            const int c0 = lane < K ? cntp[lane] : 0;
             int x = c0;
 #pragma unroll
             for (int off = 1; off < 64; off <<= 1) {
                 const int t = __shfl_up(x, off);
                 if (lane >= off) x += t;
             }
-            startp[lane] = x - c0;
+            if (lane < K) startp[lane] = x - c0;
         } else if (wv == 1) {
-            cnt[(par ^ 1) * K + lane] = 0; // the other parity's counters: last read before this group's first barrier
+            if (lane < K) cnt[(par ^ 1) * K + lane] = 0; // the other parity's counters: last read before this group's first barrier
         }
         __syncthreads();
-        if (own) lstp[startp[myrow] + mypos] = tid;
+        if (mine) lstp[startp[myrow] + mypos] = tid;
         __syncthreads();
 #pragma unroll
         for (int ri = 0; ri < RW; ri++) {
             const int r = wv + NWV * ri;
             const int n = cntp[r], s0 = startp[r];
-            if (!RED && n == 0) continue;
+            const bool scaled = HALF && r == 31 && w31 != 1.0f;
+            if (!RED && n == 0 && !scaled) continue;
             float acc[PL];
 #pragma unroll
-            for (int q = 0; q < PL; q++) acc[q] = pre[ri][q];
+            for (int q = 0; q < PL; q++) acc[q] = scaled ? pre[ri][q] * w31 : pre[ri][q];
             for (int i = 0; i < n; i += 4) {
                 int c[4];
                 float v[4];
@@ -251,7 +265,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
 #pragma unroll
                     for (int q = 0; q < PL; q++) acc[q] += v[u] * Wl[c[u] * CIN + lane * PL + q];
             }
-            if (n != 0) {
+            if (n != 0 || scaled) {
                 float *drow = da + ((size_t)g * K + r) * CIN + lane * PL;
 #pragma unroll
                 for (int q = 0; q < PL; q++) drow[q] = acc[q];
@@ -288,14 +302,18 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
 
 // dW[:, c] += sum_g x[g*k + argmax[g,c], :] * A[c] g'[g,c]   and   colsum[j] += sum_r x[r, j]
 // x = act(xz * in_scale + in_shift) staged per group in LDS; thread c owns output column c (CIN accumulators).
+// K = 32: the half-group layout (half.hip) -- a "group" is a half-group h of 32 compact rows of xz, gout / argmax / zsel are per centre
+// hc[h] and a channel counts here when its arg-max slot lies in this half; the column sums weigh row 31 by wh[h].
 template <int CIN, int K>
 __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int cout, const float *__restrict__ xz,
                                                                 const float *__restrict__ in_scale, const float *__restrict__ in_shift,
                                                                 int in_relu, const float *__restrict__ gout,
                                                                 const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                 const float *__restrict__ coef, int relu, float *__restrict__ dw,
-                                                                float *__restrict__ colsum, float *__restrict__ part)
+                                                                float *__restrict__ colsum, float *__restrict__ part,
+                                                                const int *__restrict__ hc, const float *__restrict__ wh, int G)
 {
+    constexpr bool HALF = K == 32;
     constexpr int LD = CIN + 4;
     __shared__ __attribute__((aligned(16))) float xs[K][LD];
     const int tid = threadIdx.x;
@@ -335,10 +353,19 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
         fetch(gn < groups ? gn : g); // the next tile travels while this one is used
         float gg = 0.0f, zz = 0.0f;
         int ar = 0;
+        const long ctr = HALF ? (long)hc[g] : g;
+        const float w31 = HALF ? wh[g] : 1.0f;
         if (own) {
-            zz = zsel[(size_t)g * cout + tid];
-            gg = gout[(size_t)g * cout + tid];
-            ar = argmax[(size_t)g * cout + tid];
+            zz = zsel[(size_t)ctr * cout + tid];
+            gg = gout[(size_t)ctr * cout + tid];
+            ar = argmax[(size_t)ctr * cout + tid];
+            if (HALF) {
+                ar -= g >= G ? 32 : 0;
+                if (ar < 0 || ar >= 32) { // the centre's other half holds this channel's arg-max
+                    ar = 0;
+                    gg = 0.0f;
+                }
+            }
         }
         __syncthreads();
         if (own) {
@@ -359,7 +386,8 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
         if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
             const int jc = tid - (256 - CIN);
 #pragma unroll 8
-            for (int r = 0; r < K; r++) csum += xs[r][jc];
+            for (int r = 0; r < (HALF ? K - 1 : K); r++) csum += xs[r][jc];
+            if (HALF) csum += w31 * xs[K - 1][jc];
         }
         __syncthreads();
     }
@@ -460,6 +488,11 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
 
 static int g_scatter_reverse = 0;
 extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
+static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
+                                     const float *coef, int relu, const float *wT, float *da, const float *below_z,
+                                     const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
+                                     float eps, int below_relu, double *below_sums, const votenet_coef_tail *below_tail, const int *hc,
+                                     const float *wh, int G, void *stream);
 extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
                                           const float *zsel, const float *coef, int relu, const float *wT, float *da,
                                           const float *below_z, const float *below_scale, const float *below_shift,
@@ -473,10 +506,32 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
     VN_REQUIRE((uintptr_t)wT % 16 == 0, "pool_dgrad_scatter: wT must be 16-byte aligned");
     VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
                "pool_dgrad_scatter: below_z given without the layer's BatchNorm vectors / sums");
+    return pool_dgrad_scatter_launch(groups, k, cin, cout, gout, argmax, zsel, coef, relu, wT, da, below_z, below_scale, below_shift, below_mean,
+                                     below_var, eps, below_relu, below_sums, below_tail, nullptr, nullptr, 0, stream);
+}
+
+// The same pass on the half-group layout (half.hip): da and below_z have 32 * nh compact rows; gout / argmax / zsel stay per centre.
+extern "C" int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
+                                               const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
+                                               const float *below_z, const float *below_scale, const float *below_shift,
+                                               const float *below_mean, const float *below_var, float eps, int below_relu,
+                                               double *below_sums, const votenet_coef_tail *below_tail, void *stream)
+{
+    VN_REQUIRE(hc && wh && G > 0 && nh >= G && nh <= 2L * G, "pool_dgrad_scatter_half: bad half-group arguments");
+    return pool_dgrad_scatter_launch(nh, 64, cin, cout, gout, argmax, zsel, coef, relu, wT, da, below_z, below_scale, below_shift, below_mean,
+                                     below_var, eps, below_relu, below_sums, below_tail, hc, wh, G, stream);
+}
+
+static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
+                                     const float *coef, int relu, const float *wT, float *da, const float *below_z,
+                                     const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
+                                     float eps, int below_relu, double *below_sums, const votenet_coef_tail *below_tail, const int *hc,
+                                     const float *wh, int G, void *stream)
+{
     hipStream_t st = as_stream(stream);
-    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse};
+    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse, hc, wh, G};
     auto go = [&](auto kern, int ci, int co, int threads = 512) {
-        const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
+        const size_t smem = ((size_t)co * ci + 4 * co + 4 * (hc ? 32 : k)) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         static std::set<const void *> raised; // the attribute is per kernel: set once
         static std::mutex raised_mu;          // entry points may be called from several host threads
@@ -490,7 +545,13 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
         hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(threads), smem, st, groups, gout, argmax, zsel, coef, relu,
                            wT, da, pb);
     };
-    if (below_z) {
+    if (hc) {
+        VN_REQUIRE(cin == 128 && (cout == 256 || cout == 128), "pool_dgrad_scatter_half: served shapes are 128 -> 256 and 128 -> 128");
+        if (cout == 256 && below_z) go(pool_dgrad_scatter_kernel<128, 256, 32, true, 16>, 128, 256, 1024);
+        else if (cout == 256) go(pool_dgrad_scatter_kernel<128, 256, 32, false, 16>, 128, 256, 1024);
+        else if (below_z) go(pool_dgrad_scatter_kernel<128, 128, 32, true>, 128, 128);
+        else go(pool_dgrad_scatter_kernel<128, 128, 32, false>, 128, 128);
+    } else if (below_z) {
         if (cin == 128 && cout == 256)
             go(pool_dgrad_scatter_kernel<128, 256, 64, true, 16>, 128, 256, 1024);
         else if (cin == 128)
@@ -519,7 +580,8 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
 // the fp32 kernel with its ordered reduction).
 template <int C>
 __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
-                                                       int relu, float *__restrict__ gram, long rows_per_block)
+                                                       int relu, float *__restrict__ gram, long rows_per_block,
+                                                       const float *__restrict__ wh /* half-group layout: row 32 h + 31 counts wh[h] times */)
 {
     constexpr int KPT = C / 16;          // rows of a slab per thread (8 or 4)
     constexpr int T = C / 64;            // 32 x 32 sub-tiles per wave and direction (waves 2 x 2)
@@ -538,21 +600,28 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     const float floor_ = relu ? 0.0f : -__builtin_inff();
     const float *xb = x + (size_t)r_begin * C + c;
     float R[2][KPT];
-    auto load = [&](float (&r)[KPT], int s) {
+    // a thread's last row of an odd slab is row 31 of a half-group exactly when its row group is the slab's last one (r_begin % 32 == 0)
+    const bool last_rg = rg * KPT + KPT == 16;
+    const float *whb = wh ? wh + (r_begin >> 5) : nullptr;
+    float Wq[2] = {1.0f, 1.0f}; // sqrt of that row's weight, travelling with the register set
+    auto load = [&](float (&r)[KPT], int s, float &wq) {
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
             int lr = s * 16 + rg * KPT + i;
             lr = lr < nrow ? lr : nrow - 1; // past the end: a valid row, stored as zero below
             r[i] = xb[(size_t)lr * C];
         }
+        if (whb && last_rg && (s & 1)) wq = s * 16 + 15 < nrow ? sqrtf(whb[s >> 1]) : 1.0f;
+        else wq = 1.0f;
     };
-    auto store = [&](int buf, const float (&r)[KPT], int s) {
+    auto store = [&](int buf, const float (&r)[KPT], int s, float wq) {
         float v[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
             v[i] = fmaxf(r[i] * sc + sh, floor_);
             if (s * 16 + rg * KPT + i >= nrow) v[i] = 0.0f; // padding rows contribute nothing
         }
+        v[KPT - 1] *= wq; // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
         unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
 #pragma unroll
         for (int i = 0; i < KPT / 2; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
@@ -574,11 +643,11 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 #pragma unroll
             for (int e = 0; e < 16; e++) acc[a][b][e] = 0.0f;
     // prologue: slab 0 -> buffer 0; slabs 1 and 2 in flight
-    load(R[0], 0);
-    store(0, R[0], 0);
-    load(R[1], 1);
+    load(R[0], 0, Wq[0]);
+    store(0, R[0], 0, Wq[0]);
+    load(R[1], 1, Wq[1]);
     __builtin_amdgcn_sched_barrier(0);
-    load(R[0], 2);
+    load(R[0], 2, Wq[0]);
     __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
     int buf = 0;
@@ -606,8 +675,8 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             mm(2, 0);
             mm(0, 2);
             mm(1, 1);
-            store(buf ^ 1, R[par ^ 1], s + par + 1); // the other buffer was last read one slab ago, behind a barrier
-            load(R[par ^ 1], s + par + 3);
+            store(buf ^ 1, R[par ^ 1], s + par + 1, Wq[par ^ 1]); // the other buffer was last read one slab ago, behind a barrier
+            load(R[par ^ 1], s + par + 3, Wq[par ^ 1]);
             mm(1, 0);
             mm(0, 1);
             mm(0, 0);
@@ -631,14 +700,14 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 
 int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always
 template <int C>
-static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st)
+static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st, const float *wh = nullptr)
 {
     // 384 workgroups as the fp32 weight-gradient kernels (mlp_wgrad_fast.hip, plan_fast): the launch runs beside the input-gradient chain
     long rpb = (rows + 383) / 384;
     rpb = (rpb + 31) / 32 * 32;
     if (rpb < 128) rpb = 128;
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb);
+    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh);
 }
 extern "C" void votenet_debug_gram_bf3(int on) { g_gram_bf3 = on; }
 
@@ -666,6 +735,9 @@ extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *s
     return check_launch("mlp_gram");
 }
 
+static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
+                                    const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
+                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream);
 extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
                                          const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
                                          const float *coef, int relu, float *dw, float *colsum, float *scratch, void *stream)
@@ -676,14 +748,50 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse: in_scale and in_shift go together");
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse: operands must be 16-byte aligned");
-    const int grid = pb_grid(groups, 8, 384); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
+    return pool_wgrad_sparse_launch(groups, cin, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch,
+                                    nullptr, nullptr, 0, stream);
+}
+
+// The same on the half-group layout (half.hip): xz has 32 * nh compact rows, gout / argmax / zsel stay per centre.
+// votenet_mlp_gram over the half-group layout (half.hip): G += a^T diag(w) a with w = wh[h] on row 32 h + 31, 1 elsewhere.
+extern "C" int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram,
+                                     void *stream)
+{
+    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) / c && c == 128, "mlp_gram_half expects rows %% 32 == 0 and c == 128");
+    VN_REQUIRE(z && scale_shift && wh && gram && (uintptr_t)z % 16 == 0, "mlp_gram_half: null / unaligned buffer");
+    gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
+    return check_launch("mlp_gram_half");
+}
+
+extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
+                                              int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
+                                              float *dw, float *colsum, const int *hc, const float *wh, void *stream)
+{
+    VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= 2L * G && hc && wh, "pool_wgrad_sparse_half: bad half-group arguments");
+    VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half: bad arguments");
+    VN_REQUIRE(cin == 128 && (cout == 256 || cout == 128), "pool_wgrad_sparse_half: served shapes are 128 -> 256 and 128 -> 128");
+    VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse_half: in_scale and in_shift go together");
+    VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
+               "pool_wgrad_sparse_half: operands must be 16-byte aligned");
+    return pool_wgrad_sparse_launch(nh, cin, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw, colsum, nullptr, hc, wh,
+                                    G, stream);
+}
+
+static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
+                                    const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
+                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream)
+{
+    const int grid = pb_grid(groups, hc ? 16 : 8, 384); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
-    if (cin == 128)
+    if (hc)
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
+    else if (cin == 128)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch);
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
     else
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch);
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
     if (scratch) { // ordered reduction of the workgroups' slices: dW rows, then the column sums (row cin of a slice)
         const long ps = (long)(cin + 1) * cout;
         wgrad_reduce(grid, ps, 0, (long)cin * cout, scratch, dw, st);

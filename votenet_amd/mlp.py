@@ -423,6 +423,86 @@ def assemble_rows(xyz, new_xyz, idx, want_sums=True, pts_cnt=None, in_pass=False
     return geo, cntv, mom
 
 
+# ---- HALF-GROUP layout (csrc/half.hip): the grouped MLP of a level without the rows that are copies of slot 0 ----
+_nh_ring = None  # pinned ints the half-group counts are copied into (one slot per layout, reused round-robin)
+_nh_turn = 0
+
+
+class HalfLayout:
+    """Row layout of one level (include/votenet_hip.h, 'HALF-GROUP layout'): G centres, nh half-groups of 32 compact rows.
+    pos2 (G,), hc / wh (nh,), geo (32 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
+    its use -- and copied to pinned host memory; resolve() waits for that copy (a no-op once it has landed) and trims the views."""
+
+    def __init__(self, G, pos2, hc, wh, nh_dev):
+        global _nh_ring, _nh_turn
+        self.G, self.pos2, self._hc, self._wh, self.nh_dev = G, pos2, hc, wh, nh_dev
+        if _nh_ring is None:
+            _nh_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+        self._slot = _nh_ring[_nh_turn:_nh_turn + 1]
+        _nh_turn = (_nh_turn + 1) % 256
+        self._slot.copy_(nh_dev, non_blocking=True)
+        self._ev = torch.cuda.Event()
+        self._ev.record()
+        self.nh = None
+        self._geo = None
+
+    def tensors(self):
+        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo) if t is not None]
+
+    def resolve(self):
+        if self.nh is None:
+            self._ev.synchronize()
+            self.nh = int(self._slot.item())
+            if not (self.G <= self.nh <= 2 * self.G and self.nh % 4 == 0):
+                raise L.VotenetError("half-group layout: bad count %d for %d centres" % (self.nh, self.G))
+            self.hc, self.wh = self._hc[:self.nh], self._wh[:self.nh]
+            self.geo = self._geo[:self.nh * 32] if self._geo is not None else None
+        return self
+
+    @property
+    def rows(self):
+        return self.resolve().nh * 32
+
+
+def half_groups(pts_cnt):
+    """pts_cnt (b, m) int32 -> HalfLayout (count still on its way to the host)."""
+    G = pts_cnt.numel()
+    dev = pts_cnt.device
+    ints = torch.empty(3 * G + 1, dtype=torch.int32, device=dev)
+    pos2, hc, nh = ints[:G], ints[G:3 * G], ints[3 * G:]
+    wh = torch.empty(2 * G, dtype=torch.float32, device=dev)
+    with L.device_guard(dev):
+        L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos2), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.stream_ptr()))
+        return HalfLayout(G, pos2, hc, wh, nh)
+
+
+def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
+    """assemble_rows on the half-group layout: -> geo buffer (2 G 32, 4) of which half.resolve().geo is the written part, cntv, moments."""
+    b, m, k = idx.shape
+    n = xyz.shape[1]
+    if k != 64:
+        raise L.InvalidArgumentError("assemble_rows_half expects nsample == 64")
+    geo = torch.empty((2 * b * m * 32, 4), dtype=torch.float32, device=xyz.device)
+    cntv = torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device)
+    mom = torch.zeros(9, dtype=torch.float64, device=xyz.device)
+    with L.device_guard(xyz.device):
+        L.check(L.lib().votenet_assemble_rows_half(b, n, m, L.ptr(half.nh_dev), L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
+                                                   L.ptr(half._hc), L.ptr(geo), L.ptr(cntv), L.ptr(mom), L.stream_ptr()))
+    half._geo = geo
+    return geo, cntv, mom
+
+
+def group_linear_backward_half(half, pts_cnt, b, n, P, wx, da, coef, relu, dw_xyz):
+    """group_linear_backward_assembled on the half-group layout (da = total gradients per compact row) -> S (b, n, cout)."""
+    cout = P.shape[1]
+    S = _zeros_f32((b, n, cout), P.device)
+    with L.device_guard(P.device):
+        L.check(L.lib().votenet_group_linear_backward_half(half.nh, half.G, cout, L.ptr(half.geo), L.ptr(pts_cnt), L.ptr(half.hc), L.ptr(half.wh),
+                                                           L.ptr(P), L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S),
+                                                           L.ptr(dw_xyz), L.stream_ptr()))
+    return S
+
+
 def assemble_stats(P, cntv, wx, mom):
     """BatchNorm statistics (2*c0 f64) of the never-stored z0 from one pass over the points."""
     npts, c0 = P.shape
@@ -440,8 +520,9 @@ def assemble_z0(geo, P, wx):
     return z0
 
 
-def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True):
-    """Second layer over the assembled first-layer output: z = relu(bn0(P[prow] + dxyz wx)) w + bias -> z (rows, cout), stats."""
+def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True, half=None):
+    """Second layer over the assembled first-layer output: z = relu(bn0(P[prow] + dxyz wx)) w + bias -> z (rows, cout), stats.
+    half: geo is a HalfLayout's compact rows; the statistics weigh the rows that stand for a dropped half."""
     rows, c0, cout = geo.shape[0], P.shape[1], w.shape[1]
     z = torch.empty((rows, cout), dtype=torch.float32, device=P.device)
     stats = _zeros_f64(2 * cout, P.device) if want_stats else None
@@ -450,6 +531,12 @@ def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True):
         scale, shift = in_bn.scale, in_bn.shift
     else:
         raw = in_bn.raw()
+    if half is not None:
+        with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled half")):
+            L.check(L.lib().votenet_assembled_linear_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
+                                                          ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
+                                                          L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh), L.stream_ptr()))
+        return z, stats
     with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled")):
         L.check(L.lib().votenet_assembled_linear(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
                                                  ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
@@ -457,9 +544,15 @@ def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True):
     return z, stats
 
 
-def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, da, dw):
+def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, da, dw, half=None):
     """dw (c0, cout) += relu(bn0(z0))^T dz1 with z0 rebuilt in the loader, dz1 = BatchNorm-backward(da, z, coef)."""
     rows, c0, cout = geo.shape[0], P.shape[1], z.shape[1]
+    if half is not None:
+        with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled half")):
+            L.check(L.lib().votenet_assembled_wgrad_bn_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(in_scale), L.ptr(in_shift),
+                                                            1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0,
+                                                            L.ptr(half.wh), L.ptr(dw), L.stream_ptr()))
+        return
     scr = _wgrad_scratch(None, rows, c0, cout, P.device)
     with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled")):
         L.check(L.lib().votenet_assembled_wgrad_bn(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(in_scale), L.ptr(in_shift),
@@ -467,7 +560,7 @@ def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, d
                                                    L.ptr(scr), L.stream_ptr()))
 
 
-def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_EPS, below_tail=None):
+def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_EPS, below_tail=None, half=None):
     """dgrad_bn(..., below=...) for an assembled layer below: -> (da_prev, sums) or, with below_tail, (da_prev, coef of that layer)."""
     rows, c = z.shape
     cout = wT.shape[1]
@@ -475,11 +568,18 @@ def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_E
     out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
     sums = _zeros_f64(2 * cout, z.device)
     t, coef_b = _coef_tail(below_tail, cout, z.device)
-    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled")):
-        L.check(L.lib().votenet_assembled_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
-                                                          L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh), L.ptr(bme),
-                                                          L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
-                                                          ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if half is not None:
+        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled half")):
+            L.check(L.lib().votenet_assembled_dgrad_bn_reduce_half(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                                   L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh),
+                                                                   L.ptr(bme), L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
+                                                                   ctypes.byref(t) if t is not None else None, L.ptr(half.wh), L.stream_ptr()))
+    else:
+        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled")):
+            L.check(L.lib().votenet_assembled_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                              L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh), L.ptr(bme),
+                                                              L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
+                                                              ctypes.byref(t) if t is not None else None, L.stream_ptr()))
     if below_tail is None:
         return out, sums
     return out, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))
@@ -600,24 +700,30 @@ def linear_pool_supported(rows, cin, cout, k):
     return k == 64 and rows > 0 and rows % 128 == 0 and cin % 32 == 0 and cin <= 512 and cout % 128 == 0
 
 
-def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True, in_bn=None):
+def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True, in_bn=None, half=None):
     """linear_dense whose epilogue also emits the raw max / min of every group of k rows: -> z or None, stats, pool where
     pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool."""
     rows, cin = x.shape
     cout = w.shape[1]
-    g = rows // k
+    g = rows // k if half is None else half.nh  # half: raw max / min per half-group of 32 compact rows
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if keep_z else None
     stats = _zeros_f64(2 * cout, x.device)
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
     args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
+    if half is not None:
+        with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool half")):
+            L.check(L.lib().votenet_mlp_linear_pool_half(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
+                                                         L.ptr(half.wh), L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]),
+                                                         L.stream_ptr()))
+        return z, stats, (vals[0], vals[1], args[0], args[1])
     with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool")):
         L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
                                                 L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
     return z, stats, (vals[0], vals[1], args[0], args[1])
 
 
-def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, want_zsel=False):
+def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, want_zsel=False, half=None):
     """bn: a PendingBN instead of scale / shift (the kernel finalizes it).  -> out, argmax [, zsel = raw z at the arg-max]."""
     zmax, zmin, amax, amin = pool
     raw = None
@@ -627,9 +733,17 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, 
         else:
             raw = bn.raw()
     g, c = zmax.shape
+    if half is not None:
+        g = half.G  # pool holds one entry per half-group; the result one per centre
     out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
     arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
     zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None
+    if half is not None:
+        with L.device_guard(zmax.device):
+            L.check(L.lib().votenet_bn_pool_finalize_half(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(half.pos2),
+                                                          L.ptr(scale), L.ptr(shift), ctypes.byref(raw) if raw is not None else None,
+                                                          1 if relu else 0, L.ptr(out), L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
+        return (out, arg, zsel) if want_zsel else (out, arg)
     with L.device_guard(zmax.device):
         L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
                                                  ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),
@@ -675,7 +789,7 @@ def pool_dgrad_prepare(w, bias, coef, rows=None):
 
 
 def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, argmax, zsel, k, below=None, eps=BN_EPS, mm=None,
-               below_tail=None):
+               below_tail=None, half=None):
     """da (rows, cin) of the pooled layer: x (W diag(C) W^T) + (B + C.b) W^T as ONE forward-type GEMM on the layer's input,
     then the cout scattered rows per group.  below = (scale, shift, mean, var, relu) of the layer that produced xz: the
     scatter pass then also reduces that layer's BatchNorm backward -> returns (da, sums).  mm: pool_dgrad_prepare's result
@@ -697,11 +811,19 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     sums = _zeros_f64(2 * cin, xz.device) if below is not None else None
     bsc, bsh, bme, bva, brelu = below if below is not None else (None, None, None, None, False)
     t, coef_b = _coef_tail(below_tail if below is not None else None, cin, xz.device)
-    with L.device_guard(xz.device):
-        L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
-                                                   1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(xz if below is not None else None),
-                                                   L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), float(eps), 1 if brelu else 0,
-                                                   L.ptr(sums), ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    if half is not None:
+        with L.device_guard(xz.device):
+            L.check(L.lib().votenet_pool_dgrad_scatter_half(half.nh, half.G, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
+                                                            1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(half.hc), L.ptr(half.wh),
+                                                            L.ptr(xz if below is not None else None), L.ptr(bsc), L.ptr(bsh), L.ptr(bme),
+                                                            L.ptr(bva), float(eps), 1 if brelu else 0, L.ptr(sums),
+                                                            ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    else:
+        with L.device_guard(xz.device):
+            L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
+                                                       1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(xz if below is not None else None),
+                                                       L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), float(eps), 1 if brelu else 0,
+                                                       L.ptr(sums), ctypes.byref(t) if t is not None else None, L.stream_ptr()))
     if below is None:
         return da
     if below_tail is None:
@@ -709,20 +831,33 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     return da, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))  # below_tail: (da, coef of the layer below)
 
 
-def gram(xz, scale_shift, relu):
-    """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c)."""
+def gram(xz, scale_shift, relu, half=None):
+    """(c, c) a^T a of the activation a = act(xz * scale + shift); scale_shift: contiguous (2, c).  half: a^T diag(w) a over compact rows."""
     rows, c = xz.shape
     g = _zeros_f32((c + 1, c), xz.device)  # [gram ; column sums (filled by pool_wgrad)]
+    if half is not None:
+        with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram half")):
+            L.check(L.lib().votenet_mlp_gram_half(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(half.wh), L.ptr(g), L.stream_ptr()))
+        return g
     scr = _wgrad_scratch(None, rows, c, c, xz.device)
     with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
         L.check(L.lib().votenet_mlp_gram(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(g), L.ptr(scr), L.stream_ptr()))
     return g
 
 
-def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, gout, argmax, zsel, k, dw):
+def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, gout, argmax, zsel, k, dw, half=None):
     """dw += x^T dz of the pooled layer from the Gram matrix (gram()), the gathered arg-max rows and the column sums."""
     rows, cin = xz.shape
     cout = w.shape[1]
+    if half is not None:
+        with L.device_guard(xz.device):
+            L.check(L.lib().votenet_pool_wgrad_sparse_half(half.nh, half.G, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift),
+                                                           1 if in_relu else 0, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
+                                                           1 if relu else 0, L.ptr(dw), L.ptr(gram_buf[cin]), L.ptr(half.hc), L.ptr(half.wh),
+                                                           L.stream_ptr()))
+            L.check(L.lib().votenet_pool_wgrad_finish(cin, cout, L.ptr(gram_buf), L.ptr(gram_buf[cin]), L.ptr(w), L.ptr(bias), L.ptr(coef),
+                                                      L.ptr(dw), L.stream_ptr()))
+        return
     scr = None
     if DETERMINISTIC:
         scr = torch.empty(L.lib().votenet_pool_wgrad_scratch_floats(rows // k, cin, cout), dtype=torch.float32, device=xz.device)

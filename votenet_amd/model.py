@@ -75,6 +75,8 @@ class VoteNetHotPath:
     def _hand_over(g, main):
         for v in g.values():  # tensors born on the side stream are consumed on the main stream
             for t in (v if isinstance(v, tuple) else (v,)):
+                for u in getattr(t, "tensors", tuple)() if not isinstance(t, torch.Tensor) else ():  # mlp.HalfLayout
+                    u.record_stream(main)
                 if isinstance(t, torch.Tensor):
                     t.record_stream(main)
                     for u in getattr(t, "_inv", None) or ():  # the grouping's inverse index rides on idx (mlp.attach_inverse)

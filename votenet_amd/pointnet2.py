@@ -29,6 +29,7 @@ NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the firs
 PAD_RAGGED_IN = True  # ragged INPUT widths (voting's 259) padded as well (Layer.cin_pad); False: the bounds-checked GEMMs (A/B)
 ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
 ASSEMBLE_INLINE = True  # also where the geo records were not computed ahead with the geometry (they are built in place)
+HALF_GROUPS = False    # assembled modules with nsample = 64 drop the all-copy second half of an under-full ball (csrc/half.hip): same results up to summation order, 30-60 % fewer grouped rows on room scenes
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -365,16 +366,17 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
         elif i == 0 and first[0] == "assembled":
             # first layer assembled inside its consumers (csrc/assemble.hip): the per-point GEMM P = feat W[3:] + b is all that runs here;
             # the BatchNorm statistics of z0 = P[idx] + dxyz W[0:3] come from one pass over the points
-            _, xyz, new_xyz, feat, idx, geo, cntv, mom = first
+            _, xyz, new_xyz, feat, idx, geo, cntv, mom = first[:8]
+            half = first[8] if len(first) > 8 else None  # mlp.HalfLayout: geo (and every row tensor of the chain) holds compact rows
             bb, nn, cc = feat.shape
             P, _ = M.linear_dense(feat.reshape(bb * nn, cc), w[3:], b, want_stats=False)
             zn = None
             st = M.assemble_stats(P, cntv, w[:3], mom) if (L.bn and _FROZEN.table is None) else None
-            rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3])
+            rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3], half=half)
         elif i == 1 and first[0] == "assembled":
             r0 = tape[-1]
-            zn, st = M.assembled_linear(r0["geo"], r0["P"], r0["wx"], w, b, pend, prev_relu, want_stats=L.bn)
-            rec = dict(layer=L, kind="dense", x=None, assembled=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
+            zn, st = M.assembled_linear(r0["geo"], r0["P"], r0["wx"], w, b, pend, prev_relu, want_stats=L.bn, half=r0["half"])
+            rec = dict(layer=L, kind="dense", x=None, assembled=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=r0["half"])
         elif i == 1 and first[0] == "narrow":
             zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn)
             rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
@@ -403,9 +405,12 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
                 M.linear_pool_supported(rows, w.shape[0], w.shape[1], pool_k):
             # training does not store z of this layer either when its backward runs in Gram form (it never reads z)
             gram_form = POOL_GRAM_BACKWARD and pend is not None and M.pool_backward_supported(w.shape[0], w.shape[1], pool_k)
-            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend)
+            half = tape[0].get("half") if first[0] == "assembled" else None
+            if half is not None and not (gram_form or not keep_z):
+                raise M.L.VotenetError("half-group layout: the pooled layer's backward must be in Gram form")
+            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend, half=half)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, gram_form=gram_form,
-                       in_affine=pend.out if pend is not None else None, cout=w.shape[1])
+                       in_affine=pend.out if pend is not None else None, cout=w.shape[1], half=half)
         elif L.cout_pad and i > 0:
             # ragged plain layer on zero-padded copies of W and b: the fast GEMM, output (rows, cout_pad), the layer's z = [:, :cout]
             zp, st = M.linear_dense(z, L.store.padded(L.name + "/W", L.cout_pad), L.store.padded(L.name + "/b", L.cout_pad), None, None,
@@ -534,9 +539,10 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             bn = (r["scale"], r["shift"], r["mean"], r["var"])
             coef = M.bn_backward_reduce_pool(da, zsel, *bn, L.relu, tail=tail_of(r))
             mm = M.pool_dgrad_prepare(W, b, coef, x.shape[0]) if want_da else None
-            def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da):
-                G = M.gram(x, aff[:2], r["in_relu"])
-                M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"))
+            half = r.get("half")
+            def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da, half=half):
+                G = M.gram(x, aff[:2], r["in_relu"], half=half)
+                M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"), half=half)
             on_wgrad_stream(_pooled_wgrad, x, aff, coef, da, argmax, zsel)
             if not want_da:
                 return None
@@ -544,9 +550,10 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             if below["layer"].bn and below["z"] is x:
                 da, coef_ahead = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax,
                                               zsel, k, below=(below["scale"], below["shift"], below["mean"], below["var"],
-                                                              below["layer"].relu), mm=mm, below_tail=tail_of(below))
+                                                              below["layer"].relu), mm=mm, below_tail=tail_of(below), half=half)
             else:
-                da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k, mm=mm)
+                da = M.pool_dgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], W, b, L.wT(), coef, L.relu, da, argmax, zsel, k, mm=mm,
+                                  half=half)
             continue
         rows, c = r["rows"], L.cout  # z is None for a first layer that is never stored (narrow / assembled)
         if L.bn:
@@ -561,12 +568,12 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 # second layer above an ASSEMBLED first layer (i == 1): both GEMMs rebuild z0 from geo + P; the input-gradient GEMM's
                 # epilogue reduces the first layer's BatchNorm backward on the rebuilt z0
                 r0 = recs[0]
-                geo, Pt, wx = r0["geo"], r0["P"], r0["wx"]
+                geo, Pt, wx, half = r0["geo"], r0["P"], r0["wx"], r0["half"]
                 on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.assembled_wgrad_bn(
-                    geo, Pt, wx, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W")), geo, Pt, z, coef, da)
+                    geo, Pt, wx, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W"), half=half), geo, Pt, z, coef, da)
                 da, coef_ahead = M.assembled_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, geo, Pt, wx,
                                                               (r0["scale"], r0["shift"], r0["mean"], r0["var"], r0["layer"].relu),
-                                                              below_tail=tail_of(r0))
+                                                              below_tail=tail_of(r0), half=half)
                 continue
             if r.get("narrow"):
                 # second layer above a NARROW first layer (i == 1): both GEMMs rebuild z0 from u8; the input-gradient GEMM stores
@@ -712,6 +719,14 @@ class SAModule:
                     and m[0].bn and m[1].bn and m[0].relu and M.assembled_supported(rows, m[0].cout, m[1].cout)
                     and M.group_linear_backward_supported(m[0].cout, self.nsample) and b * n * m[0].cout * 4 < 2 ** 32)
 
+    def half_groups(self, b, n):
+        """True when this module's grouped MLP runs on the half-group layout (csrc/half.hip: the rows that repeat slot 0 dropped by
+        halves of a ball) for b scenes of n points: an assembled first layer, three BatchNorm'ed layers, the pooled one in Gram form."""
+        m = self.mlp
+        return bool(HALF_GROUPS and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and self.assembled(b, n)
+                    and m[2].bn and POOL_IN_EPILOGUE and POOL_GRAM_BACKWARD and (b * self.npoint) % 4 == 0
+                    and m[1].cout == 128 and m[2].cout in (128, 256) and M.pool_backward_supported(m[1].cout, m[2].cout, 64))
+
     def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None, ahead=True):
         """The weight-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream.
         points: the module's input features; given for a narrow leaf module, the grouped rows u8 and their moments (which depend
@@ -724,6 +739,9 @@ class SAModule:
             geom = (fps_idx, new_xyz, idx, pts_cnt)
         if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
             geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
+        elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
+            half = M.half_groups(geom[3])  # the layout and the count of its half-groups: known on the host by the time the MLP runs
+            geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
             geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3], in_pass=not ahead)  # geo records + per-point sums: coordinates only
         return geom
@@ -743,10 +761,13 @@ class SAModule:
         elif points is not None and self.assembled(b, xyz.shape[1]) and (len(geom) >= 7 or ASSEMBLE_INLINE):
             geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt, in_pass=True)
             first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
+            if len(geom) >= 8:  # half-group layout: the compact rows
+                half = geom[7].resolve()
+                first = ("assembled", xyz, new_xyz, points, idx, half.geo, cntv, mom, half)
         z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
         if recs[-1]["pool"] is not None:  # utils.py:132, the pass over z already done by the GEMM epilogue
             res = M.bn_pool_finalize(recs[-1]["pool"], None, None, True, want_argmax=tape is not None, bn=pend,
-                                     want_zsel=tape is not None and bool(recs[-1].get("gram_form")))
+                                     want_zsel=tape is not None and bool(recs[-1].get("gram_form")), half=recs[-1].get("half"))
             pooled, argmax, zsel = res if len(res) == 3 else (res[0], res[1], None)
         else:
             zsel = None
@@ -800,6 +821,10 @@ class SAModule:
                 on_wgrad_stream(lambda: M.wgrad_gather(xyz, new_xyz, None, idx, dz, gW), dz)  # rows 0..2 of dW (no feature block)
             if feat is not None and PRE_LINEAR:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
+        elif r0["kind"] == "assembled" and r0.get("half") is not None:
+            if need_xyz_grad:
+                raise ValueError("SAModule: the half-group layout keeps no per-row dz for the xyz gradient")
+            S, dz = M.group_linear_backward_half(r0["half"], pts_cnt, b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
         elif r0["kind"] == "assembled":
             S, dz = M.group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"],
                                                       gW[:3], want_dz=need_xyz_grad)
