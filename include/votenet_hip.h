@@ -702,6 +702,19 @@ int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const flo
                                            const float *scale_prev, const float *shift_prev, const float *mean_prev,
                                            const float *var_prev, float eps, int relu_prev, double *sums,
                                            const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
+/* The narrow first layer (sa1) on the same layout: u8 (up to 2G*32 x 8 floats; moments over the true rows), the second layer's GEMMs. */
+int votenet_narrow_rows_half(int b, int n, int m, int c, const int *nh, const float *xyz, const float *new_xyz, const float *feat,
+                             const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream);
+int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0, const float *in_scale,
+                               const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias, float *z,
+                               double *stats, const float *wh, void *stream);
+int votenet_narrow_wgrad_bn_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0, const float *in_scale,
+                                 const float *in_shift, int in_relu, const float *da, const float *z, const float *coef, int relu,
+                                 const float *wh, float *dw, void *stream);
+int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef, int relu,
+                                        const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
+                                        const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
+                                        double *ug, const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
 int votenet_group_linear_backward_half(long nh, int G, int cout, const float *geo, const int *pts_cnt, const int *hc, const float *wh,
                                        const float *P, const float *wx, const float *da, const float *coef, int relu, float *s_points,
                                        float *dw_xyz, void *stream);

@@ -24,11 +24,14 @@ def ref_chain(x, layers, params, recs):
             if r["kind"] in ("narrow", "assembled"):  # the device never stores this layer: its own arithmetic, materialised for the active set
                 from votenet_amd import mlp as M
                 zd = M.narrow_z0(r["u8"], L.p("W"), L.p("b")) if r["kind"] == "narrow" else M.assemble_z0(r["geo"], r["P"], r["wx"])
+                if r.get("half") is not None:  # compact rows (csrc/half.hip) -> the full layout the reference runs on
+                    zd = r["half"].full_rows(zd)
                 mask = (zd * r["scale"] + r["shift"] > 0).double()
             elif r["z"] is None:  # pooled layer in Gram form: the device keeps no z; ref_sa applies the active set after the max
                 mask = 1.0
             else:
-                mask = (r["z"] * r["scale"] + r["shift"] > 0).double()
+                zd = r["z"] if r.get("half") is None else r["half"].full_rows(r["z"])
+                mask = (zd * r["scale"] + r["shift"] > 0).double()
             z = z * mask
         x = z
     return x
@@ -391,12 +394,14 @@ def test_training_gradients_are_bit_reproducible(hiplib, dev, full):
         from votenet_amd import pointnet2 as P
         # the deterministic pass stores the first SA layers (the assembled form sums per-point counts with atomics and is switched
         # off in that mode): compare like with like, or ReLU / arg-max decisions move with the last bits of the forward pass
+        # (the half-group layout likewise: it associates the BatchNorm sums differently and is not used by the deterministic pass)
         old, P.ASSEMBLE_FIRST = P.ASSEMBLE_FIRST, False
+        old_half, P.HALF_GROUPS = P.HALF_GROUPS, False
         try:
             a1 = once()[0]
             a2 = once()[0]
         finally:
-            P.ASSEMBLE_FIRST = old
+            P.ASSEMBLE_FIRST, P.HALF_GROUPS = old, old_half
         assert not torch.equal(a1, a2)                                   # atomics: summation order varies run to run ...
         assert float((a1 - g1).abs().max()) <= 1e-3 * float(g1.abs().max())          # ... around the same gradient
 

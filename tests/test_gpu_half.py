@@ -169,7 +169,7 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
 
 
 def test_model_with_and_without_the_half_group_layout(hiplib, dev):
-    """The whole hot path with sa2 / sa3 / sa4 on the half-group layout against the full layout: same outputs and losses to fp32
+    """The whole hot path with sa1 (narrow first layer) and sa2 / sa3 / sa4 (assembled first layer) on the half-group layout against the full layout: same outputs and losses to fp32
     rounding (the BatchNorm sums are associated differently), the same gradient in the L2 sense (tests/test_gpu_narrow.py: two fp32
     evaluations of a forward pass move ReLU / arg-max decisions), fewer grouped rows."""
     from votenet_amd import loss as VL
@@ -192,22 +192,76 @@ def test_model_with_and_without_the_half_group_layout(hiplib, dev):
         net.backward(tape, cot)
         torch.cuda.synchronize()
         return tape, out["proposals_output"].clone(), losses.clone(), net.store.grad.clone()
-    assert not P.HALF_GROUPS
-    tape, o0, l0, g0 = once()
-    assert all(t["recs"][0].get("half") is None for t in tape if t.get("op") == "sa")
-    P.HALF_GROUPS = True
+    assert P.HALF_GROUPS  # the default
+    tape, o1, l1, g1 = once()
+    sas = [t for t in tape if t.get("op") == "sa"]
+    halves = [t["recs"][0].get("half") for t in sas]
+    assert [h is not None for h in halves] == [True, True, True, True, False]
+    for t, h in zip(sas[:4], halves[:4]):
+        assert t["recs"][1]["z"].shape[0] == h.rows < t["recs"][0]["rows"]
+    r1 = net.predict(x, 0.25, batch_statistics=True)  # inference through the same layout
+    P.HALF_GROUPS = False
     try:
-        tape, o1, l1, g1 = once()
-        sas = [t for t in tape if t.get("op") == "sa"]
-        halves = [t["recs"][0].get("half") for t in sas]
-        assert [h is not None for h in halves] == [False, True, True, True, False]
-        for t, h in zip(sas[1:4], halves[1:4]):
-            assert t["recs"][1]["z"].shape[0] == h.rows < t["recs"][0]["rows"]
-        # inference through the same layout
-        r1 = net.predict(x, 0.25, batch_statistics=True)
+        tape, o0, l0, g0 = once()
+        assert all(t["recs"][0].get("half") is None for t in tape if t.get("op") == "sa")
+        r0 = net.predict(x, 0.25, batch_statistics=True)
     finally:
-        P.HALF_GROUPS = False
-    r0 = net.predict(x, 0.25, batch_statistics=True)
+        P.HALF_GROUPS = True
     assert relerr(o1, o0) < 5e-5 and relerr(l1, l0) < 5e-5
     assert float((g1.double() - g0.double()).norm() / g0.double().norm()) < 1e-2
     assert len(r1) == len(r0)
+
+
+@pytest.mark.parametrize("b,n,m,c,radius", [(2, 700, 64, 3, 0.5), (1, 500, 48, 0, 0.45)])
+def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_form, b, n, m, c, radius):
+    """sa1's form (csrc/narrow.hip: z0 rebuilt from eight floats per row) on the compact rows."""
+    from votenet_amd import mlp as M
+    from votenet_amd import tf_grouping, tf_sampling
+    k, c0, c1 = 64, 64, 64
+    g = torch.Generator().manual_seed(11 * n + c)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    xyz = (torch.rand(b, n, 3, generator=g) * 2.0).to(dev)
+    feat = xyz.clone() if c == 3 else None
+    new_xyz = tf_sampling.gather_point(xyz, tf_sampling.farthest_point_sample(m, xyz))
+    idx, cnt = tf_grouping.query_ball_point(radius, k, xyz, new_xyz)
+    assert bool((cnt <= 31).any()) and bool((cnt > 31).any()), cnt.flatten().tolist()
+    rows, k0 = b * m * k, 3 + c
+    w0, b0, w1 = rnd(k0, c0) * 0.5, rnd(c0) * 0.1, rnd(c0, c1) * 0.2
+    w1T = w1.t().contiguous()
+    img = M.SplitImages([w1, w1T])
+    img.refresh()
+    u8, mom = M.narrow_rows(xyz, new_xyz, feat, idx)
+    half = M.half_groups(cnt)
+    _, mom_h = M.narrow_rows_half(xyz, new_xyz, feat, idx, cnt, half)
+    half.resolve()
+    full, mult = _rows_of(half, dev)
+    assert half.rows < rows and torch.equal(half.u8, u8[full]) and relerr(mom_h, mom) < 1e-12
+    st0 = M.narrow_stats(rows, mom_h, w0, b0)
+    bn0 = M.PendingBN(st0, rnd(c0) * 0.2 + 1.0, rnd(c0) * 0.1, rows)
+    bn0.finalize()
+    z1, st1 = M.narrow_linear(u8, w0, b0, w1, None, bn0)
+    z1h, st1h = M.narrow_linear(half.u8, w0, b0, w1, None, bn0, half=half)
+    assert torch.equal(z1h, z1[full]) and relerr(st1h[:c1], st1[:c1]) < 1e-6 and relerr(st1h[c1:], st1[c1:]) < 1e-6
+    da1 = rnd(rows, c1)
+    da1h = _totals(da1, half, dev).float()
+    coef1 = rnd(5 * c1) * 0.3
+    bn1 = M.PendingBN(st1, rnd(c1) * 0.2 + 1.0, rnd(c1) * 0.1, rows)
+    bn1.finalize()
+    coef1[3 * c1:4 * c1], coef1[4 * c1:] = bn1.scale, bn1.shift
+    dw1, dw1h = torch.zeros(c0, c1, device=dev), torch.zeros(c0, c1, device=dev)
+    M.narrow_wgrad_bn(u8, w0, b0, bn0.scale, bn0.shift, True, z1, coef1, True, da1, dw1)
+    M.narrow_wgrad_bn(half.u8, w0, b0, bn0.scale, bn0.shift, True, z1h, coef1, True, da1h, dw1h, half=half)
+    assert relerr(dw1h, dw1) < 1e-5
+    below0 = (bn0.scale, bn0.shift, bn0.mean, bn0.var, True)
+    sums, ug = M.narrow_dgrad_bn_reduce(z1, coef1, True, w1T, da1, u8, w0, b0, below0)
+    sums_h, ug_h = M.narrow_dgrad_bn_reduce(z1h, coef1, True, w1T, da1h, half.u8, w0, b0, below0, half=half)
+    # scale of the sums: the absolute sums of their terms
+    dz1 = coef1[:c1] * da1 * (z1 * bn1.scale + bn1.shift > 0) + coef1[c1:2 * c1] + coef1[2 * c1:3 * c1] * z1
+    da0 = dz1.double() @ w1T.double()
+    z0 = M.narrow_z0(u8, w0, b0).double()
+    zh0 = (z0 - bn0.mean.double()) / torch.sqrt(bn0.var.double() + M.BN_EPS)
+    scale = torch.cat([da0.abs().sum(0), (da0 * zh0).abs().sum(0)])
+    assert float(((sums_h - sums).abs() / (scale + 1e-30)).max()) < 1e-5
+    uscale = (u8.double().abs().t() @ da0.abs())
+    assert float(((ug_h - ug).abs() / (uscale + 1e-30)).max()) < 1e-5
+    img.close()

@@ -250,9 +250,16 @@ def test_config5_dense_scan_forward_properties(hiplib, dev):
         from votenet_amd import mlp as M
         z2, _ = M.linear_dense(r2["x"], r2["layer"].p("W"), r2["layer"].p("b"), r2["in_scale"], r2["in_shift"], r2["in_relu"],
                                want_stats=False)
+    if r2.get("half") is not None:  # compact rows (csrc/half.hip): a dropped slot is a copy of slot 0
+        z2 = r2["half"].full_rows(z2)
     act = z2.view(4 * 2048, 64, -1) * r2["scale"] + r2["shift"]
     pooled = torch.where(act > 0, act, torch.zeros_like(act)).amax(1)
-    assert torch.equal(pooled.view(4, 2048, -1), net.sa1.forward(x, x, tape=None, geom=(sa1["fps_idx"], new_xyz, idx, cnt))[1])
+    again = net.sa1.forward(x, x, tape=None, geom=(sa1["fps_idx"], new_xyz, idx, cnt))[1]  # (a 4-tuple geometry: the full layout)
+    if r2.get("half") is None:
+        assert torch.equal(pooled.view(4, 2048, -1), again)
+    else:  # the two layouts associate the BatchNorm sums differently: equal to rounding; the same layout again: equal
+        assert float((pooled.view(4, 2048, -1) - again).abs().max()) < 1e-5 * float(again.abs().max())
+        assert torch.equal(pooled.view(4, 2048, -1), net.sa1.forward(x, x, tape=None)[1])
 
 
 def test_full_size_train_steps(hiplib, dev):
@@ -336,6 +343,9 @@ def test_moving_averages_follow_tensorflows_update(hiplib, dev):
             exp[r["layer"].name] = (0.9 * m + 0.1 * r["mean"], 0.9 * v + 0.1 * r["var"] * (rows / (rows - 1.0)))
             if r["z"] is not None and r["kind"] == "dense":
                 z = r["z"].double()
+                if r.get("half") is not None:  # compact rows (csrc/half.hip): the statistics run over the full layout's rows
+                    z = r["half"].full_rows(z)
+                    assert z.shape[0] == rows
                 assert torch.allclose(r["mean"].double(), z.mean(0), rtol=1e-4, atol=1e-6)
                 assert torch.allclose(r["var"].double(), z.var(0, unbiased=False), rtol=1e-4, atol=1e-7)
             seen += 1

@@ -18,3 +18,13 @@ for name, rec in zip(("sa1", "sa2", "sa3", "sa4"), tape[:4]):
 rec = tape[-1]
 c = rec["pts_cnt"].float(); k = rec["idx"].shape[2]
 print("proposal: K %d  mean pts_cnt %.1f  (%.0f %% repeat slot 0; untrained votes)" % (k, c.mean().item(), 100 * (1 - c.mean().item() / k)))
+# how many grouped rows a layout of g-row pieces keeps (a piece is kept when it holds at least one slot < pts_cnt; the first always)
+for name, rec in zip(("sa1", "sa2", "sa3", "sa4"), tape[:4]):
+    c = rec["pts_cnt"].float().clamp(min=1)
+    k = rec["idx"].shape[2]
+    out = []
+    for g in (32, 16, 8):
+        kept = (torch.ceil(c / g) * g).mean().item()
+        out.append("%d-row pieces keep %.0f %%" % (g, 100 * kept / k))
+    print("%s: %s; P(cnt<=15) %.2f P(cnt<=31) %.2f P(cnt<=47) %.2f" % (name, ", ".join(out), (c <= 15).float().mean().item(),
+          (c <= 31).float().mean().item(), (c <= 47).float().mean().item()))

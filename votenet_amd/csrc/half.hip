@@ -131,6 +131,73 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
         unsafeAtomicAdd(&moments[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
+// votenet_narrow_rows on the half-group layout: thread = compact row; u (8 floats) of the row's slot; the moments run over the TRUE rows
+// (slot k < pts_cnt counts once, slot 0 also for the 64 - pts_cnt copies of it).
+__global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__restrict__ nh_dev, int G, int n, int groups_per_scene, int c,
+                                                               const float *__restrict__ xyz, const float *__restrict__ new_xyz,
+                                                               const float *__restrict__ feat, const int *__restrict__ idx,
+                                                               const int *__restrict__ pts_cnt, const int *__restrict__ hc,
+                                                               float *__restrict__ u8, double *__restrict__ moments)
+{
+    __shared__ double red[4][44];
+    double acc[44]; // m[0..8), then the upper triangle of M row by row
+#pragma unroll
+    for (int i = 0; i < 44; i++) acc[i] = 0.0;
+    const long rows = (long)nh_dev[0] * 32;
+    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+        const int h = (int)(r >> 5), s = (int)(r & 31);
+        const int ctr = hc[h];
+        const int k = (h >= G ? 32 : 0) + s;
+        const int id = idx[(size_t)ctr * 64 + k];
+        const size_t prow = (size_t)((unsigned)ctr / (unsigned)groups_per_scene) * n + id;
+        float u[8];
+        u[0] = xyz[prow * 3 + 0] - new_xyz[(size_t)ctr * 3 + 0]; // utils.py:55
+        u[1] = xyz[prow * 3 + 1] - new_xyz[(size_t)ctr * 3 + 1];
+        u[2] = xyz[prow * 3 + 2] - new_xyz[(size_t)ctr * 3 + 2];
+#pragma unroll
+        for (int d = 0; d < 5; d++) u[3 + d] = d < c ? feat[prow * c + d] : 0.0f;
+        *reinterpret_cast<float4 *>(u8 + (size_t)r * 8) = make_float4(u[0], u[1], u[2], u[3]);
+        *reinterpret_cast<float4 *>(u8 + (size_t)r * 8 + 4) = make_float4(u[4], u[5], u[6], u[7]);
+        int cnt = pts_cnt[ctr];
+        if (cnt < 1) cnt = 1;
+        if (k < cnt) {
+            const double mult = (k == 0) ? (double)(64 - cnt + 1) : 1.0;
+            int t = 8;
+#pragma unroll
+            for (int d = 0; d < 8; d++) {
+                acc[d] += mult * (double)u[d];
+#pragma unroll
+                for (int e = d; e < 8; e++) acc[t++] += mult * ((double)u[d] * (double)u[e]);
+            }
+        }
+    }
+    if (!moments) return;
+#pragma unroll
+    for (int i = 0; i < 44; i++) {
+        double v = acc[i];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) v += half_shfl_xor_f64(v, m);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 44) {
+        const double v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+        const int i = threadIdx.x;
+        if (i < 8) {
+            unsafeAtomicAdd(&moments[i], v);
+        } else { // triangle position -> (d, e), written to both halves of the full matrix
+            int d = 0, t = 8;
+            while (i >= t + (8 - d)) {
+                t += 8 - d;
+                d++;
+            }
+            const int e = d + (i - t);
+            unsafeAtomicAdd(&moments[8 + d * 8 + e], v);
+            if (e != d) unsafeAtomicAdd(&moments[8 + e * 8 + d], v);
+        }
+    }
+}
+
 // votenet_bn_pool_finalize over half-groups: a centre's pooled value = the better of its one or two halves (ties -> the first half: the
 // first occurrence, as the 64-row epilogue decides); arg-max = the row offset inside the 64-slot ball.
 __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
@@ -273,6 +340,21 @@ extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, co
     hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, b * m, n, m, xyz, new_xyz, idx,
                        pts_cnt, hc, reinterpret_cast<float4 *>(geo), cntv, moments);
     return check_launch("assemble_rows_half");
+}
+
+extern "C" int votenet_narrow_rows_half(int b, int n, int m, int c, const int *nh, const float *xyz, const float *new_xyz, const float *feat,
+                                       const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream)
+{
+    VN_REQUIRE(b > 0 && n > 0 && m > 0 && c >= 0 && c <= 5, "narrow_rows_half expects 0 <= c <= 5 feature channels (3 + c <= 8)");
+    const long max_rows = 2L * b * m * 32;
+    VN_REQUIRE(max_rows < (1L << 31), "narrow_rows_half: b*m*64 must be below 2^31");
+    VN_REQUIRE(nh && xyz && new_xyz && idx && pts_cnt && hc && u8 && (c == 0 || feat), "narrow_rows_half: null buffer");
+    VN_REQUIRE((uintptr_t)u8 % 16 == 0, "narrow_rows_half: u8 must be 16-byte aligned");
+    long gx = (max_rows * 3 / 4 + 256 * 16 - 1) / (256 * 16);
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(narrow_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, b * m, n, m, c, xyz, new_xyz, feat,
+                       idx, pts_cnt, hc, u8, moments);
+    return check_launch("narrow_rows_half");
 }
 
 extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,

@@ -974,6 +974,27 @@ extern "C" int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, cons
     return check_launch("narrow_wgrad_bn");
 }
 
+// votenet_narrow_wgrad_bn on the half-group layout (half.hip): da holds totals per compact row, the affine part of dz1 is weighted.
+extern "C" int votenet_narrow_wgrad_bn_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                            const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
+                                            const float *coef, int relu, const float *wh, float *dw, void *stream)
+{
+    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) && k0 >= 3 && k0 <= 8 && c0 > 0 && cout > 0, "narrow_wgrad_bn_half: bad shape");
+    VN_REQUIRE(u8 && w0 && in_scale && in_shift && da && z && coef && wh && dw, "narrow_wgrad_bn_half: null buffer");
+    MlpIn d = {};
+    d.in_scale = in_scale;
+    d.in_shift = in_shift;
+    d.in_relu = in_relu;
+    d.u8 = u8;
+    d.w0 = w0;
+    d.b0 = b0;
+    d.k0 = k0;
+    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0, wh};
+    if (!wgrad_fast_launch(2, d, rows, c0, cout, nullptr, bs, 4, dw, as_stream(stream), nullptr))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_wgrad_bn_half: shape not served (as votenet_narrow_wgrad_bn)");
+    return check_launch("narrow_wgrad_bn_half");
+}
+
 // Weight gradient of the SECOND layer of a chain whose first layer is ASSEMBLED (assemble.hip): dw (c0 x cout) += act(z0)^T dz1 with
 // z0[r,:] = P[prow(r),:] + dxyz(r) . wx rebuilt in the loader (act = relu(z0*in_scale+in_shift)), dz1 from (da, z, coef).
 extern "C" int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,

@@ -1217,9 +1217,9 @@ extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const flo
 // Second layer of an SA chain whose first layer is NARROW (narrow.hip): z (rows x cout) = relu(bn0(z0)) w + bias with
 // z0[r,:] = narrow_z(u8[r], W0, b0) rebuilt in the operand loader (z0 is never stored), bn0 from raw statistics (in_bn) or from
 // in_scale / in_shift.  stats as for votenet_mlp_linear.
-extern "C" int votenet_narrow_linear(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
-                                     const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
-                                     const float *w, const float *bias, float *z, double *stats, void *stream)
+static int narrow_linear_impl(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0, const float *in_scale,
+                              const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias, float *z,
+                              double *stats, const float *wh, void *stream)
 {
     VN_REQUIRE(rows > 0 && k0 >= 3 && k0 <= 8 && c0 > 0 && cout > 0, "narrow_linear expects rows > 0, 3 <= k0 <= 8, c0 > 0, cout > 0");
     VN_REQUIRE(u8 && w0 && w && z, "narrow_linear: null buffer");
@@ -1240,19 +1240,33 @@ extern "C" int votenet_narrow_linear(long rows, int k0, int c0, int cout, const 
     a.bias = bias;
     a.z = z;
     a.stats = stats;
+    a.wh = wh; // half-group layout (half.hip): the statistics weigh row 31 of every half-group
     hipStream_t st = as_stream(stream);
     const bool ok = stats ? fast_dispatch<3, 0>(a, st) : fast_dispatch<3, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_linear: shape not served (rows %% 128 == 0, c0 %% 32 == 0, c0 <= 128, cout == 64 or cout %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_linear");
 }
+extern "C" int votenet_narrow_linear(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                     const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                     const float *w, const float *bias, float *z, double *stats, void *stream)
+{
+    return narrow_linear_impl(rows, k0, c0, cout, u8, w0, b0, in_scale, in_shift, in_bn, in_relu, w, bias, z, stats, nullptr, stream);
+}
+extern "C" int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                          const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                          const float *w, const float *bias, float *z, double *stats, const float *wh, void *stream)
+{
+    VN_REQUIRE(wh != nullptr && rows % 32 == 0, "narrow_linear_half: null weights / rows %% 32 != 0");
+    return narrow_linear_impl(rows, k0, c0, cout, u8, w0, b0, in_scale, in_shift, in_bn, in_relu, w, bias, z, stats, wh, stream);
+}
 
 // Input-gradient GEMM of that second layer: da0 = dz1 wT (dz1 from (da, zsrc, coef) as votenet_mlp_dgrad_bn) is NOT stored; its
 // epilogue reduces the first layer's BatchNorm backward (sums: 2*c0 doubles, as votenet_mlp_dgrad_bn_reduce, z0 rebuilt from u8)
 // and ug[d*c0 + c] += sum_r u8[r,d] da0'[r,c] (8*c0 doubles), the data term of votenet_narrow_wgrad_first.  Both pre-zeroed.
-extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
-                                              int relu, const float *wT, const float *u8, const float *w0, const float *b0,
-                                              const float *scale0, const float *shift0, const float *mean0, const float *var0,
-                                              float eps, int relu0, double *sums, double *ug, const votenet_coef_tail *tail, void *stream)
+static int narrow_dgrad_bn_reduce_impl(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef, int relu,
+                                       const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
+                                       const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
+                                       double *ug, const votenet_coef_tail *tail, const float *wh, void *stream)
 {
     VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "narrow_dgrad_bn_reduce: incomplete coefficient tail");
     VN_REQUIRE(rows > 0 && c > 0 && c0 > 0 && k0 >= 3 && k0 <= 8, "narrow_dgrad_bn_reduce expects rows > 0, c > 0, c0 > 0, 3 <= k0 <= 8");
@@ -1280,9 +1294,28 @@ extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, 
     a.stats = sums;
     a.ug = ug;
     a.tail = to_tail(tail);
-    if (!fast_dispatch<1, 4>(a, as_stream(stream)))
+    a.wh = wh; // half-group layout: da holds totals, the affine part of the rebuilt dz1 counts wh[h] times on row 32 h + 31 (SRC 5)
+    if (!(wh ? fast_dispatch<5, 4>(a, as_stream(stream)) : fast_dispatch<1, 4>(a, as_stream(stream))))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_dgrad_bn_reduce");
+}
+extern "C" int votenet_narrow_dgrad_bn_reduce(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
+                                              int relu, const float *wT, const float *u8, const float *w0, const float *b0,
+                                              const float *scale0, const float *shift0, const float *mean0, const float *var0,
+                                              float eps, int relu0, double *sums, double *ug, const votenet_coef_tail *tail, void *stream)
+{
+    return narrow_dgrad_bn_reduce_impl(rows, c, c0, k0, da, zsrc, coef, relu, wT, u8, w0, b0, scale0, shift0, mean0, var0, eps, relu0, sums, ug,
+                                       tail, nullptr, stream);
+}
+extern "C" int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
+                                                   int relu, const float *wT, const float *u8, const float *w0, const float *b0,
+                                                   const float *scale0, const float *shift0, const float *mean0, const float *var0,
+                                                   float eps, int relu0, double *sums, double *ug, const votenet_coef_tail *tail,
+                                                   const float *wh, void *stream)
+{
+    VN_REQUIRE(wh != nullptr, "narrow_dgrad_bn_reduce_half: null weights");
+    return narrow_dgrad_bn_reduce_impl(rows, c, c0, k0, da, zsrc, coef, relu, wT, u8, w0, b0, scale0, shift0, mean0, var0, eps, relu0, sums, ug,
+                                       tail, wh, stream);
 }
 
 extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }

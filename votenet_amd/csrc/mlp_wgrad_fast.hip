@@ -488,8 +488,9 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
         return launch<3, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (mode == 2) { // NARROW first layer below: x rebuilt from u8 (votenet_narrow_wgrad_bn)
-        if (!al(d.u8) || !al(d.w0) || (d.b0 && !al(d.b0)) || d.k0 < 1 || d.k0 > 8 || bsrc != 1) return false;
+        if (!al(d.u8) || !al(d.w0) || (d.b0 && !al(d.b0)) || d.k0 < 1 || d.k0 > 8 || (bsrc != 1 && bsrc != 4)) return false;
         if (d.in_scale && (!al(d.in_scale) || !al(d.in_shift))) return false;
+        if (bsrc == 4) return bs.wh != nullptr && rows % 32 == 0 && launch<2, 4>(d, rows, cin, cout, dz, bs, dw, st, scratch);
         return launch<2, 1>(d, rows, cin, cout, dz, bs, dw, st, scratch);
     }
     if (d.c != cin || !al(d.feat) || bsrc != 0) return false;

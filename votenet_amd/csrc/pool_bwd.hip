@@ -518,6 +518,12 @@ extern "C" int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout
                                                double *below_sums, const votenet_coef_tail *below_tail, void *stream)
 {
     VN_REQUIRE(hc && wh && G > 0 && nh >= G && nh <= 2L * G, "pool_dgrad_scatter_half: bad half-group arguments");
+    VN_REQUIRE(gout && argmax && zsel && coef && wT && da && (uintptr_t)wT % 16 == 0, "pool_dgrad_scatter_half: null / unaligned buffer");
+    VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_dgrad_scatter_half: unsupported shape cin=%d cout=%d", cin, cout);
+    VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
+               "pool_dgrad_scatter_half: below_z given without the layer's BatchNorm vectors / sums");
+    VN_REQUIRE(!below_tail || (below_z && below_tail->ticket && below_tail->gamma && below_tail->coef && below_tail->rows > 0),
+               "pool_dgrad_scatter_half: incomplete coefficient tail");
     return pool_dgrad_scatter_launch(nh, 64, cin, cout, gout, argmax, zsel, coef, relu, wT, da, below_z, below_scale, below_shift, below_mean,
                                      below_var, eps, below_relu, below_sums, below_tail, hc, wh, G, stream);
 }
@@ -546,8 +552,9 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
                            wT, da, pb);
     };
     if (hc) {
-        VN_REQUIRE(cin == 128 && (cout == 256 || cout == 128), "pool_dgrad_scatter_half: served shapes are 128 -> 256 and 128 -> 128");
-        if (cout == 256 && below_z) go(pool_dgrad_scatter_kernel<128, 256, 32, true, 16>, 128, 256, 1024);
+        if (cin == 64 && below_z) go(pool_dgrad_scatter_kernel<64, 128, 32, true>, 64, 128);
+        else if (cin == 64) go(pool_dgrad_scatter_kernel<64, 128, 32, false>, 64, 128);
+        else if (cout == 256 && below_z) go(pool_dgrad_scatter_kernel<128, 256, 32, true, 16>, 128, 256, 1024);
         else if (cout == 256) go(pool_dgrad_scatter_kernel<128, 256, 32, false, 16>, 128, 256, 1024);
         else if (below_z) go(pool_dgrad_scatter_kernel<128, 128, 32, true>, 128, 128);
         else go(pool_dgrad_scatter_kernel<128, 128, 32, false>, 128, 128);
@@ -757,9 +764,10 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
 extern "C" int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram,
                                      void *stream)
 {
-    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) / c && c == 128, "mlp_gram_half expects rows %% 32 == 0 and c == 128");
+    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) / c && (c == 128 || c == 64), "mlp_gram_half expects rows %% 32 == 0 and c in {64, 128}");
     VN_REQUIRE(z && scale_shift && wh && gram && (uintptr_t)z % 16 == 0, "mlp_gram_half: null / unaligned buffer");
-    gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
+    if (c == 128) gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
+    else gram_bf3_launch<64>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
     return check_launch("mlp_gram_half");
 }
 
@@ -769,7 +777,7 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
 {
     VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= 2L * G && hc && wh, "pool_wgrad_sparse_half: bad half-group arguments");
     VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half: bad arguments");
-    VN_REQUIRE(cin == 128 && (cout == 256 || cout == 128), "pool_wgrad_sparse_half: served shapes are 128 -> 256 and 128 -> 128");
+    VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_wgrad_sparse_half: unsupported shape cin=%d cout=%d", cin, cout);
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse_half: in_scale and in_shift go together");
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse_half: operands must be 16-byte aligned");
@@ -783,7 +791,10 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
 {
     const int grid = pb_grid(groups, hc ? 16 : 8, 384); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
-    if (hc)
+    if (hc && cin == 64)
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
+    else if (hc)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
                            in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
     else if (cin == 128)

@@ -444,10 +444,10 @@ class HalfLayout:
         self._ev = torch.cuda.Event()
         self._ev.record()
         self.nh = None
-        self._geo = None
+        self._geo = self._u8 = None  # the level's compact rows: geo records (assembled first layer) or u8 (narrow first layer)
 
     def tensors(self):
-        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo) if t is not None]
+        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo, self._u8) if t is not None]
 
     def resolve(self):
         if self.nh is None:
@@ -457,11 +457,30 @@ class HalfLayout:
                 raise L.VotenetError("half-group layout: bad count %d for %d centres" % (self.nh, self.G))
             self.hc, self.wh = self._hc[:self.nh], self._wh[:self.nh]
             self.geo = self._geo[:self.nh * 32] if self._geo is not None else None
+            self.u8 = self._u8[:self.nh * 32] if self._u8 is not None else None
         return self
 
     @property
     def rows(self):
         return self.resolve().nh * 32
+
+    def full_rows(self, t):
+        """A compact row tensor (32 nh, c) laid out as the full layout (64 G, c): slot s of centre c; a dropped slot holds a copy of
+        slot 0.  (Row VALUES of the forward pass; gradients per compact row are totals and do not expand this way.)  Tests, debugging."""
+        self.resolve()
+        G, dev = self.G, t.device
+        c = torch.arange(G, device=dev)[:, None]
+        s = torch.arange(64, device=dev)[None, :]
+        p2 = self.pos2.long()[:, None]
+        src = torch.where(s < 32, c * 32 + s, torch.where(p2 >= 0, (G + p2) * 32 + s - 32, c * 32))
+        return t[src.reshape(-1)]
+
+    def row_weights(self):
+        """(32 nh,) the number of full-layout rows every compact row stands for."""
+        self.resolve()
+        w = torch.ones(self.nh, 32, device=self.wh.device)
+        w[:, 31] = self.wh
+        return w.reshape(-1)
 
 
 def half_groups(pts_cnt):
@@ -490,6 +509,22 @@ def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
                                                    L.ptr(half._hc), L.ptr(geo), L.ptr(cntv), L.ptr(mom), L.stream_ptr()))
     half._geo = geo
     return geo, cntv, mom
+
+
+def narrow_rows_half(xyz, new_xyz, feat, idx, pts_cnt, half):
+    """narrow_rows on the half-group layout: -> u8 buffer (2 G 32, 8) of which half.resolve().u8 is the written part, moments (72,)."""
+    b, m, k = idx.shape
+    n = xyz.shape[1]
+    c = feat.shape[2] if feat is not None else 0
+    if k != 64:
+        raise L.InvalidArgumentError("narrow_rows_half expects nsample == 64")
+    u8 = torch.empty((2 * b * m * 32, 8), dtype=torch.float32, device=xyz.device)
+    mom = torch.zeros(72, dtype=torch.float64, device=xyz.device)
+    with L.device_guard(xyz.device):
+        L.check(L.lib().votenet_narrow_rows_half(b, n, m, c, L.ptr(half.nh_dev), L.ptr(xyz), L.ptr(new_xyz), L.ptr(feat), L.ptr(idx),
+                                                 L.ptr(pts_cnt), L.ptr(half._hc), L.ptr(u8), L.ptr(mom), L.stream_ptr()))
+    half._u8 = u8
+    return u8, mom
 
 
 def group_linear_backward_half(half, pts_cnt, b, n, P, wx, da, coef, relu, dw_xyz):
@@ -637,7 +672,7 @@ def narrow_stats(rows, mom, w0, b0):
     return stats
 
 
-def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True):
+def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True, half=None):
     """Second layer over the rebuilt first-layer output: z = relu(bn0(u8 w0 + b0)) w + bias -> z (rows, cout), stats."""
     rows = u8.shape[0]
     k0, c0 = w0.shape
@@ -649,6 +684,12 @@ def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True):
         scale, shift = in_bn.scale, in_bn.shift
     else:
         raw = in_bn.raw()
+    if half is not None:
+        with L.device_guard(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow half")):
+            L.check(L.lib().votenet_narrow_linear_half(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
+                                                       ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
+                                                       L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh), L.stream_ptr()))
+        return z, stats
     with L.device_guard(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow")):
         L.check(L.lib().votenet_narrow_linear(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
                                               ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
@@ -656,11 +697,17 @@ def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True):
     return z, stats
 
 
-def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, dw):
+def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, dw, half=None):
     """dw (c0, cout) += relu(bn0(u8 w0 + b0))^T dz1, dz1 = BatchNorm-backward(da, z, coef) formed in the loader."""
     rows = u8.shape[0]
     k0, c0 = w0.shape
     cout = z.shape[1]
+    if half is not None:
+        with L.device_guard(u8.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn narrow half")):
+            L.check(L.lib().votenet_narrow_wgrad_bn_half(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(in_scale), L.ptr(in_shift),
+                                                         1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0,
+                                                         L.ptr(half.wh), L.ptr(dw), L.stream_ptr()))
+        return
     scr = _wgrad_scratch(None, rows, c0, cout, u8.device)
     with L.device_guard(u8.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn narrow")):
         L.check(L.lib().votenet_narrow_wgrad_bn(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(in_scale), L.ptr(in_shift),
@@ -668,7 +715,7 @@ def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, 
                                                 L.ptr(scr), L.stream_ptr()))
 
 
-def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS, tail=None):
+def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS, tail=None, half=None):
     """The input-gradient GEMM of the second layer with nothing stored: -> sums (2*c0 f64: BatchNorm-backward sums of the first
     layer), ug (8, c0) f64 = sum_r u8[r,:]^T da0'[r,:].  below = (scale, shift, mean, var, relu) of the first layer."""
     rows, c = z.shape
@@ -677,11 +724,13 @@ def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS,
     out = _zeros_f64(10 * c0, z.device)
     sums, ug = out[:2 * c0], out[2 * c0:]
     t, coef0 = _coef_tail(tail, c0, z.device)
-    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow")):
-        L.check(L.lib().votenet_narrow_dgrad_bn_reduce(rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
-                                                       L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva),
-                                                       eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug),
-                                                       ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow" + (" half" if half else ""))):
+        args = (rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT), L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc),
+                L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), ctypes.byref(t) if t is not None else None)
+        if half is not None:
+            L.check(L.lib().votenet_narrow_dgrad_bn_reduce_half(*args, L.ptr(half.wh), L.stream_ptr()))
+        else:
+            L.check(L.lib().votenet_narrow_dgrad_bn_reduce(*args, L.stream_ptr()))
     if tail is None:
         return sums, ug.view(8, c0)
     return (coef0 if coef0 is not None else _coef_after(tail, (bsc, bsh, bme, bva), sums, eps)), ug.view(8, c0)  # tail: (coef of the first layer, ug)

@@ -29,7 +29,7 @@ NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the firs
 PAD_RAGGED_IN = True  # ragged INPUT widths (voting's 259) padded as well (Layer.cin_pad); False: the bounds-checked GEMMs (A/B)
 ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
 ASSEMBLE_INLINE = True  # also where the geo records were not computed ahead with the geometry (they are built in place)
-HALF_GROUPS = False    # assembled modules with nsample = 64 drop the all-copy second half of an under-full ball (csrc/half.hip): same results up to summation order, 30-60 % fewer grouped rows on room scenes
+HALF_GROUPS = True     # assembled modules with nsample = 64 drop the all-copy second half of an under-full ball (csrc/half.hip): same results up to summation order, 30-60 % fewer grouped rows on room scenes
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -359,10 +359,11 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
         if i == 0 and first[0] == "narrow":
             # narrow first layer (csrc/narrow.hip): no kernel writes z0 = u8 W0 + b0; its BatchNorm statistics follow from the moments
             # of u8 and the next layer's GEMM rebuilds it in its operand loader
-            _, u8, mom = first
+            _, u8, mom = first[:3]
+            half = first[3] if len(first) > 3 else None  # mlp.HalfLayout: u8 (and every row tensor of the chain) holds compact rows
             zn = None
             st = M.narrow_stats(rows, mom, w, b) if (L.bn and _FROZEN.table is None) else None
-            rec = dict(layer=L, kind="narrow", u8=u8, mom=mom)
+            rec = dict(layer=L, kind="narrow", u8=u8, mom=mom, half=half)
         elif i == 0 and first[0] == "assembled":
             # first layer assembled inside its consumers (csrc/assemble.hip): the per-point GEMM P = feat W[3:] + b is all that runs here;
             # the BatchNorm statistics of z0 = P[idx] + dxyz W[0:3] come from one pass over the points
@@ -378,8 +379,9 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             zn, st = M.assembled_linear(r0["geo"], r0["P"], r0["wx"], w, b, pend, prev_relu, want_stats=L.bn, half=r0["half"])
             rec = dict(layer=L, kind="dense", x=None, assembled=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=r0["half"])
         elif i == 1 and first[0] == "narrow":
-            zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn)
-            rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu)
+            half = tape[-1]["half"]
+            zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn, half=half)
+            rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=half)
         elif i == 0 and first[0] == "gather":
             # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
             # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
@@ -405,7 +407,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
                 M.linear_pool_supported(rows, w.shape[0], w.shape[1], pool_k):
             # training does not store z of this layer either when its backward runs in Gram form (it never reads z)
             gram_form = POOL_GRAM_BACKWARD and pend is not None and M.pool_backward_supported(w.shape[0], w.shape[1], pool_k)
-            half = tape[0].get("half") if first[0] == "assembled" else None
+            half = tape[0].get("half") if first[0] in ("assembled", "narrow") else None
             if half is not None and not (gram_form or not keep_z):
                 raise M.L.VotenetError("half-group layout: the pooled layer's backward must be in Gram form")
             zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend, half=half)
@@ -579,12 +581,12 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 # second layer above a NARROW first layer (i == 1): both GEMMs rebuild z0 from u8; the input-gradient GEMM stores
                 # nothing -- its epilogue leaves the first layer's BatchNorm-backward sums and the data term of its weight gradient
                 r0 = recs[0]
-                L0, u8, mom = r0["layer"], r0["u8"], r0["mom"]
+                L0, u8, mom, half = r0["layer"], r0["u8"], r0["mom"], r0["half"]
                 w0, b0 = L0.p("W"), L0.p("b")
                 on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.narrow_wgrad_bn(
-                    u8, w0, b0, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W")), u8, z, coef, da)
+                    u8, w0, b0, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W"), half=half), u8, z, coef, da)
                 coef0, ug = M.narrow_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, u8, w0, b0,
-                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0))
+                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0), half=half)
                 M.narrow_wgrad_first(mom, ug, coef0, w0, b0, L0.gp("W"))
                 return None  # a leaf: nothing upstream takes a gradient
             if r.get("cin_padded") and not pooled and M.dgrad_bn_supported(rows, c, L.cin_pad):
@@ -723,9 +725,10 @@ class SAModule:
         """True when this module's grouped MLP runs on the half-group layout (csrc/half.hip: the rows that repeat slot 0 dropped by
         halves of a ball) for b scenes of n points: an assembled first layer, three BatchNorm'ed layers, the pooled one in Gram form."""
         m = self.mlp
-        return bool(HALF_GROUPS and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and self.assembled(b, n)
-                    and m[2].bn and POOL_IN_EPILOGUE and POOL_GRAM_BACKWARD and (b * self.npoint) % 4 == 0
-                    and m[1].cout == 128 and m[2].cout in (128, 256) and M.pool_backward_supported(m[1].cout, m[2].cout, 64))
+        if not (HALF_GROUPS and not M.DETERMINISTIC and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and m[2].bn and POOL_IN_EPILOGUE
+                and POOL_GRAM_BACKWARD and (b * self.npoint) % 4 == 0 and M.pool_backward_supported(m[1].cout, m[2].cout, 64)):
+            return False
+        return bool(self.narrow(b * self.npoint * 64) or (m[1].cout == 128 and self.assembled(b, n)))
 
     def geometry(self, xyz, sample_xyz=None, fps_idx=None, points=None, ahead=True):
         """The weight-independent part of the layer (FPS, centres, ball query): can run ahead on a side stream.
@@ -738,7 +741,11 @@ class SAModule:
             idx, pts_cnt = _group_indices(self.radius, self.nsample, xyz, new_xyz, self.knn)
             geom = (fps_idx, new_xyz, idx, pts_cnt)
         if (points is not None or self.cin == 0) and self.narrow(xyz.shape[0] * self.npoint * self.nsample):
-            geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
+            if ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
+                half = M.half_groups(geom[3])
+                geom = tuple(geom) + M.narrow_rows_half(xyz, geom[1], points, geom[2], geom[3], half) + (half,)
+            else:
+                geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
         elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
             half = M.half_groups(geom[3])  # the layout and the count of its half-groups: known on the host by the time the MLP runs
             geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
@@ -758,6 +765,9 @@ class SAModule:
         if self.narrow(rows):
             u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
             first = ("narrow", u8, mom)
+            if len(geom) >= 7:  # half-group layout: the compact rows
+                half = geom[6].resolve()
+                first = ("narrow", half.u8, mom, half)
         elif points is not None and self.assembled(b, xyz.shape[1]) and (len(geom) >= 7 or ASSEMBLE_INLINE):
             geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt, in_pass=True)
             first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
