@@ -500,6 +500,7 @@ void votenet_debug_gram_bf3(int on);
 void votenet_debug_wgrad_bf3(int on);
 /* measurement hook: votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
 void votenet_debug_scatter_reverse(int on);
+void votenet_debug_scatter_form(int form); /* 1 (default): one wavefront per group, no barriers; 0: one workgroup per group */
 
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
 int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);

@@ -300,6 +300,195 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
     }
 }
 
+// The same pass with ONE WAVEFRONT per group and no workgroup barrier inside the loop (the default; the kernel above stays behind
+// votenet_debug_scatter_form(0)).  A group's fixed work -- bucketing cout channels by their arg-max row, ~cout W^T rows to add -- does
+// not shrink with the rows of a group, and with one group per 16-wave workgroup at a time every LDS round trip and every barrier
+// (6 per group) was exposed: 5.4 us per group and CU whatever K.  Here the 8 / 16 wavefronts of a workgroup share only the read-only
+// W^T image; each buckets its own group in a private LDS scratch (LDS operations of one wavefront execute in order: the lanes of one
+// ds_add_rtn are served in lane order and the four are issued in channel order, so a row's channels sit in ascending order and da is
+// reproducible bit for bit), scans the K counters with lane shuffles, then walks the rows -- their da / z rows prefetched eight at a
+// time, one batch ahead, across groups -- adding the W^T rows of each row's channels.  Channels whose masked gradient is zero are not
+// listed at all.
+template <int CIN, int COUT, int K, bool RED, int NWV>
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) void pool_dgrad_scatter_wave_kernel(long groups, const float *__restrict__ gout,
+                                                                           const int *__restrict__ argmax, const float *__restrict__ zsel,
+                                                                           const float *__restrict__ coef, int relu,
+                                                                           const float *__restrict__ wT, float *__restrict__ da, PoolBelow pb)
+{
+    static_assert(K == 64 || K == 32, "one lane per row in the prefix scan");
+    constexpr bool HALF = K == 32;
+    constexpr int PL = CIN / 64;  // floats per lane of a row
+    constexpr int NJ = COUT / 64; // channels per lane
+    constexpr int RB = 4;         // rows per prefetch batch (two batches in flight; 128 VGPRs per wavefront)
+    constexpr int NB = K / RB;    // batches per group (even: batch 0 of every group lives in register set 0)
+    constexpr int WS = COUT * 6 + K * 4; // bytes of a wavefront's scratch: values, channels (16 bit), counters
+    extern __shared__ __attribute__((aligned(16))) float pds_smem[];
+    float *Wl = pds_smem; // [COUT][CIN]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    unsigned char *scratch = reinterpret_cast<unsigned char *>(Wl + COUT * CIN) + (size_t)wv * WS;
+    float *lv = reinterpret_cast<float *>(scratch);                             // [COUT] A g' of the listed channels, row by row
+    unsigned short *lc = reinterpret_cast<unsigned short *>(scratch + COUT * 4); // [COUT] their channel numbers
+    int *cnt = reinterpret_cast<int *>(scratch + COUT * 6);                     // [K]
+    for (int e = tid; e < COUT * CIN / 4; e += NWV * 64) reinterpret_cast<float4 *>(Wl)[e] = reinterpret_cast<const float4 *>(wT)[e];
+    if (lane < K) cnt[lane] = 0;
+    float cA[NJ], cS[NJ], cH[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+        cA[j] = coef[j * 64 + lane];
+        cS[j] = coef[3 * COUT + j * 64 + lane];
+        cH[j] = coef[4 * COUT + j * 64 + lane];
+    }
+    float bS[PL], bH[PL], bM[PL], bI[PL], s1[PL], s2[PL];
+#pragma unroll
+    for (int q = 0; q < PL; q++) {
+        s1[q] = s2[q] = 0.0f;
+        bS[q] = bH[q] = bM[q] = bI[q] = 0.0f;
+        if (RED) {
+            const int j = lane * PL + q;
+            bS[q] = pb.scale[j];
+            bH[q] = pb.shift[j];
+            bM[q] = pb.mean[j];
+            bI[q] = 1.0f / sqrtf(pb.var[j] + pb.eps);
+        }
+    }
+    __syncthreads(); // W^T is in place; from here on the wavefronts run on their own
+    const long stride = (long)gridDim.x * NWV;
+    float nz[NJ], ng[NJ], nw = 1.0f;
+    int na[NJ];
+    auto fetch = [&](long g) {
+        const long ctr = HALF ? (long)pb.hc[g] : g;
+        if (HALF) nw = pb.wh[g];
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            nz[j] = zsel[(size_t)ctr * COUT + j * 64 + lane];
+            ng[j] = gout[(size_t)ctr * COUT + j * 64 + lane];
+            int a = argmax[(size_t)ctr * COUT + j * 64 + lane];
+            if (HALF) {
+                a -= g >= pb.G ? 32 : 0;
+                if (a < 0 || a >= 32) a = -1; // the centre's other half holds this channel's arg-max
+            }
+            na[j] = a;
+        }
+    };
+    struct Rows {
+        float d[RB][PL], z[RB][PL];
+    };
+    Rows R0, R1;
+    auto load_rows = [&](Rows &r, long g, int rb) {
+#pragma unroll
+        for (int u = 0; u < RB; u++)
+#pragma unroll
+            for (int q = 0; q < PL; q++) {
+                const size_t off = ((size_t)g * K + rb * RB + u) * CIN + lane * PL + q;
+                r.d[u][q] = da[off];
+                if (RED) r.z[u][q] = pb.z[off];
+            }
+    };
+    long gi = (long)blockIdx.x * NWV + wv;
+    if (gi < groups) {
+        fetch(gi);
+        load_rows(R0, gi, 0);
+    }
+    for (; gi < groups; gi += stride) {
+        const long g = gi, gn = gi + stride;
+        float v[NJ];
+        int row[NJ], pos[NJ];
+        const float w31 = nw;
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            float gg = ng[j];
+            if (relu && !(nz[j] * cS[j] + cH[j] > 0.0f)) gg = 0.0f;
+            v[j] = cA[j] * gg;
+            row[j] = v[j] != 0.0f ? na[j] : -1; // nothing to add: not listed
+        }
+        if (gn < groups) fetch(gn);
+#pragma unroll
+        for (int j = 0; j < NJ; j++) pos[j] = row[j] >= 0 ? atomicAdd(&cnt[row[j]], 1) : 0;
+        const int c0 = lane < K ? cnt[lane] : 0;
+        int x = c0; // exclusive prefix of the K counters: one lane per row
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off);
+            if (lane >= off) x += t;
+        }
+        const int start = x - c0;
+        if (lane < K) cnt[lane] = 0; // ready for the next group
+#pragma unroll
+        for (int j = 0; j < NJ; j++) {
+            const int st = __shfl(start, row[j] >= 0 ? row[j] : 0);
+            if (row[j] >= 0) {
+                lc[st + pos[j]] = (unsigned short)(j * 64 + lane);
+                lv[st + pos[j]] = v[j];
+            }
+        }
+        auto batch = [&](const Rows &r, int rb) {
+#pragma unroll
+            for (int u = 0; u < RB; u++) {
+                const int rr = rb * RB + u;
+                const int n = __builtin_amdgcn_readlane(c0, rr), s0 = __builtin_amdgcn_readlane(start, rr);
+                const bool scaled = HALF && rr == 31 && w31 != 1.0f;
+                float acc[PL];
+#pragma unroll
+                for (int q = 0; q < PL; q++) acc[q] = scaled ? r.d[u][q] * w31 : r.d[u][q];
+                for (int i = 0; i < n; i += 4) {
+                    int c[4];
+                    float vv[4];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) {
+                        const bool ok = i + t < n;
+                        c[t] = lc[s0 + (ok ? i + t : i)];
+                        vv[t] = ok ? lv[s0 + i + t] : 0.0f;
+                    }
+#pragma unroll
+                    for (int t = 0; t < 4; t++)
+#pragma unroll
+                        for (int q = 0; q < PL; q++) acc[q] += vv[t] * Wl[c[t] * CIN + lane * PL + q];
+                }
+                if (n != 0 || scaled) {
+                    float *drow = da + ((size_t)g * K + rr) * CIN + lane * PL;
+#pragma unroll
+                    for (int q = 0; q < PL; q++) drow[q] = acc[q];
+                }
+                if (RED) {
+#pragma unroll
+                    for (int q = 0; q < PL; q++) {
+                        const float zz2 = r.z[u][q];
+                        const float gp = (pb.relu && !(zz2 * bS[q] + bH[q] > 0.0f)) ? 0.0f : acc[q];
+                        s1[q] += gp;
+                        s2[q] += gp * ((zz2 - bM[q]) * bI[q]);
+                    }
+                }
+            }
+        };
+#pragma unroll 1
+        for (int rb = 0; rb < NB; rb += 2) {
+            load_rows(R1, g, rb + 1);
+            batch(R0, rb);
+            if (rb + 2 < NB) load_rows(R0, g, rb + 2);
+            else if (gn < groups) load_rows(R0, gn, 0);
+            batch(R1, rb + 1);
+        }
+    }
+    if (RED) { // combine the wavefronts' column sums in LDS (W^T is no longer needed), one fp64 atomic per column and workgroup
+        __syncthreads();
+        float *red = Wl; // [NWV][2][CIN]
+#pragma unroll
+        for (int q = 0; q < PL; q++) {
+            red[(wv * 2 + 0) * CIN + lane * PL + q] = s1[q];
+            red[(wv * 2 + 1) * CIN + lane * PL + q] = s2[q];
+        }
+        __syncthreads();
+        for (int e = tid; e < 2 * CIN; e += NWV * 64) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w8 = 0; w8 < NWV; w8++) t += red[w8 * 2 * CIN + e];
+            unsafeAtomicAdd(&pb.sums[e], (double)t);
+        }
+        coef_tail(pb.tail, gridDim.x, CIN, pb.sums, pb.scale, pb.shift, pb.mean, pb.var, pb.eps);
+    }
+}
+
 // dW[:, c] += sum_g x[g*k + argmax[g,c], :] * A[c] g'[g,c]   and   colsum[j] += sum_r x[r, j]
 // x = act(xz * in_scale + in_shift) staged per group in LDS; thread c owns output column c (CIN accumulators).
 // K = 32: the half-group layout (half.hip) -- a "group" is a half-group h of 32 compact rows of xz, gout / argmax / zsel are per centre
@@ -488,6 +677,8 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
 
 static int g_scatter_reverse = 0;
 extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
+static int g_scatter_form = 1; // 1: one wavefront per group (pool_dgrad_scatter_wave_kernel), 0: one workgroup per group
+extern "C" void votenet_debug_scatter_form(int form) { g_scatter_form = form ? 1 : 0; }
 static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
                                      const float *coef, int relu, const float *wT, float *da, const float *below_z,
                                      const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
@@ -551,6 +742,40 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
         hipLaunchKernelGGL(kern, dim3(pb_grid(groups, 2, 256 * per_cu)), dim3(threads), smem, st, groups, gout, argmax, zsel, coef, relu,
                            wT, da, pb);
     };
+    // one wavefront per group (the default)
+    auto gow = [&](auto kern, int ci, int co, int kk, int nwv) {
+        const size_t smem = (size_t)co * ci * 4 + (size_t)nwv * (co * 6 + kk * 4);
+        const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
+        static std::set<const void *> raised_w;
+        static std::mutex raised_w_mu;
+        bool fresh;
+        {
+            std::lock_guard<std::mutex> lock(raised_w_mu);
+            fresh = raised_w.insert(reinterpret_cast<const void *>(kern)).second;
+        }
+        if (fresh)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, nwv, 256 * per_cu)), dim3(nwv * 64), smem, st, groups, gout, argmax, zsel, coef, relu, wT,
+                           da, pb);
+    };
+    if (g_scatter_form == 1) {
+#define VN_SCATTER_WAVE(CI, CO, KK, NW)                                                            \
+    do {                                                                                           \
+        if (below_z) gow(pool_dgrad_scatter_wave_kernel<CI, CO, KK, true, NW>, CI, CO, KK, NW);   \
+        else gow(pool_dgrad_scatter_wave_kernel<CI, CO, KK, false, NW>, CI, CO, KK, NW);          \
+    } while (0)
+        if (hc) {
+            if (cin == 64) VN_SCATTER_WAVE(64, 128, 32, 8);
+            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 32, 16);
+            else VN_SCATTER_WAVE(128, 128, 32, 8);
+        } else {
+            if (cin == 64) VN_SCATTER_WAVE(64, 128, 64, 8);
+            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 64, 16);
+            else VN_SCATTER_WAVE(128, 128, 64, 8);
+        }
+#undef VN_SCATTER_WAVE
+        return check_launch("pool_dgrad_scatter");
+    }
     if (hc) {
         if (cin == 64 && below_z) go(pool_dgrad_scatter_kernel<64, 128, 32, true>, 64, 128);
         else if (cin == 64) go(pool_dgrad_scatter_kernel<64, 128, 32, false>, 64, 128);
