@@ -522,10 +522,26 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
     const float fl = (in_scale && in_relu) ? 0.0f : -__builtin_inff();
     constexpr int NL = K * Q / 256; // float4 per thread per group tile
     float4 nxt[NL];
+    float n_g = 0.0f, n_z = 0.0f, n_w = 1.0f; // the group's pooled gradient / raw arg-max value / arg-max row of this thread's channel,
+    int n_a = 0;                              // fetched with the tile, one group ahead (they were a loaded-memory latency per group)
     auto fetch = [&](long g) {
         const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)g * K * CIN);
 #pragma unroll
         for (int h = 0; h < NL; h++) nxt[h] = src[tid + h * 256];
+        const long ctr = HALF ? (long)hc[g] : g;
+        if (HALF) n_w = wh[g];
+        if (own) {
+            n_z = zsel[(size_t)ctr * cout + tid];
+            n_g = gout[(size_t)ctr * cout + tid];
+            n_a = argmax[(size_t)ctr * cout + tid];
+            if (HALF) {
+                n_a -= g >= G ? 32 : 0;
+                if (n_a < 0 || n_a >= 32) { // the centre's other half holds this channel's arg-max
+                    n_a = 0;
+                    n_g = 0.0f;
+                }
+            }
+        }
     };
     if ((long)blockIdx.x < groups) fetch(blockIdx.x);
     for (long g = blockIdx.x; g < groups; g += gridDim.x) {
@@ -538,24 +554,11 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
             v.w = fmaxf(v.w * sc.w + sh.w, fl);
             *reinterpret_cast<float4 *>(&xs[(tid + h * 256) / Q][q * 4]) = v;
         }
+        float gg = n_g;
+        const float zz = n_z, w31 = n_w;
+        const int ar = n_a;
         const long gn = g + gridDim.x;
         fetch(gn < groups ? gn : g); // the next tile travels while this one is used
-        float gg = 0.0f, zz = 0.0f;
-        int ar = 0;
-        const long ctr = HALF ? (long)hc[g] : g;
-        const float w31 = HALF ? wh[g] : 1.0f;
-        if (own) {
-            zz = zsel[(size_t)ctr * cout + tid];
-            gg = gout[(size_t)ctr * cout + tid];
-            ar = argmax[(size_t)ctr * cout + tid];
-            if (HALF) {
-                ar -= g >= G ? 32 : 0;
-                if (ar < 0 || ar >= 32) { // the centre's other half holds this channel's arg-max
-                    ar = 0;
-                    gg = 0.0f;
-                }
-            }
-        }
         __syncthreads();
         if (own) {
             if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
@@ -967,6 +970,8 @@ extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *s
     return check_launch("mlp_gram");
 }
 
+static int g_sparse_wgs = 384;
+extern "C" void votenet_debug_sparse_workgroups(int n) { g_sparse_wgs = n > 0 ? n : 384; } // tuning hook
 static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
                                     float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream);
@@ -1014,7 +1019,7 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
                                     float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream)
 {
-    const int grid = pb_grid(groups, hc ? 16 : 8, 384); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
+    const int grid = pb_grid(groups, hc ? 16 : 8, g_sparse_wgs); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
     if (hc && cin == 64)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
@@ -1039,7 +1044,7 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
 extern "C" size_t votenet_pool_wgrad_scratch_floats(long groups, int cin, int cout)
 {
     if (groups <= 0) return 0;
-    return (size_t)pb_grid(groups, 8, 384) * (size_t)(cin + 1) * cout;
+    return (size_t)pb_grid(groups, 8, g_sparse_wgs) * (size_t)(cin + 1) * cout;
 }
 
 extern "C" int votenet_pool_wgrad_finish(int cin, int cout, const float *gram, const float *colsum, const float *w, const float *bias,
