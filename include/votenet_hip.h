@@ -704,6 +704,15 @@ int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const flo
                                            const float *scale_prev, const float *shift_prev, const float *mean_prev,
                                            const float *var_prev, float eps, int relu_prev, double *sums,
                                            const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
+/* The scatter to the points without one atomic per row (an fp32 atomic costs an L2 channel ~14 cycles per line): with the geometry,
+ * votenet_half_sort_rows buckets the compact rows by the point they gather (order: 2G*32 ints, 32*nh[0] written; work: npts ints);
+ * votenet_group_linear_backward_sorted then sums a point's consecutive rows in a register and stores S point by point
+ * (s_points pre-zeroed; atomics only where a chunk of 64 entries shares a point with its neighbour).  Same sums as
+ * votenet_group_linear_backward_half in another order. */
+int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream);
+int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
+                                         const float *wx, const float *da, const float *coef, int relu, float *s_points, float *dw_xyz,
+                                         void *stream);
 /* The narrow first layer (sa1) on the same layout: u8 (up to 2G*32 x 8 floats; moments over the true rows), the second layer's GEMMs. */
 int votenet_narrow_rows_half(int b, int n, int m, int c, const int *nh, const float *xyz, const float *new_xyz, const float *feat,
                              const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream);

@@ -163,8 +163,18 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     dwx, dwxh = torch.zeros(3, c0, device=dev), torch.zeros(3, c0, device=dev)
     da0t = _totals(da0, half, dev).float()
     S, _ = M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, P, wx, da0, coef0, True, dwx)
+    assert getattr(half, "order", None) is None  # not sorted yet: the row-major pass with its atomics
     Sh = M.group_linear_backward_half(half, cnt, b, n, P, wx, da0t, coef0, True, dwxh)
     assert relerr(Sh, S) < 1e-5 and relerr(dwxh, dwx) < 1e-4
+    # the same over the rows bucketed by point: every compact row once, the rows of a point consecutive
+    M.half_sort_rows(half, b * n)
+    order = half.order.long()
+    assert torch.equal(torch.sort(order)[0], torch.arange(half.rows, device=dev))
+    prow_sorted = half.geo[order, 3].view(torch.int32)
+    assert bool((prow_sorted[1:] >= prow_sorted[:-1]).all())
+    dwxs = torch.zeros(3, c0, device=dev)
+    Ss = M.group_linear_backward_half(half, cnt, b, n, P, wx, da0t, coef0, True, dwxs)
+    assert relerr(Ss, S) < 1e-5 and relerr(dwxs, dwx) < 1e-4
     img.close()
 
 

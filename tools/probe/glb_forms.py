@@ -26,7 +26,13 @@ for name, rec in zip(("sa2", "sa3", "sa4"), tape[1:4]):
     da_f = torch.randn(rows, c, device=dev)
     z0 = M.assemble_z0(M.assemble_rows(xyz, new_xyz, idx, pts_cnt=cnt)[0], r0["P"], r0["wx"])
     M.arena_begin(dev)
+    M.SORTED_SCATTER = False
     t_half = timeit(lambda: M.group_linear_backward_half(half, cnt, b, n, r0["P"], r0["wx"], da_h, coef, True, dw))
+    M.SORTED_SCATTER = True
+    if getattr(half, "order", None) is None:
+        M.half_sort_rows(half, b * n)
+    t_sort = timeit(lambda: M.half_sort_rows(half, b * n))
+    t_sorted = timeit(lambda: M.group_linear_backward_half(half, cnt, b, n, r0["P"], r0["wx"], da_h, coef, True, dw))
     t_full = timeit(lambda: M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, r0["P"], r0["wx"], da_f, coef, True, dw))
     t_fullz = timeit(lambda: M.group_linear_backward(xyz, new_xyz, idx, cnt, z0, da_f, coef, True, dw))
     prev = M.set_deterministic(True)
@@ -34,5 +40,5 @@ for name, rec in zip(("sa2", "sa3", "sa4"), tape[1:4]):
     t_gather = timeit(lambda: M.group_linear_backward(xyz, new_xyz, idx, cnt, z0, da_f, coef, True, dw))
     M.set_deterministic(prev)
     M.arena_end()
-    print("%s: rows %d (half %d)  atomics full/assembled %.1f us  full/stored z %.1f us  gather (stored z, inverse index) %.1f us  atomics half %.1f us"
-          % (name, rows, half.rows, t_full, t_fullz, t_gather, t_half), flush=True)
+    print("%s: rows %d (half %d)  atomics full/assembled %.1f us  full/stored z %.1f us  gather (stored z, inverse index) %.1f us  atomics half %.1f us  sorted half %.1f us (+ %.1f us bucketing with the geometry)"
+          % (name, rows, half.rows, t_full, t_fullz, t_gather, t_half, t_sorted, t_sort), flush=True)

@@ -315,6 +315,177 @@ __global__ __launch_bounds__(256) void group_linear_bwd_half_kernel(int nh, int 
     }
 }
 
+// ---- the first layer's scatter to the points WITHOUT one atomic per row: the compact rows sorted by the point they gather -----------------
+// An fp32 atomic costs an L2 channel ~14 cycles per 64-byte line whatever the number of active lanes (tools/probe/src/atomic_scope.hip:
+// 300 G adds/s), which made the row-major pass above atomic-bound at twice the time of its loads.  The grouping depends on coordinates
+// only, so with the geometry (a step ahead, off the chain) the compact rows are bucketed by point: count, scan, fill -> order (32 nh).
+// The backward pass then walks CHUNKS of 64 consecutive entries: the rows of a point are consecutive, a thread (one channel) sums them
+// in a register and stores the point's row of S once; only a chunk's first and last point can be shared with a neighbour chunk and are
+// added with atomics -- 2 per 64 rows instead of ~30.
+// A ball's copies of slot 0 are consecutive rows with one point, and a few points are slot 0 of hundreds of balls: one atomic per RUN of
+// equal points inside a wavefront (the run's first lane adds the run's length), not one per row, or those addresses serialise the pass.
+__device__ __forceinline__ void half_sort_runs(unsigned prow, bool live, int lane, int &run_start, int &run_len)
+{
+    const unsigned prev = __shfl_up(prow, 1);
+    const bool prev_live = __shfl_up((int)live, 1) != 0;
+    const bool starts = live && (lane == 0 || !prev_live || prev != prow);
+    const unsigned long long sm = __ballot(starts), lm = __ballot(live);
+    // the run this lane belongs to starts at the highest start bit at or below the lane; it ends before the next start / the first dead lane
+    const unsigned long long below = sm & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    run_start = below ? 63 - __builtin_clzll(below) : 0;
+    const unsigned long long after = (sm | ~lm) & ~((run_start == 63) ? ~0ull : ((1ull << (run_start + 1)) - 1ull));
+    const int end = after ? __builtin_ctzll(after) : 64;
+    run_len = end - run_start;
+}
+__global__ __launch_bounds__(256) void half_sort_count_kernel(const int *__restrict__ nh_dev, const float4 *__restrict__ geo,
+                                                              int *__restrict__ count)
+{
+    const long rows = (long)nh_dev[0] * 32;
+    const int lane = threadIdx.x & 63;
+    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+        const long r = r0 + threadIdx.x;
+        const bool live = r < rows;
+        const unsigned prow = live ? __float_as_uint(geo[r].w) : 0u;
+        int rs, rl;
+        half_sort_runs(prow, live, lane, rs, rl);
+        if (live && rs == lane) atomicAdd(&count[prow], rl);
+    }
+}
+// one workgroup: count[p] -> the exclusive prefix (the fill's cursor of point p)
+__global__ __launch_bounds__(1024) void half_sort_scan_kernel(int npts, int *__restrict__ count)
+{
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int p0 = 0; p0 < npts; p0 += 1024) {
+        const int p = p0 + tid;
+        const int c = p < npts ? count[p] : 0;
+        int x = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off);
+            if (lane >= off) x += t;
+        }
+        if (lane == 63) s_wave[wv] = x;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wv; w++) base += s_wave[w];
+        if (p < npts) count[p] = base + x - c;
+        __syncthreads();
+        if (tid == 1023) s_carry = base + x;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void half_sort_fill_kernel(const int *__restrict__ nh_dev, const float4 *__restrict__ geo,
+                                                             int *__restrict__ cursor, int *__restrict__ order)
+{
+    const long rows = (long)nh_dev[0] * 32;
+    const int lane = threadIdx.x & 63;
+    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+        const long r = r0 + threadIdx.x;
+        const bool live = r < rows;
+        const unsigned prow = live ? __float_as_uint(geo[r].w) : 0u;
+        int rs, rl;
+        half_sort_runs(prow, live, lane, rs, rl);
+        int base = 0;
+        if (live && rs == lane) base = atomicAdd(&cursor[prow], rl);
+        base = __shfl(base, rs);
+        if (live) order[base + (lane - rs)] = (int)r;
+    }
+}
+
+template <int COUT>
+__global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows, const int *__restrict__ order, const float4 *__restrict__ geo,
+                                                                      const float *__restrict__ wh, const float *__restrict__ ptab,
+                                                                      const float *__restrict__ wx, const float *__restrict__ da,
+                                                                      const float *__restrict__ coef, int relu, float *__restrict__ spt,
+                                                                      float *__restrict__ dw_xyz)
+{
+    constexpr int CPB = 256 / COUT; // chunks per workgroup pass
+    constexpr int CH = 64;          // entries per chunk
+    __shared__ int s_row[CPB][CH];
+    __shared__ float4 s_geo[CPB][CH];
+    __shared__ float s_w[CPB][CH];
+    __shared__ float red[256][3];
+    const int tid = threadIdx.x;
+    const int ch = tid % COUT, cl = tid / COUT;
+    const float kA = coef[ch], kB = coef[COUT + ch], kC = coef[2 * COUT + ch], kS = coef[3 * COUT + ch], kH = coef[4 * COUT + ch];
+    const float wx0 = wx[ch], wx1 = wx[COUT + ch], wx2 = wx[2 * COUT + ch];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    const long nchunk = (rows + CH - 1) / CH;
+    for (long c0 = (long)blockIdx.x * CPB; c0 < nchunk; c0 += (long)gridDim.x * CPB) {
+        lds_barrier(); // the previous pass's records are consumed
+        if (tid < CPB * CH) {
+            const long e = c0 * CH + tid;
+            int r = -1;
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            float w = 1.0f;
+            if (e < rows) {
+                r = order[e];
+                g4 = geo[r];
+                if ((r & 31) == 31) w = wh[r >> 5];
+            }
+            s_row[tid / CH][tid % CH] = r;
+            s_geo[tid / CH][tid % CH] = g4;
+            s_w[tid / CH][tid % CH] = w;
+        }
+        lds_barrier();
+        if (c0 + cl >= nchunk) continue;
+        unsigned cur = 0xffffffffu;
+        float acc = 0.0f;
+        bool first = true;
+#pragma unroll 1
+        for (int e0 = 0; e0 < CH; e0 += 8) {
+            float gg[8], zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = s_row[cl][e0 + u];
+                const int rr = r < 0 ? 0 : r;
+                gg[u] = da[(size_t)rr * COUT + ch];
+                zz[u] = ptab[(size_t)__float_as_uint(s_geo[cl][e0 + u].w) * COUT + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (s_row[cl][e0 + u] < 0) continue; // past the end of the list (the last chunk)
+                const float4 g4 = s_geo[cl][e0 + u];
+                const unsigned prow = __float_as_uint(g4.w);
+                if (prow != cur) { // the rows of a point are consecutive: its sum is complete
+                    if (cur != 0xffffffffu) {
+                        if (first) unsafeAtomicAdd(&spt[(size_t)cur * COUT + ch], acc); // may continue the previous chunk's last point
+                        else spt[(size_t)cur * COUT + ch] = acc;
+                        first = false;
+                    }
+                    cur = prow;
+                    acc = 0.0f;
+                }
+                const float z = assembled_z(zz[u], g4, wx0, wx1, wx2);
+                float gq = gg[u];
+                if (relu && !(z * kS + kH > 0.0f)) gq = 0.0f;
+                const float d = kA * gq + s_w[cl][e0 + u] * (kB + kC * z);
+                a0 += g4.x * d;
+                a1 += g4.y * d;
+                a2 += g4.z * d;
+                acc += d;
+            }
+        }
+        if (cur != 0xffffffffu) unsafeAtomicAdd(&spt[(size_t)cur * COUT + ch], acc); // may continue in the next chunk
+    }
+    red[tid][0] = a0;
+    red[tid][1] = a1;
+    red[tid][2] = a2;
+    __syncthreads();
+    if (tid < COUT) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float t = 0.0f;
+            for (int q = 0; q < CPB; q++) t += red[q * COUT + tid][d];
+            unsafeAtomicAdd(&dw_xyz[(size_t)d * COUT + tid], t);
+        }
+    }
+}
+
 } // namespace votenet
 
 using namespace votenet;
@@ -396,4 +567,49 @@ extern "C" int votenet_group_linear_backward_half(long nh, int G, int cout, cons
         hipLaunchKernelGGL(group_linear_bwd_half_kernel<1>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
                            da, coef, relu, s_points, dw_xyz);
     return check_launch("group_linear_backward_half");
+}
+
+// order (2 G 32 ints; 32 nh[0] written) = the level's compact rows bucketed by the point they gather (geo[r].w); work: npts ints.
+// Coordinates only: runs with the geometry.  The order inside a bucket is whatever the fill's atomics decide.
+extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream)
+{
+    VN_REQUIRE(npts > 0 && G > 0 && nh && geo && work && order, "half_sort_rows: bad arguments");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "half_sort_rows: geo must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    if (hipMemsetAsync(work, 0, (size_t)npts * sizeof(int), st) != hipSuccess) return set_error(VOTENET_E_HIP, "half_sort_rows: memset failed");
+    const long max_rows = 2L * G * 32;
+    long gx = (max_rows * 3 / 4 + 256 * 4 - 1) / (256 * 4);
+    if (gx > 2048) gx = 2048;
+    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
+    hipLaunchKernelGGL(half_sort_count_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work);
+    hipLaunchKernelGGL(half_sort_scan_kernel, dim3(1), dim3(1024), 0, st, npts, work);
+    hipLaunchKernelGGL(half_sort_fill_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work, order);
+    return check_launch("half_sort_rows");
+}
+
+// votenet_group_linear_backward_half over the sorted rows: same sums, S written point by point (atomics only where a chunk of 64
+// entries shares a point with its neighbour).  s_points pre-zeroed (points nobody gathers keep their zeros).
+extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
+                                                    const float *wx, const float *da, const float *coef, int relu, float *s_points,
+                                                    float *dw_xyz, void *stream)
+{
+    VN_REQUIRE(nh > 0 && (cout == 64 || cout == 128 || cout == 256), "group_linear_backward_sorted expects nh > 0, cout in {64, 128, 256}");
+    VN_REQUIRE(order && geo && wh && P && wx && da && coef && s_points && dw_xyz, "group_linear_backward_sorted: null buffer");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_sorted: geo must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    const long rows = nh * 32, nchunk = (rows + 63) / 64;
+    const int cpb = 256 / cout;
+    long gx = (nchunk + cpb - 1) / cpb;
+    if (gx > 8192) gx = 8192;
+    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
+    if (cout == 128)
+        hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<128>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
+                           s_points, dw_xyz);
+    else if (cout == 64)
+        hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<64>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
+                           s_points, dw_xyz);
+    else
+        hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
+                           s_points, dw_xyz);
+    return check_launch("group_linear_backward_sorted");
 }

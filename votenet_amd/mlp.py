@@ -445,9 +445,10 @@ class HalfLayout:
         self._ev.record()
         self.nh = None
         self._geo = self._u8 = None  # the level's compact rows: geo records (assembled first layer) or u8 (narrow first layer)
+        self._order = None           # the compact rows bucketed by the point they gather (sort_rows)
 
     def tensors(self):
-        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo, self._u8) if t is not None]
+        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo, self._u8, self._order) if t is not None]
 
     def resolve(self):
         if self.nh is None:
@@ -458,6 +459,7 @@ class HalfLayout:
             self.hc, self.wh = self._hc[:self.nh], self._wh[:self.nh]
             self.geo = self._geo[:self.nh * 32] if self._geo is not None else None
             self.u8 = self._u8[:self.nh * 32] if self._u8 is not None else None
+            self.order = self._order[:self.nh * 32] if self._order is not None else None
         return self
 
     @property
@@ -527,10 +529,32 @@ def narrow_rows_half(xyz, new_xyz, feat, idx, pts_cnt, half):
     return u8, mom
 
 
+SORTED_SCATTER = True  # the first layer's scatter to the points over rows bucketed by point (no atomic per row): csrc/half.hip
+
+
+def half_sort_rows(half, npts):
+    """Bucket the layout's compact rows by the point they gather (geo must be assembled): half.order.  Geometry only."""
+    dev = half._geo.device
+    work = torch.empty(npts, dtype=torch.int32, device=dev)
+    order = torch.empty(2 * half.G * 32, dtype=torch.int32, device=dev)
+    with L.device_guard(dev):
+        L.check(L.lib().votenet_half_sort_rows(npts, half.G, L.ptr(half.nh_dev), L.ptr(half._geo), L.ptr(work), L.ptr(order), L.stream_ptr()))
+    half._order = order
+    if half.nh is not None:  # the count is known already
+        half.order = order[:half.nh * 32]
+    return order
+
+
 def group_linear_backward_half(half, pts_cnt, b, n, P, wx, da, coef, relu, dw_xyz):
     """group_linear_backward_assembled on the half-group layout (da = total gradients per compact row) -> S (b, n, cout)."""
     cout = P.shape[1]
     S = _zeros_f32((b, n, cout), P.device)
+    if SORTED_SCATTER and getattr(half, "order", None) is not None:
+        with L.device_guard(P.device):
+            L.check(L.lib().votenet_group_linear_backward_sorted(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(half.wh), L.ptr(P),
+                                                                 L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
+                                                                 L.stream_ptr()))
+        return S
     with L.device_guard(P.device):
         L.check(L.lib().votenet_group_linear_backward_half(half.nh, half.G, cout, L.ptr(half.geo), L.ptr(pts_cnt), L.ptr(half.hc), L.ptr(half.wh),
                                                            L.ptr(P), L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S),

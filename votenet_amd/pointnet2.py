@@ -749,6 +749,8 @@ class SAModule:
         elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
             half = M.half_groups(geom[3])  # the layout and the count of its half-groups: known on the host by the time the MLP runs
             geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
+            if M.SORTED_SCATTER:  # the rows bucketed by point, for the first layer's backward
+                M.half_sort_rows(half, xyz.shape[0] * xyz.shape[1])
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
             geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3], in_pass=not ahead)  # geo records + per-point sums: coordinates only
         return geom
