@@ -422,6 +422,41 @@ def main():
                      "what": "same workload, votenet_debug_fast_bf3(0) + votenet_debug_gram_bf3(0) + votenet_debug_wgrad_bf3(0): every GEMM product on "
                              "v_mfma_f32_32x32x2_f32 instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
 
+    # the same step on the FULL row layout (64 rows per ball, copies of slot 0 included: the reference's tensor shape), and what the
+    # half-group layout keeps of each level's grouped rows on these scenes
+    full_step = row_layout = None
+    if world == 1 and not args.headline_only and workload == "train":
+        from votenet_amd import pointnet2 as vp2
+        if vp2.HALF_GROUPS:
+            tape = []
+            net.forward(xs[0], tape)
+            kept = {}
+            for name, rec in zip(("sa1", "sa2", "sa3", "sa4"), tape[:4]):
+                half = rec["recs"][0].get("half")
+                if half is not None:
+                    kept[name] = round(half.rows / float(rec["idx"].numel()), 3)
+            row_layout = {"half_groups": True, "grouped_rows_kept": kept,
+                          "what": "a ball with pts_cnt <= 31 (tf_grouping_g.cu:26-29 pads it with copies of its first hit) keeps slots 0..31 only, "
+                                  "slot 31 standing for the 33 dropped copies with weight 33 in the BatchNorm sums (csrc/half.hip): the same results "
+                                  "up to summation order; every GEMM of sa1-sa4 runs on these rows, so executed flops and gemm time both shrink"}
+            vp2.HALF_GROUPS = False
+            try:
+                for _ in range(4):
+                    step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(10):
+                    step()
+                torch.cuda.synchronize()
+                dt5 = time.perf_counter() - t1
+            finally:
+                vp2.HALF_GROUPS = True
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            full_step = {"value": round(B * 10 / dt5, 2), "ms_per_step": round(dt5 / 10 * 1e3, 3), "steps": 10,
+                         "what": "same workload with pointnet2.HALF_GROUPS = False: all 64 rows of every ball through the grouped MLP"}
+
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None
     if rank == 0 and not args.headline_only:
@@ -627,7 +662,7 @@ def main():
                                "likewise the Gram matrices of the pooled layers' backward and the weight-gradient GEMMs; a few GEMMs on matrices made on the "
                                "fly (W diag(C) W^T of the Gram-form input gradient) stay on fp32 MFMA; tests hold both forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
-            "fp32_mfma_gemms": fp32_step, "configs": cfgs,
+            "fp32_mfma_gemms": fp32_step, "full_row_layout": full_step, "row_layout": row_layout, "configs": cfgs,
             "communicator": comm, "dp_collectives": dp_coll,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
