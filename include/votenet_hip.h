@@ -658,34 +658,36 @@ int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, vo
  * factor[i] * batch[i] over flat buffers holding all layers' (scale | shift | mean | var) blocks. */
 int votenet_ema_update(long n, float momentum, float *ema, const float *batch, const float *factor, void *stream);
 
-/* ---- HALF-GROUP layout of a set-abstraction level (half.hip): the grouped MLP without the rows that are copies ----
+/* ---- PIECE layout of a set-abstraction level (half.hip): the grouped MLP without (most of) the rows that are copies ----
  * A ball with fewer than nsample = 64 neighbours repeats its first hit in the remaining slots (tf_grouping_g.cu:26-29); a repeated
- * slot is an identical row through every layer of the grouped MLP (utils.py:125-132).  The rows of a level are laid out as half-groups
- * of 32: half-group h < G (G = b*m centres) = slots 0..31 of centre h; half-group h >= G = slots 32..63 of centre hc[h], present only
- * for centres with pts_cnt > 31 (plus up to three all-copy ones so that nh % 4 == 0).  Row 31 of a first half whose second half is
- * dropped stands for 33 identical true rows: wh[h] = 33 (else 1) is its weight in every sum over the true rows -- the BatchNorm
- * statistics and the affine part B + C z of every BatchNorm backward.  Gradients per compact row are TOTALS over the rows it stands
- * for.  Same results as the full layout up to the association of those sums.
- * votenet_half_groups: pos2 (G) = index of centre c's second half among the kept ones or -1, hc (2G) = centre of half-group h,
- * wh (2G), nh (1 int, device) = number of half-groups.  One workgroup, a prefix scan: the layout is the same in every run. */
-int votenet_half_groups(int G, const int *pts_cnt, int *pos2, int *hc, float *wh, int *nh, void *stream);
-/* votenet_assemble_rows on the half-group layout: geo (up to 2G*32 x 4 floats; rows past 32*nh[0] are not written), cntv and moments
+ * slot is an identical row through every layer of the grouped MLP (utils.py:125-132).  The rows of a level are laid out in pieces of
+ * 16 (votenet_half_piece_rows()): piece q < G (G = b*m centres) = slots 0..15 of centre q; piece q >= G = slots 16j..16j+15 of centre
+ * c, hc[q] = 4c + j, kept for j < ceil(pts_cnt / 16) (plus up to seven all-copy ones so that nh % 8 == 0: a GEMM tile is 128 rows).
+ * The dropped pieces hold copies of slot 0 only; slot 0 -- row 0 of a ball's first piece -- stands for them: wh[q] = 1 + 16 * (dropped
+ * pieces) (1 for every other piece) is its weight in every sum over the true rows -- the BatchNorm statistics and the affine part
+ * B + C z of every BatchNorm backward.  Gradients per compact row are TOTALS over the rows it stands for.  Same results as the full
+ * layout up to the association of those sums.
+ * votenet_half_groups: pos (G x 3) = index (from G) of piece j = 1..3 of centre c or -1, hc (4G), wh (4G), nh (1 int, device) = number
+ * of pieces.  One workgroup, a prefix scan: the layout is the same in every run. */
+int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh, void *stream);
+int votenet_half_piece_rows(void);
+/* votenet_assemble_rows on the piece layout: geo (up to 64G x 4 floats; rows past 16*nh[0] are not written), cntv and moments
  * exactly as votenet_assemble_rows (they run over the true rows).  nh is read on the device: no host synchronisation. */
 int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
                                const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream);
-/* Forward GEMMs on rows = 32*nh compact rows: votenet_assembled_linear / votenet_mlp_linear_pool with the statistics weighted by wh;
- * the pool variant leaves the raw max / min / arg of every 32-row half-group (nh x cout), joined per centre by
- * votenet_bn_pool_finalize_half (ties -> the first half, the first occurrence as in the 64-row epilogue; argmax = slot 0..63). */
+/* Forward GEMMs on rows = 16*nh compact rows: votenet_assembled_linear / votenet_mlp_linear_pool with the statistics weighted by wh;
+ * the pool variant leaves the raw max / min / arg of every 16-row piece (nh x cout), joined per centre by
+ * votenet_bn_pool_finalize_half (ties -> the earlier piece, the first occurrence as in the 64-row epilogue; argmax = slot 0..63). */
 int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
                                   const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias,
                                   float *z, double *stats, const float *wh, void *stream);
 int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
                                  double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin, void *stream);
-int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin, const int *pos2,
+int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin, const int *pos,
                                   const float *scale, const float *shift, const votenet_bn_raw *bn, int relu, float *out, int *argmax,
                                   float *zsel, void *stream);
 /* Backward on the compact rows (gout / argmax / zsel stay per centre): the scatter of the pooled layer's input gradient (also scales
- * the dense part of row 31 by wh), its Gram matrix a^T diag(w) a, its sparse weight-gradient part with weighted column sums, the
+ * the dense part of a piece's row 0 by wh), its Gram matrix a^T diag(w) a, its sparse weight-gradient part with weighted column sums, the
  * second layer's weight / input gradient over the assembled first layer, and the first layer's scatter to the points. */
 int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
                                     const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
@@ -705,15 +707,15 @@ int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const flo
                                            const float *var_prev, float eps, int relu_prev, double *sums,
                                            const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
 /* The scatter to the points without one atomic per row (an fp32 atomic costs an L2 channel ~14 cycles per line): with the geometry,
- * votenet_half_sort_rows buckets the compact rows by the point they gather (order: 2G*32 ints, 32*nh[0] written; work: npts ints);
+ * votenet_half_sort_rows buckets the compact rows by the point they gather (order: 64G ints, 16*nh[0] written; work: npts ints);
  * votenet_group_linear_backward_sorted then sums a point's consecutive rows in a register and stores S point by point
- * (s_points pre-zeroed; atomics only where a chunk of 64 entries shares a point with its neighbour).  Same sums as
- * votenet_group_linear_backward_half in another order. */
+ * (s_points pre-zeroed; atomics only where a chunk of 64 entries shares a point with its neighbour): the piece layout's form of
+ * votenet_group_linear_backward_assembled (da = total gradients per compact row; no xyz gradient). */
 int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream);
 int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
                                          const float *wx, const float *da, const float *coef, int relu, float *s_points, float *dw_xyz,
                                          void *stream);
-/* The narrow first layer (sa1) on the same layout: u8 (up to 2G*32 x 8 floats; moments over the true rows), the second layer's GEMMs. */
+/* The narrow first layer (sa1) on the same layout: u8 (up to 64G x 8 floats; moments over the true rows), the second layer's GEMMs. */
 int votenet_narrow_rows_half(int b, int n, int m, int c, const int *nh, const float *xyz, const float *new_xyz, const float *feat,
                              const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream);
 int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0, const float *in_scale,
@@ -726,10 +728,6 @@ int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int k0, const 
                                         const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
                                         const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
                                         double *ug, const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
-int votenet_group_linear_backward_half(long nh, int G, int cout, const float *geo, const int *pts_cnt, const int *hc, const float *wh,
-                                       const float *P, const float *wx, const float *da, const float *coef, int relu, float *s_points,
-                                       float *dw_xyz, void *stream);
-
 #ifdef __cplusplus
 }
 #endif

@@ -12,61 +12,63 @@ def relerr(a, b):
     return float((a.double() - b.double()).abs().max() / max(1e-12, float(b.double().abs().max())))
 
 
+PS, NP, TP = 16, 4, 8  # rows per piece, pieces per ball, pieces per 128-row GEMM tile
+
+
 def layout_reference(cnt):
-    """numpy restatement of votenet_half_groups: centres in ascending order, then all-copy halves until nh % 4 == 0."""
+    """numpy restatement of votenet_half_groups: a ball keeps pieces 0 .. ceil(pts_cnt / 16) - 1; centres in ascending order, then all-copy
+    pieces until the count is a multiple of 8; a ball's slot 0 stands for its dropped pieces."""
     G = cnt.size
-    pos2 = np.full(G, -1, np.int64)
-    hc = list(range(G))
+    kc = np.clip((np.maximum(cnt, 1) + PS - 1) // PS, 1, NP)
+    pos = np.full((G, NP - 1), -1, np.int64)
+    hc = [c * NP for c in range(G)]
     for c in range(G):
-        if cnt[c] > 31:
-            pos2[c] = len(hc) - G
-            hc.append(c)
+        for j in range(1, kc[c]):
+            pos[c, j - 1] = len(hc) - G
+            hc.append(c * NP + j)
     c = 0
-    while len(hc) % 4:
-        if pos2[c] < 0:
-            pos2[c] = len(hc) - G
-            hc.append(c)
+    while len(hc) % TP:
+        for j in range(1, NP):
+            if len(hc) % TP and pos[c, j - 1] < 0:
+                pos[c, j - 1] = len(hc) - G
+                hc.append(c * NP + j)
         c += 1
-    hc = np.array(hc)
-    wh = np.where((np.arange(len(hc)) < G) & (pos2[hc] < 0), 33.0, 1.0).astype(np.float32)
-    return pos2, hc, wh
+    wh = np.ones(len(hc), np.float32)
+    wh[:G] = 1 + PS * (NP - 1 - (pos >= 0).sum(1))
+    return pos, np.array(hc), wh
 
 
-@pytest.mark.parametrize("G,kind", [(8, "mixed"), (4096, "mixed"), (64, "full"), (64, "empty"), (20, "one"), (16384, "mixed")])
-def test_half_group_layout_of_a_level(hiplib, dev, G, kind):
+@pytest.mark.parametrize("G,kind", [(8, "mixed"), (4096, "mixed"), (64, "full"), (64, "empty"), (24, "one"), (16384, "mixed")])
+def test_piece_layout_of_a_level(hiplib, dev, G, kind):
     from votenet_amd import mlp as M
+    assert M.PIECE == PS and M.BALL_PIECES == NP
     rng = np.random.RandomState(G)
     cnt = {"mixed": rng.randint(0, 65, G), "full": np.full(G, 64), "empty": np.zeros(G, np.int64),
            "one": np.where(np.arange(G) == 7, 40, 3)}[kind].astype(np.int32)
     half = M.half_groups(torch.from_numpy(cnt).to(dev).view(1, G)).resolve()
-    pos2, hc, wh = layout_reference(cnt)
-    assert half.nh == len(hc) and half.nh % 4 == 0
-    assert np.array_equal(half.pos2.cpu().numpy(), pos2) and np.array_equal(half.hc.cpu().numpy(), hc)
+    pos, hc, wh = layout_reference(cnt)
+    assert half.nh == len(hc) and half.nh % TP == 0
+    assert np.array_equal(half.pos.cpu().numpy().reshape(G, NP - 1), pos) and np.array_equal(half.hc.cpu().numpy(), hc)
     assert np.array_equal(half.wh.cpu().numpy(), wh)
+    # every slot of the full layout is represented by exactly one compact row, a compact row by as many slots as its weight says
+    fi = half.full_index()
+    assert torch.equal(torch.bincount(fi, minlength=half.rows).float(), half.row_weights())
     # twice the same layout (a scan, not atomics)
     again = M.half_groups(torch.from_numpy(cnt).to(dev).view(1, G)).resolve()
-    assert torch.equal(again.hc, half.hc) and torch.equal(again.pos2, half.pos2)
+    assert torch.equal(again.hc, half.hc) and torch.equal(again.pos, half.pos)
 
 
 def _rows_of(half, dev):
-    """compact row -> (its full row, the number of full rows it stands for): row 31 of a first half without a second one stands for
-    slots 31..63 of its centre."""
-    G, nh = half.G, half.nh
-    h = torch.arange(nh, device=dev)[:, None]
-    s = torch.arange(32, device=dev)[None, :]
-    full = half.hc.long()[:, None] * 64 + torch.where(h >= G, 32, 0) + s
-    mult = torch.ones(nh, 32, device=dev)
-    mult[:, 31] = half.wh
-    return full.reshape(-1), mult.reshape(-1)
+    """compact row -> the full-layout row of the slot it holds."""
+    code = half.hc.long()[:, None]
+    s = torch.arange(PS, device=dev)[None, :]
+    return ((code // NP) * 64 + (code % NP) * PS + s).reshape(-1)
 
 
 def _totals(t_full, half, dev):
     """Sum of the full-layout rows every compact row stands for."""
-    full, mult = _rows_of(half, dev)
-    out = t_full[full].double()
-    heavy = torch.nonzero(mult > 1).flatten()
-    for j in range(1, 33):  # slots 32..63 of the centres whose second half is dropped
-        out[heavy] += t_full[full[heavy] + j].double()
+    out = torch.zeros(half.rows, t_full.shape[1], dtype=torch.float64, device=dev)
+    out.index_add_(0, half.full_index(), t_full.double())
     return out
 
 
@@ -94,18 +96,11 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     half = M.half_groups(cnt)
     _, cntv_h, mom_h = M.assemble_rows_half(xyz, new_xyz, idx, cnt, half)
     half.resolve()
-    full, mult = _rows_of(half, dev)
+    full = _rows_of(half, dev)
     saved = 1.0 - half.rows / rows
-    assert 0.0 < saved <= 0.5 and half.rows % 128 == 0, cnt.flatten().tolist()
+    assert 0.0 < saved <= 0.75 and half.rows % 128 == 0, cnt.flatten().tolist()
     assert torch.equal(half.geo, geo[full]) and torch.equal(cntv_h, cntv) and relerr(mom_h, mom) < 1e-12
-    # every full row is represented exactly once
-    cover = torch.zeros(rows, device=dev)
-    cover.index_add_(0, full, torch.ones_like(mult))
-    heavy = torch.nonzero(mult > 1).flatten()
-    for j in range(1, 33):
-        cover.index_add_(0, full[heavy] + j, torch.ones(heavy.numel(), device=dev))
-    kept_twice = (half.pos2 >= 0) & (cnt.flatten() <= 31)  # all-copy second halves kept for the tile count: represented by themselves
-    assert torch.equal(cover, torch.ones(rows, device=dev)), (int(kept_twice.sum()), cover.unique())
+    assert torch.equal(half.full_rows(half.geo), geo)  # a dropped slot is a copy of slot 0: the expansion IS the full layout
     # ---- forward: layer 1 (assembled loader), layer 2 (pool in the epilogue) with ONE BatchNorm per layer for both layouts
     st0 = M.assemble_stats(P, cntv, wx, mom)
     bn0 = M.PendingBN(st0, rnd(c0) * 0.2 + 1.0, rnd(c0) * 0.1, rows)
@@ -163,18 +158,14 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     dwx, dwxh = torch.zeros(3, c0, device=dev), torch.zeros(3, c0, device=dev)
     da0t = _totals(da0, half, dev).float()
     S, _ = M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, P, wx, da0, coef0, True, dwx)
-    assert getattr(half, "order", None) is None  # not sorted yet: the row-major pass with its atomics
-    Sh = M.group_linear_backward_half(half, cnt, b, n, P, wx, da0t, coef0, True, dwxh)
-    assert relerr(Sh, S) < 1e-5 and relerr(dwxh, dwx) < 1e-4
-    # the same over the rows bucketed by point: every compact row once, the rows of a point consecutive
+    # over the rows bucketed by point: every compact row once, the rows of a point consecutive
     M.half_sort_rows(half, b * n)
     order = half.order.long()
     assert torch.equal(torch.sort(order)[0], torch.arange(half.rows, device=dev))
     prow_sorted = half.geo[order, 3].view(torch.int32)
     assert bool((prow_sorted[1:] >= prow_sorted[:-1]).all())
-    dwxs = torch.zeros(3, c0, device=dev)
-    Ss = M.group_linear_backward_half(half, cnt, b, n, P, wx, da0t, coef0, True, dwxs)
-    assert relerr(Ss, S) < 1e-5 and relerr(dwxs, dwx) < 1e-4
+    Sh = M.group_linear_backward_half(half, b, n, P, wx, da0t, coef0, True, dwxh)
+    assert relerr(Sh, S) < 1e-5 and relerr(dwxh, dwx) < 1e-4
     img.close()
 
 
@@ -244,7 +235,7 @@ def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev,
     half = M.half_groups(cnt)
     _, mom_h = M.narrow_rows_half(xyz, new_xyz, feat, idx, cnt, half)
     half.resolve()
-    full, mult = _rows_of(half, dev)
+    full = _rows_of(half, dev)
     assert half.rows < rows and torch.equal(half.u8, u8[full]) and relerr(mom_h, mom) < 1e-12
     st0 = M.narrow_stats(rows, mom_h, w0, b0)
     bn0 = M.PendingBN(st0, rnd(c0) * 0.2 + 1.0, rnd(c0) * 0.1, rows)

@@ -26,13 +26,11 @@ for name, rec in zip(("sa2", "sa3", "sa4"), tape[1:4]):
     da_f = torch.randn(rows, c, device=dev)
     z0 = M.assemble_z0(M.assemble_rows(xyz, new_xyz, idx, pts_cnt=cnt)[0], r0["P"], r0["wx"])
     M.arena_begin(dev)
-    M.SORTED_SCATTER = False
-    t_half = timeit(lambda: M.group_linear_backward_half(half, cnt, b, n, r0["P"], r0["wx"], da_h, coef, True, dw))
-    M.SORTED_SCATTER = True
+    t_half = float("nan")  # (the row-major pass with one atomic per real row on the compact rows: removed; 110 / 112 / 80 us at sa2-4 with 32-row pieces)
     if getattr(half, "order", None) is None:
         M.half_sort_rows(half, b * n)
     t_sort = timeit(lambda: M.half_sort_rows(half, b * n))
-    t_sorted = timeit(lambda: M.group_linear_backward_half(half, cnt, b, n, r0["P"], r0["wx"], da_h, coef, True, dw))
+    t_sorted = timeit(lambda: M.group_linear_backward_half(half, b, n, r0["P"], r0["wx"], da_h, coef, True, dw))
     t_full = timeit(lambda: M.group_linear_backward_assembled(xyz, new_xyz, idx, cnt, r0["P"], r0["wx"], da_f, coef, True, dw))
     t_fullz = timeit(lambda: M.group_linear_backward(xyz, new_xyz, idx, cnt, z0, da_f, coef, True, dw))
     prev = M.set_deterministic(True)

@@ -179,7 +179,7 @@ _SIGS.update({
     "votenet_assembled_wgrad_bn_half": [_L, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, ctypes.c_void_p],
     "votenet_assembled_dgrad_bn_reduce_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 9 + [_F, _I, ctypes.c_void_p,
                                                                                              ctypes.POINTER(CoefTail), _c_f, ctypes.c_void_p],
-    "votenet_group_linear_backward_half": [_L, _I, _I] + [_c_f] * 8 + [_I] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_half_piece_rows": [],
     "votenet_half_sort_rows": [_I, _I] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_narrow_rows_half": [_I] * 4 + [_c_f] * 9 + [ctypes.c_void_p],

@@ -1,26 +1,35 @@
-// half.hip -- the HALF-GROUP layout of a set-abstraction level: the grouped MLP on the rows that are not copies (gfx950).
+// half.hip -- the PIECE layout of a set-abstraction level: the grouped MLP on (nearly) only the rows that are not copies (gfx950).
 //
 // A ball with fewer than K = 64 neighbours repeats its first hit in the remaining slots (tf_grouping_g.cu:26-29), and a repeated slot is
 // an identical row through every layer of the grouped MLP: same point, same centre, same input row, same z at every layer; the max-pool
 // takes the first occurrence, so a repeated row is never the arg-max, and its gradient is the same B + C z at every layer.  On room
-// scenes 39-76 % of the grouped rows are such copies (tools/probe/pts_cnt_stats.py).  Here a level's rows are laid out as HALF-GROUPS of
-// 32 rows:
-//     half-group h <  G (G = b * m centres):  slots  0..31 of centre h                       -- always present
-//     half-group h >= G:                      slots 32..63 of centre hc[h]                   -- only for centres with pts_cnt > 31
-// A centre whose second half is dropped has pts_cnt <= 31, so its slot 31 is itself a copy of slot 0 -- and stands for the 32 dropped copies
-// as well: row 31 of its first half carries WEIGHT 33 (wh[h]) wherever a sum runs over the true rows -- the BatchNorm statistics of the
-// forward pass and the affine part B + C z of every BatchNorm backward.  With TOTAL gradients per row (the sum over the true rows a row
-// stands for) the backward reductions, the weight gradients and the scatter to the points need no weight.  The number of half-groups is
-// kept a multiple of 4 (a 128-row GEMM tile = 4 half-groups) by keeping up to three all-copy second halves, which is exact.
-// The result differs from the full layout only in the association of those sums.
+// scenes 39-76 % of the grouped rows are such copies (tools/probe/pts_cnt_stats.py).  Here a level's rows are laid out in PIECES of
+// kPiece = 16 rows (mlp_types.h); a ball keeps the pieces that hold at least one real neighbour -- pieces 0 .. kc-1, kc = ceil(pts_cnt / 16):
+//     piece q <  G (G = b * m centres):  slots 0..15 of centre q                                   -- always present
+//     piece q >= G:                      slots 16 j .. 16 j + 15 of centre c, hc[q] = 4 c + j       -- j = 1 .. kc - 1
+// The dropped pieces hold copies of slot 0 only, and slot 0 -- row 0 of the ball's first piece -- stands for them: it carries WEIGHT
+// wh[q] = 1 + 16 (4 - kc) wherever a sum runs over the true rows: the BatchNorm statistics of the forward pass and the affine part
+// B + C z of every BatchNorm backward (1 for every other piece).  With TOTAL gradients per row (the sum over the true rows a row stands
+// for) the backward reductions, the weight gradients and the scatter to the points need no weight.  The number of pieces is kept a
+// multiple of 8 (a 128-row GEMM tile) by keeping up to seven all-copy pieces, which is exact.  The result differs from the full layout
+// only in the association of those sums.
 #include "mlp_types.h"
 
 namespace votenet {
 
-// One workgroup: pos2[c] = index among the kept second halves of centre c (or -1), hc[h] = centre of half-group h, wh[h] = weight of
-// half-group h's row 31, nh[0] = number of half-groups.  Centres in ascending order (a prefix scan, no atomics): the layout -- and with
-// it the order of every sum over the rows -- is the same in every run.
-__global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__restrict__ pts_cnt, int *__restrict__ pos2, int *__restrict__ hc,
+constexpr int PS = kPiece, NP = kBallPieces, TP = kTilePieces;
+
+__device__ __forceinline__ int kept_pieces(int cnt)
+{
+    const int c = cnt < 1 ? 1 : cnt;
+    const int k = (c + PS - 1) / PS;
+    return k > NP ? NP : k;
+}
+
+// One workgroup: pos[c * (NP - 1) + j - 1] = index (from G) of piece j >= 1 of centre c, or -1; hc[q] = NP * centre + piece number;
+// wh[q] = weight of piece q's row 0; nh[0] = number of pieces.  Centres in ascending order (a prefix scan, no atomics): the layout -- and
+// with it the order of every sum over the rows -- is the same in every run.
+__global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__restrict__ pts_cnt, int *__restrict__ pos, int *__restrict__ hc,
                                                            float *__restrict__ wh, int *__restrict__ nh_out)
 {
     __shared__ int s_wave[16];
@@ -29,7 +38,7 @@ __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__r
     const int per = (G + 1023) / 1024;
     const int c0 = tid * per, c1 = min(G, c0 + per);
     int mine = 0;
-    for (int c = c0; c < c1; c++) mine += pts_cnt[c] > 31 ? 1 : 0;
+    for (int c = c0; c < c1; c++) mine += kept_pieces(pts_cnt[c]) - 1;
     int x = mine; // inclusive scan over the wavefront, then over the 16 wavefronts
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -42,31 +51,44 @@ __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__r
     for (int w = 0; w < wv; w++) base += s_wave[w];
     int p = base + x - mine;
     for (int c = c0; c < c1; c++) {
-        hc[c] = c;
-        if (pts_cnt[c] > 31) {
-            hc[G + p] = c;
-            pos2[c] = p++;
-        } else {
-            pos2[c] = -1;
+        hc[c] = c * NP;
+        const int kc = kept_pieces(pts_cnt[c]);
+        for (int j = 1; j < NP; j++) {
+            if (j < kc) {
+                hc[G + p] = c * NP + j;
+                pos[c * (NP - 1) + j - 1] = p++;
+            } else {
+                pos[c * (NP - 1) + j - 1] = -1;
+            }
         }
     }
     if (tid == 1023) s_n2 = p; // the last thread's running index = the total (its chunk may be empty)
     __syncthreads();
     if (tid == 0) {
-        // a GEMM tile is 128 rows = 4 half-groups: round up with all-copy second halves, which is exact (G % 4 == 0: there are enough)
+        // a GEMM tile is 128 rows = TP pieces: round up with all-copy pieces (the next piece of a ball that dropped some), which is exact
+        // (G % TP == 0: there are enough)
         int n2 = s_n2;
-        for (int c = 0; c < G && ((G + n2) & 3) != 0; c++)
-            if (pos2[c] < 0) {
-                pos2[c] = n2;
-                hc[G + n2] = c;
-                n2++;
-            }
+        for (int c = 0; c < G && ((G + n2) % TP) != 0; c++)
+            for (int j = 1; j < NP && ((G + n2) % TP) != 0; j++)
+                if (pos[c * (NP - 1) + j - 1] < 0) {
+                    pos[c * (NP - 1) + j - 1] = n2;
+                    hc[G + n2] = c * NP + j;
+                    n2++;
+                }
         s_n2 = n2;
         nh_out[0] = G + n2;
     }
     __syncthreads();
     const int nh = G + s_n2;
-    for (int h = tid; h < nh; h += 1024) wh[h] = (h < G && pos2[h] < 0) ? 33.0f : 1.0f;
+    for (int q = tid; q < nh; q += 1024) {
+        float w = 1.0f;
+        if (q < G) {
+            int kc = 1;
+            for (int j = 1; j < NP; j++) kc += pos[q * (NP - 1) + j - 1] >= 0 ? 1 : 0;
+            w = 1.0f + (float)(PS * (NP - kc));
+        }
+        wh[q] = w;
+    }
 }
 
 __device__ __forceinline__ double half_shfl_xor_f64(double v, int m)
@@ -78,10 +100,10 @@ __device__ __forceinline__ double half_shfl_xor_f64(double v, int m)
 }
 __device__ __forceinline__ long long half_fixed(float v) { return (long long)((double)v * 4294967296.0); }
 
-// votenet_assemble_rows on the half-group layout: thread = compact row r = h * 32 + s <-> (centre hc[h], slot 32 [h >= G] + s).
+// votenet_assemble_rows on the piece layout: thread = compact row r = q * PS + s <-> (centre hc[q] / NP, slot PS (hc[q] % NP) + s).
 // The per-point counters and the moments run over the TRUE rows exactly as in assemble_rows_kernel: slot k < pts_cnt adds itself, slot 0
 // also the 64 - pts_cnt copies.
-__global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__restrict__ nh_dev, int G, int n, int groups_per_scene, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__restrict__ nh_dev, int n, int groups_per_scene, const float *__restrict__ xyz,
                                                                  const float *__restrict__ new_xyz, const int *__restrict__ idx,
                                                                  const int *__restrict__ pts_cnt, const int *__restrict__ hc,
                                                                  float4 *__restrict__ geo, long long *__restrict__ cntv,
@@ -91,11 +113,12 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
     double acc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) acc[i] = 0.0;
-    const long rows = (long)nh_dev[0] * 32; // the number of half-groups is known on the device only when this is enqueued
+    const long rows = (long)nh_dev[0] * PS; // the number of pieces is known on the device only when this is enqueued
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
-        const int h = (int)(r >> 5), s = (int)(r & 31);
-        const int c = hc[h];
-        const int k = (h >= G ? 32 : 0) + s;
+        const int q = (int)(r / PS), s = (int)(r % PS);
+        const int code = hc[q];
+        const int c = code / NP;
+        const int k = (code % NP) * PS + s;
         const int id = idx[(size_t)c * 64 + k];
         const unsigned prow = ((unsigned)c / (unsigned)groups_per_scene) * (unsigned)n + (unsigned)id;
         const float dx = xyz[(size_t)prow * 3 + 0] - new_xyz[(size_t)c * 3 + 0]; // utils.py:55
@@ -131,9 +154,9 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
         unsafeAtomicAdd(&moments[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
 }
 
-// votenet_narrow_rows on the half-group layout: thread = compact row; u (8 floats) of the row's slot; the moments run over the TRUE rows
+// votenet_narrow_rows on the piece layout: thread = compact row; u (8 floats) of the row's slot; the moments run over the TRUE rows
 // (slot k < pts_cnt counts once, slot 0 also for the 64 - pts_cnt copies of it).
-__global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__restrict__ nh_dev, int G, int n, int groups_per_scene, int c,
+__global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__restrict__ nh_dev, int n, int groups_per_scene, int c,
                                                                const float *__restrict__ xyz, const float *__restrict__ new_xyz,
                                                                const float *__restrict__ feat, const int *__restrict__ idx,
                                                                const int *__restrict__ pts_cnt, const int *__restrict__ hc,
@@ -143,11 +166,12 @@ __global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__rest
     double acc[44]; // m[0..8), then the upper triangle of M row by row
 #pragma unroll
     for (int i = 0; i < 44; i++) acc[i] = 0.0;
-    const long rows = (long)nh_dev[0] * 32;
+    const long rows = (long)nh_dev[0] * PS;
     for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
-        const int h = (int)(r >> 5), s = (int)(r & 31);
-        const int ctr = hc[h];
-        const int k = (h >= G ? 32 : 0) + s;
+        const int q = (int)(r / PS), s = (int)(r % PS);
+        const int code = hc[q];
+        const int ctr = code / NP;
+        const int k = (code % NP) * PS + s;
         const int id = idx[(size_t)ctr * 64 + k];
         const size_t prow = (size_t)((unsigned)ctr / (unsigned)groups_per_scene) * n + id;
         float u[8];
@@ -198,10 +222,10 @@ __global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__rest
     }
 }
 
-// votenet_bn_pool_finalize over half-groups: a centre's pooled value = the better of its one or two halves (ties -> the first half: the
-// first occurrence, as the 64-row epilogue decides); arg-max = the row offset inside the 64-slot ball.
+// votenet_bn_pool_finalize over pieces: a centre's pooled value = the best of its kept pieces (ties -> the earlier piece: the first
+// occurrence, as the 64-row epilogue decides); arg-max = the slot inside the 64-slot ball.
 __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
-                                             const int *__restrict__ amax, const int *__restrict__ amin, const int *__restrict__ pos2,
+                                             const int *__restrict__ amax, const int *__restrict__ amin, const int *__restrict__ pos,
                                              const float *__restrict__ scale, const float *__restrict__ shift, BnRaw raw, int relu,
                                              float *__restrict__ out, int *__restrict__ argmax, float *__restrict__ zsel)
 {
@@ -214,19 +238,22 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
             s = scale[ch];
             h = shift[ch];
         }
-        const int p2 = pos2[g];
         float vmax = zmax[e], vmin = zmin[e];
         int imax = amax[e], imin = amin[e];
-        if (p2 >= 0) {
-            const size_t e2 = (size_t)(G + p2) * c + ch;
-            const float bmax = zmax[e2], bmin = zmin[e2];
-            if (bmax > vmax) {
-                vmax = bmax;
-                imax = 32 + amax[e2];
-            }
-            if (bmin < vmin) {
-                vmin = bmin;
-                imin = 32 + amin[e2];
+#pragma unroll
+        for (int j = 1; j < NP; j++) {
+            const int p = pos[g * (NP - 1) + j - 1];
+            if (p >= 0) {
+                const size_t e2 = (size_t)(G + p) * c + ch;
+                const float bmax = zmax[e2], bmin = zmin[e2];
+                if (bmax > vmax) {
+                    vmax = bmax;
+                    imax = j * PS + amax[e2];
+                }
+                if (bmin < vmin) {
+                    vmin = bmin;
+                    imin = j * PS + amin[e2];
+                }
             }
         }
         const float zr = s >= 0.0f ? vmax : vmin;
@@ -238,87 +265,10 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
     }
 }
 
-// votenet_group_linear_backward_assembled on the half-group layout: da holds TOTAL gradients per compact row, so
-//   dz_total = A g' + w (B + C z),  w = wh[h] on row 31 (the rows it stands for share z, hence the mask of g')
-// and the scatter to the points / the xyz rows of dW run over the compact rows unweighted.  Thread = (half-group, channel); the
-// half-group's geo records (dxyz and the point row) are staged in LDS.  Padding rows (slot >= pts_cnt) and slot 0 share one point:
-// summed in a register, one atomic.
-template <int GPB /* half-groups per workgroup pass = 256 / cout */>
-__global__ __launch_bounds__(256) void group_linear_bwd_half_kernel(int nh, int G, int cout, const float4 *__restrict__ geo,
-                                                                    const int *__restrict__ pts_cnt, const int *__restrict__ hc,
-                                                                    const float *__restrict__ wh, const float *__restrict__ ptab,
-                                                                    const float *__restrict__ wx, const float *__restrict__ da,
-                                                                    const float *__restrict__ coef, int relu, float *__restrict__ spt,
-                                                                    float *__restrict__ dw_xyz)
-{
-    __shared__ float4 s_geo[GPB][32];
-    __shared__ float red[256][3];
-    const int tid = threadIdx.x;
-    const int ch = tid % cout, gl = tid / cout;
-    const float kA = coef[ch], kB = coef[cout + ch], kC = coef[2 * cout + ch], kS = coef[3 * cout + ch], kH = coef[4 * cout + ch];
-    const float wx0 = wx[ch], wx1 = wx[cout + ch], wx2 = wx[2 * cout + ch];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-    for (int h0 = blockIdx.x * GPB; h0 < nh; h0 += gridDim.x * GPB) {
-        __syncthreads();
-        if (tid < GPB * 32 && h0 + (tid >> 5) < nh) s_geo[tid >> 5][tid & 31] = geo[(size_t)h0 * 32 + tid];
-        __syncthreads();
-        const int h = h0 + gl;
-        if (h < nh) {
-            const int kbase = h >= G ? 32 : 0;
-            int cnt = pts_cnt[hc[h]];
-            if (cnt < 1) cnt = 1;
-            const float w31 = wh[h];
-            const float *__restrict__ darow = da + (size_t)h * 32 * cout + ch;
-            float pad = 0.0f;
-#pragma unroll 1
-            for (int s0 = 0; s0 < 32; s0 += 8) {
-                float zz[8], gg[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    zz[u] = ptab[(size_t)__float_as_uint(s_geo[gl][s0 + u].w) * cout + ch];
-                    gg[u] = darow[(size_t)(s0 + u) * cout];
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int s = s0 + u, k = kbase + s;
-                    const float4 g4 = s_geo[gl][s];
-                    const float z = assembled_z(zz[u], g4, wx0, wx1, wx2);
-                    float gq = gg[u];
-                    if (relu && !(z * kS + kH > 0.0f)) gq = 0.0f;
-                    const float aff = kB + kC * z;
-                    const float d = kA * gq + (s == 31 ? w31 * aff : aff);
-                    a0 += g4.x * d;
-                    a1 += g4.y * d;
-                    a2 += g4.z * d;
-                    if (k > 0 && k < cnt)
-                        unsafeAtomicAdd(&spt[(size_t)__float_as_uint(g4.w) * cout + ch], d);
-                    else
-                        pad += d; // slot 0 and the copies of it
-                }
-            }
-            // the point slot 0 names: row 0 of a first half; of a second half, any padding row (row 31 is one if there is any)
-            if (kbase == 0) unsafeAtomicAdd(&spt[(size_t)__float_as_uint(s_geo[gl][0].w) * cout + ch], pad);
-            else if (63 >= cnt) unsafeAtomicAdd(&spt[(size_t)__float_as_uint(s_geo[gl][31].w) * cout + ch], pad);
-        }
-    }
-    red[tid][0] = a0;
-    red[tid][1] = a1;
-    red[tid][2] = a2;
-    __syncthreads();
-    if (tid < cout) {
-#pragma unroll
-        for (int d = 0; d < 3; d++) {
-            float t = 0.0f;
-            for (int q = 0; q < GPB; q++) t += red[q * cout + tid][d];
-            unsafeAtomicAdd(&dw_xyz[(size_t)d * cout + tid], t);
-        }
-    }
-}
-
 // ---- the first layer's scatter to the points WITHOUT one atomic per row: the compact rows sorted by the point they gather -----------------
 // An fp32 atomic costs an L2 channel ~14 cycles per 64-byte line whatever the number of active lanes (tools/probe/src/atomic_scope.hip:
-// 300 G adds/s), which made the row-major pass above atomic-bound at twice the time of its loads.  The grouping depends on coordinates
-// only, so with the geometry (a step ahead, off the chain) the compact rows are bucketed by point: count, scan, fill -> order (32 nh).
+// 300 G adds/s), which made a row-major pass with one atomic per real row atomic-bound at twice the time of its loads (110 -> 79 us at sa2).  The grouping depends on coordinates
+// only, so with the geometry (a step ahead, off the chain) the compact rows are bucketed by point: count, scan, fill -> order (16 nh).
 // The backward pass then walks CHUNKS of 64 consecutive entries: the rows of a point are consecutive, a thread (one channel) sums them
 // in a register and stores the point's row of S once; only a chunk's first and last point can be shared with a neighbour chunk and are
 // added with atomics -- 2 per 64 rows instead of ~30.
@@ -340,7 +290,7 @@ __device__ __forceinline__ void half_sort_runs(unsigned prow, bool live, int lan
 __global__ __launch_bounds__(256) void half_sort_count_kernel(const int *__restrict__ nh_dev, const float4 *__restrict__ geo,
                                                               int *__restrict__ count)
 {
-    const long rows = (long)nh_dev[0] * 32;
+    const long rows = (long)nh_dev[0] * PS;
     const int lane = threadIdx.x & 63;
     for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
         const long r = r0 + threadIdx.x;
@@ -381,7 +331,7 @@ __global__ __launch_bounds__(1024) void half_sort_scan_kernel(int npts, int *__r
 __global__ __launch_bounds__(256) void half_sort_fill_kernel(const int *__restrict__ nh_dev, const float4 *__restrict__ geo,
                                                              int *__restrict__ cursor, int *__restrict__ order)
 {
-    const long rows = (long)nh_dev[0] * 32;
+    const long rows = (long)nh_dev[0] * PS;
     const int lane = threadIdx.x & 63;
     for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
         const long r = r0 + threadIdx.x;
@@ -425,7 +375,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
             if (e < rows) {
                 r = order[e];
                 g4 = geo[r];
-                if ((r & 31) == 31) w = wh[r >> 5];
+                if (r % PS == 0) w = wh[r / PS]; // row 0 of a piece: a ball's slot 0 stands for its dropped copies
             }
             s_row[tid / CH][tid % CH] = r;
             s_geo[tid / CH][tid % CH] = g4;
@@ -490,26 +440,27 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
 
 using namespace votenet;
 
-extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos2, int *hc, float *wh, int *nh_out, void *stream)
+extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh_out, void *stream)
 {
-    VN_REQUIRE(G > 0 && G % 4 == 0, "half_groups expects a positive number of centres, a multiple of 4");
-    VN_REQUIRE(pts_cnt && pos2 && hc && wh && nh_out, "half_groups: null buffer");
-    hipLaunchKernelGGL(half_groups_kernel, dim3(1), dim3(1024), 0, as_stream(stream), G, pts_cnt, pos2, hc, wh, nh_out);
+    VN_REQUIRE(G > 0 && G % TP == 0, "half_groups expects a positive number of centres, a multiple of %d", TP);
+    VN_REQUIRE(pts_cnt && pos && hc && wh && nh_out, "half_groups: null buffer");
+    hipLaunchKernelGGL(half_groups_kernel, dim3(1), dim3(1024), 0, as_stream(stream), G, pts_cnt, pos, hc, wh, nh_out);
     return check_launch("half_groups");
 }
+extern "C" int votenet_half_piece_rows(void) { return PS; }
 
 extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
                                           const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream)
 {
     VN_REQUIRE(b > 0 && n > 0 && m > 0, "assemble_rows_half: bad shape");
-    const long max_rows = 2L * b * m * 32;
+    const long max_rows = 64L * b * m;
     VN_REQUIRE(max_rows < (1L << 31) && (long)b * n < (1L << 31), "assemble_rows_half: row and point counts must be below 2^31");
     VN_REQUIRE(nh && xyz && new_xyz && idx && pts_cnt && hc && geo, "assemble_rows_half: null buffer");
     VN_REQUIRE((uintptr_t)geo % 16 == 0 && (!cntv || (uintptr_t)cntv % 16 == 0), "assemble_rows_half: geo / cntv must be 16-byte aligned");
-    long gx = (max_rows * 3 / 4 + 256 * 8 - 1) / (256 * 8); // sized for a typical fill; grid-stride covers the rest
+    long gx = (max_rows / 2 + 256 * 8 - 1) / (256 * 8); // sized for a typical fill; grid-stride covers the rest
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, b * m, n, m, xyz, new_xyz, idx,
-                       pts_cnt, hc, reinterpret_cast<float4 *>(geo), cntv, moments);
+    hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, n, m, xyz, new_xyz, idx, pts_cnt, hc,
+                       reinterpret_cast<float4 *>(geo), cntv, moments);
     return check_launch("assemble_rows_half");
 }
 
@@ -517,59 +468,34 @@ extern "C" int votenet_narrow_rows_half(int b, int n, int m, int c, const int *n
                                        const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream)
 {
     VN_REQUIRE(b > 0 && n > 0 && m > 0 && c >= 0 && c <= 5, "narrow_rows_half expects 0 <= c <= 5 feature channels (3 + c <= 8)");
-    const long max_rows = 2L * b * m * 32;
+    const long max_rows = 64L * b * m;
     VN_REQUIRE(max_rows < (1L << 31), "narrow_rows_half: b*m*64 must be below 2^31");
     VN_REQUIRE(nh && xyz && new_xyz && idx && pts_cnt && hc && u8 && (c == 0 || feat), "narrow_rows_half: null buffer");
     VN_REQUIRE((uintptr_t)u8 % 16 == 0, "narrow_rows_half: u8 must be 16-byte aligned");
-    long gx = (max_rows * 3 / 4 + 256 * 16 - 1) / (256 * 16);
+    long gx = (max_rows / 2 + 256 * 16 - 1) / (256 * 16);
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(narrow_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, b * m, n, m, c, xyz, new_xyz, feat,
-                       idx, pts_cnt, hc, u8, moments);
+    hipLaunchKernelGGL(narrow_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, n, m, c, xyz, new_xyz, feat, idx,
+                       pts_cnt, hc, u8, moments);
     return check_launch("narrow_rows_half");
 }
 
 extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
-                                             const int *pos2, const float *scale, const float *shift, const votenet_bn_raw *bn, int relu,
+                                             const int *pos, const float *scale, const float *shift, const votenet_bn_raw *bn, int relu,
                                              float *out, int *argmax, float *zsel, void *stream)
 {
     VN_REQUIRE(G >= 0 && c > 0, "bn_pool_finalize_half expects G >= 0, c > 0");
     if (G == 0) return VOTENET_OK;
     const BnRaw raw = to_raw(bn);
-    VN_REQUIRE(zmax && zmin && amax && amin && pos2 && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
+    VN_REQUIRE(zmax && zmin && amax && amin && pos && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
                "bn_pool_finalize_half: null buffer");
     long grid = (G * c + 255) / 256;
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(bn_pool_finalize_half_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), G * c, (int)G, c, zmax, zmin, amax,
-                       amin, pos2, scale, shift, raw, relu, out, argmax, zsel);
+                       amin, pos, scale, shift, raw, relu, out, argmax, zsel);
     return check_launch("bn_pool_finalize_half");
 }
 
-extern "C" int votenet_group_linear_backward_half(long nh, int G, int cout, const float *geo, const int *pts_cnt, const int *hc,
-                                                  const float *wh, const float *P, const float *wx, const float *da, const float *coef,
-                                                  int relu, float *s_points, float *dw_xyz, void *stream)
-{
-    VN_REQUIRE(nh >= G && nh <= 2L * G && G > 0, "group_linear_backward_half: bad shape");
-    VN_REQUIRE(cout == 64 || cout == 128 || cout == 256, "group_linear_backward_half expects cout in {64, 128, 256}");
-    VN_REQUIRE(geo && pts_cnt && hc && wh && P && wx && da && coef && s_points && dw_xyz, "group_linear_backward_half: null buffer");
-    VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_half: geo must be 16-byte aligned");
-    hipStream_t st = as_stream(stream);
-    const int gpb = 256 / cout;
-    long gx = (nh + gpb - 1) / gpb;
-    if (gx > 2048) gx = 2048;
-    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
-    if (gpb == 4)
-        hipLaunchKernelGGL(group_linear_bwd_half_kernel<4>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
-                           da, coef, relu, s_points, dw_xyz);
-    else if (gpb == 2)
-        hipLaunchKernelGGL(group_linear_bwd_half_kernel<2>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
-                           da, coef, relu, s_points, dw_xyz);
-    else
-        hipLaunchKernelGGL(group_linear_bwd_half_kernel<1>, dim3((unsigned)gx), dim3(256), 0, st, (int)nh, G, cout, g4, pts_cnt, hc, wh, P, wx,
-                           da, coef, relu, s_points, dw_xyz);
-    return check_launch("group_linear_backward_half");
-}
-
-// order (2 G 32 ints; 32 nh[0] written) = the level's compact rows bucketed by the point they gather (geo[r].w); work: npts ints.
+// order (64 G ints; 16 nh[0] written) = the level's compact rows bucketed by the point they gather (geo[r].w); work: npts ints.
 // Coordinates only: runs with the geometry.  The order inside a bucket is whatever the fill's atomics decide.
 extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream)
 {
@@ -577,8 +503,8 @@ extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const floa
     VN_REQUIRE((uintptr_t)geo % 16 == 0, "half_sort_rows: geo must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
     if (hipMemsetAsync(work, 0, (size_t)npts * sizeof(int), st) != hipSuccess) return set_error(VOTENET_E_HIP, "half_sort_rows: memset failed");
-    const long max_rows = 2L * G * 32;
-    long gx = (max_rows * 3 / 4 + 256 * 4 - 1) / (256 * 4);
+    const long max_rows = 64L * G;
+    long gx = (max_rows / 2 + 256 * 4 - 1) / (256 * 4);
     if (gx > 2048) gx = 2048;
     const float4 *g4 = reinterpret_cast<const float4 *>(geo);
     hipLaunchKernelGGL(half_sort_count_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work);
@@ -587,8 +513,10 @@ extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const floa
     return check_launch("half_sort_rows");
 }
 
-// votenet_group_linear_backward_half over the sorted rows: same sums, S written point by point (atomics only where a chunk of 64
-// entries shares a point with its neighbour).  s_points pre-zeroed (points nobody gathers keep their zeros).
+// votenet_group_linear_backward_assembled on the piece layout, over the rows bucketed by point: da holds TOTAL gradients per compact row, so
+//   dz_total = A g' + w (B + C z),  w = wh[q] on row 0 of piece q (the rows it stands for share z, hence the mask of g');
+// S written point by point (atomics only where a chunk of 64 entries shares a point with its neighbour).  s_points pre-zeroed (points
+// nobody gathers keep their zeros).
 extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
                                                     const float *wx, const float *da, const float *coef, int relu, float *s_points,
                                                     float *dw_xyz, void *stream)
@@ -597,7 +525,7 @@ extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int
     VN_REQUIRE(order && geo && wh && P && wx && da && coef && s_points && dw_xyz, "group_linear_backward_sorted: null buffer");
     VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_sorted: geo must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
-    const long rows = nh * 32, nchunk = (rows + 63) / 64;
+    const long rows = nh * PS, nchunk = (rows + 63) / 64;
     const int cpb = 256 / cout;
     long gx = (nchunk + cpb - 1) / cpb;
     if (gx > 8192) gx = 8192;

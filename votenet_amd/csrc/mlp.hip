@@ -618,9 +618,9 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
     return check_launch("mlp_linear_pool");
 }
 
-// votenet_mlp_linear_pool on the half-group layout (half.hip): rows = 32 x half-groups; zmax / zmin / amax / amin (half-groups x cout) are
-// the raw max / min of every 32-row half-group (votenet_bn_pool_finalize_half joins a centre's halves); the statistics count row 31 of a
-// half-group wh times.
+// votenet_mlp_linear_pool on the piece layout (half.hip): rows = 16 x pieces; zmax / zmin / amax / amin (pieces x cout) are the raw
+// max / min of every 16-row piece (votenet_bn_pool_finalize_half joins a centre's pieces); the statistics count row 0 of a piece wh
+// times.
 extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
                                             float *z, double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin,
                                             void *stream)

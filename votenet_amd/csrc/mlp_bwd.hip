@@ -974,7 +974,7 @@ extern "C" int votenet_narrow_wgrad_bn(long rows, int k0, int c0, int cout, cons
     return check_launch("narrow_wgrad_bn");
 }
 
-// votenet_narrow_wgrad_bn on the half-group layout (half.hip): da holds totals per compact row, the affine part of dz1 is weighted.
+// votenet_narrow_wgrad_bn on the piece layout (half.hip): da holds totals per compact row, the affine part of dz1 is weighted.
 extern "C" int votenet_narrow_wgrad_bn_half(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
                                             const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
                                             const float *coef, int relu, const float *wh, float *dw, void *stream)
@@ -1016,8 +1016,8 @@ extern "C" int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const flo
     return check_launch("assembled_wgrad_bn");
 }
 
-// The same on the half-group layout (half.hip): da holds TOTAL gradients per compact row, the affine part of the rebuilt dz1 counts wh[h]
-// times on row 32 h + 31.
+// The same on the piece layout (half.hip): da holds TOTAL gradients per compact row, the affine part of the rebuilt dz1 counts wh[q]
+// times on row 16 q.
 extern "C" int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
                                                const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
                                                const float *coef, int relu, const float *wh, float *dw, void *stream)

@@ -112,9 +112,9 @@ struct FastArgs {
     int k0;
     double *ug;                // EPI 4: [8][cout] doubles
     CoefTail tail;             // EPI 3 / 4: the layer below's coefficient vector from the completed sums (last workgroup, common.h)
-    // half-group layout (half.hip): rows are 32-row half-groups, wh[row / 32] = the weight of the half-group's row 31 (33 when it also
-    // stands for a dropped all-copy second half, else 1).  EPI 0 / 2: the statistics count that row wh times; SRC 5: the affine part
-    // B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per 32-row half-group instead of per 64 rows
+    // piece layout (half.hip): rows come in pieces of kPiece = 16, wh[row / 16] = the weight of the piece's row 0 (a ball's slot 0 also
+    // stands for its dropped all-copy pieces; 1 for every other piece).  EPI 0 / 2: the statistics count that row wh times; SRC 5: the
+    // affine part B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per piece instead of per 64 rows
     const float *wh;
     int pool32;
 };
@@ -207,10 +207,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
     const float *pa1 = pa0 + (size_t)64 * arow_len;
     const ptrdiff_t da_off = (SRC == 1 || SRC == 5) ? (A.da - A.zsrc) : 0; // SRC 1 / 5: da has the layout of zsrc
-    // SRC 5 (half-group layout): this thread's rows a_row / a_row + 64 of a tile are row 31 of their half-group iff a_row % 32 == 31; the
-    // weights of those two half-groups travel with the slab (no load under a branch: every thread loads, most ignore)
-    const bool sel31 = (a_row & 31) == 31;
-    const float *pw = (SRC == 5) ? A.wh + (size_t)blockIdx.x * (FG_BM / 32) + (a_row >> 5) : nullptr;
+    // SRC 5 (piece layout): this thread's rows a_row / a_row + 64 of a tile are row 0 of their piece iff a_row % kPiece == 0; the
+    // weights of those two pieces travel with the slab (no load under a branch: every thread loads, most ignore)
+    const bool sel31 = (a_row % kPiece) == 0;
+    const float *pw = (SRC == 5) ? A.wh + (size_t)blockIdx.x * (FG_BM / kPiece) + (a_row / kPiece) : nullptr;
     const size_t a_tile_jump = (SRC == 3) ? (size_t)gridDim.x * FG_BM * 8 : (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         float4 uq;     // EPI 4: this thread's quad of the tile's u rows
         int tp;        //        and the tile's parity
         float4 dq0, dq1; // SRC 4: geo of the two rows (dxyz used when the slab goes to LDS)
-        float mu0, mu1;  // SRC 5: weights of the two rows' half-groups
+        float mu0, mu1;  // SRC 5: weights of the two rows' pieces
     };
     constexpr int NSETS = BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
     Regs R[NSETS];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             r.g1 = *reinterpret_cast<const float4 *>(pa1 + da_off);
             if (SRC == 5) {
                 r.mu0 = pw[0];
-                r.mu1 = pw[2];
+                r.mu1 = pw[64 / kPiece];
             }
         } else if (SRC == 3) {
             r.g0 = *reinterpret_cast<const float4 *>(pa0 + 4);
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 pu += wrap ? (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4) : 0;
                 ltp ^= wrap ? 1 : 0;
             }
-            if (SRC == 5) pw += wrap ? (size_t)gridDim.x * (FG_BM / 32) : 0;
+            if (SRC == 5) pw += wrap ? (size_t)gridDim.x * (FG_BM / kPiece) : 0;
             if (SRC == 2) {
                 const long dg = wrap ? (long)gridDim.x * FG_BM / pk : 0;
                 g0 += dg;
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     pu += (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4);
                     ltp ^= 1;
                 }
-                if (SRC == 5) pw += (size_t)gridDim.x * (FG_BM / 32);
+                if (SRC == 5) pw += (size_t)gridDim.x * (FG_BM / kPiece);
 #pragma unroll
                 for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
                 if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
@@ -730,16 +730,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 }
             }
             if (A.wh != nullptr) {
-                // half-group layout: row 31 of every 32-row block (accumulator element 15 of the upper half-wave) stands for wh rows
+                // piece layout: rows 0 and 16 of every 32-row block (accumulator elements 0 and 8 of the lower half-wave) are row 0 of a
+                // piece and stand for wh rows
+                static_assert(kPiece == 16, "the 32 x 32 MFMA tile holds two pieces: elements e < 8 and e >= 8");
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    const int hg = __builtin_amdgcn_readfirstlane((int)(m0 >> 5) + (wm * MT + i));
-                    const float wm1 = (kh == 1) ? A.wh[hg] - 1.0f : 0.0f;
+                    const int pc = __builtin_amdgcn_readfirstlane((int)(m0 / kPiece) + (wm * MT + i) * 2);
+                    const float wa = (kh == 0) ? A.wh[pc] - 1.0f : 0.0f, wb = (kh == 0) ? A.wh[pc + 1] - 1.0f : 0.0f;
 #pragma unroll
                     for (int j = 0; j < NT; j++) {
-                        const float v = acc[i][j][15] + bvs[j];
-                        s1[j] += wm1 * v;
-                        s2[j] += wm1 * (v * v);
+                        const float va = acc[i][j][0] + bvs[j], vb = acc[i][j][8] + bvs[j];
+                        s1[j] += wa * va + wb * vb;
+                        s2[j] += wa * (va * va) + wb * (vb * vb);
                     }
                 }
             }
@@ -899,20 +901,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     }
                 }
             if (A.pool32) {
-                // half-group layout: every 32-row block is a group of its own (votenet_bn_pool_finalize_half joins a centre's halves)
+                // piece layout: every 16-row piece is a group of its own (votenet_bn_pool_finalize_half joins a centre's pieces).  A 32-row
+                // block is two pieces -- elements e < 8 / e >= 8 of both half-waves -- done one after the other from the accumulators
 #pragma unroll
-                for (int i = 0; i < MT; i++) {
-                    const long hg = (m0 >> 5) + (wm * MT + i);
+                for (int i = 0; i < MT; i++)
 #pragma unroll
-                    for (int j = 0; j < NT; j++)
-                        if (lane < 32) {
-                            const size_t o = (size_t)hg * cout + n0 + (wn * NT + j) * 32 + l31;
-                            A.zmax[o] = pmaxv[i][j];
-                            A.zmin[o] = pminv[i][j];
-                            A.amax[o] = pmaxi[i][j];
-                            A.amin[o] = pmini[i][j];
+                    for (int hh = 0; hh < 2; hh++) {
+                        const long pc = m0 / kPiece + (wm * MT + i) * 2 + hh;
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            float vmax = 0.f, vmin = 0.f;
+                            int imax = 0, imin = 0;
+#pragma unroll
+                            for (int e8 = 0; e8 < 8; e8++) {
+                                const float v = acc[i][j][hh * 8 + e8] + bvs[j];
+                                const int rloc = 4 * kh + (e8 & 3) + 8 * (e8 >> 2); // inside the piece; ascending in e8: strict compares
+                                if (e8 == 0 || v > vmax) {
+                                    vmax = v;
+                                    imax = rloc;
+                                }
+                                if (e8 == 0 || v < vmin) {
+                                    vmin = v;
+                                    imin = rloc;
+                                }
+                            }
+                            const float ov = __shfl_xor(vmax, 32), uv = __shfl_xor(vmin, 32);
+                            const int oi = __shfl_xor(imax, 32), ui = __shfl_xor(imin, 32);
+                            if (ov > vmax || (ov == vmax && oi < imax)) {
+                                vmax = ov;
+                                imax = oi;
+                            }
+                            if (uv < vmin || (uv == vmin && ui < imin)) {
+                                vmin = uv;
+                                imin = ui;
+                            }
+                            if (lane < 32) {
+                                const size_t o = (size_t)pc * cout + n0 + (wn * NT + j) * 32 + l31;
+                                A.zmax[o] = vmax;
+                                A.zmin[o] = vmin;
+                                A.amax[o] = imax;
+                                A.amin[o] = imin;
+                            }
                         }
-                }
+                    }
             } else {
                 // a wave's MT = 2 blocks are one 64-row group: the later block replaces the earlier one only when strictly better
                 const long grp = m0 / 64 + wm;
@@ -1116,8 +1147,8 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
                             float *zmin, int *amax, int *amin, hipStream_t st, const float *wh)
 {
     FastArgs a = {};
-    a.wh = wh;                       // half-group layout (half.hip): weighted statistics ...
-    a.pool32 = wh != nullptr ? 1 : 0; // ... and raw max / min per 32-row half-group
+    a.wh = wh;                       // piece layout (half.hip): weighted statistics ...
+    a.pool32 = wh != nullptr ? 1 : 0; // ... and raw max / min per 16-row piece
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;
@@ -1240,7 +1271,7 @@ static int narrow_linear_impl(long rows, int k0, int c0, int cout, const float *
     a.bias = bias;
     a.z = z;
     a.stats = stats;
-    a.wh = wh; // half-group layout (half.hip): the statistics weigh row 31 of every half-group
+    a.wh = wh; // piece layout (half.hip): the statistics weigh row 0 of every piece
     hipStream_t st = as_stream(stream);
     const bool ok = stats ? fast_dispatch<3, 0>(a, st) : fast_dispatch<3, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_linear: shape not served (rows %% 128 == 0, c0 %% 32 == 0, c0 <= 128, cout == 64 or cout %% 128 == 0, 16-byte aligned buffers)");
@@ -1256,7 +1287,7 @@ extern "C" int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, c
                                           const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
                                           const float *w, const float *bias, float *z, double *stats, const float *wh, void *stream)
 {
-    VN_REQUIRE(wh != nullptr && rows % 32 == 0, "narrow_linear_half: null weights / rows %% 32 != 0");
+    VN_REQUIRE(wh != nullptr && rows % 128 == 0, "narrow_linear_half: null weights / rows %% 128 != 0");
     return narrow_linear_impl(rows, k0, c0, cout, u8, w0, b0, in_scale, in_shift, in_bn, in_relu, w, bias, z, stats, wh, stream);
 }
 
@@ -1294,7 +1325,7 @@ static int narrow_dgrad_bn_reduce_impl(long rows, int c, int c0, int k0, const f
     a.stats = sums;
     a.ug = ug;
     a.tail = to_tail(tail);
-    a.wh = wh; // half-group layout: da holds totals, the affine part of the rebuilt dz1 counts wh[h] times on row 32 h + 31 (SRC 5)
+    a.wh = wh; // piece layout: da holds totals, the affine part of the rebuilt dz1 counts wh[q] times on row 16 q (SRC 5)
     if (!(wh ? fast_dispatch<5, 4>(a, as_stream(stream)) : fast_dispatch<1, 4>(a, as_stream(stream))))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_dgrad_bn_reduce");
@@ -1392,8 +1423,8 @@ extern "C" int votenet_assembled_linear(long rows, int c0, int cout, const float
     return check_launch("assembled_linear");
 }
 
-// votenet_assembled_linear on the half-group layout (half.hip): rows = 32 x half-groups, wh = the weight of every half-group's row 31 in
-// the BatchNorm statistics (the row also stands for a dropped all-copy second half when wh = 33).
+// votenet_assembled_linear on the piece layout (half.hip): rows = 16 x pieces, wh = the weight of every piece's row 0 in
+// the BatchNorm statistics (a ball's slot 0 also stands for its dropped all-copy pieces).
 extern "C" int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
                                              const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
                                              const float *w, const float *bias, float *z, double *stats, const float *wh, void *stream)
@@ -1462,8 +1493,8 @@ extern "C" int votenet_assembled_dgrad_bn_reduce(long rows, int c, int cout, con
     return check_launch("assembled_dgrad_bn_reduce");
 }
 
-// The same on the half-group layout (half.hip): da / da_prev are TOTAL gradients per compact row; the affine part B + C z of the rebuilt
-// dz is scaled by wh on the rows that stand for a dropped second half (SRC 5); the epilogue's sums over totals need no weight.
+// The same on the piece layout (half.hip): da / da_prev are TOTAL gradients per compact row; the affine part B + C z of the rebuilt
+// dz is scaled by wh on the rows that stand for dropped pieces (SRC 5); the epilogue's sums over totals need no weight.
 extern "C" int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
                                                       const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
                                                       const float *scale_prev, const float *shift_prev, const float *mean_prev,

@@ -52,8 +52,13 @@ struct BnSrc {
     // wgrad_reduce_kernel then adds the blockIdx.x slices to dw in ascending order (one summation order -> bit-reproducible)
     float *part;
     long pstride;
-    const float *wh; // BSRC 4 (half-group layout, half.hip): da holds totals; the affine part B + C z of row 32 h + 31 counts wh[h] times
+    const float *wh; // BSRC 4 (piece layout, half.hip): da holds totals; the affine part B + C z of row 16 q counts wh[q] times
 };
+
+// ---- the PIECE layout of a set-abstraction level (half.hip): a ball's 64 slots in pieces of kPiece rows, the all-copy pieces dropped ----
+constexpr int kPiece = 16;              // rows per piece (the MFMA tiles pool per 16 rows: elements e < 8 / e >= 8 of a 32 x 32 tile)
+constexpr int kBallPieces = 64 / kPiece; // pieces of a full ball
+constexpr int kTilePieces = 128 / kPiece; // pieces per 128-row GEMM tile: the number of pieces of a level is a multiple of this
 
 // z0[r,c] of a first SA layer assembled where it is consumed (assemble.hip): p = P[prow(r), c], g = geo[r] = (dx, dy, dz, bits(prow)),
 // w0..w2 = W[0:3][c].  ONE fma chain, the same in every kernel, so all consumers see bit-identical values (identical ReLU masks).

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             if (BSRC == 1 || BSRC == 4) r.g[h] = *reinterpret_cast<const float4 *>(gb + (size_t)off);
             if (BSRC == 4) {
                 const unsigned gr = (unsigned)(r_begin + lr);
-                r.mu[h] = (gr & 31u) == 31u ? bs.wh[gr >> 5] : 1.0f;
+                r.mu[h] = (gr % (unsigned)kPiece) == 0u ? bs.wh[gr / (unsigned)kPiece] : 1.0f; // row 0 of a piece (half.hip)
             }
             if (BSRC == 2) {
                 const unsigned gr = (unsigned)(r_begin + lr);

@@ -128,8 +128,8 @@ struct PoolBelow {
     double *sums;
     CoefTail tail; // that layer's coefficient vector from the completed sums, by the last workgroup (common.h)
     int reverse;   // walk the groups back to front (votenet_debug_scatter_reverse)
-    // half-group layout (half.hip; K = 32): a "group" is a half-group h of 32 compact rows; gout / argmax / zsel are per CENTRE hc[h],
-    // a channel belongs to this half when its arg-max slot lies in [32 [h >= G], + 32); the dense part of row 31 is scaled by wh[h]
+    // piece layout (half.hip; K = kPiece = 16): a "group" is a piece q of 16 compact rows; gout / argmax / zsel are per CENTRE hc[q] / 4,
+    // a channel belongs to this piece when its arg-max slot lies in [16 (hc[q] % 4), + 16); the dense part of row 0 is scaled by wh[q]
     const int *hc;
     const float *wh;
     int G;
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
                                                                  const float *__restrict__ coef, int relu, const float *__restrict__ wT,
                                                                  float *__restrict__ da, PoolBelow pb)
 {
-    static_assert(K == 64 || K == 32, "one lane per row in the prefix scan");
-    constexpr bool HALF = K == 32;
+    static_assert(K == 64, "one lane per row in the prefix scan");
+    constexpr bool HALF = false; // (the piece layout is served by pool_dgrad_scatter_wave_kernel only)
     constexpr int PL = CIN / 64; // floats per lane of a row
     constexpr int RW = K / NWV;  // rows per wavefront
     extern __shared__ __attribute__((aligned(16))) float pds_smem[];
@@ -315,8 +315,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
                                                                            const float *__restrict__ coef, int relu,
                                                                            const float *__restrict__ wT, float *__restrict__ da, PoolBelow pb)
 {
-    static_assert(K == 64 || K == 32, "one lane per row in the prefix scan");
-    constexpr bool HALF = K == 32;
+    static_assert(K == 64 || K == kPiece, "one lane per row in the prefix scan");
+    constexpr bool HALF = K == kPiece; // piece layout (half.hip)
     constexpr int PL = CIN / 64;  // floats per lane of a row
     constexpr int NJ = COUT / 64; // channels per lane
     constexpr int RB = 4;         // rows per prefetch batch (two batches in flight; 128 VGPRs per wavefront)
@@ -357,7 +357,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
     float nz[NJ], ng[NJ], nw = 1.0f;
     int na[NJ];
     auto fetch = [&](long g) {
-        const long ctr = HALF ? (long)pb.hc[g] : g;
+        const int code = HALF ? pb.hc[g] : 0;
+        const long ctr = HALF ? (long)(code / kBallPieces) : g;
         if (HALF) nw = pb.wh[g];
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
@@ -365,8 +366,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
             ng[j] = gout[(size_t)ctr * COUT + j * 64 + lane];
             int a = argmax[(size_t)ctr * COUT + j * 64 + lane];
             if (HALF) {
-                a -= g >= pb.G ? 32 : 0;
-                if (a < 0 || a >= 32) a = -1; // the centre's other half holds this channel's arg-max
+                a -= (code % kBallPieces) * kPiece;
+                if (a < 0 || a >= kPiece) a = -1; // another piece of the centre holds this channel's arg-max
             }
             na[j] = a;
         }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
             for (int u = 0; u < RB; u++) {
                 const int rr = rb * RB + u;
                 const int n = __builtin_amdgcn_readlane(c0, rr), s0 = __builtin_amdgcn_readlane(start, rr);
-                const bool scaled = HALF && rr == 31 && w31 != 1.0f;
+                const bool scaled = HALF && rr == 0 && w31 != 1.0f; // the ball's slot 0 also stands for its dropped copies
                 float acc[PL];
 #pragma unroll
                 for (int q = 0; q < PL; q++) acc[q] = scaled ? r.d[u][q] * w31 : r.d[u][q];
@@ -491,8 +492,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
 
 // dW[:, c] += sum_g x[g*k + argmax[g,c], :] * A[c] g'[g,c]   and   colsum[j] += sum_r x[r, j]
 // x = act(xz * in_scale + in_shift) staged per group in LDS; thread c owns output column c (CIN accumulators).
-// K = 32: the half-group layout (half.hip) -- a "group" is a half-group h of 32 compact rows of xz, gout / argmax / zsel are per centre
-// hc[h] and a channel counts here when its arg-max slot lies in this half; the column sums weigh row 31 by wh[h].
+// K = kPiece = 16: the piece layout (half.hip) -- a "group" is a piece q of 16 compact rows of xz, gout / argmax / zsel are per centre
+// hc[q] / 4 and a channel counts here when its arg-max slot lies in this piece; the column sums weigh row 0 by wh[q].
 template <int CIN, int K>
 __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int cout, const float *__restrict__ xz,
                                                                 const float *__restrict__ in_scale, const float *__restrict__ in_shift,
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
                                                                 float *__restrict__ colsum, float *__restrict__ part,
                                                                 const int *__restrict__ hc, const float *__restrict__ wh, int G)
 {
-    constexpr bool HALF = K == 32;
+    constexpr bool HALF = K == kPiece;
     constexpr int LD = CIN + 4;
     __shared__ __attribute__((aligned(16))) float xs[K][LD];
     const int tid = threadIdx.x;
@@ -528,15 +529,16 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
         const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)g * K * CIN);
 #pragma unroll
         for (int h = 0; h < NL; h++) nxt[h] = src[tid + h * 256];
-        const long ctr = HALF ? (long)hc[g] : g;
+        const int code = HALF ? hc[g] : 0;
+        const long ctr = HALF ? (long)(code / kBallPieces) : g;
         if (HALF) n_w = wh[g];
         if (own) {
             n_z = zsel[(size_t)ctr * cout + tid];
             n_g = gout[(size_t)ctr * cout + tid];
             n_a = argmax[(size_t)ctr * cout + tid];
             if (HALF) {
-                n_a -= g >= G ? 32 : 0;
-                if (n_a < 0 || n_a >= 32) { // the centre's other half holds this channel's arg-max
+                n_a -= (code % kBallPieces) * kPiece;
+                if (n_a < 0 || n_a >= kPiece) { // another piece of the centre holds this channel's arg-max
                     n_a = 0;
                     n_g = 0.0f;
                 }
@@ -578,8 +580,8 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
         if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
             const int jc = tid - (256 - CIN);
 #pragma unroll 8
-            for (int r = 0; r < (HALF ? K - 1 : K); r++) csum += xs[r][jc];
-            if (HALF) csum += w31 * xs[K - 1][jc];
+            for (int r = (HALF ? 1 : 0); r < K; r++) csum += xs[r][jc];
+            if (HALF) csum += w31 * xs[0][jc]; // the ball's slot 0 also stands for its dropped copies
         }
         __syncthreads();
     }
@@ -704,14 +706,14 @@ extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout,
                                      below_var, eps, below_relu, below_sums, below_tail, nullptr, nullptr, 0, stream);
 }
 
-// The same pass on the half-group layout (half.hip): da and below_z have 32 * nh compact rows; gout / argmax / zsel stay per centre.
+// The same pass on the piece layout (half.hip): da and below_z have 16 * nh compact rows; gout / argmax / zsel stay per centre.
 extern "C" int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
                                                const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
                                                const float *below_z, const float *below_scale, const float *below_shift,
                                                const float *below_mean, const float *below_var, float eps, int below_relu,
                                                double *below_sums, const votenet_coef_tail *below_tail, void *stream)
 {
-    VN_REQUIRE(hc && wh && G > 0 && nh >= G && nh <= 2L * G, "pool_dgrad_scatter_half: bad half-group arguments");
+    VN_REQUIRE(hc && wh && G > 0 && nh >= G && nh <= (long)kBallPieces * G, "pool_dgrad_scatter_half: bad piece-layout arguments");
     VN_REQUIRE(gout && argmax && zsel && coef && wT && da && (uintptr_t)wT % 16 == 0, "pool_dgrad_scatter_half: null / unaligned buffer");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_dgrad_scatter_half: unsupported shape cin=%d cout=%d", cin, cout);
     VN_REQUIRE(!below_z || (below_scale && below_shift && below_mean && below_var && below_sums),
@@ -731,7 +733,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
     hipStream_t st = as_stream(stream);
     const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse, hc, wh, G};
     auto go = [&](auto kern, int ci, int co, int threads = 512) {
-        const size_t smem = ((size_t)co * ci + 4 * co + 4 * (hc ? 32 : k)) * 4;
+        const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         static std::set<const void *> raised; // the attribute is per kernel: set once
         static std::mutex raised_mu;          // entry points may be called from several host threads
@@ -761,16 +763,16 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
         hipLaunchKernelGGL(kern, dim3(pb_grid(groups, nwv, 256 * per_cu)), dim3(nwv * 64), smem, st, groups, gout, argmax, zsel, coef, relu, wT,
                            da, pb);
     };
-    if (g_scatter_form == 1) {
+    if (g_scatter_form == 1 || hc) {
 #define VN_SCATTER_WAVE(CI, CO, KK, NW)                                                            \
     do {                                                                                           \
         if (below_z) gow(pool_dgrad_scatter_wave_kernel<CI, CO, KK, true, NW>, CI, CO, KK, NW);   \
         else gow(pool_dgrad_scatter_wave_kernel<CI, CO, KK, false, NW>, CI, CO, KK, NW);          \
     } while (0)
         if (hc) {
-            if (cin == 64) VN_SCATTER_WAVE(64, 128, 32, 8);
-            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 32, 16);
-            else VN_SCATTER_WAVE(128, 128, 32, 8);
+            if (cin == 64) VN_SCATTER_WAVE(64, 128, kPiece, 8);
+            else if (cout == 256) VN_SCATTER_WAVE(128, 256, kPiece, 16);
+            else VN_SCATTER_WAVE(128, 128, kPiece, 8);
         } else {
             if (cin == 64) VN_SCATTER_WAVE(64, 128, 64, 8);
             else if (cout == 256) VN_SCATTER_WAVE(128, 256, 64, 16);
@@ -779,14 +781,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
 #undef VN_SCATTER_WAVE
         return check_launch("pool_dgrad_scatter");
     }
-    if (hc) {
-        if (cin == 64 && below_z) go(pool_dgrad_scatter_kernel<64, 128, 32, true>, 64, 128);
-        else if (cin == 64) go(pool_dgrad_scatter_kernel<64, 128, 32, false>, 64, 128);
-        else if (cout == 256 && below_z) go(pool_dgrad_scatter_kernel<128, 256, 32, true, 16>, 128, 256, 1024);
-        else if (cout == 256) go(pool_dgrad_scatter_kernel<128, 256, 32, false, 16>, 128, 256, 1024);
-        else if (below_z) go(pool_dgrad_scatter_kernel<128, 128, 32, true>, 128, 128);
-        else go(pool_dgrad_scatter_kernel<128, 128, 32, false>, 128, 128);
-    } else if (below_z) {
+    if (below_z) {
         if (cin == 128 && cout == 256)
             go(pool_dgrad_scatter_kernel<128, 256, 64, true, 16>, 128, 256, 1024);
         else if (cin == 128)
@@ -816,7 +811,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
 template <int C>
 __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
                                                        int relu, float *__restrict__ gram, long rows_per_block,
-                                                       const float *__restrict__ wh /* half-group layout: row 32 h + 31 counts wh[h] times */)
+                                                       const float *__restrict__ wh /* piece layout: row 16 q counts wh[q] times */)
 {
     constexpr int KPT = C / 16;          // rows of a slab per thread (8 or 4)
     constexpr int T = C / 64;            // 32 x 32 sub-tiles per wave and direction (waves 2 x 2)
@@ -835,9 +830,10 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     const float floor_ = relu ? 0.0f : -__builtin_inff();
     const float *xb = x + (size_t)r_begin * C + c;
     float R[2][KPT];
-    // a thread's last row of an odd slab is row 31 of a half-group exactly when its row group is the slab's last one (r_begin % 32 == 0)
-    const bool last_rg = rg * KPT + KPT == 16;
-    const float *whb = wh ? wh + (r_begin >> 5) : nullptr;
+    // a slab is a piece (16 rows, r_begin % 16 == 0): a thread's first row is row 0 of the piece exactly when its row group is the first
+    static_assert(kPiece == 16, "one slab = one piece");
+    const bool first_rg = rg == 0;
+    const float *whb = wh ? wh + r_begin / kPiece : nullptr;
     float Wq[2] = {1.0f, 1.0f}; // sqrt of that row's weight, travelling with the register set
     auto load = [&](float (&r)[KPT], int s, float &wq) {
 #pragma unroll
@@ -846,7 +842,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             lr = lr < nrow ? lr : nrow - 1; // past the end: a valid row, stored as zero below
             r[i] = xb[(size_t)lr * C];
         }
-        if (whb && last_rg && (s & 1)) wq = s * 16 + 15 < nrow ? sqrtf(whb[s >> 1]) : 1.0f;
+        if (whb && first_rg) wq = s * 16 < nrow ? sqrtf(whb[s]) : 1.0f;
         else wq = 1.0f;
     };
     auto store = [&](int buf, const float (&r)[KPT], int s, float wq) {
@@ -856,7 +852,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             v[i] = fmaxf(r[i] * sc + sh, floor_);
             if (s * 16 + rg * KPT + i >= nrow) v[i] = 0.0f; // padding rows contribute nothing
         }
-        v[KPT - 1] *= wq; // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
+        v[0] *= wq; // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
         unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
 #pragma unroll
         for (int i = 0; i < KPT / 2; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
@@ -989,12 +985,12 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
                                     nullptr, nullptr, 0, stream);
 }
 
-// The same on the half-group layout (half.hip): xz has 32 * nh compact rows, gout / argmax / zsel stay per centre.
-// votenet_mlp_gram over the half-group layout (half.hip): G += a^T diag(w) a with w = wh[h] on row 32 h + 31, 1 elsewhere.
+// The same on the piece layout (half.hip): xz has 16 * nh compact rows, gout / argmax / zsel stay per centre.
+// votenet_mlp_gram over the piece layout (half.hip): G += a^T diag(w) a with w = wh[q] on row 16 q, 1 elsewhere.
 extern "C" int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram,
                                      void *stream)
 {
-    VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) / c && (c == 128 || c == 64), "mlp_gram_half expects rows %% 32 == 0 and c in {64, 128}");
+    VN_REQUIRE(rows > 0 && rows % kPiece == 0 && rows < (1L << 31) / c && (c == 128 || c == 64), "mlp_gram_half expects rows %% 16 == 0 and c in {64, 128}");
     VN_REQUIRE(z && scale_shift && wh && gram && (uintptr_t)z % 16 == 0, "mlp_gram_half: null / unaligned buffer");
     if (c == 128) gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
     else gram_bf3_launch<64>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
@@ -1005,7 +1001,7 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
                                               int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
                                               float *dw, float *colsum, const int *hc, const float *wh, void *stream)
 {
-    VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= 2L * G && hc && wh, "pool_wgrad_sparse_half: bad half-group arguments");
+    VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= (long)kBallPieces * G && hc && wh, "pool_wgrad_sparse_half: bad piece-layout arguments");
     VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half: bad arguments");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_wgrad_sparse_half: unsupported shape cin=%d cout=%d", cin, cout);
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse_half: in_scale and in_shift go together");
@@ -1019,13 +1015,13 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
                                     float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream)
 {
-    const int grid = pb_grid(groups, hc ? 16 : 8, g_sparse_wgs); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
+    const int grid = pb_grid(groups, hc ? 32 : 8, g_sparse_wgs); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
     if (hc && cin == 64)
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, kPiece>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
                            in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
     else if (hc)
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 32>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
+        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, kPiece>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
                            in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
     else if (cin == 128)
         hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,

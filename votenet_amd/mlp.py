@@ -423,20 +423,24 @@ def assemble_rows(xyz, new_xyz, idx, want_sums=True, pts_cnt=None, in_pass=False
     return geo, cntv, mom
 
 
-# ---- HALF-GROUP layout (csrc/half.hip): the grouped MLP of a level without the rows that are copies of slot 0 ----
-_nh_ring = None  # pinned ints the half-group counts are copied into (one slot per layout, reused round-robin)
+# ---- PIECE layout (csrc/half.hip): the grouped MLP of a level without (most of) the rows that are copies of slot 0 ----
+PIECE = 16           # rows per piece (votenet_half_piece_rows(), checked when the first layout is built)
+BALL_PIECES = 64 // PIECE
+_nh_ring = None  # pinned ints the piece counts are copied into (one slot per layout, reused round-robin)
 _nh_turn = 0
 
 
 class HalfLayout:
-    """Row layout of one level (include/votenet_hip.h, 'HALF-GROUP layout'): G centres, nh half-groups of 32 compact rows.
-    pos2 (G,), hc / wh (nh,), geo (32 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
+    """Row layout of one level (include/votenet_hip.h, 'PIECE layout'): G centres, nh pieces of PIECE = 16 compact rows.
+    pos (G, 3), hc / wh (nh,), geo (16 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
     its use -- and copied to pinned host memory; resolve() waits for that copy (a no-op once it has landed) and trims the views."""
 
-    def __init__(self, G, pos2, hc, wh, nh_dev):
+    def __init__(self, G, pos, hc, wh, nh_dev):
         global _nh_ring, _nh_turn
-        self.G, self.pos2, self._hc, self._wh, self.nh_dev = G, pos2, hc, wh, nh_dev
+        self.G, self.pos, self._hc, self._wh, self.nh_dev = G, pos, hc, wh, nh_dev
         if _nh_ring is None:
+            if L.lib().votenet_half_piece_rows() != PIECE:
+                raise L.VotenetError("libvotenet_hip.so was built for pieces of %d rows, the host code for %d" % (L.lib().votenet_half_piece_rows(), PIECE))
             _nh_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
         self._slot = _nh_ring[_nh_turn:_nh_turn + 1]
         _nh_turn = (_nh_turn + 1) % 256
@@ -445,43 +449,49 @@ class HalfLayout:
         self._ev.record()
         self.nh = None
         self._geo = self._u8 = None  # the level's compact rows: geo records (assembled first layer) or u8 (narrow first layer)
-        self._order = None           # the compact rows bucketed by the point they gather (sort_rows)
+        self._order = None           # the compact rows bucketed by the point they gather (half_sort_rows)
 
     def tensors(self):
-        return [t for t in (self.pos2, self._hc, self._wh, self.nh_dev, self._geo, self._u8, self._order) if t is not None]
+        return [t for t in (self.pos, self._hc, self._wh, self.nh_dev, self._geo, self._u8, self._order) if t is not None]
 
     def resolve(self):
         if self.nh is None:
             self._ev.synchronize()
             self.nh = int(self._slot.item())
-            if not (self.G <= self.nh <= 2 * self.G and self.nh % 4 == 0):
-                raise L.VotenetError("half-group layout: bad count %d for %d centres" % (self.nh, self.G))
+            if not (self.G <= self.nh <= BALL_PIECES * self.G and self.nh % (128 // PIECE) == 0):
+                raise L.VotenetError("piece layout: bad count %d for %d centres" % (self.nh, self.G))
             self.hc, self.wh = self._hc[:self.nh], self._wh[:self.nh]
-            self.geo = self._geo[:self.nh * 32] if self._geo is not None else None
-            self.u8 = self._u8[:self.nh * 32] if self._u8 is not None else None
-            self.order = self._order[:self.nh * 32] if self._order is not None else None
+            self.geo = self._geo[:self.nh * PIECE] if self._geo is not None else None
+            self.u8 = self._u8[:self.nh * PIECE] if self._u8 is not None else None
+            self.order = self._order[:self.nh * PIECE] if self._order is not None else None
         return self
 
     @property
     def rows(self):
-        return self.resolve().nh * 32
+        return self.resolve().nh * PIECE
 
-    def full_rows(self, t):
-        """A compact row tensor (32 nh, c) laid out as the full layout (64 G, c): slot s of centre c; a dropped slot holds a copy of
-        slot 0.  (Row VALUES of the forward pass; gradients per compact row are totals and do not expand this way.)  Tests, debugging."""
+    def full_index(self):
+        """(64 G,) for every slot of the full layout the compact row that holds it; a slot of a dropped piece -> the ball's slot 0."""
         self.resolve()
-        G, dev = self.G, t.device
+        G, dev = self.G, self.pos.device
         c = torch.arange(G, device=dev)[:, None]
         s = torch.arange(64, device=dev)[None, :]
-        p2 = self.pos2.long()[:, None]
-        src = torch.where(s < 32, c * 32 + s, torch.where(p2 >= 0, (G + p2) * 32 + s - 32, c * 32))
-        return t[src.reshape(-1)]
+        j = s // PIECE
+        posx = torch.cat([torch.zeros(G, 1, dtype=torch.long, device=dev), self.pos.view(G, BALL_PIECES - 1).long()], 1)  # piece 0: at c
+        p = torch.gather(posx, 1, j.expand(G, 64))
+        src = torch.where(j == 0, c * PIECE + s, torch.where(p >= 0, (G + p) * PIECE + s % PIECE, c * PIECE))
+        return src.reshape(-1)
+
+    def full_rows(self, t):
+        """A compact row tensor (16 nh, c) laid out as the full layout (64 G, c): slot s of centre c; a dropped slot holds a copy of
+        slot 0.  (Row VALUES of the forward pass; gradients per compact row are totals and do not expand this way.)  Tests, debugging."""
+        return t[self.full_index()]
 
     def row_weights(self):
-        """(32 nh,) the number of full-layout rows every compact row stands for."""
+        """(16 nh,) the number of full-layout rows every compact row stands for (row 0 of a ball's first piece: also its dropped copies)."""
         self.resolve()
-        w = torch.ones(self.nh, 32, device=self.wh.device)
-        w[:, 31] = self.wh
+        w = torch.ones(self.nh, PIECE, device=self.wh.device)
+        w[:, 0] = self.wh
         return w.reshape(-1)
 
 
@@ -489,21 +499,21 @@ def half_groups(pts_cnt):
     """pts_cnt (b, m) int32 -> HalfLayout (count still on its way to the host)."""
     G = pts_cnt.numel()
     dev = pts_cnt.device
-    ints = torch.empty(3 * G + 1, dtype=torch.int32, device=dev)
-    pos2, hc, nh = ints[:G], ints[G:3 * G], ints[3 * G:]
-    wh = torch.empty(2 * G, dtype=torch.float32, device=dev)
+    ints = torch.empty((BALL_PIECES - 1) * G + BALL_PIECES * G + 1, dtype=torch.int32, device=dev)
+    pos, hc, nh = ints[:(BALL_PIECES - 1) * G], ints[(BALL_PIECES - 1) * G:-1], ints[-1:]
+    wh = torch.empty(BALL_PIECES * G, dtype=torch.float32, device=dev)
     with L.device_guard(dev):
-        L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos2), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.stream_ptr()))
-        return HalfLayout(G, pos2, hc, wh, nh)
+        L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.stream_ptr()))
+        return HalfLayout(G, pos, hc, wh, nh)
 
 
 def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
-    """assemble_rows on the half-group layout: -> geo buffer (2 G 32, 4) of which half.resolve().geo is the written part, cntv, moments."""
+    """assemble_rows on the piece layout: -> geo buffer (64 G, 4) of which half.resolve().geo is the written part, cntv, moments."""
     b, m, k = idx.shape
     n = xyz.shape[1]
     if k != 64:
         raise L.InvalidArgumentError("assemble_rows_half expects nsample == 64")
-    geo = torch.empty((2 * b * m * 32, 4), dtype=torch.float32, device=xyz.device)
+    geo = torch.empty((b * m * 64, 4), dtype=torch.float32, device=xyz.device)
     cntv = torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device)
     mom = torch.zeros(9, dtype=torch.float64, device=xyz.device)
     with L.device_guard(xyz.device):
@@ -514,13 +524,13 @@ def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
 
 
 def narrow_rows_half(xyz, new_xyz, feat, idx, pts_cnt, half):
-    """narrow_rows on the half-group layout: -> u8 buffer (2 G 32, 8) of which half.resolve().u8 is the written part, moments (72,)."""
+    """narrow_rows on the piece layout: -> u8 buffer (64 G, 8) of which half.resolve().u8 is the written part, moments (72,)."""
     b, m, k = idx.shape
     n = xyz.shape[1]
     c = feat.shape[2] if feat is not None else 0
     if k != 64:
         raise L.InvalidArgumentError("narrow_rows_half expects nsample == 64")
-    u8 = torch.empty((2 * b * m * 32, 8), dtype=torch.float32, device=xyz.device)
+    u8 = torch.empty((b * m * 64, 8), dtype=torch.float32, device=xyz.device)
     mom = torch.zeros(72, dtype=torch.float64, device=xyz.device)
     with L.device_guard(xyz.device):
         L.check(L.lib().votenet_narrow_rows_half(b, n, m, c, L.ptr(half.nh_dev), L.ptr(xyz), L.ptr(new_xyz), L.ptr(feat), L.ptr(idx),
@@ -529,36 +539,30 @@ def narrow_rows_half(xyz, new_xyz, feat, idx, pts_cnt, half):
     return u8, mom
 
 
-SORTED_SCATTER = True  # the first layer's scatter to the points over rows bucketed by point (no atomic per row): csrc/half.hip
-
-
 def half_sort_rows(half, npts):
     """Bucket the layout's compact rows by the point they gather (geo must be assembled): half.order.  Geometry only."""
     dev = half._geo.device
     work = torch.empty(npts, dtype=torch.int32, device=dev)
-    order = torch.empty(2 * half.G * 32, dtype=torch.int32, device=dev)
+    order = torch.empty(half.G * 64, dtype=torch.int32, device=dev)
     with L.device_guard(dev):
         L.check(L.lib().votenet_half_sort_rows(npts, half.G, L.ptr(half.nh_dev), L.ptr(half._geo), L.ptr(work), L.ptr(order), L.stream_ptr()))
     half._order = order
     if half.nh is not None:  # the count is known already
-        half.order = order[:half.nh * 32]
+        half.order = order[:half.nh * PIECE]
     return order
 
 
-def group_linear_backward_half(half, pts_cnt, b, n, P, wx, da, coef, relu, dw_xyz):
-    """group_linear_backward_assembled on the half-group layout (da = total gradients per compact row) -> S (b, n, cout)."""
+def group_linear_backward_half(half, b, n, P, wx, da, coef, relu, dw_xyz):
+    """group_linear_backward_assembled on the piece layout (da = total gradients per compact row) -> S (b, n, cout): the first layer's
+    scatter to the points over the rows bucketed by point (half_sort_rows: with the geometry, or here if it has not run)."""
     cout = P.shape[1]
+    if getattr(half, "order", None) is None:
+        half_sort_rows(half, b * n)
     S = _zeros_f32((b, n, cout), P.device)
-    if SORTED_SCATTER and getattr(half, "order", None) is not None:
-        with L.device_guard(P.device):
-            L.check(L.lib().votenet_group_linear_backward_sorted(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(half.wh), L.ptr(P),
-                                                                 L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
-                                                                 L.stream_ptr()))
-        return S
     with L.device_guard(P.device):
-        L.check(L.lib().votenet_group_linear_backward_half(half.nh, half.G, cout, L.ptr(half.geo), L.ptr(pts_cnt), L.ptr(half.hc), L.ptr(half.wh),
-                                                           L.ptr(P), L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S),
-                                                           L.ptr(dw_xyz), L.stream_ptr()))
+        L.check(L.lib().votenet_group_linear_backward_sorted(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(half.wh), L.ptr(P),
+                                                             L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
+                                                             L.stream_ptr()))
     return S
 
 
@@ -778,7 +782,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
     pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool."""
     rows, cin = x.shape
     cout = w.shape[1]
-    g = rows // k if half is None else half.nh  # half: raw max / min per half-group of 32 compact rows
+    g = rows // k if half is None else half.nh  # half: raw max / min per piece of 16 compact rows
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if keep_z else None
     stats = _zeros_f64(2 * cout, x.device)
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
@@ -813,7 +817,7 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, 
     zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None
     if half is not None:
         with L.device_guard(zmax.device):
-            L.check(L.lib().votenet_bn_pool_finalize_half(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(half.pos2),
+            L.check(L.lib().votenet_bn_pool_finalize_half(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(half.pos),
                                                           L.ptr(scale), L.ptr(shift), ctypes.byref(raw) if raw is not None else None,
                                                           1 if relu else 0, L.ptr(out), L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
         return (out, arg, zsel) if want_zsel else (out, arg)

@@ -726,7 +726,7 @@ class SAModule:
         halves of a ball) for b scenes of n points: an assembled first layer, three BatchNorm'ed layers, the pooled one in Gram form."""
         m = self.mlp
         if not (HALF_GROUPS and not M.DETERMINISTIC and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and m[2].bn and POOL_IN_EPILOGUE
-                and POOL_GRAM_BACKWARD and (b * self.npoint) % 4 == 0 and M.pool_backward_supported(m[1].cout, m[2].cout, 64)):
+                and POOL_GRAM_BACKWARD and (b * self.npoint) % 8 == 0 and M.pool_backward_supported(m[1].cout, m[2].cout, 64)):
             return False
         return bool(self.narrow(b * self.npoint * 64) or (m[1].cout == 128 and self.assembled(b, n)))
 
@@ -749,8 +749,7 @@ class SAModule:
         elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
             half = M.half_groups(geom[3])  # the layout and the count of its half-groups: known on the host by the time the MLP runs
             geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
-            if M.SORTED_SCATTER:  # the rows bucketed by point, for the first layer's backward
-                M.half_sort_rows(half, xyz.shape[0] * xyz.shape[1])
+            M.half_sort_rows(half, xyz.shape[0] * xyz.shape[1])  # the rows bucketed by point, for the first layer's backward
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
             geom = tuple(geom) + M.assemble_rows(xyz, geom[1], geom[2], pts_cnt=geom[3], in_pass=not ahead)  # geo records + per-point sums: coordinates only
         return geom
@@ -836,7 +835,7 @@ class SAModule:
         elif r0["kind"] == "assembled" and r0.get("half") is not None:
             if need_xyz_grad:
                 raise ValueError("SAModule: the half-group layout keeps no per-row dz for the xyz gradient")
-            S, dz = M.group_linear_backward_half(r0["half"], pts_cnt, b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
+            S, dz = M.group_linear_backward_half(r0["half"], b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
         elif r0["kind"] == "assembled":
             S, dz = M.group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"],
                                                       gW[:3], want_dz=need_xyz_grad)
