@@ -676,16 +676,17 @@ int votenet_half_piece_rows(void);
 int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
                                const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream);
 /* Forward GEMMs on rows = 16*nh compact rows: votenet_assembled_linear / votenet_mlp_linear_pool with the statistics weighted by wh;
- * the pool variant leaves the raw max / min / arg of every 16-row piece (nh x cout), joined per centre by
- * votenet_bn_pool_finalize_half (ties -> the earlier piece, the first occurrence as in the 64-row epilogue; argmax = slot 0..63). */
+ * the pool variant leaves ONE candidate per 16-row piece and channel (zbest / abest, nh x cout): the raw max of z where gamma -- the
+ * pooled layer's BatchNorm weight, whose sign is the sign of the scale the pool applies -- is >= 0, the raw min where it is negative,
+ * first occurrence; votenet_bn_pool_finalize_half joins a centre's pieces (ties -> the earlier piece, the first occurrence as in the
+ * 64-row epilogue; argmax = slot 0..63). */
 int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
                                   const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias,
                                   float *z, double *stats, const float *wh, void *stream);
 int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
-                                 double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin, void *stream);
-int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin, const int *pos,
-                                  const float *scale, const float *shift, const votenet_bn_raw *bn, int relu, float *out, int *argmax,
-                                  float *zsel, void *stream);
+                                 double *stats, const float *wh, const float *gamma, float *zbest, int *abest, void *stream);
+int votenet_bn_pool_finalize_half(long G, int c, const float *zbest, const int *abest, const int *pos, const float *scale, const float *shift,
+                                  const votenet_bn_raw *bn, int relu, float *out, int *argmax, float *zsel, void *stream);
 /* Backward on the compact rows (gout / argmax / zsel stay per centre): the scatter of the pooled layer's input gradient (also scales
  * the dense part of a piece's row 0 by wh), its Gram matrix a^T diag(w) a, its sparse weight-gradient part with weighted column sums, the
  * second layer's weight / input gradient over the assembled first layer, and the first layer's scatter to the points. */

@@ -110,10 +110,11 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     assert relerr(st1h[:c1], st1[:c1]) < 1e-6 and relerr(st1h[c1:], st1[c1:]) < 1e-6
     bn1 = M.PendingBN(st1, rnd(c1) * 0.2 + 1.0, rnd(c1) * 0.1, rows)
     bn1.finalize()
+    gamma2 = rnd(c2) * 0.3 + 0.2  # some negative gammas: the min side of the pool
     _, st2, pool = M.linear_dense_pool(z1, w2, k, b2, bn1.scale, bn1.shift, True, keep_z=False)
-    _, st2h, poolh = M.linear_dense_pool(z1h, w2, k, b2, bn1.scale, bn1.shift, True, keep_z=False, half=half)
+    _, st2h, poolh = M.linear_dense_pool(z1h, w2, k, b2, bn1.scale, bn1.shift, True, keep_z=False, half=half, gamma=gamma2)
     assert relerr(st2h[:c2], st2[:c2]) < 1e-6 and relerr(st2h[c2:], st2[c2:]) < 1e-6
-    bn2 = M.PendingBN(st2, rnd(c2) * 0.3 + 0.2, rnd(c2) * 0.1, rows)  # some negative gammas: the min side of the pool
+    bn2 = M.PendingBN(st2, gamma2, rnd(c2) * 0.1, rows)
     bn2.finalize()
     out, arg, zsel = M.bn_pool_finalize(pool, bn2.scale, bn2.shift, True, want_argmax=True, want_zsel=True)
     outh, argh, zselh = M.bn_pool_finalize(poolh, bn2.scale, bn2.shift, True, want_argmax=True, want_zsel=True, half=half)

@@ -170,8 +170,8 @@ _SIGS.update({
     "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 9 + [ctypes.c_void_p],
     "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
-    "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 9 + [ctypes.c_void_p],
-    "votenet_bn_pool_finalize_half": [_L, _I] + [_c_f] * 7 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 3 + [ctypes.c_void_p],
+    "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 8 + [ctypes.c_void_p],
+    "votenet_bn_pool_finalize_half": [_L, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_pool_dgrad_scatter_half": [_L, _I, _I, _I] + [_c_f] * 4 + [_I] + [_c_f] * 9 + [_F, _I, _c_f, ctypes.POINTER(CoefTail),
                                                                                        ctypes.c_void_p],
     "votenet_mlp_gram_half": [_L, _I, _c_f, _c_f, _I, _c_f, _c_f, ctypes.c_void_p],

@@ -222,12 +222,13 @@ __global__ __launch_bounds__(256) void narrow_rows_half_kernel(const int *__rest
     }
 }
 
-// votenet_bn_pool_finalize over pieces: a centre's pooled value = the best of its kept pieces (ties -> the earlier piece: the first
-// occurrence, as the 64-row epilogue decides); arg-max = the slot inside the 64-slot ball.
-__global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const float *__restrict__ zmax, const float *__restrict__ zmin,
-                                             const int *__restrict__ amax, const int *__restrict__ amin, const int *__restrict__ pos,
-                                             const float *__restrict__ scale, const float *__restrict__ shift, BnRaw raw, int relu,
-                                             float *__restrict__ out, int *__restrict__ argmax, float *__restrict__ zsel)
+// votenet_bn_pool_finalize over pieces: zbest / abest hold every piece's candidate (the max of z where the scale is >= 0, the min where it
+// is negative: votenet_mlp_linear_pool_half decides by the sign of gamma, which is the sign of the scale); a centre's pooled value = the
+// best of its kept pieces (ties -> the earlier piece: the first occurrence, as the 64-row epilogue decides); arg-max = the slot inside
+// the 64-slot ball.
+__global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const float *__restrict__ zbest, const int *__restrict__ abest,
+                                             const int *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ shift,
+                                             BnRaw raw, int relu, float *__restrict__ out, int *__restrict__ argmax, float *__restrict__ zsel)
 {
     for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int ch = (int)(e % c);
@@ -238,29 +239,26 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
             s = scale[ch];
             h = shift[ch];
         }
-        float vmax = zmax[e], vmin = zmin[e];
-        int imax = amax[e], imin = amin[e];
+        const float sg = s >= 0.0f ? 1.0f : -1.0f;
+        float best = sg * zbest[e];
+        int ibest = abest[e];
 #pragma unroll
         for (int j = 1; j < NP; j++) {
             const int p = pos[g * (NP - 1) + j - 1];
             if (p >= 0) {
                 const size_t e2 = (size_t)(G + p) * c + ch;
-                const float bmax = zmax[e2], bmin = zmin[e2];
-                if (bmax > vmax) {
-                    vmax = bmax;
-                    imax = j * PS + amax[e2];
-                }
-                if (bmin < vmin) {
-                    vmin = bmin;
-                    imin = j * PS + amin[e2];
+                const float b = sg * zbest[e2];
+                if (b > best) {
+                    best = b;
+                    ibest = j * PS + abest[e2];
                 }
             }
         }
-        const float zr = s >= 0.0f ? vmax : vmin;
+        const float zr = sg * best;
         float v = zr * s + h;
         if (relu && !(v > 0.0f)) v = 0.0f;
         out[e] = v;
-        if (argmax) argmax[e] = s >= 0.0f ? imax : imin;
+        if (argmax) argmax[e] = ibest;
         if (zsel) zsel[e] = zr;
     }
 }
@@ -479,19 +477,19 @@ extern "C" int votenet_narrow_rows_half(int b, int n, int m, int c, const int *n
     return check_launch("narrow_rows_half");
 }
 
-extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zmax, const float *zmin, const int *amax, const int *amin,
-                                             const int *pos, const float *scale, const float *shift, const votenet_bn_raw *bn, int relu,
-                                             float *out, int *argmax, float *zsel, void *stream)
+extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zbest, const int *abest, const int *pos, const float *scale,
+                                             const float *shift, const votenet_bn_raw *bn, int relu, float *out, int *argmax, float *zsel,
+                                             void *stream)
 {
     VN_REQUIRE(G >= 0 && c > 0, "bn_pool_finalize_half expects G >= 0, c > 0");
     if (G == 0) return VOTENET_OK;
     const BnRaw raw = to_raw(bn);
-    VN_REQUIRE(zmax && zmin && amax && amin && pos && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
+    VN_REQUIRE(zbest && abest && pos && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
                "bn_pool_finalize_half: null buffer");
     long grid = (G * c + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(bn_pool_finalize_half_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), G * c, (int)G, c, zmax, zmin, amax,
-                       amin, pos, scale, shift, raw, relu, out, argmax, zsel);
+    hipLaunchKernelGGL(bn_pool_finalize_half_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), G * c, (int)G, c, zbest, abest, pos,
+                       scale, shift, raw, relu, out, argmax, zsel);
     return check_launch("bn_pool_finalize_half");
 }
 

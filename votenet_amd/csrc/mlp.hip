@@ -596,7 +596,8 @@ extern "C" int votenet_mlp_linear(const votenet_mlp_input *in, long rows, int ci
 namespace votenet {
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
-                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh = nullptr); // mlp_fast.hip
+                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh = nullptr,
+                            const float *pool_gamma = nullptr); // mlp_fast.hip
 }
 
 extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
@@ -618,13 +619,17 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
     return check_launch("mlp_linear_pool");
 }
 
-// votenet_mlp_linear_pool on the piece layout (half.hip): rows = 16 x pieces; zmax / zmin / amax / amin (pieces x cout) are the raw
-// max / min of every 16-row piece (votenet_bn_pool_finalize_half joins a centre's pieces); the statistics count row 0 of a piece wh
-// times.
+// votenet_mlp_linear_pool on the piece layout (half.hip): rows = 16 x pieces; zbest / abest (pieces x cout) are the pool's candidate of
+// every 16-row piece -- the raw max of z where gamma (the pooled layer's BatchNorm weight, whose sign is the sign of the scale the pool
+// applies) is >= 0, the raw min where it is negative, first occurrence -- joined per centre by votenet_bn_pool_finalize_half; the
+// statistics count row 0 of a piece wh times.
 extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
-                                            float *z, double *stats, const float *wh, float *zmax, float *zmin, int *amax, int *amin,
+                                            float *z, double *stats, const float *wh, const float *gamma, float *zbest, int *abest,
                                             void *stream)
 {
+    float *zmax = zbest, *zmin = zbest;
+    int *amax = abest, *amin = abest;
+    VN_REQUIRE(gamma != nullptr, "mlp_linear_pool_half: the pooled layer's gamma is missing");
     VN_REQUIRE(in != nullptr && in->x != nullptr, "mlp_linear_pool_half: DENSE input descriptor required");
     VN_REQUIRE(rows > 0 && cin > 0 && cout > 0, "mlp_linear_pool_half expects rows > 0, cin > 0, cout > 0");
     VN_REQUIRE(w && wh && zmax && zmin && amax && amin, "mlp_linear_pool_half: null buffer");
@@ -633,7 +638,7 @@ extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long ro
     VN_REQUIRE(in->in_bn == nullptr || (raw.stats && raw.gamma && raw.beta && raw.rows > 0 && in->in_scale == nullptr),
                "mlp_linear_pool_half: in_bn needs stats, gamma, beta, rows > 0 and no in_scale");
     if (!votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, raw, in->in_relu, rows, cin, cout, w, bias, z, stats, zmax, zmin,
-                                         amax, amin, as_stream(stream), wh))
+                                         amax, amin, as_stream(stream), wh, gamma))
         return votenet::set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_linear_pool_half: shape not served (as votenet_mlp_linear_pool)");
     return check_launch("mlp_linear_pool_half");
 }

@@ -117,6 +117,8 @@ struct FastArgs {
     // affine part B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per piece instead of per 64 rows
     const float *wh;
     int pool32;
+    const float *pool_gamma; // pool32: the pooled layer's BatchNorm gamma -- its sign is the sign of the scale the pool will apply, so the
+                             // epilogue keeps ONE candidate per piece and channel (the max where gamma >= 0, else the min) in zmax / amax
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
@@ -713,7 +715,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const float v = acc[i][j][e] + bv;
-                        if (EPI == 2) {
+                        if (EPI == 2 && !A.pool32) {
                             const int rloc = 4 * kh + (e & 3) + 8 * (e >> 2); // inside the 32-row block; ascending in e: strict compares
                             if (e == 0 || v > pmaxv[i][j]) {                  // keep the first occurrence
                                 pmaxv[i][j] = v;
@@ -885,6 +887,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         }
         if (EPI == 2) {
             // the other half-wave holds the interleaved rows of the same 32-row block: combine, smaller row wins ties
+            if (!A.pool32)
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -910,37 +913,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                         const long pc = m0 / kPiece + (wm * MT + i) * 2 + hh;
 #pragma unroll
                         for (int j = 0; j < NT; j++) {
-                            float vmax = 0.f, vmin = 0.f;
-                            int imax = 0, imin = 0;
+                            // the sign of the BatchNorm scale is the sign of gamma: the max of sg * z, first occurrence, is the entry the
+                            // pool takes (the max where the scale is >= 0, the min where it is negative)
+                            const float sg = A.pool_gamma[n0 + (wn * NT + j) * 32 + l31] >= 0.0f ? 1.0f : -1.0f;
+                            float best = 0.f;
+                            int ibest = 0;
 #pragma unroll
                             for (int e8 = 0; e8 < 8; e8++) {
-                                const float v = acc[i][j][hh * 8 + e8] + bvs[j];
+                                const float v = sg * (acc[i][j][hh * 8 + e8] + bvs[j]);
                                 const int rloc = 4 * kh + (e8 & 3) + 8 * (e8 >> 2); // inside the piece; ascending in e8: strict compares
-                                if (e8 == 0 || v > vmax) {
-                                    vmax = v;
-                                    imax = rloc;
-                                }
-                                if (e8 == 0 || v < vmin) {
-                                    vmin = v;
-                                    imin = rloc;
+                                if (e8 == 0 || v > best) {
+                                    best = v;
+                                    ibest = rloc;
                                 }
                             }
-                            const float ov = __shfl_xor(vmax, 32), uv = __shfl_xor(vmin, 32);
-                            const int oi = __shfl_xor(imax, 32), ui = __shfl_xor(imin, 32);
-                            if (ov > vmax || (ov == vmax && oi < imax)) {
-                                vmax = ov;
-                                imax = oi;
-                            }
-                            if (uv < vmin || (uv == vmin && ui < imin)) {
-                                vmin = uv;
-                                imin = ui;
+                            const float ov = __shfl_xor(best, 32);
+                            const int oi = __shfl_xor(ibest, 32);
+                            if (ov > best || (ov == best && oi < ibest)) {
+                                best = ov;
+                                ibest = oi;
                             }
                             if (lane < 32) {
                                 const size_t o = (size_t)pc * cout + n0 + (wn * NT + j) * 32 + l31;
-                                A.zmax[o] = vmax;
-                                A.zmin[o] = vmin;
-                                A.amax[o] = imax;
-                                A.amin[o] = imin;
+                                A.zmax[o] = sg * best; // the raw z
+                                A.amax[o] = ibest;
                             }
                         }
                     }
@@ -1144,11 +1140,12 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
 // forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
-                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh)
+                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh, const float *pool_gamma)
 {
     FastArgs a = {};
     a.wh = wh;                       // piece layout (half.hip): weighted statistics ...
-    a.pool32 = wh != nullptr ? 1 : 0; // ... and raw max / min per 16-row piece
+    a.pool32 = wh != nullptr ? 1 : 0; // ... and the pool's candidate (max or min by the sign of gamma) per 16-row piece
+    a.pool_gamma = pool_gamma;
     a.x = x;
     a.in_scale = in_scale;
     a.in_shift = in_shift;

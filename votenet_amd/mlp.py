@@ -777,23 +777,28 @@ def linear_pool_supported(rows, cin, cout, k):
     return k == 64 and rows > 0 and rows % 128 == 0 and cin % 32 == 0 and cin <= 512 and cout % 128 == 0
 
 
-def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True, in_bn=None, half=None):
+def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=True, keep_z=True, in_bn=None, half=None, gamma=None):
     """linear_dense whose epilogue also emits the raw max / min of every group of k rows: -> z or None, stats, pool where
-    pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool."""
+    pool = (zmax, zmin, amax, amin), each (rows/k, cout); bn_pool_finalize(pool, scale, shift) completes the max-pool.
+    half (piece layout): pool = (zbest, abest), each (pieces, cout) -- one candidate per 16-row piece, the max of z where gamma (the
+    layer's own BatchNorm weight: its sign is the sign of the scale the pool applies) is >= 0, else the min."""
     rows, cin = x.shape
     cout = w.shape[1]
-    g = rows // k if half is None else half.nh  # half: raw max / min per piece of 16 compact rows
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device) if keep_z else None
     stats = _zeros_f64(2 * cout, x.device)
-    vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
-    args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
     if half is not None:
+        if gamma is None:
+            raise L.InvalidArgumentError("linear_dense_pool(half=...): the layer's gamma decides which extreme a piece keeps")
+        zbest = torch.empty((half.nh, cout), dtype=torch.float32, device=x.device)
+        abest = torch.empty((half.nh, cout), dtype=torch.int32, device=x.device)
         with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool half")):
             L.check(L.lib().votenet_mlp_linear_pool_half(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
-                                                         L.ptr(half.wh), L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]),
-                                                         L.stream_ptr()))
-        return z, stats, (vals[0], vals[1], args[0], args[1])
+                                                         L.ptr(half.wh), L.ptr(gamma), L.ptr(zbest), L.ptr(abest), L.stream_ptr()))
+        return z, stats, (zbest, abest)
+    g = rows // k
+    vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
+    args = torch.empty((2, g, cout), dtype=torch.int32, device=x.device)
     with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool")):
         L.check(L.lib().votenet_mlp_linear_pool(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats), k,
                                                 L.ptr(vals[0]), L.ptr(vals[1]), L.ptr(args[0]), L.ptr(args[1]), L.stream_ptr()))
@@ -802,7 +807,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
 
 def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, want_zsel=False, half=None):
     """bn: a PendingBN instead of scale / shift (the kernel finalizes it).  -> out, argmax [, zsel = raw z at the arg-max]."""
-    zmax, zmin, amax, amin = pool
+    zmax = pool[0]
     raw = None
     if bn is not None:
         if bn.done:
@@ -817,10 +822,11 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, 
     zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None
     if half is not None:
         with L.device_guard(zmax.device):
-            L.check(L.lib().votenet_bn_pool_finalize_half(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(half.pos),
-                                                          L.ptr(scale), L.ptr(shift), ctypes.byref(raw) if raw is not None else None,
-                                                          1 if relu else 0, L.ptr(out), L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
+            L.check(L.lib().votenet_bn_pool_finalize_half(g, c, L.ptr(pool[0]), L.ptr(pool[1]), L.ptr(half.pos), L.ptr(scale), L.ptr(shift),
+                                                          ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),
+                                                          L.ptr(arg), L.ptr(zsel), L.stream_ptr()))
         return (out, arg, zsel) if want_zsel else (out, arg)
+    zmax, zmin, amax, amin = pool
     with L.device_guard(zmax.device):
         L.check(L.lib().votenet_bn_pool_finalize(g, c, L.ptr(zmax), L.ptr(zmin), L.ptr(amax), L.ptr(amin), L.ptr(scale), L.ptr(shift),
                                                  ctypes.byref(raw) if raw is not None else None, 1 if relu else 0, L.ptr(out),

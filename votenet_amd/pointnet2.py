@@ -410,7 +410,8 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             half = tape[0].get("half") if first[0] in ("assembled", "narrow") else None
             if half is not None and not (gram_form or not keep_z):
                 raise M.L.VotenetError("half-group layout: the pooled layer's backward must be in Gram form")
-            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend, half=half)
+            zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend, half=half,
+                                               gamma=L.p("gamma") if half is not None else None)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, gram_form=gram_form,
                        in_affine=pend.out if pend is not None else None, cout=w.shape[1], half=half)
         elif L.cout_pad and i > 0:
