@@ -505,7 +505,7 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
 {
     constexpr bool HALF = K == kPiece;
     constexpr int LD = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float xs[K][LD];
+    __shared__ __attribute__((aligned(16))) float xs[HALF ? 2 : 1][K][LD];
     const int tid = threadIdx.x;
     float acc[CIN];
 #pragma unroll
@@ -522,68 +522,94 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
     }
     const float fl = (in_scale && in_relu) ? 0.0f : -__builtin_inff();
     constexpr int NL = K * Q / 256; // float4 per thread per group tile
-    float4 nxt[NL];
-    float n_g = 0.0f, n_z = 0.0f, n_w = 1.0f; // the group's pooled gradient / raw arg-max value / arg-max row of this thread's channel,
-    int n_a = 0;                              // fetched with the tile, one group ahead (they were a loaded-memory latency per group)
-    auto fetch = [&](long g) {
+    // A piece's tile is 8 KB and its work a fraction of a microsecond: with one tile in flight per workgroup the pass ran at one loaded-memory
+    // latency per group.  D tiles (and their channels' gout / zsel / argmax) travel ahead in registers; the LDS tile is double-buffered,
+    // one barrier per group.
+    constexpr int D = HALF ? 4 : 1;
+    float4 nxt[D][NL];
+    float n_g[D], n_z[D], n_w[D]; // the group's pooled gradient / raw arg-max value of this thread's channel, the piece's weight
+    int n_a[D];                   // ... and its arg-max row
+    auto fetch = [&](int d, long g) {
         const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)g * K * CIN);
 #pragma unroll
-        for (int h = 0; h < NL; h++) nxt[h] = src[tid + h * 256];
+        for (int h = 0; h < NL; h++) nxt[d][h] = src[tid + h * 256];
         const int code = HALF ? hc[g] : 0;
         const long ctr = HALF ? (long)(code / kBallPieces) : g;
-        if (HALF) n_w = wh[g];
+        n_w[d] = HALF ? wh[g] : 1.0f;
+        n_z[d] = n_g[d] = 0.0f;
+        n_a[d] = 0;
         if (own) {
-            n_z = zsel[(size_t)ctr * cout + tid];
-            n_g = gout[(size_t)ctr * cout + tid];
-            n_a = argmax[(size_t)ctr * cout + tid];
+            n_z[d] = zsel[(size_t)ctr * cout + tid];
+            n_g[d] = gout[(size_t)ctr * cout + tid];
+            n_a[d] = argmax[(size_t)ctr * cout + tid];
             if (HALF) {
-                n_a -= (code % kBallPieces) * kPiece;
-                if (n_a < 0 || n_a >= kPiece) { // another piece of the centre holds this channel's arg-max
-                    n_a = 0;
-                    n_g = 0.0f;
+                n_a[d] -= (code % kBallPieces) * kPiece;
+                if (n_a[d] < 0 || n_a[d] >= kPiece) { // another piece of the centre holds this channel's arg-max
+                    n_a[d] = 0;
+                    n_g[d] = 0.0f;
                 }
             }
         }
     };
-    if ((long)blockIdx.x < groups) fetch(blockIdx.x);
-    for (long g = blockIdx.x; g < groups; g += gridDim.x) {
 #pragma unroll
-        for (int h = 0; h < NL; h++) { // (tid + h*256) % Q == q: 256 % Q == 0
-            float4 v = nxt[h];
-            v.x = fmaxf(v.x * sc.x + sh.x, fl);
-            v.y = fmaxf(v.y * sc.y + sh.y, fl);
-            v.z = fmaxf(v.z * sc.z + sh.z, fl);
-            v.w = fmaxf(v.w * sc.w + sh.w, fl);
-            *reinterpret_cast<float4 *>(&xs[(tid + h * 256) / Q][q * 4]) = v;
-        }
-        float gg = n_g;
-        const float zz = n_z, w31 = n_w;
-        const int ar = n_a;
-        const long gn = g + gridDim.x;
-        fetch(gn < groups ? gn : g); // the next tile travels while this one is used
-        __syncthreads();
-        if (own) {
-            if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
-            const float v = cA * gg;
-            if (v != 0.0f) {
-                const float4 *row = reinterpret_cast<const float4 *>(&xs[ar][0]);
+    for (int d = 0; d < D; d++) {
+        const long g = (long)blockIdx.x + (long)d * gridDim.x;
+        fetch(d, g < groups ? g : groups - 1);
+    }
+    int buf = 0;
+    for (long g0 = blockIdx.x; g0 < groups; g0 += (long)D * gridDim.x) {
 #pragma unroll
-                for (int i = 0; i < Q; i++) {
-                    const float4 a = row[i];
-                    acc[4 * i] += a.x * v;
-                    acc[4 * i + 1] += a.y * v;
-                    acc[4 * i + 2] += a.z * v;
-                    acc[4 * i + 3] += a.w * v;
+        for (int d = 0; d < D; d++) {
+            const long g = g0 + (long)d * gridDim.x;
+            if (g >= groups) break; // (uniform over the workgroup)
+            float(*xt)[LD] = xs[HALF ? buf : 0];
+#pragma unroll
+            for (int h = 0; h < NL; h++) { // (tid + h*256) % Q == q: 256 % Q == 0
+                float4 v = nxt[d][h];
+                v.x = fmaxf(v.x * sc.x + sh.x, fl);
+                v.y = fmaxf(v.y * sc.y + sh.y, fl);
+                v.z = fmaxf(v.z * sc.z + sh.z, fl);
+                v.w = fmaxf(v.w * sc.w + sh.w, fl);
+                *reinterpret_cast<float4 *>(&xt[(tid + h * 256) / Q][q * 4]) = v;
+            }
+            float gg = n_g[d];
+            const float zz = n_z[d], w31 = n_w[d];
+            const int ar = n_a[d];
+            const long gn = g + (long)D * gridDim.x;
+            fetch(d, gn < groups ? gn : g); // this stage's registers travel again while the tile is used
+            __syncthreads();
+            if (own) {
+                if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
+                const float v = cA * gg;
+                if (v != 0.0f) {
+                    const float4 *row = reinterpret_cast<const float4 *>(&xt[ar][0]);
+                    // eight 16-byte LDS reads in flight, then their 32 multiply-adds (one read at a time was an LDS latency per 4 flops:
+                    // ~2 us per group with the one or two wavefronts per SIMD this kernel runs at)
+#pragma unroll
+                    for (int i0 = 0; i0 < Q; i0 += 8) {
+                        float4 a[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) a[i] = row[i0 + i];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            acc[4 * (i0 + i)] += a[i].x * v;
+                            acc[4 * (i0 + i) + 1] += a[i].y * v;
+                            acc[4 * (i0 + i) + 2] += a[i].z * v;
+                            acc[4 * (i0 + i) + 3] += a[i].w * v;
+                        }
+                    }
                 }
             }
-        }
-        if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
-            const int jc = tid - (256 - CIN);
+            if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
+                const int jc = tid - (256 - CIN);
 #pragma unroll 8
-            for (int r = (HALF ? 1 : 0); r < K; r++) csum += xs[r][jc];
-            if (HALF) csum += w31 * xs[0][jc]; // the ball's slot 0 also stands for its dropped copies
+                for (int r = (HALF ? 1 : 0); r < K; r++) csum += xt[r][jc];
+                if (HALF) csum += w31 * xt[0][jc]; // the ball's slot 0 also stands for its dropped copies
+            }
+            if (HALF) buf ^= 1; // the other tile was last read before this group's barrier: the next group may overwrite it
+            else __syncthreads();
         }
-        __syncthreads();
     }
     if (part) { // this workgroup's slice [(CIN + 1) x cout]: dW rows, then the column sums; added in workgroup order afterwards
         float *__restrict__ mine = part + (size_t)blockIdx.x * (CIN + 1) * cout;
