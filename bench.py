@@ -423,7 +423,7 @@ def main():
                              "v_mfma_f32_32x32x2_f32 instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
 
     # the same step on the FULL row layout (64 rows per ball, copies of slot 0 included: the reference's tensor shape), and what the
-    # half-group layout keeps of each level's grouped rows on these scenes
+    # piece layout keeps of each level's grouped rows on these scenes
     full_step = row_layout = None
     if world == 1 and not args.headline_only and workload == "train":
         from votenet_amd import pointnet2 as vp2
@@ -435,10 +435,11 @@ def main():
                 half = rec["recs"][0].get("half")
                 if half is not None:
                     kept[name] = round(half.rows / float(rec["idx"].numel()), 3)
-            row_layout = {"half_groups": True, "grouped_rows_kept": kept,
-                          "what": "a ball with pts_cnt <= 31 (tf_grouping_g.cu:26-29 pads it with copies of its first hit) keeps slots 0..31 only, "
-                                  "slot 31 standing for the 33 dropped copies with weight 33 in the BatchNorm sums (csrc/half.hip): the same results "
-                                  "up to summation order; every GEMM of sa1-sa4 runs on these rows, so executed flops and gemm time both shrink"}
+            row_layout = {"piece_rows": 16, "grouped_rows_kept": kept,
+                          "what": "a ball (tf_grouping_g.cu:26-29 pads it to 64 slots with copies of its first hit) keeps the 16-row pieces that hold "
+                                  "a real neighbour, ceil(pts_cnt / 16) of 4; its slot 0 stands for the dropped copies with weight 1 + 16 * dropped "
+                                  "pieces in the BatchNorm sums (csrc/half.hip): the same results up to summation order; every GEMM of sa1-sa4 runs "
+                                  "on these rows, so executed flops and gemm time both shrink"}
             vp2.HALF_GROUPS = False
             try:
                 for _ in range(4):
@@ -455,7 +456,7 @@ def main():
                 step()
             torch.cuda.synchronize()
             full_step = {"value": round(B * 10 / dt5, 2), "ms_per_step": round(dt5 / 10 * 1e3, 3), "steps": 10,
-                         "what": "same workload with pointnet2.HALF_GROUPS = False: all 64 rows of every ball through the grouped MLP"}
+                         "what": "same workload with pointnet2.HALF_GROUPS = False (the piece layout off): all 64 rows of every ball through the grouped MLP"}
 
     # the same two kernels alone on the GPU (in the timed region they share it with the GEMMs of the previous batch)
     iso_fps = iso_bq = None

@@ -394,7 +394,7 @@ def test_training_gradients_are_bit_reproducible(hiplib, dev, full):
         from votenet_amd import pointnet2 as P
         # the deterministic pass stores the first SA layers (the assembled form sums per-point counts with atomics and is switched
         # off in that mode): compare like with like, or ReLU / arg-max decisions move with the last bits of the forward pass
-        # (the half-group layout likewise: it associates the BatchNorm sums differently and is not used by the deterministic pass)
+        # (the piece layout likewise: it associates the BatchNorm sums differently and is not used by the deterministic pass)
         old, P.ASSEMBLE_FIRST = P.ASSEMBLE_FIRST, False
         old_half, P.HALF_GROUPS = P.HALF_GROUPS, False
         try:

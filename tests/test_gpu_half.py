@@ -1,6 +1,6 @@
-"""GPU: the HALF-GROUP layout of a set-abstraction level (csrc/half.hip and the *_half entries of include/votenet_hip.h) against the
-full layout of the same level: the rows a ball repeats (tf_grouping_g.cu:26-29 pads with the first hit) dropped by halves of 32, one row
-standing for the dropped copies with a weight.  Same values per row, same sums up to their association."""
+"""GPU: the PIECE layout of a set-abstraction level (csrc/half.hip and the *_half entries of include/votenet_hip.h) against the full
+layout of the same level: the rows a ball repeats (tf_grouping_g.cu:26-29 pads with the first hit) dropped by pieces of 16, the ball's
+slot 0 standing for the dropped copies with a weight.  Same values per row, same sums up to their association."""
 import numpy as np
 import pytest
 import torch
@@ -171,7 +171,7 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
 
 
 def test_model_with_and_without_the_half_group_layout(hiplib, dev):
-    """The whole hot path with sa1 (narrow first layer) and sa2 / sa3 / sa4 (assembled first layer) on the half-group layout against the full layout: same outputs and losses to fp32
+    """The whole hot path with sa1 (narrow first layer) and sa2 / sa3 / sa4 (assembled first layer) on the piece layout against the full layout: same outputs and losses to fp32
     rounding (the BatchNorm sums are associated differently), the same gradient in the L2 sense (tests/test_gpu_narrow.py: two fp32
     evaluations of a forward pass move ReLU / arg-max decisions), fewer grouped rows."""
     from votenet_amd import loss as VL

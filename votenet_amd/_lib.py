@@ -164,7 +164,7 @@ _SIGS["votenet_three_interpolate_grad_strided"] = [ctypes.c_int] * 4 + [_c_f, ct
 _SIGS["votenet_bias_grad_strided"] = [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p]
 _SIGS["votenet_ema_update"] = [ctypes.c_long, ctypes.c_float, _c_f, _c_f, _c_f, ctypes.c_void_p]
 _SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(RowSegment), ctypes.c_void_p]
-# half-group layout (csrc/half.hip)
+# piece layout (csrc/half.hip)
 _I, _L, _F = ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGS.update({
     "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],

@@ -708,6 +708,8 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
 
 static int g_scatter_reverse = 0;
 extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
+static int g_scatter_wgs = 0; // votenet_debug_scatter_workgroups (tuning hook): 0 = one workgroup per CU and LDS share
+extern "C" void votenet_debug_scatter_workgroups(int n) { g_scatter_wgs = n > 0 ? n : 0; }
 static int g_scatter_form = 1; // 1: one wavefront per group (pool_dgrad_scatter_wave_kernel), 0: one workgroup per group
 extern "C" void votenet_debug_scatter_form(int form) { g_scatter_form = form ? 1 : 0; }
 static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
@@ -786,8 +788,8 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
         }
         if (fresh)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, nwv, 256 * per_cu)), dim3(nwv * 64), smem, st, groups, gout, argmax, zsel, coef, relu, wT,
-                           da, pb);
+        hipLaunchKernelGGL(kern, dim3(pb_grid(groups, nwv, g_scatter_wgs > 0 ? g_scatter_wgs : 256 * per_cu)), dim3(nwv * 64), smem, st, groups, gout,
+                           argmax, zsel, coef, relu, wT, da, pb);
     };
     if (g_scatter_form == 1 || hc) {
 #define VN_SCATTER_WAVE(CI, CO, KK, NW)                                                            \

@@ -816,7 +816,7 @@ def bn_pool_finalize(pool, scale, shift, relu=True, want_argmax=False, bn=None, 
             raw = bn.raw()
     g, c = zmax.shape
     if half is not None:
-        g = half.G  # pool holds one entry per half-group; the result one per centre
+        g = half.G  # pool holds one entry per piece; the result one per centre
     out = torch.empty((g, c), dtype=torch.float32, device=zmax.device)
     arg = torch.empty((g, c), dtype=torch.int32, device=zmax.device) if want_argmax else None
     zsel = torch.empty((g, c), dtype=torch.float32, device=zmax.device) if want_zsel else None

@@ -29,7 +29,7 @@ NARROW_FIRST = True  # leaf SA module with 3 + c <= 8 grouped channels: the firs
 PAD_RAGGED_IN = True  # ragged INPUT widths (voting's 259) padded as well (Layer.cin_pad); False: the bounds-checked GEMMs (A/B)
 ASSEMBLE_FIRST = True  # other SA modules: the first layer's output z0 = P[idx] + dxyz W[0:3] is rebuilt inside the kernels that consume it, never stored (csrc/assemble.hip)
 ASSEMBLE_INLINE = True  # also where the geo records were not computed ahead with the geometry (they are built in place)
-HALF_GROUPS = True     # assembled modules with nsample = 64 drop the all-copy second half of an under-full ball (csrc/half.hip): same results up to summation order, 30-60 % fewer grouped rows on room scenes
+HALF_GROUPS = True     # modules with nsample = 64 run their grouped MLP on the PIECE layout (csrc/half.hip): a ball keeps the 16-row pieces that hold a real neighbour, slot 0 stands for the dropped copies -- same results up to summation order, 28-68 % fewer grouped rows on room scenes
 FUSE_BN_REDUCE = True  # dense input-gradient GEMMs reduce the BatchNorm backward of the layer below in their epilogue
 
 
@@ -409,7 +409,7 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             gram_form = POOL_GRAM_BACKWARD and pend is not None and M.pool_backward_supported(w.shape[0], w.shape[1], pool_k)
             half = tape[0].get("half") if first[0] in ("assembled", "narrow") else None
             if half is not None and not (gram_form or not keep_z):
-                raise M.L.VotenetError("half-group layout: the pooled layer's backward must be in Gram form")
+                raise M.L.VotenetError("piece layout: the pooled layer's backward must be in Gram form")
             zn, st, pool = M.linear_dense_pool(z, w, pool_k, b, None, None, prev_relu, keep_z=keep_z and not gram_form, in_bn=pend, half=half,
                                                gamma=L.p("gamma") if half is not None else None)
             rec = dict(layer=L, kind="dense", x=z, in_scale=sc, in_shift=sh, in_relu=prev_relu, gram_form=gram_form,
@@ -723,7 +723,7 @@ class SAModule:
                     and M.group_linear_backward_supported(m[0].cout, self.nsample) and b * n * m[0].cout * 4 < 2 ** 32)
 
     def half_groups(self, b, n):
-        """True when this module's grouped MLP runs on the half-group layout (csrc/half.hip: the rows that repeat slot 0 dropped by
+        """True when this module's grouped MLP runs on the piece layout (csrc/half.hip: the rows that repeat slot 0 dropped by
         halves of a ball) for b scenes of n points: an assembled first layer, three BatchNorm'ed layers, the pooled one in Gram form."""
         m = self.mlp
         if not (HALF_GROUPS and not M.DETERMINISTIC and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and m[2].bn and POOL_IN_EPILOGUE
@@ -748,7 +748,7 @@ class SAModule:
             else:
                 geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
         elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
-            half = M.half_groups(geom[3])  # the layout and the count of its half-groups: known on the host by the time the MLP runs
+            half = M.half_groups(geom[3])  # the layout and the count of its pieces: known on the host by the time the MLP runs
             geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
             M.half_sort_rows(half, xyz.shape[0] * xyz.shape[1])  # the rows bucketed by point, for the first layer's backward
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
@@ -767,13 +767,13 @@ class SAModule:
         if self.narrow(rows):
             u8, mom = geom[4:6] if len(geom) >= 6 else M.narrow_rows(xyz, new_xyz, points, idx)
             first = ("narrow", u8, mom)
-            if len(geom) >= 7:  # half-group layout: the compact rows
+            if len(geom) >= 7:  # piece layout: the compact rows
                 half = geom[6].resolve()
                 first = ("narrow", half.u8, mom, half)
         elif points is not None and self.assembled(b, xyz.shape[1]) and (len(geom) >= 7 or ASSEMBLE_INLINE):
             geo, cntv, mom = geom[4:7] if len(geom) >= 7 else M.assemble_rows(xyz, new_xyz, idx, pts_cnt=pts_cnt, in_pass=True)
             first = ("assembled", xyz, new_xyz, points, idx, geo, cntv, mom)
-            if len(geom) >= 8:  # half-group layout: the compact rows
+            if len(geom) >= 8:  # piece layout: the compact rows
                 half = geom[7].resolve()
                 first = ("assembled", xyz, new_xyz, points, idx, half.geo, cntv, mom, half)
         z, pend = mlp_chain_forward(self.mlp, rows, first, recs, pool_k=self.nsample, keep_z=tape is not None)
@@ -835,7 +835,7 @@ class SAModule:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
         elif r0["kind"] == "assembled" and r0.get("half") is not None:
             if need_xyz_grad:
-                raise ValueError("SAModule: the half-group layout keeps no per-row dz for the xyz gradient")
+                raise ValueError("SAModule: the piece layout keeps no per-row dz for the xyz gradient")
             S, dz = M.group_linear_backward_half(r0["half"], b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
         elif r0["kind"] == "assembled":
             S, dz = M.group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"],
