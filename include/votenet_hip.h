@@ -675,7 +675,10 @@ int votenet_half_piece_rows(void);
 /* votenet_assemble_rows on the piece layout: geo (up to 64G x 4 floats; rows past 16*nh[0] are not written), cntv and moments
  * exactly as votenet_assemble_rows (they run over the true rows).  nh is read on the device: no host synchronisation. */
 int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
-                               const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream);
+                               const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments,
+                               int *count /* may be NULL; b*n ints, pre-zeroed: += the compact rows that gather every point -- the first
+                                             pass of votenet_half_sort_rows, which is then called with counted = 1 */,
+                               void *stream);
 /* Forward GEMMs on rows = 16*nh compact rows: votenet_assembled_linear / votenet_mlp_linear_pool with the statistics weighted by wh;
  * the pool variant leaves ONE candidate per 16-row piece and channel (zbest / abest, nh x cout): the raw max of z where gamma -- the
  * pooled layer's BatchNorm weight, whose sign is the sign of the scale the pool applies -- is >= 0, the raw min where it is negative,
@@ -713,7 +716,7 @@ int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const flo
  * votenet_group_linear_backward_sorted then sums a point's consecutive rows in a register and stores S point by point
  * (s_points pre-zeroed; atomics only where a chunk of 64 entries shares a point with its neighbour): the piece layout's form of
  * votenet_group_linear_backward_assembled (da = total gradients per compact row; no xyz gradient). */
-int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream);
+int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int counted, int *order, void *stream);
 int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
                                          const float *wx, const float *da, const float *coef, int relu, float *s_points, float *dw_xyz,
                                          void *stream);

@@ -1,16 +1,23 @@
-"""cProfile of the host side of train_step (scratch, GPU box): where do the 4.5 ms of enqueue time go?"""
-import os, sys, cProfile, pstats
+"""cProfile of the host side of one train step (enqueue only): where the host's ~4 ms per step go."""
+import os, sys, time, cProfile, pstats, io
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
 import torch
-from votenet_amd import loss as VL, model as VM, synth
+from votenet_amd import synth, loss as VL
+from votenet_amd.model import VoteNetHotPath
 dev = torch.device("cuda:0")
-B, n = 8, 20480
-xs = [torch.from_numpy(synth.room_batch(B, n, s)).to(dev) for s in (1000, 500000, 900000)]
-gts = [VL.gt_to_device(synth.room_gt(B, n, s), dev) for s in (1000, 500000, 900000)]
-net = VM.VoteNetHotPath(dev, seed=0)
-def run(k):
-    for i in range(k):
-        net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
-run(8); torch.cuda.synchronize()
-pr = cProfile.Profile(); pr.enable(); run(30); pr.disable(); torch.cuda.synchronize()
-st = pstats.Stats(pr); st.sort_stats("tottime").print_stats(28)
+net = VoteNetHotPath(dev, seed=0)
+xs = [torch.from_numpy(synth.room_batch(8, 20480, 1000 + 8 * i)).to(dev) for i in range(3)]
+gts = [VL.gt_to_device(synth.room_gt(8, 20480, 1000 + 8 * i), dev) for i in range(3)]
+for i in range(6):
+    net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+torch.cuda.synchronize()
+import gc; gc.collect(); gc.disable()
+pr = cProfile.Profile()
+for i in range(6, 26):
+    torch.cuda.synchronize()
+    pr.enable()
+    net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+    pr.disable()
+s = io.StringIO()
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
+print(s.getvalue()[:6000])

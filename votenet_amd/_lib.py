@@ -168,7 +168,7 @@ _SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(Row
 _I, _L, _F = ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGS.update({
     "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],
-    "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 9 + [ctypes.c_void_p],
+    "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 10 + [ctypes.c_void_p],
     "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_bn_pool_finalize_half": [_L, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 3 + [ctypes.c_void_p],
@@ -180,7 +180,7 @@ _SIGS.update({
     "votenet_assembled_dgrad_bn_reduce_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 9 + [_F, _I, ctypes.c_void_p,
                                                                                              ctypes.POINTER(CoefTail), _c_f, ctypes.c_void_p],
     "votenet_half_piece_rows": [],
-    "votenet_half_sort_rows": [_I, _I] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_half_sort_rows": [_I, _I] + [_c_f] * 3 + [_I, _c_f, ctypes.c_void_p],
     "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 2 + [ctypes.c_void_p],
     "votenet_narrow_rows_half": [_I] * 4 + [_c_f] * 9 + [ctypes.c_void_p],
     "votenet_narrow_linear_half": [_L, _I, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
@@ -246,8 +246,8 @@ _cur_device = getattr(torch._C, "_cuda_getDevice", None)
 def stream_ptr():
     """The current HIP stream of the current device as a void* for the C ABI."""
     if _raw_stream is not None and _cur_device is not None:
-        return ctypes.c_void_p(_raw_stream(_cur_device()))
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        return _raw_stream(_cur_device())  # (a plain int: ctypes converts it)
+    return torch.cuda.current_stream().cuda_stream
 
 
 class _NoGuard:
@@ -271,7 +271,8 @@ def device_guard(device):
 
 
 def ptr(t):
-    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    """The device address of a tensor for a void* argument (a plain int: ctypes converts it; no c_void_p object per argument)."""
+    return t.data_ptr() if t is not None else None
 
 
 def dev_f32(t, name, rank=None, last=None):

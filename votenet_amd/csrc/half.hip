@@ -33,41 +33,44 @@ __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__r
                                                            float *__restrict__ wh, int *__restrict__ nh_out)
 {
     __shared__ int s_wave[16];
-    __shared__ int s_n2;
+    __shared__ int s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int per = (G + 1023) / 1024;
-    const int c0 = tid * per, c1 = min(G, c0 + per);
-    int mine = 0;
-    for (int c = c0; c < c1; c++) mine += kept_pieces(pts_cnt[c]) - 1;
-    int x = mine; // inclusive scan over the wavefront, then over the 16 wavefronts
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(x, off);
-        if (lane >= off) x += t;
-    }
-    if (lane == 63) s_wave[wv] = x;
+    if (tid == 0) s_carry = 0;
     __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wv; w++) base += s_wave[w];
-    int p = base + x - mine;
-    for (int c = c0; c < c1; c++) {
-        hc[c] = c * NP;
-        const int kc = kept_pieces(pts_cnt[c]);
-        for (int j = 1; j < NP; j++) {
-            if (j < kc) {
-                hc[G + p] = c * NP + j;
-                pos[c * (NP - 1) + j - 1] = p++;
-            } else {
-                pos[c * (NP - 1) + j - 1] = -1;
+    for (int c0 = 0; c0 < G; c0 += 1024) { // rounds of 1024 consecutive centres: coalesced, ascending
+        const int c = c0 + tid;
+        const int kc = c < G ? kept_pieces(pts_cnt[c]) : 1;
+        const int mine = kc - 1;
+        int x = mine; // inclusive scan over the wavefront, then over the 16 wavefronts
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int t = __shfl_up(x, off);
+            if (lane >= off) x += t;
+        }
+        if (lane == 63) s_wave[wv] = x;
+        __syncthreads();
+        int base = s_carry;
+        for (int w = 0; w < wv; w++) base += s_wave[w];
+        int p = base + x - mine;
+        if (c < G) {
+            hc[c] = c * NP;
+            for (int j = 1; j < NP; j++) {
+                if (j < kc) {
+                    hc[G + p] = c * NP + j;
+                    pos[c * (NP - 1) + j - 1] = p++;
+                } else {
+                    pos[c * (NP - 1) + j - 1] = -1;
+                }
             }
         }
+        __syncthreads();
+        if (tid == 1023) s_carry = base + x;
+        __syncthreads();
     }
-    if (tid == 1023) s_n2 = p; // the last thread's running index = the total (its chunk may be empty)
-    __syncthreads();
     if (tid == 0) {
         // a GEMM tile is 128 rows = TP pieces: round up with all-copy pieces (the next piece of a ball that dropped some), which is exact
         // (G % TP == 0: there are enough)
-        int n2 = s_n2;
+        int n2 = s_carry;
         for (int c = 0; c < G && ((G + n2) % TP) != 0; c++)
             for (int j = 1; j < NP && ((G + n2) % TP) != 0; j++)
                 if (pos[c * (NP - 1) + j - 1] < 0) {
@@ -75,11 +78,11 @@ __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__r
                     hc[G + n2] = c * NP + j;
                     n2++;
                 }
-        s_n2 = n2;
+        s_carry = n2;
         nh_out[0] = G + n2;
     }
     __syncthreads();
-    const int nh = G + s_n2;
+    const int nh = G + s_carry;
     for (int q = tid; q < nh; q += 1024) {
         float w = 1.0f;
         if (q < G) {
@@ -100,6 +103,21 @@ __device__ __forceinline__ double half_shfl_xor_f64(double v, int m)
 }
 __device__ __forceinline__ long long half_fixed(float v) { return (long long)((double)v * 4294967296.0); }
 
+// A ball's copies of slot 0 are consecutive rows with one point, and a few points are slot 0 of hundreds of balls: one atomic per RUN of
+// equal points inside a wavefront (the run's first lane adds the run's length), not one per row, or those addresses serialise the pass.
+__device__ __forceinline__ void half_sort_runs(unsigned prow, bool live, int lane, int &run_start, int &run_len)
+{
+    const unsigned prev = __shfl_up(prow, 1);
+    const bool prev_live = __shfl_up((int)live, 1) != 0;
+    const bool starts = live && (lane == 0 || !prev_live || prev != prow);
+    const unsigned long long sm = __ballot(starts), lm = __ballot(live);
+    // the run this lane belongs to starts at the highest start bit at or below the lane; it ends before the next start / the first dead lane
+    const unsigned long long below = sm & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+    run_start = below ? 63 - __builtin_clzll(below) : 0;
+    const unsigned long long after = (sm | ~lm) & ~((run_start == 63) ? ~0ull : ((1ull << (run_start + 1)) - 1ull));
+    const int end = after ? __builtin_ctzll(after) : 64;
+    run_len = end - run_start;
+}
 // votenet_assemble_rows on the piece layout: thread = compact row r = q * PS + s <-> (centre hc[q] / NP, slot PS (hc[q] % NP) + s).
 // The per-point counters and the moments run over the TRUE rows exactly as in assemble_rows_kernel: slot k < pts_cnt adds itself, slot 0
 // also the 64 - pts_cnt copies.
@@ -107,14 +125,18 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
                                                                  const float *__restrict__ new_xyz, const int *__restrict__ idx,
                                                                  const int *__restrict__ pts_cnt, const int *__restrict__ hc,
                                                                  float4 *__restrict__ geo, long long *__restrict__ cntv,
-                                                                 double *__restrict__ moments)
+                                                                 double *__restrict__ moments, int *__restrict__ count)
 {
     __shared__ double red[4][9];
     double acc[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) acc[i] = 0.0;
     const long rows = (long)nh_dev[0] * PS; // the number of pieces is known on the device only when this is enqueued
-    for (long r = (long)blockIdx.x * 256 + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+        const long r = r0 + threadIdx.x;
+        const bool live = r < rows;
+        unsigned my_prow = 0;
+        if (live) {
         const int q = (int)(r / PS), s = (int)(r % PS);
         const int code = hc[q];
         const int c = code / NP;
@@ -125,6 +147,7 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
         const float dy = xyz[(size_t)prow * 3 + 1] - new_xyz[(size_t)c * 3 + 1];
         const float dz = xyz[(size_t)prow * 3 + 2] - new_xyz[(size_t)c * 3 + 2];
         geo[r] = make_float4(dx, dy, dz, __uint_as_float(prow));
+        my_prow = prow;
         int cnt = pts_cnt[c];
         if (cnt < 1) cnt = 1;
         if (k < cnt) {
@@ -139,6 +162,12 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
             const double m = (double)mult, x = dx, y = dy, z = dz;
             acc[0] += m * x; acc[1] += m * y; acc[2] += m * z;
             acc[3] += m * x * x; acc[4] += m * x * y; acc[5] += m * x * z; acc[6] += m * y * y; acc[7] += m * y * z; acc[8] += m * z * z;
+        }
+        }
+        if (count) { // the first pass of votenet_half_sort_rows rides here: rows per point, one atomic per run of equal points
+            int rs, rl;
+            half_sort_runs(my_prow, live, threadIdx.x & 63, rs, rl);
+            if (live && rs == (int)(threadIdx.x & 63)) atomicAdd(&count[my_prow], rl);
         }
     }
     if (!moments) return;
@@ -270,21 +299,6 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
 // The backward pass then walks CHUNKS of 64 consecutive entries: the rows of a point are consecutive, a thread (one channel) sums them
 // in a register and stores the point's row of S once; only a chunk's first and last point can be shared with a neighbour chunk and are
 // added with atomics -- 2 per 64 rows instead of ~30.
-// A ball's copies of slot 0 are consecutive rows with one point, and a few points are slot 0 of hundreds of balls: one atomic per RUN of
-// equal points inside a wavefront (the run's first lane adds the run's length), not one per row, or those addresses serialise the pass.
-__device__ __forceinline__ void half_sort_runs(unsigned prow, bool live, int lane, int &run_start, int &run_len)
-{
-    const unsigned prev = __shfl_up(prow, 1);
-    const bool prev_live = __shfl_up((int)live, 1) != 0;
-    const bool starts = live && (lane == 0 || !prev_live || prev != prow);
-    const unsigned long long sm = __ballot(starts), lm = __ballot(live);
-    // the run this lane belongs to starts at the highest start bit at or below the lane; it ends before the next start / the first dead lane
-    const unsigned long long below = sm & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
-    run_start = below ? 63 - __builtin_clzll(below) : 0;
-    const unsigned long long after = (sm | ~lm) & ~((run_start == 63) ? ~0ull : ((1ull << (run_start + 1)) - 1ull));
-    const int end = after ? __builtin_ctzll(after) : 64;
-    run_len = end - run_start;
-}
 __global__ __launch_bounds__(256) void half_sort_count_kernel(const int *__restrict__ nh_dev, const float4 *__restrict__ geo,
                                                               int *__restrict__ count)
 {
@@ -448,7 +462,8 @@ extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc,
 extern "C" int votenet_half_piece_rows(void) { return PS; }
 
 extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *xyz, const float *new_xyz, const int *idx,
-                                          const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, void *stream)
+                                          const int *pts_cnt, const int *hc, float *geo, long long *cntv, double *moments, int *count,
+                                          void *stream)
 {
     VN_REQUIRE(b > 0 && n > 0 && m > 0, "assemble_rows_half: bad shape");
     const long max_rows = 64L * b * m;
@@ -458,7 +473,7 @@ extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, co
     long gx = (max_rows / 2 + 256 * 8 - 1) / (256 * 8); // sized for a typical fill; grid-stride covers the rest
     if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, n, m, xyz, new_xyz, idx, pts_cnt, hc,
-                       reinterpret_cast<float4 *>(geo), cntv, moments);
+                       reinterpret_cast<float4 *>(geo), cntv, moments, count);
     return check_launch("assemble_rows_half");
 }
 
@@ -495,17 +510,19 @@ extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zbest, 
 
 // order (64 G ints; 16 nh[0] written) = the level's compact rows bucketed by the point they gather (geo[r].w); work: npts ints.
 // Coordinates only: runs with the geometry.  The order inside a bucket is whatever the fill's atomics decide.
-extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int *order, void *stream)
+extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int counted, int *order, void *stream)
 {
     VN_REQUIRE(npts > 0 && G > 0 && nh && geo && work && order, "half_sort_rows: bad arguments");
     VN_REQUIRE((uintptr_t)geo % 16 == 0, "half_sort_rows: geo must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
-    if (hipMemsetAsync(work, 0, (size_t)npts * sizeof(int), st) != hipSuccess) return set_error(VOTENET_E_HIP, "half_sort_rows: memset failed");
     const long max_rows = 64L * G;
     long gx = (max_rows / 2 + 256 * 4 - 1) / (256 * 4);
     if (gx > 2048) gx = 2048;
     const float4 *g4 = reinterpret_cast<const float4 *>(geo);
-    hipLaunchKernelGGL(half_sort_count_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work);
+    if (!counted) { // (counted: work holds the rows per point already -- votenet_assemble_rows_half's count argument)
+        if (hipMemsetAsync(work, 0, (size_t)npts * sizeof(int), st) != hipSuccess) return set_error(VOTENET_E_HIP, "half_sort_rows: memset failed");
+        hipLaunchKernelGGL(half_sort_count_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work);
+    }
     hipLaunchKernelGGL(half_sort_scan_kernel, dim3(1), dim3(1024), 0, st, npts, work);
     hipLaunchKernelGGL(half_sort_fill_kernel, dim3((unsigned)gx), dim3(256), 0, st, nh, g4, work, order);
     return check_launch("half_sort_rows");

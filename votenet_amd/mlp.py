@@ -514,12 +514,16 @@ def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
     if k != 64:
         raise L.InvalidArgumentError("assemble_rows_half expects nsample == 64")
     geo = torch.empty((b * m * 64, 4), dtype=torch.float32, device=xyz.device)
-    cntv = torch.zeros((b * n, 4), dtype=torch.int64, device=xyz.device)
-    mom = torch.zeros(9, dtype=torch.float64, device=xyz.device)
+    # ONE zero-filled buffer: the per-point counters (b n x 4 int64), the moments (9 f64) and the rows-per-point counts of the bucketing
+    npts = b * n
+    zero = torch.zeros(npts * 4 + 16 + (npts + 1) // 2, dtype=torch.int64, device=xyz.device)
+    cntv = zero[:npts * 4].view(npts, 4)
+    mom = zero[npts * 4:npts * 4 + 9].view(torch.float64)
+    work = zero[npts * 4 + 16:].view(torch.int32)[:npts]
     with L.device_guard(xyz.device):
         L.check(L.lib().votenet_assemble_rows_half(b, n, m, L.ptr(half.nh_dev), L.ptr(xyz), L.ptr(new_xyz), L.ptr(idx), L.ptr(pts_cnt),
-                                                   L.ptr(half._hc), L.ptr(geo), L.ptr(cntv), L.ptr(mom), L.stream_ptr()))
-    half._geo = geo
+                                                   L.ptr(half._hc), L.ptr(geo), L.ptr(cntv), L.ptr(mom), L.ptr(work), L.stream_ptr()))
+    half._geo, half._work = geo, work
     return geo, cntv, mom
 
 
@@ -542,10 +546,14 @@ def narrow_rows_half(xyz, new_xyz, feat, idx, pts_cnt, half):
 def half_sort_rows(half, npts):
     """Bucket the layout's compact rows by the point they gather (geo must be assembled): half.order.  Geometry only."""
     dev = half._geo.device
-    work = torch.empty(npts, dtype=torch.int32, device=dev)
+    work, half._work = getattr(half, "_work", None), None  # the rows per point, counted by assemble_rows_half (consumed here)
+    counted = work is not None
+    if not counted:
+        work = torch.empty(npts, dtype=torch.int32, device=dev)
     order = torch.empty(half.G * 64, dtype=torch.int32, device=dev)
     with L.device_guard(dev):
-        L.check(L.lib().votenet_half_sort_rows(npts, half.G, L.ptr(half.nh_dev), L.ptr(half._geo), L.ptr(work), L.ptr(order), L.stream_ptr()))
+        L.check(L.lib().votenet_half_sort_rows(npts, half.G, L.ptr(half.nh_dev), L.ptr(half._geo), L.ptr(work), 1 if counted else 0, L.ptr(order),
+                                               L.stream_ptr()))
     half._order = order
     if half.nh is not None:  # the count is known already
         half.order = order[:half.nh * PIECE]
