@@ -609,12 +609,16 @@ def main():
                 if u:
                     e["mfma_util_alone"] = u.get("mfma_util")
                     e["tflops_alone"] = u.get("alone_tflops")
+                    if u.get("hbm_gbs_alone") is not None:  # the piece-layout families: the same launch's HBM rate (FETCH + WRITE counters)
+                        e["hbm_gbs_alone"], e["hbm_frac_alone"] = u["hbm_gbs_alone"], u.get("hbm_frac_alone")
                 return e
             mfma["by_family"] = {k: fam_entry(k, v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:8]}
             mfma["by_family_note"] = ("tflops / frac: the family's executed flops / the SUM of its launch durations INSIDE the step (two GEMM streams and "
                                       "the next batch's geometry run beside them); mfma_util_alone / tflops_alone: rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES "
-                                      "share and rate of the same kernel alone on the GPU at sa2's / sa1's shape, from %s (separate --pmc passes, "
-                                      "not measured in this run)" % util_src) if util_src else None
+                                      "share and rate of the same kernel alone on the GPU at sa2's / sa1's shape, hbm_gbs_alone / hbm_frac_alone: "
+                                      "its HBM bytes (FETCH_SIZE x 2 + WRITE_SIZE) over its duration and the share of 8 TB/s -- the piece-layout "
+                                      "kernels are bound by their row traffic, not by the matrix pipe -- from %s and %s (separate --pmc passes, "
+                                      "not measured in this run)" % (util_src, pj.get("source_pieces"))) if util_src else None
             mfma["peak_bf3_equiv"] = MFMA_BF3_EQUIV_TF
             mfma["frac_bf3_equiv"] = round(ach / MFMA_BF3_EQUIV_TF, 4)
             mfma["pricing"] = ("frac prices the fp32 multiply-adds against the fp32 MFMA peak (157.3 TFLOP/s: what a kernel on v_mfma_f32_32x32x2_f32 "

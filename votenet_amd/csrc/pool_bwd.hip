@@ -958,17 +958,19 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 }
 
 int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always
+static int g_gram_wgs = 384; // votenet_debug_gram_workgroups (tuning hook)
 template <int C>
 static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st, const float *wh = nullptr)
 {
     // 384 workgroups as the fp32 weight-gradient kernels (mlp_wgrad_fast.hip, plan_fast): the launch runs beside the input-gradient chain
-    long rpb = (rows + 383) / 384;
+    long rpb = (rows + g_gram_wgs - 1) / g_gram_wgs;
     rpb = (rpb + 31) / 32 * 32;
     if (rpb < 128) rpb = 128;
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh);
 }
 extern "C" void votenet_debug_gram_bf3(int on) { g_gram_bf3 = on; }
+extern "C" void votenet_debug_gram_workgroups(int n) { g_gram_wgs = n > 0 ? n : 384; }
 
 extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
                                 void *stream)
