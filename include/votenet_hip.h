@@ -495,6 +495,8 @@ void votenet_debug_fast_bf3(int on);
 /* votenet_mlp_gram on split operands as well (pool_bwd.hip: 8 consecutive rows of a channel per MFMA fragment; c = 64 or 128,
  * no scratch = atomics mode); 0: the fp32 MFMA kernel always.  Default 1. */
 void votenet_debug_gram_bf3(int on);
+void votenet_debug_fast_xcd_chunk(int on); /* 1 (default): the piece-layout GEMMs that gather the per-point table take their row tiles in
+                                              per-XCD contiguous chunks (an XCD's L2 then holds the scenes its tiles touch); 0: round-robin */
 void votenet_debug_gram_workgroups(int n); /* tuning hook: workgroups of the split-operand Gram kernel (default 384) */
 /* every other weight-gradient GEMM (votenet_mlp_wgrad / _wgrad_bn, assembled, narrow) on split operands: row-major bf16 images in LDS,
  * fragments through ds_read_b64_tr_b16 (mlp_wgrad_fast.hip); 0: the fp32 MFMA kernel.  Default 1. */

@@ -117,6 +117,7 @@ struct FastArgs {
     // affine part B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per piece instead of per 64 rows
     const float *wh;
     int pool32;
+    int xcd_chunk;           // XCD x takes the x-th contiguous eighth of the row tiles (see the kernel)
     const float *pool_gamma; // pool32: the pooled layer's BatchNorm gamma -- its sign is the sign of the scale the pool will apply, so the
                              // epilogue keeps ONE candidate per piece and channel (the max where gamma >= 0, else the min) in zmax / amax
 };
@@ -197,8 +198,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             Eco[2][cidx] = A.e_mean[n0 + cidx];
             Eco[3][cidx] = 1.0f / sqrtf(A.e_var[n0 + cidx] + A.e_eps);
         }
-    long my_tiles = 0;
-    if ((long)blockIdx.x < ntiles) my_tiles = (ntiles - 1 - blockIdx.x) / gridDim.x + 1;
+    // which row tiles this workgroup takes: tile0, tile0 + tstride, ...  By default round-robin over the launch.  xcd_chunk (piece
+    // layout): workgroups are dealt to the 8 XCDs round-robin (workgroup b -> XCD b % 8), and every kernel that gathers rows of the
+    // per-point table P from a SCENE's 1 MB slice had all eight slices in flight on every XCD -- 8.4 MB against its 4 MB L2 (FETCH_SIZE
+    // 1.6 x the algorithmic reads on the assembled input gradient).  The rows are in scene order, so XCD x takes the x-th contiguous
+    // eighth of the tiles: its L2 then holds the one or two slices that eighth touches.
+    long tile0 = blockIdx.x, tstride = gridDim.x, my_tiles = 0;
+    if (A.xcd_chunk && (gridDim.x & 7) == 0) {
+        const long per = (ntiles + 7) / 8, lo = (long)(blockIdx.x & 7) * per, hi = lo + per < ntiles ? lo + per : ntiles;
+        tstride = gridDim.x >> 3;
+        tile0 = lo + (blockIdx.x >> 3);
+        if (tile0 < hi) my_tiles = (hi - 1 - tile0) / tstride + 1;
+    } else if ((long)blockIdx.x < ntiles) {
+        my_tiles = (ntiles - 1 - blockIdx.x) / gridDim.x + 1;
+    }
     long steps_to_load = my_tiles * nk; // steps whose operands still have to be fetched
 
     // A staging: thread t -> tile rows (t>>2) and (t>>2)+64, k-quad (t&3); W staging: float4 #t (+256)
@@ -206,22 +219,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const float *abase = (SRC == 0) ? A.x : (SRC == 3) ? A.u8 : (SRC == 4) ? A.ptab : A.zsrc; // the array the row pointers walk
     // SRC 3: the pointers stay on the row's eight floats for all slabs of a tile (re-read per slab from L2: no branch in the loop)
     const int arow_len = (SRC == 3) ? 8 : cin;
-    const float *pa0 = abase + ((size_t)blockIdx.x * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
+    const float *pa0 = abase + ((size_t)tile0 * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
     const float *pa1 = pa0 + (size_t)64 * arow_len;
     const ptrdiff_t da_off = (SRC == 1 || SRC == 5) ? (A.da - A.zsrc) : 0; // SRC 1 / 5: da has the layout of zsrc
     // SRC 5 (piece layout): this thread's rows a_row / a_row + 64 of a tile are row 0 of their piece iff a_row % kPiece == 0; the
     // weights of those two pieces travel with the slab (no load under a branch: every thread loads, most ignore)
     const bool sel31 = (a_row % kPiece) == 0;
-    const float *pw = (SRC == 5) ? A.wh + (size_t)blockIdx.x * (FG_BM / kPiece) + (a_row / kPiece) : nullptr;
-    const size_t a_tile_jump = (SRC == 3) ? (size_t)gridDim.x * FG_BM * 8 : (size_t)gridDim.x * FG_BM * cin - cin; // after the last slab of a tile
+    const float *pw = (SRC == 5) ? A.wh + (size_t)tile0 * (FG_BM / kPiece) + (a_row / kPiece) : nullptr;
+    const size_t a_tile_jump = (SRC == 3) ? (size_t)tstride * FG_BM * 8 : (size_t)tstride * FG_BM * cin - cin; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
-    const float *pu = (EPI == 4) ? A.u8 + ((size_t)blockIdx.x * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4
-                      : (EPI == 6) ? A.geo + ((size_t)blockIdx.x * FG_BM + (tid & 127)) * 4 : nullptr; // EPI 6: both halves of the workgroup fetch the row's record (no load under a branch)
+    const float *pu = (EPI == 4) ? A.u8 + ((size_t)tile0 * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4
+                      : (EPI == 6) ? A.geo + ((size_t)tile0 * FG_BM + (tid & 127)) * 4 : nullptr; // EPI 6: both halves of the workgroup fetch the row's record (no load under a branch)
     int ltp = 0; // parity of the tile being LOADED
     // SRC 4: the geo cursor runs ONE SLAB AHEAD of the operand cursor (qn = the geo of this thread's two rows of the slab the next
     // issue_loads call fetches); dq0 / dq1 in a register set are the dxyz of the rows of ITS slab
-    const float4 *pg = (SRC == 4) ? reinterpret_cast<const float4 *>(A.geo) + (size_t)blockIdx.x * FG_BM + a_row : nullptr;
+    const float4 *pg = (SRC == 4) ? reinterpret_cast<const float4 *>(A.geo) + (size_t)tile0 * FG_BM + a_row : nullptr;
     float4 qn0 = make_float4(0.f, 0.f, 0.f, 0.f), qn1 = qn0;
     int glkt = 0;
     long gsteps = steps_to_load;
@@ -230,7 +243,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         qn1 = pg[64];
         if (gsteps > 1 && ++glkt == nk) {
             glkt = 0;
-            pg += (size_t)gridDim.x * FG_BM;
+            pg += (size_t)tstride * FG_BM;
         }
         --gsteps;
     };
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     long g0 = 0, g1 = 0;    // groups of the two staged rows of the step being LOADED
     int ro0 = 0, ro1 = 0;   // their row offsets inside the group
     if (SRC == 2) {
-        const long r0 = (long)blockIdx.x * FG_BM + a_row;
+        const long r0 = (long)tile0 * FG_BM + a_row;
         g0 = r0 / pk;
         ro0 = (int)(r0 - g0 * pk);
         g1 = (r0 + 64) / pk;
@@ -340,12 +353,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             wvo += adv ? (wrap ? w3_slab - w3_slab * (unsigned)nk : w3_slab) : 0u;
             lkt = wrap ? 0 : (adv ? lkt + 1 : lkt);
             if (EPI == 4 || EPI == 6) {
-                pu += wrap ? (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4) : 0;
+                pu += wrap ? (size_t)tstride * FG_BM * (EPI == 4 ? 8 : 4) : 0;
                 ltp ^= wrap ? 1 : 0;
             }
-            if (SRC == 5) pw += wrap ? (size_t)gridDim.x * (FG_BM / kPiece) : 0;
+            if (SRC == 5) pw += wrap ? (size_t)tstride * (FG_BM / kPiece) : 0;
             if (SRC == 2) {
-                const long dg = wrap ? (long)gridDim.x * FG_BM / pk : 0;
+                const long dg = wrap ? (long)tstride * FG_BM / pk : 0;
                 g0 += dg;
                 g1 += dg;
             }
@@ -365,14 +378,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 pa0 += a_tile_jump;
                 pa1 += a_tile_jump;
                 if (EPI == 4 || EPI == 6) {
-                    pu += (size_t)gridDim.x * FG_BM * (EPI == 4 ? 8 : 4);
+                    pu += (size_t)tstride * FG_BM * (EPI == 4 ? 8 : 4);
                     ltp ^= 1;
                 }
-                if (SRC == 5) pw += (size_t)gridDim.x * (FG_BM / kPiece);
+                if (SRC == 5) pw += (size_t)tstride * (FG_BM / kPiece);
 #pragma unroll
                 for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
                 if (SRC == 2) { // next tile: rows advance by gridDim.x*128, a multiple of pool_k (checked by the launcher)
-                    const long dg = (long)gridDim.x * FG_BM / pk;
+                    const long dg = (long)tstride * FG_BM / pk;
                     g0 += dg;
                     g1 += dg;
                 }
@@ -661,7 +674,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (BF3 && BF3_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (BF3 && BF3_PRIO == 2) __builtin_amdgcn_s_setprio(1);
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-        const long m0 = ((long)blockIdx.x + t * gridDim.x) * FG_BM;
+        const long m0 = (tile0 + t * tstride) * FG_BM;
         // row pitch in bytes as an opaque scalar: the per-row scalar offsets of the buffer accesses below are then formed here,
         // per tile (a few s_mul), instead of being hoisted out of the tile loop as 64 loop-invariant SGPRs that spill
         unsigned pitch = (unsigned)cout * 4u;
@@ -1068,6 +1081,7 @@ template <int SRC, int EPI> constexpr int bf3_family()
         }                                                                                                                            \
         hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, false>), GRID_, dim3(256), 0, ST_, A_);           \
     } while (0)
+int g_fast_xcd_chunk = 1; // votenet_debug_fast_xcd_chunk: the piece-layout GEMMs that gather P take their row tiles in per-XCD chunks
 int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
 
 template <int SRC, int EPI>
@@ -1102,6 +1116,7 @@ static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
     if (a.cout % 128 == 0) {
         const int ny = a.cout / 128;
         gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
+        if (a.xcd_chunk && gx >= 64) gx &= ~7L; // a whole number of workgroups per XCD
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false; // a tile jump must be a whole number of groups
         FAST_LAUNCH(2, 2, 2, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
         return true;
@@ -1347,6 +1362,7 @@ extern "C" int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int
 }
 
 extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }
+extern "C" void votenet_debug_fast_xcd_chunk(int on) { votenet::g_fast_xcd_chunk = on ? 1 : 0; }
 extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = (on == 1) ? 63 : on; } // 0 off, 1 every family, else a mask
 
 // BF3 weight images.  table (device, 4 longs per segment): source address (cin x cout floats, row-major), image address
@@ -1445,6 +1461,7 @@ extern "C" int votenet_assembled_linear_half(long rows, int c0, int cout, const 
     a.z = z;
     a.stats = stats;
     a.wh = wh;
+    a.xcd_chunk = g_fast_xcd_chunk; // the rows are in scene order: an XCD's L2 then holds the slices of P its tiles gather
     hipStream_t st = as_stream(stream);
     const bool ok = stats ? fast_dispatch<4, 0>(a, st) : fast_dispatch<4, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_linear_half: shape not served (as votenet_assembled_linear)");
@@ -1525,6 +1542,7 @@ extern "C" int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout
     a.stats = sums;
     a.tail = to_tail(tail);
     a.wh = wh;
+    a.xcd_chunk = g_fast_xcd_chunk;
     if (!fast_dispatch<5, 6>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_dgrad_bn_reduce_half: shape not served (as votenet_mlp_dgrad_bn_reduce)");
     return check_launch("assembled_dgrad_bn_reduce_half");
