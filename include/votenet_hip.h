@@ -504,6 +504,7 @@ void votenet_debug_wgrad_bf3(int on);
 /* measurement hook: votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
 void votenet_debug_scatter_reverse(int on);
 void votenet_debug_sparse_workgroups(int n); /* tuning hook: workgroups of votenet_pool_wgrad_sparse (default 384) */
+void votenet_debug_sparse_teams(int teams, int wgs); /* tuning hook: 1 or 2 (default) teams per workgroup on the piece layout; workgroups of the 2-team form (default 256) */
 void votenet_debug_scatter_workgroups(int n); /* tuning hook: workgroups of votenet_pool_dgrad_scatter (0 = default) */
 void votenet_debug_scatter_form(int form); /* 1 (default): one wavefront per group, no barriers; 0: one workgroup per group */
 

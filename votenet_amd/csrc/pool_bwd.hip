@@ -494,8 +494,12 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
 // x = act(xz * in_scale + in_shift) staged per group in LDS; thread c owns output column c (CIN accumulators).
 // K = kPiece = 16: the piece layout (half.hip) -- a "group" is a piece q of 16 compact rows of xz, gout / argmax / zsel are per centre
 // hc[q] / 4 and a channel counts here when its arg-max slot lies in this piece; the column sums weigh row 0 by wh[q].
-template <int CIN, int K>
-__global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int cout, const float *__restrict__ xz,
+// TEAMS = 2 (piece layout): two 256-thread teams per workgroup, each walking its own groups with its own tiles; at the end the second
+// team's accumulators go through LDS and ONE team flushes.  What bounds this pass is a * groups / teams + b * workgroups with b = the flush
+// of a workgroup's cin x cout partial by atomics (tools/probe/sparse_time.py: a = 1.2 us, b = 0.11 us): two teams halve b per unit of
+// parallelism.
+template <int CIN, int K, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_kernel(long groups, int cout, const float *__restrict__ xz,
                                                                 const float *__restrict__ in_scale, const float *__restrict__ in_shift,
                                                                 int in_relu, const float *__restrict__ gout,
                                                                 const int *__restrict__ argmax, const float *__restrict__ zsel,
@@ -505,8 +509,11 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
 {
     constexpr bool HALF = K == kPiece;
     constexpr int LD = CIN + 4;
-    __shared__ __attribute__((aligned(16))) float xs[HALF ? 2 : 1][K][LD];
-    const int tid = threadIdx.x;
+    constexpr int NBUF = HALF ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) float sparse_smem[]; // [TEAMS][NBUF][K][LD]; at the end [CIN + 1][cout] of team 1
+    const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    const int tid = threadIdx.x & 255; // inside the team
+    float(*xs)[K][LD] = reinterpret_cast<float(*)[K][LD]>(sparse_smem + (size_t)team * NBUF * K * LD);
     float acc[CIN];
 #pragma unroll
     for (int i = 0; i < CIN; i++) acc[i] = 0.0f;
@@ -522,7 +529,7 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
     }
     const float fl = (in_scale && in_relu) ? 0.0f : -__builtin_inff();
     constexpr int NL = K * Q / 256; // float4 per thread per group tile
-    // A piece's tile is 8 KB and its work a fraction of a microsecond: with one tile in flight per workgroup the pass ran at one loaded-memory
+    // A piece's tile is 8 KB and its work a fraction of a microsecond: with one tile in flight per team the pass ran at one loaded-memory
     // latency per group.  D tiles (and their channels' gout / zsel / argmax) travel ahead in registers; the LDS tile is double-buffered,
     // one barrier per group.
     constexpr int D = HALF ? 4 : 1;
@@ -551,17 +558,20 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
             }
         }
     };
+    const long first = (long)blockIdx.x * TEAMS + team, stride = (long)gridDim.x * TEAMS; // this team's groups: first, first + stride, ...
 #pragma unroll
     for (int d = 0; d < D; d++) {
-        const long g = (long)blockIdx.x + (long)d * gridDim.x;
+        const long g = first + (long)d * stride;
         fetch(d, g < groups ? g : groups - 1);
     }
     int buf = 0;
-    for (long g0 = blockIdx.x; g0 < groups; g0 += (long)D * gridDim.x) {
+    // every team of the workgroup runs the same number of rounds (the barriers are the workgroup's): a team past its last group idles
+    for (long g0 = (long)blockIdx.x * TEAMS; g0 < groups; g0 += (long)D * stride) {
 #pragma unroll
         for (int d = 0; d < D; d++) {
-            const long g = g0 + (long)d * gridDim.x;
-            if (g >= groups) break; // (uniform over the workgroup)
+            if (g0 + (long)d * stride >= groups) break; // (uniform over the workgroup: no team has a group in this round)
+            const long g = g0 + team + (long)d * stride;
+            const bool live = g < groups;
             float(*xt)[LD] = xs[HALF ? buf : 0];
 #pragma unroll
             for (int h = 0; h < NL; h++) { // (tid + h*256) % Q == q: 256 % Q == 0
@@ -572,19 +582,18 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
                 v.w = fmaxf(v.w * sc.w + sh.w, fl);
                 *reinterpret_cast<float4 *>(&xt[(tid + h * 256) / Q][q * 4]) = v;
             }
-            float gg = n_g[d];
+            float gg = live ? n_g[d] : 0.0f;
             const float zz = n_z[d], w31 = n_w[d];
             const int ar = n_a[d];
-            const long gn = g + (long)D * gridDim.x;
-            fetch(d, gn < groups ? gn : g); // this stage's registers travel again while the tile is used
+            const long gn = g + (long)D * stride;
+            fetch(d, gn < groups ? gn : (live ? g : groups - 1)); // this stage's registers travel again while the tile is used
             __syncthreads();
             if (own) {
                 if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
                 const float v = cA * gg;
                 if (v != 0.0f) {
                     const float4 *row = reinterpret_cast<const float4 *>(&xt[ar][0]);
-                    // eight 16-byte LDS reads in flight, then their 32 multiply-adds (one read at a time was an LDS latency per 4 flops:
-                    // ~2 us per group with the one or two wavefronts per SIMD this kernel runs at)
+                    // eight 16-byte LDS reads in flight, then their 32 multiply-adds
 #pragma unroll
                     for (int i0 = 0; i0 < Q; i0 += 8) {
                         float4 a[8];
@@ -601,7 +610,7 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
                     }
                 }
             }
-            if (tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
+            if (live && tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
                 const int jc = tid - (256 - CIN);
 #pragma unroll 8
                 for (int r = (HALF ? 1 : 0); r < K; r++) csum += xt[r][jc];
@@ -610,6 +619,24 @@ __global__ __launch_bounds__(256) void pool_wgrad_sparse_kernel(long groups, int
             if (HALF) buf ^= 1; // the other tile was last read before this group's barrier: the next group may overwrite it
             else __syncthreads();
         }
+    }
+    if (TEAMS > 1) { // team 1 hands its sums to team 0 through LDS (the tiles are dead), team 0 flushes
+        __syncthreads();
+        float *comb = sparse_smem; // [CIN + 1][cout]
+        if (team == 1) {
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < CIN; i++) comb[(size_t)i * cout + tid] = acc[i];
+            }
+            if (tid >= 256 - CIN) comb[(size_t)CIN * cout + tid - (256 - CIN)] = csum;
+        }
+        __syncthreads();
+        if (team == 1) return;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < CIN; i++) acc[i] += comb[(size_t)i * cout + tid];
+        }
+        if (tid >= 256 - CIN) csum += comb[(size_t)CIN * cout + tid - (256 - CIN)];
     }
     if (part) { // this workgroup's slice [(CIN + 1) x cout]: dW rows, then the column sums; added in workgroup order afterwards
         float *__restrict__ mine = part + (size_t)blockIdx.x * (CIN + 1) * cout;
@@ -996,8 +1023,13 @@ extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *s
     return check_launch("mlp_gram");
 }
 
-static int g_sparse_wgs = 384;
+static int g_sparse_wgs = 384, g_sparse_wgs2 = 256, g_sparse_teams = 2;
 extern "C" void votenet_debug_sparse_workgroups(int n) { g_sparse_wgs = n > 0 ? n : 384; } // tuning hook
+extern "C" void votenet_debug_sparse_teams(int teams, int wgs) // tuning hook: 1 or 2 teams per workgroup (piece layout), workgroups of the 2-team form
+{
+    g_sparse_teams = teams == 1 ? 1 : 2;
+    if (wgs > 0) g_sparse_wgs2 = wgs;
+}
 static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
                                     float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream);
@@ -1045,20 +1077,36 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
                                     float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream)
 {
-    const int grid = pb_grid(groups, hc ? 32 : 8, g_sparse_wgs); // off the critical chain (weight-gradient stream): leaves CUs to the chain beside it
     hipStream_t st = as_stream(stream);
-    if (hc && cin == 64)
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, kPiece>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
-    else if (hc)
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, kPiece>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
-    else if (cin == 128)
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<128, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
-    else
-        hipLaunchKernelGGL((pool_wgrad_sparse_kernel<64, 64>), dim3(grid), dim3(256), 0, st, groups, cout, xz, in_scale, in_shift,
-                           in_relu, gout, argmax, zsel, coef, relu, dw, colsum, scratch, hc, wh, G);
+    int grid;
+    auto go = [&](auto kern, int ci, int kk, int teams, int cap) {
+        const size_t tiles = (size_t)teams * (kk == kPiece ? 2 : 1) * kk * (ci + 4) * 4;
+        const size_t comb = teams > 1 ? (size_t)(ci + 1) * cout * 4 : 0;
+        const size_t smem = tiles > comb ? tiles : comb;
+        static std::set<const void *> raised_s;
+        static std::mutex raised_s_mu;
+        bool fresh;
+        {
+            std::lock_guard<std::mutex> lock(raised_s_mu);
+            fresh = raised_s.insert(reinterpret_cast<const void *>(kern)).second;
+        }
+        if (fresh) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        grid = pb_grid(groups, (kk == kPiece ? 32 : 8) * teams, cap);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * teams), smem, st, groups, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef,
+                           relu, dw, colsum, scratch, hc, wh, G);
+    };
+    // off the critical chain (weight-gradient stream): the caps leave CUs to the chain beside it
+    if (hc && g_sparse_teams == 2 && !scratch) {
+        if (cin == 64) go(pool_wgrad_sparse_kernel<64, kPiece, 2>, 64, kPiece, 2, g_sparse_wgs2);
+        else go(pool_wgrad_sparse_kernel<128, kPiece, 2>, 128, kPiece, 2, g_sparse_wgs2);
+    } else if (hc) {
+        if (cin == 64) go(pool_wgrad_sparse_kernel<64, kPiece, 1>, 64, kPiece, 1, g_sparse_wgs);
+        else go(pool_wgrad_sparse_kernel<128, kPiece, 1>, 128, kPiece, 1, g_sparse_wgs);
+    } else if (cin == 128) {
+        go(pool_wgrad_sparse_kernel<128, 64, 1>, 128, 64, 1, g_sparse_wgs);
+    } else {
+        go(pool_wgrad_sparse_kernel<64, 64, 1>, 64, 64, 1, g_sparse_wgs);
+    }
     if (scratch) { // ordered reduction of the workgroups' slices: dW rows, then the column sums (row cin of a slice)
         const long ps = (long)(cin + 1) * cout;
         wgrad_reduce(grid, ps, 0, (long)cin * cout, scratch, dw, st);
