@@ -688,11 +688,17 @@ int votenet_assemble_rows_half(int b, int n, int m, const int *nh, const float *
  * pooled layer's BatchNorm weight, whose sign is the sign of the scale the pool applies -- is >= 0, the raw min where it is negative,
  * first occurrence; votenet_bn_pool_finalize_half joins a centre's pieces (ties -> the earlier piece, the first occurrence as in the
  * 64-row epilogue; argmax = slot 0..63). */
+/* nh_dev (every entry below that has it; may be NULL): the piece count when only the device knows it -- a level whose geometry is made
+ * inside the step (the proposal module groups the votes) cannot wait for the count on the host without draining the queue.  The caller
+ * then passes its upper bound as rows / nh (buffers sized for it) and the kernels stop at 16 * nh_dev[0] rows. */
 int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
                                   const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias,
-                                  float *z, double *stats, const float *wh, void *stream);
+                                  float *z, double *stats, const float *wh, const int *nh_dev, void *stream);
+int votenet_mlp_linear_half(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin, int cout,
+                            const float *w, const float *bias, float *z, const int *nh_dev, void *stream);
 int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias, float *z,
-                                 double *stats, const float *wh, const float *gamma, float *zbest, int *abest, void *stream);
+                                 double *stats, const float *wh, const float *gamma, float *zbest, int *abest, const int *nh_dev,
+                                 void *stream);
 int votenet_bn_pool_finalize_half(long G, int c, const float *zbest, const int *abest, const int *pos, const float *scale, const float *shift,
                                   const votenet_bn_raw *bn, int relu, float *out, int *argmax, float *zsel, void *stream);
 /* Backward on the compact rows (gout / argmax / zsel stay per centre): the scatter of the pooled layer's input gradient (also scales
@@ -702,19 +708,20 @@ int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout, const flo
                                     const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
                                     const float *below_z, const float *below_scale, const float *below_shift, const float *below_mean,
                                     const float *below_var, float eps, int below_relu, double *below_sums,
-                                    const votenet_coef_tail *below_tail, void *stream);
-int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram, void *stream);
+                                    const votenet_coef_tail *below_tail, const int *nh_dev, void *stream);
+int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram,
+                          const int *nh_dev, void *stream);
 int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
                                    int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
-                                   float *dw, float *colsum, const int *hc, const float *wh, void *stream);
+                                   float *dw, float *colsum, const int *hc, const float *wh, const int *nh_dev, void *stream);
 int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
                                     const float *in_shift, int in_relu, const float *da, const float *z, const float *coef, int relu,
-                                    const float *wh, float *dw, void *stream);
+                                    const float *wh, float *dw, const int *nh_dev, void *stream);
 int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
                                            const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
                                            const float *scale_prev, const float *shift_prev, const float *mean_prev,
                                            const float *var_prev, float eps, int relu_prev, double *sums,
-                                           const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
+                                           const votenet_coef_tail *tail /* may be NULL */, const float *wh, const int *nh_dev, void *stream);
 /* The scatter to the points without one atomic per row (an fp32 atomic costs an L2 channel ~14 cycles per line): with the geometry,
  * votenet_half_sort_rows buckets the compact rows by the point they gather (order: 64G ints, 16*nh[0] written; work: npts ints);
  * votenet_group_linear_backward_sorted then sums a point's consecutive rows in a register and stores S point by point
@@ -723,7 +730,13 @@ int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout, const flo
 int votenet_half_sort_rows(int npts, int G, const int *nh, const float *geo, int *work, int counted, int *order, void *stream);
 int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
                                          const float *wx, const float *da, const float *coef, int relu, float *s_points, float *dw_xyz,
-                                         void *stream);
+                                         const int *nh_dev, void *stream);
+/* The xyz gradient of such a first layer (the proposal module, model.py:89: its input coordinates are the votes).  With
+ * dz0 W[0:3]^T linear in dz0, the per-point part is S W[0:3]^T (votenet_rows_dot3 on s_points) and the per-centre part -(sum of the
+ * centre's dz0 rows) W[0:3]^T: votenet_half_centre_sums leaves T (G x cout) = MINUS the sum of the total gradients dz0 of every centre's
+ * compact rows (rebuilt from da, geo, P as in votenet_group_linear_backward_sorted); votenet_rows_dot3(T, W[0:3]) is d new_xyz. */
+int votenet_half_centre_sums(long G, int cout, const int *pos, const float *geo, const float *wh, const float *P, const float *wx,
+                             const float *da, const float *coef, int relu, float *T, void *stream);
 /* The narrow first layer (sa1) on the same layout: u8 (up to 64G x 8 floats; moments over the true rows), the second layer's GEMMs. */
 int votenet_narrow_rows_half(int b, int n, int m, int c, const int *nh, const float *xyz, const float *new_xyz, const float *feat,
                              const int *idx, const int *pts_cnt, const int *hc, float *u8, double *moments, void *stream);

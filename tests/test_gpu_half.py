@@ -198,9 +198,11 @@ def test_model_with_and_without_the_half_group_layout(hiplib, dev):
     tape, o1, l1, g1 = once()
     sas = [t for t in tape if t.get("op") == "sa"]
     halves = [t["recs"][0].get("half") for t in sas]
-    assert [h is not None for h in halves] == [True, True, True, True, False]
+    assert [h is not None for h in halves] == [True, True, True, True, True]
     for t, h in zip(sas[:4], halves[:4]):
         assert t["recs"][1]["z"].shape[0] == h.rows < t["recs"][0]["rows"]
+    # the proposal module groups the votes, which exist only inside the step: its count stays on the device
+    assert halves[4].nh_limit is not None and halves[4].true_count() * 16 < sas[4]["recs"][0]["rows"] == halves[4].rows
     r1 = net.predict(x, 0.25, batch_statistics=True)  # inference through the same layout
     P.HALF_GROUPS = False
     try:
@@ -267,3 +269,47 @@ def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev,
     uscale = (u8.double().abs().t() @ da0.abs())
     assert float(((ug_h - ug).abs() / (uscale + 1e-30)).max()) < 1e-5
     img.close()
+
+
+@pytest.mark.parametrize("radius", [0.1, 0.25, 0.6])
+def test_level_with_the_count_on_the_device_and_the_xyz_gradient(hiplib, dev, radius):
+    """An SA level whose geometry is made inside the step (the proposal module, model.py:89): the piece count never reaches the host,
+    every kernel stops at the count it reads on the device; and the gradient with respect to the coordinates on the piece layout.
+    Against the same level with the count on the host (features / parameter gradients) and on the full layout (all of it)."""
+    from votenet_amd import pointnet2 as P
+    b, n, m, cin = 2, 1024, 128, 64
+    store = P.ParamStore(dev)
+    mod = P.SAModule(store, "t", m, radius, 64, cin, [128, 128, 128], mlp2=[128, 64])
+    store.materialize(5)
+    g = torch.Generator().manual_seed(9)
+    xyz = torch.rand(b, n, 3, generator=g).to(dev)
+    pts = torch.randn(b, n, cin, generator=g).to(dev)
+    gout = None
+
+    def run(ahead, xyz_grad):
+        nonlocal gout
+        store.grad.zero_()
+        tape = []
+        geom = mod.geometry(xyz, points=pts, ahead=ahead)
+        _, out, _ = mod.forward(xyz, pts, tape=tape, geom=geom)
+        if gout is None:
+            gout = torch.randn(out.shape, generator=g).to(dev)
+        d_feat, d_xyz = mod.backward(tape[0], gout, need_feat_grad=True, need_xyz_grad=xyz_grad)
+        P.wgrad_join()
+        torch.cuda.synchronize()
+        return tape[0], out.clone(), d_feat.clone(), (d_xyz.clone() if d_xyz is not None else None), store.grad.clone()
+    assert P.HALF_GROUPS
+    rec_h, out_h, df_h, _, g_h = run(True, False)          # count on the host
+    rec_d, out_d, df_d, dx_d, g_d = run(False, True)       # count on the device, xyz gradient
+    half_h, half_d = rec_h["recs"][0]["half"], rec_d["recs"][0]["half"]
+    assert half_h.nh_limit is None and half_d.nh_limit is not None and half_d.true_count() == half_h.nh <= half_d.nh == 4 * half_d.G
+    assert relerr(out_d, out_h) < 1e-6 and relerr(df_d, df_h) < 1e-5
+    assert float((g_d.double() - g_h.double()).norm() / g_h.double().norm()) < 1e-5
+    P.HALF_GROUPS = False
+    try:
+        rec_f, out_f, df_f, dx_f, g_f = run(False, True)
+        assert rec_f["recs"][0].get("half") is None
+    finally:
+        P.HALF_GROUPS = True
+    assert relerr(out_d, out_f) < 5e-5 and relerr(df_d, df_f) < 1e-3 and relerr(dx_d, dx_f) < 1e-3
+    assert float((g_d.double() - g_f.double()).norm() / g_f.double().norm()) < 1e-2

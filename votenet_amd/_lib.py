@@ -169,19 +169,21 @@ _I, _L, _F = ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGS.update({
     "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 10 + [ctypes.c_void_p],
-    "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
-    "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 8 + [ctypes.c_void_p],
+    "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 6 + [ctypes.c_void_p],
+    "votenet_mlp_linear_half": [_c_f] * 3 + [_I, _L, _I, _I] + [_c_f] * 4 + [ctypes.c_void_p],
+    "votenet_half_centre_sums": [_L, _I] + [_c_f] * 7 + [_I, _c_f, ctypes.c_void_p],
+    "votenet_mlp_linear_pool_half": [ctypes.POINTER(MlpInput), _L, _I, _I] + [_c_f] * 9 + [ctypes.c_void_p],
     "votenet_bn_pool_finalize_half": [_L, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 3 + [ctypes.c_void_p],
-    "votenet_pool_dgrad_scatter_half": [_L, _I, _I, _I] + [_c_f] * 4 + [_I] + [_c_f] * 9 + [_F, _I, _c_f, ctypes.POINTER(CoefTail),
+    "votenet_pool_dgrad_scatter_half": [_L, _I, _I, _I] + [_c_f] * 4 + [_I] + [_c_f] * 9 + [_F, _I, _c_f, ctypes.POINTER(CoefTail), _c_f,
                                                                                        ctypes.c_void_p],
-    "votenet_mlp_gram_half": [_L, _I, _c_f, _c_f, _I, _c_f, _c_f, ctypes.c_void_p],
-    "votenet_pool_wgrad_sparse_half": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [_I] + [_c_f] * 4 + [ctypes.c_void_p],
-    "votenet_assembled_wgrad_bn_half": [_L, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, ctypes.c_void_p],
+    "votenet_mlp_gram_half": [_L, _I, _c_f, _c_f, _I, _c_f, _c_f, _c_f, ctypes.c_void_p],
+    "votenet_pool_wgrad_sparse_half": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [_I] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_assembled_wgrad_bn_half": [_L, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, _c_f, ctypes.c_void_p],
     "votenet_assembled_dgrad_bn_reduce_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 9 + [_F, _I, ctypes.c_void_p,
-                                                                                             ctypes.POINTER(CoefTail), _c_f, ctypes.c_void_p],
+                                                                                             ctypes.POINTER(CoefTail), _c_f, _c_f, ctypes.c_void_p],
     "votenet_half_piece_rows": [],
     "votenet_half_sort_rows": [_I, _I] + [_c_f] * 3 + [_I, _c_f, ctypes.c_void_p],
-    "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 2 + [ctypes.c_void_p],
+    "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_narrow_rows_half": [_I] * 4 + [_c_f] * 9 + [ctypes.c_void_p],
     "votenet_narrow_linear_half": [_L, _I, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_narrow_wgrad_bn_half": [_L, _I, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, ctypes.c_void_p],

@@ -121,7 +121,7 @@ __device__ __forceinline__ void half_sort_runs(unsigned prow, bool live, int lan
 // votenet_assemble_rows on the piece layout: thread = compact row r = q * PS + s <-> (centre hc[q] / NP, slot PS (hc[q] % NP) + s).
 // The per-point counters and the moments run over the TRUE rows exactly as in assemble_rows_kernel: slot k < pts_cnt adds itself, slot 0
 // also the 64 - pts_cnt copies.
-__global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__restrict__ nh_dev, int n, int groups_per_scene, const float *__restrict__ xyz,
+__global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__restrict__ nh_dev, long max_rows, int n, int groups_per_scene, const float *__restrict__ xyz,
                                                                  const float *__restrict__ new_xyz, const int *__restrict__ idx,
                                                                  const int *__restrict__ pts_cnt, const int *__restrict__ hc,
                                                                  float4 *__restrict__ geo, long long *__restrict__ cntv,
@@ -132,10 +132,13 @@ __global__ __launch_bounds__(256) void assemble_rows_half_kernel(const int *__re
 #pragma unroll
     for (int i = 0; i < 9; i++) acc[i] = 0.0;
     const long rows = (long)nh_dev[0] * PS; // the number of pieces is known on the device only when this is enqueued
-    for (long r0 = (long)blockIdx.x * 256; r0 < rows; r0 += (long)gridDim.x * 256) {
+    for (long r0 = (long)blockIdx.x * 256; r0 < max_rows; r0 += (long)gridDim.x * 256) {
         const long r = r0 + threadIdx.x;
         const bool live = r < rows;
         unsigned my_prow = 0;
+        // past the count the buffer holds records of point 0 (a reader that does not know the count -- a caller with the count on the
+        // device only sizes everything for the upper bound -- gathers a valid row)
+        if (!live && r < max_rows) geo[r] = make_float4(0.f, 0.f, 0.f, __uint_as_float(0u));
         if (live) {
         const int q = (int)(r / PS), s = (int)(r % PS);
         const int code = hc[q];
@@ -363,8 +366,12 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
                                                                       const float *__restrict__ wh, const float *__restrict__ ptab,
                                                                       const float *__restrict__ wx, const float *__restrict__ da,
                                                                       const float *__restrict__ coef, int relu, float *__restrict__ spt,
-                                                                      float *__restrict__ dw_xyz)
+                                                                      float *__restrict__ dw_xyz, const int *__restrict__ nh_dev)
 {
+    if (nh_dev != nullptr) { // the count is the device's (rows: the caller's upper bound)
+        const long lim = (long)nh_dev[0] * PS;
+        rows = lim < rows ? lim : rows;
+    }
     constexpr int CPB = 256 / COUT; // chunks per workgroup pass
     constexpr int CH = 64;          // entries per chunk
     __shared__ int s_row[CPB][CH];
@@ -448,6 +455,43 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
     }
 }
 
+// T[c, ch] = MINUS the sum of the total gradients dz0 = A g' + w (B + C z0) over the compact rows of centre c (its first piece at c, the others
+// through pos): what the centre's coordinates receive through dxyz = xyz[idx] - new_xyz.  Thread = (centre, channel).
+template <int COUT>
+__global__ __launch_bounds__(256) void half_centre_sums_kernel(long G, const int *__restrict__ pos, const float4 *__restrict__ geo,
+                                                               const float *__restrict__ wh, const float *__restrict__ ptab,
+                                                               const float *__restrict__ wx, const float *__restrict__ da,
+                                                               const float *__restrict__ coef, int relu, float *__restrict__ T)
+{
+    constexpr int CPB = 256 / COUT;
+    const int tid = threadIdx.x, ch = tid % COUT, cl = tid / COUT;
+    const float kA = coef[ch], kB = coef[COUT + ch], kC = coef[2 * COUT + ch], kS = coef[3 * COUT + ch], kH = coef[4 * COUT + ch];
+    const float wx0 = wx[ch], wx1 = wx[COUT + ch], wx2 = wx[2 * COUT + ch];
+    for (long c = (long)blockIdx.x * CPB + cl; c < G; c += (long)gridDim.x * CPB) {
+        float acc = 0.0f;
+#pragma unroll 1
+        for (int j = 0; j < NP; j++) {
+            long q = c;
+            if (j > 0) {
+                const int p = pos[c * (NP - 1) + j - 1];
+                if (p < 0) continue;
+                q = G + p;
+            }
+            const float w0 = wh[q];
+#pragma unroll 4
+            for (int s = 0; s < PS; s++) {
+                const long r = q * PS + s;
+                const float4 g4 = geo[r];
+                const float z = assembled_z(ptab[(size_t)__float_as_uint(g4.w) * COUT + ch], g4, wx0, wx1, wx2);
+                float gq = da[(size_t)r * COUT + ch];
+                if (relu && !(z * kS + kH > 0.0f)) gq = 0.0f;
+                acc += kA * gq + (s == 0 ? w0 : 1.0f) * (kB + kC * z);
+            }
+        }
+        T[(size_t)c * COUT + ch] = -acc; // dxyz = xyz[idx] - new_xyz: the centre receives minus the sum
+    }
+}
+
 } // namespace votenet
 
 using namespace votenet;
@@ -472,7 +516,7 @@ extern "C" int votenet_assemble_rows_half(int b, int n, int m, const int *nh, co
     VN_REQUIRE((uintptr_t)geo % 16 == 0 && (!cntv || (uintptr_t)cntv % 16 == 0), "assemble_rows_half: geo / cntv must be 16-byte aligned");
     long gx = (max_rows / 2 + 256 * 8 - 1) / (256 * 8); // sized for a typical fill; grid-stride covers the rest
     if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, n, m, xyz, new_xyz, idx, pts_cnt, hc,
+    hipLaunchKernelGGL(assemble_rows_half_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), nh, max_rows, n, m, xyz, new_xyz, idx, pts_cnt, hc,
                        reinterpret_cast<float4 *>(geo), cntv, moments, count);
     return check_launch("assemble_rows_half");
 }
@@ -534,7 +578,7 @@ extern "C" int votenet_half_sort_rows(int npts, int G, const int *nh, const floa
 // nobody gathers keep their zeros).
 extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, const float *geo, const float *wh, const float *P,
                                                     const float *wx, const float *da, const float *coef, int relu, float *s_points,
-                                                    float *dw_xyz, void *stream)
+                                                    float *dw_xyz, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(nh > 0 && (cout == 64 || cout == 128 || cout == 256), "group_linear_backward_sorted expects nh > 0, cout in {64, 128, 256}");
     VN_REQUIRE(order && geo && wh && P && wx && da && coef && s_points && dw_xyz, "group_linear_backward_sorted: null buffer");
@@ -547,12 +591,31 @@ extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int
     const float4 *g4 = reinterpret_cast<const float4 *>(geo);
     if (cout == 128)
         hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<128>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
-                           s_points, dw_xyz);
+                           s_points, dw_xyz, nh_dev);
     else if (cout == 64)
         hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<64>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
-                           s_points, dw_xyz);
+                           s_points, dw_xyz, nh_dev);
     else
         hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
-                           s_points, dw_xyz);
+                           s_points, dw_xyz, nh_dev);
     return check_launch("group_linear_backward_sorted");
+}
+
+extern "C" int votenet_half_centre_sums(long G, int cout, const int *pos, const float *geo, const float *wh, const float *P, const float *wx,
+                                        const float *da, const float *coef, int relu, float *T, void *stream)
+{
+    VN_REQUIRE(G > 0 && (cout == 64 || cout == 128 || cout == 256), "half_centre_sums expects G > 0, cout in {64, 128, 256}");
+    VN_REQUIRE(pos && geo && wh && P && wx && da && coef && T && (uintptr_t)geo % 16 == 0, "half_centre_sums: null / unaligned buffer");
+    hipStream_t st = as_stream(stream);
+    const int cpb = 256 / cout;
+    long gx = (G + cpb - 1) / cpb;
+    if (gx > 4096) gx = 4096;
+    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
+    if (cout == 128)
+        hipLaunchKernelGGL(half_centre_sums_kernel<128>, dim3((unsigned)gx), dim3(256), 0, st, G, pos, g4, wh, P, wx, da, coef, relu, T);
+    else if (cout == 64)
+        hipLaunchKernelGGL(half_centre_sums_kernel<64>, dim3((unsigned)gx), dim3(256), 0, st, G, pos, g4, wh, P, wx, da, coef, relu, T);
+    else
+        hipLaunchKernelGGL(half_centre_sums_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, G, pos, g4, wh, P, wx, da, coef, relu, T);
+    return check_launch("half_centre_sums");
 }

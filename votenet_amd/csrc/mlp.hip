@@ -597,7 +597,7 @@ namespace votenet {
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
                             float *zmin, int *amax, int *amin, hipStream_t st, const float *wh = nullptr,
-                            const float *pool_gamma = nullptr); // mlp_fast.hip
+                            const float *pool_gamma = nullptr, const int *nh_dev = nullptr); // mlp_fast.hip
 }
 
 extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w,
@@ -625,7 +625,7 @@ extern "C" int votenet_mlp_linear_pool(const votenet_mlp_input *in, long rows, i
 // statistics count row 0 of a piece wh times.
 extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long rows, int cin, int cout, const float *w, const float *bias,
                                             float *z, double *stats, const float *wh, const float *gamma, float *zbest, int *abest,
-                                            void *stream)
+                                            const int *nh_dev, void *stream)
 {
     float *zmax = zbest, *zmin = zbest;
     int *amax = abest, *amin = abest;
@@ -638,7 +638,7 @@ extern "C" int votenet_mlp_linear_pool_half(const votenet_mlp_input *in, long ro
     VN_REQUIRE(in->in_bn == nullptr || (raw.stats && raw.gamma && raw.beta && raw.rows > 0 && in->in_scale == nullptr),
                "mlp_linear_pool_half: in_bn needs stats, gamma, beta, rows > 0 and no in_scale");
     if (!votenet::mlp_linear_pool_launch(in->x, in->in_scale, in->in_shift, raw, in->in_relu, rows, cin, cout, w, bias, z, stats, zmax, zmin,
-                                         amax, amin, as_stream(stream), wh, gamma))
+                                         amax, amin, as_stream(stream), wh, gamma, nh_dev))
         return votenet::set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_linear_pool_half: shape not served (as votenet_mlp_linear_pool)");
     return check_launch("mlp_linear_pool_half");
 }

@@ -1020,7 +1020,7 @@ extern "C" int votenet_assembled_wgrad_bn(long rows, int c0, int cout, const flo
 // times on row 16 q.
 extern "C" int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
                                                const float *in_scale, const float *in_shift, int in_relu, const float *da, const float *z,
-                                               const float *coef, int relu, const float *wh, float *dw, void *stream)
+                                               const float *coef, int relu, const float *wh, float *dw, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(rows > 0 && rows % 32 == 0 && rows < (1L << 31) && c0 > 0 && cout > 0, "assembled_wgrad_bn_half: bad shape");
     VN_REQUIRE(geo && P && wx && in_scale && in_shift && da && z && coef && wh && dw, "assembled_wgrad_bn_half: null buffer");
@@ -1031,7 +1031,7 @@ extern "C" int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, cons
     d.geo = geo;
     d.ptab = P;
     d.wx = wx;
-    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0, wh};
+    BnSrc bs = {da, nullptr, nullptr, 0, -1, z, coef, relu, nullptr, 0, wh, nh_dev};
     if (!wgrad_fast_launch(3, d, rows, c0, cout, nullptr, bs, 4, dw, as_stream(stream), nullptr))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_wgrad_bn_half: shape not served (as votenet_assembled_wgrad_bn)");
     return check_launch("assembled_wgrad_bn_half");

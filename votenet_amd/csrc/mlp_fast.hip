@@ -117,6 +117,8 @@ struct FastArgs {
     // affine part B + C z of the rebuilt dz is scaled by it (total gradients); pool32 (EPI 2): raw max / min per piece instead of per 64 rows
     const float *wh;
     int pool32;
+    const int *nh_dev;       // piece layout with the count known on the device only (a level whose geometry is made inside the step):
+                             // `rows` is the caller's upper bound, the kernel stops at 16 * nh_dev[0] rows; NULL: rows is exact
     int xcd_chunk;           // XCD x takes the x-th contiguous eighth of the row tiles (see the kernel)
     const float *pool_gamma; // pool32: the pooled layer's BatchNorm gamma -- its sign is the sign of the scale the pool will apply, so the
                              // epilogue keeps ONE candidate per piece and channel (the max where gamma >= 0, else the min) in zmax / amax
@@ -158,7 +160,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const int wm = wv / WN, wn = wv % WN;
     const int n0 = blockIdx.y * BN;
     const int nk = cin / FG_BK;
-    const long ntiles = rows / FG_BM;
+    long ntiles = rows / FG_BM;
+    if (A.nh_dev != nullptr) { // (a multiple of 8 pieces = whole tiles: half.hip)
+        const long lim = (long)A.nh_dev[0] * kPiece / FG_BM;
+        ntiles = lim < ntiles ? lim : ntiles;
+    }
     const bool affine = (SRC == 0 || SRC == 3 || SRC == 4) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
     if (SRC == 4)
         for (int t = tid; t < 3 * cin; t += 256) Wxs[t / cin][t % cin] = A.wx[t];
@@ -1152,12 +1158,37 @@ bool mlp_linear_fast_launch(const float *x, const float *in_scale, const float *
     return stats ? fast_dispatch<0, 0>(a, st) : fast_dispatch<0, 1>(a, st); // no statistics wanted: skip their arithmetic
 }
 
+// z = act(x) w + bias over the first 16 * nh_dev[0] of `rows` rows (the piece layout with the count on the device: the dense part of a
+// pooled layer's Gram-form input gradient); no statistics
+extern "C" int votenet_mlp_linear_half(const float *x, const float *in_scale, const float *in_shift, int in_relu, long rows, int cin,
+                                       int cout, const float *w, const float *bias, float *z, const int *nh_dev, void *stream)
+{
+    VN_REQUIRE(rows > 0 && cin > 0 && cout > 0 && x && w && z && nh_dev, "mlp_linear_half: bad arguments");
+    VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "mlp_linear_half: in_scale and in_shift go together");
+    FastArgs a = {};
+    a.x = x;
+    a.in_scale = in_scale;
+    a.in_shift = in_shift;
+    a.in_relu = in_relu;
+    a.rows = rows;
+    a.cin = cin;
+    a.cout = cout;
+    a.w = w;
+    a.bias = bias;
+    a.z = z;
+    a.nh_dev = nh_dev;
+    if (!fast_dispatch<0, 1>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_linear_half: shape not served (rows %% 128 == 0, cin %% 32 == 0, cout %% 64 == 0, 16-byte aligned)");
+    return check_launch("mlp_linear_half");
+}
+
 // forward layer + raw max / min pooling over groups of 64 rows (EPI 2).  Returns false when the shape is not served.
 bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *in_shift, const BnRaw &in_raw, int in_relu,
                             long rows, int cin, int cout, const float *w, const float *bias, float *z, double *stats, float *zmax,
-                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh, const float *pool_gamma)
+                            float *zmin, int *amax, int *amin, hipStream_t st, const float *wh, const float *pool_gamma, const int *nh_dev)
 {
     FastArgs a = {};
+    a.nh_dev = nh_dev;
     a.wh = wh;                       // piece layout (half.hip): weighted statistics ...
     a.pool32 = wh != nullptr ? 1 : 0; // ... and the pool's candidate (max or min by the sign of gamma) per 16-row piece
     a.pool_gamma = pool_gamma;
@@ -1440,7 +1471,8 @@ extern "C" int votenet_assembled_linear(long rows, int c0, int cout, const float
 // the BatchNorm statistics (a ball's slot 0 also stands for its dropped all-copy pieces).
 extern "C" int votenet_assembled_linear_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx,
                                              const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
-                                             const float *w, const float *bias, float *z, double *stats, const float *wh, void *stream)
+                                             const float *w, const float *bias, float *z, double *stats, const float *wh, const int *nh_dev,
+                                             void *stream)
 {
     VN_REQUIRE(rows > 0 && c0 > 0 && cout > 0, "assembled_linear_half expects rows > 0, c0 > 0, cout > 0");
     VN_REQUIRE(geo && P && wx && w && z && wh, "assembled_linear_half: null buffer");
@@ -1461,6 +1493,7 @@ extern "C" int votenet_assembled_linear_half(long rows, int c0, int cout, const 
     a.z = z;
     a.stats = stats;
     a.wh = wh;
+    a.nh_dev = nh_dev;
     a.xcd_chunk = g_fast_xcd_chunk; // the rows are in scene order: an XCD's L2 then holds the slices of P its tiles gather
     hipStream_t st = as_stream(stream);
     const bool ok = stats ? fast_dispatch<4, 0>(a, st) : fast_dispatch<4, 1>(a, st);
@@ -1513,7 +1546,7 @@ extern "C" int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout
                                                       const float *wT, float *da_prev, const float *geo, const float *P, const float *wx,
                                                       const float *scale_prev, const float *shift_prev, const float *mean_prev,
                                                       const float *var_prev, float eps, int relu_prev, double *sums,
-                                                      const votenet_coef_tail *tail, const float *wh, void *stream)
+                                                      const votenet_coef_tail *tail, const float *wh, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "assembled_dgrad_bn_reduce_half expects rows > 0, c > 0, cout > 0");
     VN_REQUIRE(da && zsrc && coef && wT && da_prev && geo && P && wx && wh, "assembled_dgrad_bn_reduce_half: null buffer");
@@ -1542,6 +1575,7 @@ extern "C" int votenet_assembled_dgrad_bn_reduce_half(long rows, int c, int cout
     a.stats = sums;
     a.tail = to_tail(tail);
     a.wh = wh;
+    a.nh_dev = nh_dev;
     a.xcd_chunk = g_fast_xcd_chunk;
     if (!fast_dispatch<5, 6>(a, as_stream(stream)))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "assembled_dgrad_bn_reduce_half: shape not served (as votenet_mlp_dgrad_bn_reduce)");

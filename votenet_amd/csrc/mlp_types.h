@@ -53,6 +53,7 @@ struct BnSrc {
     float *part;
     long pstride;
     const float *wh; // BSRC 4 (piece layout, half.hip): da holds totals; the affine part B + C z of row 16 q counts wh[q] times
+    const int *nh_dev; // piece layout with the count on the device: `rows` is an upper bound, the kernel stops at 16 * nh_dev[0] rows
 };
 
 // ---- the PIECE layout of a set-abstraction level (half.hip): a ball's 64 slots in pieces of kPiece rows, the all-copy pieces dropped ----

@@ -49,6 +49,10 @@ template <int MODE, int TI, int TJ, int BSRC, bool BF3 = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) void mlp_wgrad_fast_kernel(
     MlpIn in, long rows, int cin, int cout, const float *__restrict__ dz, BnSrc bs, float *__restrict__ dw, long rows_per_block)
 {
+    if (bs.nh_dev != nullptr) {
+        const long lim = (long)bs.nh_dev[0] * kPiece;
+        rows = lim < rows ? lim : rows;
+    }
     constexpr int BI = 64 * TI, BJ = 64 * TJ;
     constexpr int QA = BI / 4, QB = BJ / 4;                       // float4 per slab row
     constexpr int NA = WF_BR * QA / 256, NB = WF_BR * QB / 256;   // float4 per thread per slab (1 or 2)

@@ -133,6 +133,7 @@ struct PoolBelow {
     const int *hc;
     const float *wh;
     int G;
+    const int *nh_dev; // the number of pieces when only the device knows it (`groups` is then an upper bound), or NULL
 };
 
 template <int CIN, int COUT, int K, bool RED, int NWV = 8 /* wavefronts: 16 when W^T leaves room for one workgroup per CU only */>
@@ -353,6 +354,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
         }
     }
     __syncthreads(); // W^T is in place; from here on the wavefronts run on their own
+    if (HALF && pb.nh_dev != nullptr) groups = pb.nh_dev[0] < groups ? pb.nh_dev[0] : groups;
     const long stride = (long)gridDim.x * NWV;
     float nz[NJ], ng[NJ], nw = 1.0f;
     int na[NJ];
@@ -505,11 +507,13 @@ __global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_kernel(long gro
                                                                 const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                 const float *__restrict__ coef, int relu, float *__restrict__ dw,
                                                                 float *__restrict__ colsum, float *__restrict__ part,
-                                                                const int *__restrict__ hc, const float *__restrict__ wh, int G)
+                                                                const int *__restrict__ hc, const float *__restrict__ wh, int G,
+                                                                const int *__restrict__ nh_dev)
 {
     constexpr bool HALF = K == kPiece;
     constexpr int LD = CIN + 4;
     constexpr int NBUF = HALF ? 2 : 1;
+    if (HALF && nh_dev != nullptr) groups = nh_dev[0] < groups ? nh_dev[0] : groups; // (uniform: every thread reads the same count)
     extern __shared__ __attribute__((aligned(16))) float sparse_smem[]; // [TEAMS][NBUF][K][LD]; at the end [CIN + 1][cout] of team 1
     const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
     const int tid = threadIdx.x & 255; // inside the team
@@ -743,7 +747,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
                                      const float *coef, int relu, const float *wT, float *da, const float *below_z,
                                      const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
                                      float eps, int below_relu, double *below_sums, const votenet_coef_tail *below_tail, const int *hc,
-                                     const float *wh, int G, void *stream);
+                                     const float *wh, int G, void *stream, const int *nh_dev = nullptr);
 extern "C" int votenet_pool_dgrad_scatter(long groups, int k, int cin, int cout, const float *gout, const int *argmax,
                                           const float *zsel, const float *coef, int relu, const float *wT, float *da,
                                           const float *below_z, const float *below_scale, const float *below_shift,
@@ -766,7 +770,7 @@ extern "C" int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout
                                                const float *coef, int relu, const float *wT, float *da, const int *hc, const float *wh,
                                                const float *below_z, const float *below_scale, const float *below_shift,
                                                const float *below_mean, const float *below_var, float eps, int below_relu,
-                                               double *below_sums, const votenet_coef_tail *below_tail, void *stream)
+                                               double *below_sums, const votenet_coef_tail *below_tail, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(hc && wh && G > 0 && nh >= G && nh <= (long)kBallPieces * G, "pool_dgrad_scatter_half: bad piece-layout arguments");
     VN_REQUIRE(gout && argmax && zsel && coef && wT && da && (uintptr_t)wT % 16 == 0, "pool_dgrad_scatter_half: null / unaligned buffer");
@@ -776,17 +780,17 @@ extern "C" int votenet_pool_dgrad_scatter_half(long nh, int G, int cin, int cout
     VN_REQUIRE(!below_tail || (below_z && below_tail->ticket && below_tail->gamma && below_tail->coef && below_tail->rows > 0),
                "pool_dgrad_scatter_half: incomplete coefficient tail");
     return pool_dgrad_scatter_launch(nh, 64, cin, cout, gout, argmax, zsel, coef, relu, wT, da, below_z, below_scale, below_shift, below_mean,
-                                     below_var, eps, below_relu, below_sums, below_tail, hc, wh, G, stream);
+                                     below_var, eps, below_relu, below_sums, below_tail, hc, wh, G, stream, nh_dev);
 }
 
 static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
                                      const float *coef, int relu, const float *wT, float *da, const float *below_z,
                                      const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
                                      float eps, int below_relu, double *below_sums, const votenet_coef_tail *below_tail, const int *hc,
-                                     const float *wh, int G, void *stream)
+                                     const float *wh, int G, void *stream, const int *nh_dev)
 {
     hipStream_t st = as_stream(stream);
-    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse, hc, wh, G};
+    const PoolBelow pb = {below_z, below_scale, below_shift, below_mean, below_var, eps, below_relu, below_sums, to_tail(below_tail), g_scatter_reverse, hc, wh, G, nh_dev};
     auto go = [&](auto kern, int ci, int co, int threads = 512) {
         const size_t smem = ((size_t)co * ci + 4 * co + 4 * k) * 4;
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
@@ -866,8 +870,13 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
 template <int C>
 __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
                                                        int relu, float *__restrict__ gram, long rows_per_block,
-                                                       const float *__restrict__ wh /* piece layout: row 16 q counts wh[q] times */)
+                                                       const float *__restrict__ wh /* piece layout: row 16 q counts wh[q] times */,
+                                                       const int *__restrict__ nh_dev /* or NULL: rows is exact */)
 {
+    if (nh_dev != nullptr) {
+        const long lim = (long)nh_dev[0] * kPiece;
+        rows = lim < rows ? lim : rows;
+    }
     constexpr int KPT = C / 16;          // rows of a slab per thread (8 or 4)
     constexpr int T = C / 64;            // 32 x 32 sub-tiles per wave and direction (waves 2 x 2)
     constexpr int PL = C * 4 + 16;       // dwords per (piece, row-half) plane; the pad keeps a wave's two halves on different banks
@@ -987,14 +996,15 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always
 static int g_gram_wgs = 384; // votenet_debug_gram_workgroups (tuning hook)
 template <int C>
-static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st, const float *wh = nullptr)
+static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st, const float *wh = nullptr,
+                            const int *nh_dev = nullptr)
 {
     // 384 workgroups as the fp32 weight-gradient kernels (mlp_wgrad_fast.hip, plan_fast): the launch runs beside the input-gradient chain
     long rpb = (rows + g_gram_wgs - 1) / g_gram_wgs;
     rpb = (rpb + 31) / 32 * 32;
     if (rpb < 128) rpb = 128;
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh);
+    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh, nh_dev);
 }
 extern "C" void votenet_debug_gram_bf3(int on) { g_gram_bf3 = on; }
 extern "C" void votenet_debug_gram_workgroups(int n) { g_gram_wgs = n > 0 ? n : 384; }
@@ -1032,7 +1042,7 @@ extern "C" void votenet_debug_sparse_teams(int teams, int wgs) // tuning hook: 1
 }
 static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
-                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream);
+                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream, const int *nh_dev = nullptr);
 extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, const float *xz, const float *in_scale,
                                          const float *in_shift, int in_relu, const float *gout, const int *argmax, const float *zsel,
                                          const float *coef, int relu, float *dw, float *colsum, float *scratch, void *stream)
@@ -1050,18 +1060,18 @@ extern "C" int votenet_pool_wgrad_sparse(long groups, int k, int cin, int cout, 
 // The same on the piece layout (half.hip): xz has 16 * nh compact rows, gout / argmax / zsel stay per centre.
 // votenet_mlp_gram over the piece layout (half.hip): G += a^T diag(w) a with w = wh[q] on row 16 q, 1 elsewhere.
 extern "C" int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_shift, int relu, const float *wh, float *gram,
-                                     void *stream)
+                                     const int *nh_dev, void *stream)
 {
     VN_REQUIRE(rows > 0 && rows % kPiece == 0 && rows < (1L << 31) / c && (c == 128 || c == 64), "mlp_gram_half expects rows %% 16 == 0 and c in {64, 128}");
     VN_REQUIRE(z && scale_shift && wh && gram && (uintptr_t)z % 16 == 0, "mlp_gram_half: null / unaligned buffer");
-    if (c == 128) gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
-    else gram_bf3_launch<64>(rows, z, scale_shift, relu, gram, as_stream(stream), wh);
+    if (c == 128) gram_bf3_launch<128>(rows, z, scale_shift, relu, gram, as_stream(stream), wh, nh_dev);
+    else gram_bf3_launch<64>(rows, z, scale_shift, relu, gram, as_stream(stream), wh, nh_dev);
     return check_launch("mlp_gram_half");
 }
 
 extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
                                               int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
-                                              float *dw, float *colsum, const int *hc, const float *wh, void *stream)
+                                              float *dw, float *colsum, const int *hc, const float *wh, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= (long)kBallPieces * G && hc && wh, "pool_wgrad_sparse_half: bad piece-layout arguments");
     VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half: bad arguments");
@@ -1070,12 +1080,12 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse_half: operands must be 16-byte aligned");
     return pool_wgrad_sparse_launch(nh, cin, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw, colsum, nullptr, hc, wh,
-                                    G, stream);
+                                    G, stream, nh_dev);
 }
 
 static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,
                                     const float *gout, const int *argmax, const float *zsel, const float *coef, int relu, float *dw,
-                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream)
+                                    float *colsum, float *scratch, const int *hc, const float *wh, int G, void *stream, const int *nh_dev)
 {
     hipStream_t st = as_stream(stream);
     int grid;
@@ -1093,7 +1103,7 @@ static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float 
         if (fresh) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         grid = pb_grid(groups, (kk == kPiece ? 32 : 8) * teams, cap);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * teams), smem, st, groups, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef,
-                           relu, dw, colsum, scratch, hc, wh, G);
+                           relu, dw, colsum, scratch, hc, wh, G, nh_dev);
     };
     // off the critical chain (weight-gradient stream): the caps leave CUs to the chain beside it
     if (hc && g_sparse_teams == 2 && !scratch) {

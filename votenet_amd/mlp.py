@@ -435,9 +435,19 @@ class HalfLayout:
     pos (G, 3), hc / wh (nh,), geo (16 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
     its use -- and copied to pinned host memory; resolve() waits for that copy (a no-op once it has landed) and trims the views."""
 
-    def __init__(self, G, pos, hc, wh, nh_dev):
+    def __init__(self, G, pos, hc, wh, nh_dev, device_count=False):
+        """device_count: the host never learns the count (a level whose geometry is made inside the step: waiting for it would drain
+        the queue).  Every row tensor then has the maximal 64 G rows, launches are sized for that, and the kernels stop at the count
+        they read on the device (nh_limit: the pointer the *_half entries take)."""
         global _nh_ring, _nh_turn
         self.G, self.pos, self._hc, self._wh, self.nh_dev = G, pos, hc, wh, nh_dev
+        self._geo = self._u8 = None  # the level's compact rows: geo records (assembled first layer) or u8 (narrow first layer)
+        self._order = None           # the compact rows bucketed by the point they gather (half_sort_rows)
+        self.nh_limit = nh_dev if device_count else None
+        if device_count:
+            self.nh = None
+            self._ev = None
+            return
         if _nh_ring is None:
             if L.lib().votenet_half_piece_rows() != PIECE:
                 raise L.VotenetError("libvotenet_hip.so was built for pieces of %d rows, the host code for %d" % (L.lib().votenet_half_piece_rows(), PIECE))
@@ -448,13 +458,14 @@ class HalfLayout:
         self._ev = torch.cuda.Event()
         self._ev.record()
         self.nh = None
-        self._geo = self._u8 = None  # the level's compact rows: geo records (assembled first layer) or u8 (narrow first layer)
-        self._order = None           # the compact rows bucketed by the point they gather (half_sort_rows)
 
     def tensors(self):
         return [t for t in (self.pos, self._hc, self._wh, self.nh_dev, self._geo, self._u8, self._order) if t is not None]
 
     def resolve(self):
+        if self.nh is None and self.nh_limit is not None:  # the device's secret: the upper bound stands in on the host
+            self.nh = BALL_PIECES * self.G
+            self.hc, self.wh, self.geo, self.u8, self.order = self._hc, self._wh, self._geo, self._u8, self._order
         if self.nh is None:
             self._ev.synchronize()
             self.nh = int(self._slot.item())
@@ -469,6 +480,10 @@ class HalfLayout:
     @property
     def rows(self):
         return self.resolve().nh * PIECE
+
+    def true_count(self):
+        """The number of pieces (a host synchronisation when only the device knows it: tests, debugging)."""
+        return int(self.nh_dev.item()) if self.nh_limit is not None else self.resolve().nh
 
     def full_index(self):
         """(64 G,) for every slot of the full layout the compact row that holds it; a slot of a dropped piece -> the ball's slot 0."""
@@ -495,8 +510,8 @@ class HalfLayout:
         return w.reshape(-1)
 
 
-def half_groups(pts_cnt):
-    """pts_cnt (b, m) int32 -> HalfLayout (count still on its way to the host)."""
+def half_groups(pts_cnt, device_count=False):
+    """pts_cnt (b, m) int32 -> HalfLayout (count still on its way to the host; device_count: never sent, see HalfLayout)."""
     G = pts_cnt.numel()
     dev = pts_cnt.device
     ints = torch.empty((BALL_PIECES - 1) * G + BALL_PIECES * G + 1, dtype=torch.int32, device=dev)
@@ -504,7 +519,7 @@ def half_groups(pts_cnt):
     wh = torch.empty(BALL_PIECES * G, dtype=torch.float32, device=dev)
     with L.device_guard(dev):
         L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.stream_ptr()))
-        return HalfLayout(G, pos, hc, wh, nh)
+        return HalfLayout(G, pos, hc, wh, nh, device_count)
 
 
 def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
@@ -555,7 +570,7 @@ def half_sort_rows(half, npts):
         L.check(L.lib().votenet_half_sort_rows(npts, half.G, L.ptr(half.nh_dev), L.ptr(half._geo), L.ptr(work), 1 if counted else 0, L.ptr(order),
                                                L.stream_ptr()))
     half._order = order
-    if half.nh is not None:  # the count is known already
+    if half.nh is not None:  # the count is known already (or stands at its upper bound)
         half.order = order[:half.nh * PIECE]
     return order
 
@@ -570,8 +585,19 @@ def group_linear_backward_half(half, b, n, P, wx, da, coef, relu, dw_xyz):
     with L.device_guard(P.device):
         L.check(L.lib().votenet_group_linear_backward_sorted(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(half.wh), L.ptr(P),
                                                              L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
-                                                             L.stream_ptr()))
+                                                             L.ptr(half.nh_limit), L.stream_ptr()))
     return S
+
+
+def half_centre_sums(half, P, wx, da, coef, relu):
+    """-> (G, cout): MINUS the sum of the total gradients dz0 over every centre's compact rows (what the centre's coordinates receive
+    through dxyz = xyz[idx] - new_xyz, before the product with W[0:3]^T): votenet_half_centre_sums."""
+    cout = P.shape[1]
+    T = torch.empty((half.G, cout), dtype=torch.float32, device=P.device)
+    with L.device_guard(P.device):
+        L.check(L.lib().votenet_half_centre_sums(half.G, cout, L.ptr(half.pos), L.ptr(half.geo), L.ptr(half.wh), L.ptr(P), L.ptr(wx), L.ptr(da),
+                                                 L.ptr(coef), 1 if relu else 0, L.ptr(T), L.stream_ptr()))
+    return T
 
 
 def assemble_stats(P, cntv, wx, mom):
@@ -606,7 +632,7 @@ def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True, 
         with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled half")):
             L.check(L.lib().votenet_assembled_linear_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
                                                           ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
-                                                          L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh), L.stream_ptr()))
+                                                          L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh), L.ptr(half.nh_limit), L.stream_ptr()))
         return z, stats
     with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled")):
         L.check(L.lib().votenet_assembled_linear(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
@@ -622,7 +648,7 @@ def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, d
         with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled half")):
             L.check(L.lib().votenet_assembled_wgrad_bn_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(in_scale), L.ptr(in_shift),
                                                             1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0,
-                                                            L.ptr(half.wh), L.ptr(dw), L.stream_ptr()))
+                                                            L.ptr(half.wh), L.ptr(dw), L.ptr(half.nh_limit), L.stream_ptr()))
         return
     scr = _wgrad_scratch(None, rows, c0, cout, P.device)
     with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled")):
@@ -644,7 +670,8 @@ def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_E
             L.check(L.lib().votenet_assembled_dgrad_bn_reduce_half(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                                    L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh),
                                                                    L.ptr(bme), L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
-                                                                   ctypes.byref(t) if t is not None else None, L.ptr(half.wh), L.stream_ptr()))
+                                                                   ctypes.byref(t) if t is not None else None, L.ptr(half.wh), L.ptr(half.nh_limit),
+                                                                   L.stream_ptr()))
     else:
         with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled")):
             L.check(L.lib().votenet_assembled_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
@@ -802,7 +829,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
         abest = torch.empty((half.nh, cout), dtype=torch.int32, device=x.device)
         with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool half")):
             L.check(L.lib().votenet_mlp_linear_pool_half(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
-                                                         L.ptr(half.wh), L.ptr(gamma), L.ptr(zbest), L.ptr(abest), L.stream_ptr()))
+                                                         L.ptr(half.wh), L.ptr(gamma), L.ptr(zbest), L.ptr(abest), L.ptr(half.nh_limit), L.stream_ptr()))
         return z, stats, (zbest, abest)
     g = rows // k
     vals = torch.empty((2, g, cout), dtype=torch.float32, device=x.device)
@@ -890,7 +917,13 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     if mm is None:
         mm = pool_dgrad_prepare(w, bias, coef, rows)
     img = getattr(mm, "_img", None)
-    if img is not None:
+    if half is not None and half.nh_limit is not None:
+        # the count is the device's: the dense GEMM stops at it too (rows = the upper bound)
+        da = torch.empty((rows, cin), dtype=torch.float32, device=xz.device)
+        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "fwd")):
+            L.check(L.lib().votenet_mlp_linear_half(L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0, rows, cin, cin, L.ptr(mm),
+                                                    L.ptr(mm[cin]), L.ptr(da), L.ptr(half.nh_limit), L.stream_ptr()))
+    elif img is not None:
         # the matrix exists only for this launch: its image is registered around the GEMM's launch only
         L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(img)))
         try:
@@ -908,7 +941,7 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
                                                             1 if relu else 0, L.ptr(wT), L.ptr(da), L.ptr(half.hc), L.ptr(half.wh),
                                                             L.ptr(xz if below is not None else None), L.ptr(bsc), L.ptr(bsh), L.ptr(bme),
                                                             L.ptr(bva), float(eps), 1 if brelu else 0, L.ptr(sums),
-                                                            ctypes.byref(t) if t is not None else None, L.stream_ptr()))
+                                                            ctypes.byref(t) if t is not None else None, L.ptr(half.nh_limit), L.stream_ptr()))
     else:
         with L.device_guard(xz.device):
             L.check(L.lib().votenet_pool_dgrad_scatter(rows // k, k, cin, cout, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
@@ -928,7 +961,8 @@ def gram(xz, scale_shift, relu, half=None):
     g = _zeros_f32((c + 1, c), xz.device)  # [gram ; column sums (filled by pool_wgrad)]
     if half is not None:
         with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram half")):
-            L.check(L.lib().votenet_mlp_gram_half(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(half.wh), L.ptr(g), L.stream_ptr()))
+            L.check(L.lib().votenet_mlp_gram_half(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(half.wh), L.ptr(g),
+                                                  L.ptr(half.nh_limit), L.stream_ptr()))
         return g
     scr = _wgrad_scratch(None, rows, c, c, xz.device)
     with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram")):
@@ -945,7 +979,7 @@ def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, g
             L.check(L.lib().votenet_pool_wgrad_sparse_half(half.nh, half.G, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift),
                                                            1 if in_relu else 0, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
                                                            1 if relu else 0, L.ptr(dw), L.ptr(gram_buf[cin]), L.ptr(half.hc), L.ptr(half.wh),
-                                                           L.stream_ptr()))
+                                                           L.ptr(half.nh_limit), L.stream_ptr()))
             L.check(L.lib().votenet_pool_wgrad_finish(cin, cout, L.ptr(gram_buf), L.ptr(gram_buf[cin]), L.ptr(w), L.ptr(bias), L.ptr(coef),
                                                       L.ptr(dw), L.stream_ptr()))
         return

@@ -726,7 +726,7 @@ class SAModule:
         """True when this module's grouped MLP runs on the piece layout (csrc/half.hip: the rows that repeat slot 0 dropped by
         halves of a ball) for b scenes of n points: an assembled first layer, three BatchNorm'ed layers, the pooled one in Gram form."""
         m = self.mlp
-        if not (HALF_GROUPS and not M.DETERMINISTIC and not self.knn and self.nsample == 64 and len(m) == 3 and self.mlp2 is None and m[2].bn and POOL_IN_EPILOGUE
+        if not (HALF_GROUPS and not M.DETERMINISTIC and not self.knn and self.nsample == 64 and len(m) == 3 and m[2].bn and POOL_IN_EPILOGUE
                 and POOL_GRAM_BACKWARD and (b * self.npoint) % 8 == 0 and M.pool_backward_supported(m[1].cout, m[2].cout, 64)):
             return False
         return bool(self.narrow(b * self.npoint * 64) or (m[1].cout == 128 and self.assembled(b, n)))
@@ -747,8 +747,11 @@ class SAModule:
                 geom = tuple(geom) + M.narrow_rows_half(xyz, geom[1], points, geom[2], geom[3], half) + (half,)
             else:
                 geom = tuple(geom) + M.narrow_rows(xyz, geom[1], points, geom[2])
-        elif ahead and self.half_groups(xyz.shape[0], xyz.shape[1]):
-            half = M.half_groups(geom[3])  # the layout and the count of its pieces: known on the host by the time the MLP runs
+        elif (ahead or ASSEMBLE_INLINE) and self.half_groups(xyz.shape[0], xyz.shape[1]):
+            # the layout and the count of its pieces: known on the host by the time the MLP runs when the geometry is computed ahead;
+            # inside the step it serves (the proposal module: the votes exist only now) the count stays on the device -- waiting for it
+            # would drain the queue -- and the kernels stop at it themselves
+            half = M.half_groups(geom[3], device_count=not ahead)
             geom = tuple(geom) + M.assemble_rows_half(xyz, geom[1], geom[2], geom[3], half) + (half,)
             M.half_sort_rows(half, xyz.shape[0] * xyz.shape[1])  # the rows bucketed by point, for the first layer's backward
         elif self.assembled(xyz.shape[0], xyz.shape[1]) and (ahead or ASSEMBLE_INLINE):  # ahead=False: called inside the step it serves
@@ -834,9 +837,14 @@ class SAModule:
             if feat is not None and PRE_LINEAR:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
         elif r0["kind"] == "assembled" and r0.get("half") is not None:
+            half = r0["half"]
+            S, dz = M.group_linear_backward_half(half, b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
             if need_xyz_grad:
-                raise ValueError("SAModule: the piece layout keeps no per-row dz for the xyz gradient")
-            S, dz = M.group_linear_backward_half(r0["half"], b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
+                # dz0 W[0:3]^T is linear in dz0: the points receive S W[0:3]^T, a centre minus the sum of its rows' dz0 times W[0:3]^T
+                d_xyz = M.rows_dot3(S.view(b * n, cout), W[:3]).view(b, n, 3)
+                d_new = M.rows_dot3(M.half_centre_sums(half, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"]), W[:3]).view(b, -1, 3)
+                d_xyz = tf_sampling.gather_point_grad_raw(n, rec["fps_idx"], d_new, into=d_xyz)
+                need_xyz_grad = False  # done
         elif r0["kind"] == "assembled":
             S, dz = M.group_linear_backward_assembled(xyz, new_xyz, idx, pts_cnt, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"],
                                                       gW[:3], want_dz=need_xyz_grad)
