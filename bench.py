@@ -431,10 +431,10 @@ def main():
             tape = []
             net.forward(xs[0], tape)
             kept = {}
-            for name, rec in zip(("sa1", "sa2", "sa3", "sa4"), tape[:4]):
+            for name, rec in list(zip(("sa1", "sa2", "sa3", "sa4"), tape[:4])) + [("proposal", tape[-1])]:
                 half = rec["recs"][0].get("half")
-                if half is not None:
-                    kept[name] = round(half.rows / float(rec["idx"].numel()), 3)
+                if half is not None:  # (the proposal module's count lives on the device: read here, outside the timed region)
+                    kept[name] = round(half.true_count() * 16 / float(rec["idx"].numel()), 3)
             row_layout = {"piece_rows": 16, "grouped_rows_kept": kept,
                           "what": "a ball (tf_grouping_g.cu:26-29 pads it to 64 slots with copies of its first hit) keeps the 16-row pieces that hold "
                                   "a real neighbour, ceil(pts_cnt / 16) of 4; its slot 0 stands for the dropped copies with weight 1 + 16 * dropped "
@@ -555,6 +555,7 @@ def main():
                                                                if iso_fps else None)}}
         mfma = None
         if gemm_events:
+            gemm_events = [vmlp.resolve_event(ev) for ev in gemm_events]  # (launches sized for an upper bound: the rows that were there)
             # GEMMs run on two streams (weight gradients beside the input-gradient chain): the time the matrix pipes are
             # in use is the UNION of the launch intervals, not their sum.  All events are placed on one time axis by
             # their distance from the first one.

@@ -20,7 +20,7 @@ for s in range(NS):
     i = 8 + s
     net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
     torch.cuda.synchronize()
-    ev = M.PROFILE_EVENTS
+    ev = [M.resolve_event(e) for e in M.PROFILE_EVENTS]
     M.PROFILE_EVENTS = None
     for j, (e0, e1, kind, fl, shape) in enumerate(ev):
         rows.setdefault(j, [kind, fl, shape, 0.0])[3] += e0.elapsed_time(e1) / NS

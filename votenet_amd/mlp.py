@@ -17,8 +17,12 @@ PROFILE_SHAPES = None  # tools/gemm_table.py: not None -> entries also carry (ro
 
 
 class _Timed:
-    def __init__(self, kind, flops, shape=None):
+    def __init__(self, kind, flops, shape=None, limit=None):
+        """limit: a HalfLayout whose piece count only the device knows -- the launch is sized for the upper bound and `flops` counts that
+        bound; the event then carries (flops, count tensor, bound) and resolve_event() prices the rows that were really there."""
         self.kind, self.flops, self.shape = kind, flops, shape
+        if limit is not None and getattr(limit, "nh_limit", None) is not None:
+            self.flops = (flops, limit.nh_dev, BALL_PIECES * limit.G)
 
     def __enter__(self):
         if PROFILE_EVENTS is not None:
@@ -29,6 +33,15 @@ class _Timed:
         if PROFILE_EVENTS is not None:
             self.e1.record()
             PROFILE_EVENTS.append((self.e0, self.e1, self.kind, self.flops) if PROFILE_SHAPES is None else (self.e0, self.e1, self.kind, self.flops, self.shape))
+
+
+def resolve_event(ev):
+    """A PROFILE_EVENTS entry with its flops as a number (reads the device's piece count where the launch was sized for an upper bound:
+    a host synchronisation -- call it after the timed region)."""
+    if isinstance(ev[3], tuple):
+        fl, nh, bound = ev[3]
+        ev = ev[:3] + (fl * float(nh.item()) / bound,) + tuple(ev[4:])
+    return ev
 
 
 class _StatsArena:
@@ -629,7 +642,7 @@ def assembled_linear(geo, P, wx, w, bias, in_bn, in_relu=True, want_stats=True, 
     else:
         raw = in_bn.raw()
     if half is not None:
-        with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled half")):
+        with L.device_guard(P.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn assembled half"), limit=half):
             L.check(L.lib().votenet_assembled_linear_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(scale), L.ptr(shift),
                                                           ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
                                                           L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh), L.ptr(half.nh_limit), L.stream_ptr()))
@@ -645,7 +658,7 @@ def assembled_wgrad_bn(geo, P, wx, in_scale, in_shift, in_relu, z, coef, relu, d
     """dw (c0, cout) += relu(bn0(z0))^T dz1 with z0 rebuilt in the loader, dz1 = BatchNorm-backward(da, z, coef)."""
     rows, c0, cout = geo.shape[0], P.shape[1], z.shape[1]
     if half is not None:
-        with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled half")):
+        with L.device_guard(P.device), _Timed("wgrad_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "wgrad_bn assembled half"), limit=half):
             L.check(L.lib().votenet_assembled_wgrad_bn_half(rows, c0, cout, L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(in_scale), L.ptr(in_shift),
                                                             1 if in_relu else 0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0,
                                                             L.ptr(half.wh), L.ptr(dw), L.ptr(half.nh_limit), L.stream_ptr()))
@@ -666,7 +679,7 @@ def assembled_dgrad_bn_reduce(z, coef, relu, wT, da, geo, P, wx, below, eps=BN_E
     sums = _zeros_f64(2 * cout, z.device)
     t, coef_b = _coef_tail(below_tail, cout, z.device)
     if half is not None:
-        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled half")):
+        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce assembled half"), limit=half):
             L.check(L.lib().votenet_assembled_dgrad_bn_reduce_half(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                                    L.ptr(out), L.ptr(geo), L.ptr(P), L.ptr(wx), L.ptr(bsc), L.ptr(bsh),
                                                                    L.ptr(bme), L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums),
@@ -827,7 +840,7 @@ def linear_dense_pool(x, w, k, bias=None, in_scale=None, in_shift=None, in_relu=
             raise L.InvalidArgumentError("linear_dense_pool(half=...): the layer's gamma decides which extreme a piece keeps")
         zbest = torch.empty((half.nh, cout), dtype=torch.float32, device=x.device)
         abest = torch.empty((half.nh, cout), dtype=torch.int32, device=x.device)
-        with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool half")):
+        with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd+pool half"), limit=half):
             L.check(L.lib().votenet_mlp_linear_pool_half(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                                          L.ptr(half.wh), L.ptr(gamma), L.ptr(zbest), L.ptr(abest), L.ptr(half.nh_limit), L.stream_ptr()))
         return z, stats, (zbest, abest)
@@ -920,7 +933,7 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     if half is not None and half.nh_limit is not None:
         # the count is the device's: the dense GEMM stops at it too (rows = the upper bound)
         da = torch.empty((rows, cin), dtype=torch.float32, device=xz.device)
-        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "fwd")):
+        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "fwd"), limit=half):
             L.check(L.lib().votenet_mlp_linear_half(L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0, rows, cin, cin, L.ptr(mm),
                                                     L.ptr(mm[cin]), L.ptr(da), L.ptr(half.nh_limit), L.stream_ptr()))
     elif img is not None:
@@ -960,7 +973,7 @@ def gram(xz, scale_shift, relu, half=None):
     rows, c = xz.shape
     g = _zeros_f32((c + 1, c), xz.device)  # [gram ; column sums (filled by pool_wgrad)]
     if half is not None:
-        with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram half")):
+        with L.device_guard(xz.device), _Timed("wgrad_dense", 2.0 * rows * c * c, (rows, c, c, "gram half"), limit=half):
             L.check(L.lib().votenet_mlp_gram_half(rows, c, L.ptr(xz), L.ptr(scale_shift), 1 if relu else 0, L.ptr(half.wh), L.ptr(g),
                                                   L.ptr(half.nh_limit), L.stream_ptr()))
         return g
