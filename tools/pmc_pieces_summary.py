@@ -31,11 +31,11 @@ def short(n):
 # the kernels of the level itself (its GEMMs carry level-specific template arguments or run REP times more often than the others)
 LEVEL_KERNELS = {
     "sa2": ["mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2, true>", "mlp_linear_fast_kernel<2, 2, 2, 2, 4, 0, true>", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 6",
-            "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false>", "mlp_wgrad_fast_kernel<3, 2, 2, 4", "pool_wgrad_sparse_kernel<128, 16>",
+            "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false>", "mlp_wgrad_fast_kernel<3, 2, 2, 4", "pool_wgrad_sparse_kernel<128, 16",
             "pool_dgrad_scatter_wave_kernel<128, 256, 16", "gram_bf3_kernel<128>", "group_linear_bwd_sorted_kernel", "bn_pool_finalize_half",
             "bn_bwd_reduce_zsel", "assemble_rows_half", "half_sort", "half_groups", "pool_wgrad_finish", "pool_dgrad_prepare_kernel<256>"],
     "sa1": ["mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2, true>", "mlp_linear_fast_kernel<4, 1, 1, 2, 3, 0, true>", "mlp_linear_fast_kernel<4, 1, 1, 2, 5, 4",
-            "mlp_linear_fast_kernel<4, 1, 1, 2, 0, 1, false>", "mlp_wgrad_fast_kernel<2, 1, 1, 4", "pool_wgrad_sparse_kernel<64, 16>",
+            "mlp_linear_fast_kernel<4, 1, 1, 2, 0, 1, false>", "mlp_wgrad_fast_kernel<2, 1, 1, 4", "pool_wgrad_sparse_kernel<64, 16",
             "pool_dgrad_scatter_wave_kernel<64, 128, 16", "gram_bf3_kernel<64>", "bn_pool_finalize_half", "bn_bwd_reduce_zsel", "narrow_rows_half",
             "half_groups", "pool_wgrad_finish", "pool_dgrad_prepare_kernel<128>", "narrow_wgrad_first"],
 }
