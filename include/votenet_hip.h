@@ -674,7 +674,9 @@ int votenet_ema_update(long n, float momentum, float *ema, const float *batch, c
  * layout up to the association of those sums.
  * votenet_half_groups: pos (G x 3) = index (from G) of piece j = 1..3 of centre c or -1, hc (4G), wh (4G), nh (1 int, device) = number
  * of pieces.  One workgroup, a prefix scan: the layout is the same in every run. */
-int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh, void *stream);
+int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh,
+                        int *nh_host /* may be NULL: pinned host memory (mapped into the device's address space) that receives the count too */,
+                        void *stream);
 int votenet_half_piece_rows(void);
 /* votenet_assemble_rows on the piece layout: geo (up to 64G x 4 floats; rows past 16*nh[0] are not written), cntv and moments
  * exactly as votenet_assemble_rows (they run over the true rows).  nh is read on the device: no host synchronisation. */

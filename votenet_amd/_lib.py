@@ -167,7 +167,7 @@ _SIGS["votenet_row_segments"] = [ctypes.c_long, ctypes.c_int, ctypes.POINTER(Row
 # piece layout (csrc/half.hip)
 _I, _L, _F = ctypes.c_int, ctypes.c_long, ctypes.c_float
 _SIGS.update({
-    "votenet_half_groups": [_I] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_half_groups": [_I] + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_assemble_rows_half": [_I] * 3 + [_c_f] * 10 + [ctypes.c_void_p],
     "votenet_assembled_linear_half": [_L, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_mlp_linear_half": [_c_f] * 3 + [_I, _L, _I, _I] + [_c_f] * 4 + [ctypes.c_void_p],

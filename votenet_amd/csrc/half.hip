@@ -30,7 +30,7 @@ __device__ __forceinline__ int kept_pieces(int cnt)
 // wh[q] = weight of piece q's row 0; nh[0] = number of pieces.  Centres in ascending order (a prefix scan, no atomics): the layout -- and
 // with it the order of every sum over the rows -- is the same in every run.
 __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__restrict__ pts_cnt, int *__restrict__ pos, int *__restrict__ hc,
-                                                           float *__restrict__ wh, int *__restrict__ nh_out)
+                                                           float *__restrict__ wh, int *__restrict__ nh_out, int *nh_host)
 {
     __shared__ int s_wave[16];
     __shared__ int s_carry;
@@ -80,6 +80,10 @@ __global__ __launch_bounds__(1024) void half_groups_kernel(int G, const int *__r
                 }
         s_carry = n2;
         nh_out[0] = G + n2;
+        if (nh_host != nullptr) { // pinned host memory, mapped into the device's address space: the host reads it after the event behind
+            nh_host[0] = G + n2;  // this kernel (no copy launch)
+            __threadfence_system();
+        }
     }
     __syncthreads();
     const int nh = G + s_carry;
@@ -496,11 +500,11 @@ __global__ __launch_bounds__(256) void half_centre_sums_kernel(long G, const int
 
 using namespace votenet;
 
-extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh_out, void *stream)
+extern "C" int votenet_half_groups(int G, const int *pts_cnt, int *pos, int *hc, float *wh, int *nh_out, int *nh_host, void *stream)
 {
     VN_REQUIRE(G > 0 && G % TP == 0, "half_groups expects a positive number of centres, a multiple of %d", TP);
     VN_REQUIRE(pts_cnt && pos && hc && wh && nh_out, "half_groups: null buffer");
-    hipLaunchKernelGGL(half_groups_kernel, dim3(1), dim3(1024), 0, as_stream(stream), G, pts_cnt, pos, hc, wh, nh_out);
+    hipLaunchKernelGGL(half_groups_kernel, dim3(1), dim3(1024), 0, as_stream(stream), G, pts_cnt, pos, hc, wh, nh_out, nh_host);
     return check_launch("half_groups");
 }
 extern "C" int votenet_half_piece_rows(void) { return PS; }

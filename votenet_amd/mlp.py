@@ -448,7 +448,19 @@ class HalfLayout:
     pos (G, 3), hc / wh (nh,), geo (16 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
     its use -- and copied to pinned host memory; resolve() waits for that copy (a no-op once it has landed) and trims the views."""
 
-    def __init__(self, G, pos, hc, wh, nh_dev, device_count=False):
+    @staticmethod
+    def host_slot():
+        """A pinned int the kernel that makes the layout writes the count into (one per layout, reused round-robin)."""
+        global _nh_ring, _nh_turn
+        if _nh_ring is None:
+            if L.lib().votenet_half_piece_rows() != PIECE:
+                raise L.VotenetError("libvotenet_hip.so was built for pieces of %d rows, the host code for %d" % (L.lib().votenet_half_piece_rows(), PIECE))
+            _nh_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
+        slot = _nh_ring[_nh_turn:_nh_turn + 1]
+        _nh_turn = (_nh_turn + 1) % 256
+        return slot
+
+    def __init__(self, G, pos, hc, wh, nh_dev, device_count=False, slot=None):
         """device_count: the host never learns the count (a level whose geometry is made inside the step: waiting for it would drain
         the queue).  Every row tensor then has the maximal 64 G rows, launches are sized for that, and the kernels stop at the count
         they read on the device (nh_limit: the pointer the *_half entries take)."""
@@ -461,13 +473,7 @@ class HalfLayout:
             self.nh = None
             self._ev = None
             return
-        if _nh_ring is None:
-            if L.lib().votenet_half_piece_rows() != PIECE:
-                raise L.VotenetError("libvotenet_hip.so was built for pieces of %d rows, the host code for %d" % (L.lib().votenet_half_piece_rows(), PIECE))
-            _nh_ring = torch.zeros(256, dtype=torch.int32).pin_memory()
-        self._slot = _nh_ring[_nh_turn:_nh_turn + 1]
-        _nh_turn = (_nh_turn + 1) % 256
-        self._slot.copy_(nh_dev, non_blocking=True)
+        self._slot = slot  # written by votenet_half_groups itself (pinned memory is mapped into the device's address space)
         self._ev = torch.cuda.Event()
         self._ev.record()
         self.nh = None
@@ -530,9 +536,10 @@ def half_groups(pts_cnt, device_count=False):
     ints = torch.empty((BALL_PIECES - 1) * G + BALL_PIECES * G + 1, dtype=torch.int32, device=dev)
     pos, hc, nh = ints[:(BALL_PIECES - 1) * G], ints[(BALL_PIECES - 1) * G:-1], ints[-1:]
     wh = torch.empty(BALL_PIECES * G, dtype=torch.float32, device=dev)
+    slot = None if device_count else HalfLayout.host_slot()
     with L.device_guard(dev):
-        L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.stream_ptr()))
-        return HalfLayout(G, pos, hc, wh, nh, device_count)
+        L.check(L.lib().votenet_half_groups(G, L.ptr(pts_cnt), L.ptr(pos), L.ptr(hc), L.ptr(wh), L.ptr(nh), L.ptr(slot), L.stream_ptr()))
+        return HalfLayout(G, pos, hc, wh, nh, device_count, slot)
 
 
 def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
