@@ -300,7 +300,9 @@ def test_pooled_layer_gram_form_equals_the_direct_form(hiplib, dev, groups, cin,
     da_ref = M.dgrad_bn(z, coef, True, wT, gout=gout, argmax=arg, k=k)
     # Gram form: never touches z
     sums2 = M.bn_backward_reduce_pool(gout, zsel, sc, sh, mean, var, True)
-    assert torch.allclose(sums2, sums, rtol=1e-9, atol=1e-9)
+    # (both are fp64 sums of per-workgroup fp32 partial sums; the two kernels split the groups over different numbers of workgroups)
+    scale = (gout.double().abs() * 4).sum(0).repeat(2) + 1e-30
+    assert float(((sums2 - sums).abs() / scale).max()) < 1e-6
     G = M.gram(xz, aff, True)
     a = torch.relu(xz.double() * aff[0].double() + aff[1].double())
     assert relerr(G[:cin].double(), a.t() @ a) < 1e-5

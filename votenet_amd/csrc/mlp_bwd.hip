@@ -85,15 +85,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_dense_vec_kernel(long rows,
     };
     const long stride = (long)gridDim.x * rpp;
     long r = (long)blockIdx.x * rpp + rl;
-    for (; r + 3 * stride < rows; r += 4 * stride) {
-        float4 zz[4], gg[4];
+    for (; r + 7 * stride < rows; r += 8 * stride) { // sixteen 16-byte loads in flight per thread: the pass is a latency chain on few workgroups
+        float4 zz[8], gg[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) {
             zz[u] = *reinterpret_cast<const float4 *>(z + (size_t)(r + u * stride) * c + 4 * q);
             gg[u] = *reinterpret_cast<const float4 *>(da + (size_t)(r + u * stride) * c + 4 * q);
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) acc(zz[u], gg[u]);
+        for (int u = 0; u < 8; u++) acc(zz[u], gg[u]);
     }
     for (; r < rows; r += stride)
         acc(*reinterpret_cast<const float4 *>(z + (size_t)r * c + 4 * q), *reinterpret_cast<const float4 *>(da + (size_t)r * c + 4 * q));

@@ -39,7 +39,25 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
     float s1 = 0, s2 = 0;
     if (col < c) {
         const float sc = scale[col], sf = shift[col], mu = mean[col], inv = 1.0f / sqrtf(var[col] + eps);
-        for (long g = (long)blockIdx.x * 4 + ry; g < groups; g += (long)gridDim.x * 4) {
+        // eight groups' loads in flight per trip: the pass sits on the backward chain of every SA level and was one loaded-memory latency
+        // per 4 groups and workgroup (22 us for 8 MB)
+        const long stride = (long)gridDim.x * 4;
+        long g = (long)blockIdx.x * 4 + ry;
+        for (; g + 7 * stride < groups; g += 8 * stride) {
+            float zz[8], gg[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                zz[u] = zsel[(size_t)(g + u * stride) * c + col];
+                gg[u] = gout[(size_t)(g + u * stride) * c + col];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (relu && !(zz[u] * sc + sf > 0.0f)) gg[u] = 0.0f;
+                s1 += gg[u];
+                s2 += gg[u] * ((zz[u] - mu) * inv);
+            }
+        }
+        for (; g < groups; g += stride) {
             const float zz = zsel[(size_t)g * c + col];
             float gg = gout[(size_t)g * c + col];
             if (relu && !(zz * sc + sf > 0.0f)) gg = 0.0f;
@@ -704,7 +722,7 @@ extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *
     VN_REQUIRE(gout && zsel && scale && shift && mean && var && sums, "bn_backward_reduce_pool: null buffer");
     VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "bn_backward_reduce_pool: incomplete coefficient tail");
     const int ny = (c + 63) / 64;
-    hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, 4, 1024 / ny + 1), ny), dim3(256), 0, as_stream(stream), groups,
+    hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, 32, 256 / ny), ny), dim3(256), 0, as_stream(stream), groups,
                        c, gout, zsel, scale, shift, mean, var, eps, relu, sums, to_tail(tail));
     return check_launch("bn_backward_reduce_pool");
 }
