@@ -92,13 +92,30 @@ __global__ __launch_bounds__(256) void assemble_stats_kernel(long npts, int c0, 
     double s1 = 0.0, s2 = 0.0;
     if (c < c0) {
         const double w0 = wx[c], w1 = wx[c0 + c], w2 = wx[2 * c0 + c];
-        for (long p = (long)blockIdx.x * 4 + py; p < npts; p += (long)gridDim.x * 4) {
-            const long long *cv = cntv + (size_t)p * 4;
-            if (cv[0] == 0) continue; // a point no ball contains
-            const double v = P[(size_t)p * c0 + c], cn = (double)cv[0];
-            const double vw = ((double)cv[1] * w0 + (double)cv[2] * w1 + (double)cv[3] * w2) * (1.0 / 4294967296.0);
-            s1 += cn * v;
-            s2 += cn * v * v + 2.0 * v * vw;
+        // four points' loads in flight per trip, few workgroups: the pass is a latency chain that ends in fp64 atomics on 2 c0 addresses
+        // (256 workgroups a column block made it 15 us for 2 MB: the atomics of one address serialise)
+        const long stride = (long)gridDim.x * 4;
+        for (long p0 = (long)blockIdx.x * 4 + py; p0 < npts; p0 += 4 * stride) {
+            long long c4[4][4];
+            float v4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const long p = p0 + u * stride < npts ? p0 + u * stride : p0; // (clamped: counted once below)
+                const long long *cv = cntv + (size_t)p * 4;
+                c4[u][0] = cv[0];
+                c4[u][1] = cv[1];
+                c4[u][2] = cv[2];
+                c4[u][3] = cv[3];
+                v4[u] = P[(size_t)p * c0 + c];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                if (p0 + u * stride >= npts || c4[u][0] == 0) continue; // past the end / a point no ball contains
+                const double v = v4[u], cn = (double)c4[u][0];
+                const double vw = ((double)c4[u][1] * w0 + (double)c4[u][2] * w1 + (double)c4[u][3] * w2) * (1.0 / 4294967296.0);
+                s1 += cn * v;
+                s2 += cn * v * v + 2.0 * v * vw;
+            }
         }
         if (blockIdx.x == 0 && py == 0) { // the coordinate-only terms, once
             s1 += mom[0] * w0 + mom[1] * w1 + mom[2] * w2;
@@ -160,7 +177,7 @@ extern "C" int votenet_assemble_stats(long npts, int c0, const float *P, const l
     VN_REQUIRE(P && cntv && wx && moments && stats, "assemble_stats: null buffer");
     const int ny = (c0 + 63) / 64;
     long gx = (npts + 4 * 16 - 1) / (4 * 16);
-    if (gx > 512) gx = 512;
+    if (gx > 128) gx = 128;
     hipLaunchKernelGGL(assemble_stats_kernel, dim3((unsigned)gx, ny), dim3(256), 0, as_stream(stream), npts, c0, P, cntv, wx, moments, stats);
     return check_launch("assemble_stats");
 }
