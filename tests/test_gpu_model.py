@@ -322,6 +322,59 @@ def test_prefetched_geometry_is_the_same_computation(hiplib, dev):
         assert torch.equal(ref_b[k], b2[k]) and torch.equal(ref_c[k], c2[k]), k
 
 
+def test_geometry_graph_replays_are_the_launch_by_launch_chain(hiplib, dev, monkeypatch):
+    """model.GeometryGraph: the prefetched chain replayed as one HIP graph gives bit-identical passes to the chain enqueued launch by
+    launch, batch after batch around the ring of graphs; a prefetch whose graph has served another batch since is not trusted; a
+    lookahead longer than the ring never replays the graph whose buffers the running pass reads."""
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    xs = [torch.from_numpy(synth.room_batch(2, 4096, 50 + i)).to(dev) for i in range(5)]
+    net = VM.VoteNetHotPath(dev, seed=6, npoints=(512, 256, 128, 64))
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", False)
+    refs = [net.forward(x) for x in xs]
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", True)
+    net.forward(xs[0], next_x=xs[1])
+    for i in range(1, 11):  # warm-up pass, three captures, then replays
+        got = net.forward(xs[i % 5], next_x=xs[(i + 1) % 5])
+        for k in refs[0]:
+            assert torch.equal(got[k], refs[i % 5][k]), (i, k)
+    ring = next(iter(net._geometry_rings.values()))
+    assert len(ring["graphs"]) == VM.GEOMETRY_RING and sum(g.generation for g in ring["graphs"]) >= 9
+    # the tape of a pass on replayed geometry drives the same backward pass
+    def grads(x, **kw):
+        tape = []
+        out = net.forward(x, tape, **kw)
+        net.store.grad.zero_()
+        net.backward(tape, net.make_cotangents(2, seed=1))
+        return out, net.store.grad.clone()
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", False)
+    net._prefetched.clear()
+    o_ref, g_ref = grads(xs[2])
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", True)
+    net.forward(xs[0], next_x=xs[2])
+    assert net._prefetched[id(xs[2])][4] is not None  # a graph served it
+    o_got, g_got = grads(xs[2])
+    assert torch.equal(o_got["proposals_output"], o_ref["proposals_output"])
+    assert (g_got - g_ref).abs().max() <= 1e-5 * g_ref.abs().max()  # atomics: the order of a sum varies run to run
+    # stale: xs[3]'s graph serves other batches before xs[3] is asked for
+    net._prefetched.clear()
+    net.prefetch_geometry(xs[3])
+    held = net._prefetched[id(xs[3])]
+    for x in (xs[0], xs[1], xs[2], xs[4]):
+        net.prefetch_geometry(x)
+    net._prefetched[id(xs[3])] = held  # (the pool had dropped it: put the stale entry back)
+    assert held[4].generation != held[5]
+    got = net.forward(xs[3])
+    assert torch.equal(got["proposals_output"], refs[3]["proposals_output"])
+    # a lookahead of four with a ring of three: the graph under the running pass is skipped (that prefetch runs launch by launch)
+    net._prefetched.clear()
+    net.forward(xs[0], next_x=xs[1])
+    got = net.forward(xs[1], next_x=[xs[2], xs[3], xs[4], xs[0]])
+    assert torch.equal(got["proposals_output"], refs[1]["proposals_output"])
+    got = net.forward(xs[0])
+    assert torch.equal(got["proposals_output"], refs[0]["proposals_output"])
+
+
 def test_moving_averages_follow_tensorflows_update(hiplib, dev):
     """The BatchNorm moving averages (reference: Tensorpack BNReLU, momentum 0.9): after a training-mode forward pass
     moving = 0.9 * moving + 0.1 * (batch mean | unbiased batch variance) for every BatchNorm layer, starting from 0 / 1; the

@@ -443,6 +443,31 @@ _nh_ring = None  # pinned ints the piece counts are copied into (one slot per la
 _nh_turn = 0
 
 
+_slot_source = None
+
+
+class layout_slots:
+    """Context: HalfLayout.host_slot() hands out the elements of `pinned` (a pinned int32 tensor its owner keeps alive), in order."""
+
+    def __init__(self, pinned):
+        self.pinned, self.turn = pinned, 0
+
+    def _next(self):
+        if self.turn >= self.pinned.numel():
+            raise L.VotenetError("layout_slots: more piece layouts than slots (%d)" % self.pinned.numel())
+        self.turn += 1
+        return self.pinned[self.turn - 1:self.turn]
+
+    def __enter__(self):
+        global _slot_source
+        self._saved, _slot_source = _slot_source, self._next
+        return self
+
+    def __exit__(self, *exc):
+        global _slot_source
+        _slot_source = self._saved
+
+
 class HalfLayout:
     """Row layout of one level (include/votenet_hip.h, 'PIECE layout'): G centres, nh pieces of PIECE = 16 compact rows.
     pos (G, 3), hc / wh (nh,), geo (16 nh, 4).  The count nh is produced on the device by the geometry chain -- typically a step ahead of
@@ -452,6 +477,8 @@ class HalfLayout:
     def host_slot():
         """A pinned int the kernel that makes the layout writes the count into (one per layout, reused round-robin)."""
         global _nh_ring, _nh_turn
+        if _slot_source is not None:  # a captured geometry chain owns its slots (layout_slots): the ring's are handed out again
+            return _slot_source()
         if _nh_ring is None:
             if L.lib().votenet_half_piece_rows() != PIECE:
                 raise L.VotenetError("libvotenet_hip.so was built for pieces of %d rows, the host code for %d" % (L.lib().votenet_half_piece_rows(), PIECE))
@@ -474,9 +501,18 @@ class HalfLayout:
             self._ev = None
             return
         self._slot = slot  # written by votenet_half_groups itself (pinned memory is mapped into the device's address space)
-        self._ev = torch.cuda.Event()
-        self._ev.record()
+        if torch.cuda.is_current_stream_capturing():
+            self._ev = None  # a layout inside a captured chain: rearm() gives it the event that follows each replay
+        else:
+            self._ev = torch.cuda.Event()
+            self._ev.record()
         self.nh = None
+
+    def rearm(self, ev):
+        """The layout's buffers have been (or are being) rewritten by a replay of the graph that holds the kernels that made it: forget
+        the count; ev = an event recorded after the replay."""
+        self.nh = None
+        self._ev = ev
 
     def tensors(self):
         return [t for t in (self.pos, self._hc, self._wh, self.nh_dev, self._geo, self._u8, self._order) if t is not None]

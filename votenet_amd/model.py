@@ -26,6 +26,41 @@ PROPOSAL_NUM = 256       # config.py:6
 PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
 
 
+GEOMETRY_GRAPHS = True  # prefetch_geometry replays the coordinate-only chain of a batch as ONE HIP graph (GeometryGraph) instead of enqueuing its ~50 launches
+GEOMETRY_RING = 3       # graphs (= sets of geometry buffers) per input shape: a prefetch may run two batches ahead of the step that consumes it
+
+
+class GeometryGraph:
+    """The coordinate-only chain of one batch -- four FPS + ball queries, the piece layouts and their compact rows, the proposal
+    layer's FPS, both three_nn: ~50 launches that depend on nothing but the points -- captured once on a prefetch stream and replayed
+    per batch.  The chain's buffers live in the graph's memory pool at fixed addresses: a replay overwrites the geometry of the batch
+    the graph served before, which is why a net keeps a ring of GEOMETRY_RING of them and tags every hand-out with the graph's
+    generation.  The piece counts still reach the host through mapped pinned ints (the graph's own), the layouts are re-armed with the
+    event that follows the replay."""
+
+    def __init__(self, net, x, side):
+        self.x = torch.empty_like(x)
+        self.slots = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.generation = 0
+        self.graph = torch.cuda.CUDAGraph()
+        g = {}
+        with M.layout_slots(self.slots), torch.cuda.graph(self.graph, stream=side):
+            net._geometry_chain(self.x, g, None, ("sa1", "sa2", "sa3", "sa4"))
+        self.g = g
+        self.layouts = [t for v in g.values() if isinstance(v, tuple) for t in v if isinstance(t, M.HalfLayout)]
+
+    def replay(self, x, side):
+        """On `side` (current): copy the points in, run the chain -> (g, ev) as _geometry_chain leaves them."""
+        self.x.copy_(x, non_blocking=True)
+        self.graph.replay()
+        done = torch.cuda.Event()
+        done.record(side)
+        self.generation += 1
+        for h in self.layouts:
+            h.rearm(done)
+        return self.g, {name: done for name in ("sa1", "sa2", "sa3", "sa4", "fp")}
+
+
 SPLIT_BF16 = True  # fused GEMMs on bf16 x 3 split operands (fp32-accurate products, six bf16 MFMAs per k-step; mlp.SplitImages)
 
 
@@ -64,12 +99,14 @@ class VoteNetHotPath:
             xyz = g[name][1]
             if name == "sa2":  # seeds = l2_xyz: the proposal layer's FPS can start as soon as they exist
                 g["prop_fps"] = P.tf_sampling.farthest_point_sample(self.proposal.npoint, xyz)
-            ev[name] = torch.cuda.Event()
-            ev[name].record()
+            if ev is not None:  # None: the chain is being captured (GeometryGraph) -- one event after the replay stands for all
+                ev[name] = torch.cuda.Event()
+                ev[name].record()
         g["fp1"] = P.FPModule.geometry(g["sa3"][1], g["sa4"][1])
         g["fp2"] = P.FPModule.geometry(g["sa2"][1], g["sa3"][1])
-        ev["fp"] = torch.cuda.Event()
-        ev["fp"].record()
+        if ev is not None:
+            ev["fp"] = torch.cuda.Event()
+            ev["fp"].record()
 
     @staticmethod
     def _hand_over(g, main):
@@ -104,7 +141,9 @@ class VoteNetHotPath:
         the proposal FPS, both three_nn) is launched now on a side stream, underneath this step's GEMMs -- FPS is a
         latency chain on one workgroup per scene (8 of 256 CUs), the one thing a step cannot hide from itself because
         everything waits for sa1's centres.  backbone(next_x) picks the result up; every step still computes one full
-        geometry.  Several batches may be in flight (two prefetch streams, used alternately): a forward-only pass is shorter
+        geometry.  With GEOMETRY_GRAPHS the chain is one graph launch (GeometryGraph) and its results live in one of GEOMETRY_RING
+        fixed sets of buffers: the geometry a pass picked up -- and a tape recorded on it -- is valid until GEOMETRY_RING - 1
+        further batches have been prefetched (a training step consumes its tape before the next one starts).  Several batches may be in flight (two prefetch streams, used alternately): a forward-only pass is shorter
         than one geometry chain, so it wants a lookahead of two.  The input pipeline knows the next batches ahead (the
         reference prefetches them through QueueInput, run.py:121-122)."""
         pool = self.__dict__.setdefault("_prefetched", {})
@@ -116,20 +155,52 @@ class VoteNetHotPath:
             self._pf_turn = 0
         side = self._pf_streams[self._pf_turn]
         self._pf_turn ^= 1
+        gg = self._geometry_graph(next_x, side)
         g, ev = {}, {}
         start = torch.cuda.Event()
-        start.record(main)  # next_x may have been produced on the main stream
+        start.record(main)  # next_x may have been produced on the main stream; a graph's buffers may still serve the step before
         with torch.cuda.stream(side):
             side.wait_event(start)
-            self._geometry_chain(next_x, g, ev, ("sa1", "sa2", "sa3", "sa4"))
-        self._hand_over(g, main)
-        while len(pool) >= 4:  # never picked up: drop the oldest
+            if gg is not None:
+                g, ev = gg.replay(next_x, side)
+            else:
+                self._geometry_chain(next_x, g, ev, ("sa1", "sa2", "sa3", "sa4"))
+        if gg is None:
+            self._hand_over(g, main)
+        while len(pool) >= (GEOMETRY_RING - 1 if gg is not None else 4):  # never picked up: drop the oldest
             pool.pop(next(iter(pool)))
-        pool[id(next_x)] = (next_x, next_x._version, g, ev)
+        pool[id(next_x)] = (next_x, next_x._version, g, ev, gg, gg.generation if gg is not None else 0)
+
+    def _geometry_graph(self, x, side):
+        """The next graph of the ring for inputs shaped like x (captured on first use), or None when the chain is enqueued launch by
+        launch: graphs off, the deterministic mode (its inverse indices ride on tensors as attributes), a capture under way."""
+        if not GEOMETRY_GRAPHS or M.DETERMINISTIC or torch.cuda.is_current_stream_capturing():
+            return None
+        key = (tuple(x.shape), x.dtype, P.HALF_GROUPS, P.ASSEMBLE_INLINE, self.proposal.npoint)
+        rings = self.__dict__.setdefault("_geometry_rings", {})
+        ring = rings.get(key)
+        if ring is None:
+            if len(rings) >= 2:  # another shape / configuration: the old graphs' buffers go
+                rings.clear()
+            ring = rings[key] = dict(graphs=[], turn=0)
+        if len(ring["graphs"]) < GEOMETRY_RING:
+            # the chain has run launch by launch before (sizes its scratch, loads its code objects): at least once per shape
+            if ring.setdefault("warm", 0) < 1:
+                ring["warm"] += 1
+                return None
+            ring["graphs"].append(GeometryGraph(self, x, side))
+            return ring["graphs"][-1]
+        gg = ring["graphs"][ring["turn"]]
+        ring["turn"] = (ring["turn"] + 1) % GEOMETRY_RING
+        if gg is getattr(self, "_geometry_current", None):  # its buffers serve the pass being enqueued (a lookahead beyond the ring)
+            return None
+        return gg
 
     def _take_prefetched(self, x):
         pf = self.__dict__.setdefault("_prefetched", {}).pop(id(x), None)
-        if pf is not None and pf[0] is x and pf[1] == x._version:
+        self._geometry_current = None
+        if pf is not None and pf[0] is x and pf[1] == x._version and (pf[4] is None or pf[4].generation == pf[5]):
+            self._geometry_current = pf[4]
             return pf[2], pf[3]
         return None
 
