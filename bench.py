@@ -661,7 +661,7 @@ def main():
                                                     "train step (fwd+bwd+Adam, fixed cotangents)")
                                                    if workload == "train" else "forward", B, n, args.scene)
                                     + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
-                                       "three_nn) runs on a side stream underneath the current step" if pipeline else "")),
+                                       "three_nn) runs on a side stream underneath the current step, replayed as one HIP graph (model.GeometryGraph)" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate; products of the fused forward and input-gradient GEMMs as bf16 x 3 "
                                "split operands (exact split, 6 of the 9 cross terms: what is dropped is < 2^-23 of a product), "

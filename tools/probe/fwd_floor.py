@@ -6,6 +6,7 @@ import torch
 from votenet_amd import model as VM, synth
 dev = torch.device("cuda:0")
 xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in (1000, 500000, 900000)]
+VM.GEOMETRY_GRAPHS = False  # the geometry of a batch is computed once, launch by launch, and handed to every step that uses it
 net = VM.VoteNetHotPath(dev, seed=0)
 def piped(k):
     for i in range(k):

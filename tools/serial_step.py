@@ -10,6 +10,7 @@ dev = torch.device("cuda:0")
 seeds = (1000, 500000, 900000)
 xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in seeds]
 gts = [VL.gt_to_device(synth.room_gt(8, 20480, s), dev) for s in seeds]
+VM.GEOMETRY_GRAPHS = False  # the geometry of a batch is computed once, launch by launch, and handed to every step that uses it
 net = VM.VoteNetHotPath(dev, seed=0)
 net.overlap_wgrad = False
 for x in xs:

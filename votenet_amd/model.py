@@ -173,9 +173,12 @@ class VoteNetHotPath:
 
     def _geometry_graph(self, x, side):
         """The next graph of the ring for inputs shaped like x (captured on first use), or None when the chain is enqueued launch by
-        launch: graphs off, the deterministic mode (its inverse indices ride on tensors as attributes), a capture under way."""
+        launch: graphs off, the deterministic mode (its inverse indices ride on tensors as attributes), a capture under way, per-launch
+        profiling events switched on."""
         if not GEOMETRY_GRAPHS or M.DETERMINISTIC or torch.cuda.is_current_stream_capturing():
             return None
+        if P.tf_sampling.PROFILE_EVENTS is not None or P.tf_grouping.PROFILE_EVENTS is not None:
+            return None  # HIP events around single launches of the chain are wanted (bench.py's roofline legs): they need the launches
         key = (tuple(x.shape), x.dtype, P.HALF_GROUPS, P.ASSEMBLE_INLINE, self.proposal.npoint)
         rings = self.__dict__.setdefault("_geometry_rings", {})
         ring = rings.get(key)
