@@ -291,10 +291,11 @@ def main():
         from votenet_amd import pointnet2
         pointnet2.POOL_GRAM_BACKWARD = False
     tf_sampling.PROFILE_EVENTS = None
-    # setup, before the W warm-up steps the caller asked for: three steps that create the streams, fill the caching allocator's
-    # pools for all three rotating batches and start the geometry pipeline (one-time work of the process, like loading the
-    # library; reported as "setup_steps")
-    SETUP_STEPS = 3
+    # setup, before the W warm-up steps the caller asked for: steps that create the streams, fill the caching allocator's
+    # pools for all three rotating batches and start the geometry pipeline -- one launch-by-launch chain, then the capture of the ring
+    # of geometry graphs (model.GEOMETRY_RING, a device synchronise each; the forward workload prefetches two batches per call) --
+    # one-time work of the process, like loading the library; reported as "setup_steps"
+    SETUP_STEPS = 6
     for _ in range(SETUP_STEPS):
         step()
     for _ in range(args.warmup):

@@ -17,7 +17,12 @@
  * Ownership is the reference's: the caller owns every buffer, launchers never allocate,
  * gradient buffers must be zeroed by the caller (tf_sampling.cpp:174, tf_grouping.cpp:204,
  * tf_interpolate.cpp:258).  All tensors are dense, row-major, fp32 / int32.
- * Calls are asynchronous with respect to the host and stateless (re-entrant).
+ * Calls are asynchronous with respect to the host and stateless (re-entrant).  No launcher synchronises with the device, allocates
+ * device memory or copies from pageable host memory, so a sequence of calls on one stream can be captured into a HIP graph
+ * (hipStreamBeginCapture ... hipStreamEndCapture) and replayed over the same buffers: the host side does that with the whole
+ * coordinate-only chain of a batch (votenet_farthest_point_sample, votenet_gather_point, votenet_query_ball_point*, votenet_three_nn,
+ * votenet_half_groups, votenet_assemble_rows_half / votenet_narrow_rows_half, votenet_half_sort_rows: votenet_amd/model.py,
+ * GeometryGraph).  votenet_half_groups writes its count into a mapped pinned host int (nh_host): that works from a graph too.
  *
  * libvotenet_hip.so additionally exports the reference's launcher names with their exact
  * C++ signatures (farthestpointsamplingLauncher, gatherpointLauncher, scatteraddpointLauncher,
