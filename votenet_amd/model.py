@@ -44,7 +44,8 @@ class GeometryGraph:
         self.generation = 0
         self.graph = torch.cuda.CUDAGraph()
         g = {}
-        with M.layout_slots(self.slots), torch.cuda.graph(self.graph, stream=side):
+        # thread_local: a process group's watchdog thread (RCCL, one rank per GPU) queries its events while this thread captures
+        with M.layout_slots(self.slots), torch.cuda.graph(self.graph, stream=side, capture_error_mode="thread_local"):
             net._geometry_chain(self.x, g, None, ("sa1", "sa2", "sa3", "sa4"))
         self.g = g
         self.layouts = [t for v in g.values() if isinstance(v, tuple) for t in v if isinstance(t, M.HalfLayout)]
