@@ -550,9 +550,10 @@ int votenet_group_linear_backward_csr(int b, int n, int m, int nsample, int cout
  * tf.clip_by_average_norm(g, clip) = g*clip/max(||g||_2/numel, clip) (skipped when clip <= 0), then
  * Adam(lr, beta1, beta2, eps) with bias correction for `step` (1-based).  seg: 2*ntensors element
  * offsets (device, int64), [start, end) of each tensor inside the bucket; g is pre-multiplied by grad_scale
- * (1/world_size after a summing all-reduce).  sumsq_scratch: 8 * ntensors floats (eight ordered partial sums per tensor:
- * the result is bit-reproducible, so data-parallel replicas that hold the same all-reduced gradient stay identical).
+ * (1/world_size after a summing all-reduce).  sumsq_scratch: VOTENET_SUMSQ_SLICES * ntensors floats (that many partial sums per
+ * tensor, added in order: the result is bit-reproducible, so data-parallel replicas that hold the same all-reduced gradient stay identical).
  * Adam in TensorFlow's form: lr_t = lr sqrt(1 - beta2^t) / (1 - beta1^t), p -= lr_t m / (sqrt(v) + eps). */
+#define VOTENET_SUMSQ_SLICES 32
 int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scratch, float *p, const float *g, float *m, float *v,
                       float lr, float beta1, float beta2, float eps, int step, float grad_scale, float clip_avg_norm,
                       void *stream);

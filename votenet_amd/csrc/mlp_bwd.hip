@@ -574,23 +574,34 @@ __global__ __launch_bounds__(256) void group_concat_grad_kernel(long groups, int
 }
 
 // ---------------------------------------------------------------- optimizer
-// sum of squares of every tensor's gradient segment: grid (8 slices, ntensors) -> out[tensor * 8 + slice]; the optimizer adds
-// the eight partials in slice order (no atomics: every data-parallel replica must compute bit-identical clip factors from
-// the same all-reduced gradient, or the replicas drift apart)
+// sum of squares of every tensor's gradient segment: grid (kSumsqSlices slices, ntensors) -> out[tensor * kSumsqSlices + slice]; the
+// optimizer adds the partials in slice order (no atomics: every data-parallel replica must compute bit-identical clip factors from
+// the same all-reduced gradient, or the replicas drift apart).  32 slices and four loads in flight per thread: the largest tensors
+// (512 x 256) bound the launch -- 27 -> see profiles (8 slices, one load at a time)
+constexpr int kSumsqSlices = VOTENET_SUMSQ_SLICES;
 __global__ __launch_bounds__(256) void seg_sumsq_kernel(const float *__restrict__ g, const long *__restrict__ seg,
                                                         float *__restrict__ out)
 {
     __shared__ float sh[256];
     const long a = seg[2 * blockIdx.y], b = seg[2 * blockIdx.y + 1];
-    float s = 0;
-    for (long i = a + (long)blockIdx.x * 256 + threadIdx.x; i < b; i += 256L * gridDim.x) s += g[i] * g[i];
-    sh[threadIdx.x] = s;
+    const long step = 256L * gridDim.x;
+    float s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    long i = a + (long)blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * step < b; i += 4 * step) {
+        const float v0 = g[i], v1 = g[i + step], v2 = g[i + 2 * step], v3 = g[i + 3 * step];
+        s0 += v0 * v0;
+        s1 += v1 * v1;
+        s2 += v2 * v2;
+        s3 += v3 * v3;
+    }
+    for (; i < b; i += step) s0 += g[i] * g[i];
+    sh[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
         if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
         __syncthreads();
     }
-    if (threadIdx.x == 0) out[blockIdx.y * 8 + blockIdx.x] = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.y * kSumsqSlices + blockIdx.x] = sh[0];
 }
 
 // tf.clip_by_average_norm(g, clip): g * clip / max(||g||/numel, clip)   (model.py:249), then tf.train.AdamOptimizer
@@ -605,7 +616,7 @@ __global__ void clip_adam_kernel(const long *__restrict__ seg, const float *__re
     if (clip > 0.0f) {
         float ss = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 8; t++) ss += sumsq[blockIdx.y * 8 + t];
+        for (int t = 0; t < kSumsqSlices; t++) ss += sumsq[blockIdx.y * kSumsqSlices + t];
         const float avg = sqrtf(ss) * gscale / (float)(b - a);
         factor = gscale * clip / (avg > clip ? avg : clip);
     }
@@ -1076,10 +1087,10 @@ extern "C" int votenet_clip_adam(int ntensors, const long *seg, float *sumsq_scr
     VN_REQUIRE(seg && sumsq_scratch && p && g && m && v, "clip_adam: null buffer");
     hipStream_t st = as_stream(stream);
     if (clip_avg_norm > 0.0f) {
-        hipLaunchKernelGGL(seg_sumsq_kernel, dim3(8, ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
+        hipLaunchKernelGGL(seg_sumsq_kernel, dim3(kSumsqSlices, ntensors), dim3(256), 0, st, g, seg, sumsq_scratch);
     }
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3(16, ntensors), dim3(256), 0, st, seg, sumsq_scratch, p, g, m, v, lr, beta1, beta2, eps,
+    hipLaunchKernelGGL(clip_adam_kernel, dim3(64, ntensors), dim3(256), 0, st, seg, sumsq_scratch, p, g, m, v, lr, beta1, beta2, eps,
                        bc1, bc2, grad_scale, clip_avg_norm);
     return check_launch("clip_adam");
 }

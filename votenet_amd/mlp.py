@@ -1309,8 +1309,13 @@ def row_segments(rows, segs):
         L.check(L.lib().votenet_row_segments(rows, len(segs), arr, L.stream_ptr()))
 
 
+SUMSQ_SLICES = 32  # VOTENET_SUMSQ_SLICES (include/votenet_hip.h): partial sums per tensor in votenet_clip_adam's scratch
+
+
 def clip_adam(seg, sumsq, p, g, m, v, lr, step, grad_scale=1.0, clip=0.5, beta1=0.9, beta2=0.999, eps=1e-8):
     """model.py:240-250: per-tensor clip_by_average_norm(g, 0.5) then Adam(lr) on the flat bucket."""
+    if sumsq.numel() < SUMSQ_SLICES * (seg.numel() // 2):
+        raise L.InvalidArgumentError("clip_adam: the scratch holds %d floats, %d tensors need %d" % (sumsq.numel(), seg.numel() // 2, SUMSQ_SLICES * (seg.numel() // 2)))
     with L.device_guard(p.device):
         L.check(L.lib().votenet_clip_adam(seg.numel() // 2, L.ptr(seg), L.ptr(sumsq), L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v),
                                           float(lr), float(beta1), float(beta2), float(eps), int(step), float(grad_scale),

@@ -506,7 +506,7 @@ class VoteNetHotPath:
             a = (s.views[name].data_ptr() - base) // 4
             seg += [a, a + math.prod(shape)]
         self._seg = torch.tensor(seg, dtype=torch.int64, device=self.device)
-        self._sumsq = torch.zeros(8 * (len(seg) // 2), dtype=torch.float32, device=self.device)  # 8 ordered partials per tensor
+        self._sumsq = torch.zeros(M.SUMSQ_SLICES * (len(seg) // 2), dtype=torch.float32, device=self.device)  # ordered partials per tensor
         self._m = torch.zeros_like(s.flat)
         self._v = torch.zeros_like(s.flat)
         self._step = 0
