@@ -101,6 +101,9 @@ int votenet_query_ball_point_indexed(int b, int n, int m, float radius, int nsam
  * the row uninitialised).  Requires radius > 0, nsample > 0 (tf_grouping.cpp:71,74). */
 int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                              const float *xyz2, int *idx, int *pts_cnt, void *stream);
+/* Measurement hook: which kernel serves n <= 2048 (0 = by cloud size: 16 waves, one super-chunk; 4 = four waves x eight groups;
+ * 16 = sixteen waves x eight groups).  Same indices and counts in every form. */
+void votenet_debug_ball_query_small(int form);
 
 /* Host helper (no GPU work): the squared-distance threshold the ball-query kernel compares
  * against, T(r) = smallest fp32 with sqrtf(T) >= r, so that  s < T(r)  <=>  sqrtf(s) < r

@@ -309,7 +309,8 @@ def test_grouping_demo_golden(ops, dev, golden):
 
 @pytest.mark.parametrize("b,n,m,r,k", [(1, 1, 1, 0.5, 4), (2, 63, 5, 0.3, 8), (2, 700, 90, 0.2, 16), (1, 2048, 512, 0.2, 32),
                                        (3, 513, 64, 0.4, 64), (1, 100, 7, 0.05, 8), (2, 64, 64, 2.0, 5), (1, 2049, 65, 0.1, 100),
-                                       (1, 4097, 130, 0.25, 64), (2, 20480, 256, 0.04, 64), (1, 9000, 64, 0.3, 64)])
+                                       (1, 4097, 130, 0.25, 64), (2, 20480, 256, 0.04, 64), (1, 9000, 64, 0.3, 64), (2, 512, 256, 0.3, 64),
+                                       (8, 1024, 256, 0.3, 64), (1, 1025, 70, 0.2, 16), (2, 1024, 100, 0.02, 64)])
 def test_ball_query_vs_oracle(ops, dev, O, b, n, m, r, k):
     rng = np.random.default_rng(n + m)
     xyz1 = rng.random((b, n, 3), dtype=np.float32)
@@ -318,6 +319,27 @@ def test_ball_query_vs_oracle(ops, dev, O, b, n, m, r, k):
     oi, oc = O.query_ball_point(r, k, xyz1, xyz2)
     assert (N(cnt) == oc).all()
     assert (N(idx) == oi).all()  # includes all-zero rows for queries with no neighbour
+
+
+@pytest.mark.parametrize("n", [33, 512, 777, 1024, 2048])
+def test_ball_query_small_cloud_forms_agree(ops, dev, hiplib, n):
+    """n <= 2048: sixteen waves with the cloud as one super-chunk (default), the four-wave kernel and sixteen waves x eight groups give
+    the same indices and counts (votenet_debug_ball_query_small)."""
+    rng = np.random.default_rng(n)
+    xyz1 = T(rng.random((3, n, 3), dtype=np.float32), dev)
+    xyz2 = T(rng.random((3, 130, 3), dtype=np.float32), dev)
+    hook = hiplib.votenet_debug_ball_query_small
+    hook.restype = None
+    got = []
+    try:
+        for form in (0, 4, 16):
+            hook(form)
+            idx, cnt = ops.g.query_ball_point(0.25, 64, xyz1, xyz2)
+            got.append((N(idx), N(cnt)))
+    finally:
+        hook(0)
+    for idx, cnt in got[1:]:
+        assert (idx == got[0][0]).all() and (cnt == got[0][1]).all()
 
 
 @pytest.mark.parametrize("b,n,m,r,k,scale", [(2, 4097, 130, 0.25, 64, 1.0), (1, 9000, 257, 0.3, 16, 2.0), (2, 20480, 500, 0.2, 64, 5.0),

@@ -22,15 +22,17 @@
 
 namespace votenet {
 
-constexpr int BQ_G = 8; // 32-candidate groups per wave per super-chunk
 
-template <int NW>
+// G = 32-candidate groups per wave per super-chunk: NW * G * 32 candidates between barriers.  Small clouds (the levels below sa1,
+// the proposal module's votes: n <= 2048) take 16 waves and a G that makes the cloud ONE super-chunk -- a wave's share of the scan is
+// a serial chain of scalar loads (4 waves x 8 groups at n = 1024: 26 us for 8 x 256 queries; 16 x 2: 13 us, tools/probe/bq_small_time.py)
+template <int NW, int G = 8>
 __global__ __launch_bounds__(NW * 64) void ball_query_kernel(int n, int m, float thr, int nsample,
                                                               const float *__restrict__ xyz1,
                                                               const float *__restrict__ xyz2, int *__restrict__ idx,
                                                               int *__restrict__ pts_cnt)
 {
-    constexpr int WPQ = NW * BQ_G;       // mask words per query per super-chunk
+    constexpr int WPQ = NW * G;          // mask words per query per super-chunk
     constexpr int CHUNK = WPQ * 32;      // candidates per super-chunk
     constexpr int QPW = 64 / NW;         // queries finalised by each wave
     constexpr int LPQ = WPQ / 64 > 0 ? WPQ / 64 : 1; // mask words per lane in the pop phase (NW=16: 2, NW=4: 1 with half the lanes idle)
@@ -61,8 +63,8 @@ __global__ __launch_bounds__(NW * 64) void ball_query_kernel(int n, int m, float
     for (int base = 0; base < n; base += CHUNK) {
         // ---- phase 1: hit masks, lane = query, candidates uniform across the wave
 #pragma unroll 1
-        for (int g = 0; g < BQ_G; g++) {
-            const int wbase = __builtin_amdgcn_readfirstlane(base + (w * BQ_G + g) * 32);
+        for (int g = 0; g < G; g++) {
+            const int wbase = __builtin_amdgcn_readfirstlane(base + (w * G + g) * 32);
             unsigned mask = 0;
             if (wbase < n) {
                 const int valid = (n - wbase) < 32 ? (n - wbase) : 32;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(NW * 64) void ball_query_kernel(int n, int m, float
                     }
                 }
             }
-            masks[lane][w * BQ_G + g] = mask;
+            masks[lane][w * G + g] = mask;
         }
         __syncthreads();
         // ---- phase 2: pop masks in candidate order, wave w finalises queries w*QPW .. +QPW-1
@@ -217,6 +219,9 @@ using namespace votenet;
 
 extern "C" float votenet_ball_threshold(float radius) { return ball_threshold(radius); }
 
+static int g_bq_small = 0; // votenet_debug_ball_query_small: 0 = by cloud size, 4 = the four-wave kernel, 16 = sixteen waves x eight groups
+extern "C" void votenet_debug_ball_query_small(int form) { g_bq_small = form; }
+
 extern "C" int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                                         const float *xyz2, int *idx, int *pts_cnt, void *stream)
 {
@@ -230,10 +235,16 @@ extern "C" int votenet_query_ball_point(int b, int n, int m, float radius, int n
     const float thr = (radius <= 1e-20f) ? -1.0f : ball_threshold(radius);
     hipStream_t st = as_stream(stream);
     dim3 grid((m + 63) / 64, b);
-    if (n > 2048)
+    if (n > 2048 || g_bq_small == 16)
         hipLaunchKernelGGL((ball_query_kernel<16>), grid, dim3(1024), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
-    else
+    else if (g_bq_small == 4)
         hipLaunchKernelGGL((ball_query_kernel<4>), grid, dim3(256), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
+    else if (n > 1024)
+        hipLaunchKernelGGL((ball_query_kernel<16, 4>), grid, dim3(1024), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
+    else if (n > 512)
+        hipLaunchKernelGGL((ball_query_kernel<16, 2>), grid, dim3(1024), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
+    else
+        hipLaunchKernelGGL((ball_query_kernel<16, 1>), grid, dim3(1024), 0, st, n, m, thr, nsample, xyz1, xyz2, idx, pts_cnt);
     return check_launch("query_ball_point");
 }
 
