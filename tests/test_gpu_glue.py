@@ -27,6 +27,34 @@ def test_row_segments_concat_slice_pad_add(hiplib, dev):
         M.row_segments(rows, [(vx.t(), xyz.t(), None)])          # not row-major
 
 
+@pytest.mark.parametrize("rows,widths", [(1, [3]), (7, [3, 3]), (1000, [6]), (4099, [5, 128, 1]), (16384, [256, 256]), (513, [255]),
+                                         (300, [256]), (64, [700, 300, 24]), (33, [1024, 8]), (8192, [3, 256, 61])])
+def test_row_segments_layouts(hiplib, dev, rows, widths):
+    """Few columns, many columns, row counts that are no multiple of anything; with and without the second source; zero segments;
+    the columns outside the segments are left alone."""
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(rows + sum(widths))
+    total = sum(widths)
+    src = torch.randn(rows, total + 5, generator=g).to(dev)
+    add = torch.randn(rows, total + 2, generator=g).to(dev)
+    dst = torch.full((rows, total + 3), -1.0, device=dev)
+    segs, exp, o = [], dst.clone(), 0
+    for i, w in enumerate(widths):
+        d = dst[:, 1 + o:1 + o + w]
+        if i % 3 == 2:
+            segs.append((d, None, None))
+            exp[:, 1 + o:1 + o + w] = 0.0
+        elif i % 3 == 1:
+            segs.append((d, src[:, 5 + o:5 + o + w], add[:, o:o + w]))
+            exp[:, 1 + o:1 + o + w] = src[:, 5 + o:5 + o + w] + add[:, o:o + w]
+        else:
+            segs.append((d, src[:, 5 + o:5 + o + w], None))
+            exp[:, 1 + o:1 + o + w] = src[:, 5 + o:5 + o + w]
+        o += w
+    M.row_segments(rows, segs)
+    assert torch.equal(dst, exp)  # the columns outside the segments keep their -1
+
+
 def test_add_rows_takes_a_column_slice(hiplib, dev):
     from votenet_amd import pointnet2 as P
     g = torch.Generator().manual_seed(1)
