@@ -304,11 +304,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events (recorded on the launch stream) around every FPS and ball-query launch of the FIRST TWO timed steps only (`roofline`:
+    # HIP events (recorded on the launch stream) around every FPS and ball-query launch of one or two timed steps only (`roofline`:
     # the sa1 FPS; those steps enqueue the geometry chain launch by launch instead of replaying its graph, ~0.3 ms each).  The events
     # around every MFMA GEMM launch (`roofline_mlp`: ~150 pairs per step, 1.4 ms of host time -- the step turns host-bound and takes
     # 6-7 ms) are taken in two EXTRA steps right after the timed region: they would cost the headline 3-6 %
-    prof_steps = min(2 if args.steps >= 20 else 1, args.steps)  # short runs: one instrumented step
+    prof_steps = min(2 if args.steps >= 40 else 1, args.steps)  # short runs: one instrumented step
     gemm_steps = 2
     # ... taken in the MIDDLE of the timed region, where the host runs ~1.3 ms ahead of the GPU and absorbs most of the 0.6 ms the
     # launch-by-launch chain costs it (right after the barrier the queue is empty and the same steps took 6.1 and 4.9 ms)
