@@ -1,0 +1,80 @@
+"""CPU: the bookkeeping around model.GeometryGraph (which graph of the ring serves the next prefetch, when the chain falls back to
+launches, which hand-outs are trusted) with a stand-in for the graph itself -- the captures and replays proper are GPU tests
+(tests/test_gpu_model.py::test_geometry_graph_replays_are_the_launch_by_launch_chain)."""
+import types
+
+import pytest
+import torch
+
+from votenet_amd import mlp as M
+from votenet_amd import model as VM
+from votenet_amd import pointnet2 as P
+
+
+class _Graph:
+    made = 0
+
+    def __init__(self, net, x, side):
+        _Graph.made += 1
+        self.generation = 0
+
+
+@pytest.fixture
+def net(monkeypatch):
+    monkeypatch.setattr(VM, "GeometryGraph", _Graph)
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", True)
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+    _Graph.made = 0
+    n = types.SimpleNamespace(proposal=types.SimpleNamespace(npoint=256))
+    n.pick = lambda x: VM.VoteNetHotPath._geometry_graph(n, x, None)
+    return n
+
+
+def test_ring_order_and_warm_up(net):
+    x = torch.zeros(2, 64, 3)
+    assert net.pick(x) is None                      # the first chain of a shape runs launch by launch (sizes the library's scratch)
+    a, b, c = net.pick(x), net.pick(x), net.pick(x)  # then one capture per ring slot
+    assert _Graph.made == VM.GEOMETRY_RING == 3 and len({id(a), id(b), id(c)}) == 3
+    assert [net.pick(x) for _ in range(6)] == [a, b, c, a, b, c]  # least recently used first
+    assert _Graph.made == 3
+
+
+def test_the_graph_under_the_running_pass_is_skipped(net):
+    x = torch.zeros(2, 64, 3)
+    net.pick(x)
+    a, b, c = net.pick(x), net.pick(x), net.pick(x)
+    net._geometry_current = a
+    assert net.pick(x) is None and net.pick(x) is b and net.pick(x) is c  # a's turn passes: that prefetch runs launch by launch
+    net._geometry_current = None
+    assert net.pick(x) is a
+
+
+def test_fallbacks_and_configuration_changes(net, monkeypatch):
+    x, y = torch.zeros(2, 64, 3), torch.zeros(2, 128, 3)
+    net.pick(x)
+    a = net.pick(x)
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", False)
+    assert net.pick(x) is None
+    monkeypatch.setattr(VM, "GEOMETRY_GRAPHS", True)
+    monkeypatch.setattr(M, "DETERMINISTIC", True)
+    assert net.pick(x) is None                       # inverse indices ride on tensors as attributes: launches
+    monkeypatch.setattr(M, "DETERMINISTIC", False)
+    monkeypatch.setattr(P.tf_sampling, "PROFILE_EVENTS", [])
+    assert net.pick(x) is None                       # per-launch events wanted
+    monkeypatch.setattr(P.tf_sampling, "PROFILE_EVENTS", None)
+    assert net.pick(y) is None and net.pick(y) is not a          # another shape: its own warm-up and ring
+    assert len(net._geometry_rings) == 2
+    monkeypatch.setattr(P, "HALF_GROUPS", not P.HALF_GROUPS)     # a third configuration: the old rings (and their buffers) go
+    assert net.pick(x) is None and len(net._geometry_rings) == 1
+
+
+def test_stale_hand_outs_are_not_trusted(net):
+    x = torch.zeros(2, 64, 3)
+    g = _Graph(None, x, None)
+    g.generation = 5
+    net._prefetched = {id(x): (x, x._version, {"sa1": 1}, {"sa1": 2}, g, 5)}
+    assert VM.VoteNetHotPath._take_prefetched(net, x) == ({"sa1": 1}, {"sa1": 2}) and net._geometry_current is g
+    net._prefetched = {id(x): (x, x._version, {"sa1": 1}, {"sa1": 2}, g, 4)}  # the graph has served another batch since
+    assert VM.VoteNetHotPath._take_prefetched(net, x) is None and net._geometry_current is None
+    net._prefetched = {id(x): (x, x._version - 1 if x._version else -1, {}, {}, None, 0)}  # the tensor was written since
+    assert VM.VoteNetHotPath._take_prefetched(net, x) is None
