@@ -78,3 +78,15 @@ def test_stale_hand_outs_are_not_trusted(net):
     assert VM.VoteNetHotPath._take_prefetched(net, x) is None and net._geometry_current is None
     net._prefetched = {id(x): (x, x._version - 1 if x._version else -1, {}, {}, None, 0)}  # the tensor was written since
     assert VM.VoteNetHotPath._take_prefetched(net, x) is None
+
+
+def test_changing_shapes_turn_the_graphs_off(net):
+    with pytest.warns(UserWarning, match="launch by launch"):
+        for i in range(4 + 2 * VM.GEOMETRY_MAX_EVICTIONS):  # two shapes are kept side by side: every second new one evicts
+            x = torch.zeros(1, 32 + i, 3)
+            net.pick(x)
+            net.pick(x)
+    assert net._geometry_graphs_off and net.pick(torch.zeros(1, 32, 3)) is None
+    made = _Graph.made
+    net.pick(torch.zeros(1, 32, 3))
+    assert _Graph.made == made

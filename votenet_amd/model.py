@@ -27,6 +27,7 @@ PROPOSAL_OUT = 5 + 2 * NH + 4 * NS + NC  # model.py:91 -> 79
 
 
 GEOMETRY_GRAPHS = True  # prefetch_geometry replays the coordinate-only chain of a batch as ONE HIP graph (GeometryGraph) instead of enqueuing its ~50 launches
+GEOMETRY_MAX_EVICTIONS = 8  # a net whose input shape keeps changing stops capturing (two shapes / configurations are kept side by side)
 GEOMETRY_RING = 3       # graphs (= sets of geometry buffers) per input shape: a prefetch may run two batches ahead of the step that consumes it
 
 
@@ -176,7 +177,7 @@ class VoteNetHotPath:
         """The next graph of the ring for inputs shaped like x (captured on first use), or None when the chain is enqueued launch by
         launch: graphs off, the deterministic mode (its inverse indices ride on tensors as attributes), a capture under way, per-launch
         profiling events switched on."""
-        if not GEOMETRY_GRAPHS or M.DETERMINISTIC or torch.cuda.is_current_stream_capturing():
+        if not GEOMETRY_GRAPHS or M.DETERMINISTIC or getattr(self, "_geometry_graphs_off", False) or torch.cuda.is_current_stream_capturing():
             return None
         if P.tf_sampling.PROFILE_EVENTS is not None or P.tf_grouping.PROFILE_EVENTS is not None:
             return None  # HIP events around single launches of the chain are wanted (bench.py's roofline legs): they need the launches
@@ -186,6 +187,13 @@ class VoteNetHotPath:
         if ring is None:
             if len(rings) >= 2:  # another shape / configuration: the old graphs' buffers go
                 rings.clear()
+                self._geometry_evictions = getattr(self, "_geometry_evictions", 0) + 1
+                if self._geometry_evictions > GEOMETRY_MAX_EVICTIONS:  # shapes keep changing: every capture is a device synchronise
+                    import warnings
+                    warnings.warn("VoteNetHotPath: the input shape / configuration changed %d times: the prefetched geometry chain is "
+                                  "enqueued launch by launch from now on (model.GEOMETRY_GRAPHS)" % self._geometry_evictions)
+                    self._geometry_graphs_off = True
+                    return None
             ring = rings[key] = dict(graphs=[], turn=0)
         if len(ring["graphs"]) < GEOMETRY_RING:
             # the chain has run launch by launch before (sizes its scratch, loads its code objects): at least once per shape
