@@ -537,8 +537,16 @@ int votenet_group_concat_grad(int b, int n, int c, int m, int nsample, const flo
  * built ahead (stable sort); one thread per (point, channel) then sums in that fixed order.
  * out[p, :] = sum over t in [offsets[p], offsets[p+1]) of weight[order[t]] * src[order[t] / div, :]   (weight may be NULL;
  * div = slots per source row: 1 for a grouped tensor (b*m*k rows), 3 for three_interpolate's (b*n, 3) taps). */
+/* The inverse itself for a small grouping, in one launch: idx (b, slots) int32 with values in [0, m), m <= 8192 targets per scene ->
+ * offsets (b*m + 1), order (b*slots): the slots (flat positions of idx) that reference target p are order[offsets[p]:offsets[p+1]],
+ * ascending.  (three_nn's taps: slots = 3 n.  Larger groupings are inverted by the caller, e.g. with a stable sort.) */
+int votenet_inverse_index(int b, int slots, int m, const int *idx, int *order, int *offsets, void *stream);
 int votenet_csr_gather_sum(long npts, int c, const float *src, const int *order, const int *offsets, const float *weight,
                            int div, float *out, void *stream);
+/* The same with the source rows src_pitch floats apart (a column slice of a wider row-major tensor, read in place: the gradient of an
+ * FP layer's concat is [d interpolated | d skip], utils.py:286). */
+int votenet_csr_gather_sum_pitched(long npts, int c, const float *src, long src_pitch, const int *order, const int *offsets,
+                                   const float *weight, int div, float *out, void *stream);
 /* votenet_group_linear_backward over the inverse index: s_points is written (not accumulated: no zero fill), the xyz rows of
  * the weight gradient go through per-workgroup partials in scratch (votenet_group_linear_backward_scratch_floats) + an
  * ordered reduction.  Bit-reproducible. */

@@ -165,3 +165,42 @@ def test_a_train_step_issues_no_tensor_library_kernels_on_its_chain(hiplib, dev)
     assert all(ops[k] <= allowed[k] for k in ops), sorted(ops.items())
     for gone in ("aten.cat.default", "aten.add.Tensor", "aten.add_.Tensor", "aten.constant_pad_nd.default", "aten.fill_.Scalar"):
         assert gone not in ops
+
+
+@pytest.mark.parametrize("b,rows,k,m", [(1, 7, 3, 5), (8, 1024, 3, 512), (3, 777, 3, 2049), (2, 4096, 3, 8192), (4, 100, 1, 1), (2, 512, 3, 4000)])
+def test_inverse_index_kernel_is_the_stable_sort(hiplib, dev, b, rows, k, m):
+    """votenet_inverse_index (one launch, one workgroup per scene) against the tensor-library construction it replaces for small
+    groupings: the same offsets and the same ascending lists, targets without any slot included."""
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(b * rows + m)
+    idx = torch.randint(0, m, (b, rows, k), generator=g, dtype=torch.int32)
+    if m > 4:
+        idx[idx == 3] = 2  # a target nobody references
+    idx = idx.to(dev)
+    order, offsets = M.inverse_index(idx, m)
+    slots = idx.numel()
+    flat = (idx.reshape(b, -1).long() + (torch.arange(b, device=dev) * m)[:, None]).reshape(-1)
+    keys, _ = torch.sort(flat * slots + torch.arange(slots, device=dev))
+    pts = torch.div(keys, slots, rounding_mode="floor")
+    assert torch.equal(order.long(), keys - pts * slots)
+    assert torch.equal(offsets.long(), torch.searchsorted(pts, torch.arange(b * m + 1, device=dev)))
+
+
+def test_three_interpolate_grad_gather_form_on_a_column_slice(hiplib, dev):
+    """tf_interpolate.GATHER_GRAD: the gradient as a gather-sum over the taps' inverse index, reading a column slice of a wider tensor in
+    place (votenet_csr_gather_sum_pitched), against the scatter-add with atomics."""
+    from votenet_amd import mlp as M, tf_interpolate as TI
+    g = torch.Generator().manual_seed(3)
+    b, n, m, c = 3, 300, 70, 200
+    x1, x2 = torch.rand(b, n, 3, generator=g).to(dev), torch.rand(b, m, 3, generator=g).to(dev)
+    dist, idx = TI.three_nn(x1, x2)
+    w = TI.three_nn_weights(dist)
+    wide = torch.randn(b, n, c + 56, generator=g).to(dev)
+    ref = TI.three_interpolate_grad_raw(m, idx, w, wide[:, :, :c])          # no inverse attached: atomics
+    M.attach_inverse(idx, m, always=True)
+    got = TI.three_interpolate_grad_raw(m, idx, w, wide[:, :, :c])          # the slice in place
+    got2 = TI.three_interpolate_grad_raw(m, idx, w, wide[:, :, :c].contiguous())
+    assert torch.equal(got, got2)
+    assert (got - ref).abs().max() <= 1e-5 * ref.abs().max()
+    again = TI.three_interpolate_grad_raw(m, idx, w, wide[:, :, :c])
+    assert torch.equal(got, again)                                          # one fixed summation order

@@ -144,7 +144,9 @@ _SIGS.update({
                                       + [ctypes.c_float, ctypes.c_int, _c_f, _c_f, ctypes.POINTER(CoefTail), ctypes.c_void_p],
     "votenet_narrow_wgrad_first": [ctypes.c_int, ctypes.c_int] + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_group_concat_grad": [ctypes.c_int] * 5 + [_c_f] * 7 + [ctypes.c_void_p],
+    "votenet_inverse_index": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_csr_gather_sum": [ctypes.c_long, ctypes.c_int] + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_csr_gather_sum_pitched": [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_long] + [_c_f] * 3 + [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_group_linear_backward_csr": [ctypes.c_int] * 5 + [_c_f] * 8 + [ctypes.c_int] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_rows_dot3": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_clip_adam": [ctypes.c_int] + [_c_f] * 6 + [ctypes.c_float] * 4 + [ctypes.c_int, ctypes.c_float, ctypes.c_float,

@@ -19,7 +19,7 @@ namespace votenet {
 void wgrad_reduce(int nslice, long pstride, long e0, long e1, const float *part, float *dw, hipStream_t st); // mlp_bwd.hip
 
 // thread = (point lane, channel): TPP = threads per point (>= c, a divisor of 256)
-__global__ __launch_bounds__(256) void csr_gather_sum_kernel(long npts, int c, int tpp, const float *__restrict__ src,
+__global__ __launch_bounds__(256) void csr_gather_sum_kernel(long npts, int c, int tpp, const float *__restrict__ src, long pitch,
                                                              const int *__restrict__ order, const int *__restrict__ offsets,
                                                              const float *__restrict__ weight, int div, float *__restrict__ out)
 {
@@ -33,10 +33,10 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(long npts, int c, i
             const int s0 = order[t], s1 = order[t + 1], s2 = order[t + 2], s3 = order[t + 3];
             float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
             if (ch < c) {
-                v0 = src[(size_t)(s0 / div) * c + ch];
-                v1 = src[(size_t)(s1 / div) * c + ch];
-                v2 = src[(size_t)(s2 / div) * c + ch];
-                v3 = src[(size_t)(s3 / div) * c + ch];
+                v0 = src[(size_t)(s0 / div) * pitch + ch];
+                v1 = src[(size_t)(s1 / div) * pitch + ch];
+                v2 = src[(size_t)(s2 / div) * pitch + ch];
+                v3 = src[(size_t)(s3 / div) * pitch + ch];
             }
             if (weight) {
                 v0 *= weight[s0];
@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void csr_gather_sum_kernel(long npts, int c, i
         }
         for (; t < t1; t++) {
             const int s = order[t];
-            float v = ch < c ? src[(size_t)(s / div) * c + ch] : 0.0f;
+            float v = ch < c ? src[(size_t)(s / div) * pitch + ch] : 0.0f;
             if (weight) v *= weight[s];
             acc += v;
         }
@@ -136,13 +136,88 @@ __global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(long npts,
     }
 }
 
+// The inverse of a small grouping in ONE launch, one workgroup per scene: idx (b, slots) with values in [0, m) -> offsets (b*m + 1),
+// order (b*slots) -- for every target the slots (flat positions of idx) that reference it, ASCENDING (one fixed summation order for
+// the gather-sums above).  Counts and cursors live in LDS (m <= kInvMaxTargets); the fill uses LDS atomics, so a target's list comes
+// out in arrival order and is sorted in place afterwards by the thread that owns the target (the lists are short: three_nn's taps,
+// ~6 per target).  Replaces a stable sort + searchsorted of the tensor library (10 launches) for the taps of three_interpolate.
+constexpr int kInvMaxTargets = 8192;
+__global__ __launch_bounds__(1024) void inverse_index_kernel(int slots, int m, const int *__restrict__ idx, int *__restrict__ order,
+                                                             int *__restrict__ offsets)
+{
+    __shared__ int cnt[kInvMaxTargets];
+    __shared__ int wsum[16];
+    const int scene = blockIdx.x, tid = threadIdx.x;
+    const int *__restrict__ si = idx + (size_t)scene * slots;
+    const int base = scene * slots;
+    for (int j = tid; j < m; j += 1024) cnt[j] = 0;
+    __syncthreads();
+    for (int t = tid; t < slots; t += 1024) atomicAdd(&cnt[si[t]], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0..m) in place: every thread owns a contiguous run of PER targets
+    const int PER = (m + 1023) / 1024;
+    const int j0 = tid * PER;
+    int mine = 0;
+    for (int q = 0; q < PER; q++) mine += (j0 + q < m) ? cnt[j0 + q] : 0;
+    int incl = mine;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        if (lane >= d) incl += t;
+    }
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int before = 0;
+    for (int w = 0; w < wv; w++) before += wsum[w];
+    int run = before + incl - mine;
+    for (int q = 0; q < PER; q++) {
+        if (j0 + q < m) {
+            const int c = cnt[j0 + q];
+            offsets[(size_t)scene * m + j0 + q] = base + run;
+            cnt[j0 + q] = run; // the cursor of the fill
+            run += c;
+        }
+    }
+    if (scene == (int)gridDim.x - 1 && tid == 0) offsets[(size_t)gridDim.x * m] = (int)gridDim.x * slots;
+    __syncthreads();
+    for (int t = tid; t < slots; t += 1024) order[base + atomicAdd(&cnt[si[t]], 1)] = base + t;
+    __syncthreads(); // the lists are complete (global writes of this workgroup, read back by this workgroup below)
+    __threadfence_block();
+    for (int j = tid; j < m; j += 1024) {
+        const int hi = cnt[j]; // the cursor now stands at the end of the list
+        const int lo = (j == 0) ? 0 : cnt[j - 1];
+        // cnt[j - 1] is the END of list j - 1 = the start of list j (lists are contiguous in target order)
+        int *__restrict__ l = order + base;
+        for (int a = lo + 1; a < hi; a++) { // insertion sort, ascending
+            const int v = l[a];
+            int k = a - 1;
+            while (k >= lo && l[k] > v) {
+                l[k + 1] = l[k];
+                k--;
+            }
+            l[k + 1] = v;
+        }
+    }
+}
+
 } // namespace votenet
 using namespace votenet;
 
-extern "C" int votenet_csr_gather_sum(long npts, int c, const float *src, const int *order, const int *offsets, const float *weight,
-                                      int div, float *out, void *stream)
+extern "C" int votenet_inverse_index(int b, int slots, int m, const int *idx, int *order, int *offsets, void *stream)
 {
-    VN_REQUIRE(npts >= 0 && c > 0 && c <= 256 && div > 0, "csr_gather_sum expects npts >= 0, 0 < c <= 256, div > 0");
+    VN_REQUIRE(b >= 0 && slots > 0 && m > 0 && m <= kInvMaxTargets, "inverse_index expects b >= 0, slots > 0, 0 < m <= 8192 targets per scene");
+    VN_REQUIRE((long)b * slots < (1L << 31), "inverse_index: more than 2^31 slots");
+    if (b == 0) return VOTENET_OK;
+    VN_REQUIRE(idx && order && offsets, "inverse_index: null buffer");
+    hipLaunchKernelGGL(inverse_index_kernel, dim3(b), dim3(1024), 0, as_stream(stream), slots, m, idx, order, offsets);
+    return check_launch("inverse_index");
+}
+
+static int csr_gather_sum_launch(long npts, int c, const float *src, long pitch, const int *order, const int *offsets, const float *weight,
+                                 int div, float *out, void *stream)
+{
+    VN_REQUIRE(npts >= 0 && c > 0 && c <= 256 && div > 0 && pitch >= c, "csr_gather_sum expects npts >= 0, 0 < c <= 256, div > 0, pitch >= c");
     if (npts == 0) return VOTENET_OK;
     VN_REQUIRE(src && order && offsets && out, "csr_gather_sum: null buffer");
     int tpp = 1;
@@ -150,9 +225,21 @@ extern "C" int votenet_csr_gather_sum(long npts, int c, const float *src, const 
     const int ppb = 256 / tpp;
     long gx = (npts + ppb - 1) / ppb;
     if (gx > 4096) gx = 4096;
-    hipLaunchKernelGGL(csr_gather_sum_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), npts, c, tpp, src, order, offsets,
+    hipLaunchKernelGGL(csr_gather_sum_kernel, dim3((unsigned)gx), dim3(256), 0, as_stream(stream), npts, c, tpp, src, pitch, order, offsets,
                        weight, div, out);
     return check_launch("csr_gather_sum");
+}
+
+extern "C" int votenet_csr_gather_sum(long npts, int c, const float *src, const int *order, const int *offsets, const float *weight,
+                                      int div, float *out, void *stream)
+{
+    return csr_gather_sum_launch(npts, c, src, c, order, offsets, weight, div, out, stream);
+}
+
+extern "C" int votenet_csr_gather_sum_pitched(long npts, int c, const float *src, long src_pitch, const int *order, const int *offsets,
+                                              const float *weight, int div, float *out, void *stream)
+{
+    return csr_gather_sum_launch(npts, c, src, src_pitch, order, offsets, weight, div, out, stream);
 }
 
 static long glbg_grid(long npts, int ppb)

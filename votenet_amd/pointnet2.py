@@ -929,7 +929,7 @@ class FPModule:
     def geometry(xyz1, xyz2):
         """three_nn + inverse-distance weights (utils.py:278-282): feature independent."""
         dist, idx = tf_interpolate.three_nn(xyz1, xyz2)
-        return M.attach_inverse(idx, xyz2.shape[1]), tf_interpolate.three_nn_weights(dist)
+        return M.attach_inverse(idx, xyz2.shape[1], always=tf_interpolate.GATHER_GRAD), tf_interpolate.three_nn_weights(dist)
 
     def forward(self, xyz1, xyz2, points1, points2, tape=None, geom=None):
         b, n1 = xyz1.shape[:2]
