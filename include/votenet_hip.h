@@ -588,6 +588,14 @@ int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int 
                  const int *semantic_labels, const int *heading_labels, const float *heading_residuals,
                  const int *size_labels, const float *size_residuals, float pos_thr, float neg_thr, float *losses,
                  float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, float *workspace, void *stream);
+/* The same with the rows of proposals_output output_pitch floats apart (>= its width): the output of the proposal module's last layer
+ * is a column slice of a padded (rows x 128) GEMM result, read in place.  d_proposals_output stays dense (b, n_prop, width). */
+int votenet_loss_pitched(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
+                         const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, long output_pitch,
+                         const float *bboxes_xyz, const float *bboxes_lwh, const float *bboxes_roty,
+                         const int *semantic_labels, const int *heading_labels, const float *heading_residuals,
+                         const int *size_labels, const float *size_residuals, float pos_thr, float neg_thr, float *losses,
+                         float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output, float *workspace, void *stream);
 size_t votenet_loss_workspace_floats(int b);
 
 /* Box decode of the predict tower (model.py:100-129): proposals_xyz (b,n_prop,3), proposals_output

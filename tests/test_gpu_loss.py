@@ -46,6 +46,23 @@ def test_loss_values_and_cotangents(hiplib, dev, seed, shape):
     assert torch.equal(losses, losses2)
 
 
+def test_loss_reads_a_column_slice_in_place(hiplib, dev):
+    """votenet_loss_pitched: proposals_output as the first 79 columns of a wider row-major tensor (what the proposal module's last GEMM
+    leaves) gives the losses and cotangents of the contiguous copy, bit for bit; the cotangent stays dense."""
+    from votenet_amd import loss as VL
+    seeds, votes, prop, out, gt = loss_ref.random_case(5, b=4, n=256, p=64, bb=7)
+    ref_l, ref_c = run_device(dev, seeds, votes, prop, out, gt)
+    wide = torch.full((out.shape[0], out.shape[1], 128), 1e30, device=dev)
+    wide[:, :, :out.shape[2]] = torch.from_numpy(out).to(dev)
+    o = dict(seeds_xyz=torch.from_numpy(seeds).to(dev), votes_xyz=torch.from_numpy(votes).to(dev),
+             proposals_xyz=torch.from_numpy(prop).to(dev), proposals_output=wide[:, :, :out.shape[2]])
+    assert not o["proposals_output"].is_contiguous()
+    got_l, got_c = VL.votenet_loss(o, VL.gt_to_device(gt, dev))
+    assert torch.equal(got_l, ref_l)
+    for k in ref_c:
+        assert torch.equal(got_c[k], ref_c[k]) and got_c[k].is_contiguous(), k
+
+
 def test_loss_without_positives_is_nan_like_tensorflow(hiplib, dev):
     seeds, votes, prop, out, gt = loss_ref.random_case(7)
     losses, cot = run_device(dev, seeds, votes, (prop + 100.0).astype(np.float32), out, gt)

@@ -96,6 +96,7 @@ _SIGS.update({
                                  + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_pool_wgrad_finish": [ctypes.c_int] * 2 + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_loss": [ctypes.c_int] * 7 + [_c_f] * 12 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_loss_pitched": [ctypes.c_int] * 7 + [_c_f] * 4 + [ctypes.c_long] + [_c_f] * 8 + [ctypes.c_float] * 2 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_decode_boxes": [ctypes.c_int] * 5 + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_iou3d_cross": [ctypes.c_int] * 3 + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_selection_sort": [ctypes.c_int] * 4 + [_c_f] * 3 + [ctypes.c_void_p],

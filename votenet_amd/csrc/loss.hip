@@ -21,6 +21,7 @@ struct LossArgs {
     const float *hres, *sres;
     float pos_thr, neg_thr;
     float *losses, *d_votes, *d_pxyz, *d_pout;
+    long pout_pitch; // floats between the rows of proposals_output (>= its width: a column slice of a wider tensor is read in place)
 };
 
 __device__ __forceinline__ float huber(float e, float &grad) // tf.losses.huber_loss, delta = 1: e = prediction - label
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
         const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
         int g;
         const float best = nearest_box(s_box, BB, px, py, pz, g);
-        const float *o = A.pout + (size_t)q * W;
+        const float *o = A.pout + (size_t)q * A.pout_pitch;
         float *go = A.d_pout + (size_t)q * W;
         const bool pos = best < A.pos_thr, neg = best > A.neg_thr;
         if (pos || neg) { // objectness, weight 0.5 (a proposal can only be one of the two: pos_thr < neg_thr)
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
             const int k = lane, q = b * P + bp;
             const float cgk = (k == 0 ? gx : (k == 1 ? gy : gz)) - A.pxyz[q * 3 + k];
             float gr;
-            acc[4] += huber(A.pout[(size_t)q * W + 2 + k] - cgk, gr);
+            acc[4] += huber(A.pout[(size_t)q * A.pout_pitch + 2 + k] - cgk, gr);
             s_dual[j][k] = gr * inv_bbb; // added to the proposal's cotangents below, box by box in ascending order
             if (k == 0) s_dualp[j] = bp;
         }
@@ -299,8 +300,9 @@ using namespace votenet;
 
 extern "C" size_t votenet_loss_workspace_floats(int b) { return 4 + (size_t)(b > 0 ? b : 0) * LOSS_NACC; }
 
-extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
-                            const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, const float *bboxes_xyz,
+extern "C" int votenet_loss_pitched(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
+                            const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, long output_pitch,
+                            const float *bboxes_xyz,
                             const float *bboxes_lwh, const float *bboxes_roty, const int *semantic_labels, const int *heading_labels,
                             const float *heading_residuals, const int *size_labels, const float *size_residuals, float pos_thr,
                             float neg_thr, float *losses, float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output,
@@ -314,14 +316,28 @@ extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, i
                    semantic_labels && heading_labels && heading_residuals && size_labels && size_residuals && losses &&
                    d_votes_xyz && d_proposals_xyz && d_proposals_output && workspace,
                "votenet_loss: null buffer");
+    VN_REQUIRE(output_pitch >= 5 + 2 * nh + 4 * ns + nc, "votenet_loss: the pitch of proposals_output is smaller than its width");
     LossArgs a = {b, n_seeds, n_prop, n_box, nh, ns, nc, seeds_xyz, votes_xyz, proposals_xyz, proposals_output, bboxes_xyz, bboxes_lwh,
                   bboxes_roty, semantic_labels, heading_labels, size_labels, heading_residuals, size_residuals, pos_thr, neg_thr, losses,
-                  d_votes_xyz, d_proposals_xyz, d_proposals_output};
+                  d_votes_xyz, d_proposals_xyz, d_proposals_output, output_pitch};
     int *counts = reinterpret_cast<int *>(workspace); // [positives, negatives, finished workgroups, pad], zero on entry
     hipStream_t st = as_stream(stream);
     hipLaunchKernelGGL(votenet_loss_count_kernel, dim3(b), dim3(256), 0, st, a, counts);
     hipLaunchKernelGGL(votenet_loss_kernel, dim3(b), dim3(LOSS_T), 0, st, a, counts, workspace + 4);
     return check_launch("votenet_loss");
+}
+
+extern "C" int votenet_loss(int b, int n_seeds, int n_prop, int n_box, int nh, int ns, int nc, const float *seeds_xyz,
+                            const float *votes_xyz, const float *proposals_xyz, const float *proposals_output, const float *bboxes_xyz,
+                            const float *bboxes_lwh, const float *bboxes_roty, const int *semantic_labels, const int *heading_labels,
+                            const float *heading_residuals, const int *size_labels, const float *size_residuals, float pos_thr,
+                            float neg_thr, float *losses, float *d_votes_xyz, float *d_proposals_xyz, float *d_proposals_output,
+                            float *workspace, void *stream)
+{
+    return votenet_loss_pitched(b, n_seeds, n_prop, n_box, nh, ns, nc, seeds_xyz, votes_xyz, proposals_xyz, proposals_output,
+                                5 + 2 * nh + 4 * ns + nc, bboxes_xyz, bboxes_lwh, bboxes_roty, semantic_labels, heading_labels,
+                                heading_residuals, size_labels, size_residuals, pos_thr, neg_thr, losses, d_votes_xyz, d_proposals_xyz,
+                                d_proposals_output, workspace, stream);
 }
 
 // ---------------------------------------------------------------- box decode of the predict tower (model.py:100-129)

@@ -23,7 +23,10 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
     seeds = L.dev_f32(out["seeds_xyz"], "loss seeds_xyz", 3, 3)
     votes = L.dev_f32(out["votes_xyz"], "loss votes_xyz", 3, 3)
     pxyz = L.dev_f32(out["proposals_xyz"], "loss proposals_xyz", 3, 3)
-    pout = L.dev_f32(out["proposals_output"], "loss proposals_output", 3)
+    pout = out["proposals_output"]
+    if not (isinstance(pout, torch.Tensor) and pout.is_cuda and pout.dtype == torch.float32 and pout.dim() == 3 and pout.stride(2) == 1
+            and pout.stride(1) >= pout.shape[2] and pout.stride(0) == pout.shape[1] * pout.stride(1)):
+        pout = L.dev_f32(pout, "loss proposals_output", 3)  # anything but rows with unit column stride: a contiguous copy
     b, n = seeds.shape[:2]
     p = pxyz.shape[1]
     bb = gt["bboxes_xyz"].shape[1]
@@ -38,7 +41,7 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
     d_votes, d_pxyz = flat[:nv].view_as(votes), flat[nv:nv + npx].view_as(pxyz)
     d_pout, ws = flat[nv + npx:nv + npx + npo].view_as(pout), flat[nv + npx + npo:]
     with L.device_guard(dev):
-        L.check(L.lib().votenet_loss(b, n, p, bb, nh, ns, nc, L.ptr(seeds), L.ptr(votes), L.ptr(pxyz), L.ptr(pout),
+        L.check(L.lib().votenet_loss_pitched(b, n, p, bb, nh, ns, nc, L.ptr(seeds), L.ptr(votes), L.ptr(pxyz), L.ptr(pout), pout.stride(1),
                                      L.ptr(gt["bboxes_xyz"]), L.ptr(gt["bboxes_lwh"]), L.ptr(gt["bboxes_roty"]),
                                      L.ptr(gt["semantic_labels"]), L.ptr(gt["heading_labels"]), L.ptr(gt["heading_residuals"]),
                                      L.ptr(gt["size_labels"]), L.ptr(gt["size_residuals"]), POSITIVE_THRES, NEGATIVE_THRES,

@@ -604,7 +604,11 @@ def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
     geo = torch.empty((b * m * 64, 4), dtype=torch.float32, device=xyz.device)
     # ONE zero-filled buffer: the per-point counters (b n x 4 int64), the moments (9 f64) and the rows-per-point counts of the bucketing
     npts = b * n
-    zero = torch.zeros(npts * 4 + 16 + (npts + 1) // 2, dtype=torch.int64, device=xyz.device)
+    nz = npts * 4 + 16 + (npts + 1) // 2
+    if half.nh_limit is not None:  # geometry made inside the pass it serves (the proposal module): the pass's one zero fill covers it
+        zero = _zeros_i64((nz,), xyz.device)
+    else:                          # computed ahead, on a geometry stream, for a later pass: its own fill
+        zero = torch.zeros(nz, dtype=torch.int64, device=xyz.device)
     cntv = zero[:npts * 4].view(npts, 4)
     mom = zero[npts * 4:npts * 4 + 9].view(torch.float64)
     work = zero[npts * 4 + 16:].view(torch.int32)[:npts]
