@@ -197,9 +197,9 @@ def inverse_index(idx, n):
     with the grouping, on the geometry stream; it travels as idx._inv."""
     b = idx.shape[0]
     slots = idx.numel()
-    if idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and 0 < n <= 8192 and b > 0 and slots // b <= 16 * n:
-        # a small grouping with short lists (three_nn's taps: ~6 per target): one launch, counts and cursors in LDS, each list sorted
-        # by one thread (votenet_inverse_index)
+    if idx.is_cuda and idx.dtype == torch.int32 and idx.is_contiguous() and 0 < n <= 8192 and b > 0 and slots // b <= 8 * n:
+        # a small grouping with short lists (three_nn's taps: ~6 per target; NOT the ball queries of the deterministic mode, whose lists run
+        # to hundreds -- one thread sorts a list by insertion): one launch, counts and cursors in LDS (votenet_inverse_index)
         order = torch.empty(slots, dtype=torch.int32, device=idx.device)
         offsets = torch.empty(b * n + 1, dtype=torch.int32, device=idx.device)
         with L.device_guard(idx.device):
