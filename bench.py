@@ -226,10 +226,15 @@ def main():
         sys.exit("bench.py: --gpus %d does not match WORLD_SIZE=%d (launch with --nproc-per-node equal to --gpus)" % (args.gpus, world))
     if args.dry_run:
         return dry_run(args)
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # the rank's host threads on eight cores of its GPU's NUMA node (votenet_amd/hostpin.py: 3.1 -> 2.75 ms of enqueue per step);
+    # before anything touches the GPU, so that the runtime's helper threads inherit the mask
+    from votenet_amd import hostpin
+    full_mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
+    pinned = hostpin.pin(local)
+    import torch
+    import torch.distributed as dist
     if torch.cuda.device_count() <= local:  # the launcher counted in sysfs (or could not count at all): fail fast here
         sys.exit("bench.py: rank %d has no GPU %d (device_count %d)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -662,12 +667,16 @@ def main():
             if bq is not None:
                 bq["alone_on_the_gpu_detail"] = bq_detail
         if world == 1 and not args.no_cpu_baseline:  # last: its OpenMP threads keep the host busy for a while after they finish
+            if pinned and full_mask:
+                hostpin.unpin(full_mask)  # the CPU oracle runs on ALL cores: every thread of the process gets the full mask back
             cpu = cpu_baseline(n, args.scene)
         out = {
             "metric": "SUN RGB-D 20k-pt scenes/sec (%s)" % ("fwd+bwd" if workload == "train" else "fwd"),
             "value": round(B * world * args.steps / dt, 2), "unit": "scenes/s", "n_gpus": comm["world_size"], "steps": args.steps,
             "warmup": args.warmup, "setup_steps": SETUP_STEPS, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "host_threads": {"cpus": pinned, "what": "CPUs this rank's host threads were confined to for the GPU legs (votenet_amd/hostpin.py: eight "
+                                                     "cores of the GPU's NUMA node; null = left to the scheduler; VOTENET_NO_PIN=1 switches it off)"},
             "config": {"workload": ("VoteNet hot path %s: sa1-4 + fp1-2 + voting + proposal, %d scenes x %d pts per GPU, "
                                     "%s scenes" % (("train step (fwd + loss graph of model.py:61-84,141-231 + bwd + clip/Adam)" if args.scene == "room" else
                                                     "train step (fwd+bwd+Adam, fixed cotangents)")

@@ -1,0 +1,66 @@
+"""CPU: votenet_amd/hostpin.py against a made-up sysfs (two NUMA nodes, four GPUs) -- which CPUs a rank is confined to."""
+import os
+
+import pytest
+
+from votenet_amd import hostpin
+
+
+def test_cpulist():
+    assert hostpin._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and hostpin._cpulist("") == []
+
+
+@pytest.fixture
+def fake(tmp_path, monkeypatch):
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    for i, (simd, loc) in enumerate([(0, 0), (0, 0), (1024, 0x0500), (1024, 0x1500), (1024, 0x8500), (1024, 0x9500)]):
+        d = kfd / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count %d\nsimd_count %d\nlocation_id %d\ndomain 0\n" % (64 if simd == 0 else 0, simd, loc))
+    for bus, node in ((0x05, 0), (0x15, 0), (0x85, 1), (0x95, 1)):
+        d = pci / ("0000:%02x:00.0" % bus)
+        d.mkdir(parents=True)
+        (d / "numa_node").write_text("%d\n" % node)
+    state = {"mask": set(range(256))}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(state["mask"]), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: state.__setitem__("mask", set(cpus)), raising=False)
+    real_nodes = hostpin.gpu_numa_nodes
+    monkeypatch.setattr(hostpin, "gpu_numa_nodes", lambda: real_nodes(str(kfd), str(pci)))
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/devices/system/node/node"):
+            n = int(path.split("node")[-1].split("/")[0])
+            import io
+            return io.StringIO("0-63,128-191\n" if n == 0 else "64-127,192-255\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "VOTENET_NO_PIN"):
+        monkeypatch.delenv(v, raising=False)
+    return state
+
+
+def test_numa_nodes_in_kfd_order(fake):
+    assert hostpin.gpu_numa_nodes() == [0, 0, 1, 1]
+
+
+def test_ranks_take_blocks_of_their_gpus_node(fake):
+    assert hostpin.pin(0) == list(range(8, 16))       # block 1 of node 0 (block 0 holds CPU 0)
+    fake["mask"] = set(range(256))
+    assert hostpin.pin(1) == list(range(16, 24))      # the second GPU of node 0: the next block
+    fake["mask"] = set(range(256))
+    assert hostpin.pin(2) == list(range(72, 80))      # node 1
+    fake["mask"] = set(range(256))
+    assert hostpin.pin(3) == list(range(80, 88))
+    assert fake["mask"] == set(range(80, 88))
+
+
+def test_no_ops(fake, monkeypatch):
+    fake["mask"] = set(range(12))
+    assert hostpin.pin(0) is None and fake["mask"] == set(range(12))   # already narrow: a launcher chose
+    fake["mask"] = set(range(256))
+    monkeypatch.setenv("VOTENET_NO_PIN", "1")
+    assert hostpin.pin(0) is None
+    monkeypatch.delenv("VOTENET_NO_PIN")
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")
+    assert hostpin.pin(0) == list(range(80, 88))      # device 0 of this process is physical GPU 3
