@@ -1,6 +1,7 @@
 """Same-box A/B of the train step for a two-argument debug hook:  python tools/ab_lib2.py votenet_debug_fast_workgroups 1024,2048 512,2048 ...   (scratch tool)"""
 import os, sys, time, gc
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
+from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
 import torch
 from votenet_amd import loss as VL, model as VM, synth, _lib as L
 hook = getattr(L.lib(), sys.argv[1])

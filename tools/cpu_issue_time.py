@@ -2,6 +2,7 @@
 launch-bound on the host and faster kernels will not show."""
 import sys, time, torch
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
+from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
 from votenet_amd import synth, loss as VL
 from votenet_amd.model import VoteNetHotPath
 dev = torch.device("cuda:0")

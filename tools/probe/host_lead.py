@@ -2,6 +2,7 @@
 event: lead = (GPU time the event fires) - (host time it was enqueued), in a free-running loop.  A lead near zero = the GPU ran dry there."""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
+from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
 import torch
 from votenet_amd import loss as VL, model as VM, pointnet2 as P, synth
 dev = torch.device("cuda:0")

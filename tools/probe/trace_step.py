@@ -2,6 +2,7 @@
    TOGGLES="pointnet2.ASSEMBLE_FIRST=False mlp.COEF_TAIL=True" rocprofv3 --kernel-trace ... -- python3 tools/probe/trace_step.py"""
 import os, sys, importlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
+from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
 import torch
 from votenet_amd import loss as VL, model as VM, synth
 for t in os.environ.get("TOGGLES", "").split():
