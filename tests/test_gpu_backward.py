@@ -77,11 +77,16 @@ def perturb(net, dev):
             v.copy_((0.1 * torch.randn(v.shape, generator=g)).to(dev))
 
 
-def test_full_backward_vs_autograd(hiplib, dev, gemm_form):
+def _full_backward_vs_autograd(dev, n, npoints, seed):
+    """The whole explicit backward pass in the DEFAULT mode (piece layout, assembled / narrow first layers, fp32 atomics, the proposal
+    module's piece count on the device) against float64 autograd over the device's own indices / active sets."""
+    from votenet_amd import mlp as M
     from votenet_amd import model as VM
+    from votenet_amd import pointnet2 as P
     from votenet_amd import synth
-    x = torch.from_numpy(synth.room_batch(2, 2048, 5)).to(dev)
-    net = VM.VoteNetHotPath(dev, seed=2, npoints=(512, 256, 128, 64))
+    assert P.HALF_GROUPS and P.ASSEMBLE_FIRST and P.NARROW_FIRST and P.POOL_GRAM_BACKWARD and not M.DETERMINISTIC  # what bench.py times
+    x = torch.from_numpy(synth.room_batch(2, n, seed)).to(dev)
+    net = VM.VoteNetHotPath(dev, seed=2, npoints=npoints)
     perturb(net, dev)
     cot = net.make_cotangents(2, seed=0)
     cot = {k: v * 100 for k, v in cot.items()}
@@ -123,6 +128,28 @@ def test_full_backward_vs_autograd(hiplib, dev, gemm_form):
     print("WORST", sorted(((round(v, 6), k) for k, v in worst.items()), reverse=True)[:30])
     assert not bad, bad
     assert np.median(list(worst.values())) < 2e-5
+    return worst, tape
+
+
+def test_full_backward_vs_autograd(hiplib, dev, gemm_form):
+    _full_backward_vs_autograd(dev, 2048, (512, 256, 128, 64), 5)
+
+
+def test_full_size_backward_vs_autograd(hiplib, dev, gemm_form):
+    """The headline shapes: 20 480 points per scene with the real 2048 / 1024 / 512 / 256 centres (model.py:39-49), default mode, both GEMM
+    forms, at the reference's own bar for its op gradients (compute_gradient_error < 1e-4, tf_grouping_op_test.py:23-25) over the WHOLE
+    backward pass of utils.py:125-132.  Two scenes: the float64 reference materialises every grouped tensor."""
+    worst, tape = _full_backward_vs_autograd(dev, 20480, (2048, 1024, 512, 256), 1000)
+    assert len(worst) > 60  # every weight / gamma / beta tensor of the stack was compared
+    # the layouts the pass really ran on: compact pieces at every level (fewer rows than the full layout at sa1-sa4), the first layers
+    # never stored, the proposal module's piece count left on the device
+    sa = [tape[i] for i in (0, 1, 2, 3, 7)]
+    assert [r["recs"][0]["kind"] for r in sa] == ["narrow", "assembled", "assembled", "assembled", "assembled"]
+    halves = [r["recs"][0]["half"] for r in sa]
+    assert all(h is not None for h in halves)
+    assert halves[4].nh_limit is not None and all(h.nh_limit is None for h in halves[:4])
+    for h, r in zip(halves[:4], sa[:4]):
+        assert h.rows < r["idx"].numel()
 
 
 def test_wgrad_and_input_grad_unit(hiplib, dev):

@@ -198,8 +198,10 @@ def test_predict_tail_nms_vs_oracle(hiplib, dev, O):
     exp = O.nms3d(boxes, score, obj, 0.25)
     iou = np.stack([O.iou3d_matrix(boxes[s]) for s in range(2)])
     got = N(r["nms_idx"])
-    if not (np.abs(iou - 0.25) < 1e-5).any() and len(np.unique(score)) == score.size:
-        assert (got == exp).all()
+    # the comparison below is exact only when no pair sits within round-off of the threshold and no two scores tie (the visit order of
+    # equal scores is unspecified in the reference): the precondition is ASSERTED for this seed, not a silent way around the comparison
+    assert not (np.abs(iou - 0.25) < 1e-5).any() and len(np.unique(score)) == score.size
+    assert got.shape == exp.shape and (got == exp).all()
     assert got.shape[1] == 2 and (obj[got[:, 0], got[:, 1], 1] > obj[got[:, 0], got[:, 1], 0]).all()
 
 
