@@ -29,8 +29,11 @@ def lib_path():
 
 def build(force=False):
     """Compile libvotenet_hip.so for gfx950 with hipcc (cross-compiles without a GPU)."""
-    if force and os.path.exists(_LIB_PATH):
-        os.remove(_LIB_PATH)
+    if force:  # a clean build: the library AND every cached object file (build.sh recompiles what is missing)
+        import glob
+        for f in [_LIB_PATH] + glob.glob(os.path.join(_HERE, "csrc", "obj", "*.o")):
+            if os.path.exists(f):
+                os.remove(f)
     out = subprocess.run(["bash", os.path.join(_HERE, "csrc", "build.sh")], capture_output=True, text=True)
     if out.returncode != 0:
         raise VotenetError("libvotenet_hip.so build failed:\n" + out.stdout + out.stderr)
