@@ -216,6 +216,16 @@ def emit(line):
     os.write(_REAL_STDOUT if _REAL_STDOUT is not None else 1, (line + "\n").encode())
 
 
+def load_hostpin():
+    """votenet_amd/hostpin.py as a stand-alone module (no package __init__, hence no torch, no library): the pin has to precede the
+    first thread torch or the HIP runtime creates."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("votenet_hostpin", os.path.join(ROOT, "votenet_amd", "hostpin.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -230,7 +240,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     # the rank's host threads on eight cores of its GPU's NUMA node (votenet_amd/hostpin.py: 3.1 -> 2.75 ms of enqueue per step);
     # before anything touches the GPU, so that the runtime's helper threads inherit the mask
-    from votenet_amd import hostpin
+    hostpin = load_hostpin()  # by path: `from votenet_amd import hostpin` would import torch (the package's __init__) BEFORE the pin
+    assert "torch" not in sys.modules, "bench.py: torch was imported before the host threads were pinned"
     full_mask = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     pinned = hostpin.pin(local)
     import torch

@@ -90,3 +90,18 @@ def test_changing_shapes_turn_the_graphs_off(net):
     made = _Graph.made
     net.pick(torch.zeros(1, 32, 3))
     assert _Graph.made == made
+
+
+def test_a_tape_whose_geometry_was_overwritten_is_refused():
+    """forward() stamps the tape with (graph, generation) when its geometry lives in a GeometryGraph's buffers; backward() refuses the
+    tape once that graph has replayed for another batch (round-3 advice: it used to differentiate through the other batch's lists)."""
+    from votenet_amd import VotenetError
+    g = _Graph(None, None, None)
+    g.generation = 3
+    tape = [dict(op="sa", geometry_stamp=(g, 3)), dict(op="sa")]
+    VM.VoteNetHotPath.check_tape(tape)              # same generation: fine
+    VM.VoteNetHotPath.check_tape([dict(op="sa")])   # geometry computed in place (fresh tensors): no stamp, nothing to check
+    VM.VoteNetHotPath.check_tape([])
+    g.generation = 4
+    with pytest.raises(VotenetError, match="overwritten by 1 later prefetch"):
+        VM.VoteNetHotPath.check_tape(tape)

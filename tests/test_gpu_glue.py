@@ -186,6 +186,31 @@ def test_inverse_index_kernel_is_the_stable_sort(hiplib, dev, b, rows, k, m):
     assert torch.equal(offsets.long(), torch.searchsorted(pts, torch.arange(b * m + 1, device=dev)))
 
 
+@pytest.mark.parametrize("hot", [30, 500, 1024, 1500])
+def test_inverse_index_long_lists_and_bad_indices(hiplib, dev, hot):
+    """Degenerate groupings (round-3 advice): one target referenced by `hot` slots per scene (duplicate points, holes mapped to point 0) --
+    its list is sorted by a wavefront's rank sort (<= 1024 entries) instead of one thread's insertion sort -- and indices outside [0, m)
+    (a caller's bug) count for target 0 instead of corrupting the LDS tables.  Same ascending lists as a stable sort."""
+    from votenet_amd import mlp as M
+    b, rows, k, m = 3, 1024, 3, 700
+    g = torch.Generator().manual_seed(hot)
+    idx = torch.randint(0, m, (b, rows * k), generator=g, dtype=torch.int32)
+    for s in range(b):
+        where = torch.randperm(rows * k, generator=g)[:hot]
+        idx[s, where] = 5 + s
+    bad = idx.clone()
+    bad[0, 7], bad[1, 100], bad[2, 9] = -3, m, 2 ** 30
+    for t in (idx, bad):
+        order, offsets = M.inverse_index(t.view(b, rows, k).to(dev), m)
+        valid = torch.where((t >= 0) & (t < m), t, torch.zeros_like(t)).to(dev)
+        slots = t.numel()
+        flat = (valid.long() + (torch.arange(b, device=dev) * m)[:, None]).reshape(-1)
+        keys, _ = torch.sort(flat * slots + torch.arange(slots, device=dev))
+        pts = torch.div(keys, slots, rounding_mode="floor")
+        assert torch.equal(order.long(), keys - pts * slots)
+        assert torch.equal(offsets.long(), torch.searchsorted(pts, torch.arange(b * m + 1, device=dev)))
+
+
 def test_three_interpolate_grad_gather_form_on_a_column_slice(hiplib, dev):
     """tf_interpolate.GATHER_GRAD: the gradient as a gather-sum over the taps' inverse index, reading a column slice of a wider tensor in
     place (votenet_csr_gather_sum_pitched), against the scatter-add with atomics."""

@@ -377,6 +377,39 @@ def test_geometry_graph_replays_are_the_launch_by_launch_chain(hiplib, dev, monk
     assert torch.equal(got["proposals_output"], refs[0]["proposals_output"])
 
 
+def test_outputs_and_tapes_on_graph_geometry_do_not_silently_go_stale(hiplib, dev):
+    """Round-3 advice: a GeometryGraph's buffers are overwritten in place by later replays.  (i) The geometry tensor handed to the CALLER
+    (seeds_xyz) is a copy outside the graph's pool: it keeps its values while the ring goes round; (ii) a tape recorded on prefetched
+    geometry is refused by backward() once its graph has served another batch, and accepted until then."""
+    from votenet_amd import VotenetError
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    xs = [torch.from_numpy(synth.room_batch(2, 4096, 70 + i)).to(dev) for i in range(4)]
+    net = VM.VoteNetHotPath(dev, seed=6, npoints=(512, 256, 128, 64))
+    for i in range(5):  # warm-up pass + three captures
+        net.forward(xs[i % 4], next_x=xs[(i + 1) % 4])
+    net._prefetched.clear()
+    net.prefetch_geometry(xs[0])
+    tape = []
+    out = net.forward(xs[0], tape)
+    gg, gen = tape[0]["geometry_stamp"]
+    assert gg is net._geometry_current and gen == gg.generation
+    sa2_centres = tape[1]["new_xyz"]
+    assert out["seeds_xyz"].data_ptr() != sa2_centres.data_ptr() and torch.equal(out["seeds_xyz"], sa2_centres)
+    seeds = out["seeds_xyz"].clone()
+    cot = net.make_cotangents(2, seed=1)
+    net.store.grad.zero_()
+    net.backward(tape, cot)                       # the tape's geometry is intact: fine
+    for x in xs[1:] + xs[1:]:                     # the ring goes round: every graph replays for other batches
+        net.prefetch_geometry(x)
+    torch.cuda.synchronize()
+    assert gg.generation > gen
+    assert torch.equal(out["seeds_xyz"], seeds)   # the caller's tensor did not change ...
+    assert not torch.equal(sa2_centres, seeds)    # ... the graph's buffer did
+    with pytest.raises(VotenetError, match="overwritten"):
+        net.backward(tape, cot)
+
+
 def test_moving_averages_follow_tensorflows_update(hiplib, dev):
     """The BatchNorm moving averages (reference: Tensorpack BNReLU, momentum 0.9): after a training-mode forward pass
     moving = 0.9 * moving + 0.1 * (batch mean | unbiased batch variance) for every BatchNorm layer, starting from 0 / 1; the

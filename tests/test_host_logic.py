@@ -1,6 +1,7 @@
 """CPU: host-side decisions of the layer stack that need no device -- which SA module takes the narrow-first-layer form
 (csrc/narrow.hip), which layers run on padded copies, what the fused kernels accept."""
 import numpy as np
+import pytest
 import torch
 
 
@@ -122,3 +123,23 @@ def test_param_store_generations():
     assert st.generation == g0 + 2 and st.t_event is None
     st.ensure_split()  # no images enabled on the CPU: a no-op, no library call
     assert st._split_gen != st.generation
+
+
+def test_a_record_of_an_overwritten_batchnorm_block_is_refused():
+    """Every BatchNorm layer's (scale | shift | mean | var) block is persistent (ParamStore.bn_flat): a record of forward pass k must not
+    be read after pass k+1 rewrote the block (round-3 advice: gradients were silently wrong).  Host logic only."""
+    import torch
+    from votenet_amd import VotenetError
+    from votenet_amd import pointnet2 as P
+    store = P.ParamStore(torch.device("cpu"))
+    layers = P.make_mlp(store, "m", 8, [8, 8], "fc")
+    store.materialize(0)
+    L = layers[0]
+    assert L.bn and L.name in store._bn_views
+    rec1 = dict(layer=L, bn_pass=store.bn_block_written(L.name))
+    P.check_bn_block(rec1)
+    P.check_bn_block(dict(layer=L))  # a record with its own buffer (frozen BatchNorm, no persistent block): nothing to check
+    rec2 = dict(layer=L, bn_pass=store.bn_block_written(L.name))
+    P.check_bn_block(rec2)
+    with pytest.raises(VotenetError, match="rewritten by a later training-mode pass"):
+        P.check_bn_block(rec1)

@@ -64,3 +64,38 @@ def test_no_ops(fake, monkeypatch):
     monkeypatch.delenv("VOTENET_NO_PIN")
     monkeypatch.setenv("HIP_VISIBLE_DEVICES", "3")
     assert hostpin.pin(0) == list(range(80, 88))      # device 0 of this process is physical GPU 3
+
+
+def test_visible_devices_mapping(monkeypatch):
+    """ROCR_VISIBLE_DEVICES filters what the runtime sees, HIP_VISIBLE_DEVICES indexes into that list; an entry that is not an index
+    (a uuid) leaves the rank unpinned with a warning instead of pinning it to some other GPU's node (round-3 advice)."""
+    import pytest
+    P = hostpin.physical_gpu
+    assert P(2, 8, {}) == 2 and P(8, 8, {}) is None
+    assert P(0, 8, {"HIP_VISIBLE_DEVICES": "3,5"}) == 3 and P(1, 8, {"HIP_VISIBLE_DEVICES": "3,5"}) == 5
+    assert P(1, 8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "2,0"}) == 4   # HIP's index 0 = ROCR's entry 0 = GPU 4
+    assert P(0, 8, {"ROCR_VISIBLE_DEVICES": "4,5,6,7", "HIP_VISIBLE_DEVICES": "2,0"}) == 6
+    assert P(0, 8, {"CUDA_VISIBLE_DEVICES": "7"}) == 7
+    assert P(0, 8, {"CUDA_VISIBLE_DEVICES": "7", "HIP_VISIBLE_DEVICES": "1"}) == 1            # HIP_VISIBLE_DEVICES wins
+    assert P(1, 8, {"HIP_VISIBLE_DEVICES": "1,9,2"}) is None                                  # the list ends at the first bad index
+    with pytest.warns(UserWarning, match="left unpinned"):
+        assert P(0, 8, {"HIP_VISIBLE_DEVICES": "GPU-abcdef0123456789"}) is None
+
+
+def test_uuid_entries_leave_the_rank_unpinned(fake, monkeypatch):
+    import pytest
+    monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "GPU-0123456789abcdef")
+    with pytest.warns(UserWarning):
+        assert hostpin.pin(0) is None
+    assert fake["mask"] == set(range(256))
+
+
+def test_bench_loads_hostpin_without_the_package():
+    """bench.py pins before torch exists in the process: the module is loaded by path, not through votenet_amd/__init__ (which imports
+    torch).  A fresh interpreter proves it."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r); import bench; h = bench.load_hostpin(); "
+            "assert 'torch' not in sys.modules and 'votenet_amd' not in sys.modules; assert callable(h.pin) and callable(h.unpin); print('ok')" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr

@@ -3,7 +3,10 @@ tower (decode -> 3D NMS) on held-out scenes and report mAP@0.25 / @0.5 with the 
     python tools/train_eval.py [steps] [train_batches]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
+import importlib.util
+_spec = importlib.util.spec_from_file_location("votenet_hostpin", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "votenet_amd", "hostpin.py"))
+hostpin = importlib.util.module_from_spec(_spec); _spec.loader.exec_module(hostpin)  # by path: the package's __init__ would import torch first
+hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
 import numpy as np, torch
 from votenet_amd import evaluator as E, loss as VL, synth
 from votenet_amd.model import VoteNetHotPath

@@ -142,17 +142,24 @@ __global__ __launch_bounds__(256) void group_linear_bwd_gather_kernel(long npts,
 // out in arrival order and is sorted in place afterwards by the thread that owns the target (the lists are short: three_nn's taps,
 // ~6 per target).  Replaces a stable sort + searchsorted of the tensor library (10 launches) for the taps of three_interpolate.
 constexpr int kInvMaxTargets = 8192;
+constexpr int kInvShortList = 24;   // lists up to this length: insertion sort by the thread that owns the target
+constexpr int kInvLongLists = 1024; // longer ones queue up for the wavefronts (a queue overflow falls back to the owner's insertion sort)
+constexpr int kInvRankPerLane = 16; // a wavefront rank-sorts lists of up to 64 * 16 entries in registers
 __global__ __launch_bounds__(1024) void inverse_index_kernel(int slots, int m, const int *__restrict__ idx, int *__restrict__ order,
                                                              int *__restrict__ offsets)
 {
     __shared__ int cnt[kInvMaxTargets];
     __shared__ int wsum[16];
+    __shared__ int longs[kInvLongLists];
+    __shared__ int nlong;
     const int scene = blockIdx.x, tid = threadIdx.x;
     const int *__restrict__ si = idx + (size_t)scene * slots;
     const int base = scene * slots;
     for (int j = tid; j < m; j += 1024) cnt[j] = 0;
     __syncthreads();
-    for (int t = tid; t < slots; t += 1024) atomicAdd(&cnt[si[t]], 1);
+    // an index outside [0, m) (a caller's bug, garbage memory) counts for target 0: the LDS tables are never indexed out of range
+    auto target = [&](int t) { const unsigned v = (unsigned)si[t]; return v < (unsigned)m ? (int)v : 0; };
+    for (int t = tid; t < slots; t += 1024) atomicAdd(&cnt[target(t)], 1);
     __syncthreads();
     // exclusive scan of cnt[0..m) in place: every thread owns a contiguous run of PER targets
     const int PER = (m + 1023) / 1024;
@@ -181,15 +188,14 @@ __global__ __launch_bounds__(1024) void inverse_index_kernel(int slots, int m, c
     }
     if (scene == (int)gridDim.x - 1 && tid == 0) offsets[(size_t)gridDim.x * m] = (int)gridDim.x * slots;
     __syncthreads();
-    for (int t = tid; t < slots; t += 1024) order[base + atomicAdd(&cnt[si[t]], 1)] = base + t;
+    for (int t = tid; t < slots; t += 1024) order[base + atomicAdd(&cnt[target(t)], 1)] = base + t;
     __syncthreads(); // the lists are complete (global writes of this workgroup, read back by this workgroup below)
     __threadfence_block();
-    for (int j = tid; j < m; j += 1024) {
-        const int hi = cnt[j]; // the cursor now stands at the end of the list
-        const int lo = (j == 0) ? 0 : cnt[j - 1];
-        // cnt[j - 1] is the END of list j - 1 = the start of list j (lists are contiguous in target order)
-        int *__restrict__ l = order + base;
-        for (int a = lo + 1; a < hi; a++) { // insertion sort, ascending
+    if (tid == 0) nlong = 0;
+    __syncthreads();
+    int *__restrict__ l = order + base;
+    auto insertion = [&](int lo, int hi) { // ascending, by one thread: O(L^2), for the short lists (three_nn's taps: ~6 per target)
+        for (int a = lo + 1; a < hi; a++) {
             const int v = l[a];
             int k = a - 1;
             while (k >= lo && l[k] > v) {
@@ -198,6 +204,54 @@ __global__ __launch_bounds__(1024) void inverse_index_kernel(int slots, int m, c
             }
             l[k + 1] = v;
         }
+    };
+    for (int j = tid; j < m; j += 1024) {
+        const int hi = cnt[j]; // the cursor now stands at the end of the list
+        const int lo = (j == 0) ? 0 : cnt[j - 1];
+        // cnt[j - 1] is the END of list j - 1 = the start of list j (lists are contiguous in target order)
+        if (hi - lo <= kInvShortList) {
+            insertion(lo, hi);
+        } else { // a long list (duplicate points, holes mapped to point 0: one target referenced by hundreds of slots): a wavefront's job
+            const int q = atomicAdd(&nlong, 1);
+            if (q < kInvLongLists)
+                longs[q] = j;
+            else
+                insertion(lo, hi);
+        }
+    }
+    __syncthreads();
+    // long lists: rank sort by one wavefront -- the values are distinct slots, so rank(v) = #{u in list : u < v} is v's final position;
+    // up to 16 values per lane stay in registers with their ranks until every read of the list is done, then they are written in place
+    const int nl = min(nlong, kInvLongLists);
+    for (int q = wv; q < nl; q += 16) {
+        const int j = longs[q];
+        const int hi = cnt[j], lo = (j == 0) ? 0 : cnt[j - 1];
+        const int len = hi - lo;
+        if (len > 64 * kInvRankPerLane) { // beyond the register budget: the slow way, still correct
+            if (lane == 0) insertion(lo, hi);
+            continue;
+        }
+        int val[kInvRankPerLane], rank[kInvRankPerLane];
+#pragma unroll
+        for (int e = 0; e < kInvRankPerLane; e++) {
+            const int a = lane + 64 * e;
+            val[e] = a < len ? l[lo + a] : 0x7fffffff;
+            rank[e] = 0;
+        }
+        for (int c0 = 0; c0 < len; c0 += 64) {
+            const int mine = (c0 + lane < len) ? l[lo + c0 + lane] : 0x7fffffff;
+            const int lim = min(64, len - c0);
+            for (int u = 0; u < lim; u++) {
+                const int other = __shfl(mine, u);
+#pragma unroll
+                for (int e = 0; e < kInvRankPerLane; e++) rank[e] += other < val[e] ? 1 : 0;
+            }
+        }
+        // (every lane of the wavefront has finished reading the list: the loop above is wave-synchronous)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+#pragma unroll
+        for (int e = 0; e < kInvRankPerLane; e++)
+            if (lane + 64 * e < len) l[lo + rank[e]] = val[e];
     }
 }
 

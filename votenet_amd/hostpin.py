@@ -3,7 +3,9 @@ threads and the driver share cache lines all the time, and the step is as fast a
 (DESIGN.md 5).  Left to the scheduler on a 2 x 64-core host the enqueue of a step takes 3.1 ms; confined to eight cores of the GPU's NUMA
 node 2.75 ms (four cores: 3.15, one: 3.5 -- the helper threads need room; the other socket: 3.1; tools/cpu_issue_time.py under taskset).
 
-No torch, no HIP: this runs before anything touches the GPU (threads created later inherit the mask)."""
+No torch, no HIP: this runs before anything touches the GPU (threads created later inherit the mask).  `from votenet_amd import hostpin`
+would run the package's __init__ and import torch first -- threads torch starts at import keep the wide mask -- so bench.py and
+tools/train_eval.py load THIS FILE by path (`load_standalone`'s recipe) before they import anything else."""
 import os
 
 
@@ -42,6 +44,33 @@ def gpu_numa_nodes(root="/sys/class/kfd/kfd/topology/nodes", pci="/sys/bus/pci/d
     return nodes
 
 
+def physical_gpu(local_rank, ngpus, environ=None):
+    """Device `local_rank` of this process -> its index in KFD topology order.  ROCR_VISIBLE_DEVICES filters (and reorders) what the
+    runtime sees; HIP_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES then index into THAT list.  An entry that is not a plain index (a GPU-uuid)
+    or is out of range -> None with a warning: the rank is then not pinned at all rather than to some other GPU's NUMA node."""
+    import warnings
+    env = os.environ if environ is None else environ
+    devs = list(range(ngpus))
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = env.get(var)
+        if not v:
+            continue
+        if var == "CUDA_VISIBLE_DEVICES" and env.get("HIP_VISIBLE_DEVICES"):
+            continue  # HIP reads one of the two; HIP_VISIBLE_DEVICES wins
+        picked = []
+        for t in (t.strip() for t in v.split(",")):
+            if not t.isdigit() or int(t) >= len(devs):
+                if t and not t.isdigit():
+                    warnings.warn("hostpin: %s=%s names a device by something other than an index: host threads left unpinned" % (var, v))
+                    return None
+                break  # the runtimes stop at the first invalid index
+            picked.append(devs[int(t)])
+        devs = picked
+    if not 0 <= local_rank < len(devs):
+        return None
+    return devs[local_rank]
+
+
 def pin(local_rank=0, cores=8, env="VOTENET_NO_PIN"):
     """Confine this process to `cores` consecutive CPUs of the NUMA node of GPU `local_rank` (rank r takes the r-th block of its node,
     so ranks sharing a node do not share cores).  A no-op when the mask is already narrow (a launcher or a container chose), the
@@ -53,14 +82,9 @@ def pin(local_rank=0, cores=8, env="VOTENET_NO_PIN"):
         if len(have) < 2 * cores:
             return None
         numas = gpu_numa_nodes()
-        phys = local_rank
-        for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):  # device r of this process = physical GPU list[r]
-            v = os.environ.get(var)
-            if v:
-                listed = [t.strip() for t in v.split(",") if t.strip()]
-                if local_rank < len(listed) and listed[local_rank].isdigit():
-                    phys = int(listed[local_rank])
-                break
+        phys = physical_gpu(local_rank, len(numas))
+        if phys is None:
+            return None
         node = numas[phys] if 0 <= phys < len(numas) else -1
         cand = have
         if node >= 0:

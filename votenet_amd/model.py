@@ -257,8 +257,10 @@ class VoteNetHotPath:
         seeds_p = self.fp2.forward(l2_xyz, l3_xyz, l2_p, l3_p2, tape=tape, geom=g.get("fp2"))
         return l2_xyz, seeds_p
 
-    def vote(self, seeds_xyz, seeds_points, tape=None):
-        """model.py:53-61: votes = [seeds_xyz, seeds_points] + FC(...)."""
+    def vote(self, seeds_xyz, seeds_points, tape=None, seeds_copy=None):
+        """model.py:53-61: votes = [seeds_xyz, seeds_points] + FC(...).  seeds_copy (b, n, 3): also receives a copy of seeds_xyz (the
+        launch that builds the voting input reads those rows anyway; forward() hands the caller that copy when seeds_xyz lives in a
+        geometry graph's buffers)."""
         b, n = seeds_xyz.shape[:2]
         rows = b * n
         # [seeds_xyz | seeds_points | 0]: the concat of model.py:53 and the zero padding of the ragged 259-wide input in ONE launch
@@ -268,6 +270,8 @@ class VoteNetHotPath:
         segs = [(xp[:, :3], seeds_xyz.reshape(rows, 3), None), (xp[:, 3:259], seeds_points.reshape(rows, 256), None)]
         if pad > 259:
             segs.append((xp[:, 259:], None, None))
+        if seeds_copy is not None:
+            segs.append((seeds_copy.view(rows, 3), seeds_xyz.reshape(rows, 3), None))
         M.row_segments(rows, segs)
         x = xp[:, :259]
         recs = []
@@ -294,8 +298,19 @@ class VoteNetHotPath:
         M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
         try:
             seeds_xyz, seeds_p = self.backbone(x, tape, next_x=next_x)
-            v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape)
+            gg = getattr(self, "_geometry_current", None)
+            seeds_out = None
+            if gg is not None:
+                # the geometry of this pass lives in a graph's fixed buffers, which a later replay overwrites: the tape is stamped with
+                # (graph, generation) so that backward() refuses a tape whose geometry is gone, and the one geometry tensor handed to the
+                # CALLER (seeds_xyz = sa2's centres) leaves the pool as a copy
+                if tape:
+                    tape[0]["geometry_stamp"] = (gg, gg.generation)
+                seeds_out = torch.empty_like(seeds_xyz)
+            v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape, seeds_copy=seeds_out)
             p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
+            if seeds_out is not None:
+                seeds_xyz = seeds_out
         finally:
             M.arena_end()
         return dict(seeds_xyz=seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
@@ -352,6 +367,8 @@ class VoteNetHotPath:
         multi-tensor launches per step on the (scale | shift | mean | var) blocks the consumers' prologues left behind."""
         ema = self._ema_state()
         recs = list(self._bn_records(tape))
+        for r in recs:
+            P.check_bn_block(r)  # the blocks read below are the ones THIS tape's pass wrote
         st = self.store
         blocks = st._bn_views
         if self._ema_flat is not None and self._ema_flat.is_cuda and len(recs) == len(blocks) and \
@@ -434,6 +451,7 @@ class VoteNetHotPath:
 
     def backward(self, tape, cot):
         """Reverse sweep over the tape of forward(); parameter gradients accumulate into store.grad."""
+        self.check_tape(tape)
         M.arena_begin(self.device)  # one fill for all BatchNorm-backward reductions of the pass
         if self.overlap_wgrad:
             if self._wgrad_stream is None:
@@ -445,6 +463,17 @@ class VoteNetHotPath:
         finally:
             P.WGRAD_STREAM = None
             M.arena_end()
+
+    @staticmethod
+    def check_tape(tape):
+        """A tape recorded on prefetched geometry reads a GeometryGraph's buffers (idx, pts_cnt, the compact rows, fps_idx, the piece
+        layouts): valid until that graph replays for another batch -- GEOMETRY_RING - 1 further prefetches.  Raises instead of
+        differentiating through another batch's neighbour lists."""
+        stamp = tape[0].get("geometry_stamp") if tape else None
+        if stamp is not None and stamp[0].generation != stamp[1]:
+            raise M.L.VotenetError("backward(): the geometry buffers this tape was recorded on have been overwritten by %d later prefetch(es) "
+                                   "(model.GeometryGraph; a tape on prefetched geometry is valid until GEOMETRY_RING - 1 = %d further "
+                                   "batches have been prefetched)" % (stamp[0].generation - stamp[1], GEOMETRY_RING - 1))
 
     def _backward(self, tape, cot):
         recs = {i: r for i, r in enumerate(tape)}

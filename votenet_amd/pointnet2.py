@@ -61,6 +61,8 @@ class ParamStore:
         self._bn_specs = []   # (layer name, cout)
         self.bn_flat = None
         self._bn_views = {}
+        self._bn_pass = {}     # layer name -> number of the forward pass that wrote its persistent block last (check_bn_block)
+        self._bn_passes = 0
 
     def want_transpose(self, name, lo=0, hi=None):
         """Register rows [lo, hi) of the 2-D tensor `name`: transposed() then serves its transpose from one bucket that
@@ -212,6 +214,12 @@ class ParamStore:
 
     def declare(self, name, shape, init):
         self._specs.append((name, tuple(shape), init))
+
+    def bn_block_written(self, name):
+        """A forward pass is about to (re)write layer `name`'s persistent BatchNorm block: -> the stamp its record keeps."""
+        self._bn_passes += 1
+        self._bn_pass[name] = self._bn_passes
+        return self._bn_passes
 
     def materialize(self, seed=0):
         # every view starts on a 16-byte boundary (float4 loads of scale/shift/W rows)
@@ -427,8 +435,13 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             pend = _FROZEN.table[L.name]  # moving averages: the batch sums of this launch are ignored
             rec.update(scale=pend.scale, shift=pend.shift)
         elif L.bn:
-            pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows, out=L.store._bn_views.get(L.name))
+            blk = L.store._bn_views.get(L.name)
+            pend = M.PendingBN(st, L.p("gamma"), L.p("beta"), rows, out=blk)
             rec.update(scale=pend.scale, shift=pend.shift, mean=pend.mean, var=pend.var, bn_out=pend.out)
+            if blk is not None:
+                # the block is PERSISTENT (one per layer, rewritten by every training-mode forward pass of the net): the record
+                # remembers which pass wrote it, and whoever reads it later through this record checks that no other pass has since
+                rec["bn_pass"] = L.store.bn_block_written(L.name)
         else:
             pend = None
         rec.update(z=zn, rows=rows, pool=pool)
@@ -528,6 +541,17 @@ def wgrad_join():
         _wgrad_pending = False
 
 
+def check_bn_block(rec):
+    """A layer's BatchNorm vectors (scale | shift | mean | var) live in ONE persistent block per layer: a record of an earlier forward
+    pass of the same net reads another pass's statistics once a second training-mode pass has run (predict(batch_statistics=True), a
+    forward without a tape, a finite-difference probe between forward(tape) and backward(tape)).  Raises instead."""
+    n = rec.get("bn_pass")
+    if n is not None and rec["layer"].store._bn_pass.get(rec["layer"].name) != n:
+        raise M.L.VotenetError("BatchNorm statistics of layer %s: the record belongs to forward pass %d, the layer's persistent block was "
+                               "rewritten by a later training-mode pass (run backward / update_moving_averages before the next forward of "
+                               "the same net)" % (rec["layer"].name, n))
+
+
 def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zsel=None, g_padded=None):
     """Backward of mlp_chain_forward.  g / mode describe the gradient arriving at the LAST layer:
          'pool'  : g = gout (rows/k, c) of the max over k of relu(bn(z))      (SA layers, utils.py:132)
@@ -544,6 +568,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
     def tail_of(rec):
         Lr = rec["layer"]
         return (rec["rows"], Lr.p("gamma"), Lr.gp("gamma"), Lr.gp("beta"))
+    for r in recs:
+        check_bn_block(r)
     for i in range(len(recs) - 1, -1, -1):
         r = recs[i]
         L = r["layer"]
