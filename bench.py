@@ -95,7 +95,7 @@ def launch_ranks(args):
     import socket
     import subprocess
     import tempfile
-    if not args.dry_run:
+    if not args.dry_run and not os.environ.get("VOTENET_BENCH_SHARE_GPU"):
         have = visible_gpu_count()
         if have is not None and have < args.gpus:
             sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) are visible (KFD topology)\n" % (args.gpus, have))
@@ -107,7 +107,8 @@ def launch_ranks(args):
         s.close()
         procs = []
         out0 = tempfile.TemporaryFile(mode="w+")
-        err0 = tempfile.TemporaryFile(mode="w+")
+        err_lines = []  # rank 0's stderr: forwarded line by line as it arrives (an outer timeout that kills this launcher still leaves
+        #                 the diagnostics on the terminal) and kept for the EADDRINUSE test below
         for r in range(args.gpus):
             # HSA_ENABLE_IPC_MODE_LEGACY=0: this pool's host driver only supports dmabuf IPC; with the legacy mode RCCL's (and torch's)
             # cross-process buffer sharing fails with `hipIpcGetMemHandle: invalid argument`.  The image exports it already; it is
@@ -116,7 +117,18 @@ def launch_ranks(args):
                        MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                        HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
             procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=err0 if r == 0 else None))
+                                          stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=subprocess.PIPE if r == 0 else None,
+                                          text=True if r == 0 else None))
+
+        def tee(pipe):
+            for ln in pipe:
+                err_lines.append(ln)
+                if "EADDRINUSE" not in ln and "address already in use" not in ln.lower():  # (a retry follows: said below)
+                    sys.stderr.write(ln)
+                    sys.stderr.flush()
+        import threading
+        th = threading.Thread(target=tee, args=(procs[0].stderr,), daemon=True)
+        th.start()
         codes = [None] * len(procs)
         while any(c is None for c in codes):
             for r, p in enumerate(procs):
@@ -129,13 +141,12 @@ def launch_ranks(args):
                         codes[r] = p.wait()
                 break
             time.sleep(0.05)
-        err0.seek(0)
-        err_text = err0.read()
+        th.join(10)
+        err_text = "".join(err_lines)
         bad = [(r, c) for r, c in enumerate(codes) if c != 0]
         if bad and attempt < 2 and ("EADDRINUSE" in err_text or "address already in use" in err_text.lower()):
             sys.stderr.write("bench.py: rendezvous port %d was taken, retrying on another\n" % port)
             continue
-        sys.stderr.write(err_text)
         out0.seek(0)
         sys.stdout.write(out0.read())
         sys.stdout.flush()
@@ -144,6 +155,54 @@ def launch_ranks(args):
             return 1
         return 0
     return 1
+
+
+def dp_self_check(dev, nets, run_step, steps=2):
+    """What `--gpus N` (N > 1) appends to its line after the timed region: dp.check_overlap_against_blocking on two replicas (nets[0]
+    exchanges gradients the overlapped way -- tail all-reduce under the backward pass of sa2 / sa1, head after the last weight gradient --
+    nets[1] with ONE blocking all-reduce between device synchronisations), what the communicator says about its ranks, and how long the
+    tail collective was still running when the main stream reached the end of the backward pass.  equal_everywhere is an all-reduce MIN:
+    every rank learns the same verdict (and exits with code 4 when it is False)."""
+    from votenet_amd import dp
+    res = dp.check_overlap_against_blocking(nets[0], nets[1], run_step, steps=steps)
+    info = dp.comm_info(dev)
+    tm = res.get("timings_last_step") or {}
+    return {"equal_everywhere": res["equal_everywhere"], "equal_on_this_rank": res["equal_on_this_rank"], "ranks_identical": res["ranks_identical"],
+            "steps": res["steps"], "collectives_per_step": res["collectives_per_step"], "world_size": info["world_size"],
+            "backend": info["backend"], "distinct_devices": info["distinct_devices"], "tail_exposed_ms": tm.get("tail_exposed_ms"),
+            "tail_ms": tm.get("tail_ms"), "head_ms": tm.get("head_ms"),
+            "what": "deterministic mode, %d train steps on two replicas per rank after the timed region: overlapped exchange (dp.GradSync) vs "
+                    "one blocking all-reduce; parameters torch.equal on every rank and equal to rank 0's" % res["steps"]}
+
+
+class _DryReplica:
+    """The dry run's stand-in for a VoteNetHotPath replica (CPU, gloo): a flat parameter / gradient bucket with the real layout names
+    (head = sa1 | sa2, tail = sa3 ...), gradients that differ per rank and step, dp.GradSync exactly as train_step drives it
+    (begin -> start_tail after the tail's gradients exist -> finish), a plain SGD update on the mean gradient.  No kernels."""
+
+    def __init__(self, seed):
+        import torch
+        from votenet_amd import pointnet2 as P
+        self.store = P.ParamStore(torch.device("cpu"))
+        for name, cin, cout in (("sa1", 6, 16), ("sa2", 19, 16), ("sa3", 19, 32), ("proposal", 35, 8)):
+            P.make_mlp(self.store, name, cin, [cout], "conv")
+        self.store.materialize(seed)
+        self._gsync = None
+
+    def train_step(self, rank, world, i):
+        import torch
+        st, gs = self.store, self._gsync
+        split = st.offset_of("sa3/")
+        gs.begin()
+        g = torch.Generator().manual_seed(1000 * rank + i)
+        st.grad[split:] = torch.randn(st.grad.numel() - split, generator=g)   # the backward pass of proposal ... sa3
+        gs.start_tail(None)
+        if os.environ.get("VOTENET_BENCH_DRYRUN_DIVERGE") and gs.overlap and gs._work:
+            gs._work[-1].wait()          # tests: a gradient written AFTER its collective ran (the bug class the check exists for)
+            st.grad[split:] += 1.0
+        st.grad[:split] = torch.randn(split, generator=g)                     # ... of sa2, sa1, beside the tail's all-reduce
+        scale = gs.finish()
+        st.flat.sub_(0.01 * scale * st.grad)
 
 
 def dry_run(args):
@@ -159,11 +218,20 @@ def dry_run(args):
     t = torch.tensor([float(rank + 1)])
     if world > 1:
         dist.all_reduce(t)
+    check = None
+    if world > 1:  # the self-check a real `--gpus N` run appends to its line, over gloo on stand-in replicas
+        from votenet_amd import dp
+        nets = [_DryReplica(seed=rank) for _ in range(2)]   # replicas start different: the broadcast makes them one model
+        for net in nets:
+            dp.broadcast_params(net.store)
+        check = dp_self_check(torch.device("cpu"), nets, lambda net, i: net.train_step(rank, world, i), steps=2)
     if rank == 0:
         emit(json.dumps({"metric": "dry run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                         "rank_sum": float(t.item())}))
+                         "rank_sum": float(t.item()), "check_dp": check}))
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check["equal_everywhere"]:
+        sys.exit(4)
 
 
 def check_dp(args, dev, world, rank):
@@ -246,6 +314,11 @@ def main():
     pinned = hostpin.pin(local)
     import torch
     import torch.distributed as dist
+    # VOTENET_BENCH_SHARE_GPU=1 (tests on the one-GPU box): every rank on cuda:0, gloo transport (RCCL refuses two ranks per device) --
+    # the N-rank code path of this file with the real kernels; the line says so (communicator.backend "gloo", distinct_devices 1)
+    share_gpu = bool(os.environ.get("VOTENET_BENCH_SHARE_GPU"))
+    if share_gpu:
+        local = 0
     if torch.cuda.device_count() <= local:  # the launcher counted in sysfs (or could not count at all): fail fast here
         sys.exit("bench.py: rank %d has no GPU %d (device_count %d)" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
@@ -258,7 +331,10 @@ def main():
             s_.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(s_.getsockname()[1])
             s_.close()
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     if args.check_dp:
         code = check_dp(args, dev, world, rank)
         dist.destroy_process_group()
@@ -427,9 +503,9 @@ def main():
     fp32_step = None
     if world == 1 and not args.headline_only:
         from votenet_amd import _lib as vlib
-        vlib.lib().votenet_debug_fast_bf3(0)
-        vlib.lib().votenet_debug_gram_bf3(0)
-        vlib.lib().votenet_debug_wgrad_bf3(0)
+        vmlp.debug_switch("fast_bf3", 0)
+        vmlp.debug_switch("gram_bf3", 0)
+        vmlp.debug_switch("wgrad_bf3", 0)
         try:
             for _ in range(4):
                 step()
@@ -440,9 +516,9 @@ def main():
             torch.cuda.synchronize()
             dt4 = time.perf_counter() - t1
         finally:
-            vlib.lib().votenet_debug_fast_bf3(1)
-            vlib.lib().votenet_debug_gram_bf3(1)
-            vlib.lib().votenet_debug_wgrad_bf3(1)
+            vmlp.debug_switch("fast_bf3", 1)
+            vmlp.debug_switch("gram_bf3", 1)
+            vmlp.debug_switch("wgrad_bf3", 1)
         for _ in range(2):
             step()
         torch.cuda.synchronize()
@@ -534,8 +610,27 @@ def main():
                                   if one_rank else ""))
             if one_rank:
                 dist.destroy_process_group()
-        except Exception as e:  # never lose the headline to this leg
+        except Exception as e:  # one GPU: never lose the headline to this leg
+            if world > 1:
+                # N ranks: a rank that swallowed its exception would walk on to destroy_process_group while the others wait in the
+                # collective it skipped -- the run would hang instead of failing.  Exit non-zero: the launcher ends the other ranks.
+                raise
             dp_coll = {"error": repr(e)[:300]}
+    # N > 1: the line validates its own data-parallel path -- overlapped exchange == blocking exchange on every rank, replicas identical
+    # across ranks, N distinct devices in the communicator (check_dp; the same comparison as `--check-dp`, two steps)
+    check = None
+    if workload == "train" and world > 1 and args.scene == "room" and not os.environ.get("VOTENET_BENCH_NO_DP_LEG"):
+        import votenet_amd
+        prev_det = votenet_amd.set_deterministic(True)
+        try:
+            pair = [VM.VoteNetHotPath(dev, seed=0) for _ in range(2)]
+            for rep in pair:
+                dp.broadcast_params(rep.store)
+                rep.init_optimizer()
+            check = dp_self_check(dev, pair, lambda rep, i: rep.train_step(xs[i % len(xs)], None, world, gt=gts[i % len(xs)]), steps=2)
+        finally:
+            votenet_amd.set_deterministic(prev_det)
+        del pair
     if rank == 0:
         # dominant kernel: the sa1 farthest-point-sampling launch (n=20480 -> 2048)
         m1 = net.sa1.npoint
@@ -701,12 +796,15 @@ def main():
                                "fly (W diag(C) W^T of the Gram-form input gradient) stay on fp32 MFMA; tests hold both forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
             "fp32_mfma_gemms": fp32_step, "full_row_layout": full_step, "row_layout": row_layout, "configs": cfgs,
-            "communicator": comm, "dp_collectives": dp_coll,
+            "communicator": comm, "dp_collectives": dp_coll, "check_dp": check,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         emit(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+    if check is not None and not check["equal_everywhere"]:
+        sys.stderr.write("bench.py: the data-parallel replicas diverged (check_dp: %s)\n" % json.dumps(check))
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -684,6 +684,16 @@ typedef struct votenet_row_segment {
     int b_pitch, b_off;
 } votenet_row_segment;
 int votenet_row_segments(long rows, int nseg, const votenet_row_segment *seg, void *stream);
+/* Up to 32 plain device-to-device copies in ONE launch: dst_s[0:bytes_s) = src_s[0:bytes_s) for s < nseg.  bytes % 4 == 0; 16-byte
+ * vectors where both ends of a segment are 16-byte aligned.  Segments must not overlap.  (The inputs of a captured stretch of the
+ * train step -- the level outputs, the feature-propagation geometry, the ground truth -- go into the graph's fixed buffers this way:
+ * one launch instead of one memcpy node per tensor.) */
+typedef struct votenet_copy_segment {
+    void *dst;
+    const void *src;
+    long bytes;
+} votenet_copy_segment;
+int votenet_copy_segments(int nseg, const votenet_copy_segment *seg, void *stream);
 /* Moving averages of every BatchNorm layer in one launch (Tensorpack BatchNorm, momentum 0.9): ema[i] = momentum * ema[i] +
  * factor[i] * batch[i] over flat buffers holding all layers' (scale | shift | mean | var) blocks. */
 int votenet_ema_update(long n, float momentum, float *ema, const float *batch, const float *factor, void *stream);

@@ -51,10 +51,9 @@ def dev():
 def gemm_form(request, hiplib):
     """The fused GEMMs on bf16 x 3 images of the weights (the model's default; a test that wants them registers its matrices with
     mlp.SplitImages) or on the fp32 MFMA kernels (votenet_debug_fast_bf3(0): registered images are ignored)."""
-    hiplib.votenet_debug_fast_bf3(request.param)
-    hiplib.votenet_debug_gram_bf3(request.param)
-    hiplib.votenet_debug_wgrad_bf3(request.param)
+    from votenet_amd import mlp as M
+    for name in ("fast_bf3", "gram_bf3", "wgrad_bf3"):  # through mlp.debug_switch: graphs captured under the other form are not reused
+        M.debug_switch(name, request.param)
     yield request.param
-    hiplib.votenet_debug_fast_bf3(1)
-    hiplib.votenet_debug_gram_bf3(1)
-    hiplib.votenet_debug_wgrad_bf3(1)
+    for name in ("fast_bf3", "gram_bf3", "wgrad_bf3"):
+        M.debug_switch(name, 1)

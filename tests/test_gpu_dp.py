@@ -118,3 +118,24 @@ def test_check_dp_one_rank_rccl_communicator(hiplib):
     assert "tail_ms" in line["check_dp"]["timings_last_step"] and "head_ms" in line["check_dp"]["timings_last_step"]
     d0 = line["communicator"]["devices"][0]
     assert "pci_bus_id" in d0 or "uuid" in d0
+
+
+def test_bench_gpus_2_line_validates_its_own_data_parallel_path():
+    """`python bench.py --gpus 2` end to end with the real kernels -- the launcher, two ranks, the timed region with dp.GradSync inside
+    train_step, the dp_collectives leg and the self-check appended to the line (round-3 verdict item 5).  The box has ONE GPU and RCCL
+    refuses two ranks on a device: VOTENET_BENCH_SHARE_GPU=1 puts both ranks on cuda:0 over gloo; everything else is the N-rank path
+    the driver runs on the 8-GPU node."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["VOTENET_BENCH_SHARE_GPU"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch", "2",
+                        "--headline-only"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "dp2" and line["config"]["global_batch"] == 4 and line["value"] > 0
+    c = line["check_dp"]
+    assert c["equal_everywhere"] and c["equal_on_this_rank"] and c["ranks_identical"] and c["world_size"] == 2
+    assert [w for w, _ in c["collectives_per_step"]] == ["tail", "head"] and c["tail_exposed_ms"] is not None
+    assert line["communicator"]["world_size"] == 2 and line["communicator"]["backend"] == "gloo"
+    assert c["distinct_devices"] == 1   # both ranks on cuda:0 HERE (the flag above); N on the driver's node

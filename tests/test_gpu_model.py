@@ -400,14 +400,57 @@ def test_outputs_and_tapes_on_graph_geometry_do_not_silently_go_stale(hiplib, de
     cot = net.make_cotangents(2, seed=1)
     net.store.grad.zero_()
     net.backward(tape, cot)                       # the tape's geometry is intact: fine
-    for x in xs[1:] + xs[1:]:                     # the ring goes round: every graph replays for other batches
+    for x in xs[1:] + xs[1:]:                     # prefetches alone never touch the graph under the LAST pass: its tape stays valid
         net.prefetch_geometry(x)
+    assert gg.generation == gen
+    net.backward(tape, cot)
+    for i in range(1, 7):                         # later passes take over; the ring goes round and the graph replays for another batch
+        net.forward(xs[i % 4], next_x=xs[(i + 1) % 4])
     torch.cuda.synchronize()
     assert gg.generation > gen
     assert torch.equal(out["seeds_xyz"], seeds)   # the caller's tensor did not change ...
     assert not torch.equal(sa2_centres, seeds)    # ... the graph's buffer did
     with pytest.raises(VotenetError, match="overwritten"):
         net.backward(tape, cot)
+
+
+def test_stretch_graph_replays_are_the_launch_by_launch_step(hiplib, dev, monkeypatch):
+    """model.StretchGraph: the static stretch of a train step (fp1 forward ... fp1 backward, moving averages and loss included) replayed
+    as one HIP graph against the same step enqueued launch by launch.  Two replicas on the same batches; before every step the graph
+    replica takes the launch replica's whole state (parameters, Adam moments, moving averages) -- Adam turns the last-bit noise of the
+    backward pass's fp32 atomics into +-lr on near-zero gradients, so free-running replicas part within steps whatever the mechanism.
+    Per step: forward results and losses bit-equal (the forward pass is order independent), gradient buckets equal to the run-to-run
+    spread of the atomics, moving averages bit-equal; and the graph replica really replayed (one measuring step, one capture per shape)."""
+    from votenet_amd import loss as VL
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    b, n = 2, 4096
+    xs = [torch.from_numpy(synth.room_batch(b, n, 90 + i)).to(dev) for i in range(3)]
+    gts = [VL.gt_to_device(synth.room_gt(b, n, 90 + i), dev) for i in range(3)]
+    ref = VM.VoteNetHotPath(dev, seed=5, npoints=(512, 256, 128, 64))
+    got = VM.VoteNetHotPath(dev, seed=5, npoints=(512, 256, 128, 64))
+    for net in (ref, got):
+        net.init_optimizer(lr=1e-3)
+        net._ema_state()
+    for i in range(8):
+        got.store.flat.copy_(ref.store.flat)
+        got.store.params_changed()
+        got._m.copy_(ref._m), got._v.copy_(ref._v), got._ema_flat.copy_(ref._ema_flat)
+        res = []
+        for net, flag in ((ref, False), (got, True)):
+            monkeypatch.setattr(VM, "STRETCH_GRAPH", flag)
+            out = net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
+            torch.cuda.synchronize()
+            res.append(({k: v.clone() for k, v in out.items()}, net.last_losses.clone(), net.store.grad.clone(), net._ema_flat.clone()))
+        (o0, l0, g0, e0), (o1, l1, g1, e1) = res
+        for k in o0:
+            assert torch.equal(o0[k], o1[k]), (i, k)
+        nn = lambda t: torch.nan_to_num(t, nan=-12345.0)  # (a batch without positives: the reference's empty means are NaN, here too)
+        assert torch.equal(nn(l0), nn(l1)), (i, l0.tolist(), l1.tolist())
+        assert torch.equal(e0, e1), i
+        assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max()), i
+    assert not ref.__dict__.get("_stretch_graphs") and len(got._stretch_graphs) >= 1
+    assert sum(g.replays for g in got._stretch_graphs.values()) == 8 - 1  # every step but the measuring one
 
 
 def test_moving_averages_follow_tensorflows_update(hiplib, dev):

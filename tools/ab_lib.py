@@ -17,7 +17,7 @@ def run(k):
         net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
 for rep in range(3):
     for v in vals:
-        hook(v)
+        hook(v); net.drop_graphs()  # captured graphs keep the kernels of the other setting
         run(6); torch.cuda.synchronize(); gc.collect(); gc.disable()
         t0 = time.perf_counter(); run(40); torch.cuda.synchronize(); dt = time.perf_counter() - t0; gc.enable()
         print("%s(%d): %.3f ms per step" % (sys.argv[1], v, dt / 40 * 1e3), flush=True)

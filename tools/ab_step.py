@@ -18,7 +18,7 @@ def run(k):
 import gc
 for rep in range(3):
     for v in vals:
-        setattr(mod, attr, v)
+        setattr(mod, attr, v); net.drop_graphs()  # captured graphs were recorded under the other setting
         run(6); torch.cuda.synchronize(); gc.collect(); gc.disable()
         t0 = time.perf_counter(); run(40); torch.cuda.synchronize(); dt = time.perf_counter() - t0; gc.enable()
         print("%s = %r: %.3f ms per step" % (sys.argv[1], v, dt / 40 * 1e3), flush=True)

@@ -1,8 +1,11 @@
 """Host time to ENQUEUE one train step (no synchronisation inside): if it approaches the GPU time of a step, the step is
 launch-bound on the host and faster kernels will not show."""
-import sys, time, torch
+import sys, time
 import os; R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
-from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
+import importlib.util
+_s = importlib.util.spec_from_file_location('hp', os.path.join(R, 'votenet_amd', 'hostpin.py')); hostpin = importlib.util.module_from_spec(_s); _s.loader.exec_module(hostpin)
+if not os.environ.get('NO_PIN'): hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node, before torch is imported
+import torch
 from votenet_amd import synth, loss as VL
 from votenet_amd.model import VoteNetHotPath
 dev = torch.device("cuda:0")

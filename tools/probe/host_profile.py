@@ -19,5 +19,5 @@ for i in range(6, 26):
     net.train_step(xs[i % 3], gt=gts[i % 3], next_x=xs[(i + 1) % 3])
     pr.disable()
 s = io.StringIO()
-pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28)
-print(s.getvalue()[:6000])
+pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(45)
+print(s.getvalue()[:12000])

@@ -165,6 +165,12 @@ class RowSegment(ctypes.Structure):
                 ("b", ctypes.c_void_p), ("b_pitch", ctypes.c_int), ("b_off", ctypes.c_int)]
 
 
+class CopySegment(ctypes.Structure):
+    """struct votenet_copy_segment (include/votenet_hip.h)."""
+    _fields_ = [("dst", ctypes.c_void_p), ("src", ctypes.c_void_p), ("bytes", ctypes.c_long)]
+
+
+_SIGS["votenet_copy_segments"] = [ctypes.c_int, ctypes.POINTER(CopySegment), ctypes.c_void_p]
 _SIGS["votenet_three_interpolate_concat"] = [ctypes.c_int] * 4 + [_c_f] * 4 + [ctypes.c_int, _c_f, ctypes.c_void_p]
 _SIGS["votenet_three_interpolate_grad_strided"] = [ctypes.c_int] * 4 + [_c_f, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p]
 _SIGS["votenet_bias_grad_strided"] = [ctypes.c_long, ctypes.c_int, _c_f, ctypes.c_int, _c_f, _c_f, ctypes.c_void_p]

@@ -78,6 +78,59 @@ extern "C" int votenet_row_segments(long rows, int nseg, const votenet_row_segme
     return check_launch("row_segments");
 }
 
+// Plain copies, many per launch (struct by value: no table in device memory, so a caller may refill the arguments per launch).
+namespace votenet {
+constexpr int kMaxCopy = 32;
+struct CopySegs {
+    int nseg;
+    char *dst[kMaxCopy];
+    const char *src[kMaxCopy];
+    long bytes[kMaxCopy];
+};
+__global__ __launch_bounds__(256) void copy_segments_kernel(CopySegs S)
+{
+    const int s = blockIdx.y;
+    if (s >= S.nseg) return;
+    char *__restrict__ d = S.dst[s];
+    const char *__restrict__ a = S.src[s];
+    const long nb = S.bytes[s];
+    if ((((uintptr_t)d | (uintptr_t)a) & 15) == 0) {
+        const long n16 = nb >> 4;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long)gridDim.x * 256)
+            reinterpret_cast<float4 *>(d)[i] = reinterpret_cast<const float4 *>(a)[i];
+        const long done = n16 << 4; // the tail (< 16 bytes, a multiple of 4)
+        if (blockIdx.x == 0 && threadIdx.x < (nb - done) / 4)
+            reinterpret_cast<float *>(d + done)[threadIdx.x] = reinterpret_cast<const float *>(a + done)[threadIdx.x];
+    } else {
+        const long n4 = nb >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+            reinterpret_cast<float *>(d)[i] = reinterpret_cast<const float *>(a)[i];
+    }
+}
+} // namespace votenet
+
+extern "C" int votenet_copy_segments(int nseg, const votenet_copy_segment *seg, void *stream)
+{
+    VN_REQUIRE(nseg >= 0 && nseg <= kMaxCopy && (nseg == 0 || seg), "copy_segments expects 0..32 segments");
+    if (nseg == 0) return VOTENET_OK;
+    CopySegs S = {};
+    S.nseg = nseg;
+    long most = 0;
+    for (int i = 0; i < nseg; i++) {
+        VN_REQUIRE(seg[i].bytes >= 0 && seg[i].bytes % 4 == 0 && (seg[i].bytes == 0 || (seg[i].dst && seg[i].src)) &&
+                       (uintptr_t)seg[i].dst % 4 == 0 && (uintptr_t)seg[i].src % 4 == 0,
+                   "copy_segments: segment %d: null buffer, or bytes / addresses not multiples of 4", i);
+        S.dst[i] = static_cast<char *>(seg[i].dst);
+        S.src[i] = static_cast<const char *>(seg[i].src);
+        S.bytes[i] = seg[i].bytes;
+        most = seg[i].bytes > most ? seg[i].bytes : most;
+    }
+    long gx = (most / 16 + 256 * 4 - 1) / (256 * 4); // four 16-byte vectors per thread on the largest segment
+    gx = gx < 1 ? 1 : (gx > 512 ? 512 : gx);
+    hipLaunchKernelGGL(copy_segments_kernel, dim3((unsigned)gx, nseg), dim3(256), 0, as_stream(stream), S);
+    return check_launch("copy_segments");
+}
+
 // BatchNorm moving averages of every layer in one launch: ema = momentum * ema + factor .* batch over the flat buffers that hold all
 // layers' (scale | shift | mean | var) blocks (factor = 1 - momentum, times rows / (rows - 1) on the variance rows: the unbiased batch
 // variance tf.nn.fused_batch_norm hands to the update).

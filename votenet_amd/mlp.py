@@ -135,6 +135,15 @@ def _zeros_f32(shape, device):
 # (7.83 -> 9.14 ms, same box; the gather-sums read the gradient rows in point order, 1.8 TB/s against 2.7 TB/s for the
 # streaming pass with atomics), and the reference itself sums with atomics (tf_grouping_g.cu:74, tf_sampling_g.cu:187-189).
 DETERMINISTIC = False
+CONFIG_EPOCH = 0  # bumped by whoever flips a library-side switch the captured graphs cannot see (debug_switch): part of their keys
+
+
+def debug_switch(name, *args):
+    """L.lib().votenet_debug_<name>(*args) for switches that change WHICH kernels a launch runs (fast_bf3, gram_bf3, wgrad_bf3 ...): graphs
+    captured before the call keep the old kernels, so the configuration epoch their keys carry moves on."""
+    global CONFIG_EPOCH
+    CONFIG_EPOCH += 1
+    return getattr(L.lib(), "votenet_debug_" + name)(*args)
 
 
 def set_deterministic(on=True):
@@ -1328,6 +1337,24 @@ def row_segments(rows, segs):
             setattr(arr[i], name + "_off", 0)
     with L.device_guard(dev):
         L.check(L.lib().votenet_row_segments(rows, len(segs), arr, L.stream_ptr()))
+
+
+def copy_segments(pairs):
+    """votenet_copy_segments (csrc/glue.hip): dst.copy_(src) for up to 32 (dst, src) pairs of contiguous device tensors of equal byte size
+    in ONE launch."""
+    arr = (L.CopySegment * len(pairs))()
+    dev = None
+    for i, (dst, src) in enumerate(pairs):
+        nb = dst.numel() * dst.element_size()
+        if not (dst.is_contiguous() and src.is_contiguous() and nb == src.numel() * src.element_size() and dst.device == src.device):
+            raise L.InvalidArgumentError("copy_segments: pair %d: tensors must be contiguous, on one device and of equal byte size (%s <- %s)"
+                                         % (i, tuple(dst.shape), tuple(src.shape)))
+        arr[i].dst, arr[i].src, arr[i].bytes = dst.data_ptr(), src.data_ptr(), nb
+        dev = dst.device
+    if not pairs:
+        return
+    with L.device_guard(dev):
+        L.check(L.lib().votenet_copy_segments(len(pairs), arr, L.stream_ptr()))
 
 
 SUMSQ_SLICES = 32  # VOTENET_SUMSQ_SLICES (include/votenet_hip.h): partial sums per tensor in votenet_clip_adam's scratch

@@ -63,6 +63,129 @@ class GeometryGraph:
         return self.g, {name: done for name in ("sa1", "sa2", "sa3", "sa4", "fp")}
 
 
+STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as ONE HIP graph (StretchGraph)
+STRETCH_SEGMENTS = True  # the stretch as four graphs cut at the modules' ends, weight gradients launched between them (False: one graph, weight gradients inline)
+STRETCH_MAX_GRAPHS = 4   # graphs kept per net (one per ground-truth shape: the padded box count of a batch varies)
+
+
+class _PrivateArena:
+    """`with _PrivateArena(buf, nd):` every zero-initialised scratch request of mlp._StatsArena comes out of `buf` (nd doubles of fp64
+    region, the rest fp32) instead of the step's arena; the enclosing pass's arena state is restored on exit.  The owner clears buf."""
+    FIELDS = ("buf", "nd", "off", "cap32", "off32", "want32", "zeroed32", "depth", "active")
+
+    def __init__(self, buf, nd):
+        self.buf, self.nd = buf, nd
+
+    def __enter__(self):
+        a = M._StatsArena
+        self.saved = {k: getattr(a, k) for k in self.FIELDS}
+        a.buf, a.nd, a.off, a.off32, a.want32 = self.buf, self.nd, 0, 0, 0
+        a.cap32 = a.zeroed32 = (self.buf.numel() - self.nd) * 2
+        a.depth, a.active = 1, True
+        return self
+
+    def __exit__(self, *exc):
+        a = M._StatsArena
+        self.used = (a.off, a.want32)
+        for k, v in self.saved.items():
+            setattr(a, k, v)
+        return False
+
+
+class StretchGraph:
+    """The static stretch of a train step -- feature propagation, voting and the proposal module forward (model.py:48-61,89-93), the
+    moving averages, the loss graph (model.py:61-84,141-231), and the backward pass of all of it down to the gradients of the level
+    outputs: ~85 launches of 5-40 us on static shapes -- captured ONCE and replayed per step.  What it buys is host time: the host
+    enqueued this stretch in 1.7 ms against 1.17 ms of GPU time, i.e. the GPU waited for the host here (tools/probe/stretch_time.py).
+
+    Segments.  The input-gradient chain is captured as FOUR graphs sharing one memory pool, cut where a module's backward ends (proposal |
+    voting | fp2 | fp1); the weight-gradient launches of a segment (14 in all) are not captured but recorded as thunks and run launch by
+    launch on the weight-gradient stream after their segment's graph, beside the next segment -- where they ran before.  (One graph
+    with the weight gradients on a side branch replays its branches concurrently -- tools/probe/graph_branches.py -- but the branch's
+    internal stream shared a hardware queue with the geometry prefetch and the graph waited for the sampling kernel: 3.94 -> 5.8 ms per
+    step; inline on the one branch: 4.27 ms; tools/probe/stretch_modes.py.)
+
+    Inputs arrive at changing addresses (level outputs from the allocator, geometry from a ring of GeometryGraphs, the batch's ground
+    truth): ONE copy launch (votenet_copy_segments) moves them into the graph's fixed input buffers.  Scratch that kernels accumulate
+    into comes from a private arena cleared by a fill node of the first graph.  Outputs (the forward results, the losses, d_l2p / d_l3p /
+    d_l4p) live in the pool: valid until the next replay."""
+
+    def __init__(self, net, ins, tape_levels, arena_demand):
+        dev = net.device
+        self.names = list(ins)
+        self.fixed = {k: torch.empty_like(v) for k, v in ins.items()}
+        nd = (int(arena_demand[0] * 1.25) + 4096 + 1) & ~1
+        n32 = int(arena_demand[1] * 1.25) + (1 << 18)
+        self.nd = nd
+        self.arena = torch.empty(nd + (n32 + 1) // 2, dtype=torch.float64, device=dev)
+        self.segments = []  # (graph, [(thunk, tensors) ...]) in replay order
+        self.replays = 0
+        self.last_used = 0
+        if getattr(net, "_capture_stream", None) is None:
+            net._capture_stream = torch.cuda.Stream(device=dev)
+        cs = net._capture_stream
+        net.store._fresh_wait()  # the wait for this step's W^T copies happens OUTSIDE the graphs (train_step repeats it before a replay)
+        self.copy_inputs(ins)    # (the capture executes nothing; this keeps the buffers defined)
+        import gc
+        torch.cuda.synchronize(dev)
+        gc.collect()
+        pool = torch.cuda.graph_pool_handle()
+        keep, defer = [], []
+        prev = (P.CAPTURE_KEEP, P.CAPTURE_DEFER, P.WGRAD_STREAM)
+        P.CAPTURE_KEEP, P.CAPTURE_DEFER = keep, (defer if STRETCH_SEGMENTS else None)
+        cur = [None]
+
+        def begin():
+            cur[0] = torch.cuda.CUDAGraph()
+            cur[0].capture_begin(pool=pool, capture_error_mode="thread_local")  # thread_local: see GeometryGraph
+
+        def end():
+            cur[0].capture_end()
+            self.segments.append((cur[0], list(defer)))
+            defer.clear()
+            cur[0] = None
+
+        def cut():
+            if STRETCH_SEGMENTS:
+                end()
+                begin()
+        cs.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(cs):
+            begin()
+            try:
+                self.arena.zero_()
+                with _PrivateArena(self.arena, nd) as pa:
+                    self.out, self.losses, self.grads = net._stretch_body(self.fixed, tape_levels, None, cut=cut)
+            finally:
+                if cur[0] is not None:
+                    end()
+                P.CAPTURE_KEEP, P.CAPTURE_DEFER, P.WGRAD_STREAM = prev
+        self.arena_used = pa.used
+        self.keep = keep
+
+    def copy_inputs(self, ins):
+        M.copy_segments([(self.fixed[k], ins[k]) for k in self.names])
+
+    def replay(self, ins, wgrad_stream=None):
+        """One copy launch, then the segments in order; a segment's weight-gradient thunks go to wgrad_stream (None: the current one)
+        behind its graph.  The caller joins the weight-gradient stream (pointnet2.wgrad_join) before it reads the gradient bucket."""
+        self.copy_inputs(ins)
+        prev = P.WGRAD_STREAM
+        P.WGRAD_STREAM = wgrad_stream
+        try:
+            for graph, thunks in self.segments:
+                graph.replay()
+                if thunks and wgrad_stream is not None:
+                    P._hand_over([f for f, _ in thunks], ())  # (their tensors live in the graphs' pool: nothing for the allocator to track)
+                else:
+                    for f, _ in thunks:
+                        f()
+        finally:
+            P.WGRAD_STREAM = prev
+        self.replays += 1
+        return self.out, self.losses, self.grads
+
+
 SPLIT_BF16 = True  # fused GEMMs on bf16 x 3 split operands (fp32-accurate products, six bf16 MFMAs per k-step; mlp.SplitImages)
 
 
@@ -218,6 +341,15 @@ class VoteNetHotPath:
 
     def backbone(self, x, tape=None, overlap=True, next_x=None):
         """model.py:35-50.  x (B,n,3) -> seeds_xyz (B,1024,3), seeds_points (B,1024,256)."""
+        lv, g = self.backbone_levels(x, tape, overlap, next_x)
+        l3_p2 = self.fp1.forward(lv["l3_xyz"], lv["l4_xyz"], lv["l3_p"], lv["l4_p"], tape=tape, geom=g.get("fp1"))
+        seeds_p = self.fp2.forward(lv["l2_xyz"], lv["l3_xyz"], lv["l2_p"], l3_p2, tape=tape, geom=g.get("fp2"))
+        return lv["l2_xyz"], seeds_p
+
+    def backbone_levels(self, x, tape=None, overlap=True, next_x=None):
+        """The four set-abstraction levels of model.py:39-45 (the part of the pass whose row counts depend on the data: the piece layout).
+        -> (dict l2_xyz, l2_p, l3_xyz, l3_p, l4_xyz, l4_p; the geometry dict g with the feature-propagation taps "fp1" / "fp2" and the
+        proposal layer's "prop_fps" when they were computed ahead).  The current stream has waited for all of g."""
         main = torch.cuda.current_stream()
         pf = self._take_prefetched(x)
         if pf is not None:
@@ -253,9 +385,7 @@ class VoteNetHotPath:
         launch_prefetch(4)
         if overlap:
             main.wait_event(ev["fp"])
-        l3_p2 = self.fp1.forward(l3_xyz, l4_xyz, l3_p, l4_p, tape=tape, geom=g.get("fp1"))
-        seeds_p = self.fp2.forward(l2_xyz, l3_xyz, l2_p, l3_p2, tape=tape, geom=g.get("fp2"))
-        return l2_xyz, seeds_p
+        return dict(l2_xyz=l2_xyz, l2_p=l2_p, l3_xyz=l3_xyz, l3_p=l3_p, l4_xyz=l4_xyz, l4_p=l4_p), g
 
     def vote(self, seeds_xyz, seeds_points, tape=None, seeds_copy=None):
         """model.py:53-61: votes = [seeds_xyz, seeds_points] + FC(...).  seeds_copy (b, n, 3): also receives a copy of seeds_xyz (the
@@ -297,23 +427,33 @@ class VoteNetHotPath:
         self.store.refresh_split()  # bf16 x 3 images of the weights as they are NOW (one launch; no-op unless enable_split())
         M.arena_begin(self.device)  # one fill for all BatchNorm statistics of the pass
         try:
-            seeds_xyz, seeds_p = self.backbone(x, tape, next_x=next_x)
-            gg = getattr(self, "_geometry_current", None)
-            seeds_out = None
-            if gg is not None:
-                # the geometry of this pass lives in a graph's fixed buffers, which a later replay overwrites: the tape is stamped with
-                # (graph, generation) so that backward() refuses a tape whose geometry is gone, and the one geometry tensor handed to the
-                # CALLER (seeds_xyz = sa2's centres) leaves the pool as a copy
-                if tape:
-                    tape[0]["geometry_stamp"] = (gg, gg.generation)
-                seeds_out = torch.empty_like(seeds_xyz)
-            v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape, seeds_copy=seeds_out)
-            p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
-            if seeds_out is not None:
-                seeds_xyz = seeds_out
+            lv, g = self.backbone_levels(x, tape, next_x=next_x)
+            self._stamp_tape(tape)
+            out = self._head_forward(lv, g.get("fp1"), g.get("fp2"), g.get("prop_fps"), tape,
+                                     copy_seeds=getattr(self, "_geometry_current", None) is not None)
         finally:
             M.arena_end()
-        return dict(seeds_xyz=seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
+        return out
+
+    def _stamp_tape(self, tape):
+        """The geometry of this pass lives in a GeometryGraph's fixed buffers, which a later replay overwrites: the tape is stamped with
+        (graph, generation) so that backward() refuses a tape whose geometry is gone."""
+        gg = getattr(self, "_geometry_current", None)
+        if gg is not None and tape:
+            tape[0]["geometry_stamp"] = (gg, gg.generation)
+
+    def _head_forward(self, lv, fp1_geom, fp2_geom, prop_fps, tape, copy_seeds=False):
+        """Everything of the forward pass behind the four levels -- feature propagation (model.py:48-49), voting (:53-61), the proposal
+        module (:89-93) -- all of it on static shapes.  copy_seeds: seeds_xyz (= sa2's centres) is handed to the caller as a copy (it
+        lives in a geometry graph's buffers)."""
+        l3_p2 = self.fp1.forward(lv["l3_xyz"], lv["l4_xyz"], lv["l3_p"], lv["l4_p"], tape=tape, geom=fp1_geom)
+        seeds_p = self.fp2.forward(lv["l2_xyz"], lv["l3_xyz"], lv["l2_p"], l3_p2, tape=tape, geom=fp2_geom)
+        seeds_xyz = lv["l2_xyz"]
+        seeds_out = torch.empty_like(seeds_xyz) if copy_seeds else None
+        v_xyz, v_p = self.vote(seeds_xyz, seeds_p, tape, seeds_copy=seeds_out)
+        self._prop_fps = prop_fps
+        p_xyz, p_out = self.propose(v_xyz, v_p, seeds_xyz, tape)
+        return dict(seeds_xyz=seeds_out if seeds_out is not None else seeds_xyz, seeds_points=seeds_p, votes_xyz=v_xyz, votes_points=v_p,
                     proposals_xyz=p_xyz, proposals_output=p_out)
 
     # ---- inference tail: box decode (caller side, torch glue) + 3D NMS (hot path) ------
@@ -476,11 +616,18 @@ class VoteNetHotPath:
                                    "batches have been prefetched)" % (stamp[0].generation - stamp[1], GEOMETRY_RING - 1))
 
     def _backward(self, tape, cot):
-        recs = {i: r for i, r in enumerate(tape)}
-        sa1, sa2, sa3, sa4, fp1, fp2, vote, prop = [recs[i] for i in range(8)]
+        d_l2p, d_l3p, d_l4p = self._head_backward(tape[4:8], cot)
+        self._levels_backward(tape[:4], d_l2p, d_l3p, d_l4p)
+
+    def _head_backward(self, tail, cot, cut=None):
+        """The backward pass of _head_forward (proposal, voting, fp2, fp1): -> the gradients of the level outputs d_l2p, d_l3p, d_l4p.
+        cut: called where a module's backward ends (StretchGraph cuts its segments there)."""
+        fp1, fp2, vote, prop = tail
+        cut = cut if cut is not None else (lambda: None)
         # proposal layer: gradients reach the vote features AND the vote xyz (grouped xyz, gathered centres)
         d_vp, d_vx = self.proposal.backward(prop, cot["proposals_output"], need_feat_grad=True, need_xyz_grad=True)
         P.wgrad_flush()  # the module's weight gradients go to their stream together, underneath the next module's chain
+        cut()
         if cot.get("proposals_xyz") is not None:  # proposals_xyz = gather(votes_xyz, fps_idx), utils.py:42-47: accumulated in place
             d_vx = P.tf_sampling.gather_point_grad_raw(d_vx.shape[1], prop["fps_idx"], cot["proposals_xyz"], into=d_vx.contiguous())
         # voting: votes = x + FC(x), x = [seeds_xyz, seeds_points].  d_votes = [d_vx (+ the loss's pull on the votes) | d_vp | 0]: the
@@ -499,15 +646,21 @@ class VoteNetHotPath:
         d_votes = d_votes_p[:, :259]
         d_in = P.mlp_chain_backward(vote["recs"], d_votes, "plain", need_input_grad=True, g_padded=d_votes_p if padw > 259 else None)
         P.wgrad_flush()
+        cut()
         # d x = d_votes + d_in; only its feature columns go on (the seeds' coordinates carry no gradient in the backbone)
         d_seeds_p = torch.empty((b, n, 256), dtype=torch.float32, device=d_vp.device)
         M.row_segments(rows, [(d_seeds_p.view(rows, 256), d_votes[:, 3:], d_in[:, 3:259])])
         # feature propagation
         d_l2p, d_l3p2 = self.fp2.backward(fp2, d_seeds_p)
         P.wgrad_flush()
+        cut()
         d_l3p, d_l4p = self.fp1.backward(fp1, d_l3p2)
         P.wgrad_flush()
-        # set abstraction (xyz carries no gradient in the backbone: the cloud is the input)
+        return d_l2p, d_l3p, d_l4p
+
+    def _levels_backward(self, levels, d_l2p, d_l3p, d_l4p):
+        """The backward pass of the four levels, sa4 ... sa1 (xyz carries no gradient in the backbone: the cloud is the input)."""
+        sa1, sa2, sa3, sa4 = levels
         g3, _ = self.sa4.backward(sa4, d_l4p)
         P.wgrad_flush()
         d_l3p = P.add_rows(d_l3p, g3)
@@ -533,6 +686,122 @@ class VoteNetHotPath:
                 P.wgrad_fine(False)
         finally:
             P.WGRAD_STREAM = keep_stream
+
+    # ---- the static stretch of a train step as one HIP graph (StretchGraph) -------------------------------------------------------
+    def _stretch_eligible(self, x, cot, gt):
+        from . import tf_interpolate
+        return bool(STRETCH_GRAPH and gt is not None and cot is None and x.is_cuda and not M.DETERMINISTIC and PREFETCH_AFTER < 5
+                    and M.PROFILE_EVENTS is None and P.tf_sampling.PROFILE_EVENTS is None and P.tf_grouping.PROFILE_EVENTS is None
+                    and P._FROZEN.table is None and not getattr(self, "_stretch_off", False)
+                    and not torch.cuda.is_current_stream_capturing())
+
+    @staticmethod
+    def _stretch_inputs(lv, g, gt):
+        """name -> tensor: everything the stretch reads that lives at an address of this step's making."""
+        ins = dict(lv)
+        for name in ("fp1", "fp2"):
+            idx, w = g[name]
+            ins[name + "_idx"], ins[name + "_w"] = idx, w
+            inv = getattr(idx, "_inv", None)
+            if inv is not None:
+                ins[name + "_inv0"], ins[name + "_inv1"] = inv
+        ins["prop_fps"] = g["prop_fps"]
+        for k, v in gt.items():
+            ins["gt/" + k] = v
+        return ins
+
+    def _stretch_body(self, I, tape_levels, wgrad_stream, cut=None):
+        """The stretch on the tensors of I (StretchGraph captures this on its fixed buffers; tests run it eagerly): forward head, moving
+        averages, loss, backward head.  -> (out, losses, (d_l2p, d_l3p, d_l4p))."""
+        from . import loss as VL
+
+        def geom(name):
+            idx = I[name + "_idx"]
+            if name + "_inv0" in I:
+                idx._inv = (I[name + "_inv0"], I[name + "_inv1"])
+            return idx, I[name + "_w"]
+        tail = []
+        lv = {k: I[k] for k in ("l2_xyz", "l2_p", "l3_xyz", "l3_p", "l4_xyz", "l4_p")}
+        out = self._head_forward(lv, geom("fp1"), geom("fp2"), I["prop_fps"], tail, copy_seeds=False)
+        self.update_moving_averages(list(tape_levels) + tail)
+        losses, cot = VL.votenet_loss(out, {k[3:]: v for k, v in I.items() if k.startswith("gt/")})
+        P.WGRAD_STREAM = wgrad_stream
+        try:
+            grads = self._head_backward(tail, cot, cut=cut)
+            if cut is None:
+                P.wgrad_join()
+        finally:
+            P.WGRAD_STREAM = None
+        self._stretch_tail = tail  # (kept: the records own the tensors the captured kernels read)
+        return out, losses, grads
+
+    def _train_step_stretch(self, x, gt, tape, next_x):
+        """train_step's middle with the stretch replayed as a graph: levels forward (launches: their row counts are the data's) ->
+        ONE copy launch + ONE graph launch -> levels backward (launches)."""
+        self.store.refresh_split()
+        lv, g = self.backbone_levels(x, tape, next_x=next_x)
+        self._stamp_tape(tape)
+        if not all(k in g for k in ("fp1", "fp2", "prop_fps")):  # geometry computed without the taps (overlap off): the launch path
+            g = dict(g)
+            g.setdefault("fp1", P.FPModule.geometry(lv["l3_xyz"], lv["l4_xyz"]))
+            g.setdefault("fp2", P.FPModule.geometry(lv["l2_xyz"], lv["l3_xyz"]))
+            g.setdefault("prop_fps", P.tf_sampling.farthest_point_sample(self.proposal.npoint, lv["l2_xyz"]))
+        ins = self._stretch_inputs(lv, g, gt)
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD,
+                                                                             self.overlap_wgrad, STRETCH_SEGMENTS, M.CONFIG_EPOCH)
+        graphs = self.__dict__.setdefault("_stretch_graphs", {})
+        sg = graphs.get(key)
+        self._gsync.begin()
+        if sg is None:
+            # what the stretch asks of the arena does not depend on the ground truth's shape or on library switches: one measurement serves
+            dkey = tuple(e for e in key[:len(ins)] if not e[0].startswith("gt/")) + key[len(ins):-1]
+            demand = self.__dict__.setdefault("_stretch_demand", {}).get(dkey)
+            if demand is None:
+                # first step of this shape: the stretch launch by launch, measuring what it asks of the arena
+                a = M._StatsArena
+                off0, want0 = a.off, a.want32
+                self.check_tape(tape)
+                if self.overlap_wgrad and self._wgrad_stream is None:
+                    self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
+                out, self.last_losses, grads = self._stretch_body(ins, tape, self._wgrad_stream if self.overlap_wgrad else None)
+                self._stretch_demand[dkey] = (a.off - off0, a.want32 - want0)
+                self._backward_levels_pass(tape, grads)
+                return out
+            while len(graphs) >= STRETCH_MAX_GRAPHS:  # the least recently replayed graph (and its pool) goes
+                graphs.pop(min(graphs, key=lambda k: graphs[k].last_used))
+            sg = graphs[key] = StretchGraph(self, ins, tape, demand)
+        self._stretch_clock = getattr(self, "_stretch_clock", 0) + 1
+        sg.last_used = self._stretch_clock
+        self.store._fresh_wait()
+        if self.overlap_wgrad and self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
+        out, self.last_losses, grads = sg.replay(ins, self._wgrad_stream if self.overlap_wgrad else None)
+        self._backward_levels_pass(tape, grads)
+        return out
+
+    def _backward_levels_pass(self, tape, grads):
+        """backward() for the four levels only (the head's gradients given)."""
+        self.check_tape(tape)
+        M.arena_begin(self.device)
+        if self.overlap_wgrad:
+            if self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
+            P.WGRAD_STREAM = self._wgrad_stream
+        try:
+            self._levels_backward(tape[:4], *grads)
+            P.wgrad_join()
+        finally:
+            P.WGRAD_STREAM = None
+            M.arena_end()
+
+    def drop_graphs(self):
+        """Forget every captured graph (geometry rings, stretch graphs): after a configuration change the captures do not key on
+        (library debug switches, hand-edited module state)."""
+        self.__dict__.pop("_stretch_graphs", None)
+        self.__dict__.pop("_stretch_demand", None)
+        self.__dict__.pop("_geometry_rings", None)
+        self.__dict__.setdefault("_prefetched", {}).clear()
+        self._geometry_current = None
 
     def init_optimizer(self, lr=1e-3):
         s = self.store
@@ -563,18 +832,21 @@ class VoteNetHotPath:
         # ONE zero fill for every accumulator and scatter target of the step (mlp._StatsArena): forward() and backward() join it
         M.arena_begin(self.device)
         try:
-            out = self.forward(x, tape, next_x=next_x)
-            self.update_moving_averages(tape)
-            if gt is not None:
-                from . import loss as VL
-                self.last_losses, cot = VL.votenet_loss(out, gt)
             if getattr(self, "_gsync", None) is None:
                 self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))
-            self._gsync.begin()
-            if PREFETCH_AFTER >= 5:  # the next batch's geometry chain under the BACKWARD pass
-                for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
-                    self.prefetch_geometry(nx)
-            self.backward(tape, cot)            # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
+            if self._stretch_eligible(x, cot, gt):
+                out = self._train_step_stretch(x, gt, tape, next_x)
+            else:
+                out = self.forward(x, tape, next_x=next_x)
+                self.update_moving_averages(tape)
+                if gt is not None:
+                    from . import loss as VL
+                    self.last_losses, cot = VL.votenet_loss(out, gt)
+                self._gsync.begin()
+                if PREFETCH_AFTER >= 5:  # the next batch's geometry chain under the BACKWARD pass
+                    for nx in (next_x if isinstance(next_x, (list, tuple)) else ([next_x] if next_x is not None else [])):
+                        self.prefetch_geometry(nx)
+                self.backward(tape, cot)            # world > 1: starts the all-reduce of the bucket's tail after sa3's backward
         finally:
             M.arena_end()
         self.store.invalidate_transposes()      # the optimizer changes W

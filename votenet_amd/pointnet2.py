@@ -189,6 +189,15 @@ class ParamStore:
             self._t_waited = True
         return v
 
+    def _fresh_wait(self):
+        """The current stream waits for this step's derived copies now (a captured stretch must not contain that wait: the event is
+        recorded outside the capture)."""
+        if self.t_event is None and self._tspecs and self.flat is not None and self.flat.is_cuda:
+            self.refresh_transposes()
+        if self.t_event is not None and not self._t_waited:
+            torch.cuda.current_stream().wait_event(self.t_event)
+            self._t_waited = True
+
     def transposed(self, name, lo=0, hi=None):
         """W[lo:hi]^T, contiguous: from the per-step bucket when registered and fresh, else an ad-hoc copy."""
         v = self._fresh((name, lo, hi, "T"))
@@ -479,8 +488,22 @@ _EVENTS = []
 _event_turn = 0
 
 
+# Set to a list while a stretch of the step is being captured into a HIP graph (model.StretchGraph): hand-overs then use fresh events
+# (a captured record must not be mixed with the eager life of a pooled event) and, instead of record_stream -- whose bookkeeping
+# the caching allocator defers during a capture -- every tensor a side-branch kernel reads is kept alive until the capture ends, so that
+# the graph's private pool cannot hand its memory to a later allocation of the main branch.
+CAPTURE_KEEP = None
+# A list while a stretch is being captured in SEGMENTS (model.StretchGraph): a weight-gradient launch is then not captured at all but
+# recorded as (thunk, tensors) -- the owner replays the segment's graph and runs its thunks on the weight-gradient stream afterwards,
+# launch by launch, beside the next segment.  (Captured on a side branch of the graph instead, the branch's internal stream shared a
+# hardware queue with the geometry prefetch: the whole graph then waited for the 1.6 ms sampling kernel -- 3.94 -> 5.8 ms per step.)
+CAPTURE_DEFER = None
+
+
 def _pooled_event():
     global _event_turn
+    if CAPTURE_KEEP is not None:
+        return torch.cuda.Event()
     if len(_EVENTS) < 64:
         _EVENTS.append(torch.cuda.Event())
         return _EVENTS[-1]
@@ -494,8 +517,12 @@ def _hand_over(thunks, tensors):
     ev = _pooled_event()
     ev.record(main)
     WGRAD_STREAM.wait_event(ev)
-    for t in tensors:
-        t.record_stream(WGRAD_STREAM)
+    if CAPTURE_KEEP is not None:
+        CAPTURE_KEEP.extend(tensors)
+        CAPTURE_KEEP.append(thunks)  # (the closures hold what the kernels they launch read)
+    else:
+        for t in tensors:
+            t.record_stream(WGRAD_STREAM)
     # set_stream both ways instead of the `with torch.cuda.stream(...)` context: the context manager looks the current stream up
     # twice on entry and exit (~40 us per hand-over on the host, ~24 hand-overs per step)
     torch.cuda.set_stream(WGRAD_STREAM)
@@ -512,7 +539,9 @@ def on_wgrad_stream(fn, *tensors):
     current stream (now, or together with the module's other weight gradients at the next wgrad_flush()); on the current
     stream when there is no weight-gradient stream."""
     tensors = [t for t in tensors if isinstance(t, torch.Tensor)]
-    if WGRAD_STREAM is None:
+    if CAPTURE_DEFER is not None:
+        CAPTURE_DEFER.append((fn, tensors))
+    elif WGRAD_STREAM is None:
         fn()
     elif WGRAD_BATCH and not _wgrad_fine:
         _wgrad_deferred.append((fn, tensors))
