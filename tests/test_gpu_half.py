@@ -103,7 +103,8 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     assert torch.equal(half.full_rows(half.geo), geo)  # a dropped slot is a copy of slot 0: the expansion IS the full layout
     # ---- forward: layer 1 (assembled loader), layer 2 (pool in the epilogue) with ONE BatchNorm per layer for both layouts
     st0 = M.assemble_stats(P, cntv, wx, mom)
-    bn0 = M.PendingBN(st0, rnd(c0) * 0.2 + 1.0, rnd(c0) * 0.1, rows)
+    gamma0 = rnd(c0) * 0.2 + 1.0
+    bn0 = M.PendingBN(st0, gamma0, rnd(c0) * 0.1, rows)
     z1, st1 = M.assembled_linear(geo, P, wx, w1, None, bn0)
     z1h, st1h = M.assembled_linear(half.geo, P, wx, w1, None, bn0, half=half)
     assert torch.equal(z1h, z1[full])
@@ -167,6 +168,28 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     assert bool((prow_sorted[1:] >= prow_sorted[:-1]).all())
     Sh = M.group_linear_backward_half(half, b, n, P, wx, da0t, coef0, True, dwxh)
     assert relerr(Sh, S) < 1e-5 and relerr(dwxh, dwx) < 1e-4
+    # ---- the same backward of layer 0 DECOMPOSED over the points (round 4): a plain input-gradient GEMM, the masked scatter that
+    # reduces the BatchNorm backward itself, a pass over the points -- against the epilogue reduce + the sorted scatter with the
+    # coefficient vector those sums give (the chain the model ran before)
+    da0p = M.dgrad_bn_half(z1h, coef1, True, w1T, da1h, half)
+    assert relerr(da0p, da0h) < 1e-6  # the same GEMM without the epilogue's reduce
+    bn0v = (bn0.scale, bn0.shift, bn0.mean, bn0.var)
+    dg_ref, db_ref = torch.zeros(c0, device=dev), torch.zeros(c0, device=dev)
+    coef_ref = M.bn_backward_coef(rows, *bn0v, gamma0, sums0h, dg_ref, db_ref)
+    dwx_ref = torch.zeros(3, c0, device=dev)
+    S_ref = M.group_linear_backward_half(half, b, n, P, wx, da0h, coef_ref, True, dwx_ref)
+    for tails in (True, False):  # the coefficient vector from the kernel's tail / from the separate launch
+        prev, M.COEF_TAIL = M.COEF_TAIL, tails
+        try:
+            dg, db, dwx_dec = torch.zeros(c0, device=dev), torch.zeros(c0, device=dev), torch.zeros(3, c0, device=dev)
+            S_dec, coef_dec = M.group_linear_backward_decomposed(half, b, n, P, wx, da0p, bn0v, True, (rows, gamma0, dg, db), cntv_h, mom_h, dwx_dec)
+        finally:
+            M.COEF_TAIL = prev
+        for q in range(3):  # A, B, C (the last two blocks are the layer's scale / shift)
+            assert relerr(coef_dec[q * c0:(q + 1) * c0], coef_ref[q * c0:(q + 1) * c0]) < 2e-5, q
+        assert torch.equal(coef_dec[3 * c0:], coef_ref[3 * c0:])
+        assert relerr(dg, dg_ref) < 2e-5 and relerr(db, db_ref) < 2e-5
+        assert relerr(S_dec, S_ref) < 2e-5 and relerr(dwx_dec, dwx_ref) < 1e-4
     img.close()
 
 

@@ -1,7 +1,8 @@
 """Same-box A/B of the train step for a module-level toggle:  python tools/ab_step.py pointnet2.WGRAD_BATCH 0 1   (scratch tool)"""
 import os, sys, time
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
-from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
+import importlib.util as _iu
+_s = _iu.spec_from_file_location("hp", os.path.join(R, "votenet_amd", "hostpin.py")); hostpin = _iu.module_from_spec(_s); _s.loader.exec_module(hostpin); hostpin.pin(0)  # as bench.py, before torch is imported
 import importlib, torch
 from votenet_amd import loss as VL, model as VM, synth
 modname, attr = sys.argv[1].rsplit(".", 1)

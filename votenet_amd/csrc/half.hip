@@ -459,6 +459,177 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
     }
 }
 
+// ---- the first layer's backward DECOMPOSED over the points (round 4) -------------------------------------------------------------
+// dz0[r] = A g[r] + B + C z0[r] with g = da0 . relu'(bn0(z0)) couples every row to the layer's BatchNorm-backward sums  (sum g, sum g zhat0),
+// which is why the input-gradient GEMM above used to reduce them in its epilogue -- gathering the per-point table P for every element of
+// its tile (half of its wave cycles parked, rocprof MfmaUtil 0.12).  But everything the points and the weights receive is LINEAR in dz0:
+//     S[p]      = sum_{r -> p} dz0[r]       = A Sg[p] + cnt_p B + C (cnt_p P[p] + V_p Wx)            Sg[p] = sum_{r -> p} g[r]
+//     dWx[d]    = sum_r dxyz_d(r) dz0[r]    = A UG[d] + B (sum dxyz_d) + C (sum_p V_p[d] P[p] + (sum dxyz_d dxyz) Wx)     UG[d] = sum_r dxyz_d(r) g[r]
+// with cnt_p / V_p (rows per point, the sum of their dxyz: votenet_assemble_rows_half's cntv) and the moments known from the geometry.
+// So ONE pass over the rows bucketed by point (this kernel: the former scatter pass without its coefficients) leaves Sg, UG and the
+// BatchNorm-backward sums -- it rebuilds z0 for the mask anyway, a point's P row once per run of rows --, the coefficient vector comes
+// out of its tail, a pass over the POINTS (assembled_point_grad_kernel) finishes S, and the GEMM above is a plain one.
+template <int COUT>
+__global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows, const int *__restrict__ order, const float4 *__restrict__ geo,
+                                                                      const float *__restrict__ ptab, const float *__restrict__ wx,
+                                                                      const float *__restrict__ da, const float *__restrict__ scale,
+                                                                      const float *__restrict__ shift, const float *__restrict__ mean,
+                                                                      const float *__restrict__ var, float eps, int relu,
+                                                                      float *__restrict__ sg, float *__restrict__ ug, double *__restrict__ sums,
+                                                                      const int *__restrict__ nh_dev, CoefTail tail)
+{
+    if (nh_dev != nullptr) { // the count is the device's (rows: the caller's upper bound)
+        const long lim = (long)nh_dev[0] * PS;
+        rows = lim < rows ? lim : rows;
+    }
+    constexpr int CPB = 256 / COUT; // chunks per workgroup pass
+    constexpr int CH = 64;          // entries per chunk
+    __shared__ int s_row[CPB][CH];
+    __shared__ float4 s_geo[CPB][CH];
+    __shared__ float red[256][5];
+    const int tid = threadIdx.x;
+    const int ch = tid % COUT, cl = tid / COUT;
+    const float kS = scale[ch], kH = shift[ch], kM = mean[ch], kR = 1.0f / sqrtf(var[ch] + eps);
+    const float wx0 = wx[ch], wx1 = wx[COUT + ch], wx2 = wx[2 * COUT + ch];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, s1 = 0.f, s2 = 0.f;
+    const long nchunk = (rows + CH - 1) / CH;
+    for (long c0 = (long)blockIdx.x * CPB; c0 < nchunk; c0 += (long)gridDim.x * CPB) {
+        lds_barrier(); // the previous pass's records are consumed
+        if (tid < CPB * CH) {
+            const long e = c0 * CH + tid;
+            int r = -1;
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < rows) {
+                r = order[e];
+                g4 = geo[r];
+            }
+            s_row[tid / CH][tid % CH] = r;
+            s_geo[tid / CH][tid % CH] = g4;
+        }
+        lds_barrier();
+        if (c0 + cl >= nchunk) continue;
+        unsigned cur = 0xffffffffu;
+        float acc = 0.0f;
+        bool first = true;
+#pragma unroll 1
+        for (int e0 = 0; e0 < CH; e0 += 8) {
+            float gg[8], zz[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int r = s_row[cl][e0 + u];
+                const int rr = r < 0 ? 0 : r;
+                gg[u] = da[(size_t)rr * COUT + ch];
+                zz[u] = ptab[(size_t)__float_as_uint(s_geo[cl][e0 + u].w) * COUT + ch];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                if (s_row[cl][e0 + u] < 0) continue; // past the end of the list (the last chunk)
+                const float4 g4 = s_geo[cl][e0 + u];
+                const unsigned prow = __float_as_uint(g4.w);
+                if (prow != cur) { // the rows of a point are consecutive: its sum is complete
+                    if (cur != 0xffffffffu) {
+                        if (first) unsafeAtomicAdd(&sg[(size_t)cur * COUT + ch], acc); // may continue the previous chunk's last point
+                        else sg[(size_t)cur * COUT + ch] = acc;
+                        first = false;
+                    }
+                    cur = prow;
+                    acc = 0.0f;
+                }
+                const float z = assembled_z(zz[u], g4, wx0, wx1, wx2);
+                float gq = gg[u];
+                if (relu && !(z * kS + kH > 0.0f)) gq = 0.0f;
+                a0 += g4.x * gq;
+                a1 += g4.y * gq;
+                a2 += g4.z * gq;
+                s1 += gq;
+                s2 += gq * ((z - kM) * kR);
+                acc += gq;
+            }
+        }
+        if (cur != 0xffffffffu) unsafeAtomicAdd(&sg[(size_t)cur * COUT + ch], acc); // may continue in the next chunk
+    }
+    red[tid][0] = a0;
+    red[tid][1] = a1;
+    red[tid][2] = a2;
+    red[tid][3] = s1;
+    red[tid][4] = s2;
+    __syncthreads();
+    if (tid < COUT) {
+        float t[5];
+#pragma unroll
+        for (int d = 0; d < 5; d++) {
+            t[d] = 0.0f;
+            for (int q = 0; q < CPB; q++) t[d] += red[q * COUT + tid][d];
+        }
+#pragma unroll
+        for (int d = 0; d < 3; d++) unsafeAtomicAdd(&ug[(size_t)d * COUT + tid], t[d]);
+        unsafeAtomicAdd(&sums[tid], (double)t[3]);
+        unsafeAtomicAdd(&sums[COUT + tid], (double)t[4]);
+    }
+    coef_tail(tail, gridDim.x, COUT, sums, scale, shift, mean, var, eps);
+}
+
+// S[p, c] = A Sg[p, c] + cnt_p B + C (cnt_p P[p, c] + V_p . Wx[:, c]) in place over Sg (points x COUT), and vp[d, c] += sum_p V_p[d] P[p, c]
+// (what the coordinate rows of the weight gradient still need).  Thread = (point lane, channel); cntv as votenet_assemble_rows leaves it
+// (count, then the dxyz sums in fixed point 2^-32).
+template <int COUT>
+__global__ __launch_bounds__(256) void assembled_point_grad_kernel(long npts, const float *__restrict__ ptab, const long long *__restrict__ cntv,
+                                                                   const float *__restrict__ wx, const float *__restrict__ coef,
+                                                                   float *__restrict__ s, float *__restrict__ vp)
+{
+    constexpr int PPB = 256 / COUT;
+    __shared__ float red[256][3];
+    const int tid = threadIdx.x, ch = tid % COUT, pl = tid / COUT;
+    const float kA = coef[ch], kB = coef[COUT + ch], kC = coef[2 * COUT + ch];
+    const float wx0 = wx[ch], wx1 = wx[COUT + ch], wx2 = wx[2 * COUT + ch];
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+    for (long p = (long)blockIdx.x * PPB + pl; p < npts; p += (long)gridDim.x * PPB) {
+        const long long *cv = cntv + (size_t)p * 4;
+        const long long cn = cv[0];
+        if (cn == 0) continue; // a point no ball contains: Sg is zero there and stays
+        const float fx = (float)((double)cv[1] * (1.0 / 4294967296.0)), fy = (float)((double)cv[2] * (1.0 / 4294967296.0)),
+                    fz = (float)((double)cv[3] * (1.0 / 4294967296.0));
+        const float pv = ptab[(size_t)p * COUT + ch];
+        const float fc = (float)cn;
+        const float zsum = fc * pv + (fx * wx0 + fy * wx1 + fz * wx2);
+        float *sp = s + (size_t)p * COUT + ch;
+        *sp = kA * *sp + fc * kB + kC * zsum;
+        v0 += fx * pv;
+        v1 += fy * pv;
+        v2 += fz * pv;
+    }
+    red[tid][0] = v0;
+    red[tid][1] = v1;
+    red[tid][2] = v2;
+    __syncthreads();
+    if (tid < COUT) {
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            float t = 0.0f;
+            for (int q = 0; q < PPB; q++) t += red[q * COUT + tid][d];
+            unsafeAtomicAdd(&vp[(size_t)d * COUT + tid], t);
+        }
+    }
+}
+
+// dWx[d, c] += A[c] UG[d, c] + B[c] (sum dxyz_d) + C[c] (VP[d, c] + sum_e (sum dxyz_d dxyz_e) Wx[e, c]); moments as assemble_rows leaves them
+// (sum dx, dy, dz, then xx, xy, xz, yy, yz, zz).  One workgroup.
+__global__ __launch_bounds__(256) void assembled_wx_finish_kernel(int cout, const float *__restrict__ coef, const float *__restrict__ ug,
+                                                                  const float *__restrict__ vp, const double *__restrict__ mom,
+                                                                  const float *__restrict__ wx, float *__restrict__ dw_xyz)
+{
+    for (int c = threadIdx.x; c < cout; c += blockDim.x) {
+        const double kA = coef[c], kB = coef[cout + c], kC = coef[2 * cout + c];
+        const double w0 = wx[c], w1 = wx[cout + c], w2 = wx[2 * cout + c];
+        const double m[3][3] = {{mom[3], mom[4], mom[5]}, {mom[4], mom[6], mom[7]}, {mom[5], mom[7], mom[8]}};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+            const double mw = m[d][0] * w0 + m[d][1] * w1 + m[d][2] * w2;
+            dw_xyz[(size_t)d * cout + c] += (float)(kA * ug[(size_t)d * cout + c] + kB * mom[d] + kC * ((double)vp[(size_t)d * cout + c] + mw));
+        }
+    }
+}
+
 // T[c, ch] = MINUS the sum of the total gradients dz0 = A g' + w (B + C z0) over the compact rows of centre c (its first piece at c, the others
 // through pos): what the centre's coordinates receive through dxyz = xyz[idx] - new_xyz.  Thread = (centre, channel).
 template <int COUT>
@@ -603,6 +774,61 @@ extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int
         hipLaunchKernelGGL(group_linear_bwd_sorted_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, wh, P, wx, da, coef, relu,
                            s_points, dw_xyz, nh_dev);
     return check_launch("group_linear_backward_sorted");
+}
+
+// The first layer's backward decomposed over the points, on the piece layout (see group_linear_bwd_masked_kernel): da = the TOTAL
+// gradients per compact row the plain input-gradient GEMM (votenet_mlp_dgrad_bn_half) stored.
+//   votenet_group_linear_backward_masked: one pass over the rows bucketed by point -> sg (points x cout, pre-zeroed) = the scatter of the
+//     MASKED gradient, ug (3 x cout, pre-zeroed) += sum_r dxyz(r)^T g[r], sums (2 cout doubles, pre-zeroed) += (sum g, sum g zhat0): the
+//     BatchNorm-backward sums of the first layer; tail: its coefficient vector from the completed sums (votenet_coef_tail).
+//   votenet_assembled_point_grad: sg -> S in place, vp (3 x cout, pre-zeroed) += sum_p V_p^T P[p].
+//   votenet_assembled_wx_finish: dw_xyz += the coordinate rows of the first layer's weight gradient.
+extern "C" int votenet_group_linear_backward_masked(long nh, int cout, const int *order, const float *geo, const float *P, const float *wx,
+                                                    const float *da, const float *scale, const float *shift, const float *mean,
+                                                    const float *var, float eps, int relu, float *sg, float *ug, double *sums,
+                                                    const votenet_coef_tail *tail, const int *nh_dev, void *stream)
+{
+    VN_REQUIRE(nh > 0 && (cout == 64 || cout == 128 || cout == 256), "group_linear_backward_masked expects nh > 0, cout in {64, 128, 256}");
+    VN_REQUIRE(order && geo && P && wx && da && scale && shift && mean && var && sg && ug && sums, "group_linear_backward_masked: null buffer");
+    VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_masked: geo must be 16-byte aligned");
+    VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "group_linear_backward_masked: incomplete coefficient tail");
+    hipStream_t st = as_stream(stream);
+    const long rows = nh * PS, nchunk = (rows + 63) / 64;
+    const int cpb = 256 / cout;
+    long gx = (nchunk + cpb - 1) / cpb;
+    if (gx > 2048) gx = 2048; // (every workgroup ends in 5 cout atomics on the same addresses: fewer, longer workgroups than the scatter alone wanted)
+    const float4 *g4 = reinterpret_cast<const float4 *>(geo);
+    const CoefTail t = to_tail(tail);
+#define GLBM(C) hipLaunchKernelGGL(group_linear_bwd_masked_kernel<C>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, P, wx, da, scale, \
+                                   shift, mean, var, eps, relu, sg, ug, sums, nh_dev, t)
+    if (cout == 128) GLBM(128);
+    else if (cout == 64) GLBM(64);
+    else GLBM(256);
+#undef GLBM
+    return check_launch("group_linear_backward_masked");
+}
+
+extern "C" int votenet_assembled_point_grad(long npts, int cout, const float *P, const long long *cntv, const float *wx, const float *coef,
+                                            float *s, float *vp, void *stream)
+{
+    VN_REQUIRE(npts > 0 && (cout == 64 || cout == 128 || cout == 256), "assembled_point_grad expects npts > 0, cout in {64, 128, 256}");
+    VN_REQUIRE(P && cntv && wx && coef && s && vp && (uintptr_t)cntv % 16 == 0, "assembled_point_grad: null / unaligned buffer");
+    hipStream_t st = as_stream(stream);
+    const int ppb = 256 / cout;
+    long gx = (npts + ppb * 8 - 1) / (ppb * 8);
+    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    if (cout == 128) hipLaunchKernelGGL(assembled_point_grad_kernel<128>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
+    else if (cout == 64) hipLaunchKernelGGL(assembled_point_grad_kernel<64>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
+    else hipLaunchKernelGGL(assembled_point_grad_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
+    return check_launch("assembled_point_grad");
+}
+
+extern "C" int votenet_assembled_wx_finish(int cout, const float *coef, const float *ug, const float *vp, const double *moments,
+                                           const float *wx, float *dw_xyz, void *stream)
+{
+    VN_REQUIRE(cout > 0 && coef && ug && vp && moments && wx && dw_xyz, "assembled_wx_finish: bad arguments");
+    hipLaunchKernelGGL(assembled_wx_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), cout, coef, ug, vp, moments, wx, dw_xyz);
+    return check_launch("assembled_wx_finish");
 }
 
 extern "C" int votenet_half_centre_sums(long G, int cout, const int *pos, const float *geo, const float *wh, const float *P, const float *wx,

@@ -1251,6 +1251,31 @@ extern "C" int votenet_mlp_dgrad_bn(long rows, int c, int cout, const float *da,
     return check_launch("mlp_dgrad_bn");
 }
 
+// votenet_mlp_dgrad_bn (dense upstream gradient) on the piece layout (half.hip): da / da_prev are TOTAL gradients per compact row, the
+// affine part B + C z of the rebuilt dz is scaled by wh on the rows that stand for dropped pieces (SRC 5); rows: the caller's upper
+// bound when nh_dev (the device's piece count) is given.  A plain GEMM: nothing but the store in its epilogue.
+extern "C" int votenet_mlp_dgrad_bn_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
+                                         const float *wT, float *da_prev, const float *wh, const int *nh_dev, void *stream)
+{
+    VN_REQUIRE(rows > 0 && c > 0 && cout > 0, "mlp_dgrad_bn_half expects rows > 0, c > 0, cout > 0");
+    VN_REQUIRE(da && zsrc && coef && wT && da_prev && wh, "mlp_dgrad_bn_half: null buffer");
+    FastArgs a = {};
+    a.da = da;
+    a.zsrc = zsrc;
+    a.coef = coef;
+    a.src_relu = relu;
+    a.rows = rows;
+    a.cin = c;
+    a.cout = cout;
+    a.w = wT;
+    a.z = da_prev;
+    a.wh = wh;
+    a.nh_dev = nh_dev;
+    if (!fast_dispatch<5, 1>(a, as_stream(stream)))
+        return set_error(VOTENET_E_INVALID_ARGUMENT, "mlp_dgrad_bn_half: shape not served (rows %% 128 == 0, c %% 32 == 0, cout %% 64 == 0, 16-byte aligned buffers)");
+    return check_launch("mlp_dgrad_bn_half");
+}
+
 // The same GEMM whose epilogue also reduces the BatchNorm backward of the layer BELOW (the one whose activation da_prev is the
 // gradient of): sums[0:cout] += sum da_prev', sums[cout:2cout] += sum da_prev' * zhat_prev -- votenet_bn_backward_reduce(rows,
 // cout, 0, da_prev, NULL, z_prev, ...) without the pass over da_prev and z_prev of its own.  sums (2*cout doubles) is zeroed by

@@ -63,9 +63,11 @@ class _StatsArena:
     zeroed32 = 0      # floats of the fp32 region this pass's fill cleared
     depth = 0
     active = False
+    whole_step = False  # the pass that owns the arena spans forward AND backward (train_step, a captured stretch): a buffer the forward pass
+    #                     fills may then be read by the backward pass (forward() and backward() on their own each clear the arena)
 
 
-def arena_begin(device, ndoubles=1 << 17):
+def arena_begin(device, ndoubles=1 << 17, whole_step=False):
     a = _StatsArena
     if a.active and a.buf is not None and a.buf.device == device:
         a.depth += 1  # a pass inside a pass (forward / backward inside train_step): one fill for both
@@ -80,6 +82,7 @@ def arena_begin(device, ndoubles=1 << 17):
     a.off = a.off32 = a.want32 = 0
     a.depth = 1
     a.active = True
+    a.whole_step = bool(whole_step)
 
 
 def arena_end():
@@ -88,6 +91,7 @@ def arena_end():
     if a.depth <= 0:
         a.active = False
         a.depth = 0
+        a.whole_step = False
 
 
 def _zeros_f64(n, device):
@@ -614,7 +618,9 @@ def assemble_rows_half(xyz, new_xyz, idx, pts_cnt, half):
     # ONE zero-filled buffer: the per-point counters (b n x 4 int64), the moments (9 f64) and the rows-per-point counts of the bucketing
     npts = b * n
     nz = npts * 4 + 16 + (npts + 1) // 2
-    if half.nh_limit is not None:  # geometry made inside the pass it serves (the proposal module): the pass's one zero fill covers it
+    if half.nh_limit is not None and _StatsArena.active and _StatsArena.whole_step:
+        # geometry made inside the pass it serves (the proposal module): the pass's one zero fill covers it -- when that pass spans the
+        # backward too, which reads cntv and the moments again (the first layer's backward decomposed over the points)
         zero = _zeros_i64((nz,), xyz.device)
     else:                          # computed ahead, on a geometry stream, for a later pass: its own fill
         zero = torch.zeros(nz, dtype=torch.int64, device=xyz.device)
@@ -673,6 +679,54 @@ def group_linear_backward_half(half, b, n, P, wx, da, coef, relu, dw_xyz):
                                                              L.ptr(wx), L.ptr(da), L.ptr(coef), 1 if relu else 0, L.ptr(S), L.ptr(dw_xyz),
                                                              L.ptr(half.nh_limit), L.stream_ptr()))
     return S
+
+
+def dgrad_bn_half(z, coef, relu, wT, da, half):
+    """votenet_mlp_dgrad_bn_half: da_prev (rows, cout) = dz wT with dz rebuilt from (da, z, coef) on the piece layout (totals; the affine
+    part weighted by half.wh) -- a plain GEMM, nothing in its epilogue but the store."""
+    rows, c = z.shape
+    cout = wT.shape[1]
+    out = torch.empty((rows, cout), dtype=torch.float32, device=z.device)
+    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn half"), limit=half):
+        L.check(L.lib().votenet_mlp_dgrad_bn_half(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT), L.ptr(out),
+                                                  L.ptr(half.wh), L.ptr(half.nh_limit), L.stream_ptr()))
+    return out
+
+
+def group_linear_backward_decomposed(half, b, n, P, wx, da, bn, relu, tail, cntv, mom, dw_xyz, eps=BN_EPS, defer=None):
+    """The first layer's backward decomposed over the points (csrc/half.hip: group_linear_bwd_masked_kernel): da = the total gradients per
+    compact row of the layer's ACTIVATION (what votenet_mlp_dgrad_bn_half stored); bn = (scale, shift, mean, var) of the layer; tail as
+    _coef_tail takes it.  -> (S (b, n, cout), coef of the layer).  dw_xyz += the coordinate rows of the weight gradient (a one-workgroup
+    launch handed to defer(fn, *tensors) -- pointnet2.on_wgrad_stream -- when given: it is not on the chain)."""
+    cout = P.shape[1]
+    dev = P.device
+    if getattr(half, "order", None) is None:
+        half_sort_rows(half, b * n)
+    sc, sh, me, va = bn
+    S = _zeros_f32((b, n, cout), dev)
+    small = _zeros_f32((6, cout), dev)  # ug (3, cout) | vp (3, cout)
+    ug, vp = small[:3], small[3:]
+    sums = _zeros_f64(2 * cout, dev)
+    t, coef = _coef_tail(tail, cout, dev)
+    with L.device_guard(dev):
+        L.check(L.lib().votenet_group_linear_backward_masked(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(P), L.ptr(wx), L.ptr(da),
+                                                             L.ptr(sc), L.ptr(sh), L.ptr(me), L.ptr(va), eps, 1 if relu else 0, L.ptr(S),
+                                                             L.ptr(ug), L.ptr(sums), ctypes.byref(t) if t is not None else None,
+                                                             L.ptr(half.nh_limit), L.stream_ptr()))
+        if coef is None:
+            coef = _coef_after(tail, bn, sums, eps)
+        L.check(L.lib().votenet_assembled_point_grad(b * n, cout, L.ptr(P), L.ptr(cntv), L.ptr(wx), L.ptr(coef), L.ptr(S), L.ptr(vp),
+                                                     L.stream_ptr()))
+
+    def finish():
+        with L.device_guard(dev):
+            L.check(L.lib().votenet_assembled_wx_finish(cout, L.ptr(coef), L.ptr(ug), L.ptr(vp), L.ptr(mom), L.ptr(wx), L.ptr(dw_xyz),
+                                                        L.stream_ptr()))
+    if defer is not None:
+        defer(finish, coef, small, mom)
+    else:
+        finish()
+    return S, coef
 
 
 def half_centre_sums(half, P, wx, da, coef, relu):

@@ -71,7 +71,7 @@ STRETCH_MAX_GRAPHS = 4   # graphs kept per net (one per ground-truth shape: the 
 class _PrivateArena:
     """`with _PrivateArena(buf, nd):` every zero-initialised scratch request of mlp._StatsArena comes out of `buf` (nd doubles of fp64
     region, the rest fp32) instead of the step's arena; the enclosing pass's arena state is restored on exit.  The owner clears buf."""
-    FIELDS = ("buf", "nd", "off", "cap32", "off32", "want32", "zeroed32", "depth", "active")
+    FIELDS = ("buf", "nd", "off", "cap32", "off32", "want32", "zeroed32", "depth", "active", "whole_step")
 
     def __init__(self, buf, nd):
         self.buf, self.nd = buf, nd
@@ -81,7 +81,7 @@ class _PrivateArena:
         self.saved = {k: getattr(a, k) for k in self.FIELDS}
         a.buf, a.nd, a.off, a.off32, a.want32 = self.buf, self.nd, 0, 0, 0
         a.cap32 = a.zeroed32 = (self.buf.numel() - self.nd) * 2
-        a.depth, a.active = 1, True
+        a.depth, a.active, a.whole_step = 1, True, True
         return self
 
     def __exit__(self, *exc):
@@ -747,7 +747,7 @@ class VoteNetHotPath:
             g.setdefault("fp2", P.FPModule.geometry(lv["l2_xyz"], lv["l3_xyz"]))
             g.setdefault("prop_fps", P.tf_sampling.farthest_point_sample(self.proposal.npoint, lv["l2_xyz"]))
         ins = self._stretch_inputs(lv, g, gt)
-        key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD,
+        key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
                                                                              self.overlap_wgrad, STRETCH_SEGMENTS, M.CONFIG_EPOCH)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
@@ -830,7 +830,7 @@ class VoteNetHotPath:
         self.store.refresh_transposes(self._side_stream())
         tape = []
         # ONE zero fill for every accumulator and scatter target of the step (mlp._StatsArena): forward() and backward() join it
-        M.arena_begin(self.device)
+        M.arena_begin(self.device, whole_step=True)
         try:
             if getattr(self, "_gsync", None) is None:
                 self._gsync = dp.GradSync(self.store, self.store.offset_of("sa3/"))

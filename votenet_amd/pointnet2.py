@@ -331,6 +331,11 @@ POOL_IN_EPILOGUE = True
 # Backward of that pooled layer in Gram form (pool_bwd.hip): both GEMMs contract over cin x cin instead of cin x cout and z
 # of the layer is neither stored nor read.  False = votenet_mlp_wgrad_bn / votenet_mlp_dgrad_bn on the stored z.
 POOL_GRAM_BACKWARD = True
+# Backward of an ASSEMBLED first layer on the piece layout decomposed over the points (csrc/half.hip, round 4): the input-gradient GEMM of
+# the layer above is a plain one (no epilogue gathers of the per-point table), the pass over the rows bucketed by point reduces the
+# first layer's BatchNorm backward and scatters the MASKED gradient, a pass over the points finishes S.  False = the epilogue reduce
+# (votenet_assembled_dgrad_bn_reduce_half) + votenet_group_linear_backward_sorted.
+ASSEMBLED_DECOMPOSED = True
 # Inference mode of every BatchNorm (model.py:98-139 runs with is_training=False): dict layer name -> mlp.FrozenBN built from the
 # moving averages (VoteNetHotPath.inference_bn); None = training mode (batch statistics).
 class _FrozenBN(threading.local):
@@ -390,7 +395,8 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             P, _ = M.linear_dense(feat.reshape(bb * nn, cc), w[3:], b, want_stats=False)
             zn = None
             st = M.assemble_stats(P, cntv, w[:3], mom) if (L.bn and _FROZEN.table is None) else None
-            rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3], half=half)
+            rec = dict(layer=L, kind="assembled", xyz=xyz, new_xyz=new_xyz, feat=feat, idx=idx, geo=geo, P=P, wx=w[:3], half=half,
+                       cntv=cntv, mom=mom)
         elif i == 1 and first[0] == "assembled":
             r0 = tape[-1]
             zn, st = M.assembled_linear(r0["geo"], r0["P"], r0["wx"], w, b, pend, prev_relu, want_stats=L.bn, half=r0["half"])
@@ -644,6 +650,13 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 geo, Pt, wx, half = r0["geo"], r0["P"], r0["wx"], r0["half"]
                 on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.assembled_wgrad_bn(
                     geo, Pt, wx, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W"), half=half), geo, Pt, z, coef, da)
+                if ASSEMBLED_DECOMPOSED and half is not None and r0["layer"].bn and r0.get("cntv") is not None:
+                    # the first layer's backward decomposed over the points (csrc/half.hip): a PLAIN input-gradient GEMM here -- no epilogue
+                    # that gathers the per-point table --; the pass over the rows bucketed by point that follows (SAModule.
+                    # _first_layer_backward) reduces the first layer's BatchNorm backward itself
+                    da = M.dgrad_bn_half(z, coef, L.relu, L.wT(), da, half)
+                    return dict(da=da, decomposed=True, relu=r0["layer"].relu, tail=tail_of(r0),
+                                bn=(r0["scale"], r0["shift"], r0["mean"], r0["var"]))
                 da, coef_ahead = M.assembled_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, geo, Pt, wx,
                                                               (r0["scale"], r0["shift"], r0["mean"], r0["var"], r0["layer"].relu),
                                                               below_tail=tail_of(r0), half=half)
@@ -908,7 +921,13 @@ class SAModule:
                 S, _, _ = M.group_concat_grad(dz, None, idx, pts_cnt, n, cout)
         elif r0["kind"] == "assembled" and r0.get("half") is not None:
             half = r0["half"]
-            S, dz = M.group_linear_backward_half(half, b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
+            if h.get("decomposed"):
+                S, coef0 = M.group_linear_backward_decomposed(half, b, n, r0["P"], r0["wx"], h["da"], h["bn"], h["relu"], h["tail"],
+                                                              r0["cntv"], r0["mom"], gW[:3], defer=on_wgrad_stream)
+                h = dict(h, coef=coef0)
+                dz = None
+            else:
+                S, dz = M.group_linear_backward_half(half, b, n, r0["P"], r0["wx"], h["da"], h["coef"], h["relu"], gW[:3]), None
             if need_xyz_grad:
                 # dz0 W[0:3]^T is linear in dz0: the points receive S W[0:3]^T, a centre minus the sum of its rows' dz0 times W[0:3]^T
                 d_xyz = M.rows_dot3(S.view(b * n, cout), W[:3]).view(b, n, 3)
