@@ -807,6 +807,18 @@ int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int k0, const 
                                         const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
                                         const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
                                         double *ug, const votenet_coef_tail *tail /* may be NULL */, const float *wh, void *stream);
+/* The narrow first layer's ReLU mask recorded by the FORWARD pass (round 4): votenet_narrow_linear_masked is votenet_narrow_linear(_half)
+ * (wh may be NULL) that also writes mask (rows x c0 / 16 16-bit words, 8-byte aligned, c0 % 64 == 0): bit k % 16 of word [row][k / 16] =
+ * [relu(bn0(z0[row, k])) > 0]; votenet_narrow_dgrad_bn_reduce_masked is votenet_narrow_dgrad_bn_reduce_half reading that mask instead of
+ * rebuilding z0 per accumulator element, with sums[c0:2 c0] derived in the (required) coefficient tail from ug and sums[0:c0] -- z0 is
+ * linear in u: sum g z0[:, c] = sum_d W0[d, c] ug[d, c] + b0[c] sum g.  (utils.py:125-127 is the loop whose backward this is.) */
+int votenet_narrow_linear_masked(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                 const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w,
+                                 const float *bias, float *z, double *stats, const float *wh, unsigned short *mask, void *stream);
+int votenet_narrow_dgrad_bn_reduce_masked(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef, int relu,
+                                          const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
+                                          const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
+                                          double *ug, const votenet_coef_tail *tail, const float *wh, const void *mask, void *stream);
 #ifdef __cplusplus
 }
 #endif

@@ -291,6 +291,26 @@ def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev,
     assert float(((sums_h - sums).abs() / (scale + 1e-30)).max()) < 1e-5
     uscale = (u8.double().abs().t() @ da0.abs())
     assert float(((ug_h - ug).abs() / (uscale + 1e-30)).max()) < 1e-5
+    # ---- round 4: the first layer's ReLU mask recorded by the forward GEMM and read by the input-gradient epilogue (EPI 7) instead of a
+    # rebuild of z0 per accumulator element; the second BatchNorm-backward sum derived in the coefficient tail from ug and the first
+    z1m, st1m, mask = M.narrow_linear(half.u8, w0, b0, w1, None, bn0, half=half, want_mask=True)
+    assert torch.equal(z1m, z1h) and torch.equal(st1m, st1h)
+    z0h = M.narrow_z0(half.u8, w0, b0)
+    act = (torch.clamp_min(z0h * bn0.scale + bn0.shift, 0.0) > 0)  # the loader's own test: relu(bn0(z0)) > 0
+    bits = torch.arange(16, device=dev)
+    want = (act.view(half.rows, c0 // 16, 16).long() << bits).sum(-1)
+    assert torch.equal(mask.long() & 0xffff, want)
+    gamma0 = rnd(c0) * 0.2 + 1.0
+    ref_dg, ref_db = torch.zeros(c0, device=dev), torch.zeros(c0, device=dev)
+    coef_ref, ug_ref = M.narrow_dgrad_bn_reduce(z1h, coef1, True, w1T, da1h, half.u8, w0, b0, below0, tail=(rows, gamma0, ref_dg, ref_db), half=half)
+    dg, db = torch.zeros(c0, device=dev), torch.zeros(c0, device=dev)
+    coef_m, ug_m = M.narrow_dgrad_bn_reduce(z1h, coef1, True, w1T, da1h, half.u8, w0, b0, below0, tail=(rows, gamma0, dg, db), half=half, mask=mask)
+    assert float(((ug_m - ug_ref).abs() / (uscale + 1e-30)).max()) < 1e-5
+    assert torch.equal(coef_m[3 * c0:], coef_ref[3 * c0:])
+    # A, B, C follow from the sums: hold them to the sums' own scale (B, C divide differences of large sums)
+    for q in range(3):
+        assert relerr(coef_m[q * c0:(q + 1) * c0], coef_ref[q * c0:(q + 1) * c0]) < 1e-4, q
+    assert relerr(dg, ref_dg) < 1e-4 and relerr(db, ref_db) < 1e-4
     img.close()
 
 

@@ -201,6 +201,9 @@ _SIGS.update({
     "votenet_assembled_wx_finish": [_I] + [_c_f] * 6 + [ctypes.c_void_p],
     "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_narrow_rows_half": [_I] * 4 + [_c_f] * 9 + [ctypes.c_void_p],
+    "votenet_narrow_linear_masked": [_L, _I, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 6 + [ctypes.c_void_p],
+    "votenet_narrow_dgrad_bn_reduce_masked": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 8 + [_F, _I, _c_f, _c_f, ctypes.POINTER(CoefTail),
+                                              _c_f, _c_f, ctypes.c_void_p],
     "votenet_narrow_linear_half": [_L, _I, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_narrow_wgrad_bn_half": [_L, _I, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, ctypes.c_void_p],
     "votenet_narrow_dgrad_bn_reduce_half": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 8 + [_F, _I, _c_f, _c_f, ctypes.POINTER(CoefTail),

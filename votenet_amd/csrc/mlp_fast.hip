@@ -87,6 +87,13 @@ constexpr int FG_LDA = FG_BM + 2;
 //   EPI 4: EPI 3 for a narrow layer below: z_prev is rebuilt from u8 (staged per tile in LDS by the loader), the epilogue also
 //          accumulates UG[d,c] = sum_r u[r,d] da'[r,c] (the data term of that layer's weight gradient) and stores NOTHING
 //          (cout <= 128: the layer below's width)
+//   EPI 7: EPI 4 without the rebuild of z_prev (round 4).  Per accumulator element EPI 4 spends 8 fmas on z_prev, 4 on the mask, 3 on
+//          s2 and 8 on UG -- twice the cycles of the tile's MFMAs, 256 VGPRs and 26 spilled (108 bytes of scratch per lane: the
+//          129.5 MB per launch rocprof saw written by a kernel that stores nothing).  Here the ReLU mask of the narrow layer comes from
+//          the FORWARD pass (SRC 3 records, per row and slab, the 16 bits [relu(bn0(z0)) > 0]: mask_out; one u64 per row and 64-column
+//          block here: mask_in, staged per tile in LDS beside the u rows), and s2 = sum da' zhat_prev is not accumulated at all: z_prev
+//          is LINEAR in u, so sum da' z_prev[:, c] = sum_d W0[d, c] UG[d, c] + b0[c] s1[c], which the coefficient tail evaluates once
+//          per column from the completed sums (needs tail.ticket).  Per element: a bit test, s1, 8 fmas.
 struct FastArgs {
     const float *x, *in_scale, *in_shift;
     BnRaw in_raw; // alternative to in_scale / in_shift: derived here from the producer's raw sums
@@ -110,7 +117,9 @@ struct FastArgs {
     const float *geo, *ptab, *wx; // SRC 4: geo (rows x 4 floats), P (points x cin), Wx (3 x cin)
     const float *u8, *w0, *b0; // SRC 3 / EPI 4: rows x 8 floats, W0 (k0 x c0), b0 (c0, may be NULL); c0 = cin (SRC 3) or cout (EPI 4)
     int k0;
-    double *ug;                // EPI 4: [8][cout] doubles
+    double *ug;                // EPI 4 / 7: [8][cout] doubles
+    unsigned short *mask_out;  // SRC 3 (may be NULL): rows x (cin / 16) words, bit k % 16 of word [row][k / 16] = [relu(bn0(z0[row, k])) > 0]
+    const unsigned long long *mask_in; // EPI 7: the same array read as rows x (cout / 64) u64
     CoefTail tail;             // EPI 3 / 4: the layer below's coefficient vector from the completed sums (last workgroup, common.h)
     // piece layout (half.hip): rows come in pieces of kPiece = 16, wh[row / 16] = the weight of the piece's row 0 (a ball's slot 0 also
     // stands for its dropped all-copy pieces; 1 for every other piece).  EPI 0 / 2: the statistics count that row wh times; SRC 5: the
@@ -143,12 +152,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     __shared__ __attribute__((aligned(16))) unsigned As3[BF3 ? 2 : 1][3][2][BF3 ? PLA : 4];
     __shared__ __attribute__((aligned(16))) unsigned Bs3[BF3 ? 2 : 1][3][2][BF3 ? PLB : 4];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
-    constexpr bool REDUCE_BELOW = (EPI == 3 || EPI == 4 || EPI == 6);
+    constexpr bool NEPI = (EPI == 4 || EPI == 7); // the layer below is a NARROW one
+    constexpr bool REDUCE_BELOW = (EPI == 3 || NEPI || EPI == 6);
     __shared__ float Eco[REDUCE_BELOW ? 4 : 1][REDUCE_BELOW ? BN : 1]; // EPI 3/4/6: scale, shift, mean, 1/std of this column block
     constexpr bool NARROW = (SRC == 3 || EPI == 4);
     __shared__ __attribute__((aligned(16))) float W0s[NARROW ? 9 : 1][NARROW ? 128 : 1]; // W0 rows 0..7 (zero padded) and b0: SRC 3 by input channel, EPI 4 by column of this block
     __shared__ __attribute__((aligned(16))) float Wxs[SRC == 4 ? 3 : 1][SRC == 4 ? 512 : 1];             // SRC 4: W[0:3] by input channel
-    __shared__ __attribute__((aligned(16))) float Us[EPI == 4 ? 2 : 1][EPI == 4 ? FG_BM : 1][8];
+    __shared__ __attribute__((aligned(16))) float Us[NEPI ? 2 : 1][NEPI ? FG_BM : 1][8];
+    __shared__ __attribute__((aligned(8))) uint2 Ms[EPI == 7 ? 2 : 1][EPI == 7 ? FG_BM : 1]; // EPI 7: the tile's mask rows (the 64 columns of this block)
     __shared__ __attribute__((aligned(16))) float4 Gs[EPI == 6 ? 2 : 1][EPI == 6 ? FG_BM : 1]; // EPI 6: geo rows of the tile, by tile parity // EPI 4: u rows of the tile, double-buffered by tile parity
 
     const long rows = A.rows;
@@ -235,7 +246,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const size_t a_tile_jump = (SRC == 3) ? (size_t)tstride * FG_BM * 8 : (size_t)tstride * FG_BM * cin - cin; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
-    const float *pu = (EPI == 4) ? A.u8 + ((size_t)tile0 * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4
+    const uint2 *pm = (EPI == 7) ? reinterpret_cast<const uint2 *>(A.mask_in) + ((size_t)tile0 * FG_BM + (tid & 127)) * (cout / 64) + n0 / 64 : nullptr;
+    const float *pu = NEPI ? A.u8 + ((size_t)tile0 * FG_BM + (tid >> 1)) * 8 + (tid & 1) * 4
                       : (EPI == 6) ? A.geo + ((size_t)tile0 * FG_BM + (tid & 127)) * 4 : nullptr; // EPI 6: both halves of the workgroup fetch the row's record (no load under a branch)
     int ltp = 0; // parity of the tile being LOADED
     // SRC 4: the geo cursor runs ONE SLAB AHEAD of the operand cursor (qn = the geo of this thread's two rows of the slab the next
@@ -293,6 +305,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         int tp;        //        and the tile's parity
         float4 dq0, dq1; // SRC 4: geo of the two rows (dxyz used when the slab goes to LDS)
         float mu0, mu1;  // SRC 5: weights of the two rows' pieces
+        uint2 mq;        // EPI 7: the mask words of tile row tid & 127
+        int row;         // SRC 3: the global row of a0 (a1: + 64), for mask_out
     };
     constexpr int NSETS = BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
     Regs R[NSETS];
@@ -343,10 +357,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
             for (int u = 0; u < NB4; u++) r.b[u] = *reinterpret_cast<const float4 *>(pb[u]);
         }
-        if (EPI == 4 || EPI == 6) {
+        if (NEPI || EPI == 6) {
             r.uq = *reinterpret_cast<const float4 *>(pu);
             r.tp = ltp;
         }
+        if (EPI == 7) r.mq = *pm;
+        if (SRC == 3) r.row = (int)((pa0 - A.u8) >> 3);
         r.k = kq;
         if constexpr (BF3) {
             // the same cursor movement as below without a branch (scalar selects): the slab body stays ONE basic block, which is
@@ -358,10 +374,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             pa1 += astep;
             wvo += adv ? (wrap ? w3_slab - w3_slab * (unsigned)nk : w3_slab) : 0u;
             lkt = wrap ? 0 : (adv ? lkt + 1 : lkt);
-            if (EPI == 4 || EPI == 6) {
-                pu += wrap ? (size_t)tstride * FG_BM * (EPI == 4 ? 8 : 4) : 0;
+            if (NEPI || EPI == 6) {
+                pu += wrap ? (size_t)tstride * FG_BM * (NEPI ? 8 : 4) : 0;
                 ltp ^= wrap ? 1 : 0;
             }
+            if (EPI == 7) pm += wrap ? (size_t)tstride * FG_BM * (cout / 64) : 0;
             if (SRC == 5) pw += wrap ? (size_t)tstride * (FG_BM / kPiece) : 0;
             if (SRC == 2) {
                 const long dg = wrap ? (long)tstride * FG_BM / pk : 0;
@@ -383,10 +400,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 lkt = 0;
                 pa0 += a_tile_jump;
                 pa1 += a_tile_jump;
-                if (EPI == 4 || EPI == 6) {
-                    pu += (size_t)tstride * FG_BM * (EPI == 4 ? 8 : 4);
+                if (NEPI || EPI == 6) {
+                    pu += (size_t)tstride * FG_BM * (NEPI ? 8 : 4);
                     ltp ^= 1;
                 }
+                if (EPI == 7) pm += (size_t)tstride * FG_BM * (cout / 64);
                 if (SRC == 5) pw += (size_t)tstride * (FG_BM / kPiece);
 #pragma unroll
                 for (int u = 0; u < NB4; u++) pb[u] -= b_wrap;
@@ -496,6 +514,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (BF3 && (BF3_ABL & 8) && !abl_prologue) return;
         const float4 v0 = act4(r.a0, SRC == 4 ? r.dq0 : r.g0, r.m0, r.ro0, r.k, (SRC == 5 && sel31) ? r.mu0 : 1.0f),
                      v1 = act4(r.a1, SRC == 4 ? r.dq1 : r.g1, r.m1, r.ro1, r.k, (SRC == 5 && sel31) ? r.mu1 : 1.0f);
+        if (SRC == 3 && A.mask_out != nullptr) {
+            // the ReLU mask of the narrow layer for the backward pass (EPI 7): this thread's four channels of its two rows; the four
+            // threads of a row (a_kq = tid & 3: adjacent lanes) OR their nibbles into the slab's 16-bit word and all four store it
+            // (same address, same value: no store under a lane-dependent branch)
+            const unsigned m0 = (v0.x > 0.f ? 1u : 0u) | (v0.y > 0.f ? 2u : 0u) | (v0.z > 0.f ? 4u : 0u) | (v0.w > 0.f ? 8u : 0u);
+            const unsigned m1 = (v1.x > 0.f ? 1u : 0u) | (v1.y > 0.f ? 2u : 0u) | (v1.z > 0.f ? 4u : 0u) | (v1.w > 0.f ? 8u : 0u);
+            unsigned mm = (m0 | (m1 << 16)) << (4 * a_kq);
+            mm |= __shfl_xor(mm, 1);
+            mm |= __shfl_xor(mm, 2);
+            const size_t wo = (size_t)r.row * nk + (r.k >> 4);
+            A.mask_out[wo] = (unsigned short)(mm & 0xffffu);
+            A.mask_out[wo + (size_t)64 * nk] = (unsigned short)(mm >> 16);
+        }
         if constexpr (BF3) {
             unsigned h[4], m[4], l[4];
             split3(v0.x, v0.y, h[0], m[0], l[0]);
@@ -514,7 +545,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 if constexpr (BN == 128) *reinterpret_cast<uint4 *>(&Bs3[buf][u][b3_pl][b3_c * 4]) = r.bq[u];
                 else *reinterpret_cast<uint2 *>(&Bs3[buf][u][b3_pl][b3_c * 4 + b3_h * 2]) = make_uint2(r.bq[u].x, r.bq[u].y);
             }
-            if (EPI == 4) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+            if (NEPI) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+            if (EPI == 7) Ms[r.tp][tid & 127] = r.mq;
             if (EPI == 6) Gs[r.tp][tid & 127] = r.uq;
             return;
         }
@@ -531,16 +563,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             const int f = tid + u * 256;
             *reinterpret_cast<float4 *>(&Bs[buf][f / (BN / 4)][(f % (BN / 4)) * 4]) = r.b[u];
         }
-        if (EPI == 4) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+        if (NEPI) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+        if (EPI == 7) Ms[r.tp][tid & 127] = r.mq;
         if (EPI == 6) Gs[r.tp][tid & 127] = r.uq;
     };
 
     float s1[NT], s2[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) s1[j] = s2[j] = 0.0f;
-    float ugs[EPI == 4 ? 8 : 1][NT]; // EPI 4: sum_r u[r,d] da'[r,col] over this lane's rows
+    float ugs[NEPI ? 8 : 1][NT]; // EPI 4 / 7: sum_r u[r,d] da'[r,col] over this lane's rows
 #pragma unroll
-    for (int d = 0; d < (EPI == 4 ? 8 : 1); d++)
+    for (int d = 0; d < (NEPI ? 8 : 1); d++)
 #pragma unroll
         for (int j = 0; j < NT; j++) ugs[d][j] = 0.0f;
     if (my_tiles == 0) { // never with the launchers below (gridDim.x <= row tiles); a workgroup without work still takes its ticket
@@ -705,7 +738,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             if (t_ == 12345.678f) z[0] = t_;
             continue;
         }
-        const bool store_z = (EPI != 4) && ((EPI != 2) || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
+        const bool store_z = !NEPI && ((EPI != 2) || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
         if (store_z) {                                   // pooling arithmetic below is not scheduled around 64 addresses
             // buffer stores: a scalar descriptor of this tile's rows, a scalar byte offset per (sub-tile, row) and ONE 32-bit lane
             // offset.  With flat 64-bit addresses the loop-invariant parts of the 64 addresses were hoisted out of the tile loop
@@ -904,6 +937,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     asm volatile("" : "+v"(urow) : "v"(s2[0]));
                 }
         }
+        if (EPI == 7) {
+            const int tp = (int)(t & 1);
+            const unsigned all = A.e_relu ? 0u : 0xffffffffu;
+            int urow = (wm * MT) * 32 + 4 * kh; // this lane's first row of the tile; four rows (e & 3) are read at a time
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int e4 = 0; e4 < 4; e4++) {
+                    float4 ua[4], ub[4];
+                    uint2 mk[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        ua[q] = *reinterpret_cast<const float4 *>(&Us[tp][urow + i * 32 + 8 * e4 + q][0]);
+                        ub[q] = *reinterpret_cast<const float4 *>(&Us[tp][urow + i * 32 + 8 * e4 + q][4]);
+                        mk[q] = Ms[tp][urow + i * 32 + 8 * e4 + q];
+                    }
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const int e = e4 * 4 + q;
+                        const float uu[8] = {ua[q].x, ua[q].y, ua[q].z, ua[q].w, ub[q].x, ub[q].y, ub[q].z, ub[q].w};
+#pragma unroll
+                        for (int j = 0; j < NT; j++) {
+                            static_assert(EPI != 7 || (WN == 1 && NT == 2), "EPI 7: a 64-column block = the two words of a mask row");
+                            const unsigned word = (j == 0 ? mk[q].x : mk[q].y) | all;
+                            const float g = ((word >> l31) & 1u) ? acc[i][j][e] : 0.0f;
+                            s1[j] += g;
+#pragma unroll
+                            for (int d = 0; d < 8; d++) ugs[d][j] = __builtin_fmaf(uu[d], g, ugs[d][j]);
+                        }
+                    }
+                    asm volatile("" : "+v"(urow) : "v"(s1[0])); // as EPI 4: the next four rows' LDS reads wait for these sums
+                }
+        }
         if (EPI == 2) {
             // the other half-wave holds the interleaved rows of the same 32-row block: combine, smaller row wins ties
             if (!A.pool32)
@@ -992,7 +1058,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         // combine the WM waves that share a column block in LDS (the operand buffers are free now: every wave is past
         // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
         // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
-        constexpr int NS = (EPI == 4) ? 10 : 2; // statistics per column: s1, s2 (+ the eight rows of UG)
+        constexpr int NS = NEPI ? 10 : 2; // statistics per column: s1, s2 (+ the eight rows of UG; EPI 7 leaves s2 to its tail)
         float *red = BF3 ? reinterpret_cast<float *>(&As3[0][0][0][0]) : &As[0][0][0]; // [NS][WM][BN]
         static_assert(NS * WM * BN <= 2 * FG_BK * FG_LDA, "reduction scratch exceeds the A buffers");
         static_assert(!BF3 || NS * WM * BN <= 2 * 3 * 2 * PLA, "reduction scratch exceeds the split A buffers");
@@ -1001,7 +1067,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             const int c = (wn * NT + j) * 32 + l31;
 #pragma unroll
             for (int q = 0; q < NS; q++) {
-                const float v = q == 0 ? s1[j] : q == 1 ? s2[j] : ugs[EPI == 4 ? q - 2 : 0][j];
+                const float v = q == 0 ? s1[j] : q == 1 ? s2[j] : ugs[NEPI ? q - 2 : 0][j];
                 const float t = v + __shfl_xor(v, 32);
                 if (lane < 32) red[(q * WM + wm) * BN + c] = t;
             }
@@ -1012,9 +1078,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             float t = 0.0f;
 #pragma unroll
             for (int i = 0; i < WM; i++) t += red[(which * WM + i) * BN + c];
+            if (EPI == 7 && which == 1) continue; // s2 comes out of the tail
             if (which < 2) unsafeAtomicAdd(&A.stats[which * cout + n0 + c], (double)t);
             else unsafeAtomicAdd(&A.ug[(size_t)(which - 2) * cout + n0 + c], (double)t);
         }
+    }
+    if (EPI == 7) {
+        // the coefficient tail of a narrow layer whose s2 was never accumulated: the last workgroup derives it per column from the
+        // completed UG and s1 (z_prev = u W0 + b0 is linear in u), leaves it in stats[cout + col] for whoever reads the sums, then
+        // computes the coefficient vector as coef_tail does.  Same hand-off as coef_tail (device-scope atomics only, vmcnt drained).
+        const CoefTail &tl = A.tail;
+        __shared__ unsigned s_last7;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            s_last7 = (__hip_atomic_fetch_add(tl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) ? 1u : 0u;
+        __syncthreads();
+        if (!s_last7) return;
+        const double invn = 1.0 / (double)tl.rows;
+        for (int col = threadIdx.x; col < cout; col += blockDim.x) {
+            const double q1 = __hip_atomic_load(&A.stats[col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            double zs = (A.b0 ? (double)A.b0[col] : 0.0) * q1;
+            for (int d = 0; d < A.k0; d++)
+                zs += (double)A.w0[(size_t)d * cout + col] * __hip_atomic_load(&A.ug[(size_t)d * cout + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const float inv = 1.0f / sqrtf(A.e_var[col] + A.e_eps);
+            const double q2 = (zs - (double)A.e_mean[col] * q1) * (double)inv;
+            A.stats[cout + col] = q2;
+            const float m1 = (float)(q1 * invn), m2 = (float)(q2 * invn);
+            const float ca = tl.gamma[col] * inv;
+            const float cc = -ca * inv * m2;
+            tl.coef[col] = ca;
+            tl.coef[cout + col] = -ca * m1 - cc * A.e_mean[col];
+            tl.coef[2 * cout + col] = cc;
+            tl.coef[3 * cout + col] = A.e_scale[col];
+            tl.coef[4 * cout + col] = A.e_shift[col];
+            if (tl.dgamma) tl.dgamma[col] += (float)q2;
+            if (tl.dbeta) tl.dbeta[col] += (float)q1;
+        }
+        if (threadIdx.x == 0) *tl.ticket = 0u;
+        return;
     }
     if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
@@ -1075,7 +1177,7 @@ template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
 // below (EPI 3), 4 the same over an assembled layer (EPI 6), 5 over a narrow layer (EPI 4)
 template <int SRC, int EPI> constexpr int bf3_family()
 {
-    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : EPI == 4 ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
+    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : (EPI == 4 || EPI == 7) ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
 }
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
@@ -1097,14 +1199,15 @@ static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
     if (bf3_built<SRC, EPI>() && g_fast_bf3) a.w3 = w3_lookup(a.w, a.cin, a.cout);
     const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : (SRC == 4) ? a.ptab : a.zsrc;
     if (SRC == 4 && ((uintptr_t)a.geo % 16 != 0 || (uintptr_t)a.wx % 16 != 0)) return false;
-    if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
+    if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4 || EPI == 7) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
+    if (EPI == 7 && (a.cout % 64 != 0 || a.mask_in == nullptr || a.tail.ticket == nullptr || (uintptr_t)a.mask_in % 8 != 0)) return false;
     const bool aligned = ((uintptr_t)abase % 16 == 0) && ((uintptr_t)a.w % 16 == 0) && ((uintptr_t)a.z % 16 == 0) &&
                          ((SRC != 1 && SRC != 5) || (uintptr_t)a.da % 16 == 0) && (SRC != 5 || a.wh != nullptr) &&
                          (SRC != 2 || ((uintptr_t)a.gout % 16 == 0 && (uintptr_t)a.argmax % 16 == 0));
     if (!aligned || a.cin % (2 * FG_BK) != 0 || a.cin > 512 || a.rows % FG_BM != 0 || a.rows == 0) return false;
     const long ntiles = a.rows / FG_BM;
     long gx;
-    if constexpr (EPI == 4) { // 128 x 64 tiles only: the epilogue's per-column constants and the u rows fit the registers of that shape
+    if constexpr (EPI == 4 || EPI == 7) { // 128 x 64 tiles only: the epilogue's per-column constants and the u rows fit the registers of that shape
         if (a.cout % 64 != 0) return false;
         const int ny = a.cout / 64;
         gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
@@ -1318,7 +1421,7 @@ extern "C" int votenet_mlp_dgrad_bn_reduce(long rows, int c, int cout, const flo
 // in_scale / in_shift.  stats as for votenet_mlp_linear.
 static int narrow_linear_impl(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0, const float *in_scale,
                               const float *in_shift, const votenet_bn_raw *in_bn, int in_relu, const float *w, const float *bias, float *z,
-                              double *stats, const float *wh, void *stream)
+                              double *stats, const float *wh, void *stream, unsigned short *mask_out = nullptr)
 {
     VN_REQUIRE(rows > 0 && k0 >= 3 && k0 <= 8 && c0 > 0 && cout > 0, "narrow_linear expects rows > 0, 3 <= k0 <= 8, c0 > 0, cout > 0");
     VN_REQUIRE(u8 && w0 && w && z, "narrow_linear: null buffer");
@@ -1340,6 +1443,8 @@ static int narrow_linear_impl(long rows, int k0, int c0, int cout, const float *
     a.z = z;
     a.stats = stats;
     a.wh = wh; // piece layout (half.hip): the statistics weigh row 0 of every piece
+    a.mask_out = mask_out;
+    VN_REQUIRE(mask_out == nullptr || (uintptr_t)mask_out % 8 == 0, "narrow_linear: the mask must be 8-byte aligned");
     hipStream_t st = as_stream(stream);
     const bool ok = stats ? fast_dispatch<3, 0>(a, st) : fast_dispatch<3, 1>(a, st);
     if (!ok) return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_linear: shape not served (rows %% 128 == 0, c0 %% 32 == 0, c0 <= 128, cout == 64 or cout %% 128 == 0, 16-byte aligned buffers)");
@@ -1358,6 +1463,17 @@ extern "C" int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, c
     VN_REQUIRE(wh != nullptr && rows % 128 == 0, "narrow_linear_half: null weights / rows %% 128 != 0");
     return narrow_linear_impl(rows, k0, c0, cout, u8, w0, b0, in_scale, in_shift, in_bn, in_relu, w, bias, z, stats, wh, stream);
 }
+// The same (wh may be NULL: the full row layout) leaving the narrow layer's ReLU mask for the backward pass: mask (rows x c0 / 16 16-bit
+// words, 8-byte aligned, c0 % 64 == 0): bit k % 16 of word [row][k / 16] = [relu(bn0(z0[row, k])) > 0] -- what
+// votenet_narrow_dgrad_bn_reduce_masked reads instead of rebuilding z0.
+extern "C" int votenet_narrow_linear_masked(long rows, int k0, int c0, int cout, const float *u8, const float *w0, const float *b0,
+                                            const float *in_scale, const float *in_shift, const votenet_bn_raw *in_bn, int in_relu,
+                                            const float *w, const float *bias, float *z, double *stats, const float *wh,
+                                            unsigned short *mask, void *stream)
+{
+    VN_REQUIRE(mask != nullptr && c0 % 64 == 0 && rows % 128 == 0, "narrow_linear_masked: null mask / c0 %% 64 != 0 / rows %% 128 != 0");
+    return narrow_linear_impl(rows, k0, c0, cout, u8, w0, b0, in_scale, in_shift, in_bn, in_relu, w, bias, z, stats, wh, stream, mask);
+}
 
 // Input-gradient GEMM of that second layer: da0 = dz1 wT (dz1 from (da, zsrc, coef) as votenet_mlp_dgrad_bn) is NOT stored; its
 // epilogue reduces the first layer's BatchNorm backward (sums: 2*c0 doubles, as votenet_mlp_dgrad_bn_reduce, z0 rebuilt from u8)
@@ -1365,7 +1481,8 @@ extern "C" int votenet_narrow_linear_half(long rows, int k0, int c0, int cout, c
 static int narrow_dgrad_bn_reduce_impl(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef, int relu,
                                        const float *wT, const float *u8, const float *w0, const float *b0, const float *scale0,
                                        const float *shift0, const float *mean0, const float *var0, float eps, int relu0, double *sums,
-                                       double *ug, const votenet_coef_tail *tail, const float *wh, void *stream)
+                                       double *ug, const votenet_coef_tail *tail, const float *wh, void *stream,
+                                       const void *mask = nullptr)
 {
     VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "narrow_dgrad_bn_reduce: incomplete coefficient tail");
     VN_REQUIRE(rows > 0 && c > 0 && c0 > 0 && k0 >= 3 && k0 <= 8, "narrow_dgrad_bn_reduce expects rows > 0, c > 0, c0 > 0, 3 <= k0 <= 8");
@@ -1394,6 +1511,14 @@ static int narrow_dgrad_bn_reduce_impl(long rows, int c, int c0, int k0, const f
     a.ug = ug;
     a.tail = to_tail(tail);
     a.wh = wh; // piece layout: da holds totals, the affine part of the rebuilt dz1 counts wh[q] times on row 16 q (SRC 5)
+    if (mask != nullptr) { // EPI 7: the mask the forward pass recorded instead of the rebuild of z0; s2 from the tail
+        VN_REQUIRE(tail != nullptr && wh != nullptr && c0 % 64 == 0 && (uintptr_t)mask % 8 == 0,
+                   "narrow_dgrad_bn_reduce_masked needs the coefficient tail, the piece layout's weights, c0 %% 64 == 0 and an 8-byte aligned mask");
+        a.mask_in = static_cast<const unsigned long long *>(mask);
+        if (!fast_dispatch<5, 7>(a, as_stream(stream)))
+            return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce_masked: shape not served (as votenet_narrow_dgrad_bn_reduce)");
+        return check_launch("narrow_dgrad_bn_reduce_masked");
+    }
     if (!(wh ? fast_dispatch<5, 4>(a, as_stream(stream)) : fast_dispatch<1, 4>(a, as_stream(stream))))
         return set_error(VOTENET_E_INVALID_ARGUMENT, "narrow_dgrad_bn_reduce: shape not served (rows %% 128 == 0, c %% 32 == 0, c <= 512, c0 == 64 or c0 %% 128 == 0, 16-byte aligned buffers)");
     return check_launch("narrow_dgrad_bn_reduce");
@@ -1415,6 +1540,20 @@ extern "C" int votenet_narrow_dgrad_bn_reduce_half(long rows, int c, int c0, int
     VN_REQUIRE(wh != nullptr, "narrow_dgrad_bn_reduce_half: null weights");
     return narrow_dgrad_bn_reduce_impl(rows, c, c0, k0, da, zsrc, coef, relu, wT, u8, w0, b0, scale0, shift0, mean0, var0, eps, relu0, sums, ug,
                                        tail, wh, stream);
+}
+
+// votenet_narrow_dgrad_bn_reduce_half with the narrow layer's ReLU mask from the forward pass (votenet_narrow_linear_masked) instead of the
+// rebuild of z0 in the epilogue, and sums[c0:2 c0] derived in the coefficient tail (required) from ug and sums[0:c0]: same sums, same ug,
+// same coefficient vector up to the association of the sums; a third of the epilogue's arithmetic, no register spills.
+extern "C" int votenet_narrow_dgrad_bn_reduce_masked(long rows, int c, int c0, int k0, const float *da, const float *zsrc, const float *coef,
+                                                     int relu, const float *wT, const float *u8, const float *w0, const float *b0,
+                                                     const float *scale0, const float *shift0, const float *mean0, const float *var0,
+                                                     float eps, int relu0, double *sums, double *ug, const votenet_coef_tail *tail,
+                                                     const float *wh, const void *mask, void *stream)
+{
+    VN_REQUIRE(mask != nullptr, "narrow_dgrad_bn_reduce_masked: null mask");
+    return narrow_dgrad_bn_reduce_impl(rows, c, c0, k0, da, zsrc, coef, relu, wT, u8, w0, b0, scale0, shift0, mean0, var0, eps, relu0, sums, ug,
+                                       tail, wh, stream, mask);
 }
 
 extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }

@@ -875,8 +875,17 @@ def narrow_stats(rows, mom, w0, b0):
     return stats
 
 
-def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True, half=None):
-    """Second layer over the rebuilt first-layer output: z = relu(bn0(u8 w0 + b0)) w + bias -> z (rows, cout), stats."""
+NARROW_MASK = True  # the narrow layer's ReLU mask is recorded by the forward pass and read by the input-gradient GEMM's epilogue (EPI 7 of mlp_fast.hip) instead of a rebuild of z0 per accumulator element
+
+
+def narrow_mask_supported(rows, c0):
+    return rows % 128 == 0 and c0 % 64 == 0
+
+
+def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True, half=None, want_mask=False):
+    """Second layer over the rebuilt first-layer output: z = relu(bn0(u8 w0 + b0)) w + bias -> z (rows, cout), stats.
+    want_mask: -> z, stats, mask (rows, c0 / 16) int16: bit k % 16 of word [row][k / 16] = [relu(bn0(z0[row, k])) > 0], for
+    narrow_dgrad_bn_reduce(mask=)."""
     rows = u8.shape[0]
     k0, c0 = w0.shape
     cout = w.shape[1]
@@ -887,6 +896,16 @@ def narrow_linear(u8, w0, b0, w, bias, in_bn, in_relu=True, want_stats=True, hal
         scale, shift = in_bn.scale, in_bn.shift
     else:
         raw = in_bn.raw()
+    if want_mask:
+        if not narrow_mask_supported(rows, c0):
+            raise L.InvalidArgumentError("narrow_linear: the mask needs rows %% 128 == 0 and c0 %% 64 == 0")
+        mask = torch.empty((rows, c0 // 16), dtype=torch.int16, device=u8.device)
+        with L.device_guard(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow" + (" half" if half else ""))):
+            L.check(L.lib().votenet_narrow_linear_masked(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
+                                                         ctypes.byref(raw) if raw is not None else None, 1 if in_relu else 0, L.ptr(w),
+                                                         L.ptr(bias), L.ptr(z), L.ptr(stats), L.ptr(half.wh) if half is not None else None,
+                                                         L.ptr(mask), L.stream_ptr()))
+        return z, stats, mask
     if half is not None:
         with L.device_guard(u8.device), _Timed("linear_dense", 2.0 * rows * c0 * cout, (rows, c0, cout, "fwd+bn narrow half")):
             L.check(L.lib().votenet_narrow_linear_half(rows, k0, c0, cout, L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(scale), L.ptr(shift),
@@ -918,15 +937,24 @@ def narrow_wgrad_bn(u8, w0, b0, in_scale, in_shift, in_relu, z, coef, relu, da, 
                                                 L.ptr(scr), L.stream_ptr()))
 
 
-def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS, tail=None, half=None):
+def narrow_dgrad_bn_reduce(z, coef, relu, wT, da, u8, w0, b0, below, eps=BN_EPS, tail=None, half=None, mask=None):
     """The input-gradient GEMM of the second layer with nothing stored: -> sums (2*c0 f64: BatchNorm-backward sums of the first
-    layer), ug (8, c0) f64 = sum_r u8[r,:]^T da0'[r,:].  below = (scale, shift, mean, var, relu) of the first layer."""
+    layer), ug (8, c0) f64 = sum_r u8[r,:]^T da0'[r,:].  below = (scale, shift, mean, var, relu) of the first layer.
+    mask (narrow_linear(want_mask=True); needs tail, the piece layout and mlp.COEF_TAIL): the first layer's ReLU mask from the forward
+    pass instead of its rebuild in the epilogue (votenet_narrow_dgrad_bn_reduce_masked)."""
     rows, c = z.shape
     k0, c0 = w0.shape
     bsc, bsh, bme, bva, brelu = below
     out = _zeros_f64(10 * c0, z.device)
     sums, ug = out[:2 * c0], out[2 * c0:]
     t, coef0 = _coef_tail(tail, c0, z.device)
+    if mask is not None and t is not None and half is not None:
+        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow half")):
+            L.check(L.lib().votenet_narrow_dgrad_bn_reduce_masked(rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
+                                                                  L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva),
+                                                                  eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), ctypes.byref(t), L.ptr(half.wh),
+                                                                  L.ptr(mask), L.stream_ptr()))
+        return coef0, ug.view(8, c0)
     with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * c0, (rows, c, c0, "dgrad_bn_reduce narrow" + (" half" if half else ""))):
         args = (rows, c, c0, k0, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT), L.ptr(u8), L.ptr(w0), L.ptr(b0), L.ptr(bsc),
                 L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps, 1 if brelu else 0, L.ptr(sums), L.ptr(ug), ctypes.byref(t) if t is not None else None)

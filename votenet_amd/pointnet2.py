@@ -403,8 +403,15 @@ def mlp_chain_forward(layers, rows, first, tape, pool_k=0, keep_z=True):
             rec = dict(layer=L, kind="dense", x=None, assembled=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=r0["half"])
         elif i == 1 and first[0] == "narrow":
             half = tape[-1]["half"]
-            zn, st = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn, half=half)
-            rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=half)
+            # training on the piece layout: the GEMM also leaves the first layer's ReLU mask (2 bytes per row and 16 channels) for the
+            # backward pass, whose input-gradient epilogue then needs no rebuild of z0 (mlp.NARROW_MASK)
+            want_mask = bool(M.NARROW_MASK and keep_z and half is not None and prev_relu and _FROZEN.table is None and M.COEF_TAIL
+                             and M.narrow_mask_supported(first[1].shape[0], layers[0].cout))
+            res = M.narrow_linear(first[1], layers[0].p("W"), layers[0].p("b"), w, b, pend, prev_relu, want_stats=L.bn, half=half,
+                                  want_mask=want_mask)
+            zn, st = res[0], res[1]
+            rec = dict(layer=L, kind="dense", x=None, narrow=True, in_scale=sc, in_shift=sh, in_relu=prev_relu, half=half,
+                       mask0=res[2] if want_mask else None)
         elif i == 0 and first[0] == "gather":
             # conv over the sample_and_group concat [xyz[idx]-new_xyz | feat[idx]] (utils.py:50-57,125-127).  A gather
             # commutes with a per-point linear map, so the feature block is ONE GEMM over the b*n points (P = feat W[3:])
@@ -670,7 +677,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
                 on_wgrad_stream(lambda r=r, z=z, coef=coef, L=L, da=da: M.narrow_wgrad_bn(
                     u8, w0, b0, r["in_scale"], r["in_shift"], r["in_relu"], z, coef, L.relu, da, L.gp("W"), half=half), u8, z, coef, da)
                 coef0, ug = M.narrow_dgrad_bn_reduce(z, coef, L.relu, L.wT(), da, u8, w0, b0,
-                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0), half=half)
+                                                     (r0["scale"], r0["shift"], r0["mean"], r0["var"], L0.relu), tail=tail_of(r0), half=half,
+                                                     mask=r.get("mask0") if M.NARROW_MASK else None)
                 M.narrow_wgrad_first(mom, ug, coef0, w0, b0, L0.gp("W"))
                 return None  # a leaf: nothing upstream takes a gradient
             if r.get("cin_padded") and not pooled and M.dgrad_bn_supported(rows, c, L.cin_pad):
