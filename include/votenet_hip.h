@@ -776,22 +776,25 @@ int votenet_group_linear_backward_sorted(long nh, int cout, const int *order, co
  * the scatter).  dz0 = A g + B + C z0 (g = da0 . relu'(bn0(z0))) is linear in everything the points and weights receive, so the
  * input-gradient GEMM of the layer above is a PLAIN one (votenet_mlp_dgrad_bn_half: no epilogue gathers) and
  *   votenet_group_linear_backward_masked  one pass over the compact rows bucketed by point (votenet_half_sort_rows): sg (points x cout,
- *       pre-zeroed) = scatter of the MASKED total gradients, ug (3 x cout, pre-zeroed) += sum_r dxyz(r)^T g[r], sums (2 cout doubles,
- *       pre-zeroed) += (sum g, sum g zhat0) -- the first layer's BatchNorm-backward sums; tail: its coefficient vector (votenet_coef_tail)
+ *       pre-zeroed) = scatter of the MASKED total gradients; ug (3 x cout) = sum_r dxyz(r)^T g[r] and sums (2 cout doubles) = (sum g,
+ *       sum g zhat0) -- the first layer's BatchNorm-backward sums -- are WRITTEN by the kernel's last workgroup from `part`
+ *       (votenet_group_linear_backward_masked_slots() x 5 x cout doubles, pre-zeroed: the workgroups' atomics spread over that many
+ *       address sets), together with the coefficient vector of the REQUIRED tail (votenet_coef_tail)
  *   votenet_assembled_point_grad          over the POINTS: sg -> S = A sg + cnt_p B + C (cnt_p P[p] + V_p wx) in place (cntv: votenet_assemble_rows);
- *       vp (3 x cout, pre-zeroed) += sum_p V_p^T P[p]
- *   votenet_assembled_wx_finish           dw_xyz (3 x cout) += A ug + B (sum dxyz) + C (vp + (sum dxyz dxyz^T) wx)   (moments: votenet_assemble_rows)
+ *       vp (votenet_group_linear_backward_masked_slots() x 3 x cout, pre-zeroed) += partial sums of sum_p V_p^T P[p]
+ *   votenet_assembled_wx_finish           dw_xyz (3 x cout) += A ug + B (sum dxyz) + C (sum of the nparts slots of vp + (sum dxyz dxyz^T) wx)
  * give the same S and dW[0:3] as votenet_group_linear_backward_sorted up to the association of the sums. */
 int votenet_mlp_dgrad_bn_half(long rows, int c, int cout, const float *da, const float *zsrc, const float *coef, int relu,
                               const float *wT, float *da_prev, const float *wh, const int *nh_dev, void *stream);
 int votenet_group_linear_backward_masked(long nh, int cout, const int *order, const float *geo, const float *P, const float *wx,
                                          const float *da, const float *scale, const float *shift, const float *mean, const float *var,
-                                         float eps, int relu, float *sg, float *ug, double *sums, const votenet_coef_tail *tail,
+                                         float eps, int relu, float *sg, float *ug, double *sums, double *part, const votenet_coef_tail *tail,
                                          const int *nh_dev, void *stream);
+int votenet_group_linear_backward_masked_slots(void);
 int votenet_assembled_point_grad(long npts, int cout, const float *P, const long long *cntv, const float *wx, const float *coef, float *s,
                                  float *vp, void *stream);
-int votenet_assembled_wx_finish(int cout, const float *coef, const float *ug, const float *vp, const double *moments, const float *wx,
-                                float *dw_xyz, void *stream);
+int votenet_assembled_wx_finish(int cout, const float *coef, const float *ug, const float *vp, int nparts, const double *moments,
+                                const float *wx, float *dw_xyz, void *stream);
 int votenet_half_centre_sums(long G, int cout, const int *pos, const float *geo, const float *wh, const float *P, const float *wx,
                              const float *da, const float *coef, int relu, float *T, void *stream);
 /* The narrow first layer (sa1) on the same layout: u8 (up to 64G x 8 floats; moments over the true rows), the second layer's GEMMs. */

@@ -196,9 +196,9 @@ _SIGS.update({
     "votenet_half_piece_rows": [],
     "votenet_half_sort_rows": [_I, _I] + [_c_f] * 3 + [_I, _c_f, ctypes.c_void_p],
     "votenet_mlp_dgrad_bn_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [ctypes.c_void_p],
-    "votenet_group_linear_backward_masked": [_L, _I] + [_c_f] * 9 + [_F, _I] + [_c_f] * 3 + [ctypes.c_void_p, _c_f, ctypes.c_void_p],
+    "votenet_group_linear_backward_masked": [_L, _I] + [_c_f] * 9 + [_F, _I] + [_c_f] * 4 + [ctypes.c_void_p, _c_f, ctypes.c_void_p],
     "votenet_assembled_point_grad": [_L, _I] + [_c_f] * 6 + [ctypes.c_void_p],
-    "votenet_assembled_wx_finish": [_I] + [_c_f] * 6 + [ctypes.c_void_p],
+    "votenet_assembled_wx_finish": [_I] + [_c_f] * 3 + [_I] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_group_linear_backward_sorted": [_L, _I] + [_c_f] * 7 + [_I] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_narrow_rows_half": [_I] * 4 + [_c_f] * 9 + [ctypes.c_void_p],
     "votenet_narrow_linear_masked": [_L, _I, _I, _I] + [_c_f] * 5 + [ctypes.POINTER(BnRaw), _I] + [_c_f] * 6 + [ctypes.c_void_p],

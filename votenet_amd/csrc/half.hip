@@ -469,6 +469,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_sorted_kernel(long rows,
 // So ONE pass over the rows bucketed by point (this kernel: the former scatter pass without its coefficients) leaves Sg, UG and the
 // BatchNorm-backward sums -- it rebuilds z0 for the mask anyway, a point's P row once per run of rows --, the coefficient vector comes
 // out of its tail, a pass over the POINTS (assembled_point_grad_kernel) finishes S, and the GEMM above is a plain one.
+constexpr int kMaskedSlots = 32;
 template <int COUT>
 __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows, const int *__restrict__ order, const float4 *__restrict__ geo,
                                                                       const float *__restrict__ ptab, const float *__restrict__ wx,
@@ -476,6 +477,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows,
                                                                       const float *__restrict__ shift, const float *__restrict__ mean,
                                                                       const float *__restrict__ var, float eps, int relu,
                                                                       float *__restrict__ sg, float *__restrict__ ug, double *__restrict__ sums,
+                                                                      double *__restrict__ part /* kMaskedSlots x 5 x COUT, zeroed */,
                                                                       const int *__restrict__ nh_dev, CoefTail tail)
 {
     if (nh_dev != nullptr) { // the count is the device's (rows: the caller's upper bound)
@@ -484,6 +486,7 @@ __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows,
     }
     constexpr int CPB = 256 / COUT; // chunks per workgroup pass
     constexpr int CH = 64;          // entries per chunk
+    constexpr int GB = 8;           // entries whose two loads are in flight together (16 measured slower: 54.6 -> 59.9 us at sa2)
     __shared__ int s_row[CPB][CH];
     __shared__ float4 s_geo[CPB][CH];
     __shared__ float red[256][5];
@@ -512,17 +515,17 @@ __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows,
         float acc = 0.0f;
         bool first = true;
 #pragma unroll 1
-        for (int e0 = 0; e0 < CH; e0 += 8) {
-            float gg[8], zz[8];
+        for (int e0 = 0; e0 < CH; e0 += GB) {
+            float gg[GB], zz[GB];
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GB; u++) {
                 const int r = s_row[cl][e0 + u];
                 const int rr = r < 0 ? 0 : r;
                 gg[u] = da[(size_t)rr * COUT + ch];
                 zz[u] = ptab[(size_t)__float_as_uint(s_geo[cl][e0 + u].w) * COUT + ch];
             }
 #pragma unroll
-            for (int u = 0; u < 8; u++) {
+            for (int u = 0; u < GB; u++) {
                 if (s_row[cl][e0 + u] < 0) continue; // past the end of the list (the last chunk)
                 const float4 g4 = s_geo[cl][e0 + u];
                 const unsigned prow = __float_as_uint(g4.w);
@@ -561,12 +564,44 @@ __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows,
             t[d] = 0.0f;
             for (int q = 0; q < CPB; q++) t[d] += red[q * COUT + tid][d];
         }
+        // every workgroup ends in 5 atomics per channel: on ONE set of addresses 2048 workgroups queue up behind each other at the L2
+        // (~7 ns per atomic and address); kMaskedSlots sets share the queue, the last workgroup adds them up
+        double *ps = part + (size_t)(blockIdx.x % kMaskedSlots) * 5 * COUT;
 #pragma unroll
-        for (int d = 0; d < 3; d++) unsafeAtomicAdd(&ug[(size_t)d * COUT + tid], t[d]);
-        unsafeAtomicAdd(&sums[tid], (double)t[3]);
-        unsafeAtomicAdd(&sums[COUT + tid], (double)t[4]);
+        for (int d = 0; d < 5; d++) unsafeAtomicAdd(&ps[(size_t)d * COUT + tid], (double)t[d]);
     }
-    coef_tail(tail, gridDim.x, COUT, sums, scale, shift, mean, var, eps);
+    // the tail (as coef_tail, common.h): the last workgroup to take a ticket folds the slots into ug / sums and computes the layer's
+    // coefficient vector
+    __shared__ unsigned s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) s_last = (__hip_atomic_fetch_add(tail.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    const double invn = 1.0 / (double)tail.rows;
+    for (int col = threadIdx.x; col < COUT; col += blockDim.x) {
+        double q[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int sl = 0; sl < kMaskedSlots; sl++)
+#pragma unroll
+            for (int d = 0; d < 5; d++)
+                q[d] += __hip_atomic_load(&part[((size_t)sl * 5 + d) * COUT + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int d = 0; d < 3; d++) ug[(size_t)d * COUT + col] = (float)q[d];
+        sums[col] = q[3];
+        sums[COUT + col] = q[4];
+        const float inv = 1.0f / sqrtf(var[col] + eps);
+        const float m1 = (float)(q[3] * invn), m2 = (float)(q[4] * invn);
+        const float cA = tail.gamma[col] * inv;
+        const float cC = -cA * inv * m2;
+        tail.coef[col] = cA;
+        tail.coef[COUT + col] = -cA * m1 - cC * mean[col];
+        tail.coef[2 * COUT + col] = cC;
+        tail.coef[3 * COUT + col] = scale[col];
+        tail.coef[4 * COUT + col] = shift[col];
+        if (tail.dgamma) tail.dgamma[col] += (float)q[4];
+        if (tail.dbeta) tail.dbeta[col] += (float)q[3];
+    }
+    if (threadIdx.x == 0) *tail.ticket = 0u;
 }
 
 // S[p, c] = A Sg[p, c] + cnt_p B + C (cnt_p P[p, c] + V_p . Wx[:, c]) in place over Sg (points x COUT), and vp[d, c] += sum_p V_p[d] P[p, c]
@@ -575,28 +610,43 @@ __global__ __launch_bounds__(256) void group_linear_bwd_masked_kernel(long rows,
 template <int COUT>
 __global__ __launch_bounds__(256) void assembled_point_grad_kernel(long npts, const float *__restrict__ ptab, const long long *__restrict__ cntv,
                                                                    const float *__restrict__ wx, const float *__restrict__ coef,
-                                                                   float *__restrict__ s, float *__restrict__ vp)
+                                                                   float *__restrict__ s, float *__restrict__ vp /* kMaskedSlots x 3 x COUT, zeroed */)
 {
     constexpr int PPB = 256 / COUT;
+    constexpr int U = 4; // points in flight per thread: the pass is a latency chain otherwise (33 us for 26 MB with one)
     __shared__ float red[256][3];
     const int tid = threadIdx.x, ch = tid % COUT, pl = tid / COUT;
     const float kA = coef[ch], kB = coef[COUT + ch], kC = coef[2 * COUT + ch];
     const float wx0 = wx[ch], wx1 = wx[COUT + ch], wx2 = wx[2 * COUT + ch];
     float v0 = 0.f, v1 = 0.f, v2 = 0.f;
-    for (long p = (long)blockIdx.x * PPB + pl; p < npts; p += (long)gridDim.x * PPB) {
-        const long long *cv = cntv + (size_t)p * 4;
-        const long long cn = cv[0];
-        if (cn == 0) continue; // a point no ball contains: Sg is zero there and stays
-        const float fx = (float)((double)cv[1] * (1.0 / 4294967296.0)), fy = (float)((double)cv[2] * (1.0 / 4294967296.0)),
-                    fz = (float)((double)cv[3] * (1.0 / 4294967296.0));
-        const float pv = ptab[(size_t)p * COUT + ch];
-        const float fc = (float)cn;
-        const float zsum = fc * pv + (fx * wx0 + fy * wx1 + fz * wx2);
-        float *sp = s + (size_t)p * COUT + ch;
-        *sp = kA * *sp + fc * kB + kC * zsum;
-        v0 += fx * pv;
-        v1 += fy * pv;
-        v2 += fz * pv;
+    const long stride = (long)gridDim.x * PPB;
+    for (long p0 = (long)blockIdx.x * PPB + pl; p0 < npts; p0 += U * stride) {
+        long long c4[U][4];
+        float pv[U], sv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long p = p0 + u * stride < npts ? p0 + u * stride : p0; // (clamped: skipped below)
+            const long long *cv = cntv + (size_t)p * 4;
+            c4[u][0] = cv[0];
+            c4[u][1] = cv[1];
+            c4[u][2] = cv[2];
+            c4[u][3] = cv[3];
+            pv[u] = ptab[(size_t)p * COUT + ch];
+            sv[u] = s[(size_t)p * COUT + ch];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const long p = p0 + u * stride;
+            if (p >= npts || c4[u][0] == 0) continue; // past the end / a point no ball contains: Sg is zero there and stays
+            const float fx = (float)((double)c4[u][1] * (1.0 / 4294967296.0)), fy = (float)((double)c4[u][2] * (1.0 / 4294967296.0)),
+                        fz = (float)((double)c4[u][3] * (1.0 / 4294967296.0));
+            const float fc = (float)c4[u][0];
+            const float zsum = fc * pv[u] + (fx * wx0 + fy * wx1 + fz * wx2);
+            s[(size_t)p * COUT + ch] = kA * sv[u] + fc * kB + kC * zsum;
+            v0 += fx * pv[u];
+            v1 += fy * pv[u];
+            v2 += fz * pv[u];
+        }
     }
     red[tid][0] = v0;
     red[tid][1] = v1;
@@ -607,7 +657,8 @@ __global__ __launch_bounds__(256) void assembled_point_grad_kernel(long npts, co
         for (int d = 0; d < 3; d++) {
             float t = 0.0f;
             for (int q = 0; q < PPB; q++) t += red[q * COUT + tid][d];
-            unsafeAtomicAdd(&vp[(size_t)d * COUT + tid], t);
+            // kMaskedSlots address sets share the workgroups' atomics (on one set they queue up at the L2: 33 -> 54 us with 2048 workgroups)
+            unsafeAtomicAdd(&vp[((size_t)(blockIdx.x % kMaskedSlots) * 3 + d) * COUT + tid], t);
         }
     }
 }
@@ -615,17 +666,21 @@ __global__ __launch_bounds__(256) void assembled_point_grad_kernel(long npts, co
 // dWx[d, c] += A[c] UG[d, c] + B[c] (sum dxyz_d) + C[c] (VP[d, c] + sum_e (sum dxyz_d dxyz_e) Wx[e, c]); moments as assemble_rows leaves them
 // (sum dx, dy, dz, then xx, xy, xz, yy, yz, zz).  One workgroup.
 __global__ __launch_bounds__(256) void assembled_wx_finish_kernel(int cout, const float *__restrict__ coef, const float *__restrict__ ug,
-                                                                  const float *__restrict__ vp, const double *__restrict__ mom,
+                                                                  const float *__restrict__ vp, int nparts, const double *__restrict__ mom,
                                                                   const float *__restrict__ wx, float *__restrict__ dw_xyz)
 {
     for (int c = threadIdx.x; c < cout; c += blockDim.x) {
+        double vs[3] = {0.0, 0.0, 0.0}; // the slots of votenet_assembled_point_grad
+        for (int q = 0; q < nparts; q++)
+#pragma unroll
+            for (int d = 0; d < 3; d++) vs[d] += (double)vp[((size_t)q * 3 + d) * cout + c];
         const double kA = coef[c], kB = coef[cout + c], kC = coef[2 * cout + c];
         const double w0 = wx[c], w1 = wx[cout + c], w2 = wx[2 * cout + c];
         const double m[3][3] = {{mom[3], mom[4], mom[5]}, {mom[4], mom[6], mom[7]}, {mom[5], mom[7], mom[8]}};
 #pragma unroll
         for (int d = 0; d < 3; d++) {
             const double mw = m[d][0] * w0 + m[d][1] * w1 + m[d][2] * w2;
-            dw_xyz[(size_t)d * cout + c] += (float)(kA * ug[(size_t)d * cout + c] + kB * mom[d] + kC * ((double)vp[(size_t)d * cout + c] + mw));
+            dw_xyz[(size_t)d * cout + c] += (float)(kA * ug[(size_t)d * cout + c] + kB * mom[d] + kC * (vs[d] + mw));
         }
     }
 }
@@ -785,28 +840,37 @@ extern "C" int votenet_group_linear_backward_sorted(long nh, int cout, const int
 //   votenet_assembled_wx_finish: dw_xyz += the coordinate rows of the first layer's weight gradient.
 extern "C" int votenet_group_linear_backward_masked(long nh, int cout, const int *order, const float *geo, const float *P, const float *wx,
                                                     const float *da, const float *scale, const float *shift, const float *mean,
-                                                    const float *var, float eps, int relu, float *sg, float *ug, double *sums,
+                                                    const float *var, float eps, int relu, float *sg, float *ug, double *sums, double *part,
                                                     const votenet_coef_tail *tail, const int *nh_dev, void *stream)
 {
     VN_REQUIRE(nh > 0 && (cout == 64 || cout == 128 || cout == 256), "group_linear_backward_masked expects nh > 0, cout in {64, 128, 256}");
-    VN_REQUIRE(order && geo && P && wx && da && scale && shift && mean && var && sg && ug && sums, "group_linear_backward_masked: null buffer");
+    VN_REQUIRE(order && geo && P && wx && da && scale && shift && mean && var && sg && ug && sums && part, "group_linear_backward_masked: null buffer");
+    VN_REQUIRE(tail != nullptr, "group_linear_backward_masked needs the coefficient tail (votenet_coef_tail): its last workgroup folds the partial sums");
     VN_REQUIRE((uintptr_t)geo % 16 == 0, "group_linear_backward_masked: geo must be 16-byte aligned");
     VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "group_linear_backward_masked: incomplete coefficient tail");
     hipStream_t st = as_stream(stream);
     const long rows = nh * PS, nchunk = (rows + 63) / 64;
     const int cpb = 256 / cout;
     long gx = (nchunk + cpb - 1) / cpb;
-    if (gx > 2048) gx = 2048; // (every workgroup ends in 5 cout atomics on the same addresses: fewer, longer workgroups than the scatter alone wanted)
+    if (gx > 2048) gx = 2048;
     const float4 *g4 = reinterpret_cast<const float4 *>(geo);
     const CoefTail t = to_tail(tail);
 #define GLBM(C) hipLaunchKernelGGL(group_linear_bwd_masked_kernel<C>, dim3((unsigned)gx), dim3(256), 0, st, rows, order, g4, P, wx, da, scale, \
-                                   shift, mean, var, eps, relu, sg, ug, sums, nh_dev, t)
+                                   shift, mean, var, eps, relu, sg, ug, sums, part, nh_dev, t)
     if (cout == 128) GLBM(128);
     else if (cout == 64) GLBM(64);
     else GLBM(256);
 #undef GLBM
     return check_launch("group_linear_backward_masked");
 }
+
+static long point_grad_grid(long npts, int cout)
+{
+    const long ppb = (cout > 0 && cout <= 256) ? 256 / cout : 1;
+    const long gx = (npts + ppb * 4 - 1) / (ppb * 4); // four points in flight per thread
+    return gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+}
+extern "C" int votenet_group_linear_backward_masked_slots(void) { return kMaskedSlots; }
 
 extern "C" int votenet_assembled_point_grad(long npts, int cout, const float *P, const long long *cntv, const float *wx, const float *coef,
                                             float *s, float *vp, void *stream)
@@ -815,19 +879,19 @@ extern "C" int votenet_assembled_point_grad(long npts, int cout, const float *P,
     VN_REQUIRE(P && cntv && wx && coef && s && vp && (uintptr_t)cntv % 16 == 0, "assembled_point_grad: null / unaligned buffer");
     hipStream_t st = as_stream(stream);
     const int ppb = 256 / cout;
-    long gx = (npts + ppb * 8 - 1) / (ppb * 8);
-    gx = gx < 1 ? 1 : (gx > 1024 ? 1024 : gx);
+    (void)ppb;
+    const long gx = point_grad_grid(npts, cout);
     if (cout == 128) hipLaunchKernelGGL(assembled_point_grad_kernel<128>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
     else if (cout == 64) hipLaunchKernelGGL(assembled_point_grad_kernel<64>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
     else hipLaunchKernelGGL(assembled_point_grad_kernel<256>, dim3((unsigned)gx), dim3(256), 0, st, npts, P, cntv, wx, coef, s, vp);
     return check_launch("assembled_point_grad");
 }
 
-extern "C" int votenet_assembled_wx_finish(int cout, const float *coef, const float *ug, const float *vp, const double *moments,
+extern "C" int votenet_assembled_wx_finish(int cout, const float *coef, const float *ug, const float *vp, int nparts, const double *moments,
                                            const float *wx, float *dw_xyz, void *stream)
 {
-    VN_REQUIRE(cout > 0 && coef && ug && vp && moments && wx && dw_xyz, "assembled_wx_finish: bad arguments");
-    hipLaunchKernelGGL(assembled_wx_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), cout, coef, ug, vp, moments, wx, dw_xyz);
+    VN_REQUIRE(cout > 0 && nparts > 0 && coef && ug && vp && moments && wx && dw_xyz, "assembled_wx_finish: bad arguments");
+    hipLaunchKernelGGL(assembled_wx_finish_kernel, dim3(1), dim3(256), 0, as_stream(stream), cout, coef, ug, vp, nparts, moments, wx, dw_xyz);
     return check_launch("assembled_wx_finish");
 }
 

@@ -940,6 +940,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (EPI == 7) {
             const int tp = (int)(t & 1);
             const unsigned all = A.e_relu ? 0u : 0xffffffffu;
+            const bool k0_wide = A.k0 > 6;
             int urow = (wm * MT) * 32 + 4 * kh; // this lane's first row of the tile; four rows (e & 3) are read at a time
 #pragma unroll
             for (int i = 0; i < MT; i++)
@@ -964,7 +965,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                             const float g = ((word >> l31) & 1u) ? acc[i][j][e] : 0.0f;
                             s1[j] += g;
 #pragma unroll
-                            for (int d = 0; d < 8; d++) ugs[d][j] = __builtin_fmaf(uu[d], g, ugs[d][j]);
+                            for (int d = 0; d < 6; d++) ugs[d][j] = __builtin_fmaf(uu[d], g, ugs[d][j]);
+                            if (k0_wide) { // (wave-uniform: sa1's rows have six channels -- 3 + 3 --, the padding multiplies zeros)
+                                ugs[6][j] = __builtin_fmaf(uu[6], g, ugs[6][j]);
+                                ugs[7][j] = __builtin_fmaf(uu[7], g, ugs[7][j]);
+                            }
                         }
                     }
                     asm volatile("" : "+v"(urow) : "v"(s1[0])); // as EPI 4: the next four rows' LDS reads wait for these sums

@@ -681,6 +681,9 @@ def group_linear_backward_half(half, b, n, P, wx, da, coef, relu, dw_xyz):
     return S
 
 
+_masked_slots = None
+
+
 def dgrad_bn_half(z, coef, relu, wT, da, half):
     """votenet_mlp_dgrad_bn_half: da_prev (rows, cout) = dz wT with dz rebuilt from (da, z, coef) on the piece layout (totals; the affine
     part weighted by half.wh) -- a plain GEMM, nothing in its epilogue but the store."""
@@ -703,24 +706,32 @@ def group_linear_backward_decomposed(half, b, n, P, wx, da, bn, relu, tail, cntv
     if getattr(half, "order", None) is None:
         half_sort_rows(half, b * n)
     sc, sh, me, va = bn
+    global _masked_slots, COEF_TAIL
+    if _masked_slots is None:
+        _masked_slots = int(L.lib().votenet_group_linear_backward_masked_slots())
+    nparts = _masked_slots
     S = _zeros_f32((b, n, cout), dev)
-    small = _zeros_f32((6, cout), dev)  # ug (3, cout) | vp (3, cout)
+    small = _zeros_f32((3 + 3 * nparts, cout), dev)  # ug (3, cout: written whole) | vp (slots, 3, cout): accumulated
     ug, vp = small[:3], small[3:]
-    sums = _zeros_f64(2 * cout, dev)
-    t, coef = _coef_tail(tail, cout, dev)
+    zeros = _zeros_f64(2 * cout + _masked_slots * 5 * cout, dev)
+    sums, part = zeros[:2 * cout], zeros[2 * cout:]
+    # the kernel's LAST workgroup folds the partial sums (a ticket): the coefficient vector comes out of that tail whatever COEF_TAIL says
+    prev_ct, COEF_TAIL = COEF_TAIL, True
+    try:
+        t, coef = _coef_tail(tail, cout, dev)
+    finally:
+        COEF_TAIL = prev_ct
     with L.device_guard(dev):
         L.check(L.lib().votenet_group_linear_backward_masked(half.nh, cout, L.ptr(half.order), L.ptr(half.geo), L.ptr(P), L.ptr(wx), L.ptr(da),
                                                              L.ptr(sc), L.ptr(sh), L.ptr(me), L.ptr(va), eps, 1 if relu else 0, L.ptr(S),
-                                                             L.ptr(ug), L.ptr(sums), ctypes.byref(t) if t is not None else None,
-                                                             L.ptr(half.nh_limit), L.stream_ptr()))
-        if coef is None:
-            coef = _coef_after(tail, bn, sums, eps)
+                                                             L.ptr(ug), L.ptr(sums), L.ptr(part), ctypes.byref(t), L.ptr(half.nh_limit),
+                                                             L.stream_ptr()))
         L.check(L.lib().votenet_assembled_point_grad(b * n, cout, L.ptr(P), L.ptr(cntv), L.ptr(wx), L.ptr(coef), L.ptr(S), L.ptr(vp),
                                                      L.stream_ptr()))
 
     def finish():
         with L.device_guard(dev):
-            L.check(L.lib().votenet_assembled_wx_finish(cout, L.ptr(coef), L.ptr(ug), L.ptr(vp), L.ptr(mom), L.ptr(wx), L.ptr(dw_xyz),
+            L.check(L.lib().votenet_assembled_wx_finish(cout, L.ptr(coef), L.ptr(ug), L.ptr(vp), nparts, L.ptr(mom), L.ptr(wx), L.ptr(dw_xyz),
                                                         L.stream_ptr()))
     if defer is not None:
         defer(finish, coef, small, mom)
