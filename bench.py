@@ -736,7 +736,17 @@ def main():
                     if u.get("hbm_gbs_alone") is not None:  # the piece-layout families: the same launch's HBM rate (FETCH + WRITE counters)
                         e["hbm_gbs_alone"], e["hbm_frac_alone"] = u["hbm_gbs_alone"], u.get("hbm_frac_alone")
                 return e
-            mfma["by_family"] = {k: fam_entry(k, v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:8]}
+            mfma["by_family"] = {k: fam_entry(k, v) for k, v in sorted(fam.items(), key=lambda kv: -kv[1][1])[:10]}
+            # ONE number for the north star's own metric (rocprof-reported MFMA utilisation of the grouped MLP): the families' alone-on-the-
+            # GPU MfmaUtil weighted by the time each family takes inside the step, over the families the counter summary covers
+            cov = [(v[1], util[k]["mfma_util"]) for k, v in fam.items() if util.get(k) and util[k].get("mfma_util") is not None]
+            if cov:
+                tsum = sum(t for t, _ in cov)
+                mfma["mfma_util_step_weighted"] = {"value": round(sum(t * u for t, u in cov) / tsum, 3),
+                                                   "covers_frac_of_gemm_time": round(tsum / sum(v[1] for v in fam.values()), 3),
+                                                   "what": "sum over GEMM families of (rocprofv3 MfmaUtil of the family's kernel alone on the GPU) x "
+                                                           "(the family's launch time inside the step) / that time; families without a counter "
+                                                           "entry (the small layers of fp / voting / proposal) are left out"}
             mfma["by_family_note"] = ("tflops / frac: the family's executed flops / the SUM of its launch durations INSIDE the step (two GEMM streams and "
                                       "the next batch's geometry run beside them); mfma_util_alone / tflops_alone: rocprofv3 SQ_VALU_MFMA_BUSY_CYCLES "
                                       "share and rate of the same kernel alone on the GPU at sa2's / sa1's shape, hbm_gbs_alone / hbm_frac_alone: "
@@ -788,7 +798,8 @@ def main():
                                                     "train step (fwd+bwd+Adam, fixed cotangents)")
                                                    if workload == "train" else "forward", B, n, args.scene)
                                     + ("; three batches rotate, the coordinate-only geometry of the next batch (FPS, ball query, "
-                                       "three_nn) runs on a side stream underneath the current step, replayed as one HIP graph (model.GeometryGraph)" if pipeline else "")),
+                                       "three_nn) runs on a side stream underneath the current step, replayed as one HIP graph (model.GeometryGraph); the step's "
+                                       "static stretch (fp1 forward ... fp1 backward: ~85 launches) replays as four HIP graphs (model.StretchGraph)" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
             "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate; products of the fused forward and input-gradient GEMMs as bf16 x 3 "
                                "split operands (exact split, 6 of the 9 cross terms: what is dropped is < 2^-23 of a product), "

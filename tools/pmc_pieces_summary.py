@@ -48,6 +48,7 @@ FAMILIES = {
     "dgrad_bn half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 1, true>", 128, 128),
     "wgrad_bn assembled half": ("sa2", "mlp_wgrad_fast_kernel<3, 2, 2, 4, true>", 128, 128),
     "gram half": ("sa2", "gram_bf3_kernel<128>", 128, 128),
+    "gram-form dense dgrad half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false>", 128, 128),
     "fwd+bn narrow half": ("sa1", "mlp_linear_fast_kernel<4, 1, 1, 2, 3, 0, true>", 64, 64),
     "dgrad_bn_reduce narrow half": ("sa1", "mlp_linear_fast_kernel<4, 1, 1, 2, 5, 7, true>", 64, 64),
     "wgrad_bn narrow half": ("sa1", "mlp_wgrad_fast_kernel<2, 1, 1, 4, true>", 64, 64),

@@ -2,7 +2,8 @@
    TOGGLES="pointnet2.ASSEMBLE_FIRST=False mlp.COEF_TAIL=True" rocprofv3 --kernel-trace ... -- python3 tools/probe/trace_step.py"""
 import os, sys, importlib
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path[:0] = [R]
-from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
+import importlib.util as _iu
+_s = _iu.spec_from_file_location("hp", os.path.join(R, "votenet_amd", "hostpin.py")); hostpin = _iu.module_from_spec(_s); _s.loader.exec_module(hostpin); hostpin.pin(0)  # as bench.py, before torch is imported
 import torch
 from votenet_amd import loss as VL, model as VM, synth
 for t in os.environ.get("TOGGLES", "").split():
@@ -16,7 +17,7 @@ gts = [VL.gt_to_device(synth.room_gt(B, n, s), dev) for s in (1000, 500000, 9000
 net = VM.VoteNetHotPath(dev, seed=0)
 fwd = os.environ.get("WORKLOAD") == "fwd"
 import time
-for i in range(14 if not fwd else 40):
+for i in range(16 if not fwd else 40):
     if i == 10:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     if fwd:
@@ -24,5 +25,5 @@ for i in range(14 if not fwd else 40):
     else:
         net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
 torch.cuda.synchronize()
-print("ms per call over the last calls: %.3f" % ((time.perf_counter() - t0) / ((14 if not fwd else 40) - 10) * 1e3))
+print("ms per call over the last calls: %.3f" % ((time.perf_counter() - t0) / ((16 if not fwd else 40) - 10) * 1e3))
 torch.cuda.synchronize()

@@ -4,7 +4,8 @@ when nothing overlaps (tools/rocpd_stats.py on the .db).  Prints the wall time o
 GPU box only:   rocprofv3 --kernel-trace -d out -o s -- python3 tools/serial_step.py"""
 import os, sys, time, gc
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
-from votenet_amd import hostpin; hostpin.pin(0)  # as bench.py: the host threads on eight cores of the GPU's NUMA node
+import importlib.util as _iu
+_s = _iu.spec_from_file_location("hp", os.path.join(R, "votenet_amd", "hostpin.py")); hostpin = _iu.module_from_spec(_s); _s.loader.exec_module(hostpin); hostpin.pin(0)  # as bench.py, before torch is imported
 import torch
 from votenet_amd import loss as VL, model as VM, synth
 dev = torch.device("cuda:0")

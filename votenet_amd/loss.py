@@ -17,9 +17,21 @@ def gt_to_device(gt, device):
     return {k: torch.from_numpy(gt[k]).contiguous().to(device) for k in GT_KEYS}
 
 
-def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
+def loss_buffers(out):
+    """The output buffers of votenet_loss for the tensors of `out`, allocated once by a caller that wants them at fixed addresses
+    (model.StretchGraph: the segments captured behind the loss read the cotangents there): -> (losses (12,), flat).  flat holds the three
+    cotangents and the kernel's workspace and must be ZERO when votenet_loss(..., buffers=) runs (here: a carve-out of the pass's arena)."""
+    from . import mlp as M
+    votes, pxyz, pout = out["votes_xyz"], out["proposals_xyz"], out["proposals_output"]
+    nws = int(L.lib().votenet_loss_workspace_floats(votes.shape[0]))
+    losses = torch.empty(12, dtype=torch.float32, device=votes.device)
+    return losses, M._zeros_f32((votes.numel() + pxyz.numel() + pout.numel() + nws,), votes.device)
+
+
+def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC, buffers=None):
     """out: the dict VoteNetHotPath.forward returns; gt: device tensors (gt_to_device).
-    -> losses (12,) f32 on the device (NAMES), cotangents dict(votes_xyz, proposals_xyz, proposals_output)."""
+    -> losses (12,) f32 on the device (NAMES), cotangents dict(votes_xyz, proposals_xyz, proposals_output).
+    buffers: (losses, flat) from loss_buffers(out), flat zeroed by the caller -- the results land there instead of in fresh tensors."""
     seeds = L.dev_f32(out["seeds_xyz"], "loss seeds_xyz", 3, 3)
     votes = L.dev_f32(out["votes_xyz"], "loss votes_xyz", 3, 3)
     pxyz = L.dev_f32(out["proposals_xyz"], "loss proposals_xyz", 3, 3)
@@ -33,11 +45,16 @@ def votenet_loss(out, gt, nh=NH, ns=NS, nc=NC):
     if pout.shape[2] != 5 + 2 * nh + 4 * ns + nc:
         raise L.InvalidArgumentError("loss: proposals_output has %d channels, expected %d" % (pout.shape[2], 5 + 2 * nh + 4 * ns + nc))
     dev = seeds.device
-    losses = torch.empty(12, dtype=torch.float32, device=dev)
     # the three cotangents and the kernel's workspace are ONE buffer cleared by ONE fill
     nv, npx, npo, nws = votes.numel(), pxyz.numel(), pout.numel(), int(L.lib().votenet_loss_workspace_floats(b))
     from . import mlp as M
-    flat = M._zeros_f32((nv + npx + npo + nws,), dev)  # inside a train step: a carve-out of the pass's one zero fill
+    if buffers is not None:
+        losses, flat = buffers
+        if flat.numel() != nv + npx + npo + nws or losses.numel() != 12:
+            raise L.InvalidArgumentError("loss: the buffers were made for other shapes (loss_buffers(out))")
+    else:
+        losses = torch.empty(12, dtype=torch.float32, device=dev)
+        flat = M._zeros_f32((nv + npx + npo + nws,), dev)  # inside a train step: a carve-out of the pass's one zero fill
     d_votes, d_pxyz = flat[:nv].view_as(votes), flat[nv:nv + npx].view_as(pxyz)
     d_pout, ws = flat[nv + npx:nv + npx + npo].view_as(pout), flat[nv + npx + npo:]
     with L.device_guard(dev):

@@ -1099,7 +1099,7 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     if half is not None and half.nh_limit is not None:
         # the count is the device's: the dense GEMM stops at it too (rows = the upper bound)
         da = torch.empty((rows, cin), dtype=torch.float32, device=xz.device)
-        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "fwd"), limit=half):
+        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "gram-form dense dgrad half"), limit=half):
             L.check(L.lib().votenet_mlp_linear_half(L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0, rows, cin, cin, L.ptr(mm),
                                                     L.ptr(mm[cin]), L.ptr(da), L.ptr(half.nh_limit), L.stream_ptr()))
     elif img is not None:

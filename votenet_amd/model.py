@@ -149,13 +149,29 @@ class StretchGraph:
             if STRETCH_SEGMENTS:
                 end()
                 begin()
+
+        def loss_hook(out):
+            # the loss graph (two launches on the batch's ground truth: its shape -- the padded box count -- varies per batch) is NOT
+            # captured: it runs between the forward segment and the first backward segment, into buffers the latter reads at fixed
+            # addresses (a carve-out of the private arena: cleared by the first segment's fill)
+            from . import loss as VL
+            end()
+            self.loss_bufs = VL.loss_buffers(out)
+            self.loss_at = len(self.segments)  # the loss runs before this segment
+            losses, flat = self.loss_bufs
+            nv, npx = out["votes_xyz"].numel(), out["proposals_xyz"].numel()
+            npo = out["proposals_output"].numel()
+            cot = dict(votes_xyz=flat[:nv].view_as(out["votes_xyz"]), proposals_xyz=flat[nv:nv + npx].view_as(out["proposals_xyz"]),
+                       proposals_output=flat[nv + npx:nv + npx + npo].view_as(out["proposals_output"]))
+            begin()
+            return losses, cot
         cs.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(cs):
             begin()
             try:
                 self.arena.zero_()
                 with _PrivateArena(self.arena, nd) as pa:
-                    self.out, self.losses, self.grads = net._stretch_body(self.fixed, tape_levels, None, cut=cut)
+                    self.out, self.losses, self.grads = net._stretch_body(self.fixed, tape_levels, None, cut=cut, loss_hook=loss_hook)
             finally:
                 if cur[0] is not None:
                     end()
@@ -166,14 +182,18 @@ class StretchGraph:
     def copy_inputs(self, ins):
         M.copy_segments([(self.fixed[k], ins[k]) for k in self.names])
 
-    def replay(self, ins, wgrad_stream=None):
-        """One copy launch, then the segments in order; a segment's weight-gradient thunks go to wgrad_stream (None: the current one)
-        behind its graph.  The caller joins the weight-gradient stream (pointnet2.wgrad_join) before it reads the gradient bucket."""
+    def replay(self, ins, gt, wgrad_stream=None):
+        """One copy launch, then the segments in order -- the loss graph on gt as launches where it belongs --; a segment's
+        weight-gradient thunks go to wgrad_stream (None: the current one) behind its graph.  The caller joins the weight-gradient stream
+        (pointnet2.wgrad_join) before it reads the gradient bucket."""
+        from . import loss as VL
         self.copy_inputs(ins)
         prev = P.WGRAD_STREAM
         P.WGRAD_STREAM = wgrad_stream
         try:
-            for graph, thunks in self.segments:
+            for i, (graph, thunks) in enumerate(self.segments):
+                if i == self.loss_at:
+                    VL.votenet_loss(self.out, gt, buffers=self.loss_bufs)
                 graph.replay()
                 if thunks and wgrad_stream is not None:
                     P._hand_over([f for f, _ in thunks], ())  # (their tensors live in the graphs' pool: nothing for the allocator to track)
@@ -696,8 +716,9 @@ class VoteNetHotPath:
                     and not torch.cuda.is_current_stream_capturing())
 
     @staticmethod
-    def _stretch_inputs(lv, g, gt):
-        """name -> tensor: everything the stretch reads that lives at an address of this step's making."""
+    def _stretch_inputs(lv, g):
+        """name -> tensor: everything the captured segments read that lives at an address of this step's making (the ground truth is
+        not among them: the loss runs as launches between two segments)."""
         ins = dict(lv)
         for name in ("fp1", "fp2"):
             idx, w = g[name]
@@ -706,13 +727,12 @@ class VoteNetHotPath:
             if inv is not None:
                 ins[name + "_inv0"], ins[name + "_inv1"] = inv
         ins["prop_fps"] = g["prop_fps"]
-        for k, v in gt.items():
-            ins["gt/" + k] = v
         return ins
 
-    def _stretch_body(self, I, tape_levels, wgrad_stream, cut=None):
-        """The stretch on the tensors of I (StretchGraph captures this on its fixed buffers; tests run it eagerly): forward head, moving
-        averages, loss, backward head.  -> (out, losses, (d_l2p, d_l3p, d_l4p))."""
+    def _stretch_body(self, I, tape_levels, wgrad_stream, gt=None, cut=None, loss_hook=None):
+        """The stretch on the tensors of I (StretchGraph captures this on its fixed buffers; the first step of a shape runs it eagerly):
+        forward head, moving averages, loss (on gt, or through loss_hook(out) -> (losses, cotangents) when captured), backward head.
+        -> (out, losses, (d_l2p, d_l3p, d_l4p))."""
         from . import loss as VL
 
         def geom(name):
@@ -724,7 +744,7 @@ class VoteNetHotPath:
         lv = {k: I[k] for k in ("l2_xyz", "l2_p", "l3_xyz", "l3_p", "l4_xyz", "l4_p")}
         out = self._head_forward(lv, geom("fp1"), geom("fp2"), I["prop_fps"], tail, copy_seeds=False)
         self.update_moving_averages(list(tape_levels) + tail)
-        losses, cot = VL.votenet_loss(out, {k[3:]: v for k, v in I.items() if k.startswith("gt/")})
+        losses, cot = loss_hook(out) if loss_hook is not None else VL.votenet_loss(out, gt)
         P.WGRAD_STREAM = wgrad_stream
         try:
             grads = self._head_backward(tail, cot, cut=cut)
@@ -746,15 +766,14 @@ class VoteNetHotPath:
             g.setdefault("fp1", P.FPModule.geometry(lv["l3_xyz"], lv["l4_xyz"]))
             g.setdefault("fp2", P.FPModule.geometry(lv["l2_xyz"], lv["l3_xyz"]))
             g.setdefault("prop_fps", P.tf_sampling.farthest_point_sample(self.proposal.npoint, lv["l2_xyz"]))
-        ins = self._stretch_inputs(lv, g, gt)
+        ins = self._stretch_inputs(lv, g)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
                                                                              self.overlap_wgrad, STRETCH_SEGMENTS, M.CONFIG_EPOCH)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
         self._gsync.begin()
         if sg is None:
-            # what the stretch asks of the arena does not depend on the ground truth's shape or on library switches: one measurement serves
-            dkey = tuple(e for e in key[:len(ins)] if not e[0].startswith("gt/")) + key[len(ins):-1]
+            dkey = key[:-1]  # what the stretch asks of the arena does not depend on library switches: one measurement serves
             demand = self.__dict__.setdefault("_stretch_demand", {}).get(dkey)
             if demand is None:
                 # first step of this shape: the stretch launch by launch, measuring what it asks of the arena
@@ -763,7 +782,7 @@ class VoteNetHotPath:
                 self.check_tape(tape)
                 if self.overlap_wgrad and self._wgrad_stream is None:
                     self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
-                out, self.last_losses, grads = self._stretch_body(ins, tape, self._wgrad_stream if self.overlap_wgrad else None)
+                out, self.last_losses, grads = self._stretch_body(ins, tape, self._wgrad_stream if self.overlap_wgrad else None, gt=gt)
                 self._stretch_demand[dkey] = (a.off - off0, a.want32 - want0)
                 self._backward_levels_pass(tape, grads)
                 return out
@@ -775,7 +794,8 @@ class VoteNetHotPath:
         self.store._fresh_wait()
         if self.overlap_wgrad and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
-        out, self.last_losses, grads = sg.replay(ins, self._wgrad_stream if self.overlap_wgrad else None)
+        out, self.last_losses, grads = sg.replay(ins, gt, self._wgrad_stream if self.overlap_wgrad else None)
+        self._ema_version += 1  # (the replay ran votenet_ema_update: inference_bn() must not serve a table built before it)
         self._backward_levels_pass(tape, grads)
         return out
 
