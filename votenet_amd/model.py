@@ -63,6 +63,7 @@ class GeometryGraph:
         return self.g, {name: done for name in ("sa1", "sa2", "sa3", "sa4", "fp")}
 
 
+GRAMS_AHEAD = False      # train_step launches the Gram matrices of the levels' pooled layers (forward data only) on the weight-gradient stream under the stretch instead of beside the levels' backward GEMMs.  Measured (tools/probe/variant_step.py, three alternations): 3.78-3.81 -> 3.86-3.89 ms -- the stretch is a chain of tiny latency-bound kernels ON the critical path, and 0.27 ms of GPU-filling kernels beside it cost it more than they save the backward pass.  Off.
 STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as ONE HIP graph (StretchGraph)
 STRETCH_SEGMENTS = True  # the stretch as four graphs cut at the modules' ends, weight gradients launched between them (False: one graph, weight gradients inline)
 STRETCH_MAX_GRAPHS = 4   # graphs kept per net (one per ground-truth shape: the padded box count of a batch varies)
@@ -761,6 +762,7 @@ class VoteNetHotPath:
         self.store.refresh_split()
         lv, g = self.backbone_levels(x, tape, next_x=next_x)
         self._stamp_tape(tape)
+        self._grams_ahead(tape)
         if not all(k in g for k in ("fp1", "fp2", "prop_fps")):  # geometry computed without the taps (overlap off): the launch path
             g = dict(g)
             g.setdefault("fp1", P.FPModule.geometry(lv["l3_xyz"], lv["l4_xyz"]))
@@ -798,6 +800,28 @@ class VoteNetHotPath:
         self._ema_version += 1  # (the replay ran votenet_ema_update: inference_bn() must not serve a table built before it)
         self._backward_levels_pass(tape, grads)
         return out
+
+    def _grams_ahead(self, tape):
+        """The Gram matrix a^T a of a pooled layer's input (pool_bwd.hip) depends on forward data only.  Launched here -- behind the
+        levels' forward pass, on the weight-gradient stream -- the four of sa1..sa4 (0.27 ms of kernels) run under the static stretch,
+        whose own kernels leave most of the GPU idle, instead of beside the backward GEMMs of their levels."""
+        if not GRAMS_AHEAD or M.DETERMINISTIC or not self.overlap_wgrad or not torch.cuda.is_available():
+            return
+        todo = [t["recs"][-1] for t in tape[:4] if t.get("op") == "sa" and t["recs"][-1].get("gram_form") and t["recs"][-1].get("in_affine") is not None]
+        if not todo:
+            return
+        if self._wgrad_stream is None:
+            self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
+        prev = P.WGRAD_STREAM
+        P.WGRAD_STREAM = self._wgrad_stream
+
+        def run():
+            for r in todo:
+                r["gram_ahead"] = M.gram(r["x"], r["in_affine"][:2], r["in_relu"], half=r.get("half"))
+        try:
+            P.on_wgrad_stream(run, *[r["x"] for r in todo])
+        finally:
+            P.WGRAD_STREAM = prev
 
     def _backward_levels_pass(self, tape, grads):
         """backward() for the four levels only (the head's gradients given)."""
@@ -858,6 +882,7 @@ class VoteNetHotPath:
                 out = self._train_step_stretch(x, gt, tape, next_x)
             else:
                 out = self.forward(x, tape, next_x=next_x)
+                self._grams_ahead(tape)
                 self.update_moving_averages(tape)
                 if gt is not None:
                     from . import loss as VL

@@ -627,7 +627,9 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             mm = M.pool_dgrad_prepare(W, b, coef, x.shape[0]) if want_da else None
             half = r.get("half")
             def _pooled_wgrad(x=x, aff=aff, r=r, W=W, b=b, coef=coef, L=L, da=da, half=half):
-                G = M.gram(x, aff[:2], r["in_relu"], half=half)
+                G = r.pop("gram_ahead", None)  # the Gram matrix depends on forward data only: train_step may have launched it ahead
+                if G is None:
+                    G = M.gram(x, aff[:2], r["in_relu"], half=half)
                 M.pool_wgrad(x, r["in_scale"], r["in_shift"], r["in_relu"], G, W, b, coef, L.relu, da, argmax, zsel, k, L.gp("W"), half=half)
             on_wgrad_stream(_pooled_wgrad, x, aff, coef, da, argmax, zsel)
             if not want_da:
