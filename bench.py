@@ -387,9 +387,16 @@ def main():
     # pools for all three rotating batches and start the geometry pipeline -- one launch-by-launch chain, then the capture of the ring
     # of geometry graphs (model.GEOMETRY_RING, a device synchronise each; the forward workload prefetches two batches per call) --
     # one-time work of the process, like loading the library; reported as "setup_steps"
-    SETUP_STEPS = 6
-    for _ in range(SETUP_STEPS):
+    SETUP_STEPS = 8
+    for k in range(SETUP_STEPS):
+        # one set-up step is instrumented the way the timed region's will be (its prefetch enqueues the geometry chain launch by launch,
+        # into buffers of the caching allocator instead of a graph's pool): the allocator then OWNS those blocks -- without this the
+        # instrumented step of the timed region and its follower call hipMalloc (6 + 3 calls, milliseconds each: a 20-step run measured
+        # 4.16 ms per step around a median of 3.79)
+        if k == SETUP_STEPS - 3 and workload == "train" and pipeline:
+            tf_sampling.PROFILE_EVENTS, tf_grouping.PROFILE_EVENTS = [], []
         step()
+        tf_sampling.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS = None
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -410,6 +417,7 @@ def main():
     gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
     t0 = time.perf_counter()
+    host_marks = [t0]
     marks[0].record()
     for i in range(args.steps):
         if i == prof_first:
@@ -417,8 +425,14 @@ def main():
         if i == prof_first + prof_steps:
             events, tf_sampling.PROFILE_EVENTS = tf_sampling.PROFILE_EVENTS, None
             bq_events, tf_grouping.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS, None
-        step()
+        if os.environ.get("VOTENET_BENCH_PROFILE_STEP") == str(i):
+            import cProfile, pstats, io
+            pr = cProfile.Profile(); pr.enable(); step(); pr.disable()
+            sio = io.StringIO(); pstats.Stats(pr, stream=sio).sort_stats("tottime").print_stats(14); sys.stderr.write(sio.getvalue()[:4000])
+        else:
+            step()
         marks[i + 1].record()
+        host_marks.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -441,6 +455,7 @@ def main():
         dt = float(t.item())
     if os.environ.get("VOTENET_BENCH_STEP_TIMES"):
         sys.stderr.write("step times (ms): %s\n" % " ".join("%.2f" % marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)))
+        sys.stderr.write("host times (ms): %s\n" % " ".join("%.2f" % ((host_marks[i + 1] - host_marks[i]) * 1e3) for i in range(args.steps)))
     per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)
                       if not prof_first <= i < prof_first + prof_steps + 1)  # un-instrumented steps (and not the one that follows them), main stream
     spread = ({"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),

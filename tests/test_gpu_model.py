@@ -449,8 +449,17 @@ def test_stretch_graph_replays_are_the_launch_by_launch_step(hiplib, dev, monkey
         assert torch.equal(nn(l0), nn(l1)), (i, l0.tolist(), l1.tolist())
         assert torch.equal(e0, e1), i
         assert float((g0 - g1).abs().max()) <= 1e-4 * float(g0.abs().max()), i
-    assert not ref.__dict__.get("_stretch_graphs") and len(got._stretch_graphs) >= 1
+    assert not ref.__dict__.get("_stretch_graphs") and len(got._stretch_graphs) == 1  # one capture: the graphs do not depend on the ground truth's shape
     assert sum(g.replays for g in got._stretch_graphs.values()) == 8 - 1  # every step but the measuring one
+    # the outputs of a replayed step live in the capture's pool: a handle kept across the next step raises instead of reading that step's values
+    from votenet_amd import VotenetError
+    monkeypatch.setattr(VM, "STRETCH_GRAPH", True)
+    o1 = got.train_step(xs[0], gt=gts[0])
+    keep = o1["proposals_output"].clone()
+    o2 = got.train_step(xs[1], gt=gts[1])
+    assert o2["proposals_output"].shape == keep.shape
+    with pytest.raises(VotenetError, match="replayed for a later step"):
+        o1["proposals_output"]
 
 
 def test_moving_averages_follow_tensorflows_update(hiplib, dev):

@@ -93,6 +93,21 @@ class _PrivateArena:
         return False
 
 
+class _StretchOutputs(dict):
+    """What a replayed train step returns: the forward results in the capture's memory pool, which the NEXT replay of that capture
+    overwrites.  Reading an entry after that raises instead of handing out another batch's values (clone what has to outlive the step)."""
+
+    def __init__(self, tensors, graph):
+        super().__init__(tensors)
+        self._graph, self._stamp = graph, graph.replays
+
+    def __getitem__(self, key):
+        if self._graph.replays != self._stamp:
+            raise M.L.VotenetError("train_step outputs: the stretch graph that holds %r has been replayed for a later step (the tensors a "
+                                   "replayed step returns are valid until the next step: clone them to keep them)" % key)
+        return super().__getitem__(key)
+
+
 class StretchGraph:
     """The static stretch of a train step -- feature propagation, voting and the proposal module forward (model.py:48-61,89-93), the
     moving averages, the loss graph (model.py:61-84,141-231), and the backward pass of all of it down to the gradients of the level
@@ -204,7 +219,7 @@ class StretchGraph:
         finally:
             P.WGRAD_STREAM = prev
         self.replays += 1
-        return self.out, self.losses, self.grads
+        return _StretchOutputs(self.out, self), self.losses, self.grads
 
 
 SPLIT_BF16 = True  # fused GEMMs on bf16 x 3 split operands (fp32-accurate products, six bf16 MFMAs per k-step; mlp.SplitImages)
@@ -710,10 +725,10 @@ class VoteNetHotPath:
 
     # ---- the static stretch of a train step as one HIP graph (StretchGraph) -------------------------------------------------------
     def _stretch_eligible(self, x, cot, gt):
-        from . import tf_interpolate
+        # (per-launch events around the GEMMs -- mlp.PROFILE_EVENTS -- need the launches; events around the sampling / ball-query launches
+        # -- bench.py's roofline legs -- concern the geometry chain only: a captured stretch still replays, see _train_step_stretch)
         return bool(STRETCH_GRAPH and gt is not None and cot is None and x.is_cuda and not M.DETERMINISTIC and PREFETCH_AFTER < 5
-                    and M.PROFILE_EVENTS is None and P.tf_sampling.PROFILE_EVENTS is None and P.tf_grouping.PROFILE_EVENTS is None
-                    and P._FROZEN.table is None and not getattr(self, "_stretch_off", False)
+                    and M.PROFILE_EVENTS is None and P._FROZEN.table is None and not getattr(self, "_stretch_off", False)
                     and not torch.cuda.is_current_stream_capturing())
 
     @staticmethod
@@ -777,8 +792,10 @@ class VoteNetHotPath:
         if sg is None:
             dkey = key[:-1]  # what the stretch asks of the arena does not depend on library switches: one measurement serves
             demand = self.__dict__.setdefault("_stretch_demand", {}).get(dkey)
-            if demand is None:
-                # first step of this shape: the stretch launch by launch, measuring what it asks of the arena
+            geometry_events = P.tf_sampling.PROFILE_EVENTS is not None or P.tf_grouping.PROFILE_EVENTS is not None
+            if demand is None or geometry_events:
+                # first step of this shape: the stretch launch by launch, measuring what it asks of the arena (also while somebody records
+                # events around the geometry launches: the proposal module's ball query sits in the stretch -- no capture then)
                 a = M._StatsArena
                 off0, want0 = a.off, a.want32
                 self.check_tape(tape)
