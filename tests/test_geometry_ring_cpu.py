@@ -105,3 +105,35 @@ def test_a_tape_whose_geometry_was_overwritten_is_refused():
     g.generation = 4
     with pytest.raises(VotenetError, match="overwritten by 1 later prefetch"):
         VM.VoteNetHotPath.check_tape(tape)
+
+
+def test_private_arena_borrows_and_restores_the_pass_arena():
+    """model._PrivateArena (the scratch of a captured stretch): requests made inside come out of the private buffer, the enclosing pass's
+    arena state -- cursors included -- is back afterwards, and the demand the stretch made is reported."""
+    a = M._StatsArena
+    saved = {k: getattr(a, k) for k in VM._PrivateArena.FIELDS}
+    try:
+        a.buf, a.nd, a.cap32, a.zeroed32 = torch.zeros(64 + 128, dtype=torch.float64), 64, 256, 256
+        a.off, a.off32, a.want32, a.depth, a.active, a.whole_step = 10, 20, 24, 1, True, False
+        outer = a.buf
+        priv = torch.zeros(32 + 64, dtype=torch.float64)
+        with VM._PrivateArena(priv, 32) as pa:
+            assert a.buf is priv and a.off == 0 and a.off32 == 0 and a.cap32 == 128 and a.whole_step
+            v64 = M._zeros_f64(6, torch.device("cpu"))
+            v32 = M._zeros_f32((5,), torch.device("cpu"))
+            assert v64.data_ptr() == priv.data_ptr() and v32.data_ptr() == priv.data_ptr() + 32 * 8
+        assert pa.used == (6, 8)  # doubles, floats (rounded up to 16 bytes)
+        assert a.buf is outer and (a.off, a.off32, a.want32, a.whole_step) == (10, 20, 24, False)
+    finally:
+        for k, v in saved.items():
+            setattr(a, k, v)
+
+
+def test_outputs_of_a_replayed_step_refuse_stale_reads():
+    from votenet_amd import VotenetError
+    g = types.SimpleNamespace(replays=3)
+    out = VM._StretchOutputs({"votes_xyz": torch.zeros(2)}, g)
+    assert out["votes_xyz"].shape == (2,) and "votes_xyz" in out
+    g.replays = 4  # the capture ran again: its pool holds a later step's values
+    with pytest.raises(VotenetError, match="replayed for a later step"):
+        out["votes_xyz"]
