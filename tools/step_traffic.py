@@ -28,7 +28,7 @@ def main(fetch_db, write_db, steps):
         dur = (rd.get(k) or wr.get(k))[2] / 1e3
         rows.append((r + w, k, cnt, r, w, dur))
     tot = sum(x[0] for x in rows)
-    print("# all dispatches of the run (%d steps incl. set-up and warm-up): %.1f GB read + written = %.2f GB per step" % (steps, tot / 1e3, tot / 1e3 / steps))
+    print("# all dispatches of the run (%d steps incl. 8 set-up and 2 warm-up steps): %.1f GB read + written = %.2f GB per step" % (steps, tot / 1e3, tot / 1e3 / steps))
     print("%-66s %9s %11s %11s %7s %10s" % ("kernel", "per step", "rd MB/step", "wr MB/step", "share", "GB/s (pmc)"))
     for t, k, cnt, r, w, dur in sorted(rows, reverse=True)[:45]:
         print("%-66s %9.1f %11.1f %11.1f %6.1f%% %10.0f" % (k[:66], cnt / steps, r / steps, w / steps, 100 * t / tot, t / 1e3 / (dur * 1e-6) if dur else 0))
