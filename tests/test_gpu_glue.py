@@ -211,6 +211,30 @@ def test_inverse_index_long_lists_and_bad_indices(hiplib, dev, hot):
         assert torch.equal(offsets.long(), torch.searchsorted(pts, torch.arange(b * m + 1, device=dev)))
 
 
+def test_copy_segments_is_copy_(hiplib, dev):
+    """votenet_copy_segments (the inputs of a captured stretch go into the capture's fixed buffers with ONE launch): every pair is
+    dst.copy_(src) -- float and int tensors, sizes with tails below 16 bytes, operands off 16-byte alignment, an empty list, too many."""
+    from votenet_amd import InvalidArgumentError
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(3)
+    big = torch.randn(1 << 20, generator=g).to(dev)
+    srcs = [torch.randn(8, 1024, 3, generator=g).to(dev), torch.randint(0, 1 << 30, (8, 512, 3), generator=g, dtype=torch.int32).to(dev),
+            torch.randn(7, generator=g).to(dev), big[1:4098], big[3:1003].view(10, 100), torch.randint(0, 99, (5,), generator=g).to(dev),
+            torch.randn(8, 1024, 256, generator=g).to(dev), torch.empty(0, device=dev)]
+    dsts = [torch.full_like(t, 7) for t in srcs]
+    odd = torch.zeros(4200, device=dev)
+    dsts[3] = odd[5:4102]   # destination off 16-byte alignment too
+    M.copy_segments(list(zip(dsts, srcs)))
+    for d, t in zip(dsts, srcs):
+        assert torch.equal(d, t)
+    assert float(odd[:5].abs().sum()) == 0.0 and float(odd[4102:].abs().sum()) == 0.0  # nothing written beside the segment
+    M.copy_segments([])
+    with pytest.raises(InvalidArgumentError):
+        M.copy_segments([(torch.zeros(4, device=dev), torch.zeros(5, device=dev))])
+    with pytest.raises(InvalidArgumentError):
+        M.copy_segments([(torch.zeros(1, device=dev), torch.zeros(1, device=dev))] * 33)
+
+
 def test_three_interpolate_grad_gather_form_on_a_column_slice(hiplib, dev):
     """tf_interpolate.GATHER_GRAD: the gradient as a gather-sum over the taps' inverse index, reading a column slice of a wider tensor in
     place (votenet_csr_gather_sum_pitched), against the scatter-add with atomics."""
