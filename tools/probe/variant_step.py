@@ -18,11 +18,18 @@ dev = torch.device("cuda:0")
 xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in (1000, 500000, 900000)]
 gts = [VL.gt_to_device(synth.room_gt(8, 20480, s), dev) for s in (1000, 500000, 900000)]
 net = VM.VoteNetHotPath(dev, seed=0)
+print("stream priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a")
+main = torch.cuda.Stream(priority=int(os.environ["MAIN_PRIORITY"])) if os.environ.get("MAIN_PRIORITY") else None
 def run(k):
+    if main is not None:
+        with torch.cuda.stream(main):
+            for i in range(k):
+                net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
+        return
     for i in range(k):
         net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
 run(10); torch.cuda.synchronize(); gc.collect(); gc.disable()
 res = []
 for rep in range(3):
     t0 = time.perf_counter(); run(30); torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 30 * 1e3)
-print("variant %-10s %-60s ms per step: %s" % (os.environ.get("VARIANT") or "(built)", os.environ.get("TOGGLES", ""), " ".join("%.3f" % v for v in res)))
+print("variant %-10s %-60s ms per step: %s" % (os.environ.get("VARIANT") or "(built)", os.environ.get("TOGGLES", "") + (" main stream priority " + os.environ["MAIN_PRIORITY"] if os.environ.get("MAIN_PRIORITY") else ""), " ".join("%.3f" % v for v in res)))

@@ -17,14 +17,15 @@ def gt_to_device(gt, device):
     return {k: torch.from_numpy(gt[k]).contiguous().to(device) for k in GT_KEYS}
 
 
-def loss_buffers(out):
+def loss_buffers(out, losses=None):
     """The output buffers of votenet_loss for the tensors of `out`, allocated once by a caller that wants them at fixed addresses
     (model.StretchGraph: the segments captured behind the loss read the cotangents there): -> (losses (12,), flat).  flat holds the three
     cotangents and the kernel's workspace and must be ZERO when votenet_loss(..., buffers=) runs (here: a carve-out of the pass's arena)."""
     from . import mlp as M
     votes, pxyz, pout = out["votes_xyz"], out["proposals_xyz"], out["proposals_output"]
     nws = int(L.lib().votenet_loss_workspace_floats(votes.shape[0]))
-    losses = torch.empty(12, dtype=torch.float32, device=votes.device)
+    if losses is None:
+        losses = torch.empty(12, dtype=torch.float32, device=votes.device)
     return losses, M._zeros_f32((votes.numel() + pxyz.numel() + pout.numel() + nws,), votes.device)
 
 

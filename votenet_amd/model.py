@@ -64,9 +64,9 @@ class GeometryGraph:
 
 
 GRAMS_AHEAD = False      # train_step launches the Gram matrices of the levels' pooled layers (forward data only) on the weight-gradient stream under the stretch instead of beside the levels' backward GEMMs.  Measured (tools/probe/variant_step.py, three alternations): 3.78-3.81 -> 3.86-3.89 ms -- the stretch is a chain of tiny latency-bound kernels ON the critical path, and 0.27 ms of GPU-filling kernels beside it cost it more than they save the backward pass.  Off.
-STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as ONE HIP graph (StretchGraph)
-STRETCH_SEGMENTS = True  # the stretch as four graphs cut at the modules' ends, weight gradients launched between them (False: one graph, weight gradients inline)
-STRETCH_MAX_GRAPHS = 4   # graphs kept per net (one per ground-truth shape: the padded box count of a batch varies)
+STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as HIP graph segments (StretchGraph)
+STRETCH_SEGMENTS = True  # the stretch's input-gradient chain cut into graphs at the modules' ends, the weight gradients launched between them (False: two graphs around the loss, weight gradients inline)
+STRETCH_MAX_GRAPHS = 4   # captures kept per net (one per input shape / configuration; least recently replayed goes first)
 
 
 class _PrivateArena:
@@ -135,6 +135,7 @@ class StretchGraph:
         self.nd = nd
         self.arena = torch.empty(nd + (n32 + 1) // 2, dtype=torch.float64, device=dev)
         self.segments = []  # (graph, [(thunk, tensors) ...]) in replay order
+        self._losses = torch.empty(12, dtype=torch.float32, device=dev)
         self.replays = 0
         self.last_used = 0
         if getattr(net, "_capture_stream", None) is None:
@@ -172,7 +173,7 @@ class StretchGraph:
             # addresses (a carve-out of the private arena: cleared by the first segment's fill)
             from . import loss as VL
             end()
-            self.loss_bufs = VL.loss_buffers(out)
+            self.loss_bufs = VL.loss_buffers(out, losses=self._losses)  # (the losses vector: allocated on the caller's stream, below)
             self.loss_at = len(self.segments)  # the loss runs before this segment
             losses, flat = self.loss_bufs
             nv, npx = out["votes_xyz"].numel(), out["proposals_xyz"].numel()
