@@ -14,6 +14,9 @@ for t in os.environ.get("TOGGLES", "").split():  # e.g. TOGGLES="pointnet2.ASSEM
     name, val = t.split("=")
     modname, attr = name.rsplit(".", 1)
     setattr(importlib.import_module("votenet_amd." + modname), attr, eval(val))
+for h in os.environ.get("HOOKS", "").split():  # e.g. HOOKS="votenet_debug_fps_lds_floor=131072"
+    name, val = h.split("=")
+    getattr(L_.lib(), name)(*[int(v) for v in val.split(",")])
 dev = torch.device("cuda:0")
 xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in (1000, 500000, 900000)]
 gts = [VL.gt_to_device(synth.room_gt(8, 20480, s), dev) for s in (1000, 500000, 900000)]
@@ -29,7 +32,13 @@ def run(k):
     for i in range(k):
         net.train_step(xs[i % 3], gt=gts[i % 3], next_x=[xs[(i + 1) % 3]])
 run(10); torch.cuda.synchronize(); gc.collect(); gc.disable()
+from votenet_amd import tf_sampling
 res = []
 for rep in range(3):
     t0 = time.perf_counter(); run(30); torch.cuda.synchronize(); res.append((time.perf_counter() - t0) / 30 * 1e3)
-print("variant %-10s %-60s ms per step: %s" % (os.environ.get("VARIANT") or "(built)", os.environ.get("TOGGLES", "") + (" main stream priority " + os.environ["MAIN_PRIORITY"] if os.environ.get("MAIN_PRIORITY") else ""), " ".join("%.3f" % v for v in res)))
+tf_sampling.PROFILE_EVENTS = []
+run(3); torch.cuda.synchronize()
+ev = [e0.elapsed_time(e1) for (e0, e1, b_, n_, m_) in tf_sampling.PROFILE_EVENTS if n_ == 20480]
+tf_sampling.PROFILE_EVENTS = None
+print("sa1 FPS inside the step: %s ms" % " ".join("%.3f" % v for v in ev))
+print("variant %-10s %-60s ms per step: %s" % (os.environ.get("VARIANT") or "(built)", os.environ.get("TOGGLES", "") + " " + os.environ.get("HOOKS", "") + (" main stream priority " + os.environ["MAIN_PRIORITY"] if os.environ.get("MAIN_PRIORITY") else ""), " ".join("%.3f" % v for v in res)))
