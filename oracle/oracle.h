@@ -14,12 +14,15 @@
  * Pinning status (see oracle/README.md):
  *   ball query / group / group-grad ... pinned against the reference's own compiled
  *                                       CPU twins (oracle/_ref, built from
- *                                       tf_ops/grouping/test/query_ball_point.cpp)
+ *                                       tf_ops/grouping/test/query_ball_point.cpp) and against
+ *                                       its device kernels (tf_grouping_g.cu compiled for gfx950:
+ *                                       oracle/_ref/libref_grouping_gpu.so, ref_gpu_grouping.npz)
  *   three_nn / interpolate / grad ..... pinned against oracle/_ref built from
  *                                       tf_ops/3d_interpolation/interpolate.cpp
- *   FPS / gather / scatter-add ........ restatement of a CUDA-only kernel; the
- *                                       reference holds no test for it: PARITY UNPINNED
- *                                       beyond property tests
+ *   FPS / gather / scatter-add ........ restatement of a device-only kernel, pinned against
+ *                                       that kernel itself: tf_sampling_g.cu compiled for
+ *                                       gfx950 where it lies (oracle/_ref/libref_sampling_gpu.so;
+ *                                       fixtures tests/golden/ref_gpu_fps.npz, ref_gpu_gather.npz)
  *   3D IoU / NMS ...................... tf_nms3d.cpp needs TensorFlow headers, which
  *                                       this image lacks: unbuildable here.  Pinned only
  *                                       by the known answer of the reference's own smoke
@@ -27,10 +30,9 @@
  *                                       polygon-clipping cross-check: PARITY PARTIAL
  *   SelectionSort ..................... pinned against oracle/_ref built from
  *                                       tf_ops/grouping/test/selection_sort.cpp
- *   ProbSample ........................ restatement of a CUDA-only kernel, no reference
- *                                       test: PARITY UNPINNED (the scan tree is checked
- *                                       against a literal simulation of the kernel's index
- *                                       loops in tests/test_oracle_variants.py)
+ *   ProbSample ........................ restatement of a device-only kernel, pinned against
+ *                                       that kernel itself (same library; fixture
+ *                                       tests/golden/ref_gpu_prob_sample.npz: cumsum and picks)
  *   grouped MLP ....................... arithmetic lives in Tensorpack/TensorFlow 1.x
  *                                       (not in the reference tree, versions unpinned):
  *                                       PARITY UNPINNED, semantics defined here

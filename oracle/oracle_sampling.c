@@ -1,7 +1,11 @@
 /*
  * oracle_sampling.c -- CPU restatement of tf_ops/sampling (FPS, gather, scatter-add).
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: the reference has no CPU
- * implementation and no test of these ops; this follows the CUDA kernel line by line.
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  The reference has no CPU implementation and no test of these ops; this follows
+ * the device kernel line by line and is PINNED against that kernel itself: tf_sampling_g.cu includes nothing and calls no
+ * CUDA runtime function, so hipcc compiles it for gfx950 where it lies (oracle/_ref/libref_sampling_gpu.so, oracle/Makefile)
+ * and its outputs on MI355X are the fixtures tests/golden/ref_gpu_{fps,gather}.npz (every pick of the 8 x 20480 -> 2048
+ * headline clouds among them: tests/test_oracle_ref_gpu_golden.py; live three-way comparison on the GPU box:
+ * tests/test_gpu_reference_kernels.py).
  */
 #include "oracle.h"
 #include <stdlib.h>

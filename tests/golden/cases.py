@@ -104,6 +104,17 @@ def fps_cases():
     return cases
 
 
+def full_size_cases():
+    """The clouds of BASELINE.json's configs for the fixtures computed by the reference's device kernels (make_ref_gpu_golden.py):
+    config 2/3 (8 x 20480 room scenes -> 2048), the uniform-cube variant, one scene of config 5 (80000 -> 2048).  (cloud, m) by name."""
+    from votenet_amd import synth
+    return {
+        "room_8x20480": (synth.room_batch(8, 20480, seed0=1000), 2048),
+        "uniform_2x20480": (synth.uniform_batch(2, 20480, seed0=1000), 2048),
+        "scan_1x80000": (synth.room_batch(1, 80000, seed0=5000, size=(8.0, 3.0, 8.0), nbox=(15, 25)), 2048),
+    }
+
+
 def selection_sort_cases():
     """SelectionSort inputs: the reference twin's own main() (test/selection_sort.cpp:66-77: b=2,n=4,m=2,k=3,
     dist[i] = 10-i), the kNN demo of tf_grouping.py:75-90 (squared distances of the demo clouds, k = 64; first 4 scenes),

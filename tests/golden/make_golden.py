@@ -5,9 +5,10 @@
 Expected outputs come from the REFERENCE's own compiled code (oracle/_ref, built by
 oracle/Makefile from tf_ops/grouping/test/query_ball_point.cpp, tf_ops/grouping/test/selection_sort.cpp and
 tf_ops/3d_interpolation/interpolate.cpp) wherever it exists, and are tagged source="ref".
-Where the reference cannot run here (FPS: CUDA only; NMS: needs TensorFlow headers) they come
-from the oracle restatement and are tagged source="oracle" -- plus the known answer of the
-reference's NMS smoke input recorded in SURVEY.md section 4.
+Where the reference cannot run here (FPS / ProbSample: device kernels, no GPU in this container; NMS: needs TensorFlow
+headers) they come from the oracle restatement and are tagged source="oracle" -- plus the known answer of the reference's
+NMS smoke input recorded in SURVEY.md section 4.  The device kernels' own outputs on MI355X are separate fixtures
+(ref_gpu_*.npz, written on the GPU box by make_ref_gpu_golden.py) that the oracle-made ones are tested against.
 Large tensors are stored as sha256 digests of their bytes (integer / pure-copy results are
 bit-exact, so a digest is a complete check).
 """
@@ -93,7 +94,7 @@ def main():
                         keep_025=O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.25),
                         keep_050=O.nms3d(c["bboxes"], c["scores"], c["objectiveness"], 0.5), source="oracle")
 
-    # ---- FPS cases (oracle; the reference holds no FPS test: parity unpinned)
+    # ---- FPS cases (oracle; the same cases computed by the reference kernel itself: ref_gpu_fps.npz, make_ref_gpu_golden.py)
     out = {}
     for name, (xyz, m) in cases.fps_cases().items():
         a = O.farthest_point_sample(m, xyz)
@@ -111,7 +112,7 @@ def main():
             out[name + "_idx_sha"], out[name + "_val_sha"], out[name + "_idx_head"] = sha(outi), sha(val), outi[0, :2, :k]
     np.savez_compressed(os.path.join(HERE, "selection_sort.npz"), source="ref", **out)
 
-    # ---- ProbSample (oracle; CUDA-only in the reference, no reference test: parity unpinned)
+    # ---- ProbSample (oracle; the same cases computed by the reference kernels themselves: ref_gpu_prob_sample.npz)
     out = {}
     for name, (p, r) in cases.prob_sample_cases().items():
         out[name] = O.prob_sample(p, r)
