@@ -652,11 +652,15 @@ __device__ unsigned long long g_fps_trace[8]; // cycles summed over rounds, per 
 #else
 #define FPS_T(i)
 #endif
+#ifndef FPS_PRIO
+#define FPS_PRIO 0 // probe builds (tools/probe/fps_prio.sh): s_setprio of the sampling waves against whatever shares their SIMDs
+#endif
 template <int NW, int VW>
 __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const float *__restrict__ xyz,
                                                              const int *__restrict__ perm, const float *__restrict__ bbox,
                                                              const float4 *__restrict__ sorted, int *__restrict__ out)
 {
+    if (FPS_PRIO) __builtin_amdgcn_s_setprio(FPS_PRIO);
     constexpr int P = VW;
     typedef typename SlotVec<VW>::type vec_t;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
