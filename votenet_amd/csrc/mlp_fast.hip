@@ -49,7 +49,8 @@ constexpr int FG_LDA = FG_BM + 2;
 #define BF3_PRIO 0 // BF3: 1 = matrix loop at s_setprio 1, epilogue at 0; 2 = the reverse; 3 = prio 1 only around the MFMAs of a slab
 #endif
 #ifndef BF3_ABL
-#define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging
+#define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging,
+                  // 16 the W image neither loaded nor staged after the prologue (upper bound of what LDS-resident weights could save)
 #endif
 #ifndef EPI6_ROWS
 #define EPI6_ROWS 8 // EPI 6: rows of a 32 x 32 sub-tile column whose P gathers are in flight together (8 or 16)
@@ -345,6 +346,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if constexpr (BF3) {
 #pragma unroll
             for (int u = 0; u < 3; u++) {
+                if ((BF3_ABL & 16) && !abl_prologue) break; // probe: the W image neither loaded nor staged after the prologue
                 if constexpr (BN == 128) {
                     r.bq[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, (unsigned)u * wpitch, 0));
                 } else {
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             *reinterpret_cast<uint2 *>(&As3[buf][2][ap][ao + 256]) = make_uint2(l[2], l[3]);
 #pragma unroll
             for (int u = 0; u < 3; u++) {
+                if ((BF3_ABL & 16) && !abl_prologue) break;
                 if constexpr (BN == 128) *reinterpret_cast<uint4 *>(&Bs3[buf][u][b3_pl][b3_c * 4]) = r.bq[u];
                 else *reinterpret_cast<uint2 *>(&Bs3[buf][u][b3_pl][b3_c * 4 + b3_h * 2]) = make_uint2(r.bq[u].x, r.bq[u].y);
             }
