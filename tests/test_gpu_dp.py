@@ -139,3 +139,61 @@ def test_bench_gpus_2_line_validates_its_own_data_parallel_path():
     assert [w for w, _ in c["collectives_per_step"]] == ["tail", "head"] and c["tail_exposed_ms"] is not None
     assert line["communicator"]["world_size"] == 2 and line["communicator"]["backend"] == "gloo"
     assert c["distinct_devices"] == 1   # both ranks on cuda:0 HERE (the flag above); N on the driver's node
+
+
+_RCCL_BESIDE_GRAPHS = r"""
+import os, sys, json
+sys.path.insert(0, %(root)r)
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = %(port)r
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import torch, torch.distributed as dist
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+from votenet_amd import dp, synth, loss as VL, model as VM
+xs = [torch.from_numpy(synth.room_batch(2, 8192, s)).to(dev) for s in (11, 22, 33)]
+gts = [VL.gt_to_device(synth.room_gt(2, 8192, s), dev) for s in (11, 22, 33)]
+nets = [VM.VoteNetHotPath(dev, seed=5, npoints=(1024, 512, 256, 128)) for _ in range(2)]
+for n in nets:
+    n.init_optimizer(1e-3)
+split = nets[0].store.offset_of("sa3/")
+nets[0]._gsync = dp.GradSync(nets[0].store, split, force=True)   # a ONE-rank RCCL communicator carries both collectives of every step
+logs, gdiff, finite = [], [], True
+for i in range(12):
+    for n in nets:
+        n.train_step(xs[i %% 3], gt=gts[i %% 3], next_x=[xs[(i + 1) %% 3]])
+    torch.cuda.synchronize()
+    logs.append(list(nets[0]._gsync.log))
+    if i == 0:  # same state, same batch: the exchanged bucket is the local gradient (a sum over one rank), up to the atomics' order
+        a, b = nets[0].store.grad, nets[1].store.grad
+        gdiff.append(float((a - b).abs().max() / b.abs().max()))
+    finite = finite and bool(torch.isfinite(nets[0].store.flat).all()) and bool(torch.isfinite(nets[0].last_losses).all())
+    nets[1].store.flat.copy_(nets[0].store.flat); nets[1]._m.copy_(nets[0]._m); nets[1]._v.copy_(nets[0]._v)
+sg = list(nets[0]._stretch_graphs.values())
+print(json.dumps(dict(logs=logs, gdiff=gdiff, finite=finite, n_stretch=len(sg), replays=[g.replays for g in sg],
+                      numel=nets[0].store.grad.numel(), split=split,
+                      loss=[float(nets[0].last_losses[0]), float(nets[1].last_losses[0])])))
+dist.destroy_process_group()
+"""
+
+
+def test_stretch_and_geometry_graphs_replay_beside_a_live_rccl_communicator(hiplib):
+    """What `bench.py --gpus N` does on every rank, on the one GPU of this box: the DEFAULT train step -- geometry ring and stretch
+    segments captured (thread_local capture mode) and replayed -- while a process group's RCCL communicator and its watchdog thread
+    are alive and dp.GradSync issues the tail / head all-reduces of every step from the communication stream (force=True: a one-rank
+    communicator still runs them).  The deterministic self-check of bench.py never replays a graph, and the two-rank tests run over
+    gloo: this is the combination they leave out.  Checked: no capture is invalidated, both collectives in every step, the captured
+    stretch replays, the exchanged bucket is the local gradient, losses finite and equal to a replica without a process group."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    code = _RCCL_BESIDE_GRAPHS % dict(root=ROOT, port=str(_free_port()))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["finite"]
+    assert d["logs"] == [[["tail", d["numel"] - d["split"]], ["head", d["split"]]]] * 12
+    assert d["n_stretch"] == 1 and d["replays"][0] >= 9      # step 1 measures the arena demand, step 2 captures, the rest replay
+    assert d["gdiff"][0] < 1e-4
+    assert abs(d["loss"][0] - d["loss"][1]) <= 1e-4 * abs(d["loss"][1])
