@@ -53,7 +53,10 @@ _pj.update({"fps_sa1": {"hbm_bytes_per_launch": int(fb[1] + fb[2]), "fetch_bytes
             "ball_query_sa1": {"hbm_bytes_per_launch": int(grp["bq"][1] + grp["bq"][2]), "source": "profiles/%s_pmc_fps.txt" % tag},
             "source": "profiles/%s_pmc_fps.txt" % tag})
 json.dump(_pj, open(_pj_path, "w"), indent=1)
-# ---- MLP
+# ---- MLP (skipped when the run collected the sampling counters only: tools/pmc_fps.sh)
+if not os.path.exists(os.path.join(src, "mlp_sq.txt")):
+    print(open(os.path.join(P, "%s_pmc_fps.txt" % tag)).read())
+    sys.exit(0)
 sq, mf, mw = table("mlp_sq.txt"), table("mlp_fetch.txt"), table("mlp_write.txt")
 hdr = open(os.path.join(src, "mlp_sq.txt")).read().splitlines()[1].split()
 ci = {name: i for i, name in enumerate(hdr[3:])}
