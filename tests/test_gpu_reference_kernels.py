@@ -153,3 +153,48 @@ def test_selection_sort_and_knn_are_the_reference_kernel(ops, dev, R):
     ri, rv = R.selection_sort(16, d)
     val, idx = ops.g.knn_point(16, T(a, dev), T(q, dev))
     assert (N(idx) == ri[..., :16]).all() and (N(val) == rv[..., :16]).all()
+
+
+def test_edge_shapes_against_the_reference_kernels(ops, dev, R):
+    """The corners the reference kernels define by construction: a one-point cloud, m = 1, nsample = 1, a radius that reaches nothing
+    and one that reaches everything, one feature channel and many, k = 1 and k = n in SelectionSort."""
+    rng = np.random.default_rng(41)
+    one = rng.random((2, 1, 3), dtype=np.float32)
+    assert (N(ops.s.farthest_point_sample(1, T(one, dev))) == R.farthest_point_sample(1, one)).all()
+    assert (N(ops.s.farthest_point_sample(5, T(one, dev))) == R.farthest_point_sample(5, one)).all()  # m > n = 1: index 0 repeats
+    xyz = rng.random((2, 777, 3), dtype=np.float32)
+    q = rng.random((2, 33, 3), dtype=np.float32)
+    for r, k in ((1e-6, 8), (10.0, 1), (10.0, 16), (0.15, 1), (0.15, 1000)):
+        ridx, rcnt = R.query_ball_point(r, k, xyz, q)
+        idx, cnt = ops.g.query_ball_point(r, k, T(xyz, dev), T(q, dev))
+        assert (N(idx) == ridx).all() and (N(cnt) == rcnt).all(), (r, k)
+    ridx, _ = R.query_ball_point(0.3, 12, xyz, q)
+    for c in (1, 2, 67, 256):
+        feats = rng.standard_normal((2, 777, c)).astype(np.float32)
+        assert (N(ops.g.group_point(T(feats, dev), T(ridx, dev))) == R.group_point(feats, ridx)).all(), c
+        cot = rng.integers(-3, 4, size=(2, 33, 12, c)).astype(np.float32)
+        assert (N(ops.g.group_point_grad_raw(777, T(ridx, dev), T(cot, dev))) == R.group_point_grad(777, ridx, cot)).all(), c
+    d = rng.random((2, 5, 40), dtype=np.float32)
+    for k in (1, 40):
+        ri, rv = R.selection_sort(k, d)
+        oi, ov = ops.g.select_top_k(k, T(d, dev))
+        assert (N(oi)[..., :k] == ri[..., :k]).all() and (N(ov)[..., :k] == rv[..., :k]).all(), k
+
+
+def test_whole_geometry_chain_of_a_backbone_pass_is_the_reference_kernels(ops, dev, R):
+    """sa1 ... sa4 of model.py's backbone on two room scenes, every level's sampling, gather, ball query and grouping computed by the
+    reference's own kernels and by the product, each level fed with the reference's result of the level above: 20480 -> 2048 (r 0.2, K 64)
+    -> 1024 (0.4, 32) -> 512 (0.8, 16) -> 256 (1.2, 16)."""
+    from votenet_amd import synth
+    xyz = synth.room_batch(2, 20480, 31337)
+    for m, r, k in ((2048, 0.2, 64), (1024, 0.4, 32), (512, 0.8, 16), (256, 1.2, 16)):
+        ref_fps = R.farthest_point_sample(m, xyz)
+        assert (N(ops.s.farthest_point_sample(m, T(xyz, dev))) == ref_fps).all(), m
+        ref_new = R.gather_point(xyz, ref_fps)
+        assert (N(ops.s.gather_point(T(xyz, dev), T(ref_fps, dev))) == ref_new).all(), m
+        ridx, rcnt = R.query_ball_point(r, k, xyz, ref_new)
+        idx, cnt = ops.g.query_ball_point(r, k, T(xyz, dev), T(ref_new, dev))
+        assert (N(idx) == ridx).all() and (N(cnt) == rcnt).all(), m
+        assert rcnt.min() >= 1  # every centre is its own neighbour
+        assert (N(ops.g.group_point(T(xyz, dev), idx)) == R.group_point(xyz, ridx)).all(), m
+        xyz = ref_new
