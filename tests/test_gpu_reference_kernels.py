@@ -198,3 +198,30 @@ def test_whole_geometry_chain_of_a_backbone_pass_is_the_reference_kernels(ops, d
         assert rcnt.min() >= 1  # every centre is its own neighbour
         assert (N(ops.g.group_point(T(xyz, dev), idx)) == R.group_point(xyz, ridx)).all(), m
         xyz = ref_new
+
+
+def test_non_finite_points_where_the_product_deliberately_leaves_the_reference(ops, dev, R):
+    """DESIGN.md section 2, "Non-finite coordinates": what the reference kernels do with a NaN point is an artefact of fminf / max / '>'
+    (tf_sampling_g.cu:142-146, tf_grouping_g.cu:24-25) -- shown here on the kernels themselves -- and the product DEFINES the case
+    instead (a hole is never sampled and never a neighbour).  On finite clouds the two agree everywhere (every other test of this file)."""
+    rng = np.random.default_rng(43)
+    xyz = rng.random((1, 600, 3), dtype=np.float32)
+    xyz[0, 137] = np.nan
+    ref = R.farthest_point_sample(8, xyz)
+    # the hole keeps its initial running distance 1e38: picked at once, and as a centre it freezes every running distance
+    # (min(NaN, td) = td), so the arg-max stays the hole itself
+    assert ref[0, 0] == 0 and (ref[0, 1:] == 137).all()
+    own = N(ops.s.farthest_point_sample(8, T(xyz, dev)))
+    assert 137 not in own[0] and len(set(own[0].tolist())) == 8
+    clean = xyz.copy()
+    clean[0, 137] = clean[0, 0]  # the product reads a hole as a copy of point 0
+    assert (own == R.farthest_point_sample(8, clean)).all()
+    q = xyz[:, :5].copy()
+    ridx, rcnt = R.query_ball_point(0.05, 64, xyz, q)
+    assert all(137 in ridx[0, j, :rcnt[0, j]] for j in range(5))  # max(sqrtf(NaN), 1e-20f) = 1e-20 < r: a "neighbour" of every centre
+    idx, cnt = ops.g.query_ball_point(0.05, 64, T(xyz, dev), T(q, dev))
+    idx, cnt = N(idx), N(cnt)
+    assert all(137 not in idx[0, j, :cnt[0, j]] for j in range(5))
+    hole_free = np.delete(xyz, 137, axis=1)
+    fidx, fcnt = R.query_ball_point(0.05, 64, hole_free, q)
+    assert (cnt == fcnt).all()  # the product's neighbour sets are the reference's on the cloud without the hole
