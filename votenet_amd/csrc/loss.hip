@@ -9,6 +9,9 @@
 
 namespace votenet {
 
+#ifndef LOSS_ABL
+#define LOSS_ABL 0 // probe builds (tools/probe/loss_ablate.sh): 1 no proposal terms, 2 no seed terms, 4 no dual term -- wrong results, time only
+#endif
 constexpr int LOSS_T = 1024;
 constexpr int LOSS_MAXC = 32;  // nh, ns, nc <= 32
 constexpr int LOSS_NACC = 12;
@@ -122,9 +125,47 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
     float acc[LOSS_NACC];
 #pragma unroll
     for (int i = 0; i < LOSS_NACC; i++) acc[i] = 0.0f;
+    // Roles.  With P proposals on LOSS_T threads only the first ceil(P / 64) waves own a proposal (P = 256: four of sixteen), and a
+    // proposal is the longest chain of the kernel (79 strided floats read, ~70 written, three softmaxes).  The other waves take the dual
+    // term (one wave per box) and ALL the seeds meanwhile instead of idling at the barrier and doing both afterwards
+    // (tools/probe/loss_ablate.sh: proposals 14.6 us, dual 5.2, seeds 4.3 of the launch).  P >= LOSS_T: every wave owns proposals, the
+    // phases run one after the other as before.
+    const int wave = tid >> 6, nwave = LOSS_T / 64;
+    const int nbusy = (P + 63) / 64 < nwave ? (P + 63) / 64 : nwave, nfree = nwave - nbusy;
+    const bool early = nfree > 0;
+    // ---- seeds: vote targets and vote regression loss (model.py:61-84), as a loop over this thread's seeds first, first + step, ...
+    const float inv_bn = 1.0f / (float)(B * N);
+    auto seed_terms = [&](int first, int step) {
+        for (int i = first; i < ((LOSS_ABL & 2) ? 0 : N); i += step) {
+            const int e = b * N + i;
+            const float sx = A.seeds[e * 3 + 0], sy = A.seeds[e * 3 + 1], sz = A.seeds[e * 3 + 2];
+            float best = 0.0f;
+            int g = 0;
+            bool surface = false;
+            for (int j = 0; j < BB; j++) {
+                // |seed - centre| first, THEN the rotation by -roty (the reference's order, model.py:61,74)
+                const float dx = fabsf(sx - s_box[j][0]), dy = fabsf(sy - s_box[j][1]), dz = fabsf(sz - s_box[j][2]);
+                const float c = s_box[j][6], s = s_box[j][7];
+                const float rx = c * dx + s * dz, ry = dy, rz = -s * dx + c * dz;
+                surface = surface || (rx < s_box[j][3] && ry < s_box[j][4] && rz < s_box[j][5]);
+                const float d = sqrtf(rx * rx + ry * ry + rz * rz);
+                if (j == 0 || d < best) {
+                    best = d;
+                    g = j;
+                }
+            }
+            if (surface) {
+                for (int k = 0; k < 3; k++) {
+                    const float df = A.votes[e * 3 + k] - s_box[g][k];
+                    acc[0] += fabsf(df);
+                    A.d_votes[e * 3 + k] = (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f)) * inv_bn;
+                }
+            }
+        }
+    };
     float pr[LOSS_MAXC];
     // ---- proposals: losses and cotangents (model.py:156-212); every weight of model.py:205,228 folded in
-    for (int pq = tid; pq < P; pq += LOSS_T) {
+    for (int pq = tid; pq < ((LOSS_ABL & 1) ? 0 : P); pq += LOSS_T) {
         const int q = b * P + pq;
         const float px = A.pxyz[q * 3 + 0], py = A.pxyz[q * 3 + 1], pz = A.pxyz[q * 3 + 2];
         int g;
@@ -175,7 +216,8 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
     }
     // ---- Chamfer / dual centre term (model.py:172-177): every ground-truth box pulls its nearest proposal
     const float inv_bbb = 1.0f / (float)(B * BB);
-    for (int j = tid >> 6; j < BB; j += LOSS_T / 64) { // one wave per box: lanes scan the proposals, wave arg-min
+    const int dw = early ? wave - nbusy : wave, dstep = early ? nfree : nwave; // (a wave that owns proposals: dw < 0 when the others take the boxes)
+    for (int j = dw < 0 ? BB : dw; j < ((LOSS_ABL & 4) ? 0 : BB); j += dstep) { // one wave per box: lanes scan the proposals, wave arg-min
         const int lane = tid & 63;
         const float gx = s_box[j][0], gy = s_box[j][1], gz = s_box[j][2];
         float best = INFINITY;
@@ -206,6 +248,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
             if (k == 0) s_dualp[j] = bp;
         }
     }
+    if (early && wave >= nbusy) seed_terms(tid - nbusy * 64, nfree * 64);
     __syncthreads(); // the proposals' own terms (above) and every box's pull are in place
     // several boxes may pull the same proposal: one thread per proposal adds them in box order (no atomics: one summation
     // order, bit-reproducible cotangents)
@@ -220,34 +263,7 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
                 }
             }
     }
-    // ---- seeds: vote targets and vote regression loss (model.py:61-84)
-    const float inv_bn = 1.0f / (float)(B * N);
-    for (int i = tid; i < N; i += LOSS_T) {
-        const int e = b * N + i;
-        const float sx = A.seeds[e * 3 + 0], sy = A.seeds[e * 3 + 1], sz = A.seeds[e * 3 + 2];
-        float best = 0.0f;
-        int g = 0;
-        bool surface = false;
-        for (int j = 0; j < BB; j++) {
-            // |seed - centre| first, THEN the rotation by -roty (the reference's order, model.py:61,74)
-            const float dx = fabsf(sx - s_box[j][0]), dy = fabsf(sy - s_box[j][1]), dz = fabsf(sz - s_box[j][2]);
-            const float c = s_box[j][6], s = s_box[j][7];
-            const float rx = c * dx + s * dz, ry = dy, rz = -s * dx + c * dz;
-            surface = surface || (rx < s_box[j][3] && ry < s_box[j][4] && rz < s_box[j][5]);
-            const float d = sqrtf(rx * rx + ry * ry + rz * rz);
-            if (j == 0 || d < best) {
-                best = d;
-                g = j;
-            }
-        }
-        if (surface) {
-            for (int k = 0; k < 3; k++) {
-                const float df = A.votes[e * 3 + k] - s_box[g][k];
-                acc[0] += fabsf(df);
-                A.d_votes[e * 3 + k] = (df > 0.0f ? 1.0f : (df < 0.0f ? -1.0f : 0.0f)) * inv_bn;
-            }
-        }
-    }
+    if (!early) seed_terms(tid, LOSS_T);
     // ---- fixed-order reduction: lanes -> waves -> scene partial -> (last workgroup) scenes in order
 #pragma unroll
     for (int i = 0; i < LOSS_NACC; i++) {
