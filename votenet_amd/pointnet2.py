@@ -720,7 +720,8 @@ def mlp_chain_backward(recs, g, mode, argmax=None, k=0, need_input_grad=True, zs
             dz = M.bn_backward_apply(z, coef, L.relu, da, argmax=argmax if pooled else None, k=k if pooled else 0)
         else:
             dz = da
-            M.bias_grad(dz, L.gp("b"))
+            # (a weight gradient like the others: on their stream -- the two launches of a column sum were 31 us of the main chain per step)
+            on_wgrad_stream(lambda dz=dz, L=L: M.bias_grad(dz, L.gp("b")), dz)
             if r.get("padded"):
                 # the same layer on the padded copies: dz -> [dz | 0] (rows, cout_pad); dW through a padded scratch, da = dz_p [W | 0]^T
                 # (g_padded: the caller already holds the last layer's gradient as [g | 0], g = g_padded[:, :cout])
