@@ -8,6 +8,10 @@ import importlib.util as _iu
 _s = _iu.spec_from_file_location("hp", os.path.join(R, "votenet_amd", "hostpin.py")); hostpin = _iu.module_from_spec(_s); _s.loader.exec_module(hostpin); hostpin.pin(0)  # as bench.py, before torch is imported
 import torch
 from votenet_amd import loss as VL, model as VM, synth
+from votenet_amd import _lib as L_
+for h in os.environ.get("HOOKS", "").split():  # e.g. HOOKS="votenet_debug_bn_reduce_passes=16"
+    name, val = h.split("=")
+    getattr(L_.lib(), name)(*[int(v) for v in val.split(",")])
 dev = torch.device("cuda:0")
 seeds = (1000, 500000, 900000)
 xs = [torch.from_numpy(synth.room_batch(8, 20480, s)).to(dev) for s in seeds]

@@ -661,6 +661,8 @@ static MlpIn to_dev(const votenet_mlp_input *in)
 
 using namespace votenet;
 
+static int g_bn_reduce_passes = 16; // (32: 8-64 workgroups, 14-18 us per launch; 16: 10-12 us; 8: the 2*c atomics of 256-512 workgroups cost more than they buy -- tools/serial_last_step.sh)
+extern "C" void votenet_debug_bn_reduce_passes(int n) { g_bn_reduce_passes = n > 0 ? n : 16; } // tuning hook
 extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                                           const float *scale, const float *shift, const float *mean, const float *var,
                                           float eps, int relu, double *sums, const votenet_coef_tail *tail_, void *stream)
@@ -679,7 +681,7 @@ extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *
     } else if (c % 4 == 0 && c <= 1024 && 256 % (c / 4) == 0 && (uintptr_t)da % 16 == 0 && (uintptr_t)z % 16 == 0 &&
                (uintptr_t)scale % 16 == 0 && (uintptr_t)shift % 16 == 0 && (uintptr_t)mean % 16 == 0 && (uintptr_t)var % 16 == 0) {
         const long rpp = 256 / (c / 4);
-        long gx = (rows + 32 * rpp - 1) / (32 * rpp); // >= 8 loop trips per workgroup: its 2*c atomics must amortise
+        long gx = (rows + g_bn_reduce_passes * rpp - 1) / (g_bn_reduce_passes * rpp); // passes per workgroup: its 2*c atomics must amortise
         if (gx > 2048) gx = 2048;
         hipLaunchKernelGGL(bn_bwd_reduce_dense_vec_kernel, dim3((unsigned)gx), dim3(256), 0, st, rows, c, da, z, scale, shift, mean,
                            var, eps, relu, sums, tail);
