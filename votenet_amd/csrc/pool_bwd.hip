@@ -714,6 +714,12 @@ extern "C" int votenet_pool_backward_supported(int cin, int cout, int k)
     return k == 64 && ((cin == 128 && (cout == 256 || cout == 128)) || (cin == 64 && cout == 128));
 }
 
+static int g_zsel_groups = 32, g_zsel_cap = 256;
+extern "C" void votenet_debug_zsel_grid(int groups_per_wg, int cap) // tuning hook
+{
+    g_zsel_groups = groups_per_wg > 0 ? groups_per_wg : 32;
+    g_zsel_cap = cap > 0 ? cap : 256;
+}
 extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *gout, const float *zsel, const float *scale,
                                                const float *shift, const float *mean, const float *var, float eps, int relu,
                                                double *sums, const votenet_coef_tail *tail, void *stream)
@@ -722,7 +728,7 @@ extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *
     VN_REQUIRE(gout && zsel && scale && shift && mean && var && sums, "bn_backward_reduce_pool: null buffer");
     VN_REQUIRE(!tail || (tail->ticket && tail->gamma && tail->coef && tail->rows > 0), "bn_backward_reduce_pool: incomplete coefficient tail");
     const int ny = (c + 63) / 64;
-    hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, 32, 256 / ny), ny), dim3(256), 0, as_stream(stream), groups,
+    hipLaunchKernelGGL(bn_bwd_reduce_zsel_kernel, dim3(pb_grid(groups, g_zsel_groups, g_zsel_cap / ny), ny), dim3(256), 0, as_stream(stream), groups,
                        c, gout, zsel, scale, shift, mean, var, eps, relu, sums, to_tail(tail));
     return check_launch("bn_backward_reduce_pool");
 }
