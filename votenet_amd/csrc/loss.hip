@@ -281,14 +281,17 @@ __global__ __launch_bounds__(LOSS_T) void votenet_loss_kernel(LossArgs A, int *c
     __syncthreads();
     if (tid == 0) s_last = (atomicAdd(&counts[2], 1) == B - 1);
     __syncthreads();
-    if (s_last && tid == 0) {
-        __threadfence();
+    if (!s_last) return; // (uniform over the workgroup)
+    __threadfence();
+    if (tid < LOSS_NACC) { // one thread per accumulator walks the scenes in order: twelve chains of B loads side by side instead of one of 12 B
+        float v = 0.0f;
+        for (int sc = 0; sc < B; sc++) v += __builtin_nontemporal_load(&partial[sc * LOSS_NACC + tid]);
+        s_red[0][tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
         float t[LOSS_NACC];
-        for (int i = 0; i < LOSS_NACC; i++) {
-            float v = 0.0f;
-            for (int sc = 0; sc < B; sc++) v += __builtin_nontemporal_load(&partial[sc * LOSS_NACC + i]);
-            t[i] = v;
-        }
+        for (int i = 0; i < LOSS_NACC; i++) t[i] = s_red[0][i];
         const float vote = t[0] * inv_bn;
         const float obj = t[1] * inv_np + t[2] * inv_nn;
         const float center = t[3] * inv_np + t[4] * inv_bbb;
