@@ -508,6 +508,7 @@ void votenet_debug_fast_xcd_chunk(int on); /* 1 (default): the piece-layout GEMM
 void votenet_debug_gram_workgroups(int n); /* tuning hook: workgroups of the split-operand Gram kernel (default 384) */
 void votenet_debug_bn_reduce_passes(int n); /* tuning hook: row passes per workgroup of the dense BatchNorm-backward reduction (default 16) */
 void votenet_debug_zsel_grid(int groups_per_wg, int cap); /* tuning hook: grid of the pooled BatchNorm-backward reduction (default 32 groups per workgroup, at most 256 workgroups: measured optimum, tools/serial_last_step.sh) */
+void votenet_debug_assemble_stats(int cap, int u); /* tuning hook: assemble_stats workgroups per column block (default 128) and points in flight per thread (4 or 8, default 8) */
 /* every other weight-gradient GEMM (votenet_mlp_wgrad / _wgrad_bn, assembled, narrow) on split operands: row-major bf16 images in LDS,
  * fragments through ds_read_b64_tr_b16 (mlp_wgrad_fast.hip); 0: the fp32 MFMA kernel.  Default 1. */
 void votenet_debug_wgrad_bf3(int on);

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void assemble_rows_kernel(long rows, int n, in
 }
 
 // BatchNorm statistics of the never-stored z0 from the per-point sums: block = 64 channels x 4 point lanes, grid.x strides the points
+template <int U>
 __global__ __launch_bounds__(256) void assemble_stats_kernel(long npts, int c0, const float *__restrict__ P, const long long *__restrict__ cntv,
                                                              const float *__restrict__ wx, const double *__restrict__ mom,
                                                              double *__restrict__ stats)
@@ -95,11 +96,11 @@ __global__ __launch_bounds__(256) void assemble_stats_kernel(long npts, int c0, 
         // four points' loads in flight per trip, few workgroups: the pass is a latency chain that ends in fp64 atomics on 2 c0 addresses
         // (256 workgroups a column block made it 15 us for 2 MB: the atomics of one address serialise)
         const long stride = (long)gridDim.x * 4;
-        for (long p0 = (long)blockIdx.x * 4 + py; p0 < npts; p0 += 4 * stride) {
-            long long c4[4][4];
-            float v4[4];
+        for (long p0 = (long)blockIdx.x * 4 + py; p0 < npts; p0 += U * stride) {
+            long long c4[U][4];
+            float v4[U];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 const long p = p0 + u * stride < npts ? p0 + u * stride : p0; // (clamped: counted once below)
                 const long long *cv = cntv + (size_t)p * 4;
                 c4[u][0] = cv[0];
@@ -109,7 +110,7 @@ __global__ __launch_bounds__(256) void assemble_stats_kernel(long npts, int c0, 
                 v4[u] = P[(size_t)p * c0 + c];
             }
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
+            for (int u = 0; u < U; u++) {
                 if (p0 + u * stride >= npts || c4[u][0] == 0) continue; // past the end / a point no ball contains
                 const double v = v4[u], cn = (double)c4[u][0];
                 const double vw = ((double)c4[u][1] * w0 + (double)c4[u][2] * w1 + (double)c4[u][3] * w2) * (1.0 / 4294967296.0);
@@ -170,6 +171,12 @@ extern "C" int votenet_assemble_rows(int b, int n, int m, int nsample, const flo
     return check_launch("assemble_rows");
 }
 
+static int g_asm_stats_cap = 128, g_asm_stats_u = 8; // (8 points in flight: 11.9 / 8.2 / 7.2 -> 10.6 / 7.5 / 6.5 us; 256 workgroups: no better)
+extern "C" void votenet_debug_assemble_stats(int cap, int u) // tuning hook: workgroups per column block, points in flight per thread and trip
+{
+    g_asm_stats_cap = cap > 0 ? cap : 128;
+    g_asm_stats_u = u == 4 ? 4 : 8;
+}
 extern "C" int votenet_assemble_stats(long npts, int c0, const float *P, const long long *cntv, const float *wx, const double *moments,
                                       double *stats, void *stream)
 {
@@ -177,8 +184,11 @@ extern "C" int votenet_assemble_stats(long npts, int c0, const float *P, const l
     VN_REQUIRE(P && cntv && wx && moments && stats, "assemble_stats: null buffer");
     const int ny = (c0 + 63) / 64;
     long gx = (npts + 4 * 16 - 1) / (4 * 16);
-    if (gx > 128) gx = 128;
-    hipLaunchKernelGGL(assemble_stats_kernel, dim3((unsigned)gx, ny), dim3(256), 0, as_stream(stream), npts, c0, P, cntv, wx, moments, stats);
+    if (gx > g_asm_stats_cap) gx = g_asm_stats_cap;
+    if (g_asm_stats_u == 8)
+        hipLaunchKernelGGL(assemble_stats_kernel<8>, dim3((unsigned)gx, ny), dim3(256), 0, as_stream(stream), npts, c0, P, cntv, wx, moments, stats);
+    else
+        hipLaunchKernelGGL(assemble_stats_kernel<4>, dim3((unsigned)gx, ny), dim3(256), 0, as_stream(stream), npts, c0, P, cntv, wx, moments, stats);
     return check_launch("assemble_stats");
 }
 
