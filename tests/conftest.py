@@ -11,6 +11,10 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The reference's device kernels (oracle/_ref/libref_*_gpu.so) travel with the snapshot.  When the directory is there the
+    # three-way tests of test_gpu_reference_kernels.py must RUN: a library that then fails to load is a failure, not a skip.
+    if os.path.isdir(os.path.join(ROOT, "oracle", "_ref")) and "VOTENET_REQUIRE_REF" not in os.environ:
+        os.environ["VOTENET_REQUIRE_REF"] = "1"
 
 
 @pytest.fixture(scope="session")
@@ -38,6 +42,25 @@ def hiplib():
     if not os.path.exists(_lib.lib_path()):
         votenet_amd.build()
     return _lib.lib()
+
+
+@pytest.fixture(scope="session")
+def linklib(hiplib):
+    """tests/link/launcher_link.cpp (the eight launcher declarations of tf_sampling.cpp:65,94,125,150 / tf_grouping.cpp:66,108,142,173)
+    linked against the product with -Wl,-z,defs: an unexported or mis-typed launcher is an undefined symbol and the link fails, as
+    dlopen(RTLD_NOW) of the reference's real wrapper would.  Returns the ctypes handle of the linked object."""
+    import ctypes
+    import subprocess
+    from votenet_amd import _lib
+    libdir = os.path.dirname(_lib.lib_path())
+    out_dir = os.path.join(ROOT, "tests", "link", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "liblauncher_link.so")
+    cmd = ["g++", "-std=c++11", "-shared", "-fPIC", "-O2", "-Wl,-z,defs", os.path.join(ROOT, "tests", "link", "launcher_link.cpp"),
+           "-o", out, "-L" + libdir, "-lvotenet_hip", "-Wl,-rpath," + libdir]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, "the drop-in link line fails:\n%s\n%s" % (" ".join(cmd), r.stderr)
+    return ctypes.CDLL(out, mode=ctypes.RTLD_GLOBAL | os.RTLD_NOW)
 
 
 @pytest.fixture(scope="session")

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(hiplib):
 
 
 def test_library_exports_reference_launcher_names(hiplib):
-    """tf_sampling.cpp:94,125,150 and tf_grouping.cpp:66,142,173 declare these (C++ linkage)."""
+    """tf_sampling.cpp:65,94,125,150 and tf_grouping.cpp:66,108,142,173 declare these eight (C++ linkage)."""
     from votenet_amd import _lib
     out = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.lib_path()], capture_output=True, text=True).stdout
     for sig in ["farthestpointsamplingLauncher(int, int, int, float const*, float*, int*)",
@@ -40,8 +40,29 @@ def test_library_exports_reference_launcher_names(hiplib):
                 "scatteraddpointLauncher(int, int, int, float const*, int const*, float*)",
                 "queryBallPointLauncher(int, int, int, float, int, float const*, float const*, int*, int*)",
                 "groupPointLauncher(int, int, int, int, int, float const*, int const*, float*)",
-                "groupPointGradLauncher(int, int, int, int, int, float const*, int const*, float*)"]:
+                "groupPointGradLauncher(int, int, int, int, int, float const*, int const*, float*)",
+                "probsampleLauncher(int, int, int, float const*, float const*, float*, int*)",
+                "selectionSortLauncher(int, int, int, int, float const*, int*, float*)"]:
         assert sig in out, sig
+    assert out.count("Launcher(") == 8
+
+
+def test_reference_wrappers_link_with_no_undefined_symbol(linklib):
+    """The drop-in link line of INTEGRATION.md 1 with -Wl,-z,defs (the conftest fixture asserts the link) and a dlopen RTLD_NOW."""
+    for name in ("link_prob_sample", "link_fps", "link_gather", "link_scatter_add", "link_query_ball", "link_selection_sort",
+                 "link_group", "link_group_grad"):
+        assert hasattr(linklib, name)
+
+
+def test_link_fails_when_a_launcher_is_missing(hiplib, tmp_path):
+    """The link test has teeth: a ninth, unexported launcher name makes the same link line fail."""
+    from votenet_amd import _lib
+    libdir = os.path.dirname(_lib.lib_path())
+    src = tmp_path / "missing.cpp"
+    src.write_text("void notALauncher(int b);\nextern \"C\" void f(int b) { notALauncher(b); }\n")
+    r = subprocess.run(["g++", "-shared", "-fPIC", "-Wl,-z,defs", str(src), "-o", str(tmp_path / "m.so"), "-L" + libdir, "-lvotenet_hip"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "notALauncher" in r.stderr
 
 
 def test_version_and_error_text(hiplib):

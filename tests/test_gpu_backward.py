@@ -7,6 +7,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 EPS = 1e-5
+ARGMAX_CHECKED = []  # (groups x channels with a clear float64 winner, all) per pooled level, filled by ref_sa
 
 
 def ref_chain(x, layers, params, recs):
@@ -46,6 +47,20 @@ def ref_sa(mod, params, xyz, pts, rec):
     if pts is not None:
         g = torch.cat([g, pts[bi, idx]], -1)
     y = ref_chain(g.reshape(b * m * k, -1), mod.mlp, params, rec["recs"]).view(b * m, k, -1)
+    # The device's arg-max is an input of this reference, so it is checked against the float64 forward first (a wrong arg-max would
+    # otherwise be invisible here): the entry the device picked must be the float64 maximum of its group up to fp32 round-off
+    # of the 3-layer chain, and for groups whose float64 top-2 gap exceeds that tolerance the picked ROW must hold the maximum
+    # value (ball-query padding repeats rows, so equal values at different k are the same row and either k is right).
+    with torch.no_grad():
+        yd = y.detach()
+        picked = yd.gather(1, rec["argmax"].long()[:, None, :])[:, 0, :]
+        top = yd.max(1).values
+        tol = 1e-4 * max(1.0, float(yd.abs().max()))
+        assert bool((picked >= top - tol).all()), "device arg-max misses the float64 maximum by %g (tol %g)" % (float((top - picked).max()), tol)
+        top2 = yd.topk(2, dim=1).values
+        clear = (top2[:, 0] - top2[:, 1]) > tol          # groups where fp32 round-off cannot decide the winner
+        assert bool((picked[clear] == top[clear]).all())
+        ARGMAX_CHECKED.append((int(clear.sum()), int(clear.numel())))
     y = y.gather(1, rec["argmax"].long()[:, None, :])[:, 0, :]  # max over k through the device argmax
     last = rec["recs"][-1]
     if last["z"] is None:  # the device's active set at the arg-max entries (raw z there = zsel)
@@ -139,7 +154,10 @@ def test_full_size_backward_vs_autograd(hiplib, dev, gemm_form):
     """The headline shapes: 20 480 points per scene with the real 2048 / 1024 / 512 / 256 centres (model.py:39-49), default mode, both GEMM
     forms, at the reference's own bar for its op gradients (compute_gradient_error < 1e-4, tf_grouping_op_test.py:23-25) over the WHOLE
     backward pass of utils.py:125-132.  Two scenes: the float64 reference materialises every grouped tensor."""
+    del ARGMAX_CHECKED[:]
     worst, tape = _full_backward_vs_autograd(dev, 20480, (2048, 1024, 512, 256), 1000)
+    # the device arg-max of all five pooled levels was held to the float64 forward (ref_sa), on entries with a clear winner
+    assert len(ARGMAX_CHECKED) == 5 and all(c > 0.2 * n for c, n in ARGMAX_CHECKED), ARGMAX_CHECKED
     assert len(worst) > 60  # every weight / gamma / beta tensor of the stack was compared
     # the layouts the pass really ran on: compact pieces at every level (fewer rows than the full layout at sa1-sa4), the first layers
     # never stored, the proposal module's piece count left on the device

@@ -462,6 +462,42 @@ def test_stretch_graph_replays_are_the_launch_by_launch_step(hiplib, dev, monkey
         o1["proposals_output"]
 
 
+def test_stretch_graphs_of_two_batch_shapes_keep_their_moving_average_factors(hiplib, dev, monkeypatch):
+    """A captured stretch has the ADDRESS of its (1 - momentum | unbiased-variance) factor tensor baked into its votenet_ema_update node.
+    Train at batch shape a, then b (whose first, launch-by-launch step builds another factor tensor), then a again: the replayed graph of
+    shape a must still read ITS factors -- the moving averages stay bit-equal to a launch-by-launch replica's through the switches."""
+    from votenet_amd import loss as VL
+    from votenet_amd import model as VM
+    from votenet_amd import synth
+    n = 4096
+    shapes = [2, 2, 2, 3, 3, 2, 3, 2]  # a: measuring step, capture + replay, replay; b: measuring, capture + replay; a, b, a: replays
+    ref = VM.VoteNetHotPath(dev, seed=6, npoints=(512, 256, 128, 64))
+    got = VM.VoteNetHotPath(dev, seed=6, npoints=(512, 256, 128, 64))
+    for net in (ref, got):
+        net.init_optimizer(lr=1e-3)
+        net._ema_state()
+    for i, b in enumerate(shapes):
+        x = torch.from_numpy(synth.room_batch(b, n, 300 + i)).to(dev)
+        gt = VL.gt_to_device(synth.room_gt(b, n, 300 + i), dev)
+        got.store.flat.copy_(ref.store.flat)
+        got.store.params_changed()
+        got._m.copy_(ref._m), got._v.copy_(ref._v), got._ema_flat.copy_(ref._ema_flat)
+        # churn the allocator between steps: a factor tensor that had gone back to it would be handed out again here and overwritten
+        junk = [torch.full((got._ema_flat.numel(),), float("nan"), device=dev) for _ in range(8)]
+        del junk
+        ema = []
+        for net, flag in ((ref, False), (got, True)):
+            monkeypatch.setattr(VM, "STRETCH_GRAPH", flag)
+            net.train_step(x, gt=gt)
+            torch.cuda.synchronize()
+            ema.append(net._ema_flat.clone())
+        assert torch.isfinite(ema[1]).all(), i
+        assert torch.equal(ema[0], ema[1]), (i, b, float((ema[0] - ema[1]).abs().max()))
+    assert len(got._stretch_graphs) == 2
+    assert sorted(g.replays for g in got._stretch_graphs.values()) == [2, 4]
+    assert len(got._ema_fac_by_rows) == 2  # one factor tensor per shape, both alive
+
+
 def test_moving_averages_follow_tensorflows_update(hiplib, dev):
     """The BatchNorm moving averages (reference: Tensorpack BNReLU, momentum 0.9): after a training-mode forward pass
     moving = 0.9 * moving + 0.1 * (batch mean | unbiased batch variance) for every BatchNorm layer, starting from 0 / 1; the

@@ -101,11 +101,26 @@ class _StretchOutputs(dict):
         super().__init__(tensors)
         self._graph, self._stamp = graph, graph.replays
 
-    def __getitem__(self, key):
+    def _check(self, key="them"):
         if self._graph.replays != self._stamp:
             raise M.L.VotenetError("train_step outputs: the stretch graph that holds %r has been replayed for a later step (the tensors a "
                                    "replayed step returns are valid until the next step: clone them to keep them)" % key)
+
+    def __getitem__(self, key):
+        self._check(key)
         return super().__getitem__(key)
+
+    def get(self, key, default=None):
+        self._check(key)
+        return super().get(key, default)
+
+    def items(self):
+        self._check()
+        return super().items()
+
+    def values(self):
+        self._check()
+        return super().values()
 
 
 class StretchGraph:
@@ -528,6 +543,7 @@ class VoteNetHotPath:
                 self._ema[L.name] = t
             self._ema_fac = {}
             self._ema_fac_flat = None
+            self._ema_fac_by_rows = {}
             self._ema_version = 0
         return self._ema
 
@@ -553,12 +569,18 @@ class VoteNetHotPath:
             # every BatchNorm layer of the model ran once and left its block in the persistent buffer: ONE launch (csrc/glue.hip)
             key = tuple(r["rows"] for r in recs)
             if self._ema_fac_flat is None or self._ema_fac_flat[0] != key:
-                f = torch.full_like(st.bn_flat, 1.0 - self.BN_MOMENTUM)
-                base = st.bn_flat.data_ptr()
-                for r in recs:
-                    c, rows = r["layer"].cout, r["rows"]
-                    o = (blocks[r["layer"].name].data_ptr() - base) // 4
-                    f[o + 3 * c:o + 4 * c] *= rows / max(rows - 1.0, 1.0)
+                # One factor tensor per rows key, kept for the life of the model: a StretchGraph captured at another batch shape has
+                # this tensor's ADDRESS baked into its votenet_ema_update node, so it must never go back to the allocator while a
+                # graph may still be replayed (a handful of shapes x 0.1 MB).
+                f = self._ema_fac_by_rows.get(key)
+                if f is None:
+                    f = torch.full_like(st.bn_flat, 1.0 - self.BN_MOMENTUM)
+                    base = st.bn_flat.data_ptr()
+                    for r in recs:
+                        c, rows = r["layer"].cout, r["rows"]
+                        o = (blocks[r["layer"].name].data_ptr() - base) // 4
+                        f[o + 3 * c:o + 4 * c] *= rows / max(rows - 1.0, 1.0)
+                    self._ema_fac_by_rows[key] = f
                 self._ema_fac_flat = (key, f)
             from . import _lib as L_
             with L_.device_guard(self.device):
@@ -746,7 +768,7 @@ class VoteNetHotPath:
         ins["prop_fps"] = g["prop_fps"]
         return ins
 
-    def _stretch_body(self, I, tape_levels, wgrad_stream, gt=None, cut=None, loss_hook=None):
+    def _stretch_body(self, I, tape_levels, wgrad_stream, gt=None, cut=None, loss_hook=None, copy_seeds=False):
         """The stretch on the tensors of I (StretchGraph captures this on its fixed buffers; the first step of a shape runs it eagerly):
         forward head, moving averages, loss (on gt, or through loss_hook(out) -> (losses, cotangents) when captured), backward head.
         -> (out, losses, (d_l2p, d_l3p, d_l4p))."""
@@ -759,7 +781,7 @@ class VoteNetHotPath:
             return idx, I[name + "_w"]
         tail = []
         lv = {k: I[k] for k in ("l2_xyz", "l2_p", "l3_xyz", "l3_p", "l4_xyz", "l4_p")}
-        out = self._head_forward(lv, geom("fp1"), geom("fp2"), I["prop_fps"], tail, copy_seeds=False)
+        out = self._head_forward(lv, geom("fp1"), geom("fp2"), I["prop_fps"], tail, copy_seeds=copy_seeds)
         self.update_moving_averages(list(tape_levels) + tail)
         losses, cot = loss_hook(out) if loss_hook is not None else VL.votenet_loss(out, gt)
         P.WGRAD_STREAM = wgrad_stream
@@ -786,7 +808,8 @@ class VoteNetHotPath:
             g.setdefault("prop_fps", P.tf_sampling.farthest_point_sample(self.proposal.npoint, lv["l2_xyz"]))
         ins = self._stretch_inputs(lv, g)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
-                                                                             self.overlap_wgrad, STRETCH_SEGMENTS, M.CONFIG_EPOCH)
+                                                                             self.overlap_wgrad, STRETCH_SEGMENTS, M.COEF_TAIL, P.WGRAD_BATCH, P.POOL_IN_EPILOGUE,
+                                                                             self.store.split, bool(getattr(self, "inline_wgrad_tail", False)), M.CONFIG_EPOCH)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
         self._gsync.begin()
@@ -802,7 +825,10 @@ class VoteNetHotPath:
                 self.check_tape(tape)
                 if self.overlap_wgrad and self._wgrad_stream is None:
                     self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
-                out, self.last_losses, grads = self._stretch_body(ins, tape, self._wgrad_stream if self.overlap_wgrad else None, gt=gt)
+                # (launch by launch on the live inputs: seeds_xyz would alias sa2's centres inside a GeometryGraph buffer that a later
+                # prefetch overwrites -- handed out as a copy, as forward() does)
+                out, self.last_losses, grads = self._stretch_body(ins, tape, self._wgrad_stream if self.overlap_wgrad else None, gt=gt,
+                                                                  copy_seeds=getattr(self, "_geometry_current", None) is not None)
                 self._stretch_demand[dkey] = (a.off - off0, a.want32 - want0)
                 self._backward_levels_pass(tape, grads)
                 return out
@@ -814,7 +840,8 @@ class VoteNetHotPath:
         self.store._fresh_wait()
         if self.overlap_wgrad and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
-        out, self.last_losses, grads = sg.replay(ins, gt, self._wgrad_stream if self.overlap_wgrad else None)
+        out, losses, grads = sg.replay(ins, gt, self._wgrad_stream if self.overlap_wgrad else None)
+        self.last_losses = losses.clone()  # 48 bytes: the graph's own vector is rewritten by the next replay
         self._ema_version += 1  # (the replay ran votenet_ema_update: inference_bn() must not serve a table built before it)
         self._backward_levels_pass(tape, grads)
         return out
