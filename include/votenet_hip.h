@@ -497,6 +497,25 @@ int votenet_transpose_segments(int nseg, const long *table, const float *src, fl
 int votenet_split_weights(int nseg, const long *table, void *stream);
 int votenet_split_weights_one(const float *w, int cin, int cout, void *image, void *stream); /* one matrix, arguments by value */
 int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3);
+
+/* ---- split-K for the fused GEMMs of few row tiles (round 5) -------------------------------------------------------------------
+ * The GEMMs of the model's static stretch (feature propagation, voting, proposal head: utils.py:286-293, model.py:53-57,89-93) have
+ * 2048-8192 rows: 16-64 row tiles of 128 rows, one wavefront per SIMD on half of the CUs with a serial chain of cin / 16 slabs.
+ * Split, the contraction of an output tile is shared by 2-4 workgroups (gridDim.z); each stores its partial tile in a workspace and
+ * takes the tile's ticket, the last arriver adds the parts in a FIXED order (results do not depend on the arrival order) and runs the
+ * usual epilogue -- BatchNorm statistics included -- on the complete tile.  Launchers never allocate: the caller
+ *   votenet_mlp_split_k_tickets(t, n)   registers n ZEROED unsigned ints of device memory once (kept alive and untouched while split
+ *                                       launches may run; NULL, 0: split-K off -- the default);
+ *   votenet_mlp_split_k_floats(rows, cin, cout)   -> floats of workspace a votenet_mlp_linear / votenet_mlp_dgrad_bn /
+ *                                       votenet_mlp_dgrad_bn_reduce launch of these sizes would use split (0: it would not split);
+ *   votenet_mlp_split_k_arm(ws, floats) hands the workspace (any contents, alive until the launch has run) to the NEXT such launch
+ *                                       of the calling thread; the launch consumes it whether it splits or not (NULL, 0: disarm).
+ * An unarmed launch never splits.  votenet_debug_split_k: tuning hook (target workgroups, maximum parts, minimum slabs per part,
+ * launches of at least that many output tiles are left alone; 0 keeps a value). */
+long votenet_mlp_split_k_floats(long rows, int cin, int cout);
+int votenet_mlp_split_k_arm(void *ws, long floats);
+int votenet_mlp_split_k_tickets(void *tickets, long n);
+void votenet_debug_split_k(int target_wgs, int max_parts, int min_slabs, int max_wgs);
 /* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used; another
  * value: a mask over GEMM families (mlp_fast.hip, bf3_family) */
 void votenet_debug_fast_bf3(int on);

@@ -60,7 +60,9 @@ def linklib(hiplib):
            "-o", out, "-L" + libdir, "-lvotenet_hip", "-Wl,-rpath," + libdir]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, "the drop-in link line fails:\n%s\n%s" % (" ".join(cmd), r.stderr)
-    return ctypes.CDLL(out, mode=ctypes.RTLD_GLOBAL | os.RTLD_NOW)
+    # RTLD_LOCAL: the product's launcher names must not enter the process's global symbol scope (the reference libraries of
+    # oracle/_ref define the same names; they are linked -Bsymbolic as well)
+    return ctypes.CDLL(out, mode=ctypes.RTLD_LOCAL | os.RTLD_NOW)
 
 
 @pytest.fixture(scope="session")

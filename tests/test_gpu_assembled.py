@@ -68,7 +68,11 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_
     assert relerr(dw, dwm) < 1e-5
     below = (bn0.scale, bn0.shift, bn0.mean, bn0.var, True)
     da0, sums = M.assembled_dgrad_bn_reduce(z1, coef1, True, wT, da1, geo, P, wx, below)
-    da0m, sumsm = M.dgrad_bn(z1, coef1, True, wT, da=da1, below=(z0,) + below)
+    split_k, M.SPLIT_K = M.SPLIT_K, False  # bit for bit against the UNSPLIT stored-layer kernel (split-K adds the same products in another order)
+    try:
+        da0m, sumsm = M.dgrad_bn(z1, coef1, True, wT, da=da1, below=(z0,) + below)
+    finally:
+        M.SPLIT_K = split_k
     assert torch.equal(da0, da0m)
     scale = torch.cat([da0.double().abs().sum(0), (da0.double() * ((z0.double() - bn0.mean.double()) / torch.sqrt(bn0.var.double() + M.BN_EPS))).abs().sum(0)])
     assert float(((sums - sumsm).abs() / (scale + 1e-30)).max()) < 1e-6

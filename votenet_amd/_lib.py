@@ -111,6 +111,8 @@ _SIGS.update({
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_split_weights": [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_split_weights_one": [_c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_mlp_split_k_arm": [ctypes.c_void_p, ctypes.c_long],
+    "votenet_mlp_split_k_tickets": [ctypes.c_void_p, ctypes.c_long],
     "votenet_register_split_weights": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p],
     "votenet_bn_finalize": [ctypes.c_long, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_float] + [_c_f] * 4 + [ctypes.c_void_p],
     "votenet_bn_relu_max": [ctypes.c_long, ctypes.c_int, ctypes.c_int] + [_c_f] * 3 + [ctypes.c_int] + [_c_f] * 2 + [ctypes.c_void_p],
@@ -238,6 +240,8 @@ def lib():
         L.votenet_knn_workspace_bytes.argtypes = [ctypes.c_int] * 3
         L.votenet_nms3d_workspace_bytes.restype = ctypes.c_size_t
         L.votenet_nms3d_workspace_bytes.argtypes = [ctypes.c_int, ctypes.c_int]
+        L.votenet_mlp_split_k_floats.restype = ctypes.c_long
+        L.votenet_mlp_split_k_floats.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int]
         L.votenet_ball_threshold.restype = ctypes.c_float
         L.votenet_ball_threshold.argtypes = [ctypes.c_float]
         for name, sig in _SIGS.items():

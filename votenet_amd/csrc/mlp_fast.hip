@@ -82,6 +82,8 @@ constexpr int FG_LDA = FG_BM + 2;
 //          relu(s*min_k z + h) for s < 0 (rounding is monotone), so the epilogue emits the raw max AND min of every
 //          group (+ arg rows) and votenet_bn_pool_finalize picks by the sign of the scale.  A wave's 2 x 32 rows
 //          are exactly one group (2x2 variant, WM = 2, MT = 2).
+//   EPI 8: EPI 2 on the piece layout (half.hip), the pool per 16-row piece compiled in (A.pool32 is set): without the 64-row pool's
+//          running max / min / arg registers and its compare-and-keep code beside it
 //   EPI 6: EPI 3 for an ASSEMBLED layer below (assemble.hip): z_prev[r,c] = P[prow(r),c] + dxyz(r) . wx[:,c] is rebuilt per element
 //          from the tile's geo records (staged in LDS by the loader) and a gather of the per-point table P through a buffer
 //          descriptor (lane offset prow * pitch + column); da is stored as in EPI 3
@@ -132,14 +134,25 @@ struct FastArgs {
     int xcd_chunk;           // XCD x takes the x-th contiguous eighth of the row tiles (see the kernel)
     const float *pool_gamma; // pool32: the pooled layer's BatchNorm gamma -- its sign is the sign of the scale the pool will apply, so the
                              // epilogue keeps ONE candidate per piece and channel (the max where gamma >= 0, else the min) in zmax / amax
+    // split-K (gridDim.z > 1; the launcher's choice for launches of few row tiles -- the static stretch's GEMMs of 2048-8192 rows, one
+    // wave per SIMD on half of the CUs with a serial chain of cin / 16 slabs): workgroup (x, y, s) contracts the s-th part of cin for
+    // output tile (x, y), stores its partial tile in sk_ws [tile][s][element][thread] and takes the tile's ticket; whoever takes the
+    // LAST ticket adds the parts in the fixed order s = 0, 1, ... (bit-reproducible whichever workgroup that is) and runs the epilogue
+    // -- statistics included -- on the complete tile; the others skip it.  Partial tiles travel as device-scope relaxed atomics (they
+    // execute at the memory side: the XCDs' L2s are not coherent with each other) and a workgroup waits for its stores' acknowledgement
+    // (vmcnt) before it takes the ticket: the same fence-free hand-off as coef_tail (common.h).
+    float *sk_ws;
+    unsigned *sk_ticket;
 };
 
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
-template <int WM, int WN, int MT, int NT, int SRC, int EPI, bool BF3 = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 || EPI == 6) ? EPI3_WAVES : (EPI == 0 || EPI == 2) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
+template <int WM, int WN, int MT, int NT, int SRC, int EPI, bool BF3 = false, bool SK = false /* split-K launch: gridDim.z parts (FastArgs::sk_ws) */>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 || EPI == 6) ? EPI3_WAVES : (EPI == 0 || EPI == 2 || EPI == 8) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
+    constexpr bool POOL = (EPI == 2 || EPI == 8); // pooled forward layer
+    constexpr bool P32 = (EPI == 8);              // ... per 16-row piece
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
     constexpr int BN = WN * NT * 32;
     constexpr int LDB = BN + 4;
@@ -171,7 +184,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wv / WN, wn = wv % WN;
     const int n0 = blockIdx.y * BN;
-    const int nk = cin / FG_BK;
+    const int nsp = SK ? (int)gridDim.z : 1;       // split-K parts
+    const int nk = cin / FG_BK / nsp;              // slabs this workgroup contracts ...
+    const int ks0 = SK ? (int)blockIdx.z * nk : 0; // ... from this one on
     long ntiles = rows / FG_BM;
     if (A.nh_dev != nullptr) { // (a multiple of 8 pieces = whole tiles: half.hip)
         const long lim = (long)A.nh_dev[0] * kPiece / FG_BM;
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     }
     if (SRC == 0 || SRC == 3 || SRC == 4) {
         if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
-            const bool writer = blockIdx.x == 0 && blockIdx.y == 0;
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && (!SK || blockIdx.z == 0);
             for (int k = tid; k < cin; k += 256) {
                 float sc, sh;
                 bn_raw_channel(A.in_raw, cin, k, writer, sc, sh);
@@ -237,14 +252,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const float *abase = (SRC == 0) ? A.x : (SRC == 3) ? A.u8 : (SRC == 4) ? A.ptab : A.zsrc; // the array the row pointers walk
     // SRC 3: the pointers stay on the row's eight floats for all slabs of a tile (re-read per slab from L2: no branch in the loop)
     const int arow_len = (SRC == 3) ? 8 : cin;
-    const float *pa0 = abase + ((size_t)tile0 * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : a_kq * 4);
+    const float *pa0 = abase + ((size_t)tile0 * FG_BM + a_row) * arow_len + (SRC == 3 ? 0 : ks0 * FG_BK + a_kq * 4);
     const float *pa1 = pa0 + (size_t)64 * arow_len;
     const ptrdiff_t da_off = (SRC == 1 || SRC == 5) ? (A.da - A.zsrc) : 0; // SRC 1 / 5: da has the layout of zsrc
     // SRC 5 (piece layout): this thread's rows a_row / a_row + 64 of a tile are row 0 of their piece iff a_row % kPiece == 0; the
     // weights of those two pieces travel with the slab (no load under a branch: every thread loads, most ignore)
     const bool sel31 = (a_row % kPiece) == 0;
     const float *pw = (SRC == 5) ? A.wh + (size_t)tile0 * (FG_BM / kPiece) + (a_row / kPiece) : nullptr;
-    const size_t a_tile_jump = (SRC == 3) ? (size_t)tstride * FG_BM * 8 : (size_t)tstride * FG_BM * cin - cin; // after the last slab of a tile
+    const size_t a_tile_jump = (SRC == 3) ? (size_t)tstride * FG_BM * 8 : (size_t)tstride * FG_BM * cin - (size_t)nk * FG_BK; // after the last slab of a tile
     const int a_slab_step = (SRC == 3) ? 0 : FG_BK;
     // EPI 4: thread t stages float4 #(t&1) of tile row t>>1 for the epilogue
     const uint2 *pm = (EPI == 7) ? reinterpret_cast<const uint2 *>(A.mask_in) + ((size_t)tile0 * FG_BM + (tid & 127)) * (cout / 64) + n0 / 64 : nullptr;
@@ -281,9 +296,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
     for (int u = 0; u < NB4; u++) {
         const int f = tid + u * 256;
-        pb[u] = w + (size_t)(f / (BN / 4)) * cout + n0 + (f % (BN / 4)) * 4;
+        pb[u] = w + ((size_t)ks0 * FG_BK + (size_t)(f / (BN / 4))) * cout + n0 + (f % (BN / 4)) * 4;
     }
-    const size_t b_step = (size_t)FG_BK * cout, b_wrap = (size_t)cin * cout;
+    const size_t b_step = (size_t)FG_BK * cout, b_wrap = (size_t)nk * FG_BK * cout;
     // BF3: W comes pre-split (votenet_split_weights): per slab [piece][k-half][column][8 bf16], i.e. the LDS image itself.  A slab
     // of this column block is 6 planes of BN x 16 bytes; thread t copies chunk t of planes (2u + t/128), u = 0..2 (16-byte chunks
     // at BN = 128, 8-byte chunks at BN = 64): one 32-bit lane offset that walks the slabs, the plane pair u as a scalar offset
@@ -292,7 +307,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     unsigned wvo = (((unsigned)b3_pl * (unsigned)cout + (unsigned)(n0 + b3_c)) * 4u + (unsigned)b3_h * 2u) * 4u;
     unsigned wpitch = (unsigned)cout * 32u; // bytes between plane pairs (= pieces)
     const unsigned w3_slab = (unsigned)cout * 96u; // bytes per slab of the split image
-    int lkt = 0; // k-slab index of the step being loaded
+    wvo += (unsigned)ks0 * w3_slab;
+    int lkt = 0; // k-slab index (from ks0) of the step being loaded
     // One k-slab step of raw operands in registers.  Two sets alternate: a set is filled two steps before its slab
     // is needed in LDS, so the global loads have two steps of matrix work (2 x 2048 MFMA cycles) to arrive -- one step
     // is less than the loaded HBM latency, which serialised memory time and matrix time.
@@ -314,7 +330,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     bool abl_prologue = true;
     auto issue_loads = [&](Regs &r) {
         if (BF3 && (BF3_ABL & 4) && !abl_prologue) return;
-        const int kq = lkt * FG_BK + a_kq * 4;
+        const int kq = (ks0 + lkt) * FG_BK + a_kq * 4;
         if (SRC == 4) {
             r.dq0 = qn0; // the geo of THIS slab's rows: loaded by the previous call, as the oldest of its loads
             r.dq1 = qn1;
@@ -580,7 +596,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
         for (int j = 0; j < NT; j++) ugs[d][j] = 0.0f;
     if (my_tiles == 0) { // never with the launchers below (gridDim.x <= row tiles); a workgroup without work still takes its ticket
-        if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
+        if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y * (SK ? gridDim.z : 1u), cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
         return;
     }
     __syncthreads(); // Sco
@@ -593,6 +609,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         bvs[j] = A.bias ? A.bias[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 0.0f;
         asm volatile("" : "+v"(bvs[j]));
     }
+    // pool32: the sign of the pooled layer's BatchNorm scale per column of this lane, loaded once like the bias (no load in the epilogue)
+    float sgs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        sgs[j] = (P32 && A.pool_gamma[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] < 0.0f) ? -1.0f : 1.0f;
+        asm volatile("" : "+v"(sgs[j]));
+    }
+    // EPI 0 / 2 (not the 64-row pool): the statistics as packed pairs (v_pk_add_f32 / v_pk_fma_f32: two accumulator elements per instruction)
+    f32x2 s1p[NT], s2p[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) s1p[j] = s2p[j] = f32x2{0.0f, 0.0f};
     // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
     if (SRC == 4) geo_next(); // qn = slab 0's geo (the cursor then stands on slab 1)
     issue_loads(R[0]);
@@ -618,6 +645,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
         for (int j = 0; j < NT; j++) fWhi[j] = *reinterpret_cast<const uint4 *>(&Bs3[0][0][kh][((wn * NT + j) * 32 + l31) * 4]);
     }
+    bool sk_contrib = true; // split-K: false once this workgroup handed a partial tile over instead of running the epilogue
     for (long t = 0; t < my_tiles; t++) {
         if (BF3 && BF3_PRIO == 1) __builtin_amdgcn_s_setprio(1);
         if (BF3 && BF3_PRIO == 2) __builtin_amdgcn_s_setprio(0);
@@ -715,6 +743,46 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         }
         if (BF3 && BF3_PRIO == 1) __builtin_amdgcn_s_setprio(0);
         if (BF3 && BF3_PRIO == 2) __builtin_amdgcn_s_setprio(1);
+        if constexpr (SK) {
+            // split-K: hand the partial tile over, or complete it (see FastArgs::sk_ws)
+            const size_t tile_id = (size_t)(tile0 + t * tstride) * gridDim.y + blockIdx.y;
+            float *wst = A.sk_ws + tile_id * (size_t)nsp * (FG_BM * BN) + tid;
+            float *mine = wst + (size_t)blockIdx.z * (FG_BM * BN);
+#pragma unroll
+            for (int i = 0; i < MT; i++)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+#pragma unroll
+                    for (int e = 0; e < 16; e++)
+                        __hip_atomic_store(mine + ((i * NT + j) * 16 + e) * 256, acc[i][j][e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __shared__ unsigned s_sk_last;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                s_sk_last = (__hip_atomic_fetch_add(A.sk_ticket + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)nsp - 1) ? 1u : 0u;
+            __syncthreads();
+            if (!s_sk_last) {
+                sk_contrib = false;
+                continue;
+            }
+            if (tid == 0) __hip_atomic_store(A.sk_ticket + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); // for the next launch on this slot
+            // fixed order s = 0, 1, ...: the sum does not depend on which part arrived last (this workgroup's own part comes back from
+            // the workspace like the others: its stores are acknowledged)
+            for (int sp = 0; sp < nsp; sp++) {
+                const float *part = wst + (size_t)sp * (FG_BM * BN);
+#pragma unroll
+                for (int i = 0; i < MT; i++)
+#pragma unroll
+                    for (int j = 0; j < NT; j++) {
+                        float pv[16];
+#pragma unroll
+                        for (int e = 0; e < 16; e++)
+                            pv[e] = __hip_atomic_load(part + ((i * NT + j) * 16 + e) * 256, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int e = 0; e < 16; e++) acc[i][j][e] = sp == 0 ? pv[e] : acc[i][j][e] + pv[e];
+                    }
+            }
+        }
         // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
         const long m0 = (tile0 + t * tstride) * FG_BM;
         // row pitch in bytes as an opaque scalar: the per-row scalar offsets of the buffer accesses below are then formed here,
@@ -741,7 +809,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             if (t_ == 12345.678f) z[0] = t_;
             continue;
         }
-        const bool store_z = !NEPI && ((EPI != 2) || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
+        const bool store_z = !NEPI && (!POOL || z != nullptr); // wave-uniform: the stores sit in their own loop nest so that the
         if (store_z) {                                   // pooling arithmetic below is not scheduled around 64 addresses
             // buffer stores: a scalar descriptor of this tile's rows, a scalar byte offset per (sub-tile, row) and ONE 32-bit lane
             // offset.  With flat 64-bit addresses the loop-invariant parts of the 64 addresses were hoisted out of the tile loop
@@ -761,7 +829,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 }
             }
         }
-        if (EPI == 0 || EPI == 2) {
+        if (EPI == 0 || P32) {
+#pragma unroll
+            for (int j = 0; j < NT; j++) {
+                const f32x2 bv2 = {bvs[j], bvs[j]};
+#pragma unroll
+                for (int i = 0; i < MT; i++) {
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 v = f32x2{acc[i][j][e], acc[i][j][e + 1]} + bv2;
+                        s1p[j] += v;
+                        s2p[j] = __builtin_elementwise_fma(v, v, s2p[j]);
+                    }
+                }
+            }
+        }
+        if (EPI == 2) {
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const float bv = bvs[j];
@@ -770,7 +853,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
                         const float v = acc[i][j][e] + bv;
-                        if (EPI == 2 && !A.pool32) {
+                        {
                             const int rloc = 4 * kh + (e & 3) + 8 * (e >> 2); // inside the 32-row block; ascending in e: strict compares
                             if (e == 0 || v > pmaxv[i][j]) {                  // keep the first occurrence
                                 pmaxv[i][j] = v;
@@ -786,14 +869,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     }
                 }
             }
+        }
+        if (EPI == 0 || POOL) {
             if (A.wh != nullptr) {
                 // piece layout: rows 0 and 16 of every 32-row block (accumulator elements 0 and 8 of the lower half-wave) are row 0 of a
-                // piece and stand for wh rows
+                // piece and stand for wh rows.  The 2 MT weights of this wave's blocks are consecutive: ONE scalar load per tile
+                // (s_load through the constant address space: lgkmcnt, not vmcnt -- round 4 had four global loads here, each under a
+                // branch with its own s_waitcnt vmcnt(0): four serial memory round trips per tile that also drained the operand prefetch)
                 static_assert(kPiece == 16, "the 32 x 32 MFMA tile holds two pieces: elements e < 8 and e >= 8");
+                static_assert(MT == 1 || MT == 2, "2 or 4 piece weights per wave");
+                const int pc0 = __builtin_amdgcn_readfirstlane((int)(m0 / kPiece) + wm * MT * 2);
+                float whs[2 * MT];
+                if constexpr (MT == 2) {
+                    const f32x4 q = *reinterpret_cast<const __attribute__((address_space(4))) f32x4 *>((unsigned long)(A.wh + pc0));
+                    whs[0] = q.x, whs[1] = q.y, whs[2] = q.z, whs[3] = q.w;
+                } else {
+                    const f32x2 q = *reinterpret_cast<const __attribute__((address_space(4))) f32x2 *>((unsigned long)(A.wh + pc0));
+                    whs[0] = q.x, whs[1] = q.y;
+                }
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
-                    const int pc = __builtin_amdgcn_readfirstlane((int)(m0 / kPiece) + (wm * MT + i) * 2);
-                    const float wa = (kh == 0) ? A.wh[pc] - 1.0f : 0.0f, wb = (kh == 0) ? A.wh[pc + 1] - 1.0f : 0.0f;
+                    const float wa = (kh == 0) ? whs[2 * i] - 1.0f : 0.0f, wb = (kh == 0) ? whs[2 * i + 1] - 1.0f : 0.0f;
 #pragma unroll
                     for (int j = 0; j < NT; j++) {
                         const float va = acc[i][j][0] + bvs[j], vb = acc[i][j][8] + bvs[j];
@@ -978,9 +1074,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     asm volatile("" : "+v"(urow) : "v"(s1[0])); // as EPI 4: the next four rows' LDS reads wait for these sums
                 }
         }
-        if (EPI == 2) {
+        if (POOL) {
             // the other half-wave holds the interleaved rows of the same 32-row block: combine, smaller row wins ties
-            if (!A.pool32)
+            if (!P32)
 #pragma unroll
             for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -996,9 +1092,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                         pmini[i][j] = ui;
                     }
                 }
-            if (A.pool32) {
+            if constexpr (P32) {
                 // piece layout: every 16-row piece is a group of its own (votenet_bn_pool_finalize_half joins a centre's pieces).  A 32-row
-                // block is two pieces -- elements e < 8 / e >= 8 of both half-waves -- done one after the other from the accumulators
+                // block is two pieces -- elements e < 8 / e >= 8 of both half-waves -- done one after the other from the accumulators.
+                // Branch-free (round 5: the compare-and-keep chain compiled into 115 exec-mask regions per tile): the maximum by v_max,
+                // its FIRST row by an equality scan from the last element down, the other half-wave through v_permlane32_swap.
+                const int kh4 = 4 * kh;
 #pragma unroll
                 for (int i = 0; i < MT; i++)
 #pragma unroll
@@ -1007,25 +1106,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
                         for (int j = 0; j < NT; j++) {
                             // the sign of the BatchNorm scale is the sign of gamma: the max of sg * z, first occurrence, is the entry the
-                            // pool takes (the max where the scale is >= 0, the min where it is negative)
-                            const float sg = A.pool_gamma[n0 + (wn * NT + j) * 32 + l31] >= 0.0f ? 1.0f : -1.0f;
-                            float best = 0.f;
-                            int ibest = 0;
+                            // pool takes (the max where the scale is >= 0, the min where it is negative); sg * (z + b) as one fma (sg = +-1: exact)
+                            const float sg = sgs[j], sb = sg * bvs[j];
+                            float v[8];
 #pragma unroll
-                            for (int e8 = 0; e8 < 8; e8++) {
-                                const float v = sg * (acc[i][j][hh * 8 + e8] + bvs[j]);
-                                const int rloc = 4 * kh + (e8 & 3) + 8 * (e8 >> 2); // inside the piece; ascending in e8: strict compares
-                                if (e8 == 0 || v > best) {
-                                    best = v;
-                                    ibest = rloc;
-                                }
-                            }
-                            const float ov = __shfl_xor(best, 32);
-                            const int oi = __shfl_xor(ibest, 32);
-                            if (ov > best || (ov == best && oi < ibest)) {
-                                best = ov;
-                                ibest = oi;
-                            }
+                            for (int e8 = 0; e8 < 8; e8++) v[e8] = __builtin_fmaf(sg, acc[i][j][hh * 8 + e8], sb);
+                            float best = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
+                                                         __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7])));
+                            int ibest = kh4 + 11; // rloc(e8) = 4 kh + (e8 & 3) + 8 (e8 >> 2), ascending in e8
+#pragma unroll
+                            for (int e8 = 6; e8 >= 0; e8--) ibest = (v[e8] == best) ? kh4 + (e8 & 3) + 8 * (e8 >> 2) : ibest;
+                            // lanes < 32 take the other half-wave's candidate (rows 4..7 / 12..15 of the piece); smaller row wins ties
+                            const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+                            const auto si = __builtin_amdgcn_permlane32_swap((unsigned)ibest, (unsigned)ibest, false, false);
+                            const float ov = __uint_as_float(sv[1]);
+                            const int oi = (int)si[1];
+                            const bool take = ov > best || (ov == best && oi < ibest);
+                            best = take ? ov : best;
+                            ibest = take ? oi : ibest;
                             if (lane < 32) {
                                 const size_t o = (size_t)pc * cout + n0 + (wn * NT + j) * 32 + l31;
                                 A.zmax[o] = sg * best; // the raw z
@@ -1062,7 +1160,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             }
         }
     }
-    if (EPI != 1 && A.stats) {
+    if (EPI == 0 || P32) {
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            s1[j] += s1p[j].x + s1p[j].y;
+            s2[j] += s2p[j].x + s2p[j].y;
+        }
+    }
+    if (EPI != 1 && A.stats && sk_contrib) {
         // combine the WM waves that share a column block in LDS (the operand buffers are free now: every wave is past
         // the last step's barrier), then one atomic per column and statistic per workgroup: a column's address takes
         // gridDim.x atomics instead of WM*gridDim.x, which is what bounds the tail of the narrow (BN = 64) variant
@@ -1100,7 +1205,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (threadIdx.x == 0)
-            s_last7 = (__hip_atomic_fetch_add(tl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y - 1) ? 1u : 0u;
+            s_last7 = (__hip_atomic_fetch_add(tl.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x * gridDim.y * (SK ? gridDim.z : 1u) - 1) ? 1u : 0u;
         __syncthreads();
         if (!s_last7) return;
         const double invn = 1.0 / (double)tl.rows;
@@ -1126,7 +1231,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (threadIdx.x == 0) *tl.ticket = 0u;
         return;
     }
-    if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y, cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
+    if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y * (SK ? gridDim.z : 1u), cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
 }
 
 // ---- BF3: weights pre-split into the kernel's LDS order -----------------------------------------------------------------------
@@ -1185,10 +1290,20 @@ template <int SRC, int EPI> constexpr bool bf3_built() { return true; }
 // below (EPI 3), 4 the same over an assembled layer (EPI 6), 5 over a narrow layer (EPI 4)
 template <int SRC, int EPI> constexpr int bf3_family()
 {
-    return (EPI == 0 || EPI == 2) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : (EPI == 4 || EPI == 7) ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
+    return (EPI == 0 || EPI == 2 || EPI == 8) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : (EPI == 4 || EPI == 7) ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
 }
+template <int SRC, int EPI> constexpr bool sk_built() { return (SRC == 0 || SRC == 1) && (EPI == 0 || EPI == 1 || EPI == 3); }
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
+        if constexpr (sk_built<SRC_, EPI_>()) {                                                                                      \
+            if ((GRID_).z > 1) { /* split-K (sk_take): its own instantiations, so that the others keep their registers */            \
+                if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0)       \
+                    hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_); \
+                else                                                                                                                 \
+                    hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, false, true>), GRID_, dim3(256), 0, ST_, A_); \
+                break;                                                                                                               \
+            }                                                                                                                        \
+        }                                                                                                                            \
         if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
             if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
                 hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_);    \
@@ -1199,6 +1314,57 @@ template <int SRC, int EPI> constexpr int bf3_family()
     } while (0)
 int g_fast_xcd_chunk = 1; // votenet_debug_fast_xcd_chunk: the piece-layout GEMMs that gather P take their row tiles in per-XCD chunks
 int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
+
+// ---- split-K for launches of few row tiles (FastArgs::sk_ws) ----------------------------------------------------------------------
+// The caller arms the NEXT launch of its thread with a workspace (votenet_mlp_split_k_arm; size from votenet_mlp_split_k_floats) and
+// registers one persistent zeroed ticket array per process (votenet_mlp_split_k_tickets: tiles of consecutive launches take
+// consecutive slots of it as a ring; the last arriver of a tile puts its slot back to zero).  Unarmed launches never split.
+static thread_local float *t_sk_ws = nullptr;
+static thread_local size_t t_sk_floats = 0;
+static std::mutex g_sk_mu;
+static unsigned *g_sk_tickets = nullptr;
+static long g_sk_nticket = 0, g_sk_tpos = 0;
+int g_sk_target = 640, g_sk_max_parts = 4, g_sk_min_slabs = 4, g_sk_max_wgs = 400; // votenet_debug_split_k (tuning hook)
+struct SkPlan {
+    int parts, bn; // parts (1: no split), column-block width of the variant the launch takes
+    long tiles;    // output tiles = row tiles x column blocks
+};
+// the variant fast_dispatch picks for (rows, cin, cout) and the parts it is split into; pooled / piece-layout / gather launches never split
+static SkPlan sk_plan(long rows, int cin, int cout, bool pooled)
+{
+    SkPlan p = {1, 0, 0};
+    if (pooled || rows <= 0 || rows % FG_BM != 0 || cin % (2 * FG_BK) != 0 || cin > 512 || cout % 64 != 0) return p;
+    const long ntiles = rows / FG_BM;
+    p.bn = (cout % 128 == 0 && ntiles * (cout / 128) >= 200) ? 128 : 64;
+    p.tiles = ntiles * (cout / p.bn);
+    if (p.tiles >= g_sk_max_wgs) return p;
+    const int nk = cin / FG_BK;
+    int parts = (int)((g_sk_target + p.tiles / 2) / p.tiles);
+    parts = parts > g_sk_max_parts ? g_sk_max_parts : parts;
+    while (parts > 1 && (nk % (2 * parts) != 0 || nk / parts < g_sk_min_slabs)) --parts;
+    p.parts = parts < 1 ? 1 : parts;
+    return p;
+}
+// -> parts for this launch (and the workspace / tickets in `a`), consuming the thread's armed workspace
+template <int SRC, int EPI>
+static int sk_take(FastArgs &a, long gx, long ntiles, int bn)
+{
+    float *ws = t_sk_ws;
+    const size_t have = t_sk_floats;
+    t_sk_ws = nullptr;
+    t_sk_floats = 0;
+    if (!sk_built<SRC, EPI>()) return 1;
+    if (ws == nullptr || gx != ntiles || a.nh_dev != nullptr || a.wh != nullptr || a.xcd_chunk) return 1;
+    const SkPlan p = sk_plan(a.rows, a.cin, a.cout, false);
+    if (p.parts <= 1 || p.bn != bn || (size_t)p.tiles * p.parts * FG_BM * bn > have) return 1;
+    std::lock_guard<std::mutex> lk(g_sk_mu);
+    if (g_sk_tickets == nullptr || p.tiles > g_sk_nticket) return 1;
+    if (g_sk_tpos + p.tiles > g_sk_nticket) g_sk_tpos = 0;
+    a.sk_ticket = g_sk_tickets + g_sk_tpos;
+    g_sk_tpos += p.tiles;
+    a.sk_ws = ws;
+    return p.parts;
+}
 
 template <int SRC, int EPI>
 static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
@@ -1227,7 +1393,8 @@ static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
         const int ny = a.cout / 64;
         gx = ntiles;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
-        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
+        const dim3 grid((unsigned)gx, ny, sk_take<SRC, EPI>(a, gx, ntiles, 64));
+        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, grid, st, a);
         return true;
     }
     if (a.cout % 128 == 0) {
@@ -1235,14 +1402,16 @@ static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
         gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
         if (a.xcd_chunk && gx >= 64) gx &= ~7L; // a whole number of workgroups per XCD
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false; // a tile jump must be a whole number of groups
-        FAST_LAUNCH(2, 2, 2, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
+        const dim3 grid((unsigned)gx, ny, EPI == 2 ? 1 : sk_take<SRC, EPI>(a, gx, ntiles, 128));
+        FAST_LAUNCH(2, 2, 2, 2, SRC, EPI, grid, st, a);
         return true;
     }
     if (EPI != 2 && a.cout % 64 == 0) { // 64, and the odd multiples of 64 (320 = voting's 259 padded): 128 x 64 tiles, cout / 64 column blocks
         const int ny = a.cout / 64;
         gx = ntiles < g_fast_cap41 / ny ? ntiles : g_fast_cap41 / ny;
         if (SRC == 2 && (gx * FG_BM) % a.pool_k != 0) return false;
-        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, dim3((unsigned)gx, ny), st, a);
+        const dim3 grid((unsigned)gx, ny, sk_take<SRC, EPI>(a, gx, ntiles, 64));
+        FAST_LAUNCH(4, 1, 1, 2, SRC, EPI, grid, st, a);
         return true;
     }
     }
@@ -1325,7 +1494,8 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
     const long ntiles = rows / FG_BM;
     const int ny = cout / 128;
     const long gx = ntiles < g_fast_cap22 / ny ? ntiles : g_fast_cap22 / ny;
-    FAST_LAUNCH(2, 2, 2, 2, 0, 2, dim3((unsigned)gx, ny), st, a);
+    if (a.pool32) FAST_LAUNCH(2, 2, 2, 2, 0, 8, dim3((unsigned)gx, ny), st, a);
+    else FAST_LAUNCH(2, 2, 2, 2, 0, 2, dim3((unsigned)gx, ny), st, a);
     return true;
 }
 
@@ -1562,6 +1732,44 @@ extern "C" int votenet_narrow_dgrad_bn_reduce_masked(long rows, int c, int c0, i
     VN_REQUIRE(mask != nullptr, "narrow_dgrad_bn_reduce_masked: null mask");
     return narrow_dgrad_bn_reduce_impl(rows, c, c0, k0, da, zsrc, coef, relu, wT, u8, w0, b0, scale0, shift0, mean0, var0, eps, relu0, sums, ug,
                                        tail, wh, stream, mask);
+}
+
+// ---- split-K (see sk_plan / FastArgs::sk_ws) -----------------------------------------------------------------------------------
+// floats of workspace a launch of votenet_mlp_linear / votenet_mlp_dgrad_bn / votenet_mlp_dgrad_bn_reduce with these sizes would use
+// split (0: it would not split: nothing to arm)
+extern "C" long votenet_mlp_split_k_floats(long rows, int cin, int cout)
+{
+    {
+        std::lock_guard<std::mutex> lk(votenet::g_sk_mu);
+        if (votenet::g_sk_tickets == nullptr) return 0;
+    }
+    const votenet::SkPlan p = votenet::sk_plan(rows, cin, cout, false);
+    return p.parts > 1 ? p.tiles * p.parts * votenet::FG_BM * p.bn : 0;
+}
+// the workspace (device memory, any contents, alive until the launch has run) for the NEXT fused-GEMM launch of the calling thread
+extern "C" int votenet_mlp_split_k_arm(void *ws, long floats)
+{
+    VN_REQUIRE((ws == nullptr) == (floats <= 0) && (uintptr_t)ws % 16 == 0, "mlp_split_k_arm: a 16-byte aligned workspace and its size");
+    votenet::t_sk_ws = static_cast<float *>(ws);
+    votenet::t_sk_floats = ws ? (size_t)floats : 0;
+    return VOTENET_OK;
+}
+// n ZEROED unsigned ints of device memory that stay alive (and untouched by anyone else) while split launches may run; NULL: split-K off
+extern "C" int votenet_mlp_split_k_tickets(void *tickets, long n)
+{
+    VN_REQUIRE((tickets == nullptr) == (n <= 0), "mlp_split_k_tickets: an array and its length, or NULL and 0");
+    std::lock_guard<std::mutex> lk(votenet::g_sk_mu);
+    votenet::g_sk_tickets = static_cast<unsigned *>(tickets);
+    votenet::g_sk_nticket = tickets ? n : 0;
+    votenet::g_sk_tpos = 0;
+    return VOTENET_OK;
+}
+extern "C" void votenet_debug_split_k(int target_wgs, int max_parts, int min_slabs, int max_wgs) // tuning hook: 0 keeps a value
+{
+    if (target_wgs > 0) votenet::g_sk_target = target_wgs;
+    if (max_parts > 0) votenet::g_sk_max_parts = max_parts;
+    if (min_slabs > 0) votenet::g_sk_min_slabs = min_slabs;
+    if (max_wgs > 0) votenet::g_sk_max_wgs = max_wgs;
 }
 
 extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }

@@ -5,6 +5,8 @@
 namespace votenet {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // The implicit input matrix of a layer (mirror of struct votenet_mlp_input, include/votenet_hip.h)
 struct MlpIn {

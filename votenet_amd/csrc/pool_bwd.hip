@@ -891,6 +891,10 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
 // per 32 x 32 sub-tile and 16-row slab instead of eight v_mfma_f32_32x32x2_f32 of twice the length; two register sets of raw
 // rows in flight, LDS double-buffered, one barrier per slab.  Partial tiles are added with atomics (the deterministic mode keeps
 // the fp32 kernel with its ordered reduction).
+#ifndef GRAM_ABL
+#define GRAM_ABL 0 // probe builds only (tools/probe/ablate_half.sh): 1 no MFMAs, 2 no epilogue (atomics), 4 no global loads after the prologue,
+                   // 8 no staging (activation, split, LDS writes) after the prologue -- results wrong by construction, only the time is read
+#endif
 template <int C>
 __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
                                                        int relu, float *__restrict__ gram, long rows_per_block,
@@ -923,7 +927,9 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     const bool first_rg = rg == 0;
     const float *whb = wh ? wh + r_begin / kPiece : nullptr;
     float Wq[2] = {1.0f, 1.0f}; // sqrt of that row's weight, travelling with the register set
+    bool abl_prologue = true;
     auto load = [&](float (&r)[KPT], int s, float &wq) {
+        if ((GRAM_ABL & 4) && !abl_prologue) return;
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
             int lr = s * 16 + rg * KPT + i;
@@ -934,6 +940,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
         else wq = 1.0f;
     };
     auto store = [&](int buf, const float (&r)[KPT], int s, float wq) {
+        if ((GRAM_ABL & 8) && !abl_prologue) return;
         float v[KPT];
 #pragma unroll
         for (int i = 0; i < KPT; i++) {
@@ -970,6 +977,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     __syncthreads();
     const int kh = lane >> 5, l31 = lane & 31;
     int buf = 0;
+    abl_prologue = false;
     const int nslab2 = (nslab + 1) & ~1; // the loop runs slab pairs; a padding slab multiplies zeros
     for (int s = 0; s < nslab2; s += 2) {
 #pragma unroll
@@ -984,6 +992,10 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
                 }
             }
             auto mm = [&](int pa, int pb) {
+                if (GRAM_ABL & 1) {
+                    acc[0][0][0] += __uint_as_float(fa[pa][0].x ^ fb[pb][0].y);
+                    return;
+                }
 #pragma unroll
                 for (int a = 0; a < T; a++)
 #pragma unroll
@@ -1002,6 +1014,17 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             lds_barrier();
             buf ^= 1;
         }
+    }
+    if (GRAM_ABL & 2) {
+        float t_ = 0.0f;
+#pragma unroll
+        for (int a = 0; a < T; a++)
+#pragma unroll
+            for (int b = 0; b < T; b++)
+#pragma unroll
+                for (int e = 0; e < 16; e++) t_ += acc[a][b][e];
+        if (t_ == 12345.678f) gram[0] = t_;
+        return;
     }
     // C/D layout of the 32 x 32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
 #pragma unroll

@@ -404,6 +404,42 @@ class SplitImages:
             pass
 
 
+SPLIT_K = False      # the fused GEMMs of few row tiles (the static stretch: 2048-8192 rows) share an output tile's contraction between 2-4 workgroups (csrc/mlp_fast.hip, FastArgs::sk_ws)
+_SK_TICKETS = {}     # device -> the zeroed ticket array registered with the library (kept alive here)
+
+
+class _SplitK:
+    """`with _SplitK(rows, cin, cout, device):` the fused-GEMM launch inside may split its contraction: a workspace of the size the
+    library asks for (from the caching allocator -- inside a graph capture: the capture's pool) is armed for it and disarmed
+    afterwards.  The ticket array is registered on first use, outside of any capture (the first step of a shape runs launch by launch)."""
+    __slots__ = ("ws",)
+
+    def __init__(self, rows, cin, cout, device):
+        self.ws = None
+        if not SPLIT_K or rows <= 0 or rows > 16384:
+            return
+        if device not in _SK_TICKETS:
+            if torch.cuda.is_current_stream_capturing():
+                return
+            t = torch.zeros(1 << 16, dtype=torch.int32, device=device)
+            torch.cuda.current_stream(device).synchronize()  # zeroed before any stream may launch a split GEMM
+            L.check(L.lib().votenet_mlp_split_k_tickets(L.ptr(t), t.numel()))
+            _SK_TICKETS[device] = t
+        n = L.lib().votenet_mlp_split_k_floats(rows, cin, cout)
+        if n > 0:
+            self.ws = torch.empty(n, dtype=torch.float32, device=device)
+
+    def __enter__(self):
+        if self.ws is not None:
+            L.lib().votenet_mlp_split_k_arm(L.ptr(self.ws), self.ws.numel())
+        return self
+
+    def __exit__(self, *exc):
+        if self.ws is not None:
+            L.lib().votenet_mlp_split_k_arm(None, 0)
+        return False
+
+
 def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, want_stats=True, in_bn=None):
     """z = act(x) @ w + bias with act = relu(x*in_scale+in_shift) folded into the load (or identity).
     x (rows, cin) f32 -> z (rows, cout), stats (2*cout) f64 [column sums of z, of z*z] or None."""
@@ -416,7 +452,8 @@ def linear_dense(x, w, bias=None, in_scale=None, in_shift=None, in_relu=True, wa
     z = torch.empty((rows, cout), dtype=torch.float32, device=x.device)
     stats = _zeros_f64(2 * cout, x.device) if want_stats else None
     d = _desc_dense(x, in_scale, in_shift, in_relu, in_bn)
-    with L.device_guard(x.device), _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd" + ("+bn" if (in_scale is not None or in_bn is not None) else ""))):
+    with L.device_guard(x.device), _SplitK(rows, cin, cout, x.device), \
+            _Timed("linear_dense", 2.0 * rows * cin * cout, (rows, cin, cout, "fwd" + ("+bn" if (in_scale is not None or in_bn is not None) else ""))):
         L.check(L.lib().votenet_mlp_linear(ctypes.byref(d), rows, cin, cout, L.ptr(w), L.ptr(bias), L.ptr(z), L.ptr(stats),
                                            L.stream_ptr()))
     return z, stats
@@ -1324,7 +1361,7 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
         zp, bsc, bsh, bme, bva, brelu = below
         sums = _zeros_f64(2 * cout, z.device)
         t, coef_b = _coef_tail(below_tail, cout, z.device)
-        with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
+        with L.device_guard(z.device), _SplitK(rows, c, cout, z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn_reduce")):
             L.check(L.lib().votenet_mlp_dgrad_bn_reduce(rows, c, cout, L.ptr(da), L.ptr(z), L.ptr(coef), 1 if relu else 0, L.ptr(wT),
                                                         L.ptr(out), L.ptr(zp), L.ptr(bsc), L.ptr(bsh), L.ptr(bme), L.ptr(bva), eps,
                                                         1 if brelu else 0, L.ptr(sums), ctypes.byref(t) if t is not None else None,
@@ -1332,7 +1369,7 @@ def dgrad_bn(z, coef, relu, wT, da=None, gout=None, argmax=None, k=0, below=None
         if below_tail is None:
             return out, sums
         return out, (coef_b if coef_b is not None else _coef_after(below_tail, (bsc, bsh, bme, bva), sums, eps))  # (da_prev, coef of the layer below)
-    with L.device_guard(z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
+    with L.device_guard(z.device), _SplitK(rows if da is not None else 0, c, cout, z.device), _Timed("linear_dense", 2.0 * rows * c * cout, (rows, c, cout, "dgrad_bn")):
         L.check(L.lib().votenet_mlp_dgrad_bn(rows, c, cout, L.ptr(da), L.ptr(gout), L.ptr(argmax), k, L.ptr(z), L.ptr(coef),
                                              1 if relu else 0, L.ptr(wT), L.ptr(out), L.stream_ptr()))
     return out

@@ -151,6 +151,7 @@ class StretchGraph:
         self.arena = torch.empty(nd + (n32 + 1) // 2, dtype=torch.float64, device=dev)
         self.segments = []  # (graph, [(thunk, tensors) ...]) in replay order
         self._losses = torch.empty(12, dtype=torch.float32, device=dev)
+        self._loss_ring = [torch.empty(12, dtype=torch.float32, device=dev) for _ in range(8)]
         self.replays = 0
         self.last_used = 0
         if getattr(net, "_capture_stream", None) is None:
@@ -225,7 +226,10 @@ class StretchGraph:
         try:
             for i, (graph, thunks) in enumerate(self.segments):
                 if i == self.loss_at:
-                    VL.votenet_loss(self.out, gt, buffers=self.loss_bufs)
+                    # the loss launch is not captured and no captured kernel reads the 12 losses: each replay writes them into the next
+                    # vector of a small ring, so a handle to last_losses kept across a few steps still shows ITS step (no copy launch)
+                    losses = self._loss_ring[self.replays % len(self._loss_ring)]
+                    VL.votenet_loss(self.out, gt, buffers=(losses, self.loss_bufs[1]))
                 graph.replay()
                 if thunks and wgrad_stream is not None:
                     P._hand_over([f for f, _ in thunks], ())  # (their tensors live in the graphs' pool: nothing for the allocator to track)
@@ -235,7 +239,7 @@ class StretchGraph:
         finally:
             P.WGRAD_STREAM = prev
         self.replays += 1
-        return _StretchOutputs(self.out, self), self.losses, self.grads
+        return _StretchOutputs(self.out, self), losses, self.grads
 
 
 SPLIT_BF16 = True  # fused GEMMs on bf16 x 3 split operands (fp32-accurate products, six bf16 MFMAs per k-step; mlp.SplitImages)
@@ -808,7 +812,7 @@ class VoteNetHotPath:
             g.setdefault("prop_fps", P.tf_sampling.farthest_point_sample(self.proposal.npoint, lv["l2_xyz"]))
         ins = self._stretch_inputs(lv, g)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
-                                                                             self.overlap_wgrad, STRETCH_SEGMENTS, M.COEF_TAIL, P.WGRAD_BATCH, P.POOL_IN_EPILOGUE,
+                                                                             self.overlap_wgrad, STRETCH_SEGMENTS, M.SPLIT_K, M.COEF_TAIL, P.WGRAD_BATCH, P.POOL_IN_EPILOGUE,
                                                                              self.store.split, bool(getattr(self, "inline_wgrad_tail", False)), M.CONFIG_EPOCH)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
@@ -840,8 +844,7 @@ class VoteNetHotPath:
         self.store._fresh_wait()
         if self.overlap_wgrad and self._wgrad_stream is None:
             self._wgrad_stream = torch.cuda.Stream(device=self.device, priority=WGRAD_PRIORITY)
-        out, losses, grads = sg.replay(ins, gt, self._wgrad_stream if self.overlap_wgrad else None)
-        self.last_losses = losses.clone()  # 48 bytes: the graph's own vector is rewritten by the next replay
+        out, self.last_losses, grads = sg.replay(ins, gt, self._wgrad_stream if self.overlap_wgrad else None)  # (a vector of the graph's ring: rewritten eight replays later)
         self._ema_version += 1  # (the replay ran votenet_ema_update: inference_bn() must not serve a table built before it)
         self._backward_levels_pass(tape, grads)
         return out
