@@ -205,6 +205,27 @@ class _DryReplica:
         st.flat.sub_(0.01 * scale * st.grad)
 
 
+def per_rank_record(rank, local, world, ms_per_step, spread, pinned, hostpin):
+    """N > 1: every rank's own clock and host placement gathered over the group into ONE record of the line (every rank calls this)."""
+    import torch.distributed as dist
+    numa = None
+    try:
+        numas = hostpin.gpu_numa_nodes()
+        phys = hostpin.physical_gpu(local, len(numas))
+        numa = numas[phys] if phys is not None and 0 <= phys < len(numas) else None
+    except Exception:
+        pass
+    mine = {"rank": rank, "local_rank": local, "ms_per_step": round(ms_per_step, 3),
+            "step_ms_min": spread["min"] if spread else None, "step_ms_median": spread["median"] if spread else None,
+            "step_ms_max": spread["max"] if spread else None, "hostpin": {"cpus": pinned, "gpu_numa_node": numa}}
+    got = [None] * world
+    dist.all_gather_object(got, mine)
+    ms = [g["ms_per_step"] for g in got]
+    return {"ranks": got, "ms_per_step_min": min(ms), "ms_per_step_max": max(ms),
+            "what": "each rank's own wall clock over the timed region (`value` uses the maximum), the spread of its step boundaries "
+                    "(HIP events on its main stream) and where its host threads were pinned (votenet_amd/hostpin.py)"}
+
+
 def dry_run(args):
     """Launcher self-test without a GPU (`--dry-run`, used by tests/): the ranks rendezvous over gloo exactly as the real run
     does over RCCL, all-reduce one number and rank 0 prints a line with n_gpus; no kernel runs, nothing is measured."""
@@ -225,9 +246,17 @@ def dry_run(args):
         for net in nets:
             dp.broadcast_params(net.store)
         check = dp_self_check(torch.device("cpu"), nets, lambda net, i: net.train_step(rank, world, i), steps=2)
+    per_rank = None
+    if world > 1:  # the per-rank record of a real `--gpus N` line (clocks made up here: nothing is measured)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("votenet_hostpin", os.path.join(ROOT, "votenet_amd", "hostpin.py"))
+        hostpin = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(hostpin)
+        per_rank = per_rank_record(rank, int(os.environ.get("LOCAL_RANK", "0")), world, 1.0 + rank,
+                                   {"min": 0.9 + rank, "median": 1.0 + rank, "max": 1.2 + rank}, None, hostpin)
     if rank == 0:
         emit(json.dumps({"metric": "dry run (launcher self-test, nothing measured)", "value": None, "n_gpus": world,
-                         "rank_sum": float(t.item()), "check_dp": check}))
+                         "rank_sum": float(t.item()), "check_dp": check, "per_rank": per_rank}))
     if world > 1:
         dist.destroy_process_group()
     if check is not None and not check["equal_everywhere"]:
@@ -449,6 +478,7 @@ def main():
             step()
         torch.cuda.synchronize()
         gemm_events, vmlp.PROFILE_EVENTS = vmlp.PROFILE_EVENTS, None
+    dt_own = dt
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -461,6 +491,10 @@ def main():
     spread = ({"min": round(per_step[0], 3), "median": round(per_step[len(per_step) // 2], 3), "max": round(per_step[-1], 3),
                "steps": len(per_step), "what": "ms between consecutive step boundaries on the main stream (HIP events), steps without "
                                                "kernel-level timing events"} if per_step else None)
+
+    # N > 1: every rank's own clock and host placement in ONE record of the line (a straggling rank -- a NUMA-remote host thread, a
+    # throttled GPU -- is then visible in a single SCALE record: `value` only shows the maximum)
+    per_rank = per_rank_record(rank, local, world, dt_own / args.steps * 1e3, spread, pinned, hostpin) if world > 1 else None
 
     # the same step with every batch's geometry computed inside its own step (nothing carried across steps): reported beside
     # the headline value, not instead of it
@@ -822,7 +856,7 @@ def main():
                                "fly (W diag(C) W^T of the Gram-form input gradient) stay on fp32 MFMA; tests hold both forms to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
             "fp32_mfma_gemms": fp32_step, "full_row_layout": full_step, "row_layout": row_layout, "configs": cfgs,
-            "communicator": comm, "dp_collectives": dp_coll, "check_dp": check,
+            "communicator": comm, "per_rank": per_rank, "dp_collectives": dp_coll, "check_dp": check,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,
         }
         emit(json.dumps(out))

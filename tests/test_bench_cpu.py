@@ -61,6 +61,11 @@ def test_gpus_n_starts_n_ranks_itself():
     assert c["world_size"] == 2 and c["distinct_devices"] == 2 and c["backend"] == "gloo" and c["steps"] == 2
     assert [w for w, _ in c["collectives_per_step"]] == ["tail", "head"]
     assert "tail_exposed_ms" in c
+    # ... and every rank's own clock / host placement (a straggler is visible in the one SCALE record)
+    pr = line["per_rank"]
+    assert [r_["rank"] for r_ in pr["ranks"]] == [0, 1] and [r_["ms_per_step"] for r_ in pr["ranks"]] == [1.0, 2.0]
+    assert pr["ms_per_step_min"] == 1.0 and pr["ms_per_step_max"] == 2.0
+    assert all(set(r_["hostpin"]) == {"cpus", "gpu_numa_node"} for r_ in pr["ranks"])
 
 
 def test_diverged_replicas_fail_the_run():

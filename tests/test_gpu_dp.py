@@ -139,6 +139,13 @@ def test_bench_gpus_2_line_validates_its_own_data_parallel_path():
     assert [w for w, _ in c["collectives_per_step"]] == ["tail", "head"] and c["tail_exposed_ms"] is not None
     assert line["communicator"]["world_size"] == 2 and line["communicator"]["backend"] == "gloo"
     assert c["distinct_devices"] == 1   # both ranks on cuda:0 HERE (the flag above); N on the driver's node
+    # every rank's own clock and host placement in the one line (a straggler shows in a single SCALE record)
+    pr = line["per_rank"]
+    assert [r_["rank"] for r_ in pr["ranks"]] == [0, 1]
+    for r_ in pr["ranks"]:
+        assert r_["ms_per_step"] > 0 and r_["step_ms_min"] <= r_["step_ms_median"] <= r_["step_ms_max"]
+        assert set(r_["hostpin"]) == {"cpus", "gpu_numa_node"}
+    assert pr["ms_per_step_min"] <= pr["ms_per_step_max"] and abs(pr["ms_per_step_max"] - line["ms_per_step"]) < 1e-3 + 0.001 * line["ms_per_step"]
 
 
 _RCCL_BESIDE_GRAPHS = r"""

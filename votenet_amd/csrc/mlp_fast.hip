@@ -193,44 +193,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         ntiles = lim < ntiles ? lim : ntiles;
     }
     const bool affine = (SRC == 0 || SRC == 3 || SRC == 4) && (A.in_scale != nullptr || A.in_raw.stats != nullptr);
-    if (SRC == 4)
-        for (int t = tid; t < 3 * cin; t += 256) Wxs[t / cin][t % cin] = A.wx[t];
-    if (NARROW) {
-        const int c0 = (SRC == 3) ? cin : cout, cb = (SRC == 3) ? 0 : n0, cw = (SRC == 3) ? cin : BN;
-        for (int t = tid; t < 9 * cw; t += 256) {
-            const int d = t / cw, c = t % cw;
-            W0s[d][c] = d < 8 ? (d < A.k0 ? A.w0[(size_t)d * c0 + cb + c] : 0.0f) : (A.b0 ? A.b0[cb + c] : 0.0f);
-        }
-    }
-    if (SRC == 0 || SRC == 3 || SRC == 4) {
-        if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
-            const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && (!SK || blockIdx.z == 0);
-            for (int k = tid; k < cin; k += 256) {
-                float sc, sh;
-                bn_raw_channel(A.in_raw, cin, k, writer, sc, sh);
-                Sco[0][k] = sc;
-                Sco[1][k] = sh;
-            }
-        } else if (affine)
-            for (int k = tid; k < cin; k += 256) {
-                Sco[0][k] = A.in_scale[k];
-                Sco[1][k] = A.in_shift[k];
-            }
-        else if (BF3) // the BF3 loader has no branch on `affine`: x * 1 + 0
-            for (int k = tid; k < cin; k += 256) {
-                Sco[0][k] = 1.0f;
-                Sco[1][k] = 0.0f;
-            }
-    } else {
-        for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
-    }
-    if (REDUCE_BELOW)
-        for (int cidx = tid; cidx < BN; cidx += 256) {
-            Eco[0][cidx] = A.e_scale[n0 + cidx];
-            Eco[1][cidx] = A.e_shift[n0 + cidx];
-            Eco[2][cidx] = A.e_mean[n0 + cidx];
-            Eco[3][cidx] = 1.0f / sqrtf(A.e_var[n0 + cidx] + A.e_eps);
-        }
     // which row tiles this workgroup takes: tile0, tile0 + tstride, ...  By default round-robin over the launch.  xcd_chunk (piece
     // layout): workgroups are dealt to the 8 XCDs round-robin (workgroup b -> XCD b % 8), and every kernel that gathers rows of the
     // per-point table P from a SCENE's 1 MB slice had all eight slices in flight on every XCD -- 8.4 MB against its 4 MB L2 (FETCH_SIZE
@@ -599,30 +561,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (REDUCE_BELOW) coef_tail(A.tail, gridDim.x * gridDim.y * (SK ? gridDim.z : 1u), cout, A.stats, A.e_scale, A.e_shift, A.e_mean, A.e_var, A.e_eps);
         return;
     }
+    // Round 5: the FIRST operand loads go out before anything else touches memory.  The per-channel tables below (BatchNorm of the
+    // input from raw sums / coefficient vector / the layer below's BatchNorm / bias) are a chain of small dependent round trips --
+    // kernel arguments, table loads in loops, LDS, barrier -- that used to run BEFORE the first operand load was issued: 5-6 memory
+    // latencies in a row ahead of the first MFMA, a third of a 15 us launch of the static stretch.  Now they wait together.
+    if (SRC == 4) geo_next(); // qn = slab 0's geo (the cursor then stands on slab 1)
+    issue_loads(R[0]);
+    // (the bias and, pool32, the pooled layer's gamma -- the sign of the scale the pool will apply -- of this lane's columns: loaded
+    // here, consumed below)
+    float bvs[NT], sgs[NT];
+#pragma unroll
+    for (int j = 0; j < NT; j++) {
+        bvs[j] = A.bias ? A.bias[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 0.0f;
+        sgs[j] = P32 ? A.pool_gamma[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 1.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (SRC == 4)
+        for (int t = tid; t < 3 * cin; t += 256) Wxs[t / cin][t % cin] = A.wx[t];
+    if (NARROW) {
+        const int c0 = (SRC == 3) ? cin : cout, cb = (SRC == 3) ? 0 : n0, cw = (SRC == 3) ? cin : BN;
+        for (int t = tid; t < 9 * cw; t += 256) {
+            const int d = t / cw, c = t % cw;
+            W0s[d][c] = d < 8 ? (d < A.k0 ? A.w0[(size_t)d * c0 + cb + c] : 0.0f) : (A.b0 ? A.b0[cb + c] : 0.0f);
+        }
+    }
+    if (SRC == 0 || SRC == 3 || SRC == 4) {
+        if (A.in_raw.stats) { // the producer's BatchNorm, finalized here; workgroup (0,0) records it for the backward pass
+            const bool writer = blockIdx.x == 0 && blockIdx.y == 0 && (!SK || blockIdx.z == 0);
+            for (int k = tid; k < cin; k += 256) {
+                float sc, sh;
+                bn_raw_channel(A.in_raw, cin, k, writer, sc, sh);
+                Sco[0][k] = sc;
+                Sco[1][k] = sh;
+            }
+        } else if (affine)
+            for (int k = tid; k < cin; k += 256) {
+                Sco[0][k] = A.in_scale[k];
+                Sco[1][k] = A.in_shift[k];
+            }
+        else if (BF3) // the BF3 loader has no branch on `affine`: x * 1 + 0
+            for (int k = tid; k < cin; k += 256) {
+                Sco[0][k] = 1.0f;
+                Sco[1][k] = 0.0f;
+            }
+    } else {
+        for (int k = tid; k < 5 * cin; k += 256) Sco[k / cin][k % cin] = A.coef[k];
+    }
+    if (REDUCE_BELOW)
+        for (int cidx = tid; cidx < BN; cidx += 256) {
+            Eco[0][cidx] = A.e_scale[n0 + cidx];
+            Eco[1][cidx] = A.e_shift[n0 + cidx];
+            Eco[2][cidx] = A.e_mean[n0 + cidx];
+            Eco[3][cidx] = 1.0f / sqrtf(A.e_var[n0 + cidx] + A.e_eps);
+        }
     __syncthreads(); // Sco
     // bias of this lane's columns, loaded ONCE and consumed (the empty asm) before any prefetch is in flight: a load inside
     // the per-tile epilogue -- or one still pending in the compiler's bookkeeping -- costs an s_waitcnt vmcnt(0) there,
     // i.e. drains both prefetch sets at every tile boundary (every 4 slabs at cin = 64)
-    float bvs[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) {
-        bvs[j] = A.bias ? A.bias[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 0.0f;
         asm volatile("" : "+v"(bvs[j]));
-    }
-    // pool32: the sign of the pooled layer's BatchNorm scale per column of this lane, loaded once like the bias (no load in the epilogue)
-    float sgs[NT];
-#pragma unroll
-    for (int j = 0; j < NT; j++) {
-        sgs[j] = (P32 && A.pool_gamma[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] < 0.0f) ? -1.0f : 1.0f;
+        sgs[j] = (P32 && sgs[j] < 0.0f) ? -1.0f : 1.0f;
         asm volatile("" : "+v"(sgs[j]));
     }
     // EPI 0 / 2 (not the 64-row pool): the statistics as packed pairs (v_pk_add_f32 / v_pk_fma_f32: two accumulator elements per instruction)
     f32x2 s1p[NT], s2p[NT];
 #pragma unroll
     for (int j = 0; j < NT; j++) s1p[j] = s2p[j] = f32x2{0.0f, 0.0f};
-    // prologue: slab 0 -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
-    if (SRC == 4) geo_next(); // qn = slab 0's geo (the cursor then stands on slab 1)
-    issue_loads(R[0]);
+    // prologue: slab 0 (in flight since the top) -> LDS buffer 0; slabs 1 and 2 in flight in register sets 1 and 0
     store_regs(0, R[0]);
 #pragma unroll
     for (int q = 1; q <= NSETS; q++) { // same issue order as in the loop: sets 1 .. NSETS-1, then set 0
