@@ -773,6 +773,13 @@ int votenet_mlp_gram_half(long rows, int c, const float *z, const float *scale_s
 int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
                                    int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef, int relu,
                                    float *dw, float *colsum, const int *hc, const float *wh, const int *nh_dev, void *stream);
+/* The same walking CENTRES (round 5): pos = the layout's (G, 3) table of every centre's pieces j >= 1 (votenet_half_groups); all kept
+ * pieces of a ball are staged together and every channel reads its arg-max row once -- the piece form sends every wavefront through
+ * the row loop once per piece with 1 / pieces of its lanes live.  Same sums in another association. */
+int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
+                                           int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef,
+                                           int relu, float *dw, float *colsum, const int *pos, const float *wh, const int *nh_dev,
+                                           void *stream);
 int votenet_assembled_wgrad_bn_half(long rows, int c0, int cout, const float *geo, const float *P, const float *wx, const float *in_scale,
                                     const float *in_shift, int in_relu, const float *da, const float *z, const float *coef, int relu,
                                     const float *wh, float *dw, const int *nh_dev, void *stream);

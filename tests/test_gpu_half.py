@@ -130,6 +130,15 @@ def test_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_f
     M.pool_wgrad(z1, bn1.scale, bn1.shift, True, Gm, w2, b2, coef2, True, gout, arg, zsel, k, dw2)
     M.pool_wgrad(z1h, bn1.scale, bn1.shift, True, Gh, w2, b2, coef2, True, gout, arg, zsel, k, dw2h, half=half)
     assert relerr(Gh[:c1], Gm[:c1]) < 2e-6 and relerr(Gh[c1], Gm[c1]) < 2e-6 and relerr(dw2h, dw2) < 1e-5
+    # the two forms of the piece layout's arg-max gather: walking centres (default, round 5) and walking pieces -- the same sums
+    assert M.POOL_WGRAD_CENTRES
+    M.POOL_WGRAD_CENTRES = False
+    try:
+        Gp, dw2p = M.gram(z1h, aff1, True, half=half), torch.zeros(c1, c2, device=dev)
+        M.pool_wgrad(z1h, bn1.scale, bn1.shift, True, Gp, w2, b2, coef2, True, gout, arg, zsel, k, dw2p, half=half)
+    finally:
+        M.POOL_WGRAD_CENTRES = True
+    assert relerr(dw2p, dw2) < 1e-5 and relerr(dw2p, dw2h) < 2e-6 and relerr(Gp[c1], Gh[c1]) < 2e-6  # (row c1: the weighted column sums)
     below = (bn1.scale, bn1.shift, bn1.mean, bn1.var, True)
     da1, sums1 = M.pool_dgrad(z1, bn1.scale, bn1.shift, True, w2, b2, w2T, coef2, True, gout, arg, zsel, k, below=below)
     da1h, sums1h = M.pool_dgrad(z1h, bn1.scale, bn1.shift, True, w2, b2, w2T, coef2, True, gout, arg, zsel, k, below=below, half=half)

@@ -192,6 +192,7 @@ _SIGS.update({
                                                                                        ctypes.c_void_p],
     "votenet_mlp_gram_half": [_L, _I, _c_f, _c_f, _I, _c_f, _c_f, _c_f, ctypes.c_void_p],
     "votenet_pool_wgrad_sparse_half": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [_I] + [_c_f] * 5 + [ctypes.c_void_p],
+    "votenet_pool_wgrad_sparse_half_centres": [_L, _I, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 4 + [_I] + [_c_f] * 5 + [ctypes.c_void_p],
     "votenet_assembled_wgrad_bn_half": [_L, _I, _I] + [_c_f] * 5 + [_I] + [_c_f] * 3 + [_I, _c_f, _c_f, _c_f, ctypes.c_void_p],
     "votenet_assembled_dgrad_bn_reduce_half": [_L, _I, _I] + [_c_f] * 3 + [_I] + [_c_f] * 9 + [_F, _I, ctypes.c_void_p,
                                                                                              ctypes.POINTER(CoefTail), _c_f, _c_f, ctypes.c_void_p],

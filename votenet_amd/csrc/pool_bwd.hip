@@ -676,6 +676,169 @@ __global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_kernel(long gro
     if (tid >= 256 - CIN) unsafeAtomicAdd(&colsum[tid - (256 - CIN)], csum);
 }
 
+// The piece-layout pass above walks PIECES: a channel counts in the one piece of its centre that holds its arg-max slot, so a centre of
+// kc pieces sends every wavefront through the 32-read / 128-multiply-add row loop kc times with 1 / kc of its lanes active (sa1, sa3,
+// sa4: 2.5-2.9 pieces per centre).  Here a group is a CENTRE (round 5): the tiles of all its kept pieces (piece 0 at compact rows
+// 16 c, piece j >= 1 at 16 (G + pos[3 c + j - 1]), half.hip) are staged together -- up to 4 x 16 rows, double-buffered -- and every
+// channel reads its arg-max row once: the row loop runs once per centre with every lane of a live channel active.  Same sums as the
+// piece pass in another association.  colsum: every row of every kept piece, the ball's slot 0 weighted by wh[c].
+template <int CIN, int TEAMS>
+__global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_centre_kernel(int G, long nh, int cout, const float *__restrict__ xz,
+                                                                       const float *__restrict__ in_scale, const float *__restrict__ in_shift,
+                                                                       int in_relu, const float *__restrict__ gout,
+                                                                       const int *__restrict__ argmax, const float *__restrict__ zsel,
+                                                                       const float *__restrict__ coef, int relu, float *__restrict__ dw,
+                                                                       float *__restrict__ colsum, const int *__restrict__ pos,
+                                                                       const float *__restrict__ wh, const int *__restrict__ nh_dev)
+{
+    constexpr int K = kPiece, NP = kBallPieces;
+    constexpr int LD = CIN + 4;
+    if (nh_dev != nullptr) nh = nh_dev[0] < nh ? nh_dev[0] : nh; // (uniform: every thread reads the same count)
+    extern __shared__ __attribute__((aligned(16))) float sparse_smem[]; // [TEAMS][2][NP][K][LD]; at the end [CIN + 1][cout] of team 1
+    const int team = TEAMS > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+    const int tid = threadIdx.x & 255; // inside the team
+    float(*xs)[NP][K][LD] = reinterpret_cast<float(*)[NP][K][LD]>(sparse_smem + (size_t)team * 2 * NP * K * LD);
+    float acc[CIN];
+#pragma unroll
+    for (int i = 0; i < CIN; i++) acc[i] = 0.0f;
+    float csum = 0.0f;
+    const bool own = tid < cout;
+    const float cA = own ? coef[tid] : 0.0f, cS = own ? coef[3 * cout + tid] : 0.0f, cH = own ? coef[4 * cout + tid] : 0.0f;
+    constexpr int Q = CIN / 4;
+    const int q = tid % Q;
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (in_scale) {
+        sc = *reinterpret_cast<const float4 *>(in_scale + q * 4);
+        sh = *reinterpret_cast<const float4 *>(in_shift + q * 4);
+    }
+    const float fl = (in_scale && in_relu) ? 0.0f : -__builtin_inff();
+    constexpr int NL = K * Q / 256; // float4 per thread per piece tile (2 at CIN = 128, 1 at CIN = 64)
+    constexpr int D = 2;            // centres in flight in registers (their tiles and their channels' gout / zsel / argmax)
+    float4 nxt[D][NP][NL];
+    long n_row[D][NP];              // first compact row of piece j of the staged centre, -1: not kept (uniform over the team)
+    float n_g[D], n_z[D], n_w[D];
+    int n_a[D];
+    auto fetch = [&](int d, long c) {
+        n_row[d][0] = c * K;
+#pragma unroll
+        for (int j = 1; j < NP; j++) {
+            const int p = pos[(size_t)c * (NP - 1) + j - 1];
+            n_row[d][j] = (p >= 0 && (long)G + p < nh) ? ((long)G + p) * K : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            if (n_row[d][j] < 0) continue; // (uniform over the team)
+            const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)n_row[d][j] * CIN);
+#pragma unroll
+            for (int h = 0; h < NL; h++) nxt[d][j][h] = src[tid + h * 256];
+        }
+        n_w[d] = wh[c];
+        n_z[d] = n_g[d] = 0.0f;
+        n_a[d] = 0;
+        if (own) {
+            n_z[d] = zsel[(size_t)c * cout + tid];
+            n_g[d] = gout[(size_t)c * cout + tid];
+            n_a[d] = argmax[(size_t)c * cout + tid];
+        }
+    };
+    const long first = (long)blockIdx.x * TEAMS + team, stride = (long)gridDim.x * TEAMS; // this team's centres: first, first + stride, ...
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        const long c = first + (long)d * stride;
+        fetch(d, c < G ? c : G - 1);
+    }
+    int buf = 0;
+    // every team of the workgroup runs the same number of rounds (the barriers are the workgroup's): a team past its last centre idles
+    for (long c0 = (long)blockIdx.x * TEAMS; c0 < G; c0 += (long)D * stride) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (c0 + (long)d * stride >= G) break; // (uniform over the workgroup: no team has a centre in this round)
+            const long c = c0 + team + (long)d * stride;
+            const bool live = c < G;
+            float(*xt)[K][LD] = xs[buf];
+            bool kept[NP];
+#pragma unroll
+            for (int j = 0; j < NP; j++) {
+                kept[j] = n_row[d][j] >= 0;
+                if (!kept[j]) continue;
+#pragma unroll
+                for (int h = 0; h < NL; h++) { // (tid + h*256) % Q == q: 256 % Q == 0
+                    float4 v = nxt[d][j][h];
+                    v.x = fmaxf(v.x * sc.x + sh.x, fl);
+                    v.y = fmaxf(v.y * sc.y + sh.y, fl);
+                    v.z = fmaxf(v.z * sc.z + sh.z, fl);
+                    v.w = fmaxf(v.w * sc.w + sh.w, fl);
+                    *reinterpret_cast<float4 *>(&xt[j][(tid + h * 256) / Q][q * 4]) = v;
+                }
+            }
+            float gg = live ? n_g[d] : 0.0f;
+            const float zz = n_z[d], w31 = n_w[d];
+            const int ar = n_a[d];
+            const long cn = c + (long)D * stride;
+            fetch(d, cn < G ? cn : (live ? c : G - 1)); // this stage's registers travel again while the tiles are used
+            __syncthreads();
+            if (own) {
+                if (relu && !(zz * cS + cH > 0.0f)) gg = 0.0f;
+                const float v = cA * gg;
+                const int pj = ar >> 4;
+                const bool there = pj == 0 ? kept[0] : pj == 1 ? kept[1] : pj == 2 ? kept[2] : kept[3]; // (an arg-max is a real neighbour: always)
+                if (v != 0.0f && there) {
+                    const float4 *row = reinterpret_cast<const float4 *>(&xt[pj][ar & (K - 1)][0]);
+                    // eight 16-byte LDS reads in flight, then their 32 multiply-adds
+#pragma unroll
+                    for (int i0 = 0; i0 < Q; i0 += 8) {
+                        float4 a[8];
+#pragma unroll
+                        for (int i = 0; i < 8; i++) a[i] = row[i0 + i];
+                        asm volatile("" ::: "memory");
+#pragma unroll
+                        for (int i = 0; i < 8; i++) {
+                            acc[4 * (i0 + i)] += a[i].x * v;
+                            acc[4 * (i0 + i) + 1] += a[i].y * v;
+                            acc[4 * (i0 + i) + 2] += a[i].z * v;
+                            acc[4 * (i0 + i) + 3] += a[i].w * v;
+                        }
+                    }
+                }
+            }
+            if (live && tid >= 256 - CIN) { // the column sums ride on the waves that own no (or the last) output columns
+                const int jc = tid - (256 - CIN);
+#pragma unroll
+                for (int j = 0; j < NP; j++) {
+                    if (!kept[j]) continue;
+#pragma unroll 8
+                    for (int r = (j == 0 ? 1 : 0); r < K; r++) csum += xt[j][r][jc];
+                }
+                csum += w31 * xt[0][0][jc]; // the ball's slot 0 also stands for its dropped copies
+            }
+            buf ^= 1; // the other buffer was last read before this centre's barrier: the next centre may overwrite it
+        }
+    }
+    if (TEAMS > 1) { // team 1 hands its sums to team 0 through LDS (the tiles are dead), team 0 flushes
+        __syncthreads();
+        float *comb = sparse_smem; // [CIN + 1][cout]
+        if (team == 1) {
+            if (own) {
+#pragma unroll
+                for (int i = 0; i < CIN; i++) comb[(size_t)i * cout + tid] = acc[i];
+            }
+            if (tid >= 256 - CIN) comb[(size_t)CIN * cout + tid - (256 - CIN)] = csum;
+        }
+        __syncthreads();
+        if (team == 1) return;
+        if (own) {
+#pragma unroll
+            for (int i = 0; i < CIN; i++) acc[i] += comb[(size_t)i * cout + tid];
+        }
+        if (tid >= 256 - CIN) csum += comb[(size_t)CIN * cout + tid - (256 - CIN)];
+    }
+    if (own) {
+#pragma unroll
+        for (int i = 0; i < CIN; i++) unsafeAtomicAdd(&dw[(size_t)i * cout + tid], acc[i]);
+    }
+    if (tid >= 256 - CIN) unsafeAtomicAdd(&colsum[tid - (256 - CIN)], csum);
+}
+
 // dW[j,c] += C[c] * (gram[j,:] . W[:,c]) + colsum[j] * (B[c] + C[c] b[c])
 __global__ __launch_bounds__(256) void pool_wgrad_finish_kernel(int cin, int cout, const float *__restrict__ gram,
                                                                 const float *__restrict__ colsum, const float *__restrict__ w,
@@ -1128,6 +1291,44 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
                "pool_wgrad_sparse_half: operands must be 16-byte aligned");
     return pool_wgrad_sparse_launch(nh, cin, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw, colsum, nullptr, hc, wh,
                                     G, stream, nh_dev);
+}
+
+static int g_sparse_centre_wgs = 192; // votenet_debug_sparse_centre_workgroups (tuning hook)
+extern "C" void votenet_debug_sparse_centre_workgroups(int n) { g_sparse_centre_wgs = n > 0 ? n : 192; }
+// votenet_pool_wgrad_sparse_half walking CENTRES instead of pieces (pool_wgrad_sparse_centre_kernel): pos = the layout's (G, 3) table of
+// the pieces j >= 1 of every centre (votenet_half_groups), wh[0:G] the weights of the balls' slot 0.  Same results up to the association
+// of the sums.
+extern "C" int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, int cout, const float *xz, const float *in_scale,
+                                                      const float *in_shift, int in_relu, const float *gout, const int *argmax,
+                                                      const float *zsel, const float *coef, int relu, float *dw, float *colsum,
+                                                      const int *pos, const float *wh, const int *nh_dev, void *stream)
+{
+    VN_REQUIRE(nh > 0 && G > 0 && nh >= G && nh <= (long)kBallPieces * G && pos && wh, "pool_wgrad_sparse_half_centres: bad piece-layout arguments");
+    VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half_centres: bad arguments");
+    VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_wgrad_sparse_half_centres: unsupported shape cin=%d cout=%d", cin, cout);
+    VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse_half_centres: in_scale and in_shift go together");
+    VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
+               "pool_wgrad_sparse_half_centres: operands must be 16-byte aligned");
+    hipStream_t st = as_stream(stream);
+    auto go = [&](auto kern, int ci) {
+        const size_t tiles = (size_t)2 * 2 * kBallPieces * kPiece * (ci + 4) * 4;
+        const size_t comb = (size_t)(ci + 1) * cout * 4;
+        const size_t smem = tiles > comb ? tiles : comb;
+        static std::set<const void *> raised_c;
+        static std::mutex raised_c_mu;
+        bool fresh;
+        {
+            std::lock_guard<std::mutex> lock(raised_c_mu);
+            fresh = raised_c.insert(reinterpret_cast<const void *>(kern)).second;
+        }
+        if (fresh) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        const int grid = pb_grid(G, 8 * 2, g_sparse_centre_wgs);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, G, nh, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw,
+                           colsum, pos, wh, nh_dev);
+    };
+    if (cin == 64) go(pool_wgrad_sparse_centre_kernel<64, 2>, 64);
+    else go(pool_wgrad_sparse_centre_kernel<128, 2>, 128);
+    return check_launch("pool_wgrad_sparse_half_centres");
 }
 
 static int pool_wgrad_sparse_launch(long groups, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift, int in_relu,

@@ -1186,10 +1186,22 @@ def gram(xz, scale_shift, relu, half=None):
     return g
 
 
+POOL_WGRAD_CENTRES = True  # piece layout: the arg-max gather of a pooled layer's weight gradient walks centres (all kept pieces of a ball staged together), not pieces
+
+
 def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, gout, argmax, zsel, k, dw, half=None):
     """dw += x^T dz of the pooled layer from the Gram matrix (gram()), the gathered arg-max rows and the column sums."""
     rows, cin = xz.shape
     cout = w.shape[1]
+    if half is not None and POOL_WGRAD_CENTRES:
+        with L.device_guard(xz.device):
+            L.check(L.lib().votenet_pool_wgrad_sparse_half_centres(half.nh, half.G, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift),
+                                                                   1 if in_relu else 0, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
+                                                                   1 if relu else 0, L.ptr(dw), L.ptr(gram_buf[cin]), L.ptr(half.pos), L.ptr(half.wh),
+                                                                   L.ptr(half.nh_limit), L.stream_ptr()))
+            L.check(L.lib().votenet_pool_wgrad_finish(cin, cout, L.ptr(gram_buf), L.ptr(gram_buf[cin]), L.ptr(w), L.ptr(bias), L.ptr(coef),
+                                                      L.ptr(dw), L.stream_ptr()))
+        return
     if half is not None:
         with L.device_guard(xz.device):
             L.check(L.lib().votenet_pool_wgrad_sparse_half(half.nh, half.G, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift),

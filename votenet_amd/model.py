@@ -63,6 +63,7 @@ class GeometryGraph:
         return self.g, {name: done for name in ("sa1", "sa2", "sa3", "sa4", "fp")}
 
 
+GRAM_EARLY = ()          # levels whose Gram matrix is launched at the start of the levels' backward pass (see _grams_early): measured below
 GRAMS_AHEAD = False      # train_step launches the Gram matrices of the levels' pooled layers (forward data only) on the weight-gradient stream under the stretch instead of beside the levels' backward GEMMs.  Measured (tools/probe/variant_step.py, three alternations): 3.78-3.81 -> 3.86-3.89 ms -- the stretch is a chain of tiny latency-bound kernels ON the critical path, and 0.27 ms of GPU-filling kernels beside it cost it more than they save the backward pass.  Off.
 STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as HIP graph segments (StretchGraph)
 STRETCH_SEGMENTS = True  # the stretch's input-gradient chain cut into graphs at the modules' ends, the weight gradients launched between them (False: two graphs around the loss, weight gradients inline)
@@ -724,6 +725,7 @@ class VoteNetHotPath:
     def _levels_backward(self, levels, d_l2p, d_l3p, d_l4p):
         """The backward pass of the four levels, sa4 ... sa1 (xyz carries no gradient in the backbone: the cloud is the input)."""
         sa1, sa2, sa3, sa4 = levels
+        self._grams_early(dict(sa1=sa1, sa2=sa2, sa3=sa3, sa4=sa4))
         g3, _ = self.sa4.backward(sa4, d_l4p)
         P.wgrad_flush()
         d_l3p = P.add_rows(d_l3p, g3)
@@ -848,6 +850,25 @@ class VoteNetHotPath:
         self._ema_version += 1  # (the replay ran votenet_ema_update: inference_bn() must not serve a table built before it)
         self._backward_levels_pass(tape, grads)
         return out
+
+    def _grams_early(self, levels):
+        """GRAM_EARLY: the Gram matrices of the named levels (forward data only) go to the weight-gradient stream at the START of the
+        levels' backward pass instead of beside their own level's backward GEMMs.  The step's tail is sa1's backward, where the chain
+        (arg-max scatter, dense input gradient, narrow input gradient: 0.31 ms alone) and the weight-gradient stream (Gram matrix, sparse
+        gather, narrow weight gradient: 0.28 ms alone) run beside each other at 0.45 ms: sa1's matrix ahead takes a third of that
+        stream's tail away and runs beside sa4's / sa3's smaller kernels instead."""
+        if not GRAM_EARLY or M.DETERMINISTIC or P.WGRAD_STREAM is None:
+            return
+        todo = [levels[n]["recs"][-1] for n in GRAM_EARLY if n in levels]
+        todo = [r for r in todo if r.get("gram_form") and r.get("in_affine") is not None and "gram_ahead" not in r]
+        if not todo:
+            return
+
+        def run():
+            for r in todo:
+                r["gram_ahead"] = M.gram(r["x"], r["in_affine"][:2], r["in_relu"], half=r.get("half"))
+        P.on_wgrad_stream(run, *[r["x"] for r in todo])
+        P.wgrad_flush()
 
     def _grams_ahead(self, tape):
         """The Gram matrix a^T a of a pooled layer's input (pool_bwd.hip) depends on forward data only.  Launched here -- behind the
