@@ -62,10 +62,10 @@ const char *votenet_version(void);
  * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
 int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
 /* Experiment hook (not part of the drop-in surface): route 4096 < n <= 24576 through the kernel that emits up to two samples
- * per round (same indices, same order).  Off by default: measured slower than the one-sample rounds. */
+ * per round (same indices, same order; DESIGN_HISTORY.md 4.1).  Off by default: measured slower than the one-sample rounds. */
 void votenet_fps_debug_two_pick(int on);
 /* Measurement hook: 0 disables the parallel "already in farthest-point order?" check that precedes the sampling rounds for
- * n <= 2048; the result is the same either way. */
+ * n <= 2048 (DESIGN_HISTORY.md 4.1); the result is the same either way. */
 void votenet_fps_debug_prefix_check(int on);
 size_t votenet_fps_temp_floats(int b, int n);
 
@@ -531,7 +531,7 @@ void votenet_debug_assemble_stats(int cap, int u); /* tuning hook: assemble_stat
 /* every other weight-gradient GEMM (votenet_mlp_wgrad / _wgrad_bn, assembled, narrow) on split operands: row-major bf16 images in LDS,
  * fragments through ds_read_b64_tr_b16 (mlp_wgrad_fast.hip); 0: the fp32 MFMA kernel.  Default 1. */
 void votenet_debug_wgrad_bf3(int on);
-/* measurement hook: votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
+/* measurement hook (DESIGN_HISTORY.md 4.3): votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
 void votenet_debug_scatter_reverse(int on);
 void votenet_debug_sparse_workgroups(int n); /* tuning hook: workgroups of votenet_pool_wgrad_sparse (default 384) */
 void votenet_debug_sparse_teams(int teams, int wgs); /* tuning hook: 1 or 2 (default) teams per workgroup on the piece layout; workgroups of the 2-team form (default 256) */

@@ -36,7 +36,7 @@ void oracle_query_ball_point(int b, int n, int m, float radius, int nsample,
                 float d = s > 1e-20f ? s : 1e-20f;
                 /* NOT a restatement: CUDA's max(NaN, 1e-20f) is 1e-20f, so a point (or centre) with a NaN coordinate is a "hit"
                  * of every pair in the reference -- an artefact of fmaxf.  The build defines a non-finite distance as no hit
-                 * (the device kernels decide s < T(r), false for NaN); finite clouds are untouched. */
+                 * (the device kernels decide s < T(r), false for NaN; DESIGN_HISTORY.md 2); finite clouds are untouched. */
                 if (s != s) continue;
                 if (d < radius) {
                     if (cnt == 0)

@@ -26,7 +26,7 @@
 /*
  * Non-finite coordinates.  NOT a restatement: with a NaN point the CUDA kernel's fminf / '>' leave it at its initial distance
  * 1e38, pick it at once and, with a NaN centre, freeze every running distance -- an artefact, not a behaviour anyone relies on.
- * The build DEFINES the case (csrc/fps.hip fps_get): a point with a non-finite coordinate is read as a copy of
+ * The build DEFINES the case (DESIGN_HISTORY.md 2 "Non-finite coordinates", csrc/fps.hip fps_get): a point with a non-finite coordinate is read as a copy of
  * point 0 (so it is never sampled), point 0's own non-finite components are read as 0.  Finite clouds are untouched.
  * -> a sanitized copy of the batch, or NULL when every coordinate is finite.
  */

@@ -248,9 +248,12 @@ def test_model_with_and_without_the_half_group_layout(hiplib, dev):
     assert len(r1) == len(r0)
 
 
-@pytest.mark.parametrize("b,n,m,c,radius", [(2, 700, 64, 3, 0.5), (1, 500, 48, 0, 0.45)])
-def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_form, b, n, m, c, radius):
-    """sa1's form (csrc/narrow.hip: z0 rebuilt from eight floats per row) on the compact rows."""
+@pytest.mark.parametrize("b,n,m,c,radius,b0_shift", [(2, 700, 64, 3, 0.5, 0.0), (1, 500, 48, 0, 0.45, 0.0), (2, 700, 64, 3, 0.5, 40.0)])
+def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev, gemm_form, b, n, m, c, radius, b0_shift):
+    """sa1's form (csrc/narrow.hip: z0 rebuilt from eight floats per row) on the compact rows.  b0_shift = 40: a first-layer bias that
+    puts |mean| / std of z0 at ~50 (the masked input-gradient tail derives sum g zhat as a DIFFERENCE of two sums of that
+    size, (sum_d W0 UG + b0 s1) - mean s1; it does so in double on double totals, so the bias cancels to the last bit of its fp32
+    value and what remains is the accuracy of the fp32 per-lane partials of UG and s1 -- the same as the round-3 epilogue's)."""
     from votenet_amd import mlp as M
     from votenet_amd import tf_grouping, tf_sampling
     k, c0, c1 = 64, 64, 64
@@ -262,7 +265,7 @@ def test_narrow_stage_kernels_on_compact_rows_match_the_full_layout(hiplib, dev,
     idx, cnt = tf_grouping.query_ball_point(radius, k, xyz, new_xyz)
     assert bool((cnt <= 31).any()) and bool((cnt > 31).any()), cnt.flatten().tolist()
     rows, k0 = b * m * k, 3 + c
-    w0, b0, w1 = rnd(k0, c0) * 0.5, rnd(c0) * 0.1, rnd(c0, c1) * 0.2
+    w0, b0, w1 = rnd(k0, c0) * 0.5, rnd(c0) * 0.1 + b0_shift, rnd(c0, c1) * 0.2
     w1T = w1.t().contiguous()
     img = M.SplitImages([w1, w1T])
     img.refresh()

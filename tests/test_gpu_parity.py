@@ -63,7 +63,7 @@ def test_fps_exact_ties_vs_oracle(ops, dev, O):
 
 def test_fps_two_samples_per_round_experiment_is_the_same_sequence(ops, dev, O, hiplib):
     """fps_bucket2_kernel (votenet_fps_debug_two_pick): up to two picks per round when the runner-up is provably the next
-    arg-max.  Off by default (slower); the indices must be the oracle's, duplicates and exact ties included."""
+    arg-max.  Off by default (slower, DESIGN_HISTORY.md 4.1); the indices must be the oracle's, duplicates and exact ties included."""
     from votenet_amd import synth
     hiplib.votenet_fps_debug_two_pick.restype = None
     hiplib.votenet_fps_debug_two_pick(1)

@@ -205,7 +205,7 @@ def test_whole_geometry_chain_of_a_backbone_pass_is_the_reference_kernels(ops, d
 
 
 def test_non_finite_points_where_the_product_deliberately_leaves_the_reference(ops, dev, R):
-    """DESIGN.md section 2, "Non-finite coordinates": what the reference kernels do with a NaN point is an artefact of fminf / max / '>'
+    """DESIGN_HISTORY.md section 2, "Non-finite coordinates": what the reference kernels do with a NaN point is an artefact of fminf / max / '>'
     (tf_sampling_g.cu:142-146, tf_grouping_g.cu:24-25) -- shown here on the kernels themselves -- and the product DEFINES the case
     instead (a hole is never sampled and never a neighbour).  On finite clouds the two agree everywhere (every other test of this file).
     Also the canary that the "reference" of this file IS the reference: the product exports the same launcher names (the drop-in seam),

@@ -1349,7 +1349,7 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
     } else if (n <= kFpsBucketMax) {
         const SpatialIndex sidx = spatial_index_view(temp, b, n);
         if (build_spatial_index(b, n, inp, temp, st) != VOTENET_OK) return VOTENET_E_HIP;
-        const bool single = !g_fps_two_pick; // measured: the two-pick rounds are 1.9x as long as the plain ones
+        const bool single = !g_fps_two_pick; // measured: the two-pick rounds are 1.9x as long as the plain ones (DESIGN_HISTORY.md 4.1)
         if (n <= 16 * 16 * 64) {
             if (single) FPS_BUCKET_LAUNCH(16, 16); // 16 waves x 16 slots
             else FPS_BUCKET2_LAUNCH(16, 16);

@@ -1293,8 +1293,9 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
                                     G, stream, nh_dev);
 }
 
-static int g_sparse_centre_wgs = 192; // votenet_debug_sparse_centre_workgroups (tuning hook)
+static int g_sparse_centre_wgs = 192, g_sparse_centre_teams = 2; // votenet_debug_sparse_centre_workgroups (tuning hook)
 extern "C" void votenet_debug_sparse_centre_workgroups(int n) { g_sparse_centre_wgs = n > 0 ? n : 192; }
+extern "C" void votenet_debug_sparse_centre_teams(int t) { g_sparse_centre_teams = t == 1 ? 1 : 2; }
 // votenet_pool_wgrad_sparse_half walking CENTRES instead of pieces (pool_wgrad_sparse_centre_kernel): pos = the layout's (G, 3) table of
 // the pieces j >= 1 of every centre (votenet_half_groups), wh[0:G] the weights of the balls' slot 0.  Same results up to the association
 // of the sums.
@@ -1310,9 +1311,10 @@ extern "C" int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, i
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse_half_centres: operands must be 16-byte aligned");
     hipStream_t st = as_stream(stream);
+    const int teams = g_sparse_centre_teams;
     auto go = [&](auto kern, int ci) {
-        const size_t tiles = (size_t)2 * 2 * kBallPieces * kPiece * (ci + 4) * 4;
-        const size_t comb = (size_t)(ci + 1) * cout * 4;
+        const size_t tiles = (size_t)teams * 2 * kBallPieces * kPiece * (ci + 4) * 4;
+        const size_t comb = teams > 1 ? (size_t)(ci + 1) * cout * 4 : 0;
         const size_t smem = tiles > comb ? tiles : comb;
         static std::set<const void *> raised_c;
         static std::mutex raised_c_mu;
@@ -1322,11 +1324,14 @@ extern "C" int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, i
             fresh = raised_c.insert(reinterpret_cast<const void *>(kern)).second;
         }
         if (fresh) (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        const int grid = pb_grid(G, 8 * 2, g_sparse_centre_wgs);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(512), smem, st, G, nh, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw,
+        const int grid = pb_grid(G, 8 * teams, g_sparse_centre_wgs * 2 / teams);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256 * teams), smem, st, G, nh, cout, xz, in_scale, in_shift, in_relu, gout, argmax, zsel, coef, relu, dw,
                            colsum, pos, wh, nh_dev);
     };
-    if (cin == 64) go(pool_wgrad_sparse_centre_kernel<64, 2>, 64);
+    if (teams == 1) {
+        if (cin == 64) go(pool_wgrad_sparse_centre_kernel<64, 1>, 64);
+        else go(pool_wgrad_sparse_centre_kernel<128, 1>, 128);
+    } else if (cin == 64) go(pool_wgrad_sparse_centre_kernel<64, 2>, 64);
     else go(pool_wgrad_sparse_centre_kernel<128, 2>, 128);
     return check_launch("pool_wgrad_sparse_half_centres");
 }

@@ -1,6 +1,6 @@
 """Where the host thread of a rank runs.  A train step is ~160 launches of 10-20 us each: the Python thread, the HIP runtime's helper
 threads and the driver share cache lines all the time, and the step is as fast as the host can enqueue it on its small-kernel stretch
-(DESIGN.md 5).  Left to the scheduler on a 2 x 64-core host the enqueue of a step takes 3.1 ms; confined to eight cores of the GPU's NUMA
+(DESIGN_HISTORY.md 5).  Left to the scheduler on a 2 x 64-core host the enqueue of a step takes 3.1 ms; confined to eight cores of the GPU's NUMA
 node 2.75 ms (four cores: 3.15, one: 3.5 -- the helper threads need room; the other socket: 3.1; tools/cpu_issue_time.py under taskset).
 
 No torch, no HIP: this runs before anything touches the GPU (threads created later inherit the mask).  `from votenet_amd import hostpin`
