@@ -340,15 +340,21 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
     constexpr int NJ = COUT / 64; // channels per lane
     constexpr int RB = 4;         // rows per prefetch batch (two batches in flight; 128 VGPRs per wavefront)
     constexpr int NB = K / RB;    // batches per group (even: batch 0 of every group lives in register set 0)
-    constexpr int WS = COUT * 6 + K * 4; // bytes of a wavefront's scratch: values, channels (16 bit), counters
+    // a wavefront's scratch: the rows' lists of (value, channel), every row's list PADDED to a multiple of four entries with (0, channel 0)
+    // -- the row loop then reads four entries with one 16-byte and one 8-byte LDS read and has no tail predicate (round 5: the loop over
+    // single entries with its per-entry bounds branches was ~10 vector + 8 scalar instructions per entry: the pass was issue-bound) --
+    // and the K counters
+    constexpr int LCAP = COUT + 3 * K;   // entries incl. padding (at most three per row)
+    constexpr int WS = LCAP * 6 + K * 4; // bytes: values (fp32), channels (16 bit), counters
+    static_assert(WS % 16 == 0 && (LCAP * 4) % 16 == 0, "the value lists are read 16 bytes at a time");
     extern __shared__ __attribute__((aligned(16))) float pds_smem[];
     float *Wl = pds_smem; // [COUT][CIN]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     unsigned char *scratch = reinterpret_cast<unsigned char *>(Wl + COUT * CIN) + (size_t)wv * WS;
-    float *lv = reinterpret_cast<float *>(scratch);                             // [COUT] A g' of the listed channels, row by row
-    unsigned short *lc = reinterpret_cast<unsigned short *>(scratch + COUT * 4); // [COUT] their channel numbers
-    int *cnt = reinterpret_cast<int *>(scratch + COUT * 6);                     // [K]
+    float *lv = reinterpret_cast<float *>(scratch);                             // [LCAP] A g' of the listed channels, row by row
+    unsigned short *lc = reinterpret_cast<unsigned short *>(scratch + LCAP * 4); // [LCAP] their channel numbers
+    int *cnt = reinterpret_cast<int *>(scratch + LCAP * 6);                     // [K]
     for (int e = tid; e < COUT * CIN / 4; e += NWV * 64) reinterpret_cast<float4 *>(Wl)[e] = reinterpret_cast<const float4 *>(wT)[e];
     if (lane < K) cnt[lane] = 0;
     float cA[NJ], cS[NJ], cH[NJ];
@@ -427,14 +433,21 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
         for (int j = 0; j < NJ; j++) pos[j] = row[j] >= 0 ? atomicAdd(&cnt[row[j]], 1) : 0;
         const int c0 = lane < K ? cnt[lane] : 0;
-        int x = c0; // exclusive prefix of the K counters: one lane per row
+        const int c4 = (c0 + 3) & ~3; // the row's list, padded
+        int x = c4; // exclusive prefix of the K padded counts: one lane per row
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int t = __shfl_up(x, off);
             if (lane >= off) x += t;
         }
-        const int start = x - c0;
-        if (lane < K) cnt[lane] = 0; // ready for the next group
+        const int start = x - c4;
+        if (lane < K) {
+            cnt[lane] = 0; // ready for the next group
+            for (int t = c0; t < c4; t++) { // the padding: nothing times W^T row 0
+                lc[start + t] = 0;
+                lv[start + t] = 0.0f;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < NJ; j++) {
             const int st = __shfl(start, row[j] >= 0 ? row[j] : 0);
@@ -447,24 +460,32 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
             for (int u = 0; u < RB; u++) {
                 const int rr = rb * RB + u;
-                const int n = __builtin_amdgcn_readlane(c0, rr), s0 = __builtin_amdgcn_readlane(start, rr);
+                const int n = __builtin_amdgcn_readlane(c4, rr), s0 = __builtin_amdgcn_readlane(start, rr);
                 const bool scaled = HALF && rr == 0 && w31 != 1.0f; // the ball's slot 0 also stands for its dropped copies
                 float acc[PL];
 #pragma unroll
                 for (int q = 0; q < PL; q++) acc[q] = scaled ? r.d[u][q] * w31 : r.d[u][q];
-                for (int i = 0; i < n; i += 4) {
-                    int c[4];
-                    float vv[4];
+                for (int i = 0; i < n; i += 4) { // four entries per trip: their channels in 8 bytes, their values in 16 (all lanes read the same words)
+                    const uint2 c4w = *reinterpret_cast<const uint2 *>(&lc[s0 + i]);
+                    const float4 v4 = *reinterpret_cast<const float4 *>(&lv[s0 + i]);
+                    const unsigned cc[4] = {c4w.x & 0xffffu, c4w.x >> 16, c4w.y & 0xffffu, c4w.y >> 16};
+                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+                    if constexpr (PL == 2) {
+                        f32x2 wr[4];
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const bool ok = i + t < n;
-                        c[t] = lc[s0 + (ok ? i + t : i)];
-                        vv[t] = ok ? lv[s0 + i + t] : 0.0f;
+                        for (int t = 0; t < 4; t++) wr[t] = *reinterpret_cast<const f32x2 *>(&Wl[cc[t] * CIN + lane * PL]);
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const f32x2 a2 = __builtin_elementwise_fma(wr[t], f32x2{vv[t], vv[t]}, f32x2{acc[0], acc[1]});
+                            acc[0] = a2.x;
+                            acc[1] = a2.y;
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; t++)
+#pragma unroll
+                            for (int q = 0; q < PL; q++) acc[q] = __builtin_fmaf(vv[t], Wl[cc[t] * CIN + lane * PL + q], acc[q]);
                     }
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-#pragma unroll
-                        for (int q = 0; q < PL; q++) acc[q] += vv[t] * Wl[c[t] * CIN + lane * PL + q];
                 }
                 if (n != 0 || scaled) {
                     float *drow = da + ((size_t)g * K + rr) * CIN + lane * PL;
@@ -995,7 +1016,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
     };
     // one wavefront per group (the default)
     auto gow = [&](auto kern, int ci, int co, int kk, int nwv) {
-        const size_t smem = (size_t)co * ci * 4 + (size_t)nwv * (co * 6 + kk * 4);
+        const size_t smem = (size_t)co * ci * 4 + (size_t)nwv * ((co + 3 * kk) * 6 + kk * 4);
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         static std::set<const void *> raised_w;
         static std::mutex raised_w_mu;
@@ -1021,7 +1042,7 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
             else VN_SCATTER_WAVE(128, 128, kPiece, 8);
         } else {
             if (cin == 64) VN_SCATTER_WAVE(64, 128, 64, 8);
-            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 64, 16);
+            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 64, 8); // (8 wavefronts: the padded lists of 64-row groups + the 128 KB of W^T)
             else VN_SCATTER_WAVE(128, 128, 64, 8);
         }
 #undef VN_SCATTER_WAVE
