@@ -9,6 +9,8 @@ _s = _iu.spec_from_file_location("hp", os.path.join(R, "votenet_amd", "hostpin.p
 import torch
 from votenet_amd import loss as VL, model as VM, synth
 from votenet_amd import _lib as L_
+if os.environ.get("VARIANT"):  # a library variant under tools/probe/lib (same-box A/B of kernel alone-times)
+    L_._LIB_PATH = os.path.join(R, "tools", "probe", "lib", "libvotenet_%s.so" % os.environ["VARIANT"])
 for h in os.environ.get("HOOKS", "").split():  # e.g. HOOKS="votenet_debug_bn_reduce_passes=16"
     name, val = h.split("=")
     getattr(L_.lib(), name)(*[int(v) for v in val.split(",")])

@@ -739,6 +739,12 @@ __global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_centre_kernel(i
     long n_row[D][NP];              // first compact row of piece j of the staged centre, -1: not kept (uniform over the team)
     float n_g[D], n_z[D], n_w[D];
     int n_a[D];
+    // No load under a branch: a conditional load makes the compiler wait for vmcnt(0) at the next use of ANY loaded value, which
+    // turned the two-centre prefetch into one full memory round trip per centre (25 such waits in the loop's code).  The tiles of
+    // pieces a ball did not keep are "loaded" through a buffer descriptor at an offset past its end: such a read returns zeros and
+    // moves no data; the channels beyond cout read channel 0 of the centre and ignore it.
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void *)xz, 0, (int)((size_t)nh * K * CIN * 4), 0x00020000);
+    const int ch = own ? tid : 0;
     auto fetch = [&](int d, long c) {
         n_row[d][0] = c * K;
 #pragma unroll
@@ -748,19 +754,17 @@ __global__ __launch_bounds__(256 * TEAMS) void pool_wgrad_sparse_centre_kernel(i
         }
 #pragma unroll
         for (int j = 0; j < NP; j++) {
-            if (n_row[d][j] < 0) continue; // (uniform over the team)
-            const float4 *src = reinterpret_cast<const float4 *>(xz + (size_t)n_row[d][j] * CIN);
+            // (the whole offset in the lane offset: that is what the descriptor's range check sees)
+            const unsigned base = n_row[d][j] < 0 ? 0x80000000u : (unsigned)(n_row[d][j] * CIN * 4);
 #pragma unroll
-            for (int h = 0; h < NL; h++) nxt[d][j][h] = src[tid + h * 256];
+            for (int h = 0; h < NL; h++)
+                nxt[d][j][h] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, base + (unsigned)(tid + h * 256) * 16u, 0, 0));
         }
         n_w[d] = wh[c];
-        n_z[d] = n_g[d] = 0.0f;
-        n_a[d] = 0;
-        if (own) {
-            n_z[d] = zsel[(size_t)c * cout + tid];
-            n_g[d] = gout[(size_t)c * cout + tid];
-            n_a[d] = argmax[(size_t)c * cout + tid];
-        }
+        n_z[d] = zsel[(size_t)c * cout + ch];
+        const float gv = gout[(size_t)c * cout + ch];
+        n_g[d] = own ? gv : 0.0f;
+        n_a[d] = argmax[(size_t)c * cout + ch];
     };
     const long first = (long)blockIdx.x * TEAMS + team, stride = (long)gridDim.x * TEAMS; // this team's centres: first, first + stride, ...
 #pragma unroll
