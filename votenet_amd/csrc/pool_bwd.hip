@@ -329,7 +329,7 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
 // time, one batch ahead, across groups -- adding the W^T rows of each row's channels.  Channels whose masked gradient is zero are not
 // listed at all.
 template <int CIN, int COUT, int K, bool RED, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) void pool_dgrad_scatter_wave_kernel(long groups, const float *__restrict__ gout,
+__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 12 ? 3 : 4))) void pool_dgrad_scatter_wave_kernel(long groups, const float *__restrict__ gout,
                                                                            const int *__restrict__ argmax, const float *__restrict__ zsel,
                                                                            const float *__restrict__ coef, int relu,
                                                                            const float *__restrict__ wT, float *__restrict__ da, PoolBelow pb)
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
             v[j] = cA[j] * gg;
             row[j] = v[j] != 0.0f ? na[j] : -1; // nothing to add: not listed
         }
-        if (gn < groups) fetch(gn);
+        fetch(gn < groups ? gn : g); // (never a load under a branch: past the last group its own records are read again, unused)
 #pragma unroll
         for (int j = 0; j < NJ; j++) pos[j] = row[j] >= 0 ? atomicAdd(&cnt[row[j]], 1) : 0;
         const int c0 = lane < K ? cnt[lane] : 0;
@@ -507,8 +507,8 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) v
         for (int rb = 0; rb < NB; rb += 2) {
             load_rows(R1, g, rb + 1);
             batch(R0, rb);
-            if (rb + 2 < NB) load_rows(R0, g, rb + 2);
-            else if (gn < groups) load_rows(R0, gn, 0);
+            const bool more = rb + 2 < NB;
+            load_rows(R0, more ? g : (gn < groups ? gn : g), more ? rb + 2 : 0); // (the next group's first rows; at the very end: unused)
             batch(R1, rb + 1);
         }
     }
@@ -951,6 +951,8 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
 
 static int g_scatter_reverse = 0;
 extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
+static int g_scatter_nwv = 16; // votenet_debug_scatter_waves (tuning hook): wavefronts per workgroup of the 128 -> 256 piece-layout scatter (12 or 16)
+extern "C" void votenet_debug_scatter_waves(int n) { g_scatter_nwv = n == 12 ? 12 : 16; }
 static int g_scatter_wgs = 0; // votenet_debug_scatter_workgroups (tuning hook): 0 = one workgroup per CU and LDS share
 extern "C" void votenet_debug_scatter_workgroups(int n) { g_scatter_wgs = n > 0 ? n : 0; }
 static int g_scatter_form = 1; // 1: one wavefront per group (pool_dgrad_scatter_wave_kernel), 0: one workgroup per group
@@ -1042,7 +1044,13 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
     } while (0)
         if (hc) {
             if (cin == 64) VN_SCATTER_WAVE(64, 128, kPiece, 8);
-            else if (cout == 256) VN_SCATTER_WAVE(128, 256, kPiece, 16);
+            else if (cout == 256) {
+                // (round 5: with 16 wavefronts the kernel is held to 128 VGPRs; it spilled 19 of them -- a reload inside the group loop is a
+                // scratch load with an s_waitcnt vmcnt(0) behind it -- until the prefetch loads lost their branches (1 spill now).  12
+                // wavefronts, 132 VGPRs, no spill: measured equal, hook kept)
+                if (g_scatter_nwv == 12) VN_SCATTER_WAVE(128, 256, kPiece, 12);
+                else VN_SCATTER_WAVE(128, 256, kPiece, 16);
+            }
             else VN_SCATTER_WAVE(128, 128, kPiece, 8);
         } else {
             if (cin == 64) VN_SCATTER_WAVE(64, 128, 64, 8);
