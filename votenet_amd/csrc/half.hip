@@ -276,18 +276,30 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
             h = shift[ch];
         }
         const float sg = s >= 0.0f ? 1.0f : -1.0f;
-        float best = sg * zbest[e];
-        int ibest = abest[e];
+        // no load under a branch (round 5): the three piece slots, then all candidates together -- a piece the ball did not keep reads the
+        // ball's first piece again and is ignored.  (With the loads under `if (p >= 0)` the compiler put an s_waitcnt vmcnt(0) behind each:
+        // up to four dependent memory round trips per element on a kernel that sits on the forward chain of every level.)
+        int pj[NP - 1];
+#pragma unroll
+        for (int j = 1; j < NP; j++) pj[j - 1] = pos[g * (NP - 1) + j - 1];
+        float zb[NP];
+        int ab[NP];
+        zb[0] = zbest[e];
+        ab[0] = abest[e];
 #pragma unroll
         for (int j = 1; j < NP; j++) {
-            const int p = pos[g * (NP - 1) + j - 1];
-            if (p >= 0) {
-                const size_t e2 = (size_t)(G + p) * c + ch;
-                const float b = sg * zbest[e2];
-                if (b > best) {
-                    best = b;
-                    ibest = j * PS + abest[e2];
-                }
+            const size_t e2 = pj[j - 1] >= 0 ? (size_t)(G + pj[j - 1]) * c + ch : (size_t)e;
+            zb[j] = zbest[e2];
+            ab[j] = abest[e2];
+        }
+        float best = sg * zb[0];
+        int ibest = ab[0];
+#pragma unroll
+        for (int j = 1; j < NP; j++) {
+            const float b = sg * zb[j];
+            if (pj[j - 1] >= 0 && b > best) {
+                best = b;
+                ibest = j * PS + ab[j];
             }
         }
         const float zr = sg * best;
