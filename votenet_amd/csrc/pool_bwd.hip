@@ -1122,6 +1122,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     static_assert(kPiece == 16, "one slab = one piece");
     const bool first_rg = rg == 0;
     const float *whb = wh ? wh + r_begin / kPiece : nullptr;
+    const float *whp = whb ? whb : scale_shift; // (a valid address either way: no load under a branch)
     float Wq[2] = {1.0f, 1.0f}; // sqrt of that row's weight, travelling with the register set
     bool abl_prologue = true;
     auto load = [&](float (&r)[KPT], int s, float &wq) {
@@ -1132,8 +1133,11 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             lr = lr < nrow ? lr : nrow - 1; // past the end: a valid row, stored as zero below
             r[i] = xb[(size_t)lr * C];
         }
-        if (whb && first_rg) wq = s * 16 < nrow ? sqrtf(whb[s]) : 1.0f;
-        else wq = 1.0f;
+        // the piece's weight travels RAW with the register set and every thread loads it (round 5): under `if (whb && first_rg)` with the
+        // square root right behind it this was a conditional load followed by s_waitcnt vmcnt(0) -- it drained the eight row loads just
+        // issued, once per 16-row slab: the kernel ran at one exposed memory latency per slab
+        const int sw = s * 16 < nrow ? s : 0;
+        wq = whp[sw];
     };
     auto store = [&](int buf, const float (&r)[KPT], int s, float wq) {
         if ((GRAM_ABL & 8) && !abl_prologue) return;
@@ -1143,7 +1147,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             v[i] = fmaxf(r[i] * sc + sh, floor_);
             if (s * 16 + rg * KPT + i >= nrow) v[i] = 0.0f; // padding rows contribute nothing
         }
-        v[0] *= wq; // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
+        if (whb != nullptr && first_rg && s * 16 < nrow) v[0] *= sqrtf(wq); // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
         unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
 #pragma unroll
         for (int i = 0; i < KPT / 2; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
