@@ -144,3 +144,19 @@ def test_build_force_is_a_clean_build(monkeypatch, tmp_path):
     assert seen["left"] == ["fps.o", "mlp_fast.o", "libvotenet_hip.so"]   # an incremental build keeps its cache
     _lib.build(force=True)
     assert seen["left"] == []
+
+
+def test_library_has_no_packed_f32_op_reading_the_high_register_of_src1(hiplib):
+    """v_pk_{fma,mul,add}_f32 with op_sel[1] = 1 returns wrong low halves beside another kernel's MFMA wavefronts on MI355X
+    (tools/probe/src/pk_opsel_hazard.hip, profiles/r05_pk_opsel_hazard.txt): the form must not be in the shipped code object."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("check_isa_hazards", os.path.join(ROOT, "tools", "check_isa_hazards.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    from votenet_amd import _lib
+    found = mod.hazards(_lib.lib_path())
+    assert not found, "%d hazardous instructions, e.g. %s in %s" % (len(found), found[0][1], found[0][0])
+    # ... and the check sees the form when it is there
+    assert mod.BAD.search("v_pk_fma_f32 v[18:19], v[56:57], v[52:53], v[18:19] op_sel:[0,1,0]")
+    assert not mod.BAD.search("v_pk_fma_f32 v[18:19], v[52:53], v[56:57], v[18:19] op_sel:[1,0,0]")
+    assert not mod.BAD.search("v_pk_fma_f32 v[18:19], v[36:37], v[52:53], v[18:19] op_sel_hi:[1,0,1]")

@@ -7,7 +7,7 @@ from votenet_amd import mlp as M
 dev = torch.device("cuda:0")
 g = torch.Generator().manual_seed(3)
 rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
-for (G, cin, cout) in [(2048, 128, 256), (4096, 128, 128), (4096, 64, 128)]:
+for (G, cin, cout) in [(2048, 128, 256), (8192, 128, 256), (4096, 128, 128), (16384, 64, 128)]:
     k = 64
     rows = G * k
     xz = rnd(rows, cin)

@@ -328,194 +328,6 @@ __global__ __launch_bounds__(NWV * 64) void pool_dgrad_scatter_kernel(long group
 // reproducible bit for bit), scans the K counters with lane shuffles, then walks the rows -- their da / z rows prefetched eight at a
 // time, one batch ahead, across groups -- adding the W^T rows of each row's channels.  Channels whose masked gradient is zero are not
 // listed at all.
-// The wavefront-per-group pass as round 4 left it, kept for the FULL row layout (groups of 64 contiguous rows: pointnet2.HALF_GROUPS off, which
-// is also the deterministic mode).  The round-5 rewrite below (padded row lists, branch-free prefetch) serves the piece layout only: with it on
-// 64-row groups the two-rank self-check of `bench.py --gpus 2` (deterministic mode, replicas with the overlapped and the blocking gradient
-// exchange must stay bit-equal) failed in 3-7 of 8 runs, with this kernel in 0 of 6 -- although the new pass is bit-reproducible run after run
-// alone, under load from another process and over 16 steps of two replicas in one process (tools/probe/scatter_determinism.py, det_step.py).
-// Not understood; the full layout is not the timed path, so it keeps the code that has passed that check since round 3.
-template <int CIN, int COUT, int K, bool RED, int NWV>
-__global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(4))) void pool_dgrad_scatter_wave_full_kernel(long groups, const float *__restrict__ gout,
-                                                                           const int *__restrict__ argmax, const float *__restrict__ zsel,
-                                                                           const float *__restrict__ coef, int relu,
-                                                                           const float *__restrict__ wT, float *__restrict__ da, PoolBelow pb)
-{
-    static_assert(K == 64 || K == kPiece, "one lane per row in the prefix scan");
-    constexpr bool HALF = K == kPiece; // piece layout (half.hip)
-    constexpr int PL = CIN / 64;  // floats per lane of a row
-    constexpr int NJ = COUT / 64; // channels per lane
-    constexpr int RB = 4;         // rows per prefetch batch (two batches in flight; 128 VGPRs per wavefront)
-    constexpr int NB = K / RB;    // batches per group (even: batch 0 of every group lives in register set 0)
-    constexpr int WS = COUT * 6 + K * 4; // bytes of a wavefront's scratch: values, channels (16 bit), counters
-    extern __shared__ __attribute__((aligned(16))) float pds_smem[];
-    float *Wl = pds_smem; // [COUT][CIN]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char *scratch = reinterpret_cast<unsigned char *>(Wl + COUT * CIN) + (size_t)wv * WS;
-    float *lv = reinterpret_cast<float *>(scratch);                             // [COUT] A g' of the listed channels, row by row
-    unsigned short *lc = reinterpret_cast<unsigned short *>(scratch + COUT * 4); // [COUT] their channel numbers
-    int *cnt = reinterpret_cast<int *>(scratch + COUT * 6);                     // [K]
-    for (int e = tid; e < COUT * CIN / 4; e += NWV * 64) reinterpret_cast<float4 *>(Wl)[e] = reinterpret_cast<const float4 *>(wT)[e];
-    if (lane < K) cnt[lane] = 0;
-    float cA[NJ], cS[NJ], cH[NJ];
-#pragma unroll
-    for (int j = 0; j < NJ; j++) {
-        cA[j] = coef[j * 64 + lane];
-        cS[j] = coef[3 * COUT + j * 64 + lane];
-        cH[j] = coef[4 * COUT + j * 64 + lane];
-    }
-    float bS[PL], bH[PL], bM[PL], bI[PL], s1[PL], s2[PL];
-#pragma unroll
-    for (int q = 0; q < PL; q++) {
-        s1[q] = s2[q] = 0.0f;
-        bS[q] = bH[q] = bM[q] = bI[q] = 0.0f;
-        if (RED) {
-            const int j = lane * PL + q;
-            bS[q] = pb.scale[j];
-            bH[q] = pb.shift[j];
-            bM[q] = pb.mean[j];
-            bI[q] = 1.0f / sqrtf(pb.var[j] + pb.eps);
-        }
-    }
-    __syncthreads(); // W^T is in place; from here on the wavefronts run on their own
-    if (HALF && pb.nh_dev != nullptr) groups = pb.nh_dev[0] < groups ? pb.nh_dev[0] : groups;
-    const long stride = (long)gridDim.x * NWV;
-    float nz[NJ], ng[NJ], nw = 1.0f;
-    int na[NJ];
-    auto fetch = [&](long g) {
-        const int code = HALF ? pb.hc[g] : 0;
-        const long ctr = HALF ? (long)(code / kBallPieces) : g;
-        if (HALF) nw = pb.wh[g];
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            nz[j] = zsel[(size_t)ctr * COUT + j * 64 + lane];
-            ng[j] = gout[(size_t)ctr * COUT + j * 64 + lane];
-            int a = argmax[(size_t)ctr * COUT + j * 64 + lane];
-            if (HALF) {
-                a -= (code % kBallPieces) * kPiece;
-                if (a < 0 || a >= kPiece) a = -1; // another piece of the centre holds this channel's arg-max
-            }
-            na[j] = a;
-        }
-    };
-    struct Rows {
-        float d[RB][PL], z[RB][PL];
-    };
-    Rows R0, R1;
-    auto load_rows = [&](Rows &r, long g, int rb) {
-#pragma unroll
-        for (int u = 0; u < RB; u++)
-#pragma unroll
-            for (int q = 0; q < PL; q++) {
-                const size_t off = ((size_t)g * K + rb * RB + u) * CIN + lane * PL + q;
-                r.d[u][q] = da[off];
-                if (RED) r.z[u][q] = pb.z[off];
-            }
-    };
-    long gi = (long)blockIdx.x * NWV + wv;
-    if (gi < groups) {
-        fetch(gi);
-        load_rows(R0, gi, 0);
-    }
-    for (; gi < groups; gi += stride) {
-        const long g = gi, gn = gi + stride;
-        float v[NJ];
-        int row[NJ], pos[NJ];
-        const float w31 = nw;
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            float gg = ng[j];
-            if (relu && !(nz[j] * cS[j] + cH[j] > 0.0f)) gg = 0.0f;
-            v[j] = cA[j] * gg;
-            row[j] = v[j] != 0.0f ? na[j] : -1; // nothing to add: not listed
-        }
-        if (gn < groups) fetch(gn);
-#pragma unroll
-        for (int j = 0; j < NJ; j++) pos[j] = row[j] >= 0 ? atomicAdd(&cnt[row[j]], 1) : 0;
-        const int c0 = lane < K ? cnt[lane] : 0;
-        int x = c0; // exclusive prefix of the K counters: one lane per row
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int t = __shfl_up(x, off);
-            if (lane >= off) x += t;
-        }
-        const int start = x - c0;
-        if (lane < K) cnt[lane] = 0; // ready for the next group
-#pragma unroll
-        for (int j = 0; j < NJ; j++) {
-            const int st = __shfl(start, row[j] >= 0 ? row[j] : 0);
-            if (row[j] >= 0) {
-                lc[st + pos[j]] = (unsigned short)(j * 64 + lane);
-                lv[st + pos[j]] = v[j];
-            }
-        }
-        auto batch = [&](const Rows &r, int rb) {
-#pragma unroll
-            for (int u = 0; u < RB; u++) {
-                const int rr = rb * RB + u;
-                const int n = __builtin_amdgcn_readlane(c0, rr), s0 = __builtin_amdgcn_readlane(start, rr);
-                const bool scaled = HALF && rr == 0 && w31 != 1.0f; // the ball's slot 0 also stands for its dropped copies
-                float acc[PL];
-#pragma unroll
-                for (int q = 0; q < PL; q++) acc[q] = scaled ? r.d[u][q] * w31 : r.d[u][q];
-                for (int i = 0; i < n; i += 4) {
-                    int c[4];
-                    float vv[4];
-#pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const bool ok = i + t < n;
-                        c[t] = lc[s0 + (ok ? i + t : i)];
-                        vv[t] = ok ? lv[s0 + i + t] : 0.0f;
-                    }
-#pragma unroll
-                    for (int t = 0; t < 4; t++)
-#pragma unroll
-                        for (int q = 0; q < PL; q++) acc[q] += vv[t] * Wl[c[t] * CIN + lane * PL + q];
-                }
-                if (n != 0 || scaled) {
-                    float *drow = da + ((size_t)g * K + rr) * CIN + lane * PL;
-#pragma unroll
-                    for (int q = 0; q < PL; q++) drow[q] = acc[q];
-                }
-                if (RED) {
-#pragma unroll
-                    for (int q = 0; q < PL; q++) {
-                        const float zz2 = r.z[u][q];
-                        const float gp = (pb.relu && !(zz2 * bS[q] + bH[q] > 0.0f)) ? 0.0f : acc[q];
-                        s1[q] += gp;
-                        s2[q] += gp * ((zz2 - bM[q]) * bI[q]);
-                    }
-                }
-            }
-        };
-#pragma unroll 1
-        for (int rb = 0; rb < NB; rb += 2) {
-            load_rows(R1, g, rb + 1);
-            batch(R0, rb);
-            if (rb + 2 < NB) load_rows(R0, g, rb + 2);
-            else if (gn < groups) load_rows(R0, gn, 0);
-            batch(R1, rb + 1);
-        }
-    }
-    if (RED) { // combine the wavefronts' column sums in LDS (W^T is no longer needed), one fp64 atomic per column and workgroup
-        __syncthreads();
-        float *red = Wl; // [NWV][2][CIN]
-#pragma unroll
-        for (int q = 0; q < PL; q++) {
-            red[(wv * 2 + 0) * CIN + lane * PL + q] = s1[q];
-            red[(wv * 2 + 1) * CIN + lane * PL + q] = s2[q];
-        }
-        __syncthreads();
-        for (int e = tid; e < 2 * CIN; e += NWV * 64) {
-            float t = 0.0f;
-#pragma unroll
-            for (int w8 = 0; w8 < NWV; w8++) t += red[w8 * 2 * CIN + e];
-            unsafeAtomicAdd(&pb.sums[e], (double)t);
-        }
-        coef_tail(pb.tail, gridDim.x, CIN, pb.sums, pb.scale, pb.shift, pb.mean, pb.var, pb.eps);
-    }
-}
-
 template <int CIN, int COUT, int K, bool RED, int NWV>
 __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV == 12 ? 3 : 4))) void pool_dgrad_scatter_wave_kernel(long groups, const float *__restrict__ gout,
                                                                            const int *__restrict__ argmax, const float *__restrict__ zsel,
@@ -654,17 +466,31 @@ __global__ __launch_bounds__(NWV * 64) __attribute__((amdgpu_waves_per_eu(NWV ==
 #pragma unroll
                 for (int q = 0; q < PL; q++) acc[q] = scaled ? r.d[u][q] * w31 : r.d[u][q];
                 for (int i = 0; i < n; i += 4) { // four entries per trip: their channels in 8 bytes, their values in 16 (all lanes read the same words)
-                    const uint2 c4w = *reinterpret_cast<const uint2 *>(&lc[s0 + i]);
-                    const float4 v4 = *reinterpret_cast<const float4 *>(&lv[s0 + i]);
-                    const unsigned cc[4] = {c4w.x & 0xffffu, c4w.x >> 16, c4w.y & 0xffffu, c4w.y >> 16};
-                    const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
-                    if constexpr (PL == 2) {
+                    // (element types as written -- no type punning between the 16-bit stores and a wider read; the alignment lets the
+                    // compiler merge the four reads of each list into one 8-byte / 16-byte LDS read)
+                    const unsigned short *pc = static_cast<const unsigned short *>(__builtin_assume_aligned(&lc[s0 + i], 8));
+                    const float *pv = static_cast<const float *>(__builtin_assume_aligned(&lv[s0 + i], 16));
+                    const unsigned cc[4] = {pc[0], pc[1], pc[2], pc[3]};
+                    const float vv[4] = {pv[0], pv[1], pv[2], pv[3]};
+                    constexpr bool kPacked = PL == 2;
+                    if constexpr (kPacked) {
                         f32x2 wr[4];
 #pragma unroll
                         for (int t = 0; t < 4; t++) wr[t] = *reinterpret_cast<const f32x2 *>(&Wl[cc[t] * CIN + lane * PL]);
 #pragma unroll
                         for (int t = 0; t < 4; t++) {
+                            // THE BROADCAST OPERAND FIRST.  Written second -- fma(row, {v, v}, acc) -- the compiler folds the broadcast into
+                            // op_sel on src1: v_pk_fma_f32 acc, row, [v_t, v_t+1], acc op_sel:[0,1,0] for the odd entries, whose LOW half
+                            // takes src1's HIGH register -- and that form returns a wrong low half in lanes 48-63 now and then while MFMA
+                            // wavefronts of another kernel (the weight-gradient stream) run on the same compute unit: one list entry's
+                            // contribution missing in 16 columns of a row, 10-25 % of the launches with three processes on the GPU
+                            // (tools/probe/src/pk_opsel_hazard.hip, profiles/r05_pk_opsel_hazard.txt; tools/check_isa_hazards.py keeps
+                            // the form out of the library).  op_sel on src0 is exact.
+#ifdef SCATTER_PK_SRC1 /* probe build: the hazardous operand order, for tools/probe/scatter_repeat.py */
                             const f32x2 a2 = __builtin_elementwise_fma(wr[t], f32x2{vv[t], vv[t]}, f32x2{acc[0], acc[1]});
+#else
+                            const f32x2 a2 = __builtin_elementwise_fma(f32x2{vv[t], vv[t]}, wr[t], f32x2{acc[0], acc[1]});
+#endif
                             acc[0] = a2.x;
                             acc[1] = a2.y;
                         }
@@ -1209,8 +1035,8 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
                            wT, da, pb);
     };
     // one wavefront per group (the default)
-    auto gow = [&](auto kern, int ci, int co, int kk, int nwv, bool full = false) {
-        const size_t smem = (size_t)co * ci * 4 + (size_t)nwv * (full ? (co * 6 + kk * 4) : ((co + 3 * kk) * 6 + kk * 4));
+    auto gow = [&](auto kern, int ci, int co, int kk, int nwv) {
+        const size_t smem = (size_t)co * ci * 4 + (size_t)nwv * ((co + 3 * kk) * 6 + kk * 4);
         const int per_cu = smem > 80 * 1024 ? 1 : (smem > 40 * 1024 ? 2 : 4);
         static std::set<const void *> raised_w;
         static std::mutex raised_w_mu;
@@ -1241,15 +1067,10 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
             }
             else VN_SCATTER_WAVE(128, 128, kPiece, 8);
         } else {
-#define VN_SCATTER_FULL(CI, CO, NW)                                                                     \
-    do {                                                                                                \
-        if (below_z) gow(pool_dgrad_scatter_wave_full_kernel<CI, CO, 64, true, NW>, CI, CO, 64, NW, true);   \
-        else gow(pool_dgrad_scatter_wave_full_kernel<CI, CO, 64, false, NW>, CI, CO, 64, NW, true);          \
-    } while (0)
-            if (cin == 64) VN_SCATTER_FULL(64, 128, 8);
-            else if (cout == 256) VN_SCATTER_FULL(128, 256, 16);
-            else VN_SCATTER_FULL(128, 128, 8);
-#undef VN_SCATTER_FULL
+            // (64-row groups: the row lists need 8 wavefronts' scratch beside W^T)
+            if (cin == 64) VN_SCATTER_WAVE(64, 128, 64, 8);
+            else if (cout == 256) VN_SCATTER_WAVE(128, 256, 64, 8);
+            else VN_SCATTER_WAVE(128, 128, 64, 8);
         }
 #undef VN_SCATTER_WAVE
         return check_launch("pool_dgrad_scatter");
