@@ -7,7 +7,7 @@
 // ds_read2_b32, rows of a table in LDS by ds_read_b64) and accumulates them TWICE from the same registers -- once with the broadcast
 // operand in src1, once in src0 -- into two accumulators that must stay bit-equal.
 //   build: hipcc --offload-arch=gfx950 -O3 pk_opsel_hazard.hip -o pk_opsel_hazard      run: ./pk_opsel_hazard [launches] [side]
-//   side = 1: a second stream runs MFMA-only workgroups beside it.  Run three at once to share the GPU (tools/probe/pk3.sh).
+//   side = 1: a second stream runs MFMA-only workgroups beside it; side = 2: vector-only workgroups.  Run three at once to share the GPU (tools/probe/pk3.sh).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -250,6 +250,18 @@ __global__ __launch_bounds__(256) void mfma_side(int iters, float *out)
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// side = 2: the neighbour runs plain vector multiply-adds instead of MFMAs (is it the matrix pipe, or any neighbour?)
+__global__ __launch_bounds__(256) void valu_side(int iters, float *out)
+{
+    float a[8];
+    for (int i = 0; i < 8; i++) a[i] = 0.001f * (float)(threadIdx.x + i);
+    for (int it = 0; it < iters * 8; it++)
+        for (int i = 0; i < 8; i++) asm volatile("v_fma_f32 %0, %0, %1, %0" : "+v"(a[i]) : "v"(0.999f));
+    float s = 0.0f;
+    for (int i = 0; i < 8; i++) s += a[i];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 int main(int argc, char **argv)
 {
     const int launches = argc > 1 ? atoi(argv[1]) : 200;
@@ -293,7 +305,8 @@ int main(int argc, char **argv)
     CHECK(hipStreamCreate(&st2));
     // 1. the self-checking kernel
     for (int l = 0; l < launches; l++) {
-        if (side) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+        if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
         hipLaunchKernelGGL(pk_kernel, dim3(grid), dim3(NWV * 64), smem, st, d_table, d_vals, d_codes, trips, rounds, d_bad, d_out);
     }
     CHECK(hipDeviceSynchronize());
@@ -307,7 +320,8 @@ int main(int argc, char **argv)
     for (int form = 1; form <= 10; form++) {
         CHECK(hipMemset(d_bad, 0, 8));
         for (int l = 0; l < launches; l++) {
-            if (side) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
 #define GO(F) case F: hipLaunchKernelGGL(pk_kernel_regs<F>, dim3(grid), dim3(NWV * 64), 0, st, trips * 8, rounds, d_bad, d_out); break;
             switch (form) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) GO(10) }
 #undef GO
@@ -321,7 +335,8 @@ int main(int argc, char **argv)
     std::vector<float> ref(per), got(per);
     for (int form = 1; form >= 0; form--) {
         auto launch = [&](float *dst) {
-            if (side) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
             if (form)
                 hipLaunchKernelGGL(pk_kernel_one<true>, dim3(grid), dim3(NWV * 64), smem, st, d_table, d_vals, d_codes, trips, rounds, dst);
             else
