@@ -242,6 +242,28 @@ def test_config5_scene_fps_and_ball_query_bit_exact(ops, dev, O):
     assert (N(c2) == oc2).all() and (N(i2) == oi2).all()
 
 
+@pytest.mark.parametrize("b,n,m", [(2, 80000, 300), (1, 24577, 64), (3, 98304, 40), (9, 30001, 33), (1, 50000, 1)])
+def test_fps_scene_over_four_workgroups_gives_the_same_indices(ops, dev, hiplib, b, n, m):
+    """fps_bucket_split_kernel (votenet_debug_fps_split(1); off by default, profiles/r05_fps_split.txt): a scene's buckets held in the
+    registers of four workgroups that agree on every round's winner through L2 -- the indices of tf_sampling_g.cu:105-170 exactly as
+    the default kernel gives them (that one is pinned to the oracle and to the reference's kernel above), more scenes than XCDs,
+    ragged sizes, both ends of the kernel's range; no poll may have given up."""
+    import ctypes
+    from votenet_amd import synth
+    hiplib.votenet_debug_fps_split_timeouts.restype = ctypes.c_uint
+    x = T(synth.room_batch(b, n, 5 + n % 7), dev)
+    ref = ops.s.farthest_point_sample(m, x)
+    hiplib.votenet_debug_fps_split(1)
+    try:
+        got = ops.s.farthest_point_sample(m, x)
+        again = ops.s.farthest_point_sample(m, x)  # the exchange buffer is zeroed per launch: a second call sees no stale round numbers
+        torch.cuda.synchronize()
+    finally:
+        hiplib.votenet_debug_fps_split(0)
+    assert (N(got) == N(ref)).all() and (N(again) == N(ref)).all()
+    assert hiplib.votenet_debug_fps_split_timeouts() == 0
+
+
 def test_fps_reference_launcher_shim_large_batch(ops, dev, hiplib):
     """tf_sampling.cpp:94,115: the reference calls farthestpointsamplingLauncher with a TensorShape{32,n} scratch whatever
     the batch.  The exported shim (C++ linkage, the reference's exact signature) must give the op's result with exactly

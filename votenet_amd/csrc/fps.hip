@@ -188,6 +188,8 @@ struct FpsOut {
 struct FpsWinner {
     unsigned k;    // original point index
     float x, y, z; // its coordinates (uniform)
+    unsigned d2;   // its running distance (bits) and its tie key re-packed to 28 bits (fps_cross_wave): what a further exchange
+    unsigned key28; // between workgroups compares (fps_bucket_split_kernel)
 };
 
 // Cross-wave stage: every wave contributes (wmax, wkey, wx, wy, wz); returns the block winner (the same value in every
@@ -216,6 +218,8 @@ __device__ __forceinline__ FpsWinner fps_cross_wave(unsigned wmax, unsigned wkey
         r.x = wx;
         r.y = wy;
         r.z = wz;
+        r.d2 = wmax;
+        r.key28 = ((wkey >> 23) << 19) | (wkey & 0x7FFFFu);
         return r;
     }
     unsigned long long *slot = reinterpret_cast<unsigned long long *>(s_ex);
@@ -243,6 +247,8 @@ __device__ __forceinline__ FpsWinner fps_cross_wave(unsigned wmax, unsigned wkey
     r.x = c.x;
     r.y = c.y;
     r.z = c.z;
+    r.d2 = (unsigned)(v >> 32);
+    r.key28 = key28;
     return r;
 }
 
@@ -788,6 +794,175 @@ __global__ __launch_bounds__(NW * 64) void fps_bucket_kernel(int n, int m, const
     }
 }
 
+// ------------------------------------------------------------------ exact bucket-pruned FPS, ONE SCENE OVER W WORKGROUPS
+// 24 576 < n <= W * 24 576 (config 5: 80 000 points).  fps_bucket_l2_kernel keeps such a scene's points in L2 and pays one dependent
+// L2 round trip per round for the touched buckets (1.40 us per round, 0.46 of the HBM model).  Here W workgroups hold the scene in
+// REGISTERS, fps_bucket_kernel's way -- bucket g belongs to workgroup g % W (spatial neighbours in different workgroups AND different
+// waves: a round's ~30 touched buckets spread over W x NW waves) -- and agree on the winner every round through L2:
+//   every workgroup runs fps_bucket_kernel's round on its part up to its own winner (in-CU exchange: one LDS atomic, one barrier);
+//   wave 0 PUBLISHES (distance, tie key, x, y, z) as five 64-bit words [round | payload] -- relaxed device-scope stores, nothing waits
+//   for them; EVERY wave then polls the 5 W words of the round (one 8-byte load per lane, lanes < 5 W) until all carry the round's
+//   number and picks the maximum itself: no second barrier, every wave of every workgroup derives the same winner from the same words.
+// A word is single-copy atomic, so a lane never sees half a record; the round number in every word makes a record complete exactly
+// when its five words match.  Two sets of slots by round parity: a workgroup can publish round j + 1 only after every workgroup
+// published round j, i.e. after all of them finished reading round j - 1 -- the set it overwrites.  The buffer is zeroed before the
+// launch (round numbers start at 1).
+// MEASURED (round 5, profiles/r05_fps_split.txt), and why it stays behind votenet_debug_fps_split(1): 1.90 us per round at config 5
+// against the L2-resident kernel's 1.33.  The exchange alone is 0.52-0.55 us per round (tools/probe/src/xwg_publish_poll.hip: the
+// round-4 budget's 0.85 came from a probe that serialised four L2 round trips) -- but a workgroup's own round is 0.82 us, not the
+// budgeted 0.35 (a quarter of an 80 000-point scene keeps its waves as busy as a whole 20 480-point scene: the dense scan touches
+// several times as many buckets per round), and in the loop the exchange costs 1.08 us because every round now waits for the slowest
+// of 48 waves instead of 12.  Indices are bit-identical to the other kernels' (tests/test_gpu_parity.py).
+// Placement: workgroups go round-robin over the 8 XCDs, so blocks x, x + 8, x + 16, ... share an XCD and its L2: scene = XCD (+ 8 per
+// further turn), part = turn.  Deadlock: the parts of a scene wait for each other, so the whole grid must be resident -- the launcher
+// takes this kernel only for grids of at most 256 workgroups -- and a poll gives up after 2^22 tries (~1 s; counted in
+// g_fps_split_timeouts, read by votenet_debug_fps_split_timeouts: the result is then garbage, the GPU is not hung).
+__device__ unsigned g_fps_split_timeouts;
+
+template <int NW, int VW, int W>
+__global__ __launch_bounds__(NW * 64) void fps_bucket_split_kernel(int b, int n, int m, const float *__restrict__ xyz,
+                                                                   const float *__restrict__ bbox, const float4 *__restrict__ sorted,
+                                                                   int *__restrict__ out, unsigned long long *__restrict__ xch, int ablate)
+{
+    constexpr int P = VW;
+    typedef typename SlotVec<VW>::type vec_t;
+    const int xcd = blockIdx.x & 7, turn = blockIdx.x >> 3;
+    const int scene = xcd + 8 * (turn / W), q = turn % W;
+    if (scene >= b) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned *s_key = reinterpret_cast<unsigned *>(smem);                          // NW*P*64 tie keys by (slot, wave, lane)
+    unsigned *s_ex = reinterpret_cast<unsigned *>(smem + (size_t)NW * P * 64 * 4); // 2 x 16 x 5 exchange
+    const float *__restrict__ pts = xyz + (size_t)scene * n * 3;
+    int *__restrict__ o = out + (size_t)scene * m;
+    unsigned long long *__restrict__ xs = xch + (size_t)scene * 2 * W * 5;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = wave_id_uniform();
+    const int nb = (n + 63) / 64;
+
+    vec_t X, Y, Z, TD;
+#pragma unroll
+    for (int i = 0; i < P; i++) {
+        const int g = (i * NW + w) * W + q; // the scene's bucket in this slot
+        const int p = g * 64 + lane;
+        const bool valid = p < n;
+        unsigned key = 0xFFFFFFFFu;
+        float px = 0.f, py = 0.f, pz = 0.f;
+        if (valid) {
+            const float4 v = sorted[(size_t)scene * nb * 64 + p];
+            px = v.x;
+            py = v.y;
+            pz = v.z;
+            key = fps_tiekey((unsigned)__float_as_int(v.w));
+        }
+        X[i] = px;
+        Y[i] = py;
+        Z[i] = pz;
+        TD[i] = valid ? 1e38f : 0.0f; // tf_sampling_g.cu:118; an empty slot never wins
+        s_key[(size_t)(i * NW + w) * 64 + lane] = key;
+    }
+    const int myg = (lane * NW + w) * W + q;
+    const bool hasb = lane < P && myg < nb;
+    const float *__restrict__ bb = bbox + ((size_t)scene * nb + (hasb ? myg : 0)) * 6;
+    const float bxl = hasb ? bb[0] : INFINITY, byl = hasb ? bb[1] : INFINITY, bzl = hasb ? bb[2] : INFINITY;
+    const float bxh = hasb ? bb[3] : -INFINITY, byh = hasb ? bb[4] : -INFINITY, bzh = hasb ? bb[5] : -INFINITY;
+    unsigned bmax = hasb ? fbits(1e38f) : 0u;
+    unsigned bkey = 0xFFFFFFFFu;
+    int blane = 0;
+    if (tid == 0) fps_cross_init(s_ex);
+    __syncthreads();
+    FpsOut fo = {o, m, 0};
+    if (q == 0) fo.put(0, 0, tid); // tf_sampling_g.cu:114-116
+    float cx, cy, cz;
+    fps_get0(pts, cx, cy, cz);
+    unsigned cw_max = 0u, cw_key = 0xFFFFFFFFu;
+    int cw_slot = -1;
+    float cw_x = 0.f, cw_y = 0.f, cw_z = 0.f;
+    bool dead = false; // a poll timed out: keep going without waiting (the result is garbage, the kernel ends)
+    for (int j = 1; j < m; j++) {
+        // (1)-(3): fps_bucket_kernel's round on this workgroup's buckets
+        const float ex = fmaxf(fmaxf(bxl - cx, cx - bxh), 0.0f);
+        const float ey = fmaxf(fmaxf(byl - cy, cy - byh), 0.0f);
+        const float ez = fmaxf(fmaxf(bzl - cz, cz - bzh), 0.0f);
+        const float lb = (ex * ex + ey * ey + ez * ez) * 0.99999f;
+        unsigned long long act = __ballot(hasb && !(lb >= __uint_as_float(bmax)));
+        bool changed = false;
+        while (act) {
+            const int i = __ffsll((long long)act) - 1;
+            act &= act - 1;
+            const float dx = X[i] - cx, dy = Y[i] - cy, dz = Z[i] - cz;
+            const float d = dx * dx + dy * dy + dz * dz;     // tf_sampling_g.cu:142, un-fused
+            const unsigned d2 = min(fbits(d), fbits(TD[i])); // :143
+            TD[i] = __uint_as_float(d2);
+            const int ol = __builtin_amdgcn_readlane(blane, i);
+            const unsigned omax = (unsigned)__builtin_amdgcn_readlane((int)bmax, i);
+            if ((unsigned)__builtin_amdgcn_readlane((int)d2, ol) != omax) {
+                const unsigned key = s_key[(size_t)(i * NW + w) * 64 + lane];
+                unsigned nmax, nkey;
+                const int nl = wave_argmax(d2, key, nmax, nkey);
+                if (lane == i) {
+                    bmax = nmax;
+                    bkey = nkey;
+                    blane = nl;
+                }
+                changed = changed || (i == cw_slot);
+            }
+        }
+        if (changed || j == 1) {
+            const int ws = wave_argmax(lane < P ? bmax : 0u, lane < P ? bkey : 0xFFFFFFFFu, cw_max, cw_key);
+            cw_slot = ws;
+            const int fl = __builtin_amdgcn_readlane(blane, ws);
+            cw_x = readlane_f32(X[ws], fl);
+            cw_y = readlane_f32(Y[ws], fl);
+            cw_z = readlane_f32(Z[ws], fl);
+        }
+        const FpsWinner mine = fps_cross_wave<NW>(cw_max, cw_key, cw_x, cw_y, cw_z, s_ex, j); // this workgroup's winner, in every wave
+        // (4) between the workgroups of the scene
+        unsigned long long *__restrict__ cur = xs + (size_t)(j & 1) * W * 5;
+        if (w == 0 && lane < 5) {
+            const unsigned lo = lane == 0   ? mine.d2
+                                : lane == 1 ? 0xFFFFFFFu - mine.key28 // larger = smaller tie key
+                                : lane == 2 ? __float_as_uint(mine.x)
+                                : lane == 3 ? __float_as_uint(mine.y)
+                                            : __float_as_uint(mine.z);
+            __hip_atomic_store(&cur[q * 5 + lane], ((unsigned long long)(unsigned)j << 32) | lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        unsigned long long got = ((unsigned long long)(unsigned)j << 32);
+        if (ablate == 1) { // timing ablation (votenet_debug_fps_split(2)): no exchange, every workgroup follows its own winner -- NOT the FPS indices
+            cx = mine.x;
+            cy = mine.y;
+            cz = mine.z;
+            continue;
+        }
+        for (int spin = 0; !dead; spin++) {
+            if (lane < 5 * W) got = __hip_atomic_load(&cur[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (__ballot(lane < 5 * W && (unsigned)(got >> 32) != (unsigned)j) == 0ull) break;
+            if (spin > (1 << 22)) {
+                dead = true;
+                if (tid == 0) atomicAdd(&g_fps_split_timeouts, 1u);
+            }
+        }
+        const int glo = (int)(unsigned)got;
+        unsigned long long best = 0ull;
+        int bq = 0;
+#pragma unroll
+        for (int qq = 0; qq < W; qq++) {
+            const unsigned long long c = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane(glo, 5 * qq) << 32) |
+                                         (unsigned)__builtin_amdgcn_readlane(glo, 5 * qq + 1);
+            if (qq == 0 || c > best) { // records are distinct (a point has one tie key)
+                best = c;
+                bq = qq;
+            }
+        }
+        cx = __uint_as_float((unsigned)__builtin_amdgcn_readlane(glo, 5 * bq + 2));
+        cy = __uint_as_float((unsigned)__builtin_amdgcn_readlane(glo, 5 * bq + 3));
+        cz = __uint_as_float((unsigned)__builtin_amdgcn_readlane(glo, 5 * bq + 4));
+        if (q == 0) {
+            const unsigned key28 = 0xFFFFFFFu - (unsigned)best;
+            fo.put(j, (int)((key28 >> 19) | ((key28 & 0x7FFFFu) << 9)), tid);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ exact bucket-pruned FPS, L2-resident points
 // ------------------------------------------------------------------ two samples per round
 // fps_bucket_kernel with up to TWO picks per round.  If q1 is the arg-max of a round and q2 the runner-up (in the full order:
@@ -1236,6 +1411,9 @@ extern "C" void votenet_fps_trace_read(unsigned long long *out, int reset)
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
 static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)
+static const int kFpsSplitW = 4;                           // fps_bucket_split_kernel: workgroups per scene ...
+static const int kFpsSplitMax = kFpsSplitW * 12 * 32 * 64; // ... each holding 12 waves x 32 slots x 64 points in registers (98 304)
+static const int kFpsSplitScenes = 64;                     // 8 XCDs x 8 turns x 4 parts = 256 workgroups: all resident
 
 } // namespace votenet
 
@@ -1263,9 +1441,12 @@ extern "C" int votenet_spatial_index(int b, int n, const float *xyz, float *inde
     return build_spatial_index(b, n, xyz, index, as_stream(stream));
 }
 
+static size_t fps_split_floats(int b) { return (size_t)b * 2 * kFpsSplitW * 5 * 2 + 4; } // [b][2][W][5] 64-bit words behind the index (+ alignment)
+
 extern "C" size_t votenet_fps_temp_floats(int b, int n)
 {
     if (n <= kFpsRegMax) return 0;
+    if (n > kFpsBucketMax && n <= kFpsSplitMax) return spatial_index_floats(b, n) + fps_split_floats(b); // the index + the split kernel's exchange
     if (n <= kFpsL2Max) return spatial_index_floats(b, n); // the spatial index: permutation, bucket boxes, sorted float4, work
     return (size_t)(b < 32 ? b : 32) * (size_t)n;                                          // running distances, tf_sampling.cpp:115
 }
@@ -1315,6 +1496,15 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
                            (const float *)sidx.bbox, (const float4 *)sidx.sorted, out);                            \
     } while (0)
 
+static int g_fps_split = 0; // 1: 24 576 < n <= 98 304 samples one scene over four workgroups (fps_bucket_split_kernel) -- measured SLOWER than the
+                            // L2-resident kernel (1.90 vs 1.33 us per round at config 5, profiles/r05_fps_split.txt): off; 2: that kernel without its exchange (timing)
+extern "C" void votenet_debug_fps_split(int on) { g_fps_split = on; } // A/B and test hook
+extern "C" unsigned votenet_debug_fps_split_timeouts(void)            // polls of the split kernel that gave up (0 unless a part never ran)
+{
+    unsigned v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_fps_split_timeouts), sizeof(v));
+    return v;
+}
 static int g_fps_lds_floor = 0;
 extern "C" void votenet_debug_fps_lds_floor(int bytes) { g_fps_lds_floor = bytes > 0 ? bytes : 0; } // tuning hook
 
@@ -1363,7 +1553,20 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
         if (build_spatial_index(b, n, inp, temp, st) != VOTENET_OK) return VOTENET_E_HIP;
         float *boxes = sidx.bbox;
         float4 *sorted = sidx.sorted;
-        if (nb <= 16 * 64)
+        if (g_fps_split && n <= kFpsSplitMax && b <= kFpsSplitScenes) {
+            constexpr size_t lds = (size_t)12 * 32 * 64 * 4 + 2 * 16 * 5 * 4;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_split_kernel<12, 32, kFpsSplitW>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                attr_set = true;
+            }
+            unsigned long long *xch = reinterpret_cast<unsigned long long *>(
+                (reinterpret_cast<uintptr_t>(temp + spatial_index_floats(b, n)) + 15) & ~(uintptr_t)15);
+            if (hipMemsetAsync(xch, 0, (fps_split_floats(b) - 4) * sizeof(float), st) != hipSuccess) return check_launch("farthest_point_sample");
+            hipLaunchKernelGGL((fps_bucket_split_kernel<12, 32, kFpsSplitW>), dim3(8 * kFpsSplitW * ((b + 7) / 8)), dim3(12 * 64), lds, st, b, n,
+                               m, inp, boxes, sorted, out, xch, g_fps_split == 2 ? 1 : 0);
+        } else if (nb <= 16 * 64)
             hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 1>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
         else if (nb <= 16 * 64 * 2)
             hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 2>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
