@@ -21,6 +21,10 @@ sc, sh, mu, var = torch.rand(c0, generator=g).to(dev) + 0.5, rnd(c0), rnd(c0), t
 bn = M.FrozenBN(torch.stack([sc, sh]))
 z1, da1, coef1 = rnd(rows, c1), rnd(rows, c1), rnd(5 * c1)
 wT = w1.t().contiguous()
+w1 = w1.contiguous()
+imgs = M.SplitImages([w1, wT])  # the bf16 x 3 images: the GEMMs then take the split-operand kernels the step runs
+imgs.refresh()
+print("split images registered:", imgs.nseg)
 dw = torch.zeros(c0, c1, device=dev)
 t = {}
 t["fwd materialised (z0 read)"] = gpu_ms(lambda: M.linear_dense(z0, w1, None, sc, sh, True), it=10)
