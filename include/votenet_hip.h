@@ -64,7 +64,7 @@ int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *
 /* Experiment hook (not part of the drop-in surface): route 4096 < n <= 24576 through the kernel that emits up to two samples
  * per round (same indices, same order; DESIGN_HISTORY.md 4.1).  Off by default: measured slower than the one-sample rounds. */
 void votenet_fps_debug_two_pick(int on);
-void votenet_debug_fps_split(int on);            /* 24 576 < n <= 98 304: 1 = one scene over four workgroups (same indices; measured slower: off by default) */
+void votenet_debug_fps_split(int on);            /* 24 576 < n <= 98 304: one scene over 4 (on = 1), 12 (3) or 6 (5) workgroups; same indices, measured slower: 0 by default */
 unsigned votenet_debug_fps_split_timeouts(void); /* polls of the split kernel that gave up (0 unless a part of a scene never ran) */
 /* Measurement hook: 0 disables the parallel "already in farthest-point order?" check that precedes the sampling rounds for
  * n <= 2048 (DESIGN_HISTORY.md 4.1); the result is the same either way. */

@@ -103,8 +103,8 @@ def test_workspace_queries(hiplib):
     work = 16 * 4096 + 6 * 16 + 8                                               # per-workgroup cell histograms + partial bounds
     # the spatial index: Morton permutation + bucket boxes + sorted float4 points + work (also what the indexed ball query reads)
     assert hiplib.votenet_fps_temp_floats(8, 20480) == 8 * (20480 + 6 * 320 + 256 * 320 + work) + 4
-    # 24 576 < n <= 98 304: behind the index, the exchange words of the four-workgroups-per-scene kernel ([b][2][4][5] x 8 bytes + alignment)
-    assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * (80000 + 6 * 1250 + 256 * 1250 + work) + 4 + 4 * 2 * 4 * 5 * 2 + 4
+    # 24 576 < n <= 98 304: behind the index, the exchange words of the scene-over-several-workgroups kernel ([b][2][12][5] x 8 bytes + alignment)
+    assert hiplib.votenet_fps_temp_floats(4, 80000) == 4 * (80000 + 6 * 1250 + 256 * 1250 + work) + 4 + 4 * 2 * 12 * 5 * 2 + 4
     assert hiplib.votenet_fps_temp_floats(1, 140000) == hiplib.votenet_spatial_index_floats(1, 140000)
     assert hiplib.votenet_spatial_index_floats(8, 20480) == hiplib.votenet_fps_temp_floats(8, 20480)
     assert hiplib.votenet_fps_temp_floats(4, 300000) == 4 * 300000              # unpruned streaming fallback

@@ -242,8 +242,9 @@ def test_config5_scene_fps_and_ball_query_bit_exact(ops, dev, O):
     assert (N(c2) == oc2).all() and (N(i2) == oi2).all()
 
 
+@pytest.mark.parametrize("mode", [1, 3, 5])
 @pytest.mark.parametrize("b,n,m", [(2, 80000, 300), (1, 24577, 64), (3, 98304, 40), (9, 30001, 33), (1, 50000, 1)])
-def test_fps_scene_over_four_workgroups_gives_the_same_indices(ops, dev, hiplib, b, n, m):
+def test_fps_scene_over_four_workgroups_gives_the_same_indices(ops, dev, hiplib, b, n, m, mode):
     """fps_bucket_split_kernel (votenet_debug_fps_split(1); off by default, profiles/r05_fps_split.txt): a scene's buckets held in the
     registers of four workgroups that agree on every round's winner through L2 -- the indices of tf_sampling_g.cu:105-170 exactly as
     the default kernel gives them (that one is pinned to the oracle and to the reference's kernel above), more scenes than XCDs,
@@ -253,7 +254,7 @@ def test_fps_scene_over_four_workgroups_gives_the_same_indices(ops, dev, hiplib,
     hiplib.votenet_debug_fps_split_timeouts.restype = ctypes.c_uint
     x = T(synth.room_batch(b, n, 5 + n % 7), dev)
     ref = ops.s.farthest_point_sample(m, x)
-    hiplib.votenet_debug_fps_split(1)
+    hiplib.votenet_debug_fps_split(mode)  # 1: 4 workgroups x 12 waves per scene, 3: 12 x 4, 5: 6 x 8
     try:
         got = ops.s.farthest_point_sample(m, x)
         again = ops.s.farthest_point_sample(m, x)  # the exchange buffer is zeroed per launch: a second call sees no stale round numbers

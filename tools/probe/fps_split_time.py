@@ -16,18 +16,19 @@ def timeit(fn, it=6, warm=2):
     for _ in range(it): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / it
+SP = int(os.environ.get("SPLIT", "1"))
 for (b, n, m) in [(4, 80000, 2048), (1, 80000, 2048), (8, 80000, 2048), (4, 30000, 1024), (2, 98304, 512), (9, 40000, 256)]:
     x = torch.from_numpy(synth.room_batch(b, n, 7)).to(dev)
     res = {}
-    for on in (0, 1):
+    for on in (0, int(os.environ.get("SPLIT", "1"))):
         lib.votenet_debug_fps_split(on)
         idx = tf_sampling.farthest_point_sample(m, x)
         torch.cuda.synchronize()
         t = timeit(lambda: tf_sampling.farthest_point_sample(m, x))
         res[on] = (idx.clone(), t)
-    same = torch.equal(res[0][0], res[1][0])
+    same = torch.equal(res[0][0], res[SP][0])
     model = b * n * 16.0 * (m - 1)
     print("%d x %6d -> %4d: L2-resident %.3f ms (%.3f us per round, %.3f of 8 TB/s)   split %.3f ms (%.3f us per round, %.3f)   indices equal: %s   timeouts %d" % (
-        b, n, m, res[0][1], res[0][1] * 1e3 / (m - 1), model / (res[0][1] * 1e-3) / 8e12, res[1][1], res[1][1] * 1e3 / (m - 1),
-        model / (res[1][1] * 1e-3) / 8e12, same, lib.votenet_debug_fps_split_timeouts()))
-lib.votenet_debug_fps_split(1)
+        b, n, m, res[0][1], res[0][1] * 1e3 / (m - 1), model / (res[0][1] * 1e-3) / 8e12, res[SP][1], res[SP][1] * 1e3 / (m - 1),
+        model / (res[SP][1] * 1e-3) / 8e12, same, lib.votenet_debug_fps_split_timeouts()))
+lib.votenet_debug_fps_split(0)

@@ -1411,9 +1411,9 @@ extern "C" void votenet_fps_trace_read(unsigned long long *out, int reset)
 static const int kFpsRegMax = 4096;         // brute-force register kernel
 static const int kFpsBucketMax = 1024 * 24; // bucket-pruned register kernel
 static const int kFpsL2Max = 16 * 64 * 64 * 4; // bucket-pruned kernel with L2-resident points (262 144)
-static const int kFpsSplitW = 4;                           // fps_bucket_split_kernel: workgroups per scene ...
-static const int kFpsSplitMax = kFpsSplitW * 12 * 32 * 64; // ... each holding 12 waves x 32 slots x 64 points in registers (98 304)
-static const int kFpsSplitScenes = 64;                     // 8 XCDs x 8 turns x 4 parts = 256 workgroups: all resident
+static const int kFpsSplitW = 12;                          // fps_bucket_split_kernel: at most this many workgroups per scene (exchange words) ...
+static const int kFpsSplitMax = 4 * 12 * 32 * 64;          // ... together holding 48 waves x 32 slots x 64 points in registers (98 304)
+static const int kFpsSplitScenes = 16;                     // 8 XCDs x 2 turns x 12 parts = 192 workgroups: all resident
 
 } // namespace votenet
 
@@ -1496,8 +1496,8 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
                            (const float *)sidx.bbox, (const float4 *)sidx.sorted, out);                            \
     } while (0)
 
-static int g_fps_split = 0; // 1: 24 576 < n <= 98 304 samples one scene over four workgroups (fps_bucket_split_kernel) -- measured SLOWER than the
-                            // L2-resident kernel (1.90 vs 1.33 us per round at config 5, profiles/r05_fps_split.txt): off; 2: that kernel without its exchange (timing)
+static int g_fps_split = 0; // 1 / 3 / 5: 24 576 < n <= 98 304 samples one scene over 4 / 12 / 6 workgroups (fps_bucket_split_kernel) -- measured SLOWER than
+                            // the L2-resident kernel (1.9-2.6 vs 1.33 us per round at config 5, profiles/r05_fps_split.txt): off; 2 / 4 / 6: without the exchange (timing)
 extern "C" void votenet_debug_fps_split(int on) { g_fps_split = on; } // A/B and test hook
 extern "C" unsigned votenet_debug_fps_split_timeouts(void)            // polls of the split kernel that gave up (0 unless a part never ran)
 {
@@ -1507,6 +1507,25 @@ extern "C" unsigned votenet_debug_fps_split_timeouts(void)            // polls o
 }
 static int g_fps_lds_floor = 0;
 extern "C" void votenet_debug_fps_lds_floor(int bytes) { g_fps_lds_floor = bytes > 0 ? bytes : 0; } // tuning hook
+
+template <int NW, int VW, int W>
+static void fps_split_launch(int b, int n, int m, const float *inp, float *temp, const float *boxes, const float4 *sorted, int *out, int ablate,
+                             hipStream_t st)
+{
+    static_assert(NW * VW * W * 64 >= kFpsSplitMax && 5 * W <= 64 && W <= kFpsSplitW, "split shape");
+    constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_split_kernel<NW, VW, W>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        attr_set = true;
+    }
+    unsigned long long *xch =
+        reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(temp + spatial_index_floats(b, n)) + 15) & ~(uintptr_t)15);
+    if (hipMemsetAsync(xch, 0, (fps_split_floats(b) - 4) * sizeof(float), st) != hipSuccess) return;
+    hipLaunchKernelGGL((fps_bucket_split_kernel<NW, VW, W>), dim3(8 * W * ((b + 7) / 8)), dim3(NW * 64), lds, st, b, n, m, inp, boxes, sorted,
+                       out, xch, ablate);
+}
 
 extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
 {
@@ -1554,18 +1573,12 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
         float *boxes = sidx.bbox;
         float4 *sorted = sidx.sorted;
         if (g_fps_split && n <= kFpsSplitMax && b <= kFpsSplitScenes) {
-            constexpr size_t lds = (size_t)12 * 32 * 64 * 4 + 2 * 16 * 5 * 4;
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&fps_bucket_split_kernel<12, 32, kFpsSplitW>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                attr_set = true;
-            }
-            unsigned long long *xch = reinterpret_cast<unsigned long long *>(
-                (reinterpret_cast<uintptr_t>(temp + spatial_index_floats(b, n)) + 15) & ~(uintptr_t)15);
-            if (hipMemsetAsync(xch, 0, (fps_split_floats(b) - 4) * sizeof(float), st) != hipSuccess) return check_launch("farthest_point_sample");
-            hipLaunchKernelGGL((fps_bucket_split_kernel<12, 32, kFpsSplitW>), dim3(8 * kFpsSplitW * ((b + 7) / 8)), dim3(12 * 64), lds, st, b, n,
-                               m, inp, boxes, sorted, out, xch, g_fps_split == 2 ? 1 : 0);
+            // 1 (and 2 = its timing ablation): 4 workgroups x 12 waves; 3 (4): 12 workgroups x 4 waves -- one wave per SIMD, every
+            // instruction of the round issued once per SIMD instead of three times; 5 (6): 6 workgroups x 8 waves
+            const int abl = (g_fps_split % 2 == 0) ? 1 : 0;
+            if (g_fps_split <= 2) fps_split_launch<12, 32, 4>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            else if (g_fps_split <= 4) fps_split_launch<4, 32, 12>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            else fps_split_launch<8, 32, 6>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
         } else if (nb <= 16 * 64)
             hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 1>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
         else if (nb <= 16 * 64 * 2)
