@@ -368,3 +368,54 @@ def test_level_with_the_count_on_the_device_and_the_xyz_gradient(hiplib, dev, ra
         P.HALF_GROUPS = True
     assert relerr(out_d, out_f) < 5e-5 and relerr(df_d, df_f) < 1e-3 and relerr(dx_d, dx_f) < 1e-3
     assert float((g_d.double() - g_f.double()).norm() / g_f.double().norm()) < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["pieces", "full"])
+def test_pooled_input_gradient_is_bit_reproducible_beside_matrix_kernels(hiplib, dev, layout):
+    """Guard for the packed-f32 hazard of round 5 (profiles/r05_pk_opsel_hazard.txt): v_pk_fma_f32 whose low half takes
+    src1's HIGH register returns wrong low halves in lanes 48-63 while another kernel's MFMA wavefronts share the compute unit -- the
+    arg-max scatter's row loop had that form (one list entry missing in 16 columns of a row, now and then).  Its rows are stored, not
+    accumulated: launched again and again on the same inputs BESIDE split-operand GEMMs on a second stream, every result must be
+    bit-equal to the first.  A behavioural guard only: with the hazardous operand order this test still passes most of the time (the
+    window needs MFMA wavefronts on the scatter's own compute units; in the step it took three processes to open it) -- the proof that
+    the form is absent is tools/check_isa_hazards.py (tests/test_abi.py), the proof that it is harmful tools/probe/src/pk_opsel_hazard.hip."""
+    from votenet_amd import mlp as M
+    g = torch.Generator().manual_seed(11)
+    rnd = lambda *s: torch.randn(*s, generator=g).to(dev)
+    G, cin, cout = 4096, 128, 256
+    half = None
+    if layout == "pieces":
+        cnt = torch.randint(1, 65, (1, G), generator=g, dtype=torch.int32).to(dev)
+        half = M.half_groups(cnt)
+        half.resolve()
+        rows = half.rows
+        argmax = (torch.rand(G, cout, generator=g).to(dev) * cnt.view(G, 1).float()).int().clamp_(0, 63)
+    else:
+        rows = G * 64
+        argmax = torch.randint(0, 64, (G, cout), generator=g, dtype=torch.int32).to(dev)
+    xz = rnd(rows, cin)
+    w, b = rnd(cin, cout) * 0.1, rnd(cout) * 0.1
+    wT = w.t().contiguous()
+    coef, gout, zsel = rnd(5 * cout) * 0.3, rnd(G, cout), rnd(G, cout)
+    sc, sh = torch.rand(cin, generator=g).to(dev) + 0.5, rnd(cin) * 0.1
+    below = (sc, sh, rnd(cin) * 0.1, torch.rand(cin, generator=g).to(dev) + 0.5, True)
+    # the neighbour: a split-operand (MFMA) GEMM on a second stream, launched around every call
+    side = torch.cuda.Stream()
+    ax, aw = rnd(65536, 256), (rnd(256, 256) * 0.1).contiguous()
+    imgs = M.SplitImages([aw])
+    imgs.refresh()
+    ref, bad = None, 0
+    for it in range(40):
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                M.linear_dense(ax, aw, None, None, None, False, want_stats=False)
+        da, _ = M.pool_dgrad(xz, sc, sh, True, w, b, wT, coef, True, gout, argmax, zsel, 64, below=below, half=half)
+        torch.cuda.synchronize()
+        live = da if half is None else da[:16 * half.nh]
+        if ref is None:
+            ref = live.clone()
+        elif not torch.equal(live, ref):
+            bad += 1
+    imgs.close()
+    assert bad == 0, "%d of 39 repeats differ from the first launch" % bad
