@@ -266,7 +266,11 @@ int main(int argc, char **argv)
 {
     const int launches = argc > 1 ? atoi(argv[1]) : 200;
     const int side = argc > 2 ? atoi(argv[2]) : 0;
-    const int trips = 64, rounds = 48, grid = 256;
+    // argv[4] = workgroups of the checked kernels (default 256: one per CU), argv[5] = dynamic LDS bytes the MFMA neighbour asks for (with
+    // 32768 it cannot share a CU with a checked workgroup of the LDS-fed kernel: is the hazard local to a compute unit?)
+    const int trips = 64, rounds = 48, grid = argc > 4 ? atoi(argv[4]) : 256;
+    const int side_lds = argc > 5 ? atoi(argv[5]) : 0;
+    const int regs_lds = argc > 6 ? atoi(argv[6]) : 0; // unused dynamic LDS of the register-fed kernels (131072 + a neighbour asking for 32768: never on one CU)
     std::vector<float> table(NC * CIN), vals(4096);
     std::vector<unsigned short> codes(4096);
     unsigned s = 12345u;
@@ -305,7 +309,7 @@ int main(int argc, char **argv)
     CHECK(hipStreamCreate(&st2));
     // 1. the self-checking kernel
     for (int l = 0; l < launches; l++) {
-        if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+        if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), side_lds, st2, 4000, d_side);
             if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
         hipLaunchKernelGGL(pk_kernel, dim3(grid), dim3(NWV * 64), smem, st, d_table, d_vals, d_codes, trips, rounds, d_bad, d_out);
     }
@@ -320,9 +324,10 @@ int main(int argc, char **argv)
     for (int form = 1; form <= 10; form++) {
         CHECK(hipMemset(d_bad, 0, 8));
         for (int l = 0; l < launches; l++) {
-            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), side_lds, st2, 4000, d_side);
             if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
-#define GO(F) case F: hipLaunchKernelGGL(pk_kernel_regs<F>, dim3(grid), dim3(NWV * 64), 0, st, trips * 8, rounds, d_bad, d_out); break;
+#define GO(F) case F: if (l == 0 && regs_lds) CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(pk_kernel_regs<F>), hipFuncAttributeMaxDynamicSharedMemorySize, regs_lds)); \
+    hipLaunchKernelGGL(pk_kernel_regs<F>, dim3(grid), dim3(NWV * 64), regs_lds, st, trips * 8, rounds, d_bad, d_out); break;
             switch (form) { GO(1) GO(2) GO(3) GO(4) GO(5) GO(6) GO(7) GO(8) GO(9) GO(10) }
 #undef GO
         }
@@ -335,7 +340,7 @@ int main(int argc, char **argv)
     std::vector<float> ref(per), got(per);
     for (int form = 1; form >= 0; form--) {
         auto launch = [&](float *dst) {
-            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
+            if (side == 1) hipLaunchKernelGGL(mfma_side, dim3(1024), dim3(256), side_lds, st2, 4000, d_side);
             if (side == 2) hipLaunchKernelGGL(valu_side, dim3(1024), dim3(256), 0, st2, 4000, d_side);
             if (form)
                 hipLaunchKernelGGL(pk_kernel_one<true>, dim3(grid), dim3(NWV * 64), smem, st, d_table, d_vals, d_codes, trips, rounds, dst);
