@@ -426,6 +426,12 @@ def main():
             tf_sampling.PROFILE_EVENTS, tf_grouping.PROFILE_EVENTS = [], []
         step()
         tf_sampling.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS = None
+    # The interpreter's garbage pass and the step-boundary events BEFORE the warm-up: between the warm-up's last step and the first timed
+    # one there is then nothing but the barrier.  (With a gc.collect() -- tens of milliseconds of an idle GPU -- behind the warm-up, the first
+    # four timed steps took 4.1 / 3.8 / 3.65 / 3.67 ms instead of 3.55: tools/probe/step_series.py, the device has to wake up again.)
+    gc.collect()
+    gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -442,9 +448,6 @@ def main():
     # launch-by-launch chain costs it (right after the barrier the queue is empty and the same steps took 6.1 and 4.9 ms)
     prof_first = (args.steps - prof_steps) // 2
     events, bq_events, gemm_events = [], [], []
-    gc.collect()
-    gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
     t0 = time.perf_counter()
     host_marks = [t0]
     marks[0].record()
