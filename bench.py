@@ -424,14 +424,16 @@ def main():
         # 4.16 ms per step around a median of 3.79)
         if k == SETUP_STEPS - 3 and workload == "train" and pipeline:
             tf_sampling.PROFILE_EVENTS, tf_grouping.PROFILE_EVENTS = [], []
+        if k == SETUP_STEPS - 2:
+            # The interpreter's garbage pass and the step-boundary events two set-up steps BEFORE the warm-up: between the last untimed
+            # step and the first timed one there is then nothing but the barrier, whatever W is.  (With a gc.collect() -- tens of
+            # milliseconds of an idle GPU -- right in front of the timed region its first four steps took 4.1 / 3.8 / 3.65 / 3.67 ms instead
+            # of 3.55: tools/probe/step_series.py, profiles/r05_bench_start.txt -- the device has to wake up again.)
+            gc.collect()
+            gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
+            marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
         step()
         tf_sampling.PROFILE_EVENTS = tf_grouping.PROFILE_EVENTS = None
-    # The interpreter's garbage pass and the step-boundary events BEFORE the warm-up: between the warm-up's last step and the first timed
-    # one there is then nothing but the barrier.  (With a gc.collect() -- tens of milliseconds of an idle GPU -- behind the warm-up, the first
-    # four timed steps took 4.1 / 3.8 / 3.65 / 3.67 ms instead of 3.55: tools/probe/step_series.py, the device has to wake up again.)
-    gc.collect()
-    gc.disable()  # a cyclic-garbage pass of the interpreter in the middle of 20 steps shows up as a 30 ms step (measured)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]  # one per step boundary: the per-step spread
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
