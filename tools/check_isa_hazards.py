@@ -52,6 +52,9 @@ def hazards(lib):
 def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(root, "votenet_amd", "lib", "libvotenet_hip.so")
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):  # a box without the ROCm LLVM tools: the build goes on, tests/test_abi.py checks where they exist
+        print("check_isa_hazards: %s/llvm-objdump not found, %s NOT checked" % (LLVM, lib))
+        return 0
     found = hazards(lib)
     if not found:
         print("check_isa_hazards: %s is clean" % lib)
