@@ -1,6 +1,6 @@
 """Same-box A/B of the train step for an attribute of the net object:  python tools/ab_net.py overlap_wgrad True False   (scratch tool)"""
 import os, sys, time, gc
-R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path[:0] = [R]
+R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))); sys.path[:0] = [R]
 import torch
 from votenet_amd import loss as VL, model as VM, synth
 attr = sys.argv[1]
