@@ -17,17 +17,24 @@
  * Ownership is the reference's: the caller owns every buffer, launchers never allocate,
  * gradient buffers must be zeroed by the caller (tf_sampling.cpp:174, tf_grouping.cpp:204,
  * tf_interpolate.cpp:258).  All tensors are dense, row-major, fp32 / int32.
- * Calls are asynchronous with respect to the host and stateless (re-entrant).  No launcher synchronises with the device, allocates
+ * Calls are asynchronous with respect to the host and re-entrant.  What a call does depends on its arguments only, with two
+ * documented pieces of per-thread / registered state: the split-K arming (votenet_mlp_split_k_*: per calling thread, consumed by the
+ * next launch) and the bf16 x 3 weight images a host registers (votenet_register_split_weights: keyed by the weight pointer).  The
+ * process-global measurement / tuning switches live in votenet_hip_debug.h and are INERT unless the host opts in with
+ * votenet_debug_enable(1) (or VOTENET_DEBUG=1 in the environment): a drop-in consumer never sees them.  The shared object exports
+ * exactly the functions declared in these two headers plus the reference's eight launcher names (csrc/exports.map, checked by
+ * tests/test_abi.py); nothing else is visible.  No launcher synchronises with the device, allocates
  * device memory or copies from pageable host memory, so a sequence of calls on one stream can be captured into a HIP graph
  * (hipStreamBeginCapture ... hipStreamEndCapture) and replayed over the same buffers: the host side does that with the whole
  * coordinate-only chain of a batch (votenet_farthest_point_sample, votenet_gather_point, votenet_query_ball_point*, votenet_three_nn,
  * votenet_half_groups, votenet_assemble_rows_half / votenet_narrow_rows_half, votenet_half_sort_rows: votenet_amd/model.py,
  * GeometryGraph).  votenet_half_groups writes its count into a mapped pinned host int (nh_host): that works from a graph too.
  *
- * libvotenet_hip.so additionally exports the reference's launcher names with their exact
- * C++ signatures (farthestpointsamplingLauncher, gatherpointLauncher, scatteraddpointLauncher,
- * queryBallPointLauncher, groupPointLauncher, groupPointGradLauncher), so tf_sampling.cpp /
- * tf_grouping.cpp link against it unchanged in place of tf_*_g.cu.o -- see INTEGRATION.md.
+ * libvotenet_hip.so additionally exports the reference's EIGHT launcher names with their exact
+ * C++ signatures (probsampleLauncher, farthestpointsamplingLauncher, gatherpointLauncher,
+ * scatteraddpointLauncher -- tf_sampling.cpp:65,94,125,150; queryBallPointLauncher,
+ * selectionSortLauncher, groupPointLauncher, groupPointGradLauncher -- tf_grouping.cpp:66,108,142,173),
+ * so tf_sampling.cpp / tf_grouping.cpp link against it unchanged in place of tf_*_g.cu.o -- see INTEGRATION.md.
  */
 #ifndef VOTENET_HIP_H
 #define VOTENET_HIP_H
@@ -61,14 +68,6 @@ const char *votenet_version(void);
  * Bit-exact with the reference rule: start at 0, running distance 1e38, arg-max of
  * min(d, running) with ties -> smallest (k mod 512), then smallest k. */
 int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream);
-/* Experiment hook (not part of the drop-in surface): route 4096 < n <= 24576 through the kernel that emits up to two samples
- * per round (same indices, same order; DESIGN_HISTORY.md 4.1).  Off by default: measured slower than the one-sample rounds. */
-void votenet_fps_debug_two_pick(int on);
-void votenet_debug_fps_split(int on);            /* 24 576 < n <= 98 304: one scene over 4 (on = 1), 12 (3) or 6 (5) workgroups; same indices, measured slower: 0 by default */
-unsigned votenet_debug_fps_split_timeouts(void); /* polls of the split kernel that gave up (0 unless a part of a scene never ran) */
-/* Measurement hook: 0 disables the parallel "already in farthest-point order?" check that precedes the sampling rounds for
- * n <= 2048 (DESIGN_HISTORY.md 4.1); the result is the same either way. */
-void votenet_fps_debug_prefix_check(int on);
 size_t votenet_fps_temp_floats(int b, int n);
 
 /* Replaces gatherpointLauncher (tf_sampling.cpp:125, tf_sampling_g.cu:172-181,206-208).
@@ -103,9 +102,6 @@ int votenet_query_ball_point_indexed(int b, int n, int m, float radius, int nsam
  * the row uninitialised).  Requires radius > 0, nsample > 0 (tf_grouping.cpp:71,74). */
 int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                              const float *xyz2, int *idx, int *pts_cnt, void *stream);
-/* Measurement hook: which kernel serves n <= 2048 (0 = by cloud size: 16 waves, one super-chunk; 4 = four waves x eight groups;
- * 16 = sixteen waves x eight groups).  Same indices and counts in every form. */
-void votenet_debug_ball_query_small(int form);
 
 /* Host helper (no GPU work): the squared-distance threshold the ball-query kernel compares
  * against, T(r) = smallest fp32 with sqrtf(T) >= r, so that  s < T(r)  <=>  sqrtf(s) < r
@@ -512,33 +508,10 @@ int votenet_register_split_weights(const float *w, int cin, int cout, const void
  *                                       votenet_mlp_dgrad_bn_reduce launch of these sizes would use split (0: it would not split);
  *   votenet_mlp_split_k_arm(ws, floats) hands the workspace (any contents, alive until the launch has run) to the NEXT such launch
  *                                       of the calling thread; the launch consumes it whether it splits or not (NULL, 0: disarm).
- * An unarmed launch never splits.  votenet_debug_split_k: tuning hook (target workgroups, maximum parts, minimum slabs per part,
- * launches of at least that many output tiles are left alone; 0 keeps a value). */
+ * An unarmed launch never splits (tuning hook: votenet_debug_split_k, votenet_hip_debug.h). */
 long votenet_mlp_split_k_floats(long rows, int cin, int cout);
 int votenet_mlp_split_k_arm(void *ws, long floats);
 int votenet_mlp_split_k_tickets(void *tickets, long n);
-void votenet_debug_split_k(int target_wgs, int max_parts, int min_slabs, int max_wgs);
-/* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used; another
- * value: a mask over GEMM families (mlp_fast.hip, bf3_family) */
-void votenet_debug_fast_bf3(int on);
-/* votenet_mlp_gram on split operands as well (pool_bwd.hip: 8 consecutive rows of a channel per MFMA fragment; c = 64 or 128,
- * no scratch = atomics mode); 0: the fp32 MFMA kernel always.  Default 1. */
-void votenet_debug_gram_bf3(int on);
-void votenet_debug_fast_xcd_chunk(int on); /* 1 (default): the piece-layout GEMMs that gather the per-point table take their row tiles in
-                                              per-XCD contiguous chunks (an XCD's L2 then holds the scenes its tiles touch); 0: round-robin */
-void votenet_debug_gram_workgroups(int n); /* tuning hook: workgroups of the split-operand Gram kernel (default 384) */
-void votenet_debug_bn_reduce_passes(int n); /* tuning hook: row passes per workgroup of the dense BatchNorm-backward reduction (default 16) */
-void votenet_debug_zsel_grid(int groups_per_wg, int cap); /* tuning hook: grid of the pooled BatchNorm-backward reduction (default 32 groups per workgroup, at most 256 workgroups: measured optimum, tools/serial_last_step.sh) */
-void votenet_debug_assemble_stats(int cap, int u); /* tuning hook: assemble_stats workgroups per column block (default 128) and points in flight per thread (4 or 8, default 8) */
-/* every other weight-gradient GEMM (votenet_mlp_wgrad / _wgrad_bn, assembled, narrow) on split operands: row-major bf16 images in LDS,
- * fragments through ds_read_b64_tr_b16 (mlp_wgrad_fast.hip); 0: the fp32 MFMA kernel.  Default 1. */
-void votenet_debug_wgrad_bf3(int on);
-/* measurement hook (DESIGN_HISTORY.md 4.3): votenet_pool_dgrad_scatter walks its groups back to front.  Default 0. */
-void votenet_debug_scatter_reverse(int on);
-void votenet_debug_sparse_workgroups(int n); /* tuning hook: workgroups of votenet_pool_wgrad_sparse (default 384) */
-void votenet_debug_sparse_teams(int teams, int wgs); /* tuning hook: 1 or 2 (default) teams per workgroup on the piece layout; workgroups of the 2-team form (default 256) */
-void votenet_debug_scatter_workgroups(int n); /* tuning hook: workgroups of votenet_pool_dgrad_scatter (0 = default) */
-void votenet_debug_scatter_form(int form); /* 1 (default): one wavefront per group, no barriers; 0: one workgroup per group */
 
 /* out (rows x 3) = dz (rows x c) * w3 (3 x c)^T: the xyz columns of an input gradient (dz W[0:3]^T), c % 4 == 0. */
 int votenet_rows_dot3(long rows, int c, const float *dz, const float *w3, float *out, void *stream);
@@ -777,7 +750,8 @@ int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout, const floa
                                    float *dw, float *colsum, const int *hc, const float *wh, const int *nh_dev, void *stream);
 /* The same walking CENTRES (round 5): pos = the layout's (G, 3) table of every centre's pieces j >= 1 (votenet_half_groups); all kept
  * pieces of a ball are staged together and every channel reads its arg-max row once -- the piece form sends every wavefront through
- * the row loop once per piece with 1 / pieces of its lanes live.  Same sums in another association. */
+ * the row loop once per piece with 1 / pieces of its lanes live.  Same sums in another association.
+ * Limit: nh * 16 * cin * 4 < 2^31 bytes (32-bit buffer offsets; VOTENET_E_INVALID above it -- call the piece form there). */
 int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, int cout, const float *xz, const float *in_scale, const float *in_shift,
                                            int in_relu, const float *gout, const int *argmax, const float *zsel, const float *coef,
                                            int relu, float *dw, float *colsum, const int *pos, const float *wh, const int *nh_dev,

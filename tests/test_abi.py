@@ -12,10 +12,73 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "votenet_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(votenet_[a-z0-9_]+)\s*\(", text)))
+def declared_symbols(headers=("votenet_hip.h", "votenet_hip_debug.h")):
+    syms = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        syms |= set(re.findall(r"\b(votenet_[a-z0-9_]+)\s*\(", text))
+    return sorted(syms)
+
+
+LAUNCHERS = ["farthestpointsamplingLauncher(int, int, int, float const*, float*, int*)",
+             "gatherpointLauncher(int, int, int, float const*, int const*, float*)",
+             "scatteraddpointLauncher(int, int, int, float const*, int const*, float*)",
+             "queryBallPointLauncher(int, int, int, float, int, float const*, float const*, int*, int*)",
+             "groupPointLauncher(int, int, int, int, int, float const*, int const*, float*)",
+             "groupPointGradLauncher(int, int, int, int, int, float const*, int const*, float*)",
+             "probsampleLauncher(int, int, int, float const*, float const*, float*, int*)",
+             "selectionSortLauncher(int, int, int, int, float const*, int*, float*)"]
+
+
+def test_export_list_is_exactly_the_two_headers_plus_the_eight_launchers(hiplib):
+    """The drop-in library exports the C ABI it declares and the reference's launcher names -- no kernel stubs, no votenet:: internals,
+    no global variables (csrc/exports.map, -fvisibility=hidden)."""
+    from votenet_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.lib_path()], capture_output=True, text=True, check=True).stdout
+    exported = set()
+    for line in out.splitlines():
+        parts = line.split(None, 2)
+        assert parts[1] in "Tt", "a non-function export: " + line   # no data symbols (the old g_* switches)
+        exported.add(parts[2])
+    assert exported == set(declared_symbols()) | set(LAUNCHERS), sorted(exported ^ (set(declared_symbols()) | set(LAUNCHERS)))
+    assert not [s for s in exported if "votenet::" in s]
+    # the switches are all in the debug header, none in the drop-in one
+    assert not [s for s in declared_symbols(("votenet_hip.h",)) if "debug" in s]
+
+
+def test_debug_switches_are_inert_until_the_host_opts_in():
+    """include/votenet_hip_debug.h: a consumer that never calls votenet_debug_enable(1) gets launches that depend on their arguments only.
+    Own process (the suite's shared handle has long opted in)."""
+    import sys
+    from votenet_amd import _lib
+    code = (
+        "import ctypes, os, sys\n"
+        "os.environ.pop('VOTENET_DEBUG', None)\n"
+        "L = ctypes.CDLL(sys.argv[1])\n"
+        "L.votenet_last_error.restype = ctypes.c_char_p\n"
+        "assert L.votenet_debug_enabled() == 0\n"
+        "L.votenet_debug_fast_bf3(0)\n"
+        "assert b'debug switches are disabled' in L.votenet_last_error(), L.votenet_last_error()\n"
+        "assert L.votenet_debug_enabled() == 0\n"
+        "L.votenet_debug_enable(1)\n"
+        "assert L.votenet_debug_enabled() == 1\n"
+        "L.votenet_debug_enable(0)\n"
+        "assert L.votenet_debug_enabled() == 0\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code, _lib.lib_path()], capture_output=True, text=True)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+    env = dict(os.environ, VOTENET_DEBUG="1")
+    code2 = ("import ctypes, sys\nL = ctypes.CDLL(sys.argv[1])\nL.votenet_debug_fast_bf3(1)\nassert L.votenet_debug_enabled() == 1\nprint('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code2, _lib.lib_path()], capture_output=True, text=True, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_python_host_opts_in_on_first_switch_lookup(hiplib):
+    from votenet_amd import _lib
+    L = _lib.lib()
+    L.votenet_debug_gram_workgroups  # a lookup is enough
+    assert L.votenet_debug_enabled() == 1
 
 
 def test_header_declares_the_path():
@@ -35,14 +98,7 @@ def test_library_exports_reference_launcher_names(hiplib):
     """tf_sampling.cpp:65,94,125,150 and tf_grouping.cpp:66,108,142,173 declare these eight (C++ linkage)."""
     from votenet_amd import _lib
     out = subprocess.run(["nm", "-D", "--defined-only", "-C", _lib.lib_path()], capture_output=True, text=True).stdout
-    for sig in ["farthestpointsamplingLauncher(int, int, int, float const*, float*, int*)",
-                "gatherpointLauncher(int, int, int, float const*, int const*, float*)",
-                "scatteraddpointLauncher(int, int, int, float const*, int const*, float*)",
-                "queryBallPointLauncher(int, int, int, float, int, float const*, float const*, int*, int*)",
-                "groupPointLauncher(int, int, int, int, int, float const*, int const*, float*)",
-                "groupPointGradLauncher(int, int, int, int, int, float const*, int const*, float*)",
-                "probsampleLauncher(int, int, int, float const*, float const*, float*, int*)",
-                "selectionSortLauncher(int, int, int, int, float const*, int*, float*)"]:
+    for sig in LAUNCHERS:
         assert sig in out, sig
     assert out.count("Launcher(") == 8
 

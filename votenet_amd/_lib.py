@@ -214,6 +214,17 @@ _SIGS.update({
 })
 
 
+class _Library(ctypes.CDLL):
+    """The library's measurement / tuning switches (include/votenet_hip_debug.h) are inert until the host opts in.  This host opts in
+    the first time something (a test, a profile tool, mlp.debug_switch) looks one up; code that never touches a switch never does."""
+
+    def __getattr__(self, name):  # only reached for names not bound yet (CDLL caches what it has resolved)
+        fn = super().__getattr__(name)
+        if "debug" in name and name not in ("votenet_debug_enable", "votenet_debug_enabled", "votenet_debug_fps_split_timeouts"):
+            super().__getattr__("votenet_debug_enable")(1)
+        return fn
+
+
 def lib():
     """Load the library once; raise loudly if it has not been built."""
     global _lib
@@ -222,7 +233,7 @@ def lib():
             raise VotenetError(
                 "libvotenet_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % _LIB_PATH)
-        L = ctypes.CDLL(_LIB_PATH)
+        L = _Library(_LIB_PATH)
         L.votenet_last_error.restype = ctypes.c_char_p
         L.votenet_version.restype = ctypes.c_char_p
         L.votenet_fps_temp_floats.restype = ctypes.c_size_t

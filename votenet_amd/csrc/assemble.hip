@@ -174,6 +174,7 @@ extern "C" int votenet_assemble_rows(int b, int n, int m, int nsample, const flo
 static int g_asm_stats_cap = 128, g_asm_stats_u = 8; // (8 points in flight: 11.9 / 8.2 / 7.2 -> 10.6 / 7.5 / 6.5 us; 256 workgroups: no better)
 extern "C" void votenet_debug_assemble_stats(int cap, int u) // tuning hook: workgroups per column block, points in flight per thread and trip
 {
+    VN_DEBUG_GATE();
     g_asm_stats_cap = cap > 0 ? cap : 128;
     g_asm_stats_u = u == 4 ? 4 : 8;
 }

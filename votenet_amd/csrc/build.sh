@@ -7,11 +7,14 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 OUT="$HERE/../lib"
 mkdir -p "$OUT" "$HERE/obj"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -ffp-contract=off -Wall -Wno-unused-function"
 pids=()
 for src in "$HERE"/*.hip; do
   obj="$HERE/obj/$(basename "${src%.hip}").o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/mlp_types.h" -nt "$obj" ] || [ "$HERE/../../include/votenet_hip.h" -nt "$obj" ]; then
+  # (this script carries the flags: an object older than it is stale too)
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/common.h" -nt "$obj" ] || [ "$HERE/mlp_types.h" -nt "$obj" ] \
+     || [ "$HERE/../../include/votenet_hip.h" -nt "$obj" ] || [ "$HERE/../../include/votenet_hip_debug.h" -nt "$obj" ] \
+     || [ "${BASH_SOURCE[0]}" -nt "$obj" ]; then
     extra=""
     # fps.hip: no NaN can occur (distances of finite points); dropping NaN canonicalisation shortens the
     # serial per-round instruction chain.  Infinities (empty bucket boxes) are still honoured.
@@ -25,6 +28,11 @@ for src in "$HERE"/*.hip; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC "$HERE"/obj/*.o -o "$OUT/libvotenet_hip.so"
-python3 "$HERE/../../tools/check_isa_hazards.py" "$OUT/libvotenet_hip.so"
+# Link under a temporary name, run the ISA-hazard gate on THAT, and only then move it into place: a library that fails the gate never
+# becomes the one later imports load.  exports.map: only the votenet_* C ABI and the reference's eight launcher names are visible.
+TMP="$OUT/.libvotenet_hip.so.tmp.$$"
+trap 'rm -f "$TMP"' EXIT
+$HIPCC --offload-arch=gfx950 -shared -fPIC -Wl,--version-script="$HERE/exports.map" "$HERE"/obj/*.o -o "$TMP"
+python3 "$HERE/../../tools/check_isa_hazards.py" "$TMP"
+mv -f "$TMP" "$OUT/libvotenet_hip.so"
 echo "built $OUT/libvotenet_hip.so"

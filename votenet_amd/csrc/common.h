@@ -3,7 +3,12 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+// the library is built -fvisibility=hidden: only what the two public headers declare (and the reference's launcher names, VN_EXPORT) is exported
+#pragma GCC visibility push(default)
 #include "../../include/votenet_hip.h"
+#include "../../include/votenet_hip_debug.h"
+#pragma GCC visibility pop
+#define VN_EXPORT __attribute__((visibility("default")))
 
 namespace votenet {
 
@@ -11,6 +16,15 @@ namespace votenet {
 int set_error(int code, const char *fmt, ...);
 int check_launch(const char *what);
 inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// The votenet_debug_* / votenet_fps_debug_* switches (include/votenet_hip_debug.h) are process-global measurement / tuning hooks.  They do
+// nothing until votenet_debug_enable(1) has been called (or VOTENET_DEBUG=1 was in the environment when the first one was called): a host that
+// never opts in gets a library whose launches depend on their arguments only.
+bool debug_gate(const char *name);
+#define VN_DEBUG_GATE()                                      \
+    do {                                                     \
+        if (!::votenet::debug_gate(__func__)) return;        \
+    } while (0)
 
 #define VN_REQUIRE(cond, ...)                                                   \
     do {                                                                        \

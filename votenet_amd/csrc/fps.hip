@@ -1456,15 +1456,18 @@ static int g_fps_dbg_nw = 0, g_fps_dbg_p = 0;
 static int g_fps_prefix_check = 1;
 extern "C" void votenet_fps_debug_prefix_check(int on) // measurement hook: 0 = always run the sampling rounds
 {
+    VN_DEBUG_GATE();
     g_fps_prefix_check = on;
 }
 static int g_fps_two_pick = 0; // 1: two samples per round; 2: that kernel with the second pick disabled (measurement)
 extern "C" void votenet_fps_debug_two_pick(int on) // experiment hook: fps_bucket2_kernel (two samples per round) for 4096 < n <= 24576
 {
+    VN_DEBUG_GATE();
     g_fps_two_pick = on;
 }
 extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a brute-force configuration (0,0 = automatic)
 {
+    VN_DEBUG_GATE();
     g_fps_dbg_nw = nw;
     g_fps_dbg_p = p;
 }
@@ -1498,7 +1501,7 @@ extern "C" void votenet_fps_debug_config(int nw, int p) // tuning hook: force a 
 
 static int g_fps_split = 0; // 1 / 3 / 5: 24 576 < n <= 98 304 samples one scene over 4 / 12 / 6 workgroups (fps_bucket_split_kernel) -- measured SLOWER than
                             // the L2-resident kernel (1.9-2.6 vs 1.33 us per round at config 5, profiles/r05_fps_split.txt): off; 2 / 4 / 6: without the exchange (timing)
-extern "C" void votenet_debug_fps_split(int on) { g_fps_split = on; } // A/B and test hook
+extern "C" void votenet_debug_fps_split(int on) { VN_DEBUG_GATE(); g_fps_split = on; } // A/B and test hook
 extern "C" unsigned votenet_debug_fps_split_timeouts(void)            // polls of the split kernel that gave up (0 unless a part never ran)
 {
     unsigned v = 0;
@@ -1506,11 +1509,11 @@ extern "C" unsigned votenet_debug_fps_split_timeouts(void)            // polls o
     return v;
 }
 static int g_fps_lds_floor = 0;
-extern "C" void votenet_debug_fps_lds_floor(int bytes) { g_fps_lds_floor = bytes > 0 ? bytes : 0; } // tuning hook
+extern "C" void votenet_debug_fps_lds_floor(int bytes) { VN_DEBUG_GATE(); g_fps_lds_floor = bytes > 0 ? bytes : 0; } // tuning hook
 
 template <int NW, int VW, int W>
-static void fps_split_launch(int b, int n, int m, const float *inp, float *temp, const float *boxes, const float4 *sorted, int *out, int ablate,
-                             hipStream_t st)
+static int fps_split_launch(int b, int n, int m, const float *inp, float *temp, const float *boxes, const float4 *sorted, int *out, int ablate,
+                            hipStream_t st)
 {
     static_assert(NW * VW * W * 64 >= kFpsSplitMax && 5 * W <= 64 && W <= kFpsSplitW, "split shape");
     constexpr size_t lds = (size_t)NW * VW * 64 * 4 + 2 * 16 * 5 * 4;
@@ -1522,9 +1525,11 @@ static void fps_split_launch(int b, int n, int m, const float *inp, float *temp,
     }
     unsigned long long *xch =
         reinterpret_cast<unsigned long long *>((reinterpret_cast<uintptr_t>(temp + spatial_index_floats(b, n)) + 15) & ~(uintptr_t)15);
-    if (hipMemsetAsync(xch, 0, (fps_split_floats(b) - 4) * sizeof(float), st) != hipSuccess) return;
+    const hipError_t me = hipMemsetAsync(xch, 0, (fps_split_floats(b) - 4) * sizeof(float), st);
+    if (me != hipSuccess) return set_error(VOTENET_E_HIP, "FarthestPointSample (split): clearing the exchange words: %s", hipGetErrorString(me));
     hipLaunchKernelGGL((fps_bucket_split_kernel<NW, VW, W>), dim3(8 * W * ((b + 7) / 8)), dim3(NW * 64), lds, st, b, n, m, inp, boxes, sorted,
                        out, xch, ablate);
+    return VOTENET_OK;
 }
 
 extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *inp, float *temp, int *out, void *stream)
@@ -1576,9 +1581,11 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
             // 1 (and 2 = its timing ablation): 4 workgroups x 12 waves; 3 (4): 12 workgroups x 4 waves -- one wave per SIMD, every
             // instruction of the round issued once per SIMD instead of three times; 5 (6): 6 workgroups x 8 waves
             const int abl = (g_fps_split % 2 == 0) ? 1 : 0;
-            if (g_fps_split <= 2) fps_split_launch<12, 32, 4>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
-            else if (g_fps_split <= 4) fps_split_launch<4, 32, 12>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
-            else fps_split_launch<8, 32, 6>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            int rc;
+            if (g_fps_split <= 2) rc = fps_split_launch<12, 32, 4>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            else if (g_fps_split <= 4) rc = fps_split_launch<4, 32, 12>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            else rc = fps_split_launch<8, 32, 6>(b, n, m, inp, temp, boxes, sorted, out, abl, st);
+            if (rc != VOTENET_OK) return rc;
         } else if (nb <= 16 * 64)
             hipLaunchKernelGGL((fps_bucket_l2_kernel<16, 1>), dim3(b), dim3(1024), 0, st, n, m, inp, (const int *)temp, boxes, sorted, out);
         else if (nb <= 16 * 64 * 2)
@@ -1595,7 +1602,7 @@ extern "C" int votenet_farthest_point_sample(int b, int n, int m, const float *i
 // the reference's own launcher name, C++ linkage, exact signature (tf_sampling.cpp:94)
 // The reference's scratch is TensorShape{32, n} whatever the batch (tf_sampling.cpp:115): the bucket path needs about
 // 1.1*n floats per scene, so larger batches go through in slices that fit 32*n floats (launches are stream-ordered).
-void farthestpointsamplingLauncher(int b, int n, int m, const float *inp, float *temp, int *out)
+VN_EXPORT void farthestpointsamplingLauncher(int b, int n, int m, const float *inp, float *temp, int *out)
 {
     int chunk = b;
     while (chunk > 1 && votenet_fps_temp_floats(chunk, n) > (size_t)32 * (size_t)n) chunk--;

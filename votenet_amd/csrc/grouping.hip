@@ -220,7 +220,7 @@ using namespace votenet;
 extern "C" float votenet_ball_threshold(float radius) { return ball_threshold(radius); }
 
 static int g_bq_small = 0; // votenet_debug_ball_query_small: 0 = by cloud size, 4 = the four-wave kernel, 16 = sixteen waves x eight groups
-extern "C" void votenet_debug_ball_query_small(int form) { g_bq_small = form; }
+extern "C" void votenet_debug_ball_query_small(int form) { VN_DEBUG_GATE(); g_bq_small = form; }
 
 extern "C" int votenet_query_ball_point(int b, int n, int m, float radius, int nsample, const float *xyz1,
                                         const float *xyz2, int *idx, int *pts_cnt, void *stream)
@@ -431,16 +431,16 @@ extern "C" int votenet_group_point_grad(int b, int n, int c, int m, int nsample,
 }
 
 // ---- reference launcher names, C++ linkage, exact signatures (tf_grouping.cpp:66,142,173)
-void queryBallPointLauncher(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int *idx,
+VN_EXPORT void queryBallPointLauncher(int b, int n, int m, float radius, int nsample, const float *xyz1, const float *xyz2, int *idx,
                             int *pts_cnt)
 {
     votenet_query_ball_point(b, n, m, radius, nsample, xyz1, xyz2, idx, pts_cnt, nullptr);
 }
-void groupPointLauncher(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out)
+VN_EXPORT void groupPointLauncher(int b, int n, int c, int m, int nsample, const float *points, const int *idx, float *out)
 {
     votenet_group_point(b, n, c, m, nsample, points, idx, out, nullptr);
 }
-void groupPointGradLauncher(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points)
+VN_EXPORT void groupPointGradLauncher(int b, int n, int c, int m, int nsample, const float *grad_out, const int *idx, float *grad_points)
 {
     votenet_group_point_grad(b, n, c, m, nsample, grad_out, idx, grad_points, nullptr);
 }

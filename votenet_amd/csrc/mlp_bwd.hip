@@ -662,7 +662,7 @@ static MlpIn to_dev(const votenet_mlp_input *in)
 using namespace votenet;
 
 static int g_bn_reduce_passes = 16; // (32: 8-64 workgroups, 14-18 us per launch; 16: 10-12 us; 8: the 2*c atomics of 256-512 workgroups cost more than they buy -- tools/serial_last_step.sh)
-extern "C" void votenet_debug_bn_reduce_passes(int n) { g_bn_reduce_passes = n > 0 ? n : 16; } // tuning hook
+extern "C" void votenet_debug_bn_reduce_passes(int n) { VN_DEBUG_GATE(); g_bn_reduce_passes = n > 0 ? n : 16; } // tuning hook
 extern "C" int votenet_bn_backward_reduce(long rows, int c, int k, const float *da, const int *argmax, const float *z,
                                           const float *scale, const float *shift, const float *mean, const float *var,
                                           float eps, int relu, double *sums, const votenet_coef_tail *tail_, void *stream)

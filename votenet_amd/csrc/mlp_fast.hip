@@ -843,7 +843,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 for (int i = 0; i < MT; i++) {
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        const f32x2 v = f32x2{acc[i][j][e], acc[i][j][e + 1]} + bv2;
+                        const f32x2 v = bv2 + f32x2{acc[i][j][e], acc[i][j][e + 1]}; // broadcast operand FIRST: op_sel lands on src0 (packed-f32 hazard)
                         s1p[j] += v;
                         s2p[j] = __builtin_elementwise_fma(v, v, s2p[j]);
                     }
@@ -1772,15 +1772,16 @@ extern "C" int votenet_mlp_split_k_tickets(void *tickets, long n)
 }
 extern "C" void votenet_debug_split_k(int target_wgs, int max_parts, int min_slabs, int max_wgs) // tuning hook: 0 keeps a value
 {
+    VN_DEBUG_GATE();
     if (target_wgs > 0) votenet::g_sk_target = target_wgs;
     if (max_parts > 0) votenet::g_sk_max_parts = max_parts;
     if (min_slabs > 0) votenet::g_sk_min_slabs = min_slabs;
     if (max_wgs > 0) votenet::g_sk_max_wgs = max_wgs;
 }
 
-extern "C" void votenet_debug_fast_dyn_lds(int bytes) { votenet::g_fast_dyn_lds = bytes; }
-extern "C" void votenet_debug_fast_xcd_chunk(int on) { votenet::g_fast_xcd_chunk = on ? 1 : 0; }
-extern "C" void votenet_debug_fast_bf3(int on) { votenet::g_fast_bf3 = (on == 1) ? 63 : on; } // 0 off, 1 every family, else a mask
+extern "C" void votenet_debug_fast_dyn_lds(int bytes) { VN_DEBUG_GATE(); votenet::g_fast_dyn_lds = bytes; }
+extern "C" void votenet_debug_fast_xcd_chunk(int on) { VN_DEBUG_GATE(); votenet::g_fast_xcd_chunk = on ? 1 : 0; }
+extern "C" void votenet_debug_fast_bf3(int on) { VN_DEBUG_GATE(); votenet::g_fast_bf3 = (on == 1) ? 63 : on; } // 0 off, 1 every family, else a mask
 
 // BF3 weight images.  table (device, 4 longs per segment): source address (cin x cout floats, row-major), image address
 // (cin * cout * 6 bytes, 16-byte aligned), cin (% 16 == 0), cout.  One launch for all segments.
@@ -1818,6 +1819,7 @@ extern "C" int votenet_register_split_weights(const float *w, int cin, int cout,
 }
 extern "C" void votenet_debug_fast_workgroups(int cap22, int cap41) // tuning hook: 0 keeps a value
 {
+    VN_DEBUG_GATE();
     if (cap22 > 0) votenet::g_fast_cap22 = cap22;
     if (cap41 > 0) votenet::g_fast_cap41 = cap41;
 }

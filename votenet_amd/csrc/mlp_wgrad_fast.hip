@@ -503,5 +503,5 @@ bool wgrad_fast_launch(int mode, const MlpIn &d, long rows, int cin, int cout, c
 
 } // namespace votenet
 
-extern "C" void votenet_debug_wgrad_workgroups(int n) { votenet::g_wgrad_fast_wgs = n > 0 ? n : 0; } // tuning hook
-extern "C" void votenet_debug_wgrad_bf3(int on) { votenet::g_wgrad_bf3 = on ? 1 : 0; } // 0: the fp32 MFMA form of every weight gradient
+extern "C" void votenet_debug_wgrad_workgroups(int n) { VN_DEBUG_GATE(); votenet::g_wgrad_fast_wgs = n > 0 ? n : 0; } // tuning hook
+extern "C" void votenet_debug_wgrad_bf3(int on) { VN_DEBUG_GATE(); votenet::g_wgrad_bf3 = on ? 1 : 0; } // 0: the fp32 MFMA form of every weight gradient

@@ -919,6 +919,7 @@ extern "C" int votenet_pool_backward_supported(int cin, int cout, int k)
 static int g_zsel_groups = 32, g_zsel_cap = 256;
 extern "C" void votenet_debug_zsel_grid(int groups_per_wg, int cap) // tuning hook
 {
+    VN_DEBUG_GATE();
     g_zsel_groups = groups_per_wg > 0 ? groups_per_wg : 32;
     g_zsel_cap = cap > 0 ? cap : 256;
 }
@@ -964,13 +965,13 @@ extern "C" int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *
 }
 
 static int g_scatter_reverse = 0;
-extern "C" void votenet_debug_scatter_reverse(int on) { g_scatter_reverse = on ? 1 : 0; }
+extern "C" void votenet_debug_scatter_reverse(int on) { VN_DEBUG_GATE(); g_scatter_reverse = on ? 1 : 0; }
 static int g_scatter_nwv = 16; // votenet_debug_scatter_waves (tuning hook): wavefronts per workgroup of the 128 -> 256 piece-layout scatter (12 or 16)
-extern "C" void votenet_debug_scatter_waves(int n) { g_scatter_nwv = n == 12 ? 12 : 16; }
+extern "C" void votenet_debug_scatter_waves(int n) { VN_DEBUG_GATE(); g_scatter_nwv = n == 12 ? 12 : 16; }
 static int g_scatter_wgs = 0; // votenet_debug_scatter_workgroups (tuning hook): 0 = one workgroup per CU and LDS share
-extern "C" void votenet_debug_scatter_workgroups(int n) { g_scatter_wgs = n > 0 ? n : 0; }
+extern "C" void votenet_debug_scatter_workgroups(int n) { VN_DEBUG_GATE(); g_scatter_wgs = n > 0 ? n : 0; }
 static int g_scatter_form = 1; // 1: one wavefront per group (pool_dgrad_scatter_wave_kernel), 0: one workgroup per group
-extern "C" void votenet_debug_scatter_form(int form) { g_scatter_form = form ? 1 : 0; }
+extern "C" void votenet_debug_scatter_form(int form) { VN_DEBUG_GATE(); g_scatter_form = form ? 1 : 0; }
 static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, const float *gout, const int *argmax, const float *zsel,
                                      const float *coef, int relu, const float *wT, float *da, const float *below_z,
                                      const float *below_scale, const float *below_shift, const float *below_mean, const float *below_var,
@@ -1151,7 +1152,8 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
         // the piece's weight travels RAW with the register set and every thread loads it (round 5): under `if (whb && first_rg)` with the
         // square root right behind it this was a conditional load followed by s_waitcnt vmcnt(0) -- it drained the eight row loads just
         // issued, once per 16-row slab: the kernel ran at one exposed memory latency per slab
-        const int sw = s * 16 < nrow ? s : 0;
+        // (no weight array -- the full-row layout -- reads element 0 of scale_shift: always inside that array, never used)
+        const int sw = (whb != nullptr && s * 16 < nrow) ? s : 0;
         wq = whp[sw];
     };
     auto store = [&](int buf, const float (&r)[KPT], int s, float wq) {
@@ -1268,8 +1270,8 @@ static void gram_bf3_launch(long rows, const float *z, const float *scale_shift,
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
     hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh, nh_dev);
 }
-extern "C" void votenet_debug_gram_bf3(int on) { g_gram_bf3 = on; }
-extern "C" void votenet_debug_gram_workgroups(int n) { g_gram_wgs = n > 0 ? n : 384; }
+extern "C" void votenet_debug_gram_bf3(int on) { VN_DEBUG_GATE(); g_gram_bf3 = on; }
+extern "C" void votenet_debug_gram_workgroups(int n) { VN_DEBUG_GATE(); g_gram_wgs = n > 0 ? n : 384; }
 
 extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *scale_shift, int relu, float *gram, float *scratch,
                                 void *stream)
@@ -1296,9 +1298,10 @@ extern "C" int votenet_mlp_gram(long rows, int c, const float *z, const float *s
 }
 
 static int g_sparse_wgs = 384, g_sparse_wgs2 = 256, g_sparse_teams = 2;
-extern "C" void votenet_debug_sparse_workgroups(int n) { g_sparse_wgs = n > 0 ? n : 384; } // tuning hook
+extern "C" void votenet_debug_sparse_workgroups(int n) { VN_DEBUG_GATE(); g_sparse_wgs = n > 0 ? n : 384; } // tuning hook
 extern "C" void votenet_debug_sparse_teams(int teams, int wgs) // tuning hook: 1 or 2 teams per workgroup (piece layout), workgroups of the 2-team form
 {
+    VN_DEBUG_GATE();
     g_sparse_teams = teams == 1 ? 1 : 2;
     if (wgs > 0) g_sparse_wgs2 = wgs;
 }
@@ -1346,8 +1349,8 @@ extern "C" int votenet_pool_wgrad_sparse_half(long nh, int G, int cin, int cout,
 }
 
 static int g_sparse_centre_wgs = 192, g_sparse_centre_teams = 2; // votenet_debug_sparse_centre_workgroups (tuning hook)
-extern "C" void votenet_debug_sparse_centre_workgroups(int n) { g_sparse_centre_wgs = n > 0 ? n : 192; }
-extern "C" void votenet_debug_sparse_centre_teams(int t) { g_sparse_centre_teams = t == 1 ? 1 : 2; }
+extern "C" void votenet_debug_sparse_centre_workgroups(int n) { VN_DEBUG_GATE(); g_sparse_centre_wgs = n > 0 ? n : 192; }
+extern "C" void votenet_debug_sparse_centre_teams(int t) { VN_DEBUG_GATE(); g_sparse_centre_teams = t == 1 ? 1 : 2; }
 // votenet_pool_wgrad_sparse_half walking CENTRES instead of pieces (pool_wgrad_sparse_centre_kernel): pos = the layout's (G, 3) table of
 // the pieces j >= 1 of every centre (votenet_half_groups), wh[0:G] the weights of the balls' slot 0.  Same results up to the association
 // of the sums.
@@ -1360,6 +1363,11 @@ extern "C" int votenet_pool_wgrad_sparse_half_centres(long nh, int G, int cin, i
     VN_REQUIRE(xz && gout && argmax && zsel && coef && dw && colsum, "pool_wgrad_sparse_half_centres: bad arguments");
     VN_REQUIRE(votenet_pool_backward_supported(cin, cout, 64), "pool_wgrad_sparse_half_centres: unsupported shape cin=%d cout=%d", cin, cout);
     VN_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "pool_wgrad_sparse_half_centres: in_scale and in_shift go together");
+    // the kernel addresses xz through a buffer descriptor with 32-bit byte offsets and uses offset 2^31 as its "piece not kept" marker:
+    // above this size call votenet_pool_wgrad_sparse_half (the piece-walking form, 64-bit addressing)
+    VN_REQUIRE((size_t)nh * kPiece * (size_t)cin * 4 < ((size_t)1 << 31),
+               "pool_wgrad_sparse_half_centres: nh*16*cin*4 = %zu bytes exceeds the 2 GiB the centre-walking kernel addresses; "
+               "use votenet_pool_wgrad_sparse_half", (size_t)nh * kPiece * (size_t)cin * 4);
     VN_REQUIRE((uintptr_t)xz % 16 == 0 && (!in_scale || ((uintptr_t)in_scale % 16 == 0 && (uintptr_t)in_shift % 16 == 0)),
                "pool_wgrad_sparse_half_centres: operands must be 16-byte aligned");
     hipStream_t st = as_stream(stream);

@@ -68,11 +68,11 @@ extern "C" int votenet_gather_point_grad(int b, int n, int m, const float *out_g
 
 // ---- the reference's own launcher names, C++ linkage, exact signatures (tf_sampling.cpp:94,125,150)
 // so that tf_sampling.cpp links against this library unchanged.  Null stream, as the reference.
-void gatherpointLauncher(int b, int n, int m, const float *inp, const int *idx, float *out)
+VN_EXPORT void gatherpointLauncher(int b, int n, int m, const float *inp, const int *idx, float *out)
 {
     votenet_gather_point(b, n, m, inp, idx, out, nullptr);
 }
-void scatteraddpointLauncher(int b, int n, int m, const float *out_g, const int *idx, float *inp_g)
+VN_EXPORT void scatteraddpointLauncher(int b, int n, int m, const float *out_g, const int *idx, float *inp_g)
 {
     votenet_gather_point_grad(b, n, m, out_g, idx, inp_g, nullptr);
 }

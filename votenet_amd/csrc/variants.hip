@@ -312,11 +312,11 @@ extern "C" int votenet_prob_sample(int b, int n, int m, const float *inp_p, cons
 // ---- the reference's own launcher names, C++ linkage, exact signatures (tf_sampling.cpp:65 called :89;
 // tf_grouping.cpp:108 called :134), so that tf_sampling.cpp / tf_grouping.cpp link against this library
 // unchanged.  Null stream, as the reference; `temp` is the caller's (b,n) float scratch of tf_sampling.cpp:86.
-void probsampleLauncher(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out)
+VN_EXPORT void probsampleLauncher(int b, int n, int m, const float *inp_p, const float *inp_r, float *temp, int *out)
 {
     votenet_prob_sample(b, n, m, inp_p, inp_r, temp, out, nullptr);
 }
-void selectionSortLauncher(int b, int n, int m, int k, const float *dist, int *outi, float *out)
+VN_EXPORT void selectionSortLauncher(int b, int n, int m, int k, const float *dist, int *outi, float *out)
 {
     votenet_selection_sort(b, n, m, k, dist, outi, out, nullptr);
 }

@@ -1193,7 +1193,8 @@ def pool_wgrad(xz, in_scale, in_shift, in_relu, gram_buf, w, bias, coef, relu, g
     """dw += x^T dz of the pooled layer from the Gram matrix (gram()), the gathered arg-max rows and the column sums."""
     rows, cin = xz.shape
     cout = w.shape[1]
-    if half is not None and POOL_WGRAD_CENTRES:
+    # (the centre-walking kernel addresses xz with 32-bit byte offsets: above 2 GiB of compact rows -- B >= 64 or so -- the piece form runs)
+    if half is not None and POOL_WGRAD_CENTRES and half.nh * 16 * cin * 4 < 2 ** 31:
         with L.device_guard(xz.device):
             L.check(L.lib().votenet_pool_wgrad_sparse_half_centres(half.nh, half.G, cin, cout, L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift),
                                                                    1 if in_relu else 0, L.ptr(gout), L.ptr(argmax), L.ptr(zsel), L.ptr(coef),
