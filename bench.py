@@ -43,8 +43,8 @@ def parse():
     ap.add_argument("--no-gram", action="store_true", help="pooled layers: direct backward GEMMs on the stored z instead of the Gram form")
     ap.add_argument("--check-dp", action="store_true",
                     help="data-parallel self-check instead of a measurement: in deterministic mode, train steps with the overlapped "
-                         "gradient exchange (dp.GradSync: tail under sa2/sa1's backward, head at the end) against the same steps with ONE "
-                         "blocking all-reduce after a device synchronise; parameters must be bit-equal on every rank, else exit code 4.  "
+                         "gradient exchange (dp.GradSync: tail under sa2/sa1's backward, head at the end) against the same steps with "
+                         "blocking all-reduces of the same two slices after a device synchronise; parameters must be bit-equal on every rank, else exit code 4.  "
                          "Works at --gpus 1 too (a one-rank RCCL communicator still runs both collectives)")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="do not compute the coordinate-only geometry of the next batch underneath the current step")
@@ -160,7 +160,7 @@ def launch_ranks(args):
 def dp_self_check(dev, nets, run_step, steps=2):
     """What `--gpus N` (N > 1) appends to its line after the timed region: dp.check_overlap_against_blocking on two replicas (nets[0]
     exchanges gradients the overlapped way -- tail all-reduce under the backward pass of sa2 / sa1, head after the last weight gradient --
-    nets[1] with ONE blocking all-reduce between device synchronisations), what the communicator says about its ranks, and how long the
+    nets[1] with blocking all-reduces of the same two slices between device synchronisations), what the communicator says about its ranks, and how long the
     tail collective was still running when the main stream reached the end of the backward pass.  equal_everywhere is an all-reduce MIN:
     every rank learns the same verdict (and exits with code 4 when it is False)."""
     from votenet_amd import dp
@@ -172,7 +172,7 @@ def dp_self_check(dev, nets, run_step, steps=2):
             "backend": info["backend"], "distinct_devices": info["distinct_devices"], "tail_exposed_ms": tm.get("tail_exposed_ms"),
             "tail_ms": tm.get("tail_ms"), "head_ms": tm.get("head_ms"),
             "what": "deterministic mode, %d train steps on two replicas per rank after the timed region: overlapped exchange (dp.GradSync) vs "
-                    "one blocking all-reduce; parameters torch.equal on every rank and equal to rank 0's" % res["steps"]}
+                    "blocking all-reduces of the same two slices; parameters torch.equal on every rank and equal to rank 0's" % res["steps"]}
 
 
 class _DryReplica:
@@ -265,7 +265,7 @@ def dry_run(args):
 
 def check_dp(args, dev, world, rank):
     """--check-dp (see parse()): two replicas from the same seed, deterministic mode, the same scenes; one exchanges gradients the
-    overlapped way, the other with one blocking all-reduce.  Prints one JSON line on rank 0; exit code 4 when they differ."""
+    overlapped way, the other with blocking all-reduces of the same slices.  Prints one JSON line on rank 0; exit code 4 when they differ."""
     import torch
     import torch.distributed as dist
     import votenet_amd
@@ -289,8 +289,8 @@ def check_dp(args, dev, world, rank):
     if rank == 0:
         emit(json.dumps({"metric": "data-parallel self-check (--check-dp; nothing measured)", "value": None,
                          "n_gpus": info["world_size"], "communicator": info, "check_dp": res,
-                         "what": "deterministic mode; parameters after %d train steps with dp.GradSync's overlapped exchange vs one "
-                                 "blocking all-reduce between device synchronisations: torch.equal on every rank, every rank equal to "
+                         "what": "deterministic mode; parameters after %d train steps with dp.GradSync's overlapped exchange vs "
+                                 "blocking all-reduces of the same two slices between device synchronisations: torch.equal on every rank, every rank equal to "
                                  "rank 0" % res["steps"]}))
     return 0 if res["equal_everywhere"] else 4
 

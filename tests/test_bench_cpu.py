@@ -68,6 +68,23 @@ def test_gpus_n_starts_n_ranks_itself():
     assert all(set(r_["hostpin"]) == {"cpus", "gpu_numa_node"} for r_ in pr["ranks"])
 
 
+def test_gpus_8_starts_eight_ranks_itself():
+    """The first real `--gpus 8` run must not die on rank plumbing: eight ranks started by bench.py itself rendezvous (gloo here),
+    every rank takes part in the self-check's collectives and reports its own clock / host pin, and rank 0 prints ONE line."""
+    import json
+    r = _run_bench("--gpus", "8", "--dry-run")
+    assert r.returncode == 0, r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["rank_sum"] == float(sum(range(1, 9)))
+    c = line["check_dp"]
+    assert c["equal_everywhere"] and c["ranks_identical"] and c["world_size"] == 8 and c["distinct_devices"] == 8
+    pr = line["per_rank"]
+    assert [r_["rank"] for r_ in pr["ranks"]] == list(range(8))
+    assert pr["ms_per_step_min"] == 1.0 and pr["ms_per_step_max"] == 8.0
+
+
 def test_diverged_replicas_fail_the_run():
     """bench.dp_self_check's verdict decides the exit code: replicas that differ after the check's steps -> exit code 4 on every rank."""
     r = _run_bench("--gpus", "2", "--dry-run", env={"VOTENET_BENCH_DRYRUN_DIVERGE": "1"})

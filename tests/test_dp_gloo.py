@@ -5,6 +5,7 @@ import os
 import socket
 import sys
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -255,24 +256,31 @@ def _check_worker(rank, world, port, q, sabotage):
     dist.destroy_process_group()
 
 
-def test_train_step_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_train_step_world2(world):
+    """world 2, and world 8 = the node BASELINE config 4 names (eight ranks, 8 scenes each): the same host path per rank."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_train_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    res = sorted([q.get(timeout=600) for _ in range(world)], key=lambda t: t[0])
     for p in procs:
-        p.join(60)
+        p.join(120)
         assert p.exitcode == 0
-    (_, f0, e0, s0, logs0, numel, split), (_, f1, e1, s1, logs1, _, _) = [
-        tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in r) for r in res]
-    assert torch.equal(s0, s1)                       # identical replicas at the start (broadcast)
-    assert torch.equal(f0, f1)                       # ... and after two optimizer steps: bit-identical parameters
+    res = [tuple(torch.from_numpy(v) if hasattr(v, "dtype") else v for v in r) for r in res]
+    (_, f0, e0, s0, logs0, numel, split) = res[0]
+    logs_all = []
+    for (_, f1, e1, s1, logs1, _, _) in res:
+        assert torch.equal(s0, s1)                   # identical replicas at the start (broadcast)
+        assert torch.equal(f0, f1)                   # ... and after two optimizer steps: bit-identical parameters on every rank
+        # the mean-gradient update.  world 2: a + b has one order; world 8: the ring adds the eight terms in another order than the
+        # expectation's rank loop, and Adam's g / sqrt(v) turns a last-bit difference of a nearly cancelled sum into ~1e-3 of one update (lr 1e-3)
+        assert torch.allclose(f1, e1, rtol=1e-6, atol=1e-9 if world == 2 else 2e-6), float((f1 - e1).abs().max())
+        logs_all += logs1
     assert not torch.equal(f0, s0)
-    assert torch.allclose(f0, e0, rtol=1e-6, atol=1e-9) and torch.allclose(f1, e1, rtol=1e-6, atol=1e-9)  # the mean-gradient update
-    for events, colls in logs0 + logs1:
+    for events, colls in logs_all:
         # two collectives per step, contiguous slices of the one flat bucket: tail = sa3 ... proposal, head = sa1 + sa2
         assert colls == [("tail", numel - split), ("head", split)]
         order = [e for e in events if e.endswith(".backward") or e.startswith("tail")]

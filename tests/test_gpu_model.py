@@ -147,6 +147,7 @@ def test_forward_full_size_vs_oracle_layer_by_layer(hiplib, dev, O, gemm_form):
     for k in ("l1x", "l2x", "l3x", "l4x"):
         assert (got[k] == r[k]).all(), k  # FPS picks (incl. the prefix shortcut of the lower levels) and gathered centres: exact
     errs = {k: relerr(got[k], r[k]) for k in ("l1p", "l2p", "l3p", "l4p", "l3p2", "seeds", "vx", "vp")}
+    _record_parity("chained_stack", gemm_form, errs)
     assert max(errs.values()) < 2e-5, errs
     # proposal layer on the DEVICE votes (its neighbour lists depend on the vote coordinates to the last bit)
     prev = O.set_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
@@ -158,9 +159,73 @@ def test_forward_full_size_vs_oracle_layer_by_layer(hiplib, dev, O, gemm_form):
     assert relerr(got["pout"], pout) < 2e-5 and got["pout"].shape == (2, 256, 79)
 
 
+def _record_parity(name, form, errs):
+    """Achieved per-module errors into gpurun_out/parity_errors.txt (copied to profiles/ per round)."""
+    import os
+    root = os.environ.get("GRAFT_REPO_ROOT") or os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "parity_errors.txt"), "a") as f:
+            f.write("%s  %s  %s\n" % (name, "bf16x3_images" if form else "fp32_mfma",
+                                      "  ".join("%s=%.2e" % (k, v) for k, v in errs.items())))
+    except OSError:
+        pass
+
+
+def test_forward_full_size_each_module_on_the_oracles_input(hiplib, dev, O, gemm_form):
+    """north_star's bar -- grouped features within 1e-5 (fp32) of the reference on IDENTICAL inputs -- module by module at the real
+    sizes: every device module (sa1-4, fp1-2, voting, proposal: utils.py:125-132,286-293, model.py:53-57,89-93) is fed the ORACLE's
+    input of that module, so an error is that module's own (three GEMM + BatchNorm layers and the pool), not what the chain
+    accumulated up to it.  Sampled centres exact; features to 1e-5 of the tensor maximum.  (The chained stack is held to its own bar
+    by test_forward_full_size_vs_oracle_layer_by_layer.)  The achieved maxima are recorded."""
+    import os
+    from votenet_amd import mlp as M
+    from votenet_amd import synth
+    x = synth.room_batch(2, 20480, 4242)
+    net = _perturbed_net(dev, 3)
+    if "ref" not in _FULL:
+        test_forward_full_size_vs_oracle_layer_by_layer(hiplib, dev, O, gemm_form)
+    r = _FULL["ref"]
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def relerr(a, b):
+        return float(np.abs(N(a) - b).max() / max(1.0, np.abs(b).max()))
+    errs = {}
+    net.store.refresh_split()
+    M.arena_begin(dev)
+    try:
+        xt = T(x)
+        cx, cp, _ = net.sa1.forward(xt, xt)
+        assert (N(cx) == r["l1x"]).all()
+        errs["sa1"] = relerr(cp, r["l1p"])
+        for name, mod, xin, pin, xo, po in (("sa2", net.sa2, "l1x", "l1p", "l2x", "l2p"), ("sa3", net.sa3, "l2x", "l2p", "l3x", "l3p"),
+                                            ("sa4", net.sa4, "l3x", "l3p", "l4x", "l4p")):
+            cx, cp, _ = mod.forward(T(r[xin]), T(r[pin]))
+            assert (N(cx) == r[xo]).all(), name
+            errs[name] = relerr(cp, r[po])
+        errs["fp1"] = relerr(net.fp1.forward(T(r["l3x"]), T(r["l4x"]), T(r["l3p"]), T(r["l4p"])), r["l3p2"])
+        errs["fp2"] = relerr(net.fp2.forward(T(r["l2x"]), T(r["l3x"]), T(r["l2p"]), T(r["l3p2"])), r["seeds"])
+        vx, vp = net.vote(T(r["l2x"]), T(r["seeds"]))
+        errs["vote_xyz"], errs["vote_feat"] = relerr(vx, r["vx"]), relerr(vp, r["vp"])
+        if "prop" not in _FULL:
+            prev = O.set_threads(max(1, min(128, len(os.sched_getaffinity(0)))))
+            try:
+                _FULL["prop"] = oracle_sa(O, net.proposal, np.ascontiguousarray(r["vx"]), np.ascontiguousarray(r["vp"]), sample_xyz=r["l2x"])
+            finally:
+                O.set_threads(prev)
+        px, pout = net.propose(T(r["vx"]), T(r["vp"]), T(r["l2x"]))
+        assert (N(px) == _FULL["prop"][0]).all()
+        errs["proposal"] = relerr(pout, _FULL["prop"][1])
+    finally:
+        M.arena_end()
+    _record_parity("module_on_oracle_input", gemm_form, errs)
+    assert max(errs.values()) < 1e-5, errs
+
+
 def test_config5_scene_through_sa1_vs_oracle(hiplib, dev, O, gemm_form):
     """One 80 000-point config-5 scene through sa1 -- the L2-resident bucket FPS, the indexed ball query and the narrow
-    first layer + two GEMMs + max over K at 131 072 grouped rows -- against the oracle: centres exact, features to 2e-5."""
+    first layer + two GEMMs + max over K at 131 072 grouped rows -- against the oracle: centres exact, features to 1e-5."""
     import os
     from votenet_amd import synth
     x = synth.room_batch(1, 80000, 77, size=(8.0, 3.0, 8.0), nbox=(15, 25))
@@ -182,7 +247,8 @@ def test_config5_scene_through_sa1_vs_oracle(hiplib, dev, O, gemm_form):
     rx, rp = _FULL["cfg5"]
     assert (N(l1x) == rx).all()
     err = float(np.abs(N(l1p) - rp).max() / max(1.0, np.abs(rp).max()))
-    assert err < 2e-5, err
+    _record_parity("config5_sa1", gemm_form, {"sa1": err})
+    assert err < 1e-5, err
 
 
 def test_predict_tail_nms_vs_oracle(hiplib, dev, O):

@@ -463,7 +463,8 @@ def test_interpolate_reference_test_shape_golden(ops, dev, golden):
     assert (N(out) == g["out"]).all()  # same un-fused evaluation order -> bit-exact
     out.backward(T(c["grad_out"], dev))
     assert np.allclose(N(pts.grad), g["grad"], rtol=1e-5, atol=1e-6)
-    assert np.allclose(N(ops.i.three_nn_weights(dist)), g["weights_idw"], rtol=1e-6, atol=0)
+    # utils.py:279-282 on both sides as un-fused fp32 with correctly rounded division (v_div_scale / v_div_fmas / v_div_fixup): bit-exact
+    assert (N(ops.i.three_nn_weights(dist)) == g["weights_idw"]).all()
 
 
 def test_interpolate_demo_golden(ops, dev, golden):
@@ -487,6 +488,25 @@ def test_three_nn_ties_and_tiles_vs_oracle(ops, dev, O, n, m):
     assert (N(idx) == oi).all() and (N(dist) == od).all()
 
 
+def test_three_nn_weights_bit_exact_over_the_whole_range(ops, dev, O):
+    """Inverse-distance weights (utils.py:279-282) against the oracle, bit for bit, over everything a squared distance can be: zero and
+    below the 1e-10 clamp, subnormal, ordinary (random exponents), huge, exact ties; plus the distances of a real cloud."""
+    rng = np.random.default_rng(5)
+    e = rng.integers(-140, 120, size=(4, 50000, 3))
+    d = (rng.random((4, 50000, 3)) * np.exp2(e.astype(np.float64))).astype(np.float32)
+    d[0, :1000] = 0.0
+    d[0, 1000:2000, 1] = 1e-10
+    d[0, 2000:3000] = np.float32(1e-10) * (1 + rng.integers(-3, 4, size=(1000, 3)) * np.float32(2.0 ** -23))
+    d[1, :1000, 2] = d[1, :1000, 1]
+    d[2, :1000] = np.float32(3e38)
+    d[3, :1000] = np.float32(1e-45)
+    w, ow = ops.i.three_nn_weights(T(d, dev)), O.three_nn_weights(d)
+    assert (N(w).view(np.uint32) == ow.view(np.uint32)).all()
+    xyz1, xyz2 = rng.random((2, 4096, 3), dtype=np.float32), rng.random((2, 512, 3), dtype=np.float32)
+    dist, _ = ops.i.three_nn(T(xyz1, dev), T(xyz2, dev))
+    assert (N(ops.i.three_nn_weights(dist)) == O.three_nn_weights(N(dist))).all()
+
+
 @pytest.mark.parametrize("b,n,m,c", [(2, 300, 40, 8), (1, 1024, 512, 256), (1, 50, 2, 4), (1, 50, 1, 5), (8, 512, 256, 256)])
 def test_three_nn_interpolate_vs_oracle(ops, dev, O, b, n, m, c):
     rng = np.random.default_rng(n + m)
@@ -500,7 +520,7 @@ def test_three_nn_interpolate_vs_oracle(ops, dev, O, b, n, m, c):
     dsafe = np.where(np.isfinite(od), od, 1.0).astype(np.float32)
     w = ops.i.three_nn_weights(T(dsafe, dev))
     ow = O.three_nn_weights(dsafe)
-    assert np.allclose(N(w), ow, rtol=1e-6, atol=0)
+    assert (N(w) == ow).all()  # bit-exact: same three operations in the same order, IEEE division
     pts = rng.random((b, m, c), dtype=np.float32)
     p = T(pts, dev).requires_grad_(True)
     out = ops.i.three_interpolate(p, idx, T(ow, dev))

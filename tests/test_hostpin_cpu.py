@@ -99,3 +99,47 @@ def test_bench_loads_hostpin_without_the_package():
             "assert 'torch' not in sys.modules and 'votenet_amd' not in sys.modules; assert callable(h.pin) and callable(h.unpin); print('ok')" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr
+
+
+def test_eight_gpus_two_nodes_every_rank_gets_its_own_block(tmp_path, monkeypatch):
+    """The node of BASELINE config 4 (8 GPUs, 4 per NUMA node, 2 x 64 cores + SMT): eight ranks -> eight disjoint blocks of eight CPUs,
+    each on its GPU's node, none holding CPU 0."""
+    kfd, pci = tmp_path / "kfd", tmp_path / "pci"
+    buses = [0x05, 0x15, 0x25, 0x35, 0x85, 0x95, 0xa5, 0xb5]
+    for i in range(2):
+        d = kfd / str(i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 64\nsimd_count 0\nlocation_id 0\ndomain 0\n")
+    for i, bus in enumerate(buses):
+        d = kfd / str(2 + i)
+        d.mkdir(parents=True)
+        (d / "properties").write_text("cpu_cores_count 0\nsimd_count 1024\nlocation_id %d\ndomain 0\n" % (bus << 8))
+        dp_ = pci / ("0000:%02x:00.0" % bus)
+        dp_.mkdir(parents=True)
+        (dp_ / "numa_node").write_text("%d\n" % (0 if i < 4 else 1))
+    state = {"mask": set(range(256))}
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(state["mask"]), raising=False)
+    monkeypatch.setattr(os, "sched_setaffinity", lambda pid, cpus: state.__setitem__("mask", set(cpus)), raising=False)
+    real_nodes = hostpin.gpu_numa_nodes
+    monkeypatch.setattr(hostpin, "gpu_numa_nodes", lambda: real_nodes(str(kfd), str(pci)))
+    real_open = open
+
+    def fake_open(path, *a, **k):
+        if isinstance(path, str) and path.startswith("/sys/devices/system/node/node"):
+            import io
+            n = int(path.split("node")[-1].split("/")[0])
+            return io.StringIO("0-63,128-191\n" if n == 0 else "64-127,192-255\n")
+        return real_open(path, *a, **k)
+    monkeypatch.setattr("builtins.open", fake_open)
+    for v in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "VOTENET_NO_PIN"):
+        monkeypatch.delenv(v, raising=False)
+    assert hostpin.gpu_numa_nodes() == [0, 0, 0, 0, 1, 1, 1, 1]
+    blocks = []
+    for rank in range(8):
+        state["mask"] = set(range(256))
+        got = hostpin.pin(rank)
+        assert got is not None and len(got) == 8 and 0 not in got
+        node0 = set(range(0, 64)) | set(range(128, 192))
+        assert set(got) <= (node0 if rank < 4 else set(range(256)) - node0), (rank, got)
+        blocks.append(set(got))
+    assert len(set().union(*blocks)) == 64          # pairwise disjoint

@@ -88,15 +88,20 @@ class GradSync:
     issued from a dedicated HIP stream so that neither the main stream nor the weight-gradient stream ever waits for the network
     before finish().
 
-    overlap=False is the control the overlapped form is checked against (bench.py --check-dp, tests): no tail, and finish()
-    drains the device, runs ONE blocking all-reduce of the whole bucket on the current stream and drains again -- nothing can
-    race with it by construction.
+    overlap=False is the control the overlapped form is checked against (bench.py --check-dp, tests): no tail under the backward, and
+    finish() drains the device, runs BLOCKING all-reduces on the current stream and drains again -- nothing can race with them by
+    construction.  The control reduces the SAME two slices (bucket[split:], then bucket[:split]) as the overlapped form: a ring /
+    tree all-reduce adds an element's contributions in an order that depends on where the element sits in the reduced buffer, so with
+    more than two ranks ONE all-reduce of the whole bucket gives sums that differ in the last bit from two all-reduces of its slices --
+    a bit-equality check against it fails with nothing wrong (found by the world-8 gloo test, round 6; world 2 cannot see it: a + b
+    has one order).  same_slices=False keeps the old single collective.
     profile=True records HIP events around both collectives: after finish(), timings() gives their latency on the communication
     stream and how much of the tail had finished before the main stream arrived at finish() (= hidden under sa2 / sa1)."""
 
-    def __init__(self, store, split, overlap=True, force=False, profile=False):
+    def __init__(self, store, split, overlap=True, force=False, profile=False, same_slices=True):
         self.store, self.split = store, int(split)
         self.overlap, self.force, self.profile = bool(overlap), bool(force), bool(profile)
+        self.same_slices = bool(same_slices)
         self._work = []
         self._comm = None
         self._marks = {}
@@ -148,10 +153,15 @@ class GradSync:
             if not self.overlap:
                 if g.is_cuda:
                     torch.cuda.synchronize(g.device)
-                dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                if self.same_slices and 0 < self.split < g.numel():
+                    for what, t in (("blocking tail", g[self.split:]), ("blocking head", g[:self.split])):
+                        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                        self.log.append((what, t.numel()))
+                else:
+                    dist.all_reduce(g, op=dist.ReduceOp.SUM)
+                    self.log.append(("blocking", g.numel()))
                 if g.is_cuda:
                     torch.cuda.synchronize(g.device)
-                self.log.append(("blocking", g.numel()))
                 self._tail_started = False
                 return 1.0 / w
             if g.is_cuda and self.profile:
@@ -187,7 +197,8 @@ def check_overlap_against_blocking(net_a, net_b, run_step, steps=2):
     """The overlapped exchange cannot be told from a blocking one: net_a and net_b are two replicas in the SAME state (same
     parameters, optimizer state, deterministic mode on); run_step(net, i) runs training step i on a net.  net_a exchanges its
     gradients with GradSync's overlap (tail issued after sa3's backward from the communication stream, head after the last weight
-    gradient), net_b with ONE blocking all-reduce between two device synchronisations.  Any missing stream dependency in the
+    gradient), net_b with blocking all-reduces of the same two slices between two device synchronisations (same slices: see GradSync --
+    the reduction order inside a collective depends on the buffer it reduces).  Any missing stream dependency in the
     overlapped form (a collective that starts before a gradient is final, an optimizer that starts before a collective is done)
     shows as different parameters.  -> dict(equal_on_this_rank, ranks_identical, equal_everywhere, collectives, timings):
     equal_everywhere is the AND over all ranks (one MIN all-reduce)."""
