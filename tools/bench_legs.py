@@ -326,6 +326,22 @@ def config_legs(net, xs, gts, dev, B, n, cpu=True):
     alg5 = 4 * 2047 * 80000 * 16 + 4 * 80000 * 12 + 4 * 2048 * 4
     cfg["config5_dense_scan"] = dict(forward_ms=round(fw5, 3), scenes_per_s=round(4 / fw5 * 1e3, 1), fps_ms=round(fps5, 3), ball_query_ms=round(bq5, 4),
                                      fps_effective_GBs=round(alg5 / (fps5 * 1e-3) / 1e9, 1), fps_hbm_model_frac=round(alg5 / (fps5 * 1e-3) / 8e12, 4),
-                                     what="BASELINE configs[4]: 4 x 80000-pt scenes, forward (unpipelined); FPS = fps_bucket_l2_kernel "
-                                          "(L2-resident, exact bucket pruning), algorithmic bytes B(m-1)n16 + Bn12 + Bm4")
+                                     what="BASELINE configs[4]: 4 x 80000-pt scenes, forward; forward_ms = one batch by itself (its own geometry "
+                                          "inside the call), forward_pipelined_ms = three batches rotating with the next batches' geometry on the side "
+                                          "stream, as the other legs run; FPS = fps_bucket_l2_kernel (L2-resident, exact bucket pruning), "
+                                          "algorithmic bytes B(m-1)n16 + Bn12 + Bm4")
+    # the same forward the way the other legs are measured: three batches rotate, the coordinate-only geometry of the next ones prefetched
+    try:
+        x5s = [x5] + [torch.from_numpy(synth.room_batch(4, 80000, 77 + 1000 * j, size=(8.0, 3.0, 8.0), nbox=(15, 25))).to(dev) for j in (1, 2)]
+        k5 = [0]
+
+        def fwd5():
+            i = k5[0]
+            k5[0] += 1
+            return net.forward(x5s[i % 3], next_x=[x5s[(i + 1) % 3], x5s[(i + 2) % 3]])
+        fw5p = gpu_ms(fwd5, it=9, warm=6)
+        cfg["config5_dense_scan"].update(forward_pipelined_ms=round(fw5p, 3), scenes_per_s_pipelined=round(4 / fw5p * 1e3, 1))
+    except Exception as e:  # never lose the line to this leg
+        cfg["config5_dense_scan"]["forward_pipelined_error"] = repr(e)[:300]
+    net.__dict__.get("_prefetched", {}).clear()
     return cfg
