@@ -495,6 +495,16 @@ int votenet_transpose_segments(int nseg, const long *table, const float *src, fl
 int votenet_split_weights(int nseg, const long *table, void *stream);
 int votenet_split_weights_one(const float *w, int cin, int cout, void *image, void *stream); /* one matrix, arguments by value */
 int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3);
+/* Round 6: the image as TWO fp16 pieces per weight (x = hi + lo, hi = rne16(x), lo = rne16(x - hi); [k/16][hi, lo][k-half][column][8 fp16],
+ * cin * cout * 4 bytes) for matrices that multiply FORWARD operands -- activations behind a BatchNorm, coordinates: a product is three
+ * v_mfma_f32_32x32x16_f16 instead of six bf16 ones, error against float64 equal to the bf16 x 3 form's (profiles/r06_mfma_f16_denorm.txt).
+ * fp16's range applies to both operands: |value| < 65504, values below 2^-24 vanish (a diverged network shows as inf / NaN, loudly).
+ * votenet_split_weights_h2 builds such images from the same table; votenet_register_split_weights_pieces(w, ..., w3, 2) registers one
+ * (pieces = 3: votenet_register_split_weights).  Only forward-type entry points (votenet_mlp_linear*, votenet_assembled_linear*,
+ * votenet_narrow_linear*) have a two-piece kernel; any other entry point that receives `w` ignores a two-piece image and multiplies w
+ * itself on the fp32 MFMA kernel. */
+int votenet_split_weights_h2(int nseg, const long *table, void *stream);
+int votenet_register_split_weights_pieces(const float *w, int cin, int cout, const void *w3, int pieces);
 
 /* ---- split-K for the fused GEMMs of few row tiles (round 5) -------------------------------------------------------------------
  * The GEMMs of the model's static stretch (feature propagation, voting, proposal head: utils.py:286-293, model.py:53-57,89-93) have

@@ -45,6 +45,8 @@ void votenet_debug_split_k(int target_wgs, int max_parts, int min_slabs, int max
 /* 0: every GEMM on the fp32 MFMA kernels whatever is registered (A/B and parity tests); 1 (default): images are used; another
  * value: a mask over GEMM families (mlp_fast.hip, bf3_family) */
 void votenet_debug_fast_bf3(int on);
+/* 0: two-piece (fp16 x 2) weight images are ignored, those GEMMs run on the fp32 MFMA kernel; 1 (default): used */
+void votenet_debug_fast_h2(int on);
 void votenet_debug_fast_dyn_lds(int bytes);  /* extra dynamic LDS per workgroup of the fast GEMMs (occupancy experiments) */
 void votenet_debug_fast_xcd_chunk(int on);   /* 1 (default): the piece-layout GEMMs that gather the per-point table take their row tiles in
                                                 per-XCD contiguous chunks (an XCD's L2 then holds the scenes its tiles touch); 0: round-robin */

@@ -72,13 +72,19 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(params=[1, 0], ids=["bf16x3_images", "fp32_mfma"])
+@pytest.fixture(params=[2, 1, 0], ids=["fp16x2_forward_images", "bf16x3_images", "fp32_mfma"])
 def gemm_form(request, hiplib):
-    """The fused GEMMs on bf16 x 3 images of the weights (the model's default; a test that wants them registers its matrices with
-    mlp.SplitImages) or on the fp32 MFMA kernels (votenet_debug_fast_bf3(0): registered images are ignored)."""
+    """The fused GEMMs on split-operand images of the weights -- 2: the model's default (forward matrices as fp16 x 2, the transposed
+    copies of the backward pass as bf16 x 3: mlp.FORWARD_H2); 1: bf16 x 3 everywhere (the round-3..5 form) -- or, 0, on the fp32 MFMA
+    kernels (votenet_debug_fast_bf3(0): registered images are ignored).  A test that wants images registers its matrices with
+    mlp.SplitImages; a ParamStore picks the form when it first builds its images, i.e. after this fixture ran."""
     from votenet_amd import mlp as M
+    prev_h2 = M.FORWARD_H2
+    M.FORWARD_H2 = request.param == 2
+    on = 1 if request.param else 0
     for name in ("fast_bf3", "gram_bf3", "wgrad_bf3"):  # through mlp.debug_switch: graphs captured under the other form are not reused
-        M.debug_switch(name, request.param)
+        M.debug_switch(name, on)
     yield request.param
+    M.FORWARD_H2 = prev_h2
     for name in ("fast_bf3", "gram_bf3", "wgrad_bf3"):
         M.debug_switch(name, 1)

@@ -28,7 +28,11 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_
     w0, b0, w1 = rnd(3 + cf, c0) * 0.3, rnd(c0) * 0.1, rnd(c0, c1) * 0.2
     wx = w0[:3].contiguous()
     wT = w1.t().contiguous()
-    img = M.SplitImages([w1, wT])  # the second layer's forward (SRC 4 / SRC 0) and input-gradient (EPI 6 / EPI 3) GEMMs when gemm_form == 1
+    # images for the second layer's forward GEMM (fp16 x 2 when gemm_form == 2, as the model registers its forward matrices) and its
+    # input-gradient GEMM (the transposed copy: always bf16 x 3); gemm_form == 0 ignores them
+    img_f = M.SplitImages([w1], pieces=2 if gemm_form == 2 else 3)
+    img_f.refresh()
+    img = M.SplitImages([wT])
     img.refresh()
     P, _ = M.linear_dense(feat.reshape(b * n, cf), w0[3:].contiguous(), b0, want_stats=False)
     # geometry records and the per-point sums (padding slots repeat slot 0: with and without pts_cnt the sums agree)
@@ -83,6 +87,7 @@ def test_assembled_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_
     Sm, _ = M.group_linear_backward(xyz, new_xyz, idx, cnt, z0, da0, coef0, True, dwxm)
     assert relerr(S, Sm) < 1e-5 and relerr(dwx, dwxm) < 1e-4
     img.close()
+    img_f.close()
 
 
 def test_model_with_and_without_the_assembled_first_layers(hiplib, dev):

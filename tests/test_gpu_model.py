@@ -167,7 +167,7 @@ def _record_parity(name, form, errs):
     try:
         os.makedirs(d, exist_ok=True)
         with open(os.path.join(d, "parity_errors.txt"), "a") as f:
-            f.write("%s  %s  %s\n" % (name, "bf16x3_images" if form else "fp32_mfma",
+            f.write("%s  %s  %s\n" % (name, {2: "fp16x2_forward_images", 1: "bf16x3_images", 0: "fp32_mfma"}[form],
                                       "  ".join("%s=%.2e" % (k, v) for k, v in errs.items())))
     except OSError:
         pass

@@ -35,7 +35,11 @@ def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_for
     from votenet_amd import mlp as M
     xyz, new_xyz, feat, idx, w0, b0, w1, rows_in, rnd = setup(dev, b, n, m, k, c, c0, c1, 7 * n + c)
     wT = w1.t().contiguous()
-    img = M.SplitImages([w1, wT])  # used by the second layer's forward (SRC 3) and input-gradient (EPI 4) GEMMs when gemm_form == 1
+    # images for the second layer's forward GEMM (fp16 x 2 when gemm_form == 2, as the model registers its forward matrices) and its
+    # input-gradient GEMM (the transposed copy: always bf16 x 3); gemm_form == 0 ignores them
+    img_f = M.SplitImages([w1], pieces=2 if gemm_form == 2 else 3)
+    img_f.refresh()
+    img = M.SplitImages([wT])
     img.refresh()
     rows, k0 = rows_in.shape
     assert M.narrow_supported(rows, k0, c0, c1)
@@ -87,6 +91,7 @@ def test_narrow_first_layer_matches_the_materialised_layer(hiplib, dev, gemm_for
     M.narrow_wgrad_first(mom, ug, coef0, w0, b0, dw0)
     assert relerr(dw0, ud[:, :k0].t() @ dz0) < 2e-5
     img.close()
+    img_f.close()
 
 
 def test_narrow_kernels_reject_unserved_shapes(hiplib, dev):

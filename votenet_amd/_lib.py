@@ -110,6 +110,8 @@ _SIGS.update({
     "votenet_augment_boxes": [ctypes.c_int, ctypes.c_int] + [_c_f] * 11 + [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_transpose_segments": [ctypes.c_int] + [_c_f] * 3 + [ctypes.c_void_p],
     "votenet_split_weights": [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_split_weights_h2": [ctypes.c_int, _c_f, ctypes.c_void_p],
+    "votenet_register_split_weights_pieces": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int],
     "votenet_split_weights_one": [_c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_mlp_split_k_arm": [ctypes.c_void_p, ctypes.c_long],
     "votenet_mlp_split_k_tickets": [ctypes.c_void_p, ctypes.c_long],

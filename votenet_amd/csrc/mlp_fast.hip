@@ -111,6 +111,7 @@ struct FastArgs {
     int cin, cout;
     const float *w, *bias;
     const unsigned *w3;    // BF3: w as three bf16 pieces in the kernel's LDS order (votenet_split_weights), or NULL
+    int w3_np;             // pieces of that image: 3 (bf16 x 3) or 2 (fp16 x 2: H2 instantiations, forward families only)
     float *z;              // may be NULL with EPI 2 (inference: only the pooled result is wanted)
     float *zmax, *zmin;    // EPI 2: per 64-row group and channel, raw max / min of z ...
     int *amax, *amin;      //        ... and the row offsets (first occurrence) where they are attained
@@ -148,9 +149,12 @@ struct FastArgs {
 // WM x WN waves (WM*WN = 4), each MT x NT tiles of 32x32: BM = WM*MT*32 = 128, BN = WN*NT*32.
 // amdgpu_waves_per_eu caps the occupancy the register allocator aims for: at 4 waves/SIMD (128 VGPRs) the
 // 2x2 variant spills exactly its prefetch registers, which makes the prefetch synchronous.
-template <int WM, int WN, int MT, int NT, int SRC, int EPI, bool BF3 = false, bool SK = false /* split-K launch: gridDim.z parts (FastArgs::sk_ws) */>
+template <int WM, int WN, int MT, int NT, int SRC, int EPI, bool BF3 = false, bool SK = false /* split-K launch: gridDim.z parts (FastArgs::sk_ws) */,
+          bool H2 = false /* BF3 path on TWO fp16 pieces and three MFMAs per product (mlp_types.h: split2); forward families */>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 || EPI == 6) ? EPI3_WAVES : (EPI == 0 || EPI == 2 || EPI == 8) ? FWD_WAVES : 2, 3))) void mlp_linear_fast_kernel(FastArgs A)
 {
+    static_assert(!H2 || (BF3 && !SK && (SRC == 0 || SRC == 3 || SRC == 4)), "H2: a split-operand forward-type instantiation");
+    constexpr int NPC = H2 ? 2 : 3;               // pieces per operand (split images, LDS planes)
     constexpr bool POOL = (EPI == 2 || EPI == 8); // pooled forward layer
     constexpr bool P32 = (EPI == 8);              // ... per 16-row piece
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
@@ -163,8 +167,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     // a lane's MFMA fragment is ONE 16-byte read and consecutive lanes read consecutive 16 bytes (conflict-free ds_read_b128);
     // 16 dwords between the planes put the two k-halves one staging wave writes on different banks
     constexpr int PLA = FG_BM * 4 + 16, PLB = BN * 4 + 16;
-    __shared__ __attribute__((aligned(16))) unsigned As3[BF3 ? 2 : 1][3][2][BF3 ? PLA : 4];
-    __shared__ __attribute__((aligned(16))) unsigned Bs3[BF3 ? 2 : 1][3][2][BF3 ? PLB : 4];
+    __shared__ __attribute__((aligned(16))) unsigned As3[BF3 ? 2 : 1][NPC][2][BF3 ? PLA : 4];
+    __shared__ __attribute__((aligned(16))) unsigned Bs3[BF3 ? 2 : 1][NPC][2][BF3 ? PLB : 4];
     __shared__ __attribute__((aligned(16))) float Sco[(SRC == 0 ? 2 : 5)][512]; // per-input-channel coefficients
     constexpr bool NEPI = (EPI == 4 || EPI == 7); // the layer below is a NARROW one
     constexpr bool REDUCE_BELOW = (EPI == 3 || NEPI || EPI == 6);
@@ -268,7 +272,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     const int b3_pl = tid >> 7, b3_c = (BN == 128) ? (tid & 127) : ((tid & 127) >> 1), b3_h = (BN == 128) ? 0 : (tid & 1);
     unsigned wvo = (((unsigned)b3_pl * (unsigned)cout + (unsigned)(n0 + b3_c)) * 4u + (unsigned)b3_h * 2u) * 4u;
     unsigned wpitch = (unsigned)cout * 32u; // bytes between plane pairs (= pieces)
-    const unsigned w3_slab = (unsigned)cout * 96u; // bytes per slab of the split image
+    const unsigned w3_slab = (unsigned)cout * 32u * (unsigned)NPC; // bytes per slab of the split image
     wvo += (unsigned)ks0 * w3_slab;
     int lkt = 0; // k-slab index (from ks0) of the step being loaded
     // One k-slab step of raw operands in registers.  Two sets alternate: a set is filled two steps before its slab
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     // is less than the loaded HBM latency, which serialised memory time and matrix time.
     struct Regs {
         float4 a0, a1, b[BF3 ? 1 : NB4];
-        uint4 bq[BF3 ? 3 : 1];   // BF3: this thread's chunk of the three pieces of the W slab (x, y only at BN = 64)
+        uint4 bq[BF3 ? NPC : 1]; // BF3: this thread's chunk of the three (H2: two) pieces of the W slab (x, y only at BN = 64)
         float4 g0, g1; // SRC 1: da quads; SRC 2: gout quads; SRC 3: the second half of the rows' u
         int4 m0, m1;   // SRC 2: arg-max quads
         int k, ro0, ro1; // k / row offsets of the quads
@@ -323,7 +327,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         }
         if constexpr (BF3) {
 #pragma unroll
-            for (int u = 0; u < 3; u++) {
+            for (int u = 0; u < NPC; u++) {
                 if ((BF3_ABL & 16) && !abl_prologue) break; // probe: the W image neither loaded nor staged after the prologue
                 if constexpr (BN == 128) {
                     r.bq[u] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wvo, (unsigned)u * wpitch, 0));
@@ -507,7 +511,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             A.mask_out[wo] = (unsigned short)(mm & 0xffffu);
             A.mask_out[wo + (size_t)64 * nk] = (unsigned short)(mm >> 16);
         }
-        if constexpr (BF3) {
+        if constexpr (H2) {
+            unsigned h[4], l[4];
+            split2(v0.x, v0.y, h[0], l[0]);
+            split2(v0.z, v0.w, h[1], l[1]);
+            split2(v1.x, v1.y, h[2], l[2]);
+            split2(v1.z, v1.w, h[3], l[3]);
+            const int ao = a_row * 4 + (a_kq & 1) * 2, ap = a_kq >> 1;
+            *reinterpret_cast<uint2 *>(&As3[buf][0][ap][ao]) = make_uint2(h[0], h[1]);
+            *reinterpret_cast<uint2 *>(&As3[buf][1][ap][ao]) = make_uint2(l[0], l[1]);
+            *reinterpret_cast<uint2 *>(&As3[buf][0][ap][ao + 256]) = make_uint2(h[2], h[3]);
+            *reinterpret_cast<uint2 *>(&As3[buf][1][ap][ao + 256]) = make_uint2(l[2], l[3]);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                if ((BF3_ABL & 16) && !abl_prologue) break;
+                if constexpr (BN == 128) *reinterpret_cast<uint4 *>(&Bs3[buf][u][b3_pl][b3_c * 4]) = r.bq[u];
+                else *reinterpret_cast<uint2 *>(&Bs3[buf][u][b3_pl][b3_c * 4 + b3_h * 2]) = make_uint2(r.bq[u].x, r.bq[u].y);
+            }
+            if (NEPI) *reinterpret_cast<float4 *>(&Us[r.tp][tid >> 1][(tid & 1) * 4]) = r.uq;
+            if (EPI == 7) Ms[r.tp][tid & 127] = r.mq;
+            if (EPI == 6) Gs[r.tp][tid & 127] = r.uq;
+            return;
+        } else if constexpr (BF3) {
             unsigned h[4], m[4], l[4];
             split3(v0.x, v0.y, h[0], m[0], l[0]);
             split3(v0.z, v0.w, h[1], m[1], l[1]);
@@ -642,10 +667,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     abl_prologue = false;
     constexpr int MX = MT > NT ? MT : NT;
     uint4 fAlo[MX], fWhi[MX], fAhi[MX], fWmid[MX], fX[2][MX]; // BF3: fragments that live across slabs (see the slab body)
-    if constexpr (BF3) {
+    if constexpr (H2) {
+#pragma unroll
+        for (int i = 0; i < MT; i++) fAlo[i] = *reinterpret_cast<const uint4 *>(&As3[0][1][kh][((wm * MT + i) * 32 + l31) * 4]);
+#pragma unroll
+        for (int j = 0; j < NT; j++) fWhi[j] = *reinterpret_cast<const uint4 *>(&Bs3[0][0][kh][((wn * NT + j) * 32 + l31) * 4]);
+    } else if constexpr (BF3) {
 #pragma unroll
         for (int i = 0; i < MT; i++) {
-            fAlo[i] = *reinterpret_cast<const uint4 *>(&As3[0][2][kh][((wm * MT + i) * 32 + l31) * 4]);
+            fAlo[i] = *reinterpret_cast<const uint4 *>(&As3[0][NPC - 1][kh][((wm * MT + i) * 32 + l31) * 4]);
             fX[0][i] = *reinterpret_cast<const uint4 *>(&As3[0][1][kh][((wm * MT + i) * 32 + l31) * 4]);
         }
 #pragma unroll
@@ -695,10 +725,30 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                         for (int i = 0; i < MT; i++)
 #pragma unroll
                             for (int j = 0; j < NT; j++)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]),
-                                                                                    __builtin_bit_cast(bf16x8, fw_[j]), acc[i][j], 0, 0, 0);
+                                if constexpr (H2)
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa_[i]),
+                                                                                       __builtin_bit_cast(f16x8, fw_[j]), acc[i][j], 0, 0, 0);
+                                else
+                                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa_[i]),
+                                                                                        __builtin_bit_cast(bf16x8, fw_[j]), acc[i][j], 0, 0, 0);
                         if (BF3_PRIO == 3) __builtin_amdgcn_s_setprio(0);
                     };
+                    if constexpr (H2) {
+                        // two pieces, three products: A.lo and W.hi of this slab are in registers since the previous slab's barrier
+                        rdA(fAhi, 0, buf);
+                        rdW(fWmid, 1, buf);      // W.lo (in the block the three-piece schedule keeps W.mid in)
+                        mm(fAlo, fWhi);
+                        store_regs(buf ^ 1, rs); // the other buffer was last read before the previous slab's barrier
+                        mm(fAhi, fWhi);
+                        lds_barrier();
+                        rdA(fAlo, 1, buf ^ 1);   // the next slab's A.lo and W.hi: their blocks are free from here on
+                        rdW(fWhi, 0, buf ^ 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                        issue_loads(rs);
+                        mm(fAhi, fWmid);
+                        buf ^= 1;
+                        continue;
+                    }
                     rdA(fAhi, 0, buf);
                     rdW(fWmid, 1, buf);
                     rdW(fX[par ^ 1], 2, buf); // W.lo
@@ -1180,7 +1230,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         constexpr int NS = NEPI ? 10 : 2; // statistics per column: s1, s2 (+ the eight rows of UG; EPI 7 leaves s2 to its tail)
         float *red = BF3 ? reinterpret_cast<float *>(&As3[0][0][0][0]) : &As[0][0][0]; // [NS][WM][BN]
         static_assert(NS * WM * BN <= 2 * FG_BK * FG_LDA, "reduction scratch exceeds the A buffers");
-        static_assert(!BF3 || NS * WM * BN <= 2 * 3 * 2 * PLA, "reduction scratch exceeds the split A buffers");
+        static_assert(!BF3 || NS * WM * BN <= 2 * NPC * 2 * PLA, "reduction scratch exceeds the split A buffers");
 #pragma unroll
         for (int j = 0; j < NT; j++) {
             const int c = (wn * NT + j) * 32 + l31;
@@ -1262,11 +1312,34 @@ __device__ __forceinline__ void split_weights_body(const float *__restrict__ w, 
         dst[(size_t)4 * cout] = make_uint4(l[0], l[1], l[2], l[3]);
     }
 }
-__global__ __launch_bounds__(256) void split_weights_kernel(const long *__restrict__ table)
+// H2 image: [slab = k/16][piece hi, lo][k-half][column][8 fp16 = 4 dwords], 4 bytes per weight (mlp_types.h: split2)
+__device__ __forceinline__ void split_weights_body_h2(const float *__restrict__ w, unsigned *__restrict__ out, int cin, int cout, int first,
+                                                      int stride)
+{
+    const int items = (cin / 8) * cout;
+    for (int it = first; it < items; it += stride) {
+        const int o = it / cout, c = it - o * cout;
+        float v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) v[i] = w[(size_t)(o * 8 + i) * cout + c];
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+        const int sl = o >> 1, kh = o & 1;
+        uint4 *dst = reinterpret_cast<uint4 *>(out) + ((size_t)(sl * 2) * 2 + kh) * cout + c;
+        dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+        dst[(size_t)2 * cout] = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+}
+__global__ __launch_bounds__(256) void split_weights_kernel(const long *__restrict__ table, int pieces)
 {
     const long *e = table + (size_t)blockIdx.x * 4;
-    split_weights_body(reinterpret_cast<const float *>(e[0]), reinterpret_cast<unsigned *>(e[1]), (int)e[2], (int)e[3],
-                       blockIdx.y * 256 + threadIdx.x, gridDim.y * 256);
+    if (pieces == 2)
+        split_weights_body_h2(reinterpret_cast<const float *>(e[0]), reinterpret_cast<unsigned *>(e[1]), (int)e[2], (int)e[3],
+                              blockIdx.y * 256 + threadIdx.x, gridDim.y * 256);
+    else
+        split_weights_body(reinterpret_cast<const float *>(e[0]), reinterpret_cast<unsigned *>(e[1]), (int)e[2], (int)e[3],
+                           blockIdx.y * 256 + threadIdx.x, gridDim.y * 256);
 }
 __global__ __launch_bounds__(256) void split_weights_one_kernel(const float *__restrict__ w, unsigned *__restrict__ out, int cin, int cout)
 {
@@ -1275,17 +1348,26 @@ __global__ __launch_bounds__(256) void split_weights_one_kernel(const float *__r
 
 // which matrices have an image: keyed by the address the GEMM entry points receive as `w` (the caller keeps the image current:
 // votenet_split_weights after every change of the weights -- pointnet2.ParamStore does, once per step)
+int g_fast_h2 = 1;   // 0: two-piece (fp16 x 2) images are ignored -- those GEMMs then run on the fp32 MFMA kernel (votenet_debug_fast_h2)
 struct W3Entry {
     int cin, cout;
     const unsigned *w3;
+    int np; // pieces: 3 (bf16 x 3) or 2 (fp16 x 2)
 };
 static std::mutex g_w3_mu;
 static std::unordered_map<const void *, W3Entry> g_w3;
-static const unsigned *w3_lookup(const float *w, int cin, int cout)
+// -> the image of w and its piece count in `a`; h2_ok: the caller has a two-piece instantiation (an fp16 x 2 image is useless to the
+// others: they run on w itself, the fp32 MFMA kernel -- never a three-piece kernel on a two-piece image)
+template <class Args> static void w3_lookup(Args &a, const float *w, int cin, int cout, bool h2_ok)
 {
     std::lock_guard<std::mutex> lk(g_w3_mu);
     auto it = g_w3.find(w);
-    return (it != g_w3.end() && it->second.cin == cin && it->second.cout == cout) ? it->second.w3 : nullptr;
+    a.w3 = nullptr;
+    a.w3_np = 3;
+    if (it == g_w3.end() || it->second.cin != cin || it->second.cout != cout) return;
+    if (it->second.np == 2 && !(h2_ok && g_fast_h2)) return;
+    a.w3 = it->second.w3;
+    a.w3_np = it->second.np;
 }
 
 int g_fast_dyn_lds = 0; // probe (votenet_debug_fast_dyn_lds): unused dynamic LDS per BF3 workgroup, to lower the occupancy
@@ -1298,20 +1380,28 @@ template <int SRC, int EPI> constexpr int bf3_family()
 {
     return (EPI == 0 || EPI == 2 || EPI == 8) ? 0 : EPI == 3 ? 3 : EPI == 6 ? 4 : (EPI == 4 || EPI == 7) ? 5 : (SRC == 1 || SRC == 2 || SRC == 5) ? 2 : 1;
 }
+// the families with a two-piece (fp16 x 2) instantiation: forward-type operands only (activations / coordinates x weights)
+template <int SRC, int EPI> constexpr bool h2_built() { return (SRC == 0 || SRC == 3 || SRC == 4) && (EPI == 0 || EPI == 1 || EPI == 2 || EPI == 8); }
 template <int SRC, int EPI> constexpr bool sk_built() { return (SRC == 0 || SRC == 1) && (EPI == 0 || EPI == 1 || EPI == 3); }
 #define FAST_LAUNCH(WM_, WN_, MT_, NT_, SRC_, EPI_, GRID_, ST_, A_)                                                                  \
     do {                                                                                                                             \
         if constexpr (sk_built<SRC_, EPI_>()) {                                                                                      \
             if ((GRID_).z > 1) { /* split-K (sk_take): its own instantiations, so that the others keep their registers */            \
-                if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0)       \
+                if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).w3_np == 3 && (A_).cin % (FG_BK * BF3_SETS) == 0) \
                     hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_); \
                 else                                                                                                                 \
                     hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, false, true>), GRID_, dim3(256), 0, ST_, A_); \
                 break;                                                                                                               \
             }                                                                                                                        \
         }                                                                                                                            \
+        if constexpr (h2_built<SRC_, EPI_>()) {                                                                                      \
+            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).w3_np == 2 && (A_).cin % (FG_BK * BF3_SETS) == 0) { \
+                hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true, false, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_); \
+                break;                                                                                                               \
+            }                                                                                                                        \
+        }                                                                                                                            \
         if constexpr (bf3_built<SRC_, EPI_>()) {                                                                                     \
-            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).cin % (FG_BK * BF3_SETS) == 0) {                                                                  \
+            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).w3_np == 3 && (A_).cin % (FG_BK * BF3_SETS) == 0) { \
                 hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_);    \
                 break;                                                                                                               \
             }                                                                                                                        \
@@ -1376,7 +1466,7 @@ template <int SRC, int EPI>
 static bool fast_dispatch(const FastArgs &a_in, hipStream_t st)
 {
     FastArgs a = a_in;
-    if (bf3_built<SRC, EPI>() && g_fast_bf3) a.w3 = w3_lookup(a.w, a.cin, a.cout);
+    if (bf3_built<SRC, EPI>() && g_fast_bf3) w3_lookup(a, a.w, a.cin, a.cout, h2_built<SRC, EPI>());
     const float *abase = (SRC == 0) ? a.x : (SRC == 3) ? a.u8 : (SRC == 4) ? a.ptab : a.zsrc;
     if (SRC == 4 && ((uintptr_t)a.geo % 16 != 0 || (uintptr_t)a.wx % 16 != 0)) return false;
     if ((SRC == 3 && a.cin > 128) || ((SRC == 3 || EPI == 4 || EPI == 7) && (a.k0 < 1 || a.k0 > 8 || (uintptr_t)a.u8 % 16 != 0))) return false;
@@ -1494,7 +1584,7 @@ bool mlp_linear_pool_launch(const float *x, const float *in_scale, const float *
     a.zmin = zmin;
     a.amax = amax;
     a.amin = amin;
-    if (g_fast_bf3) a.w3 = w3_lookup(w, cin, cout);
+    if (g_fast_bf3) w3_lookup(a, w, cin, cout, true);
     const bool aligned = ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0) && ((uintptr_t)z % 16 == 0);
     if (!aligned || cin % (2 * FG_BK) != 0 || cin > 512 || rows % FG_BM != 0 || rows == 0 || cout % 128 != 0) return false;
     const long ntiles = rows / FG_BM;
@@ -1790,8 +1880,18 @@ extern "C" int votenet_split_weights(int nseg, const long *table, void *stream)
     VN_REQUIRE(nseg >= 0, "split_weights expects nseg >= 0");
     if (nseg == 0) return VOTENET_OK;
     VN_REQUIRE(table != nullptr, "split_weights: null table");
-    hipLaunchKernelGGL(votenet::split_weights_kernel, dim3(nseg, 8), dim3(256), 0, as_stream(stream), table);
+    hipLaunchKernelGGL(votenet::split_weights_kernel, dim3(nseg, 8), dim3(256), 0, as_stream(stream), table, 3);
     return check_launch("split_weights");
+}
+// The same table as TWO fp16 pieces per weight (image address: cin * cout * 4 bytes; mlp_types.h: split2) -- for matrices whose GEMMs
+// multiply forward operands (register them with votenet_register_split_weights_pieces(..., 2)).
+extern "C" int votenet_split_weights_h2(int nseg, const long *table, void *stream)
+{
+    VN_REQUIRE(nseg >= 0, "split_weights_h2 expects nseg >= 0");
+    if (nseg == 0) return VOTENET_OK;
+    VN_REQUIRE(table != nullptr, "split_weights_h2: null table");
+    hipLaunchKernelGGL(votenet::split_weights_kernel, dim3(nseg, 8), dim3(256), 0, as_stream(stream), table, 2);
+    return check_launch("split_weights_h2");
 }
 
 // The image of ONE matrix, arguments by value (a matrix made on the fly, e.g. votenet_pool_dgrad_prepare's).
@@ -1807,15 +1907,25 @@ extern "C" int votenet_split_weights_one(const float *w, int cin, int cout, void
 
 // Tell the GEMM entry points that the matrix they receive at address `w` (cin x cout) has a current image at `w3`
 // (w3 == NULL: forget it).  While registered, the fused forward / input-gradient GEMMs read the image instead of w.
-extern "C" int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3)
+extern "C" int votenet_register_split_weights_pieces(const float *w, int cin, int cout, const void *w3, int pieces)
 {
     VN_REQUIRE(w != nullptr, "register_split_weights: null w");
     VN_REQUIRE(w3 == nullptr || (cin > 0 && cin % 16 == 0 && cout > 0 && (uintptr_t)w3 % 16 == 0),
                "register_split_weights expects cin % 16 == 0, cout > 0 and a 16-byte aligned image");
+    VN_REQUIRE(pieces == 2 || pieces == 3, "register_split_weights: pieces must be 3 (bf16 x 3) or 2 (fp16 x 2)");
     std::lock_guard<std::mutex> lk(votenet::g_w3_mu);
-    if (w3) votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3)};
+    if (w3) votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3), pieces};
     else votenet::g_w3.erase(w);
     return VOTENET_OK;
+}
+extern "C" int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3)
+{
+    return votenet_register_split_weights_pieces(w, cin, cout, w3, 3);
+}
+extern "C" void votenet_debug_fast_h2(int on)
+{
+    VN_DEBUG_GATE();
+    votenet::g_fast_h2 = on ? 1 : 0;
 }
 extern "C" void votenet_debug_fast_workgroups(int cap22, int cap41) // tuning hook: 0 keeps a value
 {

@@ -94,4 +94,27 @@ __device__ __forceinline__ void split3(float x, float y, unsigned &h, unsigned &
     l = pack_bf16_rne(sx, sy);
 }
 
+// H2 (round 6): the same idea on fp16.  x = hi + lo with hi = rne16(x), lo = rne16(x - hi): 22 significant bits, a product is the THREE
+// fp16 MFMA terms hi*hi + hi*lo + lo*hi (v_mfma_f32_32x32x16_f16, fp32 accumulate; gfx950 honours fp16 subnormals in MFMA inputs:
+// tools/probe/src/mfma_f16_denorm.hip, profiles/r06_mfma_f16_denorm.txt -- the lo piece of an O(0.1) value IS a subnormal).  What is
+// left out (lo*lo and the 2^-22 the split itself drops) is below the fp32 rounding of a 128-term dot product: measured error against
+// float64 equal to bf16 x 3's and the fp32 chain's (same probe).  Half the MFMAs and a third of the staging instructions of split3 --
+// but fp16's RANGE: |x| must stay below 65504 and values below 2^-24 vanish, so this form serves FORWARD operands only (activations
+// behind a BatchNorm, coordinates, weights); gradients stay on bf16 x 3.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split2(float x, float y, unsigned &h, unsigned &l)
+{
+    const f16x2 hv = {(_Float16)x, (_Float16)y};
+    h = __builtin_bit_cast(unsigned, hv);
+    // the residual x - hi as ONE v_fma_mix_f32 (-hi * 1 + x, exact: hi is read as fp16 straight out of the packed register) instead of
+    // v_cvt_f32_f16 + v_sub_f32: the staging arithmetic is what bounds these kernels.  (The compiler folds fmaf(ext(hi), -1, x) back
+    // into the subtraction, hence the asm.)
+    float rx, ry;
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel_hi:[1,0,0]" : "=v"(rx) : "v"(h), "v"(x));
+    asm("v_fma_mix_f32 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(ry) : "v"(h), "v"(y));
+    const f16x2 lv = {(_Float16)rx, (_Float16)ry};
+    l = __builtin_bit_cast(unsigned, lv);
+}
+
 } // namespace votenet

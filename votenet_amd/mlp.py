@@ -365,17 +365,20 @@ class SplitImages:
     registered with the library so that the GEMM entry points which receive one of the matrices read its image.  The owner calls
     refresh() after every change of the weights; close() (or deletion) withdraws the registrations."""
 
-    def __init__(self, mats):
+    def __init__(self, mats, pieces=3):
+        """pieces = 3: bf16 x 3 (any operand); 2: fp16 x 2 (votenet_split_weights_h2: matrices that multiply FORWARD operands only)."""
         mats = [w for w in mats if w.dim() == 2 and w.is_contiguous() and split_eligible(*w.shape)]
         self.mats = mats
         self.nseg = len(mats)
+        self.pieces = int(pieces)
+        assert self.pieces in (2, 3)
         if not mats:
             return
         dev = mats[0].device
         total, offs = 0, []
         for w in mats:
             offs.append(total)
-            total += w.shape[0] * w.shape[1] * 6
+            total += w.shape[0] * w.shape[1] * 2 * self.pieces
             total = (total + 15) // 16 * 16
         self.buf = torch.empty(total, dtype=torch.uint8, device=dev)
         base = self.buf.data_ptr()
@@ -385,12 +388,13 @@ class SplitImages:
         self.table = torch.tensor(table, dtype=torch.int64, device=dev)
         self._reg = [(w.data_ptr(), w.shape[0], w.shape[1], base + o) for w, o in zip(mats, offs)]
         for wp, cin, cout, ip in self._reg:
-            L.check(L.lib().votenet_register_split_weights(ctypes.c_void_p(wp), cin, cout, ctypes.c_void_p(ip)))
+            L.check(L.lib().votenet_register_split_weights_pieces(ctypes.c_void_p(wp), cin, cout, ctypes.c_void_p(ip), self.pieces))
 
     def refresh(self):
         if self.nseg:
             with L.device_guard(self.buf.device):
-                L.check(L.lib().votenet_split_weights(self.nseg, L.ptr(self.table), L.stream_ptr()))
+                fn = L.lib().votenet_split_weights_h2 if self.pieces == 2 else L.lib().votenet_split_weights
+                L.check(fn(self.nseg, L.ptr(self.table), L.stream_ptr()))
 
     def close(self):
         for wp, cin, cout, _ in getattr(self, "_reg", []):
@@ -404,6 +408,7 @@ class SplitImages:
             pass
 
 
+FORWARD_H2 = True    # the images of the FORWARD weight matrices as fp16 x 2 (three MFMAs per product instead of six; csrc/mlp_types.h: split2); the transposed copies the backward GEMMs read stay bf16 x 3 (gradients need fp32's range)
 SPLIT_K = False      # the fused GEMMs of few row tiles (the static stretch: 2048-8192 rows) share an output tile's contraction between 2-4 workgroups (csrc/mlp_fast.hip, FastArgs::sk_ws)
 _SK_TICKETS = {}     # device -> the zeroed ticket array registered with the library (kept alive here)
 

@@ -100,7 +100,7 @@ class ParamStore:
         if self._split_flat is None:
             mats = [v for v in self.views.values() if v.dim() == 2]
             mats += [self.views[name][lo:hi] for name, lo, hi in self._split_rows]  # e.g. W[3:]: the per-point GEMM P = feat W[3:]
-            self._split_flat = M.SplitImages(mats)
+            self._split_flat = M.SplitImages(mats, pieces=2 if (M.FORWARD_H2 and not M.SPLIT_K) else 3)
         self._split_flat.refresh()
         self._split_gen = self.generation
 
