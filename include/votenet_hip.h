@@ -302,6 +302,13 @@ int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *b
  * votenet_split_weights) for the one forward-type GEMM that multiplies by it (register it around that launch) */
 int votenet_pool_dgrad_prepare_split(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                      float *cvec, void *image, void *stream);
+/* Round 6: the image as two fp16 pieces scaled by powers of two (the matrix is gradient-sized: below fp16's range unscaled).  image:
+ * cin * cin * 4 bytes; ascale / unscale: cin floats each, written by the launch -- the power-of-two factors of the GEMM's input
+ * channels and output columns.  Register the three around the ONE GEMM that multiplies by mmat:
+ *   votenet_register_split_weights_scaled(mmat, cin, cin, image, ascale, unscale); <the GEMM>; votenet_register_split_weights(mmat, cin, cin, NULL). */
+int votenet_pool_dgrad_prepare_h2(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat, float *cvec,
+                                  void *image, float *ascale, float *unscale, void *stream);
+int votenet_register_split_weights_scaled(const float *w, int cin, int cout, const void *w3, const float *ascale, const float *unscale);
 /* da (groups*k x cin) += the scattered rows; wT = W^T (cout x cin).  With below_z != NULL (the raw output, rows x cin, of
  * the layer BELOW, whose output gradient da is) the same pass also performs that layer's votenet_bn_backward_reduce:
  * below_sums (2*cin doubles, pre-zeroed) += [sum g', sum g' zhat] with g' = the final da masked by the layer's ReLU. */

@@ -61,8 +61,8 @@ void votenet_debug_wgrad_workgroups(int n);  /* workgroups of the split-operand 
 void votenet_debug_bn_reduce_passes(int n);  /* row passes per workgroup of the dense BatchNorm-backward reduction (default 16) */
 
 /* ---- pooled layers' backward (pool_bwd.hip) ---- */
-/* votenet_mlp_gram on split operands as well (8 consecutive rows of a channel per MFMA fragment; c = 64 or 128, no scratch = atomics
- * mode); 0: the fp32 MFMA kernel always.  Default 1. */
+/* votenet_mlp_gram on split operands (8 consecutive rows of a channel per MFMA fragment; c = 64 or 128, no scratch = atomics mode):
+ * 1 (default) as fp16 x 2 pieces (both operands are activations), 3 as bf16 x 3 pieces; 0: the fp32 MFMA kernel always. */
 void votenet_debug_gram_bf3(int on);
 void votenet_debug_gram_workgroups(int n);            /* workgroups of the split-operand Gram kernel (default 384) */
 void votenet_debug_zsel_grid(int groups_per_wg, int cap); /* grid of the pooled BatchNorm-backward reduction (default 32 groups per workgroup, at most 256 workgroups) */

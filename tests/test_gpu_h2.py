@@ -34,14 +34,16 @@ def test_the_two_piece_image_has_the_kernels_lds_order_and_22_bits(h2, dev):
     from votenet_amd import mlp
     rng = np.random.default_rng(0)
     cin, cout = 64, 128
-    w = (rng.normal(size=(cin, cout)) * np.exp(rng.uniform(-6, 6, size=(cin, cout)))).astype(np.float32)
-    w[0, 0], w[1, 1], w[2, 2], w[3, 3] = 0.0, -0.0, np.float32(2.0 ** -30), np.float32(60000.0)
-    w[4, 4], w[5, 5], w[6, 6], w[7, 7] = np.float32(3e-6), np.float32(-5e-5), np.float32(7e-8), np.float32(6.1e-5)  # hi itself a subnormal
-    hi, lo = split2_numpy(w)
-    rec = hi.astype(np.float64) + lo.astype(np.float64)
-    ok = np.abs(w) >= 2.0 ** -3  # hi AND lo normal: 22 significant bits
+    w = (rng.normal(size=(cin, cout)) * np.exp(rng.uniform(-9, 3, size=(cin, cout)))).astype(np.float32)
+    w[0, 0], w[1, 1], w[2, 2], w[3, 3] = 0.0, -0.0, np.float32(2.0 ** -34), np.float32(200.0)
+    w[4, 4], w[5, 5], w[6, 6], w[7, 7] = np.float32(3e-6 / 256), np.float32(-5e-5 / 256), np.float32(7e-8 / 256), np.float32(6.1e-5 / 256)  # hi itself a subnormal
+    w[3, 3] = np.float32(200.0)               # the image holds 2^8 w (exact): |w| < 255
+    ws = w * np.float32(256.0)
+    hi, lo = split2_numpy(ws)
+    rec = (hi.astype(np.float64) + lo.astype(np.float64)) / 256.0
+    ok = np.abs(w) >= 2.0 ** -10  # hi AND lo normal numbers (of 2^8 w): 22 significant bits
     assert (np.abs(rec - w)[ok] <= np.abs(w)[ok] * 2.0 ** -22).all()
-    assert (np.abs(rec - w) <= np.maximum(np.abs(w) * 2.0 ** -22, 2.0 ** -25)).all()  # below: the subnormal spacing of the lo piece
+    assert (np.abs(rec - w) <= np.maximum(np.abs(w) * 2.0 ** -22, 2.0 ** -33)).all()  # below: the subnormal spacing of the lo piece / 2^8
     wt = T(w, dev)
     img = mlp.SplitImages([wt], pieces=2)
     img.refresh()
@@ -104,7 +106,7 @@ def test_small_and_large_magnitudes_inside_fp16s_range(h2, dev):
     from votenet_amd import mlp
     rng = np.random.default_rng(3)
     rows, cin, cout = 4096, 128, 128
-    for xs, ws in ((1e-3, 1.0), (1.0, 1e-3), (300.0, 0.05), (1e-2, 1e-2), (2000.0, 1.0)):
+    for xs, ws in ((1e-2, 1.0), (1.0, 1e-3), (300.0, 0.05), (3e-2, 1e-2), (500.0, 1.0), (1.0, 50.0)):
         x = (rng.normal(size=(rows, cin)) * xs).astype(np.float32)
         w = (rng.normal(size=(cin, cout)) * ws).astype(np.float32)
         xt, wt = T(x, dev), T(w, dev)
@@ -135,3 +137,64 @@ def test_a_backward_entry_point_ignores_a_two_piece_image(h2, dev):
     got = mlp.dgrad_bn(z, coef, True, wT, da=da)
     img.close()
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("cin,cout", [(128, 256), (128, 128), (64, 128)])
+@pytest.mark.parametrize("cscale", [1.0, 1e-6, 1e-12])
+def test_the_gram_form_dgrad_matrix_as_a_scaled_two_piece_image(h2, dev, cin, cout, cscale):
+    """votenet_pool_dgrad_prepare_h2: W diag(C) W^T is gradient-sized (C is a BatchNorm-backward coefficient): its fp16 x 2 image is
+    scaled by powers of two taken from |W[j,:]|, |W[k,:]| and max|C| inside the launch that forms it; the GEMM scales its staged input
+    channels and its output columns back.  Against float64 and the fp32 MFMA kernel, at coefficient magnitudes from 1 down to 1e-12,
+    with weight rows of very different norms."""
+    from votenet_amd import mlp
+    g = torch.Generator().manual_seed(cin + cout)
+    groups, k = 512, 64
+    rows = groups * k
+    w = torch.randn(cin, cout, generator=g) * 0.15
+    w[::7] *= 30.0     # rows of very different norms
+    w[3::11] *= 1e-3
+    w[5] = 0.0         # a dead input channel
+    w = w.to(dev)
+    b = (torch.randn(cout, generator=g) * 0.1).to(dev)
+    coef = (torch.randn(5 * cout, generator=g) * cscale).to(dev)
+    xz = torch.randn(rows, cin, generator=g).to(dev)
+    aff = torch.stack([torch.randn(cin, generator=g) * 0.3 + 1, torch.randn(cin, generator=g) * 0.2]).to(dev).contiguous()
+    assert mlp.ADHOC_H2 and mlp.FORWARD_H2
+    mm = mlp.pool_dgrad_prepare(w, b, coef, rows)
+    assert getattr(mm, "_h2", None) is not None and mm._img.numel() == cin * cin * 4
+    mlp.ADHOC_H2 = False
+    try:
+        mm0 = mlp.pool_dgrad_prepare(w, b, coef, rows)
+    finally:
+        mlp.ADHOC_H2 = True
+    assert getattr(mm0, "_img", None) is None and torch.equal(mm0, mm)  # the fp32 matrix itself is the same
+    # the scale vectors are powers of two, the scaled matrix fits fp16 with room to spare
+    sv = N(mm._h2)
+    assert (np.frexp(sv)[0] == 0.5).all()
+    scaled = N(mm[:cin]).astype(np.float64) * (sv[0][:, None] / 16.0) ** -1 / (sv[1][None, :] * 16.0)
+    assert np.abs(scaled).max() <= 2.0 ** 13
+    from votenet_amd import _lib as L
+
+    def dense(m):
+        if getattr(m, "_h2", None) is not None:
+            L.check(L.lib().votenet_register_split_weights_scaled(L.ptr(m), cin, cin, L.ptr(m._img), L.ptr(m._h2[0]), L.ptr(m._h2[1])))
+        try:
+            return mlp.linear_dense(xz, m[:cin], m[cin], aff[0], aff[1], True, want_stats=False)[0]
+        finally:
+            L.lib().votenet_register_split_weights(L.ptr(m), cin, cin, None)
+    d2, d0 = dense(mm), dense(mm0)
+    a = torch.relu(xz.double() * aff[0].double() + aff[1].double())
+    exact = a @ mm[:cin].double() + mm[cin].double()
+    bound = float((a.abs() @ mm[:cin].double().abs()).max())
+    e2, e0 = float((d2.double() - exact).abs().max()) / bound, float((d0.double() - exact).abs().max()) / bound
+    assert not torch.equal(d2, d0)
+    assert e2 <= 2e-6 and e2 <= 3.0 * e0 + 3e-7, (e2, e0)
+    # and the whole pooled-layer input gradient through mlp.pool_dgrad
+    gout = (torch.randn(groups, cout, generator=g) * cscale).to(dev)
+    arg = torch.randint(0, k, (groups, cout), generator=g, dtype=torch.int32).to(dev)
+    zsel = torch.randn(groups, cout, generator=g).to(dev)
+    wT = w.t().contiguous()
+    da2 = mlp.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k, mm=mm)
+    da0 = mlp.pool_dgrad(xz, aff[0], aff[1], True, w, b, wT, coef, True, gout, arg, zsel, k, mm=mm0)
+    d = float((da2 - da0).abs().max() / da0.abs().max())
+    assert 0.0 < d < 5e-6, d

@@ -112,6 +112,8 @@ _SIGS.update({
     "votenet_split_weights": [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_split_weights_h2": [ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_register_split_weights_pieces": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int],
+    "votenet_register_split_weights_scaled": [_c_f, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, _c_f, _c_f],
+    "votenet_pool_dgrad_prepare_h2": [ctypes.c_int, ctypes.c_int] + [_c_f] * 8 + [ctypes.c_void_p],
     "votenet_split_weights_one": [_c_f, ctypes.c_int, ctypes.c_int, _c_f, ctypes.c_void_p],
     "votenet_mlp_split_k_arm": [ctypes.c_void_p, ctypes.c_long],
     "votenet_mlp_split_k_tickets": [ctypes.c_void_p, ctypes.c_long],

@@ -48,6 +48,9 @@ constexpr int FG_LDA = FG_BM + 2;
 #ifndef BF3_PRIO
 #define BF3_PRIO 0 // BF3: 1 = matrix loop at s_setprio 1, epilogue at 0; 2 = the reverse; 3 = prio 1 only around the MFMAs of a slab
 #endif
+#ifndef H2_SCALE
+#define H2_SCALE 1 // H2: operands travel scaled by powers of two (see kH2A below); 0 in probe builds only
+#endif
 #ifndef BF3_ABL
 #define BF3_ABL 0 // probe builds only (tools/probe/bf3_ablate.sh): 1 no MFMAs, 2 no epilogue, 4 no global loads after the prologue, 8 no staging,
                   // 16 the W image neither loaded nor staged after the prologue (upper bound of what LDS-resident weights could save)
@@ -112,6 +115,8 @@ struct FastArgs {
     const float *w, *bias;
     const unsigned *w3;    // BF3: w as three bf16 pieces in the kernel's LDS order (votenet_split_weights), or NULL
     int w3_np;             // pieces of that image: 3 (bf16 x 3) or 2 (fp16 x 2: H2 instantiations, forward families only)
+    const float *h2_ascale, *h2_unscale; // H2 with a matrix made on the fly (votenet_pool_dgrad_prepare_h2): power-of-two scale per INPUT channel
+                                         // (replaces the 2^4 of the staged activations) and per OUTPUT column (replaces 2^-12); NULL: the constants
     float *z;              // may be NULL with EPI 2 (inference: only the pooled result is wanted)
     float *zmax, *zmin;    // EPI 2: per 64-row group and channel, raw max / min of z ...
     int *amax, *amin;      //        ... and the row offsets (first occurrence) where they are attained
@@ -155,6 +160,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 {
     static_assert(!H2 || (BF3 && !SK && (SRC == 0 || SRC == 3 || SRC == 4)), "H2: a split-operand forward-type instantiation");
     constexpr int NPC = H2 ? 2 : 3;               // pieces per operand (split images, LDS planes)
+    // H2: both operands travel scaled by a power of two (exact) so that their lo pieces stay NORMAL fp16 numbers for everyday magnitudes:
+    // the weights by 2^8 in the image (split_weights_body_h2), the staged activations by 2^4 (folded into the BatchNorm scale / shift
+    // table: no instruction), the accumulators are scaled back by 2^-12 inside the epilogue's bias add (an fma instead of an add: no
+    // instruction).  Full 22 bits for |a| >= 2^-6 and |w| >= 2^-10 (unscaled: 2^-2 each); |a| < 4094, |w| < 255 or the result is inf.
+    constexpr float kH2A = (H2 && H2_SCALE) ? 16.0f : 1.0f, kH2Un = (H2 && H2_SCALE) ? 1.0f / 4096.0f : 1.0f;
     constexpr bool POOL = (EPI == 2 || EPI == 8); // pooled forward layer
     constexpr bool P32 = (EPI == 8);              // ... per 16-row piece
     static_assert(WM * WN == 4 && WM * MT * 32 == FG_BM, "tile shape");
@@ -594,11 +604,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     issue_loads(R[0]);
     // (the bias and, pool32, the pooled layer's gamma -- the sign of the scale the pool will apply -- of this lane's columns: loaded
     // here, consumed below)
-    float bvs[NT], sgs[NT];
+    float bvs[NT], sgs[NT], uns[NT]; // uns: what scales an accumulator back (1 unless H2)
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         bvs[j] = A.bias ? A.bias[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 0.0f;
         sgs[j] = P32 ? A.pool_gamma[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : 1.0f;
+        uns[j] = (H2 && A.h2_unscale) ? A.h2_unscale[n0 + (wv % WN * NT + j) * 32 + (lane & 31)] : kH2Un;
     }
     __builtin_amdgcn_sched_barrier(0);
     if (SRC == 4)
@@ -616,17 +627,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             for (int k = tid; k < cin; k += 256) {
                 float sc, sh;
                 bn_raw_channel(A.in_raw, cin, k, writer, sc, sh);
-                Sco[0][k] = sc;
-                Sco[1][k] = sh;
+                const float ka = (H2 && A.h2_ascale) ? A.h2_ascale[k] : kH2A;
+                Sco[0][k] = sc * ka;
+                Sco[1][k] = sh * ka;
             }
         } else if (affine)
             for (int k = tid; k < cin; k += 256) {
-                Sco[0][k] = A.in_scale[k];
-                Sco[1][k] = A.in_shift[k];
+                const float ka = (H2 && A.h2_ascale) ? A.h2_ascale[k] : kH2A;
+                Sco[0][k] = A.in_scale[k] * ka;
+                Sco[1][k] = A.in_shift[k] * ka;
             }
         else if (BF3) // the BF3 loader has no branch on `affine`: x * 1 + 0
             for (int k = tid; k < cin; k += 256) {
-                Sco[0][k] = 1.0f;
+                Sco[0][k] = (H2 && A.h2_ascale) ? A.h2_ascale[k] : kH2A;
                 Sco[1][k] = 0.0f;
             }
     } else {
@@ -646,6 +659,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
     for (int j = 0; j < NT; j++) {
         asm volatile("" : "+v"(bvs[j]));
+        if (H2) asm volatile("" : "+v"(uns[j]));
         sgs[j] = (P32 && sgs[j] < 0.0f) ? -1.0f : 1.0f;
         asm volatile("" : "+v"(sgs[j]));
     }
@@ -880,7 +894,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     const unsigned sbase = (unsigned)((wm * MT + i) * 32) * pitch + (unsigned)((wn * NT + j) * 32) * 4u;
 #pragma unroll
                     for (int e = 0; e < 16; e++)
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][e] + bv), zr, svoff,
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(H2 ? __builtin_fmaf(acc[i][j][e], uns[j], bv) : acc[i][j][e] + bv), zr, svoff,
                                                               sbase + (unsigned)((e & 3) + 8 * (e >> 2)) * pitch, 0);
                 }
             }
@@ -889,11 +903,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
 #pragma unroll
             for (int j = 0; j < NT; j++) {
                 const f32x2 bv2 = {bvs[j], bvs[j]};
+                const f32x2 un2 = {uns[j], uns[j]};
 #pragma unroll
                 for (int i = 0; i < MT; i++) {
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
-                        const f32x2 v = bv2 + f32x2{acc[i][j][e], acc[i][j][e + 1]}; // broadcast operand FIRST: op_sel lands on src0 (packed-f32 hazard)
+                        // broadcast operand FIRST: op_sel lands on src0 (packed-f32 hazard)
+                        const f32x2 v = H2 ? __builtin_elementwise_fma(un2, f32x2{acc[i][j][e], acc[i][j][e + 1]}, bv2)
+                                           : bv2 + f32x2{acc[i][j][e], acc[i][j][e + 1]};
                         s1p[j] += v;
                         s2p[j] = __builtin_elementwise_fma(v, v, s2p[j]);
                     }
@@ -908,7 +925,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                 for (int i = 0; i < MT; i++) {
 #pragma unroll
                     for (int e = 0; e < 16; e++) {
-                        const float v = acc[i][j][e] + bv;
+                        const float v = H2 ? __builtin_fmaf(acc[i][j][e], uns[j], bv) : acc[i][j][e] + bv;
                         {
                             const int rloc = 4 * kh + (e & 3) + 8 * (e >> 2); // inside the 32-row block; ascending in e: strict compares
                             if (e == 0 || v > pmaxv[i][j]) {                  // keep the first occurrence
@@ -948,7 +965,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     const float wa = (kh == 0) ? whs[2 * i] - 1.0f : 0.0f, wb = (kh == 0) ? whs[2 * i + 1] - 1.0f : 0.0f;
 #pragma unroll
                     for (int j = 0; j < NT; j++) {
-                        const float va = acc[i][j][0] + bvs[j], vb = acc[i][j][8] + bvs[j];
+                        const float va = H2 ? __builtin_fmaf(acc[i][j][0], uns[j], bvs[j]) : acc[i][j][0] + bvs[j];
+                        const float vb = H2 ? __builtin_fmaf(acc[i][j][8], uns[j], bvs[j]) : acc[i][j][8] + bvs[j];
                         s1[j] += wa * va + wb * vb;
                         s2[j] += wa * (va * va) + wb * (vb * vb);
                     }
@@ -1163,10 +1181,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                         for (int j = 0; j < NT; j++) {
                             // the sign of the BatchNorm scale is the sign of gamma: the max of sg * z, first occurrence, is the entry the
                             // pool takes (the max where the scale is >= 0, the min where it is negative); sg * (z + b) as one fma (sg = +-1: exact)
-                            const float sg = sgs[j], sb = sg * bvs[j];
+                            const float sg = sgs[j], sb = sg * bvs[j], sgu = sg * uns[j]; // (H2: the accumulators are 2^12 x the sums)
                             float v[8];
 #pragma unroll
-                            for (int e8 = 0; e8 < 8; e8++) v[e8] = __builtin_fmaf(sg, acc[i][j][hh * 8 + e8], sb);
+                            for (int e8 = 0; e8 < 8; e8++) v[e8] = __builtin_fmaf(sgu, acc[i][j][hh * 8 + e8], sb);
                             float best = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaxf(v[0], v[1]), __builtin_fmaxf(v[2], v[3])),
                                                          __builtin_fmaxf(__builtin_fmaxf(v[4], v[5]), __builtin_fmaxf(v[6], v[7])));
                             int ibest = kh4 + 11; // rloc(e8) = 4 kh + (e8 & 3) + 8 (e8 >> 2), ascending in e8
@@ -1321,7 +1339,7 @@ __device__ __forceinline__ void split_weights_body_h2(const float *__restrict__ 
         const int o = it / cout, c = it - o * cout;
         float v[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) v[i] = w[(size_t)(o * 8 + i) * cout + c];
+        for (int i = 0; i < 8; i++) v[i] = w[(size_t)(o * 8 + i) * cout + c] * (H2_SCALE ? 256.0f : 1.0f); // 2^8: see kH2A / kH2Un in the kernel
         unsigned h[4], l[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
@@ -1353,6 +1371,7 @@ struct W3Entry {
     int cin, cout;
     const unsigned *w3;
     int np; // pieces: 3 (bf16 x 3) or 2 (fp16 x 2)
+    const float *ascale, *unscale; // np == 2, a matrix made on the fly: FastArgs::h2_ascale / h2_unscale (else NULL)
 };
 static std::mutex g_w3_mu;
 static std::unordered_map<const void *, W3Entry> g_w3;
@@ -1364,10 +1383,13 @@ template <class Args> static void w3_lookup(Args &a, const float *w, int cin, in
     auto it = g_w3.find(w);
     a.w3 = nullptr;
     a.w3_np = 3;
+    a.h2_ascale = a.h2_unscale = nullptr;
     if (it == g_w3.end() || it->second.cin != cin || it->second.cout != cout) return;
     if (it->second.np == 2 && !(h2_ok && g_fast_h2)) return;
     a.w3 = it->second.w3;
     a.w3_np = it->second.np;
+    a.h2_ascale = it->second.ascale;
+    a.h2_unscale = it->second.unscale;
 }
 
 int g_fast_dyn_lds = 0; // probe (votenet_debug_fast_dyn_lds): unused dynamic LDS per BF3 workgroup, to lower the occupancy
@@ -1914,8 +1936,19 @@ extern "C" int votenet_register_split_weights_pieces(const float *w, int cin, in
                "register_split_weights expects cin % 16 == 0, cout > 0 and a 16-byte aligned image");
     VN_REQUIRE(pieces == 2 || pieces == 3, "register_split_weights: pieces must be 3 (bf16 x 3) or 2 (fp16 x 2)");
     std::lock_guard<std::mutex> lk(votenet::g_w3_mu);
-    if (w3) votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3), pieces};
+    if (w3) votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3), pieces, nullptr, nullptr};
     else votenet::g_w3.erase(w);
+    return VOTENET_OK;
+}
+// A two-piece image whose scaling is NOT the standard one (weights x 2^8): ascale (cin floats, device) scales the staged input channels,
+// unscale (cout floats, device) the output columns -- votenet_pool_dgrad_prepare_h2 writes the image and both vectors.
+extern "C" int votenet_register_split_weights_scaled(const float *w, int cin, int cout, const void *w3, const float *ascale, const float *unscale)
+{
+    VN_REQUIRE(w != nullptr && w3 != nullptr && ascale != nullptr && unscale != nullptr, "register_split_weights_scaled: null argument");
+    VN_REQUIRE(cin > 0 && cin % 16 == 0 && cout > 0 && (uintptr_t)w3 % 16 == 0,
+               "register_split_weights_scaled expects cin % 16 == 0, cout > 0 and a 16-byte aligned image");
+    std::lock_guard<std::mutex> lk(votenet::g_w3_mu);
+    votenet::g_w3[w] = votenet::W3Entry{cin, cout, static_cast<const unsigned *>(w3), 2, ascale, unscale};
     return VOTENET_OK;
 }
 extern "C" int votenet_register_split_weights(const float *w, int cin, int cout, const void *w3)

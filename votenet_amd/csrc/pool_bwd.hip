@@ -83,7 +83,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_zsel_kernel(long groups, in
 template <int COUT>
 __global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, const float *__restrict__ w, const float *__restrict__ bias,
                                                                  const float *__restrict__ coef, float *__restrict__ mmat,
-                                                                 float *__restrict__ cvec, unsigned *__restrict__ image)
+                                                                 float *__restrict__ cvec, unsigned *__restrict__ image,
+                                                                 float *__restrict__ h2_ascale = nullptr, float *__restrict__ h2_unscale = nullptr)
 {
     constexpr int LD = COUT + 4;
     __shared__ __attribute__((aligned(16))) float Wj[16][LD], Wk[16][LD];
@@ -112,7 +113,64 @@ __global__ __launch_bounds__(256) void pool_dgrad_prepare_kernel(int cin, const 
     }
     if (j0 + ty < cin && k0 + tx < cin) mmat[(size_t)(j0 + ty) * cin + k0 + tx] = acc;
     if (blockIdx.y == 0 && ty == 0 && k0 + tx < cin) cvec[k0 + tx] = accv;
-    if (image != nullptr) {
+    if (image != nullptr && h2_ascale != nullptr) {
+        // Round 6: the image as TWO fp16 pieces (mlp_types.h: split2).  The matrix is gradient-sized (C is a BatchNorm-backward
+        // coefficient), far below fp16's range: it travels scaled by powers of two chosen from what THIS workgroup holds --
+        //   |M[j][k]| <= max|C| * |W[j,:]| * |W[k,:]|   (Cauchy-Schwarz)
+        // so M'[j][k] = M[j][k] * S / (rn[j] rn[k]) with rn[r] = the power of two >= |W[r,:]| and S = 2^13 / (the power of two >= max|C|)
+        // is below 2^13 everywhere.  The GEMM multiplies input channel j by 16 rn[j] while it stages it (h2_ascale, folded into the
+        // BatchNorm table) and scales output column k back by rn[k] / (16 S) in its bias add (h2_unscale): every factor a power of
+        // two, the product exact.
+        __shared__ float nj[16], nk[16], cmax[4];
+        __syncthreads();
+        {
+            float pj = 0.0f, pk = 0.0f; // thread (ty, tx): partial squared norms of rows j0 + ty (Wj) and k0 + ty (Wk)
+            for (int c = tx; c < COUT; c += 16) {
+                pj += Wj[ty][c] * Wj[ty][c];
+                pk += Wk[ty][c] * Wk[ty][c];
+            }
+#pragma unroll
+            for (int o = 8; o >= 1; o >>= 1) {
+                pj += __shfl_xor(pj, o);
+                pk += __shfl_xor(pk, o);
+            }
+            if (tx == 0) {
+                nj[ty] = sqrtf(pj);
+                nk[ty] = sqrtf(pk);
+            }
+            float cm = 0.0f;
+            for (int c = tid; c < COUT; c += 256) cm = fmaxf(cm, fabsf(Cs[c]));
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) cm = fmaxf(cm, __shfl_xor(cm, o));
+            if ((tid & 63) == 0) cmax[tid >> 6] = cm;
+        }
+        __syncthreads();
+        auto pow2_ge = [](float v) { // the power of two >= v (1 for 0; clamped: a dead layer must not produce inf)
+            int e = 0;
+            if (v > 0.0f) (void)frexpf(v, &e);
+            e = e < -100 ? -100 : (e > 100 ? 100 : e);
+            return ldexpf(1.0f, e);
+        };
+        const float S = ldexpf(1.0f, 13) / pow2_ge(fmaxf(fmaxf(cmax[0], cmax[1]), fmaxf(cmax[2], cmax[3])));
+        const float rj = pow2_ge(nj[ty]), rk = pow2_ge(nk[tx]);
+        if (blockIdx.y == 0 && ty == 0 && k0 + tx < cin) {
+            h2_ascale[k0 + tx] = 16.0f * rk;
+            h2_unscale[k0 + tx] = rk / (16.0f * S);
+        }
+        float(*T)[LD] = Wj; // the panels are dead: the tile goes through them
+        __syncthreads();
+        T[ty][tx] = acc * (S / (rj * rk));
+        __syncthreads();
+        if (tid < 32) {
+            const int kh = tid >> 4, c = tid & 15;
+            unsigned h[4], l[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) split2(T[kh * 8 + 2 * i][c], T[kh * 8 + 2 * i + 1][c], h[i], l[i]);
+            uint4 *dst = reinterpret_cast<uint4 *>(image) + ((size_t)(blockIdx.y * 2) * 2 + kh) * cin + k0 + c;
+            dst[0] = make_uint4(h[0], h[1], h[2], h[3]);
+            dst[(size_t)2 * cin] = make_uint4(l[0], l[1], l[2], l[3]);
+        }
+    } else if (image != nullptr) {
         // the matrix is the weight operand of ONE forward-type GEMM (mlp_fast.hip): its bf16 x 3 image goes out with it, in that
         // kernel's LDS order [slab = row / 16][piece][k-half][column][8 bf16] (cin % 16 == 0: this tile is one slab of 16 columns)
         __syncthreads();
@@ -937,7 +995,7 @@ extern "C" int votenet_bn_backward_reduce_pool(long groups, int c, const float *
 }
 
 static int pool_dgrad_prepare_launch(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat, float *cvec,
-                                     void *image, void *stream)
+                                     void *image, void *stream, float *h2_ascale = nullptr, float *h2_unscale = nullptr)
 {
     VN_REQUIRE(cin > 0 && w && coef && mmat && cvec, "pool_dgrad_prepare: bad arguments");
     VN_REQUIRE((cout == 128 || cout == 256) && (uintptr_t)w % 16 == 0, "pool_dgrad_prepare: cout must be 128 or 256 (got %d), w 16-byte aligned", cout);
@@ -945,15 +1003,24 @@ static int pool_dgrad_prepare_launch(int cin, int cout, const float *w, const fl
     const dim3 grid((cin + 15) / 16, (cin + 15) / 16);
     unsigned *img = static_cast<unsigned *>(image);
     if (cout == 256)
-        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<256>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img);
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<256>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img, h2_ascale, h2_unscale);
     else
-        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<128>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img);
+        hipLaunchKernelGGL(pool_dgrad_prepare_kernel<128>, grid, dim3(256), 0, as_stream(stream), cin, w, bias, coef, mmat, cvec, img, h2_ascale, h2_unscale);
     return check_launch("pool_dgrad_prepare");
 }
 extern "C" int votenet_pool_dgrad_prepare(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
                                           float *cvec, void *stream)
 {
     return pool_dgrad_prepare_launch(cin, cout, w, bias, coef, mmat, cvec, nullptr, stream);
+}
+// The same, and the matrix's image as TWO fp16 pieces (cin * cin * 4 bytes) scaled by powers of two, with the two vectors (cin floats
+// each) the GEMM needs to undo the scaling: register all three with votenet_register_split_weights_scaled around the one GEMM that
+// multiplies by mmat (see the kernel for the bound the scales come from).
+extern "C" int votenet_pool_dgrad_prepare_h2(int cin, int cout, const float *w, const float *bias, const float *coef, float *mmat,
+                                             float *cvec, void *image, float *ascale, float *unscale, void *stream)
+{
+    VN_REQUIRE(image != nullptr && ascale != nullptr && unscale != nullptr, "pool_dgrad_prepare_h2: null image / scale vectors");
+    return pool_dgrad_prepare_launch(cin, cout, w, bias, coef, mmat, cvec, image, stream, ascale, unscale);
 }
 // The same, and the bf16 x 3 image of mmat (cin * cin * 6 bytes, votenet_split_weights' layout) written by the same launch: the
 // caller registers it (votenet_register_split_weights) around the one GEMM that multiplies by mmat.
@@ -1107,7 +1174,10 @@ static int pool_dgrad_scatter_launch(long groups, int k, int cin, int cout, cons
 #define GRAM_ABL 0 // probe builds only (tools/probe/ablate_half.sh): 1 no MFMAs, 2 no epilogue (atomics), 4 no global loads after the prologue,
                    // 8 no staging (activation, split, LDS writes) after the prologue -- results wrong by construction, only the time is read
 #endif
-template <int C>
+// NP = 2 (round 6, the default): the same on fp16 x 2 pieces (mlp_types.h: split2) -- both operands are ACTIVATIONS behind a BatchNorm,
+// inside fp16's range; staged scaled by 2^4 (folded into scale / shift: no instruction), the tile scaled back by 2^-8 before its
+// atomics; three v_mfma_f32_32x32x16_f16 per sub-tile and slab, two LDS planes per operand instead of three.
+template <int C, int NP = 3>
 __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *__restrict__ x, const float *__restrict__ scale_shift,
                                                        int relu, float *__restrict__ gram, long rows_per_block,
                                                        const float *__restrict__ wh /* piece layout: row 16 q counts wh[q] times */,
@@ -1120,7 +1190,9 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     constexpr int KPT = C / 16;          // rows of a slab per thread (8 or 4)
     constexpr int T = C / 64;            // 32 x 32 sub-tiles per wave and direction (waves 2 x 2)
     constexpr int PL = C * 4 + 16;       // dwords per (piece, row-half) plane; the pad keeps a wave's two halves on different banks
-    __shared__ __attribute__((aligned(16))) unsigned Ts[2][3][2][PL];
+    static_assert(NP == 2 || NP == 3, "pieces per operand");
+    constexpr float kA = NP == 2 ? 16.0f : 1.0f, kUn = NP == 2 ? 1.0f / 256.0f : 1.0f;
+    __shared__ __attribute__((aligned(16))) unsigned Ts[2][NP][2][PL];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = wv >> 1, wj = wv & 1;
@@ -1130,7 +1202,7 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     const int nslab = (nrow + 15) / 16;
     const int c = tid % C, rg = tid / C; // C = 128: rg = row-half; C = 64: rg = quarter (row-half rg >> 1, dword pair rg & 1)
     const int kh_w = (C == 128) ? rg : (rg >> 1), d_w = (C == 128) ? 0 : (rg & 1) * 2;
-    const float sc = scale_shift[c], sh = scale_shift[C + c];
+    const float sc = scale_shift[c] * kA, sh = scale_shift[C + c] * kA;
     const float floor_ = relu ? 0.0f : -__builtin_inff();
     const float *xb = x + (size_t)r_begin * C + c;
     float R[2][KPT];
@@ -1165,17 +1237,30 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
             if (s * 16 + rg * KPT + i >= nrow) v[i] = 0.0f; // padding rows contribute nothing
         }
         if (whb != nullptr && first_rg && s * 16 < nrow) v[0] *= sqrtf(wq); // a^T diag(w) a = (sqrt(w) a)^T (sqrt(w) a)
+        if constexpr (NP == 2) {
+            unsigned h[KPT / 2], l[KPT / 2];
+#pragma unroll
+            for (int i = 0; i < KPT / 2; i++) split2(v[2 * i], v[2 * i + 1], h[i], l[i]);
+            if constexpr (C == 128) {
+                *reinterpret_cast<uint4 *>(&Ts[buf][0][kh_w][c * 4]) = make_uint4(h[0], h[1], h[2], h[3]);
+                *reinterpret_cast<uint4 *>(&Ts[buf][1][kh_w][c * 4]) = make_uint4(l[0], l[1], l[2], l[3]);
+            } else {
+                *reinterpret_cast<uint2 *>(&Ts[buf][0][kh_w][c * 4 + d_w]) = make_uint2(h[0], h[1]);
+                *reinterpret_cast<uint2 *>(&Ts[buf][1][kh_w][c * 4 + d_w]) = make_uint2(l[0], l[1]);
+            }
+            return;
+        }
         unsigned h[KPT / 2], m[KPT / 2], l[KPT / 2];
 #pragma unroll
         for (int i = 0; i < KPT / 2; i++) split3(v[2 * i], v[2 * i + 1], h[i], m[i], l[i]);
         if constexpr (C == 128) {
             *reinterpret_cast<uint4 *>(&Ts[buf][0][kh_w][c * 4]) = make_uint4(h[0], h[1], h[2], h[3]);
             *reinterpret_cast<uint4 *>(&Ts[buf][1][kh_w][c * 4]) = make_uint4(m[0], m[1], m[2], m[3]);
-            *reinterpret_cast<uint4 *>(&Ts[buf][2][kh_w][c * 4]) = make_uint4(l[0], l[1], l[2], l[3]);
+            *reinterpret_cast<uint4 *>(&Ts[buf][NP - 1][kh_w][c * 4]) = make_uint4(l[0], l[1], l[2], l[3]);
         } else {
             *reinterpret_cast<uint2 *>(&Ts[buf][0][kh_w][c * 4 + d_w]) = make_uint2(h[0], h[1]);
             *reinterpret_cast<uint2 *>(&Ts[buf][1][kh_w][c * 4 + d_w]) = make_uint2(m[0], m[1]);
-            *reinterpret_cast<uint2 *>(&Ts[buf][2][kh_w][c * 4 + d_w]) = make_uint2(l[0], l[1]);
+            *reinterpret_cast<uint2 *>(&Ts[buf][NP - 1][kh_w][c * 4 + d_w]) = make_uint2(l[0], l[1]);
         }
     };
     f32x16 acc[T][T];
@@ -1199,9 +1284,9 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
     for (int s = 0; s < nslab2; s += 2) {
 #pragma unroll
         for (int par = 0; par < 2; par++) {
-            uint4 fa[3][T], fb[3][T];
+            uint4 fa[NP][T], fb[NP][T];
 #pragma unroll
-            for (int p = 0; p < 3; p++) {
+            for (int p = 0; p < NP; p++) {
 #pragma unroll
                 for (int t = 0; t < T; t++) {
                     fa[p][t] = *reinterpret_cast<const uint4 *>(&Ts[buf][p][kh][((wi * T + t) * 32 + l31) * 4]);
@@ -1216,18 +1301,31 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 #pragma unroll
                 for (int a = 0; a < T; a++)
 #pragma unroll
-                    for (int b = 0; b < T; b++)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][a]),
-                                                                            __builtin_bit_cast(bf16x8, fb[pb][b]), acc[a][b], 0, 0, 0);
+                    for (int b = 0; b < T; b++) {
+                        if constexpr (NP == 2)
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[pa][a]),
+                                                                               __builtin_bit_cast(f16x8, fb[pb][b]), acc[a][b], 0, 0, 0);
+                        else
+                            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[pa][a]),
+                                                                                __builtin_bit_cast(bf16x8, fb[pb][b]), acc[a][b], 0, 0, 0);
+                    }
             };
-            mm(2, 0);
-            mm(0, 2);
-            mm(1, 1);
-            store(buf ^ 1, R[par ^ 1], s + par + 1, Wq[par ^ 1]); // the other buffer was last read one slab ago, behind a barrier
-            load(R[par ^ 1], s + par + 3, Wq[par ^ 1]);
-            mm(1, 0);
-            mm(0, 1);
-            mm(0, 0);
+            if constexpr (NP == 2) {
+                mm(1, 0);
+                mm(0, 1);
+                store(buf ^ 1, R[par ^ 1], s + par + 1, Wq[par ^ 1]); // the other buffer was last read one slab ago, behind a barrier
+                load(R[par ^ 1], s + par + 3, Wq[par ^ 1]);
+                mm(0, 0);
+            } else {
+                mm(2, 0);
+                mm(0, 2);
+                mm(1, 1);
+                store(buf ^ 1, R[par ^ 1], s + par + 1, Wq[par ^ 1]); // the other buffer was last read one slab ago, behind a barrier
+                load(R[par ^ 1], s + par + 3, Wq[par ^ 1]);
+                mm(1, 0);
+                mm(0, 1);
+                mm(0, 0);
+            }
             lds_barrier();
             buf ^= 1;
         }
@@ -1252,12 +1350,12 @@ __global__ __launch_bounds__(256) void gram_bf3_kernel(long rows, const float *_
 #pragma unroll
             for (int e = 0; e < 16; e++) {
                 const int i = (wi * T + a) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                unsafeAtomicAdd(&gram[(size_t)i * C + j], acc[a][b][e]);
+                unsafeAtomicAdd(&gram[(size_t)i * C + j], acc[a][b][e] * kUn);
             }
         }
 }
 
-int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always
+int g_gram_bf3 = 1; // votenet_debug_gram_bf3: 0 = the fp32 MFMA kernel always, 1 (default) = split operands as fp16 x 2 pieces, 3 = as bf16 x 3 pieces
 static int g_gram_wgs = 384; // votenet_debug_gram_workgroups (tuning hook)
 template <int C>
 static void gram_bf3_launch(long rows, const float *z, const float *scale_shift, int relu, float *gram, hipStream_t st, const float *wh = nullptr,
@@ -1268,7 +1366,8 @@ static void gram_bf3_launch(long rows, const float *z, const float *scale_shift,
     rpb = (rpb + 31) / 32 * 32;
     if (rpb < 128) rpb = 128;
     const unsigned gx = (unsigned)((rows + rpb - 1) / rpb);
-    hipLaunchKernelGGL((gram_bf3_kernel<C>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh, nh_dev);
+    if (g_gram_bf3 != 3) hipLaunchKernelGGL((gram_bf3_kernel<C, 2>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh, nh_dev);
+    else hipLaunchKernelGGL((gram_bf3_kernel<C, 3>), dim3(gx), dim3(256), 0, st, rows, z, scale_shift, relu, gram, rpb, wh, nh_dev);
 }
 extern "C" void votenet_debug_gram_bf3(int on) { VN_DEBUG_GATE(); g_gram_bf3 = on; }
 extern "C" void votenet_debug_gram_workgroups(int n) { VN_DEBUG_GATE(); g_gram_wgs = n > 0 ? n : 384; }

@@ -353,6 +353,10 @@ def _desc_gather(xyz, new_xyz, feat, idx):
 # 54 KB, 112) shares the CUs better (tools/trace_ab.sh adhoc: main queue +38 us, the other queue -95 us, the step +0.1 ms).  Off.
 SPLIT_ADHOC = False
 SPLIT_ADHOC_ROWS = 65536
+# Round 6: the same matrix as TWO fp16 pieces, scaled by powers of two chosen inside the launch that forms it (pool_bwd.hip:
+# pool_dgrad_prepare_kernel): the activations it multiplies are forward operands, the matrix is brought into fp16's range exactly.  The
+# GEMM then runs three fp16 MFMAs per product instead of the fp32 MFMA kernel's v_mfma_f32_32x32x2_f32 chain.
+ADHOC_H2 = True
 
 
 def split_eligible(cin, cout):
@@ -1117,7 +1121,13 @@ def pool_dgrad_prepare(w, bias, coef, rows=None):
     mm = torch.empty((cin + 1, cin), dtype=torch.float32, device=w.device)
     want_img = SPLIT_ADHOC and split_eligible(cin, cin) and (rows is None or rows >= SPLIT_ADHOC_ROWS)
     with L.device_guard(w.device):
-        if want_img:
+        if ADHOC_H2 and FORWARD_H2 and split_eligible(cin, cin):
+            img = torch.empty(cin * cin * 4, dtype=torch.uint8, device=w.device)
+            sv = torch.empty((2, cin), dtype=torch.float32, device=w.device)
+            L.check(L.lib().votenet_pool_dgrad_prepare_h2(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]),
+                                                          L.ptr(img), L.ptr(sv[0]), L.ptr(sv[1]), L.stream_ptr()))
+            mm._img, mm._h2 = img, sv
+        elif want_img:
             img = torch.empty(cin * cin * 6, dtype=torch.uint8, device=w.device)
             L.check(L.lib().votenet_pool_dgrad_prepare_split(cin, cout, L.ptr(w), L.ptr(bias), L.ptr(coef), L.ptr(mm), L.ptr(mm[cin]),
                                                              L.ptr(img), L.stream_ptr()))
@@ -1138,15 +1148,27 @@ def pool_dgrad(xz, in_scale, in_shift, in_relu, w, bias, wT, coef, relu, gout, a
     if mm is None:
         mm = pool_dgrad_prepare(w, bias, coef, rows)
     img = getattr(mm, "_img", None)
+    h2 = getattr(mm, "_h2", None)
+
+    def register():  # the matrix exists only for this launch: its image is registered around the GEMM's launch only
+        if h2 is not None:
+            L.check(L.lib().votenet_register_split_weights_scaled(L.ptr(mm), cin, cin, L.ptr(img), L.ptr(h2[0]), L.ptr(h2[1])))
+        else:
+            L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(img)))
     if half is not None and half.nh_limit is not None:
         # the count is the device's: the dense GEMM stops at it too (rows = the upper bound)
         da = torch.empty((rows, cin), dtype=torch.float32, device=xz.device)
-        with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "gram-form dense dgrad half"), limit=half):
-            L.check(L.lib().votenet_mlp_linear_half(L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0, rows, cin, cin, L.ptr(mm),
-                                                    L.ptr(mm[cin]), L.ptr(da), L.ptr(half.nh_limit), L.stream_ptr()))
+        if h2 is not None:
+            register()
+        try:
+            with L.device_guard(xz.device), _Timed("linear_dense", 2.0 * rows * cin * cin, (rows, cin, cin, "gram-form dense dgrad half"), limit=half):
+                L.check(L.lib().votenet_mlp_linear_half(L.ptr(xz), L.ptr(in_scale), L.ptr(in_shift), 1 if in_relu else 0, rows, cin, cin, L.ptr(mm),
+                                                        L.ptr(mm[cin]), L.ptr(da), L.ptr(half.nh_limit), L.stream_ptr()))
+        finally:
+            if h2 is not None:
+                L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, None)
     elif img is not None:
-        # the matrix exists only for this launch: its image is registered around the GEMM's launch only
-        L.check(L.lib().votenet_register_split_weights(L.ptr(mm), cin, cin, L.ptr(img)))
+        register()
         try:
             da, _ = linear_dense(xz, mm[:cin], mm[cin], in_scale, in_shift, in_relu, want_stats=False)
         finally:
