@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # same guide: v_mfma_f32_32x32x2_f32, fp32 in / fp32 accumulate, dense
 MFMA_BF3_EQUIV_TF = round(16 * 157.3 / 6, 1)  # dense bf16 MFMA peak (16 x the fp32 rate, 2.5 PFLOP/s) / six bf16 MFMAs per fp32 product = 419.5
+MFMA_H2_EQUIV_TF = round(16 * 157.3 / 3, 1)   # dense fp16 MFMA peak (the same rate) / three fp16 MFMAs per fp32 product (round 6: forward operands) = 838.9
 
 
 def parse():
@@ -584,6 +585,30 @@ def main():
                      "what": "same workload, votenet_debug_fast_bf3(0) + votenet_debug_gram_bf3(0) + votenet_debug_wgrad_bf3(0): every GEMM product on "
                              "v_mfma_f32_32x32x2_f32 instead of six v_mfma_f32_32x32x16_bf16 on exactly split operands"}
 
+    # the same step with the FORWARD operands on bf16 x 3 again (the round-3..5 form: six MFMAs per product instead of three fp16 ones)
+    bf3_step = None
+    if world == 1 and not args.headline_only and workload == "train" and vmlp.FORWARD_H2:
+        vmlp.FORWARD_H2 = False
+        net.store.rebuild_split()
+        try:
+            for _ in range(4):
+                step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            dt6 = time.perf_counter() - t1
+        finally:
+            vmlp.FORWARD_H2 = True
+            net.store.rebuild_split()
+        for _ in range(4):
+            step()
+        torch.cuda.synchronize()
+        bf3_step = {"value": round(B * 10 / dt6, 2), "ms_per_step": round(dt6 / 10 * 1e3, 3), "steps": 10,
+                    "what": "same workload with mlp.FORWARD_H2 = False: the forward matrices' images as bf16 x 3 (six v_mfma_f32_32x32x16_bf16 per "
+                            "product) and the Gram-form dense input gradient on the fp32 MFMA kernel, as rounds 3-5 ran them"}
+
     # the same step on the FULL row layout (64 rows per ball, copies of slot 0 included: the reference's tensor shape), and what the
     # piece layout keeps of each level's grouped rows on these scenes
     full_step = row_layout = None
@@ -762,10 +787,11 @@ def main():
             ach = tot_fl / (tot_ms * 1e-3) / 1e12
             mfma = {"bound": "mfma", "kernel": "mlp_linear_fast_kernel / mlp_linear_kernel / mlp_wgrad_fast_kernel (all %d GEMM launches of "
                                                "two steps right after the timed region, fp32 in / fp32 accumulate; executed flops / union of the "
-                                               "launch intervals over both streams).  The fused forward / input-gradient GEMMs multiply each fp32 "
-                                               "operand as three bf16 pieces (x = hi + mid + lo exactly): six v_mfma_f32_32x32x16_bf16 per "
-                                               "k-step, fp32 accumulate, error vs float64 equal to the fp32 MFMA kernel's; so do the Gram matrices "
-                                               "of the pooled layers' backward and (round 3) every other weight-gradient GEMM (row-major bf16 images, fragments through ds_read_b64_tr_b16).  flops = fp32 multiply-adds of the GEMM (2 rows cin "
+                                               "launch intervals over both streams).  Forward GEMMs, Gram matrices and the Gram-form dense input gradient "
+                                               "multiply each fp32 operand as two fp16 pieces (three v_mfma_f32_32x32x16_f16 per k-step, round 6); the "
+                                               "input-gradient and weight-gradient GEMMs as three bf16 pieces (x = hi + mid + lo exactly: six "
+                                               "v_mfma_f32_32x32x16_bf16 per k-step; row-major images, fragments through ds_read_b64_tr_b16 in the weight gradients); "
+                                               "fp32 accumulate, error vs float64 equal to the fp32 MFMA kernel's.  flops = fp32 multiply-adds of the GEMM (2 rows cin "
                                                "cout), priced against the fp32 MFMA peak" % len(gemm_events),
                     "achieved": round(ach, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_F32_PEAK_TF, 4),
                     "gemm_ms_per_step": round(tot_ms / gemm_steps, 3), "gemm_ms_per_step_summed": round(sum_ms / gemm_steps, 3),
@@ -820,10 +846,12 @@ def main():
                                       "not measured in this run)" % (util_src, pj.get("source_pieces"))) if util_src else None
             mfma["peak_bf3_equiv"] = MFMA_BF3_EQUIV_TF
             mfma["frac_bf3_equiv"] = round(ach / MFMA_BF3_EQUIV_TF, 4)
+            mfma["peak_h2_equiv"] = MFMA_H2_EQUIV_TF
             mfma["pricing"] = ("frac prices the fp32 multiply-adds against the fp32 MFMA peak (157.3 TFLOP/s: what a kernel on v_mfma_f32_32x32x2_f32 "
                                "could reach at most); the kernels issue six v_mfma_f32_32x32x16_bf16 per product on exactly split operands, whose "
                                "ceiling is the dense bf16 peak / 6 = %.1f TFLOP/s of fp32 multiply-adds: frac_bf3_equiv is the utilisation of the "
-                               "pipe that is actually used" % MFMA_BF3_EQUIV_TF)
+                               "pipe that is actually used by the gradient GEMMs; the forward GEMMs, the Gram matrices and the Gram-form dense input "
+                               "gradient (round 6) issue THREE v_mfma_f32_32x32x16_f16 per product: ceiling %.1f (peak_h2_equiv)" % (MFMA_BF3_EQUIV_TF, MFMA_H2_EQUIV_TF))
             if workload == "train" and B == 8 and n == 20480:
                 # SURVEY.md 8(d)'s ALGORITHMIC figure for the grouped MLP: flops = 2 rows sum(C_in C_out) of the reference's
                 # formulation (conv over the materialised grouped tensor): 186.0 GFLOP forward at B = 8, backward = 2 x forward.
@@ -887,12 +915,16 @@ def main():
                                        "three_nn) runs on a side stream underneath the current step, replayed as one HIP graph (model.GeometryGraph); the step's "
                                        "static stretch (fp1 forward ... fp1 backward: ~85 launches) replays as four HIP graphs (model.StretchGraph)" if pipeline else "")),
                        "global_batch": B * world, "points": n, "parallelism": "dp%d" % world},
-            "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate; products of the fused forward and input-gradient GEMMs as bf16 x 3 "
-                               "split operands (exact split, 6 of the 9 cross terms: what is dropped is < 2^-23 of a product), "
-                               "likewise the Gram matrices of the pooled layers' backward and the weight-gradient GEMMs; a few GEMMs on matrices made on the "
-                               "fly (W diag(C) W^T of the Gram-form input gradient) stay on fp32 MFMA; tests hold both forms to the same tolerances",
+            "gemm_arithmetic": "fp32 in / fp32 out / fp32 accumulate.  FORWARD operands (activations behind a BatchNorm, coordinates, weights) are "
+                               "multiplied as fp16 x 2 split operands (round 6: x = hi + lo, 22 bits, three v_mfma_f32_32x32x16_f16 per product, both "
+                               "operands scaled by exact powers of two so that the lo pieces stay normal fp16 numbers; measured error against float64 "
+                               "equal to the bf16 x 3 form's and the fp32 chain's: profiles/r06_mfma_f16_denorm.txt, tests/test_gpu_h2.py) -- every "
+                               "forward GEMM, the Gram matrices and the Gram-form dense input gradient (its on-the-fly matrix W diag(C) W^T is scaled "
+                               "into fp16's range by powers of two from row norms and max|C|).  GRADIENT operands stay bf16 x 3 (exact split, 6 of the 9 "
+                               "cross terms, six v_mfma_f32_32x32x16_bf16 per product): fp32's range, and an ablation shows nothing to gain there "
+                               "(profiles/r06_ablate_h2_bwd.txt).  Tests hold every form to the same tolerances",
             "ms_per_step_spread": spread, "without_cross_step_pipelining": in_step, "deterministic_mode": det_step,
-            "fp32_mfma_gemms": fp32_step, "full_row_layout": full_step, "row_layout": row_layout, "configs": cfgs,
+            "fp32_mfma_gemms": fp32_step, "bf16x3_forward_operands": bf3_step, "full_row_layout": full_step, "row_layout": row_layout, "configs": cfgs,
             "communicator": comm, "per_rank": per_rank, "dp_collectives": dp_coll, "check_dp": check,
             "gpu_busy_seconds": gpu_busy,
             "roofline": roof, "roofline_ball_query": bq, "roofline_mlp": mfma, "cpu_baseline": cpu,

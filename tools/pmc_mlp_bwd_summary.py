@@ -28,7 +28,7 @@ def table(name):
 FAM = [("mlp_linear_fast_kernel<2, 2, 2, 2, 1, 6, true>", "dgrad_bn_reduce assembled", 524288, 128, 128),
        ("mlp_wgrad_fast_kernel<3, 2, 2, 1, true>", "wgrad_bn assembled", 524288, 128, 128),
        ("mlp_wgrad_fast_kernel<3, 2, 2, 1>", "wgrad_bn assembled (fp32 MFMA)", 524288, 128, 128),
-       ("gram_bf3_kernel<128>", "gram", 524288, 128, 128),
+       ("gram_bf3_kernel<128", "gram", 524288, 128, 128),
        ("mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, true>", "fwd+bn (the dense part of the Gram-form dgrad)", 524288, 128, 128),
        ("mlp_linear_fast_kernel<2, 2, 2, 2, 1, 1, true>", "dgrad_bn", 524288, 128, 128),
        ("mlp_linear_fast_kernel<2, 2, 2, 2, 0, 2, true>", "fwd+pool", 524288, 128, 256),
@@ -36,7 +36,7 @@ FAM = [("mlp_linear_fast_kernel<2, 2, 2, 2, 1, 6, true>", "dgrad_bn_reduce assem
        ("mlp_linear_fast_kernel<4, 1, 1, 2, 1, 4, true>", "dgrad_bn_reduce narrow", 1048576, 64, 64),
        ("mlp_wgrad_fast_kernel<2, 1, 1, 1, true>", "wgrad_bn narrow", 1048576, 64, 64),
        ("mlp_wgrad_fast_kernel<2, 1, 1, 1>", "wgrad_bn narrow (fp32 MFMA)", 1048576, 64, 64),
-       ("gram_bf3_kernel<64>", "gram (64)", 1048576, 64, 64)]
+       ("gram_bf3_kernel<64", "gram (64)", 1048576, 64, 64)]
 a, ha = table("a.txt")
 b, hb = table("b.txt")
 c, hc = table("c.txt")

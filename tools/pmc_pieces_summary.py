@@ -32,12 +32,12 @@ def short(n):
 LEVEL_KERNELS = {
     "sa2": ["mlp_linear_fast_kernel<2, 2, 2, 2, 0, 8, true", "mlp_linear_fast_kernel<2, 2, 2, 2, 4, 0, true", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 6", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 1",
             "group_linear_bwd_masked_kernel", "assembled_point_grad_kernel", "assembled_wx_finish",
-            "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false", "mlp_wgrad_fast_kernel<3, 2, 2, 4", "pool_wgrad_sparse_kernel<128, 16", "pool_wgrad_sparse_centre_kernel<128",
-            "pool_dgrad_scatter_wave_kernel<128, 256, 16", "gram_bf3_kernel<128>", "group_linear_bwd_sorted_kernel", "bn_pool_finalize_half",
+            "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false", "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, true", "mlp_wgrad_fast_kernel<3, 2, 2, 4", "pool_wgrad_sparse_kernel<128, 16", "pool_wgrad_sparse_centre_kernel<128",
+            "pool_dgrad_scatter_wave_kernel<128, 256, 16", "gram_bf3_kernel<128", "group_linear_bwd_sorted_kernel", "bn_pool_finalize_half",
             "bn_bwd_reduce_zsel", "assemble_rows_half", "half_sort", "half_groups", "pool_wgrad_finish", "pool_dgrad_prepare_kernel<256>"],
     "sa1": ["mlp_linear_fast_kernel<2, 2, 2, 2, 0, 8, true", "mlp_linear_fast_kernel<4, 1, 1, 2, 3, 0, true", "mlp_linear_fast_kernel<4, 1, 1, 2, 5, 4", "mlp_linear_fast_kernel<4, 1, 1, 2, 5, 7",
-            "mlp_linear_fast_kernel<4, 1, 1, 2, 0, 1, false", "mlp_wgrad_fast_kernel<2, 1, 1, 4", "pool_wgrad_sparse_kernel<64, 16", "pool_wgrad_sparse_centre_kernel<64",
-            "pool_dgrad_scatter_wave_kernel<64, 128, 16", "gram_bf3_kernel<64>", "bn_pool_finalize_half", "bn_bwd_reduce_zsel", "narrow_rows_half",
+            "mlp_linear_fast_kernel<4, 1, 1, 2, 0, 1, false", "mlp_linear_fast_kernel<4, 1, 1, 2, 0, 1, true", "mlp_wgrad_fast_kernel<2, 1, 1, 4", "pool_wgrad_sparse_kernel<64, 16", "pool_wgrad_sparse_centre_kernel<64",
+            "pool_dgrad_scatter_wave_kernel<64, 128, 16", "gram_bf3_kernel<64", "bn_pool_finalize_half", "bn_bwd_reduce_zsel", "narrow_rows_half",
             "half_groups", "pool_wgrad_finish", "pool_dgrad_prepare_kernel<128>", "narrow_wgrad_first"],
 }
 # bench.py's family names (mlp._Timed shapes) -> (level, kernel, cin, cout) for the mlp_families block of profiles/pmc_latest.json
@@ -47,8 +47,8 @@ FAMILIES = {
     "dgrad_bn_reduce assembled half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 6, true", 128, 128),
     "dgrad_bn half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 5, 1, true", 128, 128),
     "wgrad_bn assembled half": ("sa2", "mlp_wgrad_fast_kernel<3, 2, 2, 4, true>", 128, 128),
-    "gram half": ("sa2", "gram_bf3_kernel<128>", 128, 128),
-    "gram-form dense dgrad half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, false", 128, 128),
+    "gram half": ("sa2", "gram_bf3_kernel<128", 128, 128),
+    "gram-form dense dgrad half": ("sa2", "mlp_linear_fast_kernel<2, 2, 2, 2, 0, 1, true", 128, 128),
     "fwd+bn narrow half": ("sa1", "mlp_linear_fast_kernel<4, 1, 1, 2, 3, 0, true", 64, 64),
     "dgrad_bn_reduce narrow half": ("sa1", "mlp_linear_fast_kernel<4, 1, 1, 2, 5, 7, true", 64, 64),
     "wgrad_bn narrow half": ("sa1", "mlp_wgrad_fast_kernel<2, 1, 1, 4, true>", 64, 64),

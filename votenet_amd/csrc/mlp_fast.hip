@@ -767,7 +767,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     rdW(fWmid, 1, buf);
                     rdW(fX[par ^ 1], 2, buf); // W.lo
                     mm(fAlo, fWhi);
-                    mm(fX[par], fWhi); // A.mid
+                    if (!(BF3_ABL & 32)) mm(fX[par], fWhi); // A.mid   (BF3_ABL 32, probe builds: three of the six products, timing only)
                     store_regs(buf ^ 1, rs); // the other buffer was last read before the previous slab's barrier
                     mm(fAhi, fWhi);
                     lds_barrier();
@@ -777,8 +777,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
                     __builtin_amdgcn_sched_barrier(0);
                     rdA(fX[par ^ 1], 1, buf ^ 1); // the next slab's A.mid
                     issue_loads(rs);
-                    mm(fAhi, fWmid);
-                    mm(fX[par], fWmid);
+                    if (!(BF3_ABL & 32)) {
+                        mm(fAhi, fWmid);
+                        mm(fX[par], fWmid);
+                    }
                     buf ^= 1;
                     continue;
                 }

@@ -338,17 +338,26 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
                             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa3[pa][a]),
                                                                                 __builtin_bit_cast(bf16x8, fb3[pb][b]), acc[a][b], 0, 0, 0);
                 };
+#ifdef WG_ABL_HALF // probe builds only (tools/probe/ablate_h2_bwd.sh): three of the six products -- results wrong by construction, only the time is read
+                mm(2, 0);
+#else
                 mm(2, 0); // lo * hi
                 mm(0, 2); // hi * lo: the smallest terms first
                 mm(1, 1);
+#endif
                 store_slab(buf ^ 1, rs); // the other buffer was last read one step ago, behind a barrier
 #pragma unroll
                 for (int h = 0; h < NA; h++) pcur[h] = pidx[h];
                 load_idx(s + par + 4);
                 load_slab(rs, s + par + 3, pcur);
+#ifdef WG_ABL_HALF
+                mm(0, 1);
+                mm(0, 0);
+#else
                 mm(1, 0);
                 mm(0, 1);
                 mm(0, 0);
+#endif
                 lds_barrier();
                 buf ^= 1;
                 continue;

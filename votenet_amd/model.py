@@ -815,7 +815,7 @@ class VoteNetHotPath:
         ins = self._stretch_inputs(lv, g)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
                                                                              self.overlap_wgrad, STRETCH_SEGMENTS, M.SPLIT_K, M.COEF_TAIL, P.WGRAD_BATCH, P.POOL_IN_EPILOGUE,
-                                                                             self.store.split, bool(getattr(self, "inline_wgrad_tail", False)), M.CONFIG_EPOCH)
+                                                                             self.store.split, bool(getattr(self, "inline_wgrad_tail", False)), M.CONFIG_EPOCH, M.FORWARD_H2, M.ADHOC_H2)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
         self._gsync.begin()

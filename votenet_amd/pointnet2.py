@@ -104,6 +104,15 @@ class ParamStore:
         self._split_flat.refresh()
         self._split_gen = self.generation
 
+    def rebuild_split(self):
+        """Forget the images of the forward matrices: the next refresh_split() builds them in the form mlp.FORWARD_H2 names NOW (fp16 x 2
+        or bf16 x 3).  Captured graphs hold the old images' addresses: the configuration epoch their keys carry moves on."""
+        if self._split_flat is not None:
+            self._split_flat.close()
+            self._split_flat = None
+        self._split_gen = -1
+        M.CONFIG_EPOCH += 1
+
     def ensure_split(self):
         """Images of the current generation before a GEMM reads them: a no-op inside a pass (forward() refreshed them at its start),
         one launch when a module is driven directly after the parameters changed (SAModule.forward after an optimizer step)."""
