@@ -65,6 +65,7 @@ class GeometryGraph:
 
 GRAM_EARLY = ()          # levels whose Gram matrix is launched at the start of the levels' backward pass (see _grams_early): measured below
 GRAMS_AHEAD = False      # train_step launches the Gram matrices of the levels' pooled layers (forward data only) on the weight-gradient stream under the stretch instead of beside the levels' backward GEMMs.  Measured (tools/probe/variant_step.py, three alternations): 3.78-3.81 -> 3.86-3.89 ms -- the stretch is a chain of tiny latency-bound kernels ON the critical path, and 0.27 ms of GPU-filling kernels beside it cost it more than they save the backward pass.  Off.
+INLINE_WGRAD_TAIL = False  # experiment (see _levels_backward): the weight gradients of sa2 / sa1 on the main stream
 STRETCH_GRAPH = True     # train_step replays its static stretch (fp1 forward ... fp1 backward: ~85 launches) as HIP graph segments (StretchGraph)
 STRETCH_SEGMENTS = True  # the stretch's input-gradient chain cut into graphs at the modules' ends, the weight gradients launched between them (False: two graphs around the loss, weight gradients inline)
 STRETCH_MAX_GRAPHS = 4   # captures kept per net (one per input shape / configuration; least recently replayed goes first)
@@ -739,7 +740,7 @@ class VoteNetHotPath:
         # inline_wgrad_tail (experiment, default off): the weight gradients of the two largest modules on the MAIN stream -- by the time
         # their backward runs the next batch's sampling kernel has finished, and pairs of GPU-filling kernels gain nothing from two streams
         keep_stream = P.WGRAD_STREAM
-        if getattr(self, "inline_wgrad_tail", False):
+        if getattr(self, "inline_wgrad_tail", INLINE_WGRAD_TAIL):
             P.WGRAD_STREAM = None
         try:
             g1, _ = self.sa2.backward(sa2, d_l2p)
@@ -815,7 +816,7 @@ class VoteNetHotPath:
         ins = self._stretch_inputs(lv, g)
         key = tuple((k, tuple(v.shape), v.dtype) for k, v in ins.items()) + (P.HALF_GROUPS, P.ASSEMBLE_FIRST, P.ASSEMBLE_INLINE, P.POOL_GRAM_BACKWARD, P.ASSEMBLED_DECOMPOSED,
                                                                              self.overlap_wgrad, STRETCH_SEGMENTS, M.SPLIT_K, M.COEF_TAIL, P.WGRAD_BATCH, P.POOL_IN_EPILOGUE,
-                                                                             self.store.split, bool(getattr(self, "inline_wgrad_tail", False)), M.CONFIG_EPOCH, M.FORWARD_H2, M.ADHOC_H2)
+                                                                             self.store.split, bool(getattr(self, "inline_wgrad_tail", INLINE_WGRAD_TAIL)), M.FORWARD_H2, M.ADHOC_H2, M.CONFIG_EPOCH)
         graphs = self.__dict__.setdefault("_stretch_graphs", {})
         sg = graphs.get(key)
         self._gsync.begin()
