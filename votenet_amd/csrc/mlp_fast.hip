@@ -45,6 +45,9 @@ constexpr int FG_LDA = FG_BM + 2;
 #ifndef BF3_SETS
 #define BF3_SETS 2 // BF3: register sets of raw operands in flight (slabs of lead); cin % (16 * BF3_SETS) == 0
 #endif
+#ifndef H2_SETS
+#define H2_SETS 2 // H2: register sets of raw operands in flight (its slabs are shorter: the same lead in slabs is less lead in time); cin % (16 * H2_SETS) == 0
+#endif
 #ifndef BF3_PRIO
 #define BF3_PRIO 0 // BF3: 1 = matrix loop at s_setprio 1, epilogue at 0; 2 = the reverse; 3 = prio 1 only around the MFMAs of a slab
 #endif
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         uint2 mq;        // EPI 7: the mask words of tile row tid & 127
         int row;         // SRC 3: the global row of a0 (a1: + 64), for mask_out
     };
-    constexpr int NSETS = BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
+    constexpr int NSETS = H2 ? H2_SETS : BF3 ? BF3_SETS : 2; // register sets = slabs in flight; the slab loop is unrolled by it (launcher: nk % NSETS == 0)
     Regs R[NSETS];
     bool abl_prologue = true;
     auto issue_loads = [&](Regs &r) {
@@ -1419,7 +1422,7 @@ template <int SRC, int EPI> constexpr bool sk_built() { return (SRC == 0 || SRC 
             }                                                                                                                        \
         }                                                                                                                            \
         if constexpr (h2_built<SRC_, EPI_>()) {                                                                                      \
-            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).w3_np == 2 && (A_).cin % (FG_BK * BF3_SETS) == 0) { \
+            if (((g_fast_bf3 >> bf3_family<SRC_, EPI_>()) & 1) && (A_).w3 != nullptr && (A_).w3_np == 2 && (A_).cin % (FG_BK * H2_SETS) == 0) { \
                 hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, true, false, true>), GRID_, dim3(256), g_fast_dyn_lds, ST_, A_); \
                 break;                                                                                                               \
             }                                                                                                                        \
