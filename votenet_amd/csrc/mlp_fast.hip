@@ -1436,7 +1436,10 @@ template <int SRC, int EPI> constexpr bool sk_built() { return (SRC == 0 || SRC 
         hipLaunchKernelGGL((mlp_linear_fast_kernel<WM_, WN_, MT_, NT_, SRC_, EPI_, false>), GRID_, dim3(256), 0, ST_, A_);           \
     } while (0)
 int g_fast_xcd_chunk = 1; // votenet_debug_fast_xcd_chunk: the piece-layout GEMMs that gather P take their row tiles in per-XCD chunks
-int g_fast_cap22 = 1024, g_fast_cap41 = 2048; // persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook)
+// persistent workgroups per launch (votenet_debug_fast_workgroups: tuning hook).  Round 6: 512 / 1024 = what is RESIDENT at two workgroups per
+// CU -- every workgroup starts at once and walks 2-5 row tiles, so the prologue (tables, first loads) is paid once per resident slot and no
+// second round of workgroups is dispatched behind the first (1024 / 2048, the round-3 optimum of the six-MFMA kernels: 3.446 -> 3.390 ms per step)
+int g_fast_cap22 = 512, g_fast_cap41 = 1024;
 
 // ---- split-K for launches of few row tiles (FastArgs::sk_ws) ----------------------------------------------------------------------
 // The caller arms the NEXT launch of its thread with a workspace (votenet_mlp_split_k_arm; size from votenet_mlp_split_k_floats) and
