@@ -266,15 +266,21 @@ __global__ void bn_pool_finalize_half_kernel(long total, int G, int c, const flo
                                              const int *__restrict__ pos, const float *__restrict__ scale, const float *__restrict__ shift,
                                              BnRaw raw, int relu, float *__restrict__ out, int *__restrict__ argmax, float *__restrict__ zsel)
 {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(e % c);
-        const long g = e / c;
-        float s, h;
-        if (raw.stats) bn_raw_channel(raw, c, ch, e < c, s, h);
+    // The launcher makes the grid's stride a multiple of c: a thread's channel never changes, so its BatchNorm scale / shift -- from raw
+    // sums: two fp64 divisions and a square root -- are computed ONCE, not per element (round 6: they were most of this kernel's time; it
+    // sits on the forward chain of every level)
+    const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int ch = (int)(e0 % c);
+    float s = 0.0f, h = 0.0f;
+    if (e0 < total) {
+        if (raw.stats) bn_raw_channel(raw, c, ch, e0 < c, s, h);
         else {
             s = scale[ch];
             h = shift[ch];
         }
+    }
+    for (long e = e0; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long g = e / c;
         const float sg = s >= 0.0f ? 1.0f : -1.0f;
         // no load under a branch (round 5): the three piece slots, then all candidates together -- a piece the ball did not keep reads the
         // ball's first piece again and is ignored.  (With the loads under `if (p >= 0)` the compiler put an s_waitcnt vmcnt(0) behind each:
@@ -816,8 +822,9 @@ extern "C" int votenet_bn_pool_finalize_half(long G, int c, const float *zbest, 
     const BnRaw raw = to_raw(bn);
     VN_REQUIRE(zbest && abest && pos && out && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)),
                "bn_pool_finalize_half: null buffer");
+    VN_REQUIRE(256 % c == 0, "bn_pool_finalize_half: c must divide 256 (a thread keeps its channel over the grid's stride), got %d", c);
     long grid = (G * c + 255) / 256;
-    if (grid > 4096) grid = 4096;
+    if (grid > 1024) grid = 1024;
     hipLaunchKernelGGL(bn_pool_finalize_half_kernel, dim3((unsigned)grid), dim3(256), 0, as_stream(stream), G * c, (int)G, c, zbest, abest, pos,
                        scale, shift, raw, relu, out, argmax, zsel);
     return check_launch("bn_pool_finalize_half");

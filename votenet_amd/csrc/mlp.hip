@@ -460,13 +460,27 @@ __global__ __launch_bounds__(256) void bn_relu_max_vec_kernel(long groups, int k
 __global__ void bn_relu_kernel(long total, int c, const float *__restrict__ z, const float *__restrict__ scale,
                                const float *__restrict__ shift, BnRaw raw, int relu, float *__restrict__ y)
 {
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(e % c);
-        float sc, sh;
-        if (raw.stats) bn_raw_channel(raw, c, ch, e < c, sc, sh); // the first c elements also record the four vectors
+    const long e0 = (long)blockIdx.x * blockDim.x + threadIdx.x, stride = (long)gridDim.x * blockDim.x;
+    // When the grid's stride is a multiple of c (the launcher arranges it whenever c divides 256) a thread's channel never changes: its
+    // scale / shift -- from raw sums: two fp64 divisions and a square root -- are computed once, not per element (round 6)
+    const bool fixed = stride % c == 0;
+    float sc = 0.0f, sh = 0.0f;
+    if (fixed && e0 < total) {
+        const int ch = (int)(e0 % c);
+        if (raw.stats) bn_raw_channel(raw, c, ch, e0 < c, sc, sh); // the first c elements also record the four vectors
         else {
             sc = scale[ch];
             sh = shift[ch];
+        }
+    }
+    for (long e = e0; e < total; e += stride) {
+        if (!fixed) {
+            const int ch = (int)(e % c);
+            if (raw.stats) bn_raw_channel(raw, c, ch, e < c, sc, sh);
+            else {
+                sc = scale[ch];
+                sh = shift[ch];
+            }
         }
         float v = z[e] * sc + sh;
         if (relu && !(v > 0.0f)) v = 0.0f;
@@ -691,7 +705,7 @@ extern "C" int votenet_bn_relu(long rows, int c, const float *z, const float *sc
     if (rows == 0) return VOTENET_OK;
     const BnRaw raw = to_raw(bn);
     VN_REQUIRE(z && y && ((scale && shift) || (raw.stats && raw.gamma && raw.beta && raw.rows > 0)), "bn_relu: null buffer");
-    hipLaunchKernelGGL(bn_relu_kernel, dim3(grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows * c, c, z, scale,
+    hipLaunchKernelGGL(bn_relu_kernel, dim3(256 % c == 0 && rows * c > 1024L * 256 ? 1024 : grid_for(rows * c, 256)), dim3(256), 0, as_stream(stream), rows * c, c, z, scale,
                        shift, raw, relu, y);
     return check_launch("bn_relu");
 }
