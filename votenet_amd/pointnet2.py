@@ -88,10 +88,10 @@ class ParamStore:
         (VoteNetHotPath.forward does, at its start; refresh_transposes() covers the transposed / padded copies)."""
         self.split = bool(on)
         if not on:
-            for im in (self._split_flat, self._split_t):
+            for im in (self._split_flat, self._split_t, getattr(self, "_split_tf", None)):
                 if im is not None:
                     im.close()
-            self._split_flat = self._split_t = None
+            self._split_flat = self._split_t = self._split_tf = None
 
     def refresh_split(self):
         """One launch on the current stream: the images of every eligible 2-D tensor of the bucket."""
@@ -107,10 +107,13 @@ class ParamStore:
     def rebuild_split(self):
         """Forget the images of the forward matrices: the next refresh_split() builds them in the form mlp.FORWARD_H2 names NOW (fp16 x 2
         or bf16 x 3).  Captured graphs hold the old images' addresses: the configuration epoch their keys carry moves on."""
-        if self._split_flat is not None:
-            self._split_flat.close()
-            self._split_flat = None
+        for name in ("_split_flat", "_split_t", "_split_tf"):  # (the padded forward copies change form with the flat images)
+            im = getattr(self, name, None)
+            if im is not None:
+                im.close()
+            setattr(self, name, None)
         self._split_gen = -1
+        self.t_event = None  # the copies' images are rebuilt with the next refresh_transposes()
         M.CONFIG_EPOCH += 1
 
     def ensure_split(self):
@@ -173,8 +176,17 @@ class ParamStore:
                                                          L_.ptr(self._tflat), L_.stream_ptr()))
             if self.split:  # the images of the copies, behind the copies on the same stream
                 if self._split_t is None:
-                    self._split_t = M.SplitImages([v for v in self._tviews.values() if v.dim() == 2])
+                    # transposes ("T", "RT", "PT") are read by the backward GEMMs (gradient operands: bf16 x 3); the zero-padded copies
+                    # ("R", "P") stand in for W itself in FORWARD GEMMs of ragged widths (voting 259 -> 288 rows, mlp2 79 -> 128 columns):
+                    # fp16 x 2 like every other forward matrix (mlp.FORWARD_H2)
+                    fwd = [v for k, v in self._tviews.items() if v.dim() == 2 and k[3] in ("R", "P")]
+                    bwd = [v for k, v in self._tviews.items() if v.dim() == 2 and k[3] not in ("R", "P")]
+                    h2 = M.FORWARD_H2 and not M.SPLIT_K
+                    self._split_t = M.SplitImages(bwd + ([] if h2 else fwd))
+                    self._split_tf = M.SplitImages(fwd, pieces=2) if h2 else None
                 self._split_t.refresh()
+                if self._split_tf is not None:
+                    self._split_tf.refresh()
             self.t_event = torch.cuda.Event()
             self.t_event.record(st)
         self._t_waited = False
