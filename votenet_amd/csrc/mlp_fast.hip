@@ -442,10 +442,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             v.z = uu[2] + b4.z + wq[2][2];
             v.w = uu[3] + uu[7] + b4.w + wq[3][3];
 #else
-            v.x = narrow_z(uu, wq[0], b4.x);
-            v.y = narrow_z(uu, wq[1], b4.y);
-            v.z = narrow_z(uu, wq[2], b4.z);
-            v.w = narrow_z(uu, wq[3], b4.w);
+            const f32x2 z01 = narrow_z2(uu, wq[0], wq[1], b4.x, b4.y), z23 = narrow_z2(uu, wq[2], wq[3], b4.z, b4.w);
+            v.x = z01.x;
+            v.y = z01.y;
+            v.z = z23.x;
+            v.w = z23.y;
 #endif
         }
         if constexpr (BF3 && (SRC == 0 || SRC == 3 || SRC == 4)) {
@@ -453,10 +454,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
             const float4 sh = *reinterpret_cast<const float4 *>(&Sco[1][rk]);
             // the same two roundings as the fp32 loader (mul, add: every consumer of this BatchNorm sees one ReLU mask); the ReLU as
             // one v_max against the uniform floor (the staging arithmetic is issue-bound: T ~ 4 N_valu + 32 N_mfma per SIMD)
-            v.x = __builtin_fmaxf(v.x * sc.x + sh.x, relu_floor);
-            v.y = __builtin_fmaxf(v.y * sc.y + sh.y, relu_floor);
-            v.z = __builtin_fmaxf(v.z * sc.z + sh.z, relu_floor);
-            v.w = __builtin_fmaxf(v.w * sc.w + sh.w, relu_floor);
+            // (as packed pairs: v_pk_mul_f32 + v_pk_add_f32 -- the same two roundings per element, half the instructions; every operand
+            // a real register pair, no broadcast: nothing for op_sel to select)
+            const f32x2 t01 = f32x2{v.x, v.y} * f32x2{sc.x, sc.y} + f32x2{sh.x, sh.y};
+            const f32x2 t23 = f32x2{v.z, v.w} * f32x2{sc.z, sc.w} + f32x2{sh.z, sh.w};
+            v.x = __builtin_fmaxf(t01.x, relu_floor);
+            v.y = __builtin_fmaxf(t01.y, relu_floor);
+            v.z = __builtin_fmaxf(t23.x, relu_floor);
+            v.w = __builtin_fmaxf(t23.y, relu_floor);
             return v;
         }
         if (SRC == 0 || SRC == 3 || SRC == 4) {

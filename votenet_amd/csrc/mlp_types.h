@@ -38,6 +38,17 @@ __device__ __forceinline__ float narrow_z(const float (&u)[8], const float (&w)[
     return z;
 }
 
+// Two channels at once: the same fma chain per channel as ONE v_pk_fma_f32 per u[d] (bit-identical to narrow_z: a packed fma is the same
+// IEEE fma in each half).  The broadcast operand is written FIRST (op_sel lands on src0: the packed-f32 hazard of DESIGN_HISTORY, round 5,
+// concerns src1).  The operand loaders are bound by their vector-instruction count: this halves the 64 fmas per 16-deep slab and thread.
+__device__ __forceinline__ f32x2 narrow_z2(const float (&u)[8], const float (&wa)[8], const float (&wb)[8], float ba, float bb)
+{
+    f32x2 z = {ba, bb};
+#pragma unroll
+    for (int d = 0; d < 8; d++) z = __builtin_elementwise_fma(f32x2{u[d], u[d]}, f32x2{wa[d], wb[d]}, z);
+    return z;
+}
+
 // How a backward GEMM obtains its dz operand (rows x cout):
 //   da == gout == NULL: dz read from memory;
 //   da   : dz = A*g + B + C*z with g = da masked by [z*S+H > 0]                    (BatchNorm backward folded in)

@@ -196,10 +196,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             if (MODE == 2) {
                 const float4 v2 = r.a2[h];
                 const float uu[8] = {v.x, v.y, v.z, v.w, v2.x, v2.y, v2.z, v2.w};
-                v.x = narrow_z(uu, w0r[0], b0r[0]);
-                v.y = narrow_z(uu, w0r[1], b0r[1]);
-                v.z = narrow_z(uu, w0r[2], b0r[2]);
-                v.w = narrow_z(uu, w0r[3], b0r[3]);
+                const f32x2 z01 = narrow_z2(uu, w0r[0], w0r[1], b0r[0], b0r[1]), z23 = narrow_z2(uu, w0r[2], w0r[3], b0r[2], b0r[3]);
+                v.x = z01.x;
+                v.y = z01.y;
+                v.z = z23.x;
+                v.w = z23.y;
             }
             if (MODE == 3) {
                 const float4 g = r.a2[h];
