@@ -419,10 +419,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
         if (SRC == 4) { // v = the P quad of the row, g = its geo: z0 of the four channels rk..rk+3
             const float4 w0 = *reinterpret_cast<const float4 *>(&Wxs[0][rk]), w1 = *reinterpret_cast<const float4 *>(&Wxs[1][rk]);
             const float4 w2 = *reinterpret_cast<const float4 *>(&Wxs[2][rk]);
-            v.x = assembled_z(v.x, g, w0.x, w1.x, w2.x);
-            v.y = assembled_z(v.y, g, w0.y, w1.y, w2.y);
-            v.z = assembled_z(v.z, g, w0.z, w1.z, w2.z);
-            v.w = assembled_z(v.w, g, w0.w, w1.w, w2.w);
+            const f32x2 z01 = assembled_z2(v.x, v.y, g, w0.x, w0.y, w1.x, w1.y, w2.x, w2.y);
+            const f32x2 z23 = assembled_z2(v.z, v.w, g, w0.z, w0.w, w1.z, w1.w, w2.z, w2.w);
+            v.x = z01.x;
+            v.y = z01.y;
+            v.z = z23.x;
+            v.w = z23.y;
         }
         if (SRC == 3) { // v, g = the row's u[0..4), u[4..8): z0 of the four channels rk..rk+3, then the folded BatchNorm + ReLU below
             const float uu[8] = {v.x, v.y, v.z, v.w, g.x, g.y, g.z, g.w};

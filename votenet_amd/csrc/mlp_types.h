@@ -80,6 +80,13 @@ __device__ __forceinline__ float assembled_z(float p, const float4 &g, float w0,
 {
     return __builtin_fmaf(g.z, w2, __builtin_fmaf(g.y, w1, __builtin_fmaf(g.x, w0, p)));
 }
+// Two channels at once (bit-identical per channel; broadcast operand first: see narrow_z2)
+__device__ __forceinline__ f32x2 assembled_z2(float pa, float pb, const float4 &g, float w0a, float w0b, float w1a, float w1b, float w2a, float w2b)
+{
+    f32x2 z = __builtin_elementwise_fma(f32x2{g.x, g.x}, f32x2{w0a, w0b}, f32x2{pa, pb});
+    z = __builtin_elementwise_fma(f32x2{g.y, g.y}, f32x2{w1a, w1b}, z);
+    return __builtin_elementwise_fma(f32x2{g.z, g.z}, f32x2{w2a, w2b}, z);
+}
 
 // ---- bf16 x 3 split operands (BF3: mlp_fast.hip, the Gram kernel of pool_bwd.hip) ---------------------------------------------
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

@@ -204,10 +204,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 3))) voi
             }
             if (MODE == 3) {
                 const float4 g = r.a2[h];
-                v.x = assembled_z(v.x, g, wx0.x, wx1.x, wx2.x);
-                v.y = assembled_z(v.y, g, wx0.y, wx1.y, wx2.y);
-                v.z = assembled_z(v.z, g, wx0.z, wx1.z, wx2.z);
-                v.w = assembled_z(v.w, g, wx0.w, wx1.w, wx2.w);
+                const f32x2 z01 = assembled_z2(v.x, v.y, g, wx0.x, wx0.y, wx1.x, wx1.y, wx2.x, wx2.y);
+                const f32x2 z23 = assembled_z2(v.z, v.w, g, wx0.z, wx0.w, wx1.z, wx1.w, wx2.z, wx2.w);
+                v.x = z01.x;
+                v.y = z01.y;
+                v.z = z23.x;
+                v.w = z23.y;
             }
             v.x = fmaxf(v.x * csc.x + csh.x, x_floor);
             v.y = fmaxf(v.y * csc.y + csh.y, x_floor);
