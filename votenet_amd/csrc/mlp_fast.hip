@@ -416,6 +416,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((EPI == 3 |
     };
     const float relu_floor = (affine && A.in_relu) ? 0.0f : -__builtin_inff(); // BF3: the folded ReLU as a select against a uniform floor
     auto act4 = [&](float4 v, const float4 &g, const int4 &am, int ro, int rk, float mu = 1.0f) {
+        // rk is a multiple of 4 (the thread's channel quad): said aloud so that the table reads below are ONE 16-byte LDS read each with an
+        // immediate offset (unproven, the compiler split every float4 of W0s / Sco / Wxs into two ds_read2_b32 behind their own address adds:
+        // 18 + 18 instructions per slab in the narrow loader)
+        __builtin_assume((rk & 3) == 0);
         if (SRC == 4) { // v = the P quad of the row, g = its geo: z0 of the four channels rk..rk+3
             const float4 w0 = *reinterpret_cast<const float4 *>(&Wxs[0][rk]), w1 = *reinterpret_cast<const float4 *>(&Wxs[1][rk]);
             const float4 w2 = *reinterpret_cast<const float4 *>(&Wxs[2][rk]);
